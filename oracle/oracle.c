@@ -1,0 +1,769 @@
+/*
+ * oracle.c -- CPU restatement (plain C, fp64) of the LIA_RAL / ALIZE GMM + i-vector hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under lia_ral_amd/ (the product) may include, link or call
+ * this file; it is imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * Parity status: the per-frame arithmetic (rows 1-6 of SURVEY.md 8(a)) lives in the external,
+ * un-vendored alize-core library; its semantics are pinned here by the reference's own fixtures
+ * KAT-1 (ComputeTest/test/test1.validate.res), KAT-2 (TrainTarget/test/test1.validate.gmm) and
+ * KAT-4 (NormFeat/test/test1.validate.prm) -- see tests/test_oracle_kat.py.  The i-vector / PLDA
+ * rows (11-19) restate self-contained loops of LIA_SpkTools 1:1 but the reference ships no test
+ * for them: "parity unpinned" for those rows.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * All matrices row-major, all arithmetic double, like the reference.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EPS_LK 1e-200 /* LIA_SpkTools/src/TopGauss.cpp:67 (EPS_LK) */
+#define ORC_PI 3.14159265358979323846
+
+/* ---------------------------------------------------------------------------------------------
+ * Rows 1-3: DistribGD::computeLK, MixtureGDStat::computeAndAccumulateLLK, top-C state
+ * ------------------------------------------------------------------------------------------- */
+
+/* cst_c = (2 pi)^(-D/2) det_c^(-1/2), det_c = prod_d cov_cd (RAW GMM file fields, verified on
+ * LIA_SpkDet/ComputeTest/test/wld; DistribGD::computeAll() is called after every setCov,
+ * LIA_SpkTools/src/TrainTools.cpp:582). */
+void orc_gmm_cst(int C, int D, const double *covinv, double *cst, double *det)
+{
+    for (int c = 0; c < C; ++c) {
+        double d = 1.0;
+        for (int k = 0; k < D; ++k) d *= 1.0 / covinv[(size_t)c * D + k];
+        det[c] = d;
+        cst[c] = pow(2.0 * ORC_PI, -0.5 * D) / sqrt(d);
+    }
+}
+
+/* lk_c(x) = cst_c exp(-1/2 sum_d (x_d - mu_cd)^2 covInv_cd): DistribGD::computeLK as used at
+ * LIA_SpkTools/src/TopGauss.cpp:254, FactorAnalysis.cpp:289, GeneralTools.cpp:768. */
+static double distrib_lk(int D, const double *x, const double *mean, const double *covinv, double cst)
+{
+    double m = 0.0;
+    for (int k = 0; k < D; ++k) {
+        double d = x[k] - mean[k];
+        m += d * d * covinv[k];
+    }
+    return cst * exp(-0.5 * m);
+}
+
+static double clamp_llk(double lk, double min_llk, double max_llk)
+{
+    /* EPS_LK floor then [minLLK,maxLLK] clamp: TopGauss.cpp:190-192,258-260 */
+    if (lk < ORC_EPS_LK) lk = ORC_EPS_LK;
+    double llk = log(lk);
+    if (llk < min_llk) llk = min_llk;
+    if (llk > max_llk) llk = max_llk;
+    return llk;
+}
+
+/* computeAndAccumulateLLK(f, 1.0, TOP_DISTRIBS_NO_ACTION) per frame:
+ * call sites LIA_SpkTools/src/AccumulateStat.cpp:77, AccumulateTVStat.cpp:1644-1648. */
+void orc_llk(int C, int D, const double *w, const double *mean, const double *covinv,
+             const double *x, long T, double min_llk, double max_llk, double *llk)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    for (long t = 0; t < T; ++t) {
+        double s = 0.0;
+        for (int c = 0; c < C; ++c)
+            s += w[c] * distrib_lk(D, x + t * D, mean + (size_t)c * D, covinv + (size_t)c * D, cst[c]);
+        llk[t] = clamp_llk(s, min_llk, max_llk);
+    }
+    free(cst); free(det);
+}
+
+typedef struct { double lk; long idx; } lkpair;
+static int cmp_desc(const void *a, const void *b)
+{
+    const lkpair *x = a, *y = b;
+    if (x->lk > y->lk) return -1;
+    if (x->lk < y->lk) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx); /* tie-break: lower index first (assumed, U4) */
+}
+
+/* DETERMINE_TOP_DISTRIBS: LIA_SpkDet/ComputeTest/src/ComputeTest.cpp:163, TopGauss.cpp:167-193.
+ * Sort w_c lk_c descending, keep ctop (idx, lk); sumNonTopLK = total - sum top (TopGauss.cpp:183-187),
+ * sumNonTopWeights = 1 - sum top weights.  World llk: COMPLETE -> log(total);
+ * PARTIAL -> log(sum top) (assumed). */
+void orc_llk_determine_top(int C, int D, const double *w, const double *mean, const double *covinv,
+                           const double *x, long T, int ctop, int complete,
+                           double min_llk, double max_llk,
+                           long *idx, double *lk, double *nontop_lk, double *nontop_w, double *llk)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    lkpair *v = malloc(sizeof(lkpair) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    if (ctop > C) ctop = C;
+    for (long t = 0; t < T; ++t) {
+        double tot = 0.0;
+        for (int c = 0; c < C; ++c) {
+            v[c].lk = w[c] * distrib_lk(D, x + t * D, mean + (size_t)c * D, covinv + (size_t)c * D, cst[c]);
+            v[c].idx = c;
+            tot += v[c].lk;
+        }
+        qsort(v, C, sizeof(lkpair), cmp_desc);
+        double top = 0.0, tw = 0.0;
+        for (int j = 0; j < ctop; ++j) {
+            idx[t * ctop + j] = v[j].idx;
+            lk[t * ctop + j] = v[j].lk;
+            top += v[j].lk;
+            tw += w[v[j].idx];
+        }
+        /* non-top remainder summed directly over the non-selected components (same quantity as
+         * total - top, without the cancellation) */
+        double rest = 0.0;
+        for (int j = ctop; j < C; ++j) rest += v[j].lk;
+        nontop_lk[t] = rest;
+        nontop_w[t] = 1.0 - tw;
+        llk[t] = clamp_llk(complete ? top + rest : top, min_llk, max_llk);
+        (void)tot;
+    }
+    free(cst); free(det); free(v);
+}
+
+/* USE_TOP_DISTRIBS for a (client) model: ComputeTest.cpp:166-167.
+ * lk = sum_{c in top} w_c lk_c(client) [+ sumNonTopLK(world) if COMPLETE]. */
+void orc_llk_use_top(int C, int D, const double *w, const double *mean, const double *covinv,
+                     const double *x, long T, int ctop, const long *idx, const double *nontop_lk,
+                     int complete, double min_llk, double max_llk, double *llk)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    for (long t = 0; t < T; ++t) {
+        double s = 0.0;
+        for (int j = 0; j < ctop; ++j) {
+            long c = idx[t * ctop + j];
+            s += w[c] * distrib_lk(D, x + t * D, mean + (size_t)c * D, covinv + (size_t)c * D, cst[c]);
+        }
+        if (complete) s += nontop_lk[t];
+        llk[t] = clamp_llk(s, min_llk, max_llk);
+    }
+    free(cst); free(det);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Rows 4-6: EM accumulators, occupation vector, FrameAccGD
+ * ------------------------------------------------------------------------------------------- */
+
+/* MixtureGDStat::computeAndAccumulateOcc + getOccVect: full posterior gamma_c = lk_c / sum lk
+ * (call site AccumulateTVStat.cpp:334-335).  Returns the linear frame likelihood. */
+static double occ_frame(int C, int D, const double *w, const double *mean, const double *covinv,
+                        const double *cst, const double *x, double *gamma)
+{
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) {
+        gamma[c] = w[c] * distrib_lk(D, x, mean + (size_t)c * D, covinv + (size_t)c * D, cst[c]);
+        s += gamma[c];
+    }
+    if (s > 0.0)
+        for (int c = 0; c < C; ++c) gamma[c] /= s;
+    else
+        for (int c = 0; c < C; ++c) gamma[c] = 0.0; /* U1: assumed (FactorAnalysis.cpp:293) */
+    return s;
+}
+
+void orc_occ(int C, int D, const double *w, const double *mean, const double *covinv,
+             const double *x, long T, double *gamma /* T x C */)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    for (long t = 0; t < T; ++t) occ_frame(C, D, w, mean, covinv, cst, x + t * D, gamma + t * C);
+    free(cst); free(det);
+}
+
+/* accumulateStatEM frame loop: llkAcc += log(emAcc.computeAndAccumulateEM(f[,weight]))
+ * LIA_SpkTools/src/AccumulateStat.cpp:103-114 (weighted variant :143-152, :206).
+ * occ_c += w g_c ; sx_c += w g_c x ; sxx_c += w g_c x^2 ; count += w.  Accumulating (no reset). */
+double orc_em_accumulate(int C, int D, const double *w, const double *mean, const double *covinv,
+                         const double *x, long T, double weight,
+                         double *occ, double *sx, double *sxx, double *count)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    double *g = malloc(sizeof(double) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    double llk_acc = 0.0;
+    for (long t = 0; t < T; ++t) {
+        const double *f = x + t * D;
+        double lk = occ_frame(C, D, w, mean, covinv, cst, f, g);
+        llk_acc += log(lk);
+        for (int c = 0; c < C; ++c) {
+            double gc = g[c] * weight;
+            occ[c] += gc;
+            for (int k = 0; k < D; ++k) {
+                sx[(size_t)c * D + k] += gc * f[k];
+                sxx[(size_t)c * D + k] += gc * f[k] * f[k];
+            }
+        }
+        *count += weight;
+    }
+    free(cst); free(det); free(g);
+    return llk_acc;
+}
+
+/* MixtureStat::getEM(): w_c = occ_c/count ; mu = sx/occ ; cov = sxx/occ - mu^2
+ * (weights/means verified by KAT-2 through computeMAPOccDep, TrainTools.cpp:445-489, where
+ * alpha = client.weight(c)*frameCount = occ_c; variance formula = standard ML, U3 assumed).
+ * Components with occ == 0 keep the previous parameters (assumed). */
+void orc_em_get(int C, int D, const double *occ, const double *sx, const double *sxx, double count,
+                double *w, double *mean, double *cov)
+{
+    for (int c = 0; c < C; ++c) {
+        w[c] = occ[c] / count;
+        if (occ[c] <= 0.0) continue;
+        for (int k = 0; k < D; ++k) {
+            double m = sx[(size_t)c * D + k] / occ[c];
+            mean[(size_t)c * D + k] = m;
+            cov[(size_t)c * D + k] = sxx[(size_t)c * D + k] / occ[c] - m * m;
+        }
+    }
+}
+
+/* setItParameter: LIA_SpkTools/src/TrainTools.cpp:560-564 */
+double orc_set_it_parameter(double begin, double end, int nb_it, int it)
+{
+    if (nb_it < 2) return begin;
+    double it_val = (begin - end) / ((double)nb_it - 1);
+    return begin - it_val * it;
+}
+
+/* varianceControl: LIA_SpkTools/src/TrainTools.cpp:567-587 (floor then ceiling, in this order) */
+void orc_variance_control(int C, int D, double *cov, double flooring, double ceiling,
+                          const double *cov_signal, long *n_floor, long *n_ceil)
+{
+    long nf = 0, nc = 0;
+    for (int c = 0; c < C; ++c)
+        for (int v = 0; v < D; ++v) {
+            double cv = cov[(size_t)c * D + v];
+            if (cv <= flooring * cov_signal[v]) { cv = flooring * cov_signal[v]; nf++; }
+            if (cv >= ceiling * cov_signal[v]) { cv = ceiling * cov_signal[v]; nc++; }
+            cov[(size_t)c * D + v] = cv;
+        }
+    if (n_floor) *n_floor = nf;
+    if (n_ceil) *n_ceil = nc;
+}
+
+/* computeMAPOccDep, mean-only: LIA_SpkTools/src/TrainTools.cpp:445-466 (pinned by KAT-2).
+ * alpha_c = occ_c ; a = alpha/(alpha+r) ; mu = (1-a) mu_world + a mu_ML. */
+void orc_map_occdep_mean(int C, int D, const double *mean_world, const double *w_ml,
+                         const double *mean_ml, double frame_count, double reg, double *mean_out)
+{
+    for (int c = 0; c < C; ++c) {
+        double alpha = w_ml[c] * frame_count;
+        double a = alpha / (alpha + reg);
+        for (int k = 0; k < D; ++k)
+            mean_out[(size_t)c * D + k] =
+                (1 - a) * mean_world[(size_t)c * D + k] + a * mean_ml[(size_t)c * D + k];
+    }
+}
+
+/* FrameAccGD::accumulate / getMeanVect / getCovVect: sum x, sum x^2, n; mean, BIASED diagonal
+ * covariance sum x^2/n - mean^2 (AccumulateStat.cpp:387-396, TrainTools.cpp:593-601; pinned by KAT-4). */
+void orc_frame_acc(int D, const double *x, long T, double *sum, double *sumsq, double *count)
+{
+    for (long t = 0; t < T; ++t) {
+        for (int k = 0; k < D; ++k) {
+            double v = x[t * D + k];
+            sum[k] += v;
+            sumsq[k] += v * v;
+        }
+        *count += 1.0;
+    }
+}
+void orc_frame_mean_cov(int D, const double *sum, const double *sumsq, double count, double *mean, double *cov)
+{
+    for (int k = 0; k < D; ++k) {
+        mean[k] = sum[k] / count;
+        cov[k] = sumsq[k] / count - mean[k] * mean[k];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Row 10: bagging (glibc rand) -- GeneralTools.cpp:309-314, 455-510; seed TrainTools.cpp:1070
+ * ------------------------------------------------------------------------------------------- */
+static int bagged_frame(double p) { return ((double)rand() / (double)RAND_MAX) < p; }
+
+/* in: nseg segments (begin,len); out: up to max_out bagged segments. Returns number written
+ * (or the needed count if larger than max_out). */
+long orc_bagged_segments(unsigned seed, const long *seg_begin, const long *seg_len, long nseg,
+                         double p, long min_len, long max_len,
+                         long *out_begin, long *out_len, long *out_src, long max_out)
+{
+    srand(seed);
+    long n = 0, s = 0;
+    if (nseg == 0) return 0;
+    long begin = seg_begin[0], len = seg_len[0];
+    int end = 0;
+    while (!end) {
+        long verify = len;
+        if (verify < min_len) verify = min_len;
+        if (verify > max_len) verify = max_len;
+        int move;
+        long length;
+        if (len <= verify) { move = 1; length = len; }
+        else { move = 0; length = verify; }
+        if (length > 0 && bagged_frame(p)) {
+            if (n < max_out) { out_begin[n] = begin; out_len[n] = length; out_src[n] = s; }
+            n++;
+        }
+        if (move) {
+            s++;
+            end = (s >= nseg);
+            if (!end) { begin = seg_begin[s]; len = seg_len[s]; }
+        } else {
+            len -= length;
+            begin += length;
+        }
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Rows 11-17: TVAcc (total variability)
+ * ------------------------------------------------------------------------------------------- */
+
+/* computeAndAccumulateTVStatUnThreaded inner loops: LIA_SpkTools/src/AccumulateTVStat.cpp:332-348.
+ * frame t belongs to statistics row utt[t]. N[u,c] += g_c ; F[u, c*D+i] += g_c x_i. */
+void orc_tv_stats(int C, int D, const double *w, const double *mean, const double *covinv,
+                  const double *x, long T, const long *utt, double *N, double *F)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    double *g = malloc(sizeof(double) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    size_t SV = (size_t)C * D;
+    for (long t = 0; t < T; ++t) {
+        const double *f = x + t * D;
+        occ_frame(C, D, w, mean, covinv, cst, f, g);
+        long u = utt[t];
+        for (int k = 0; k < C; ++k) {
+            N[u * C + k] += g[k];
+            for (int i = 0; i < D; ++i) F[u * SV + (size_t)k * D + i] += g[k] * f[i];
+        }
+    }
+    free(cst); free(det); free(g);
+}
+
+/* substractMUnThreaded: AccumulateTVStat.cpp:1088-1105 */
+void orc_tv_subtract_m(long U, int C, int D, const double *N, double *F, const double *ubm_means)
+{
+    size_t SV = (size_t)C * D;
+    for (long u = 0; u < U; ++u)
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < D; ++j)
+                F[u * SV + (size_t)i * D + j] -= ubm_means[(size_t)i * D + j] * N[u * C + i];
+}
+
+/* estimateTETtUnThreaded: AccumulateTVStat.cpp:777-805. TETt[c] is R x R (full, mirrored). */
+void orc_tv_tett(int C, int D, int R, const double *Tm /* R x SV */, const double *invvar, double *TETt)
+{
+    size_t SV = (size_t)C * D;
+    for (int d = 0; d < C; ++d) {
+        double *o = TETt + (size_t)d * R * R;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < D; ++k)
+                    s += Tm[i * SV + (size_t)d * D + k] * invvar[(size_t)d * D + k] * Tm[j * SV + (size_t)d * D + k];
+                o[(size_t)i * R + j] = s;
+            }
+        for (int i = 0; i < R; ++i)
+            for (int j = i + 1; j < R; ++j) o[(size_t)i * R + j] = o[(size_t)j * R + i];
+    }
+}
+
+/* DoubleSquareMatrix::invert (alize-core, algorithm unknown: U5). Gauss-Jordan with partial
+ * pivoting; returns 0 on success. */
+int orc_invert(int n, const double *a_in, double *inv)
+{
+    double *a = malloc(sizeof(double) * n * n);
+    memcpy(a, a_in, sizeof(double) * n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) inv[(size_t)i * n + j] = (i == j);
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = fabs(a[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; ++r)
+            if (fabs(a[(size_t)r * n + c]) > best) { best = fabs(a[(size_t)r * n + c]); p = r; }
+        if (best == 0.0) { free(a); return 1; }
+        if (p != c)
+            for (int j = 0; j < n; ++j) {
+                double t = a[(size_t)c * n + j]; a[(size_t)c * n + j] = a[(size_t)p * n + j]; a[(size_t)p * n + j] = t;
+                t = inv[(size_t)c * n + j]; inv[(size_t)c * n + j] = inv[(size_t)p * n + j]; inv[(size_t)p * n + j] = t;
+            }
+        double d = 1.0 / a[(size_t)c * n + c];
+        for (int j = 0; j < n; ++j) { a[(size_t)c * n + j] *= d; inv[(size_t)c * n + j] *= d; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            double f = a[(size_t)r * n + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; ++j) {
+                a[(size_t)r * n + j] -= f * a[(size_t)c * n + j];
+                inv[(size_t)r * n + j] -= f * inv[(size_t)c * n + j];
+            }
+        }
+    }
+    free(a);
+    return 0;
+}
+
+/* DoubleSquareMatrix::upperCholesky (alize-core): upper factor Ch with R = Ch^T Ch (assumed; the
+ * minimum-divergence update T <- Ch T, AccumulateTVStat.cpp:2070-2094, whitens w only for this
+ * convention). Returns 0 on success. */
+int orc_upper_cholesky(int n, const double *a, double *ch)
+{
+    memset(ch, 0, sizeof(double) * n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            double s = a[(size_t)i * n + j];
+            for (int k = 0; k < i; ++k) s -= ch[(size_t)k * n + i] * ch[(size_t)k * n + j];
+            if (i == j) {
+                if (s <= 0.0) return 1;
+                ch[(size_t)i * n + i] = sqrt(s);
+            } else
+                ch[(size_t)i * n + j] = s / ch[(size_t)i * n + i];
+        }
+    return 0;
+}
+
+/* L = I + sum_c N[u,c] TETt_c (lower, mirrored): AccumulateTVStat.cpp:2126-2146 */
+static void build_L(int C, int R, const double *Nu, const double *TETt, double *L)
+{
+    memset(L, 0, sizeof(double) * R * R);
+    for (int i = 0; i < R; ++i) L[(size_t)i * R + i] = 1.0;
+    for (int c = 0; c < C; ++c) {
+        const double *t = TETt + (size_t)c * R * R;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j <= i; ++j) L[(size_t)i * R + j] += t[(size_t)i * R + j] * Nu[c];
+    }
+    for (int i = 0; i < R; ++i)
+        for (int j = i + 1; j < R; ++j) L[(size_t)i * R + j] = L[(size_t)j * R + i];
+}
+
+/* estimateWUnThreaded: AccumulateTVStat.cpp:2114-2169. F must already be centred (substractM). */
+int orc_tv_estimate_w(long U, int C, int D, int R, const double *N, const double *F,
+                      const double *Tm, const double *invvar, const double *TETt, double *W)
+{
+    size_t SV = (size_t)C * D;
+    double *L = malloc(sizeof(double) * R * R), *Li = malloc(sizeof(double) * R * R);
+    double *aux = malloc(sizeof(double) * R);
+    int rc = 0;
+    for (long u = 0; u < U; ++u) {
+        build_L(C, R, N + u * C, TETt, L);
+        if (orc_invert(R, L, Li)) { rc = 1; break; }
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+            for (size_t k = 0; k < SV; ++k) s += F[u * SV + k] * invvar[k] * Tm[i * SV + k];
+            aux[i] = s;
+        }
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < R; ++k) s += aux[k] * Li[(size_t)i * R + k];
+            W[u * R + i] = s;
+        }
+    }
+    free(L); free(Li); free(aux);
+    return rc;
+}
+
+/* estimateAandCUnthreaded: AccumulateTVStat.cpp:1702-1795.
+ * Outputs: W[U x R], A[C x R*R], Cmx[R x SV], Rm[R x R], r[R], meanW[R] (= sum w / U). */
+int orc_tv_estimate_a_and_c(long U, int C, int D, int R, const double *N, const double *F,
+                            const double *Tm, const double *invvar, const double *TETt,
+                            double *W, double *A, double *Cmx, double *Rm, double *r, double *meanW)
+{
+    size_t SV = (size_t)C * D, RR = (size_t)R * R;
+    double *L = malloc(sizeof(double) * RR), *Li = malloc(sizeof(double) * RR);
+    double *aux = malloc(sizeof(double) * R);
+    memset(A, 0, sizeof(double) * C * RR);
+    memset(Cmx, 0, sizeof(double) * R * SV);
+    memset(Rm, 0, sizeof(double) * RR);
+    memset(r, 0, sizeof(double) * R);
+    memset(meanW, 0, sizeof(double) * R);
+    int rc = 0;
+    for (long u = 0; u < U; ++u) {
+        build_L(C, R, N + u * C, TETt, L);
+        if (orc_invert(R, L, Li)) { rc = 1; break; }
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+            for (size_t k = 0; k < SV; ++k) s += F[u * SV + k] * invvar[k] * Tm[i * SV + k];
+            aux[i] = s;
+        }
+        double *y = W + u * R;
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < R; ++k) s += aux[k] * Li[(size_t)i * R + k];
+            y[i] = s;
+        }
+        for (int k = 0; k < R; ++k) meanW[k] += y[k];
+        for (int i = 0; i < R; ++i) {
+            for (int j = 0; j < R; ++j) {
+                Li[(size_t)i * R + j] += y[i] * y[j];
+                Rm[(size_t)i * R + j] += Li[(size_t)i * R + j];
+            }
+            r[i] += y[i];
+        }
+        for (int c = 0; c < C; ++c) {
+            double n = N[u * C + c];
+            double *a = A + (size_t)c * RR;
+            for (size_t e = 0; e < RR; ++e) a[e] += Li[e] * n;
+        }
+        for (int i = 0; i < R; ++i)
+            for (size_t j = 0; j < SV; ++j) Cmx[i * SV + j] += y[i] * F[u * SV + j];
+    }
+    for (int k = 0; k < R; ++k) meanW[k] /= (double)U;
+    free(L); free(Li); free(aux);
+    return rc;
+}
+
+/* updateTestimate: T_c = A_c^-1 Cmx_c, AccumulateTVStat.cpp:974-1005 */
+int orc_tv_update_t(int C, int D, int R, const double *A, const double *Cmx, double *Tm)
+{
+    size_t SV = (size_t)C * D, RR = (size_t)R * R;
+    double *Ai = malloc(sizeof(double) * RR);
+    int rc = 0;
+    for (int c = 0; c < C; ++c) {
+        if (orc_invert(R, A + (size_t)c * RR, Ai)) { rc = 1; break; }
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < D; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < R; ++k) s += Ai[(size_t)i * R + k] * Cmx[k * SV + (size_t)c * D + j];
+                Tm[i * SV + (size_t)c * D + j] = s;
+            }
+    }
+    free(Ai);
+    return rc;
+}
+
+/* minDivergence: AccumulateTVStat.cpp:2056-2099. In/out: Rm, r (normalised in place like the
+ * reference), ubm_means (+= T^T meanW), T (<- Ch T). */
+int orc_tv_min_divergence(int C, int D, int R, double n_sessions, double *Rm, double *r,
+                          const double *meanW, double *ubm_means, double *Tm)
+{
+    size_t SV = (size_t)C * D;
+    for (int i = 0; i < R; ++i) r[i] /= n_sessions;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < R; ++j) Rm[(size_t)i * R + j] = Rm[(size_t)i * R + j] / n_sessions - r[i] * r[j];
+    double *ch = malloc(sizeof(double) * R * R);
+    if (orc_upper_cholesky(R, Rm, ch)) { free(ch); return 1; }
+    for (size_t j = 0; j < SV; ++j)
+        for (int k = 0; k < R; ++k) ubm_means[j] += meanW[k] * Tm[k * SV + j];
+    double *tmp = calloc((size_t)R * SV, sizeof(double));
+    for (int i = 0; i < R; ++i)
+        for (int k = 0; k < R; ++k) {
+            double c = ch[(size_t)i * R + k];
+            if (c == 0.0) continue;
+            for (size_t j = 0; j < SV; ++j) tmp[i * SV + j] += c * Tm[k * SV + j];
+        }
+    memcpy(Tm, tmp, sizeof(double) * R * SV);
+    free(tmp); free(ch);
+    return 0;
+}
+
+/* orthonormalizeT: classical Gram-Schmidt over the rows of T, AccumulateTVStat.cpp:1548-1596 */
+void orc_tv_orthonormalize_t(int R, size_t SV, double *Tm)
+{
+    double *Q = calloc((size_t)R * SV, sizeof(double));
+    double *v = malloc(sizeof(double) * SV);
+    for (int j = 0; j < R; ++j) {
+        memcpy(v, Tm + j * SV, sizeof(double) * SV);
+        for (int i = 0; i < j; ++i) {
+            double rij = 0.0;
+            for (size_t k = 0; k < SV; ++k) rij += Q[i * SV + k] * Tm[j * SV + k];
+            for (size_t k = 0; k < SV; ++k) v[k] -= rij * Q[i * SV + k];
+        }
+        double nv = 0.0;
+        for (size_t k = 0; k < SV; ++k) nv += v[k] * v[k];
+        double rjj = sqrt(nv);
+        if (rjj == 0.0) for (size_t k = 0; k < SV; ++k) Q[j * SV + k] = 0;
+        else for (size_t k = 0; k < SV; ++k) Q[j * SV + k] = v[k] / rjj;
+    }
+    memcpy(Tm, Q, sizeof(double) * R * SV);
+    free(Q); free(v);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Row 19: i-vector scoring (PldaTest). models[dim x M], segments[dim x S] column = vector, like
+ * the reference's _models/_segments; scores[M x S]; trials mask (NULL = all).
+ * ------------------------------------------------------------------------------------------- */
+
+/* cosineDistance: LIA_SpkTools/src/PldaTools.cpp:3842-3879 */
+void orc_score_cosine(int dim, long M, long S, const double *models, const double *segs,
+                      const unsigned char *trials, double *scores)
+{
+    double *nm = calloc(M, sizeof(double)), *ns = calloc(S, sizeof(double));
+    for (int k = 0; k < dim; ++k) {
+        for (long m = 0; m < M; ++m) nm[m] += models[k * M + m] * models[k * M + m];
+        for (long s = 0; s < S; ++s) ns[s] += segs[k * S + s] * segs[k * S + s];
+    }
+    for (long m = 0; m < M; ++m) nm[m] = sqrt(nm[m]);
+    for (long s = 0; s < S; ++s) ns[s] = sqrt(ns[s]);
+    for (long m = 0; m < M; ++m)
+        for (long s = 0; s < S; ++s) {
+            if (trials && !trials[m * S + s]) continue;
+            double v = 0.0;
+            for (int k = 0; k < dim; ++k) v += models[k * M + m] * segs[k * S + s];
+            scores[m * S + s] = v / (nm[m] * ns[s]);
+        }
+    free(nm); free(ns);
+}
+
+/* mahalanobisDistance: PldaTools.cpp:3882-3909. score = -1/2 (m-s)^T Mah (m-s) */
+void orc_score_mahalanobis(int dim, long M, long S, const double *models, const double *segs,
+                           const double *Mah, const unsigned char *trials, double *scores)
+{
+    double *d = malloc(sizeof(double) * dim), *t = malloc(sizeof(double) * dim);
+    for (long m = 0; m < M; ++m)
+        for (long s = 0; s < S; ++s) {
+            if (trials && !trials[m * S + s]) continue;
+            for (int k = 0; k < dim; ++k) d[k] = models[k * M + m] - segs[k * S + s];
+            for (int k = 0; k < dim; ++k) {
+                double a = 0.0;
+                for (int i = 0; i < dim; ++i) a += -0.5 * d[i] * Mah[(size_t)i * dim + k];
+                t[k] = a;
+            }
+            double v = 0.0;
+            for (int i = 0; i < dim; ++i) v += t[i] * d[i];
+            scores[m * S + s] = v;
+        }
+    free(d); free(t);
+}
+
+static void matmul(int n, const double *a, const double *b, double *c)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += a[(size_t)i * n + k] * b[(size_t)k * n + j];
+            c[(size_t)i * n + j] = s;
+        }
+}
+
+/* two-covariance model matrices G, H from W, B: PldaTools.cpp:4089-4125 */
+int orc_twocov_model(int dim, const double *Wm, const double *Bm, double *G, double *H)
+{
+    size_t nn = (size_t)dim * dim;
+    double *iW = malloc(sizeof(double) * nn), *iB = malloc(sizeof(double) * nn);
+    double *sG = malloc(sizeof(double) * nn), *sH = malloc(sizeof(double) * nn);
+    double *tG = malloc(sizeof(double) * nn), *tH = malloc(sizeof(double) * nn);
+    double *t2 = malloc(sizeof(double) * nn);
+    int rc = orc_invert(dim, Wm, iW) | orc_invert(dim, Bm, iB);
+    for (size_t e = 0; e < nn; ++e) { sG[e] = iB[e] + 2 * iW[e]; sH[e] = iB[e] + iW[e]; }
+    rc |= orc_invert(dim, sG, tG) | orc_invert(dim, sH, tH);
+    matmul(dim, iW, tG, t2); matmul(dim, t2, iW, G);
+    matmul(dim, iW, tH, t2); matmul(dim, t2, iW, H);
+    free(iW); free(iB); free(sG); free(sH); free(tG); free(tH); free(t2);
+    return rc;
+}
+
+/* twoCovScoring scores given G,H: PldaTools.cpp:4127-4171 + :3923-3949.
+ * score = (m+s)^T G (m+s) - m^T H m - s^T H s   (all pairs, no mask in the reference) */
+void orc_score_twocov(int dim, long M, long S, const double *models, const double *segs,
+                      const double *G, const double *H, double *scores)
+{
+    double *md = calloc(M, sizeof(double)), *sd = calloc(S, sizeof(double));
+    double *a = malloc(sizeof(double) * dim), *d = malloc(sizeof(double) * dim);
+    for (long m = 0; m < M; ++m) {
+        for (int k = 0; k < dim; ++k) {
+            double s = 0.0;
+            for (int i = 0; i < dim; ++i) s += models[i * M + m] * H[(size_t)i * dim + k];
+            a[k] = s;
+        }
+        for (int j = 0; j < dim; ++j) md[m] += a[j] * models[j * M + m];
+    }
+    for (long s = 0; s < S; ++s) {
+        for (int k = 0; k < dim; ++k) {
+            double v = 0.0;
+            for (int i = 0; i < dim; ++i) v += segs[i * S + s] * H[(size_t)i * dim + k];
+            a[k] = v;
+        }
+        for (int j = 0; j < dim; ++j) sd[s] += a[j] * segs[j * S + s];
+    }
+    for (long m = 0; m < M; ++m)
+        for (long s = 0; s < S; ++s) {
+            for (int j = 0; j < dim; ++j) d[j] = models[j * M + m] + segs[j * S + s];
+            double v = 0.0;
+            for (int k = 0; k < dim; ++k) {
+                double c = 0.0;
+                for (int i = 0; i < dim; ++i) c += d[i] * G[(size_t)i * dim + k];
+                v += c * d[k];
+            }
+            scores[m * S + s] = v - (md[m] + sd[s]);
+        }
+    free(md); free(sd); free(a); free(d);
+}
+
+static double logdet_spd(int n, const double *a)
+{
+    /* alpha = 2 sum log diag(chol(K)): PldaTools.cpp:4236-4241 */
+    double *ch = malloc(sizeof(double) * n * n);
+    double s = 0.0;
+    if (orc_upper_cholesky(n, a, ch) == 0)
+        for (int i = 0; i < n; ++i) s += log(ch[(size_t)i * n + i]);
+    else
+        s = NAN;
+    free(ch);
+    return 2.0 * s;
+}
+
+/* PLDA native scoring on vectors ALREADY projected by FTJ (rank rf):
+ * pldaScoringUnThreaded PldaTools.cpp:4186-4271 (+ K_one/alpha_one from :4506-4516).
+ * models[rf x M] are the per-speaker SUMS of nsess[m] enrolment vectors.
+ * K_n = (n FTJF + I)^-1, alpha_n = log det K_n,
+ * score = ((s+m)^T K_{L+1} (s+m) - m^T K_L m - s^T K_1 s)/2 + (alpha_{L+1} - alpha_L - alpha_1)/2 */
+int orc_score_plda(int rf, long M, long S, const double *models, const long *nsess,
+                   const double *segs, const double *FTJF, double *scores)
+{
+    size_t nn = (size_t)rf * rf;
+    double *K1 = malloc(sizeof(double) * nn), *KL = malloc(sizeof(double) * nn), *KL1 = malloc(sizeof(double) * nn);
+    double *tmp = malloc(sizeof(double) * nn), *v = malloc(sizeof(double) * rf);
+    double *s1 = malloc(sizeof(double) * S);
+    int rc = 0;
+    for (size_t e = 0; e < nn; ++e) tmp[e] = FTJF[e];
+    for (int i = 0; i < rf; ++i) tmp[(size_t)i * rf + i] += 1.0;
+    rc |= orc_invert(rf, tmp, K1);
+    double alpha1 = logdet_spd(rf, K1);
+    for (long s = 0; s < S; ++s) {
+        double q = 0.0;
+        for (int i = 0; i < rf; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < rf; ++j) a += K1[(size_t)i * rf + j] * segs[j * S + s];
+            q += segs[i * S + s] * a;
+        }
+        s1[s] = q;
+    }
+    long cur = -1;
+    double cst = 0.0;
+    for (long m = 0; m < M; ++m) {
+        if (nsess[m] != cur) {
+            cur = nsess[m];
+            for (size_t e = 0; e < nn; ++e) tmp[e] = cur * FTJF[e];
+            for (int i = 0; i < rf; ++i) tmp[(size_t)i * rf + i] += 1.0;
+            rc |= orc_invert(rf, tmp, KL);
+            for (size_t e = 0; e < nn; ++e) tmp[e] = (cur + 1) * FTJF[e];
+            for (int i = 0; i < rf; ++i) tmp[(size_t)i * rf + i] += 1.0;
+            rc |= orc_invert(rf, tmp, KL1);
+            cst = (logdet_spd(rf, KL1) - logdet_spd(rf, KL) - alpha1) / 2.0;
+        }
+        double s2 = 0.0;
+        for (int i = 0; i < rf; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < rf; ++j) a += KL[(size_t)i * rf + j] * models[j * M + m];
+            s2 += models[i * M + m] * a;
+        }
+        for (long s = 0; s < S; ++s) {
+            for (int i = 0; i < rf; ++i) v[i] = segs[i * S + s] + models[i * M + m];
+            double s3 = 0.0;
+            for (int i = 0; i < rf; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < rf; ++j) a += KL1[(size_t)i * rf + j] * v[j];
+                s3 += v[i] * a;
+            }
+            scores[m * S + s] = (s3 - s2 - s1[s]) / 2.0 + cst;
+        }
+    }
+    free(K1); free(KL); free(KL1); free(tmp); free(v); free(s1);
+    return rc;
+}

@@ -1,0 +1,339 @@
+"""ctypes front-end to oracle/liboracle.so (the C restatement of the reference arithmetic).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by lia_ral_amd (the product).
+"""
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+c_dp = ct.POINTER(ct.c_double)
+c_lp = ct.POINTER(ct.c_long)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _lib(fast=False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        _LIBS[name] = ct.CDLL(path)
+    return _LIBS[name]
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_dp)
+
+
+def _l(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(c_lp)
+
+
+class Gmm:
+    """w[C], mean[C,D], covinv[C,D] (fp64)."""
+
+    def __init__(self, w, mean, covinv):
+        self.w = np.ascontiguousarray(w, np.float64)
+        self.mean = np.ascontiguousarray(mean, np.float64)
+        self.covinv = np.ascontiguousarray(covinv, np.float64)
+        self.C, self.D = self.mean.shape
+
+    def args(self):
+        return (ct.c_int(self.C), ct.c_int(self.D), self.w.ctypes.data_as(c_dp),
+                self.mean.ctypes.data_as(c_dp), self.covinv.ctypes.data_as(c_dp))
+
+
+def llk(g, x, min_llk=-200.0, max_llk=200.0):
+    x, xp = _d(x)
+    T = x.shape[0]
+    out = np.empty(T)
+    _lib().orc_llk(*g.args(), xp, ct.c_long(T), ct.c_double(min_llk), ct.c_double(max_llk),
+                   out.ctypes.data_as(c_dp))
+    return out
+
+
+def llk_determine_top(g, x, ctop, complete=True, min_llk=-200.0, max_llk=200.0):
+    x, xp = _d(x)
+    T = x.shape[0]
+    ctop = min(ctop, g.C)
+    idx = np.empty((T, ctop), np.int64)
+    lk = np.empty((T, ctop))
+    nlk = np.empty(T); nw = np.empty(T); out = np.empty(T)
+    _lib().orc_llk_determine_top(*g.args(), xp, ct.c_long(T), ct.c_int(ctop), ct.c_int(int(complete)),
+                                 ct.c_double(min_llk), ct.c_double(max_llk),
+                                 idx.ctypes.data_as(c_lp), lk.ctypes.data_as(c_dp),
+                                 nlk.ctypes.data_as(c_dp), nw.ctypes.data_as(c_dp), out.ctypes.data_as(c_dp))
+    return dict(idx=idx, lk=lk, nontop_lk=nlk, nontop_w=nw, llk=out)
+
+
+def llk_use_top(g, x, idx, nontop_lk, complete=True, min_llk=-200.0, max_llk=200.0):
+    x, xp = _d(x)
+    T = x.shape[0]
+    idx, ip = _l(idx)
+    nlk, nlp = _d(nontop_lk)
+    out = np.empty(T)
+    _lib().orc_llk_use_top(*g.args(), xp, ct.c_long(T), ct.c_int(idx.shape[1]), ip, nlp,
+                           ct.c_int(int(complete)), ct.c_double(min_llk), ct.c_double(max_llk),
+                           out.ctypes.data_as(c_dp))
+    return out
+
+
+def occ(g, x):
+    x, xp = _d(x)
+    T = x.shape[0]
+    out = np.empty((T, g.C))
+    _lib().orc_occ(*g.args(), xp, ct.c_long(T), out.ctypes.data_as(c_dp))
+    return out
+
+
+def em_accumulate(g, x, weight=1.0, acc=None, fast=False, threads=0):
+    """Returns dict(occ, sx, sxx, count, llk) -- accumulating into `acc` when given."""
+    x, xp = _d(x)
+    T = x.shape[0]
+    if acc is None:
+        acc = dict(occ=np.zeros(g.C), sx=np.zeros((g.C, g.D)), sxx=np.zeros((g.C, g.D)), count=0.0, llk=0.0)
+    cnt = ct.c_double(acc["count"])
+    lib = _lib(fast)
+    if threads and fast:
+        f = lib.orc_em_accumulate_mt
+        f.restype = ct.c_double
+        r = f(ct.c_int(threads), *g.args(), xp, ct.c_long(T), ct.c_double(weight),
+              acc["occ"].ctypes.data_as(c_dp), acc["sx"].ctypes.data_as(c_dp),
+              acc["sxx"].ctypes.data_as(c_dp), ct.byref(cnt))
+    else:
+        f = lib.orc_em_accumulate
+        f.restype = ct.c_double
+        r = f(*g.args(), xp, ct.c_long(T), ct.c_double(weight),
+              acc["occ"].ctypes.data_as(c_dp), acc["sx"].ctypes.data_as(c_dp),
+              acc["sxx"].ctypes.data_as(c_dp), ct.byref(cnt))
+    acc["count"] = cnt.value
+    acc["llk"] += r
+    return acc
+
+
+def em_get(acc, prev_mean, prev_cov):
+    C, D = acc["sx"].shape
+    w = np.empty(C); mean = np.array(prev_mean, np.float64); cov = np.array(prev_cov, np.float64)
+    _lib().orc_em_get(ct.c_int(C), ct.c_int(D), acc["occ"].ctypes.data_as(c_dp),
+                      acc["sx"].ctypes.data_as(c_dp), acc["sxx"].ctypes.data_as(c_dp),
+                      ct.c_double(acc["count"]), w.ctypes.data_as(c_dp), mean.ctypes.data_as(c_dp),
+                      cov.ctypes.data_as(c_dp))
+    return w, mean, cov
+
+
+def set_it_parameter(begin, end, nb_it, it):
+    f = _lib().orc_set_it_parameter
+    f.restype = ct.c_double
+    return f(ct.c_double(begin), ct.c_double(end), ct.c_int(nb_it), ct.c_int(it))
+
+
+def variance_control(cov, flooring, ceiling, cov_signal):
+    cov = np.array(cov, np.float64)
+    C, D = cov.shape
+    cs, csp = _d(cov_signal)
+    nf = ct.c_long(0); nc = ct.c_long(0)
+    _lib().orc_variance_control(ct.c_int(C), ct.c_int(D), cov.ctypes.data_as(c_dp),
+                                ct.c_double(flooring), ct.c_double(ceiling), csp, ct.byref(nf), ct.byref(nc))
+    return cov, nf.value, nc.value
+
+
+def map_occdep_mean(mean_world, w_ml, mean_ml, frame_count, reg):
+    mw, mwp = _d(mean_world); wm, wmp = _d(w_ml); mm, mmp = _d(mean_ml)
+    C, D = mw.shape
+    out = np.empty((C, D))
+    _lib().orc_map_occdep_mean(ct.c_int(C), ct.c_int(D), mwp, wmp, mmp, ct.c_double(frame_count),
+                               ct.c_double(reg), out.ctypes.data_as(c_dp))
+    return out
+
+
+def frame_acc(x):
+    x, xp = _d(x)
+    T, D = x.shape
+    s = np.zeros(D); ss = np.zeros(D); n = ct.c_double(0)
+    _lib().orc_frame_acc(ct.c_int(D), xp, ct.c_long(T), s.ctypes.data_as(c_dp), ss.ctypes.data_as(c_dp), ct.byref(n))
+    return s, ss, n.value
+
+
+def frame_mean_cov(s, ss, n):
+    D = len(s)
+    m = np.empty(D); c = np.empty(D)
+    _lib().orc_frame_mean_cov(ct.c_int(D), _d(s)[1], _d(ss)[1], ct.c_double(n), m.ctypes.data_as(c_dp), c.ctypes.data_as(c_dp))
+    return m, c
+
+
+def bagged_segments(seed, seg_begin, seg_len, p, min_len=3, max_len=7):
+    sb, sbp = _l(seg_begin); sl, slp = _l(seg_len)
+    cap = int(sl.sum()) + len(sl) + 8
+    ob = np.empty(cap, np.int64); ol = np.empty(cap, np.int64); os_ = np.empty(cap, np.int64)
+    f = _lib().orc_bagged_segments
+    f.restype = ct.c_long
+    n = f(ct.c_uint(seed), sbp, slp, ct.c_long(len(sb)), ct.c_double(p), ct.c_long(min_len), ct.c_long(max_len),
+          ob.ctypes.data_as(c_lp), ol.ctypes.data_as(c_lp), os_.ctypes.data_as(c_lp), ct.c_long(cap))
+    return ob[:n].copy(), ol[:n].copy(), os_[:n].copy()
+
+
+# ---------------------------------------------------------------- total variability
+def tv_stats(g, x, utt, U):
+    x, xp = _d(x)
+    T = x.shape[0]
+    utt, up = _l(utt)
+    N = np.zeros((U, g.C)); F = np.zeros((U, g.C * g.D))
+    _lib().orc_tv_stats(*g.args(), xp, ct.c_long(T), up, N.ctypes.data_as(c_dp), F.ctypes.data_as(c_dp))
+    return N, F
+
+
+def tv_subtract_m(N, F, means):
+    U, C = N.shape
+    D = F.shape[1] // C
+    F = np.array(F, np.float64)
+    _lib().orc_tv_subtract_m(ct.c_long(U), ct.c_int(C), ct.c_int(D), _d(N)[1], F.ctypes.data_as(c_dp), _d(means)[1])
+    return F
+
+
+def tv_tett(Tm, invvar, C, D):
+    Tm, tp = _d(Tm)
+    R = Tm.shape[0]
+    out = np.empty((C, R, R))
+    _lib().orc_tv_tett(ct.c_int(C), ct.c_int(D), ct.c_int(R), tp, _d(invvar)[1], out.ctypes.data_as(c_dp))
+    return out
+
+
+def tv_estimate_w(N, F, Tm, invvar, TETt, fast=False, threads=0):
+    N, Np = _d(N); F, Fp = _d(F); Tm, tp = _d(Tm); iv, ivp = _d(invvar); TE, tep = _d(TETt)
+    U, C = N.shape
+    R = Tm.shape[0]
+    D = Tm.shape[1] // C
+    W = np.zeros((U, R))
+    lib = _lib(fast)
+    if threads and fast:
+        rc = lib.orc_tv_estimate_w_mt(ct.c_int(threads), ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(R),
+                                      Np, Fp, tp, ivp, tep, W.ctypes.data_as(c_dp))
+    else:
+        rc = lib.orc_tv_estimate_w(ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(R), Np, Fp, tp, ivp, tep,
+                                   W.ctypes.data_as(c_dp))
+    assert rc == 0
+    return W
+
+
+def tv_estimate_a_and_c(N, F, Tm, invvar, TETt):
+    N, Np = _d(N); F, Fp = _d(F); Tm, tp = _d(Tm); iv, ivp = _d(invvar); TE, tep = _d(TETt)
+    U, C = N.shape
+    R = Tm.shape[0]
+    SV = Tm.shape[1]
+    D = SV // C
+    W = np.zeros((U, R)); A = np.zeros((C, R * R)); Cmx = np.zeros((R, SV))
+    Rm = np.zeros((R, R)); r = np.zeros(R); meanW = np.zeros(R)
+    rc = _lib().orc_tv_estimate_a_and_c(ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(R), Np, Fp, tp, ivp, tep,
+                                        *[a.ctypes.data_as(c_dp) for a in (W, A, Cmx, Rm, r, meanW)])
+    assert rc == 0
+    return dict(W=W, A=A, Cmx=Cmx, Rm=Rm, r=r, meanW=meanW)
+
+
+def tv_update_t(A, Cmx, C, D):
+    A, Ap = _d(A); Cmx, Cp = _d(Cmx)
+    R = Cmx.shape[0]
+    Tm = np.zeros((R, C * D))
+    rc = _lib().orc_tv_update_t(ct.c_int(C), ct.c_int(D), ct.c_int(R), Ap, Cp, Tm.ctypes.data_as(c_dp))
+    assert rc == 0
+    return Tm
+
+
+def tv_min_divergence(Rm, r, meanW, means, Tm, n_sessions, C, D):
+    Rm = np.array(Rm, np.float64); r = np.array(r, np.float64)
+    means = np.array(means, np.float64); Tm = np.array(Tm, np.float64)
+    R = Tm.shape[0]
+    rc = _lib().orc_tv_min_divergence(ct.c_int(C), ct.c_int(D), ct.c_int(R), ct.c_double(n_sessions),
+                                      Rm.ctypes.data_as(c_dp), r.ctypes.data_as(c_dp), _d(meanW)[1],
+                                      means.ctypes.data_as(c_dp), Tm.ctypes.data_as(c_dp))
+    assert rc == 0
+    return means, Tm
+
+
+def tv_orthonormalize_t(Tm):
+    Tm = np.array(Tm, np.float64)
+    R, SV = Tm.shape
+    _lib().orc_tv_orthonormalize_t(ct.c_int(R), ct.c_size_t(SV), Tm.ctypes.data_as(c_dp))
+    return Tm
+
+
+def invert(a):
+    a, ap = _d(a)
+    n = a.shape[0]
+    out = np.empty((n, n))
+    rc = _lib().orc_invert(ct.c_int(n), ap, out.ctypes.data_as(c_dp))
+    assert rc == 0
+    return out
+
+
+def upper_cholesky(a):
+    a, ap = _d(a)
+    n = a.shape[0]
+    out = np.empty((n, n))
+    rc = _lib().orc_upper_cholesky(ct.c_int(n), ap, out.ctypes.data_as(c_dp))
+    assert rc == 0
+    return out
+
+
+# ---------------------------------------------------------------- scoring (vectors as columns)
+def _trials(tr):
+    if tr is None:
+        return None, None
+    tr = np.ascontiguousarray(tr, np.uint8)
+    return tr, tr.ctypes.data_as(ct.POINTER(ct.c_ubyte))
+
+
+def score_cosine(models, segs, trials=None):
+    m, mp = _d(models); s, sp = _d(segs)
+    dim, M = m.shape; S = s.shape[1]
+    out = np.zeros((M, S)); tr, trp = _trials(trials)
+    _lib().orc_score_cosine(ct.c_int(dim), ct.c_long(M), ct.c_long(S), mp, sp, trp, out.ctypes.data_as(c_dp))
+    return out
+
+
+def score_mahalanobis(models, segs, Mah, trials=None):
+    m, mp = _d(models); s, sp = _d(segs)
+    dim, M = m.shape; S = s.shape[1]
+    out = np.zeros((M, S)); tr, trp = _trials(trials)
+    _lib().orc_score_mahalanobis(ct.c_int(dim), ct.c_long(M), ct.c_long(S), mp, sp, _d(Mah)[1], trp,
+                                 out.ctypes.data_as(c_dp))
+    return out
+
+
+def twocov_model(Wm, Bm):
+    Wm, wp = _d(Wm); Bm, bp = _d(Bm)
+    n = Wm.shape[0]
+    G = np.empty((n, n)); H = np.empty((n, n))
+    rc = _lib().orc_twocov_model(ct.c_int(n), wp, bp, G.ctypes.data_as(c_dp), H.ctypes.data_as(c_dp))
+    assert rc == 0
+    return G, H
+
+
+def score_twocov(models, segs, G, H):
+    m, mp = _d(models); s, sp = _d(segs)
+    dim, M = m.shape; S = s.shape[1]
+    out = np.zeros((M, S))
+    _lib().orc_score_twocov(ct.c_int(dim), ct.c_long(M), ct.c_long(S), mp, sp, _d(G)[1], _d(H)[1],
+                            out.ctypes.data_as(c_dp))
+    return out
+
+
+def score_plda(models_sum, nsess, segs, FTJF):
+    m, mp = _d(models_sum); s, sp = _d(segs)
+    rf, M = m.shape; S = s.shape[1]
+    ns, nsp = _l(nsess)
+    out = np.zeros((M, S))
+    rc = _lib().orc_score_plda(ct.c_int(rf), ct.c_long(M), ct.c_long(S), mp, nsp, sp, _d(FTJF)[1],
+                               out.ctypes.data_as(c_dp))
+    assert rc == 0
+    return out

@@ -1,0 +1,95 @@
+/*
+ * oracle_mt.c -- pthread driver around the oracle's EM / TV-stat loops, used ONLY by bench.py's
+ * cpu_baseline leg (TEST INFRASTRUCTURE).  It reproduces the reference's CPU partitioning:
+ *   - EM: workers take frame ranges and own a private accumulator, merged at the end
+ *     (LIA_SpkTools/src/AccumulateStat.cpp:170-212 EMthread, :286-292 addAccEM merge);
+ *   - TV stats / i-vectors: contiguous utterance ranges per thread, disjoint output rows
+ *     (LIA_SpkTools/src/AccumulateTVStat.cpp:498-507, :2282-2300).
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+double orc_em_accumulate(int C, int D, const double *w, const double *mean, const double *covinv,
+                         const double *x, long T, double weight,
+                         double *occ, double *sx, double *sxx, double *count);
+int orc_tv_estimate_w(long U, int C, int D, int R, const double *N, const double *F,
+                      const double *Tm, const double *invvar, const double *TETt, double *W);
+
+typedef struct {
+    int C, D; const double *w, *mean, *covinv, *x; long T; double weight;
+    double *occ, *sx, *sxx; double count, llk;
+} em_job;
+
+static void *em_worker(void *p)
+{
+    em_job *j = p;
+    j->llk = orc_em_accumulate(j->C, j->D, j->w, j->mean, j->covinv, j->x, j->T, j->weight,
+                               j->occ, j->sx, j->sxx, &j->count);
+    return NULL;
+}
+
+double orc_em_accumulate_mt(int nthreads, int C, int D, const double *w, const double *mean,
+                            const double *covinv, const double *x, long T, double weight,
+                            double *occ, double *sx, double *sxx, double *count)
+{
+    if (nthreads < 1) nthreads = 1;
+    em_job *jobs = calloc(nthreads, sizeof(em_job));
+    pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
+    size_t CD = (size_t)C * D;
+    long per = (T + nthreads - 1) / nthreads;
+    for (int i = 0; i < nthreads; ++i) {
+        long b = i * per, e = b + per > T ? T : b + per;
+        if (b > T) b = e = T;
+        em_job *j = &jobs[i];
+        j->C = C; j->D = D; j->w = w; j->mean = mean; j->covinv = covinv;
+        j->x = x + b * D; j->T = e - b; j->weight = weight;
+        j->occ = calloc(C, sizeof(double)); j->sx = calloc(CD, sizeof(double)); j->sxx = calloc(CD, sizeof(double));
+        pthread_create(&th[i], NULL, em_worker, j);
+    }
+    double llk = 0.0;
+    for (int i = 0; i < nthreads; ++i) {
+        pthread_join(th[i], NULL);
+        em_job *j = &jobs[i];
+        for (int c = 0; c < C; ++c) occ[c] += j->occ[c];
+        for (size_t k = 0; k < CD; ++k) { sx[k] += j->sx[k]; sxx[k] += j->sxx[k]; }
+        *count += j->count;
+        llk += j->llk;
+        free(j->occ); free(j->sx); free(j->sxx);
+    }
+    free(jobs); free(th);
+    return llk;
+}
+
+typedef struct {
+    long U; int C, D, R; const double *N, *F, *Tm, *invvar, *TETt; double *W; int rc;
+} w_job;
+
+static void *w_worker(void *p)
+{
+    w_job *j = p;
+    j->rc = orc_tv_estimate_w(j->U, j->C, j->D, j->R, j->N, j->F, j->Tm, j->invvar, j->TETt, j->W);
+    return NULL;
+}
+
+int orc_tv_estimate_w_mt(int nthreads, long U, int C, int D, int R, const double *N, const double *F,
+                         const double *Tm, const double *invvar, const double *TETt, double *W)
+{
+    if (nthreads < 1) nthreads = 1;
+    w_job *jobs = calloc(nthreads, sizeof(w_job));
+    pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
+    size_t SV = (size_t)C * D;
+    long per = (U + nthreads - 1) / nthreads;
+    for (int i = 0; i < nthreads; ++i) {
+        long b = i * per, e = b + per > U ? U : b + per;
+        if (b > U) b = e = U;
+        w_job *j = &jobs[i];
+        j->U = e - b; j->C = C; j->D = D; j->R = R; j->N = N + b * C; j->F = F + b * SV;
+        j->Tm = Tm; j->invvar = invvar; j->TETt = TETt; j->W = W + b * R;
+        pthread_create(&th[i], NULL, w_worker, j);
+    }
+    int rc = 0;
+    for (int i = 0; i < nthreads; ++i) { pthread_join(th[i], NULL); rc |= jobs[i].rc; }
+    free(jobs); free(th);
+    return rc;
+}
