@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: one UBM EM pass (TrainWorld hot path) per step.
+
+Workload (BASELINE.json configs[1]): 2048-Gaussian diagonal UBM, 60-dim float32 frames,
+10 M synthetic frames resident in HBM per GPU.  One step = the E-step of one EM iteration:
+log-likelihood pass + full-posterior sufficient statistics over every frame (HIP, fp64 MFMA),
+the RCCL all-reduce of the 1.98 MB statistics when N > 1, the M-step and the model re-pack.
+Metric: Gframe-Gaussian evaluations/s, whole job (all ranks).  Scaling is weak (10 M frames/GPU).
+
+Launch: python bench.py --gpus 1   |   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+C, D = 2048, 60
+FLOP_PER_PAIR_STATS = 480.0   # 240 (logits) + 242 (statistics) per frame-Gaussian pair
+FLOP_PER_PAIR_LLK = 240.0
+PEAK_F64_TFLOPS = 78.6        # MI355X fp64 matrix = vector peak (AMD datasheet; measured ceiling in DESIGN.md)
+
+
+def synth_frames(w, mean, iv, T, device, seed):
+    """x = mu_c + sqrt(var_c) N(0,1), component ~ weights, float32 (generated on the GPU)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    wt = torch.from_numpy(w).to(device)
+    mt = torch.from_numpy(mean).to(device=device, dtype=torch.float32)
+    st = torch.from_numpy(1.0 / np.sqrt(iv)).to(device=device, dtype=torch.float32)
+    x = torch.empty((T, D), dtype=torch.float32, device=device)
+    step = 1 << 20
+    for b in range(0, T, step):
+        n = min(step, T - b)
+        comp = torch.multinomial(wt, n, replacement=True, generator=g)
+        x[b:b + n] = mt[comp] + st[comp] * torch.randn((n, D), device=device, dtype=torch.float32, generator=g)
+    return x
+
+
+def cpu_baseline(w, mean, iv, seed):
+    """Oracle port (-O3 -ffast-math, pthreads with the reference's frame partitioning) on the host cores."""
+    from conftest import make_frames
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    frames = min(30000 * cores, 2_000_000)
+    x = make_frames(w, mean, iv, frames, seed=seed).astype(np.float64)
+    g = orc.Gmm(w, mean, iv)
+    orc.em_accumulate(g, x[:2000], fast=True, threads=cores)       # warm-up / page-in
+    t = time.time()
+    orc.em_accumulate(g, x, fast=True, threads=cores)
+    dt = time.time() - t
+    return {"value": frames * C / dt / 1e9, "unit": "Gframe-Gaussian/s", "cores": cores, "kind": "port",
+            "sample": "%d frames x %d Gaussians, one EM statistics pass, %d pthreads (oracle/oracle_mt.c, "
+                      "gcc -O3 -ffast-math like the reference), %.1f s" % (frames, C, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL over xGMI
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from conftest import make_gmm
+    from lia_ral_amd import capi
+
+    w, mean, iv = make_gmm(C, D, seed=0)
+    T = args.frames
+    x = synth_frames(w, mean, iv, T, dev, seed=1234 + rank)
+    ctx = capi.Context(local, torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("timing", 1)
+    g = ctx.gmm(w, mean, iv)
+    nacc = g.em_acc_len()
+    acc = torch.zeros(nacc, dtype=torch.float64, device=dev)
+    mean_d = torch.from_numpy(mean).to(dev)
+    cov_d = torch.from_numpy(1.0 / iv).to(dev)
+    w_d = torch.empty(C, dtype=torch.float64, device=dev)
+    nm_d = torch.empty_like(mean_d)
+    nc_d = torch.empty_like(cov_d)
+    floor = 1e-3 * cov_d.mean(0, keepdim=True)
+
+    kern_ms = {}
+
+    def step(record=False):
+        nonlocal mean_d, cov_d, nm_d, nc_d
+        acc.zero_()
+        g.em_accumulate(x, acc=acc)                         # K1 (lse) + K2 (statistics) + reduce
+        if record:
+            ms, name = ctx.last_kernel_ms()
+            kern_ms.setdefault(name, []).append(ms)
+        if world > 1:
+            dist.all_reduce(acc)                            # EM sufficient statistics, 1.98 MB fp64
+        # M-step (MixtureStat::getEM) + variance flooring + re-pack of the device model
+        capi._chk(capi.lib.gmmiv_em_get(ctx._h, C, D, capi._ptr(acc), capi._ptr(mean_d), capi._ptr(cov_d),
+                                        capi._ptr(w_d), capi._ptr(nm_d), capi._ptr(nc_d)))
+        torch.maximum(nc_d, floor, out=nc_d)
+        g.set(w_d, nm_d, 1.0 / nc_d)
+        mean_d, nm_d = nm_d, mean_d
+        cov_d, nc_d = nc_d, cov_d
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    pairs_per_step = float(T) * C * world
+    value = pairs_per_step * args.steps / dt / 1e9
+    out = {
+        "metric": "Gframe-Gaussian evals/s (UBM EM pass: LLK + full-posterior statistics)",
+        "value": value, "unit": "Gframe-Gaussian/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "TrainWorld EM: 2048-Gaussian diag UBM, 60-dim float32 frames, %d frames per GPU "
+                               "resident in HBM, 1 EM iteration per step" % T,
+                   "gaussians": C, "dim": D, "frames_per_gpu": T, "partitioning": "frames sharded per rank, "
+                   "one RCCL all-reduce of %d doubles per step" % nacc},
+    }
+    if rank == 0:
+        ms = float(np.mean(kern_ms.get("k_stats_mfma", [float("nan")])))
+        achieved = FLOP_PER_PAIR_STATS * T * C / (ms * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("k_stats_mfma_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": "k_stats_mfma<15,true,float>", "achieved": achieved,
+                           "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
+                           "traffic": traffic, "kernel_ms": ms,
+                           "algorithmic_flop_per_launch": FLOP_PER_PAIR_STATS * T * C}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, mean, iv, seed=99)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

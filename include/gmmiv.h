@@ -1,0 +1,160 @@
+/*
+ * gmmiv.h -- C ABI of libgmmiv, the MI355X (gfx950) GMM / i-vector compute engine.
+ *
+ * Drop-in boundary for ONE hot path of LIA_RAL: per-frame diagonal-GMM log-likelihood, top-C
+ * selection, full-posterior (Baum-Welch / EM) sufficient statistics, the i-vector solve and the
+ * i-vector scoring rules.  The reference has no FFI layer: these loops call C++ objects of the
+ * external alize-core library once per frame.  Each entry point below therefore
+ * replaces one *batched* reference loop; the comment on it cites the loop (paths relative to the
+ * LIA_RAL tree).  INTEGRATION.md shows the branch a maintainer adds at each of those call sites.
+ *
+ * Conventions
+ *  - plain C, opaque handles, int status (0 = ok, <0 = error; gmmiv_last_error() has the text);
+ *  - every array argument may be a HOST pointer or a DEVICE (HIP) pointer -- detected with
+ *    hipPointerGetAttributes.  Host arrays are staged through the context's device workspace;
+ *    device arrays are used in place (no copy), which is what bench.py times;
+ *  - matrices are row-major, arithmetic is fp64 like the reference (features may be given as
+ *    float32, the on-disk SPro type, or as double, the type Feature::getDataVector() returns);
+ *  - one context per GPU / per host thread; a context is not thread-safe, different contexts are;
+ *  - no hidden state: the per-frame top-C vector that ALIZE keeps inside StatServer is an
+ *    explicit output / input here.
+ */
+#ifndef GMMIV_H
+#define GMMIV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gmmiv_ctx gmmiv_ctx; /* device + stream + workspace                       */
+typedef struct gmmiv_gmm gmmiv_gmm; /* device-resident diagonal GMM in kernel-ready layout */
+
+enum { GMMIV_F32 = 0, GMMIV_F64 = 1 };           /* feature element type               */
+enum { GMMIV_TOP_PARTIAL = 0, GMMIV_TOP_COMPLETE = 1 }; /* computeLLKWithTopDistribs */
+
+#define GMMIV_OK 0
+#define GMMIV_ERR_ARG (-1)
+#define GMMIV_ERR_HIP (-2)
+#define GMMIV_ERR_UNSUPPORTED (-3)
+#define GMMIV_ERR_NUMERIC (-4)
+
+/* ---- context --------------------------------------------------------------------------- */
+/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a private one. */
+int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out);
+void gmmiv_ctx_destroy(gmmiv_ctx *ctx);
+int gmmiv_ctx_sync(gmmiv_ctx *ctx);
+const char *gmmiv_last_error(void);
+const char *gmmiv_version(void);
+/* Runtime knobs for A/B measurements ("glds", "em_chunks", ...); returns previous value. */
+long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);
+/* Duration (ms, HIP events on the context's stream) of the last call's dominant kernel. */
+double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *ctx, const char **kernel_name);
+
+/* ---- model: MixtureGD / DistribGD ----------------------------------------------------------
+ * w[C], mean[C*D], covinv[C*D] (DistribGD::getMeanVect / getCovInvVect, MixtureGD::weight(c);
+ * LIA_SpkTools/src/AccumulateTVStat.cpp:154-162).  cst/det are derived like computeAll(). */
+int gmmiv_gmm_create(gmmiv_ctx *ctx, int C, int D, const double *w, const double *mean,
+                     const double *covinv, gmmiv_gmm **out);
+int gmmiv_gmm_set(gmmiv_gmm *g, const double *w, const double *mean, const double *covinv);
+void gmmiv_gmm_destroy(gmmiv_gmm *g);
+
+/* ---- FrameAccGD::accumulate loop (LIA_SpkTools/src/AccumulateStat.cpp:387-396) ---------------
+ * acc[0..D) += sum x, acc[D..2D) += sum x^2, acc[2D] += T.  mean/cov: sum/n, sumsq/n - mean^2. */
+int gmmiv_frame_moments(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t T, int64_t ldx, int D,
+                        double *acc);
+
+/* ---- MixtureStat::computeAndAccumulateLLK(f,1.0,TOP_DISTRIBS_NO_ACTION) loop -------------------
+ * (LIA_SpkTools/src/AccumulateStat.cpp:69-94, :344-379; AccumulateTVStat.cpp:1644-1648)
+ * llk_out[T] (nullable) = clamp(log sum_c w_c lk_c(x_t), min_llk, max_llk);
+ * sums[0] += sum_t llk_out[t] (clamped), sums[1] += T  -> getMeanLLK() = sums[0]/sums[1]. */
+int gmmiv_llk(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x_dtype, int64_t T, int64_t ldx,
+              double min_llk, double max_llk, double *llk_out, double *sums);
+
+/* ---- computeAndAccumulateLLK(f,1.0,DETERMINE_TOP_DISTRIBS) + StatServer::getTopDistribIndexVector
+ * (LIA_SpkDet/ComputeTest/src/ComputeTest.cpp:163; LIA_SpkTools/src/TopGauss.cpp:167-193)
+ * Per frame: idx[t*ctop+j] / lk[t*ctop+j] = the ctop largest w_c lk_c, descending (ties: lower
+ * index first); nontop_lk = sum of the others (linear, may underflow), nontop_llk = its log
+ * (-inf when empty), nontop_w = 1 - sum of the selected weights; llk = clamp(log(top [+ rest])).
+ * lk, nontop_lk, nontop_w, llk_out may be NULL. ctop <= 64. */
+int gmmiv_llk_determine_top(gmmiv_ctx *ctx, const gmmiv_gmm *world, const void *x, int x_dtype,
+                            int64_t T, int64_t ldx, int ctop, int mode, double min_llk, double max_llk,
+                            int32_t *idx, double *lk, double *nontop_lk, double *nontop_llk,
+                            double *nontop_w, double *llk_out);
+
+/* ---- computeAndAccumulateLLK(f,1.0,USE_TOP_DISTRIBS) on a client model ------------------------
+ * (ComputeTest.cpp:166-167; StatServer::setTopDistribIndexVector, TopGauss.cpp:297-308)
+ * llk_out[t] = clamp(log(sum_j w_c lk_c(client) over c = idx[t][j]  [+ exp(nontop_llk[t])])). */
+int gmmiv_llk_use_top(gmmiv_ctx *ctx, const gmmiv_gmm *client, const void *x, int x_dtype, int64_t T,
+                      int64_t ldx, int ctop, const int32_t *idx, const double *nontop_llk, int mode,
+                      double min_llk, double max_llk, double *llk_out);
+
+/* ---- MixtureStat::computeAndAccumulateEM loop (accumulateStatEM, AccumulateStat.cpp:103-152) ---
+ * acc is the flat EM accumulator, length gmmiv_em_acc_len(C,D) = C*(1+2D)+2 doubles:
+ *   [ occ[C] | sum g x [C*D] | sum g x^2 [C*D] | sum_t weight*log lk_t | sum_t weight ].
+ * ACCUMULATES (resetEM = zero the array; addAccEM = add two arrays; one RCCL all-reduce of this
+ * array merges ranks).  gamma_tc = full posterior (all C). */
+size_t gmmiv_em_acc_len(int C, int D);
+int gmmiv_em_accumulate(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x_dtype, int64_t T,
+                        int64_t ldx, double weight, double *acc);
+/* MixtureStat::getEM(): w = occ/count, mean = sx/occ, cov = sxx/occ - mean^2 (host formula run on
+ * the device copy; components with occ == 0 keep prev_mean / prev_cov).  Outputs [C],[C*D],[C*D]. */
+int gmmiv_em_get(gmmiv_ctx *ctx, int C, int D, const double *acc, const double *prev_mean,
+                 const double *prev_cov, double *w, double *mean, double *cov);
+
+/* ---- TVAcc::computeAndAccumulateTVStat (LIA_SpkTools/src/AccumulateTVStat.cpp:281-351) ---------
+ * Frames of statistics row u are x[utt_begin[u] .. utt_begin[u+1]) (utt_begin: U+1 HOST offsets).
+ * N[u*C+c] = sum_t g_tc ; F[u*C*D + c*D + i] = sum_t g_tc x_ti   (rows are overwritten). */
+int gmmiv_tv_stats(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x_dtype, int64_t T,
+                   int64_t ldx, const int64_t *utt_begin, int64_t U, double *N, double *F);
+
+/* ---- TVAcc i-vector maths (exact mode) -------------------------------------------------------
+ * T: [R x C*D] row-major total-variability matrix; invvar: [C*D] UBM inverse variances.
+ * substractM          AccumulateTVStat.cpp:1088-1105   F[u,c,:] -= mean[c,:] N[u,c]  (in place)
+ * estimateTETt        :777-805    TETt packed lower triangle: [C x R(R+1)/2], row i>=j at i(i+1)/2+j
+ * estimateW           :2114-2169  W[U x R] = (I + sum_c N[u,c] TETt_c)^-1 T Sigma^-1 F_u
+ * estimateAandC       :1702-1795  + A[C x R(R+1)/2] (packed), Cmx[R x C*D], Rm[R x R], r[R], meanW[R]
+ *                     (A, Cmx, Rm, r, meanW ACCUMULATE: zero them first; meanW is the SUM of w --
+ *                      divide by the total utterance count after the all-reduce)
+ * updateTestimate     :974-1005   T_c = A_c^-1 Cmx_c
+ * minDivergence       :2056-2099  T <- chol_upper(Rm/n - r r^T / n^2) T ; mean += T^T meanW
+ */
+int gmmiv_tv_subtract_m(gmmiv_ctx *ctx, int64_t U, int C, int D, const double *N, double *F,
+                        const double *ubm_means);
+size_t gmmiv_tv_packed_len(int R);
+int gmmiv_tv_tett(gmmiv_ctx *ctx, int C, int D, int R, const double *Tm, const double *invvar,
+                  double *tett_packed);
+int gmmiv_tv_estimate_w(gmmiv_ctx *ctx, int64_t U, int C, int D, int R, const double *N,
+                        const double *F, const double *Tm, const double *invvar,
+                        const double *tett_packed, double *W);
+int gmmiv_tv_estimate_a_and_c(gmmiv_ctx *ctx, int64_t U, int C, int D, int R, const double *N,
+                              const double *F, const double *Tm, const double *invvar,
+                              const double *tett_packed, double *W, double *A_packed, double *Cmx,
+                              double *Rm, double *r, double *meanW);
+int gmmiv_tv_update_t(gmmiv_ctx *ctx, int C, int D, int R, const double *A_packed, const double *Cmx,
+                      double *Tm);
+int gmmiv_tv_min_divergence(gmmiv_ctx *ctx, int C, int D, int R, double n_sessions, double *Rm,
+                            double *r, const double *meanW, double *ubm_means, double *Tm);
+
+/* ---- PldaTest scoring (LIA_SpkTools/src/PldaTools.cpp) ------------------------------------------
+ * models[dim x M], segs[dim x S]: one vector per COLUMN like PldaTest::_models/_segments;
+ * scores[M x S].
+ * cosineDistance :3842-3879, mahalanobisDistance :3882-3909 (-1/2 (m-s)^T Mah (m-s)),
+ * twoCovScoring :4127-4171 ((m+s)^T G (m+s) - m^T H m - s^T H s),
+ * pldaScoringUnThreaded :4186-4271 on vectors already projected by FTJ; models = per-speaker sums,
+ * nsess[m] = enrolment sessions of model m (HOST array). */
+int gmmiv_score_cosine(gmmiv_ctx *ctx, int dim, int64_t M, int64_t S, const double *models,
+                       const double *segs, double *scores);
+int gmmiv_score_mahalanobis(gmmiv_ctx *ctx, int dim, int64_t M, int64_t S, const double *models,
+                            const double *segs, const double *Mah, double *scores);
+int gmmiv_score_twocov(gmmiv_ctx *ctx, int dim, int64_t M, int64_t S, const double *models,
+                       const double *segs, const double *G, const double *H, double *scores);
+int gmmiv_score_plda(gmmiv_ctx *ctx, int rf, int64_t M, int64_t S, const double *models_sum,
+                     const int64_t *nsess, const double *segs, const double *FTJF, double *scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMMIV_H */

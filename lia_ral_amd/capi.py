@@ -1,0 +1,283 @@
+"""ctypes binding of include/gmmiv.h.  Arrays may be numpy arrays (host) or torch CUDA tensors
+(device, used in place).  Raises GmmivError on any non-zero status -- never falls back to a CPU path."""
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgmmiv.so")
+
+F32, F64 = 0, 1
+TOP_PARTIAL, TOP_COMPLETE = 0, 1
+
+
+class GmmivError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise GmmivError("libgmmiv.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "or `make -C lia_ral_amd/csrc`" % LIB_PATH)
+    lib = ct.CDLL(LIB_PATH)
+    lib.gmmiv_last_error.restype = ct.c_char_p
+    lib.gmmiv_version.restype = ct.c_char_p
+    lib.gmmiv_em_acc_len.restype = ct.c_size_t
+    lib.gmmiv_tv_packed_len.restype = ct.c_size_t
+    lib.gmmiv_ctx_last_kernel_ms.restype = ct.c_double
+    lib.gmmiv_ctx_set_option.restype = ct.c_long
+    return lib
+
+
+lib = _load()
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GmmivError("gmmiv error %d: %s" % (rc, lib.gmmiv_last_error().decode()))
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    """void* of a numpy array or torch tensor (None -> NULL)."""
+    if a is None:
+        return ct.c_void_p(0)
+    if _is_torch(a):
+        assert a.is_contiguous()
+        return ct.c_void_p(a.data_ptr())
+    assert a.flags["C_CONTIGUOUS"]
+    return ct.c_void_p(a.ctypes.data)
+
+
+def _f64(a):
+    if a is None or _is_torch(a):
+        return a
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _feat(x):
+    """-> (array, dtype code, T, ldx)"""
+    if _is_torch(x):
+        import torch
+        assert x.dim() == 2 and x.stride(1) == 1
+        dt = F64 if x.dtype == torch.float64 else F32
+        assert x.dtype in (torch.float32, torch.float64)
+        return x, dt, x.shape[0], x.stride(0) if x.shape[0] > 1 else x.shape[1]
+    x = np.asarray(x)
+    if x.dtype not in (np.float32, np.float64):
+        x = x.astype(np.float64)
+    x = np.ascontiguousarray(x)
+    return x, (F64 if x.dtype == np.float64 else F32), x.shape[0], x.shape[1]
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self._h = ct.c_void_p()
+        _chk(lib.gmmiv_ctx_create(ct.c_int(device), ct.c_void_p(stream or 0), ct.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.gmmiv_ctx_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(lib.gmmiv_ctx_sync(self._h))
+
+    def set_option(self, key, value):
+        return lib.gmmiv_ctx_set_option(self._h, key.encode(), ct.c_long(value))
+
+    def last_kernel_ms(self):
+        name = ct.c_char_p()
+        ms = lib.gmmiv_ctx_last_kernel_ms(self._h, ct.byref(name))
+        return ms, (name.value.decode() if name.value else "")
+
+    # ---- model
+    def gmm(self, w, mean, covinv):
+        return Gmm(self, w, mean, covinv)
+
+    # ---- FrameAccGD
+    def frame_moments(self, x, acc=None):
+        x, dt, T, ldx = _feat(x)
+        D = x.shape[1]
+        if acc is None:
+            acc = np.zeros(2 * D + 1)
+        _chk(lib.gmmiv_frame_moments(self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), D, _ptr(acc)))
+        return acc
+
+    # ---- TVAcc maths
+    def tv_subtract_m(self, N, F, means, C, D):
+        U = N.shape[0]
+        _chk(lib.gmmiv_tv_subtract_m(self._h, ct.c_int64(U), C, D, _ptr(N), _ptr(F), _ptr(means)))
+        return F
+
+    def tv_tett(self, Tm, invvar, C, D, out=None):
+        R = Tm.shape[0]
+        if out is None:
+            out = np.empty((C, lib.gmmiv_tv_packed_len(R)))
+        _chk(lib.gmmiv_tv_tett(self._h, C, D, R, _ptr(Tm), _ptr(invvar), _ptr(out)))
+        return out
+
+    def tv_estimate_w(self, N, F, Tm, invvar, tett, C, D, out=None):
+        U, R = N.shape[0], Tm.shape[0]
+        if out is None:
+            out = np.empty((U, R))
+        _chk(lib.gmmiv_tv_estimate_w(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(invvar),
+                                     _ptr(tett), _ptr(out)))
+        return out
+
+    def tv_estimate_a_and_c(self, N, F, Tm, invvar, tett, C, D, acc=None):
+        U, R = N.shape[0], Tm.shape[0]
+        P = lib.gmmiv_tv_packed_len(R)
+        if acc is None:
+            acc = dict(A=np.zeros((C, P)), Cmx=np.zeros((R, C * D)), Rm=np.zeros((R, R)), r=np.zeros(R),
+                       meanW=np.zeros(R))
+        W = acc.get("W")
+        if W is None or W.shape[0] != U:
+            W = np.empty((U, R))
+        _chk(lib.gmmiv_tv_estimate_a_and_c(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(invvar),
+                                           _ptr(tett), _ptr(W), _ptr(acc["A"]), _ptr(acc["Cmx"]), _ptr(acc["Rm"]),
+                                           _ptr(acc["r"]), _ptr(acc["meanW"])))
+        acc["W"] = W
+        return acc
+
+    def tv_update_t(self, A_packed, Cmx, C, D, out=None):
+        R = Cmx.shape[0]
+        if out is None:
+            out = np.empty((R, C * D))
+        _chk(lib.gmmiv_tv_update_t(self._h, C, D, R, _ptr(A_packed), _ptr(Cmx), _ptr(out)))
+        return out
+
+    def tv_min_divergence(self, Rm, r, meanW, means, Tm, n_sessions, C, D):
+        R = Tm.shape[0]
+        _chk(lib.gmmiv_tv_min_divergence(self._h, C, D, R, ct.c_double(n_sessions), _ptr(Rm), _ptr(r), _ptr(meanW),
+                                         _ptr(means), _ptr(Tm)))
+        return means, Tm
+
+    # ---- scoring (vectors as columns: models[dim, M], segs[dim, S])
+    def _score_out(self, models, segs, out):
+        M, S = models.shape[1], segs.shape[1]
+        if out is None:
+            out = np.empty((M, S))
+        return M, S, out
+
+    def score_cosine(self, models, segs, out=None):
+        M, S, out = self._score_out(models, segs, out)
+        _chk(lib.gmmiv_score_cosine(self._h, models.shape[0], ct.c_int64(M), ct.c_int64(S), _ptr(models), _ptr(segs),
+                                    _ptr(out)))
+        return out
+
+    def score_mahalanobis(self, models, segs, Mah, out=None):
+        M, S, out = self._score_out(models, segs, out)
+        _chk(lib.gmmiv_score_mahalanobis(self._h, models.shape[0], ct.c_int64(M), ct.c_int64(S), _ptr(models),
+                                         _ptr(segs), _ptr(Mah), _ptr(out)))
+        return out
+
+    def score_twocov(self, models, segs, G, H, out=None):
+        M, S, out = self._score_out(models, segs, out)
+        _chk(lib.gmmiv_score_twocov(self._h, models.shape[0], ct.c_int64(M), ct.c_int64(S), _ptr(models), _ptr(segs),
+                                    _ptr(G), _ptr(H), _ptr(out)))
+        return out
+
+    def score_plda(self, models_sum, nsess, segs, FTJF, out=None):
+        M, S, out = self._score_out(models_sum, segs, out)
+        ns = np.ascontiguousarray(nsess, dtype=np.int64)
+        _chk(lib.gmmiv_score_plda(self._h, models_sum.shape[0], ct.c_int64(M), ct.c_int64(S), _ptr(models_sum),
+                                  ns.ctypes.data_as(ct.c_void_p), _ptr(segs), _ptr(FTJF), _ptr(out)))
+        return out
+
+
+class Gmm:
+    """Device-resident MixtureGD: w[C], mean[C,D], covinv[C,D]."""
+
+    def __init__(self, ctx, w, mean, covinv):
+        self.ctx = ctx
+        w, mean, covinv = _f64(w), _f64(mean), _f64(covinv)
+        self.C, self.D = mean.shape
+        self._h = ct.c_void_p()
+        _chk(lib.gmmiv_gmm_create(ctx._h, self.C, self.D, _ptr(w), _ptr(mean), _ptr(covinv), ct.byref(self._h)))
+
+    def set(self, w, mean, covinv):
+        _chk(lib.gmmiv_gmm_set(self._h, _ptr(_f64(w)), _ptr(_f64(mean)), _ptr(_f64(covinv))))
+
+    def close(self):
+        if self._h:
+            lib.gmmiv_gmm_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def llk(self, x, min_llk=-200.0, max_llk=200.0, out=None, sums=None):
+        x, dt, T, ldx = _feat(x)
+        if out is None:
+            out = np.empty(T)
+        _chk(lib.gmmiv_llk(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), ct.c_double(min_llk),
+                           ct.c_double(max_llk), _ptr(out), _ptr(sums)))
+        return out
+
+    def llk_determine_top(self, x, ctop, complete=True, min_llk=-200.0, max_llk=200.0):
+        x, dt, T, ldx = _feat(x)
+        ctop = min(ctop, self.C)
+        idx = np.empty((T, ctop), np.int32)
+        lk = np.empty((T, ctop)); nlk = np.empty(T); nllk = np.empty(T); nw = np.empty(T); out = np.empty(T)
+        _chk(lib.gmmiv_llk_determine_top(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), ctop,
+                                         TOP_COMPLETE if complete else TOP_PARTIAL, ct.c_double(min_llk),
+                                         ct.c_double(max_llk), _ptr(idx), _ptr(lk), _ptr(nlk), _ptr(nllk), _ptr(nw),
+                                         _ptr(out)))
+        return dict(idx=idx, lk=lk, nontop_lk=nlk, nontop_llk=nllk, nontop_w=nw, llk=out)
+
+    def llk_use_top(self, x, idx, nontop_llk, complete=True, min_llk=-200.0, max_llk=200.0):
+        x, dt, T, ldx = _feat(x)
+        idx = np.ascontiguousarray(idx, np.int32)
+        out = np.empty(T)
+        _chk(lib.gmmiv_llk_use_top(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), idx.shape[1],
+                                   _ptr(idx), _ptr(_f64(nontop_llk)), TOP_COMPLETE if complete else TOP_PARTIAL,
+                                   ct.c_double(min_llk), ct.c_double(max_llk), _ptr(out)))
+        return out
+
+    def em_acc_len(self):
+        return lib.gmmiv_em_acc_len(self.C, self.D)
+
+    def em_accumulate(self, x, weight=1.0, acc=None):
+        x, dt, T, ldx = _feat(x)
+        if acc is None:
+            acc = np.zeros(self.em_acc_len())
+        _chk(lib.gmmiv_em_accumulate(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx),
+                                     ct.c_double(weight), _ptr(acc)))
+        return acc
+
+    def em_get(self, acc, prev_mean, prev_cov):
+        C, D = self.C, self.D
+        w = np.empty(C); mean = np.empty((C, D)); cov = np.empty((C, D))
+        _chk(lib.gmmiv_em_get(self.ctx._h, C, D, _ptr(acc), _ptr(_f64(prev_mean)), _ptr(_f64(prev_cov)), _ptr(w),
+                              _ptr(mean), _ptr(cov)))
+        return w, mean, cov
+
+    def split_acc(self, acc):
+        C, D = self.C, self.D
+        a = np.asarray(acc)
+        return dict(occ=a[:C], sx=a[C:C + C * D].reshape(C, D), sxx=a[C + C * D:C + 2 * C * D].reshape(C, D),
+                    llk=a[-2], count=a[-1])
+
+    def tv_stats(self, x, utt_begin, N=None, F=None):
+        x, dt, T, ldx = _feat(x)
+        ub = np.ascontiguousarray(utt_begin, dtype=np.int64)
+        U = len(ub) - 1
+        if N is None:
+            N = np.empty((U, self.C)); F = np.empty((U, self.C * self.D))
+        _chk(lib.gmmiv_tv_stats(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx),
+                                ub.ctypes.data_as(ct.c_void_p), ct.c_int64(U), _ptr(N), _ptr(F)))
+        return N, F

@@ -1,0 +1,419 @@
+// capi_gmm.hip -- C ABI (include/gmmiv.h): context, model, GMM likelihood / statistics entry points.
+#include <math.h>
+#include <stdarg.h>
+
+#include "ctx.h"
+#include "gmm_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void gmmiv_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+bool gmmiv_is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc'ed host memory on older runtimes
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+extern "C" {
+
+const char *gmmiv_last_error(void) { return g_err; }
+const char *gmmiv_version(void) { return "gmmiv 0.1 (gfx950)"; }
+
+int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out)
+{
+    if (!out) { gmmiv_set_error("ctx_create: out == NULL"); return GMMIV_ERR_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        gmmiv_set_error("ctx_create: no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return GMMIV_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) { gmmiv_set_error("ctx_create: device %d out of range [0,%d)", device, ndev); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(device));
+    gmmiv_ctx *c = new gmmiv_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { GCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    GCHK(hipEventCreate(&c->ev0));
+    GCHK(hipEventCreate(&c->ev1));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return GMMIV_OK;
+}
+
+void gmmiv_ctx_destroy(gmmiv_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < WS_COUNT; ++i)
+        if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gmmiv_ctx_sync(gmmiv_ctx *c)
+{
+    if (!c) return GMMIV_ERR_ARG;
+    GCHK(hipStreamSynchronize(c->stream));
+    return GMMIV_OK;
+}
+
+long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
+{
+    if (!c || !key) return -1;
+    long *slot = nullptr;
+    if (!strcmp(key, "glds")) slot = &c->use_glds;
+    else if (!strcmp(key, "em_chunks")) slot = &c->em_chunks;
+    else if (!strcmp(key, "timing")) slot = &c->timing;
+    if (!slot) return -1;
+    long prev = *slot;
+    *slot = value;
+    return prev;
+}
+
+double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *c, const char **name)
+{
+    if (!c || !c->ev_valid) return -1.0;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+    if (name) *name = c->ev_name;
+    return (double)ms;
+}
+
+// ---- model -------------------------------------------------------------------------------
+static int gmm_upload(gmmiv_gmm *g, const double *w, const double *mean, const double *covinv)
+{
+    gmmiv_ctx *c = g->ctx;
+    GCHK(hipSetDevice(c->device));
+    const size_t CD = (size_t)g->C * g->D;
+    auto kind = [](const void *p) { return gmmiv_is_device_ptr(p) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; };
+    GCHK(hipMemcpyAsync(g->w, w, g->C * sizeof(double), kind(w), c->stream));
+    GCHK(hipMemcpyAsync(g->mean, mean, CD * sizeof(double), kind(mean), c->stream));
+    GCHK(hipMemcpyAsync(g->iv, covinv, CD * sizeof(double), kind(covinv), c->stream));
+    GCHK(gmmk_pack_model(c->stream, g->C, g->D, g->KS, g->nct, g->Cp64, g->w, g->mean, g->iv, g->a, g->lwc, g->Pt,
+                         g->meanT, g->ivT));
+    GCHK(hipStreamSynchronize(c->stream)); // host sources may be freed by the caller on return
+    return GMMIV_OK;
+}
+
+int gmmiv_gmm_create(gmmiv_ctx *c, int C, int D, const double *w, const double *mean, const double *covinv,
+                     gmmiv_gmm **out)
+{
+    if (!c || !out || !w || !mean || !covinv || C <= 0 || D <= 0) { gmmiv_set_error("gmm_create: bad argument"); return GMMIV_ERR_ARG; }
+    const int KS = gmmk_ks_for_dim(D);
+    if (!KS) { gmmiv_set_error("gmm_create: vectSize %d not supported (max 80)", D); return GMMIV_ERR_UNSUPPORTED; }
+    GCHK(hipSetDevice(c->device));
+    gmmiv_gmm *g = new gmmiv_gmm();
+    g->ctx = c; g->C = C; g->D = D; g->KS = KS;
+    g->nct = ((C + 15) / 16 + 1) / 2 * 2; // c-tiles of 16, padded to the LLK kernel's stage of 2
+    g->Cp64 = (C + 63) / 64 * 64;
+    const size_t CD = (size_t)C * D;
+    const int Cpa = g->Cp64 > g->nct * 16 ? g->Cp64 : g->nct * 16;
+    GCHK(hipMalloc(&g->w, C * sizeof(double)));
+    GCHK(hipMalloc(&g->mean, CD * sizeof(double)));
+    GCHK(hipMalloc(&g->iv, CD * sizeof(double)));
+    GCHK(hipMalloc(&g->a, Cpa * sizeof(double)));
+    GCHK(hipMalloc(&g->lwc, Cpa * sizeof(double)));
+    GCHK(hipMalloc(&g->Pt, (size_t)g->nct * (2 * KS + 2) * 64 * sizeof(double)));
+    GCHK(hipMalloc(&g->meanT, (size_t)D * g->Cp64 * sizeof(double)));
+    GCHK(hipMalloc(&g->ivT, (size_t)D * g->Cp64 * sizeof(double)));
+    int rc = gmm_upload(g, w, mean, covinv);
+    if (rc) { gmmiv_gmm_destroy(g); return rc; }
+    *out = g;
+    return GMMIV_OK;
+}
+
+int gmmiv_gmm_set(gmmiv_gmm *g, const double *w, const double *mean, const double *covinv)
+{
+    if (!g || !w || !mean || !covinv) { gmmiv_set_error("gmm_set: bad argument"); return GMMIV_ERR_ARG; }
+    return gmm_upload(g, w, mean, covinv);
+}
+
+void gmmiv_gmm_destroy(gmmiv_gmm *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    void *ptrs[] = {g->w, g->mean, g->iv, g->a, g->lwc, g->Pt, g->meanT, g->ivT};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+// ---- helpers -----------------------------------------------------------------------------
+static size_t esize(int dt) { return dt == GMMIV_F64 ? 8 : 4; }
+
+// Device view of the feature block [T x ldx]; host input is copied (compacted to ldx = D).
+struct XView {
+    const void *d = nullptr;
+    int64_t ldx = 0;
+    int init(gmmiv_ctx *c, const void *x, int dt, int64_t T, int64_t ld, int D)
+    {
+        if (dt != GMMIV_F32 && dt != GMMIV_F64) { gmmiv_set_error("feature dtype must be GMMIV_F32 or GMMIV_F64"); return GMMIV_ERR_ARG; }
+        if (ld < D) { gmmiv_set_error("ldx (%ld) < D (%d)", (long)ld, D); return GMMIV_ERR_ARG; }
+        if (T == 0) { d = x; ldx = ld; return GMMIV_OK; }
+        if (!x) { gmmiv_set_error("x == NULL"); return GMMIV_ERR_ARG; }
+        if (gmmiv_is_device_ptr(x)) { d = x; ldx = ld; return GMMIV_OK; }
+        void *buf;
+        int rc = c->scratch(WS_X, (size_t)T * D * esize(dt), &buf);
+        if (rc) return rc;
+        GCHK(hipMemcpy2DAsync(buf, D * esize(dt), x, ld * esize(dt), D * esize(dt), T, hipMemcpyHostToDevice, c->stream));
+        d = buf; ldx = D;
+        return GMMIV_OK;
+    }
+};
+
+static int check_model(gmmiv_ctx *c, const gmmiv_gmm *g)
+{
+    if (!c || !g) { gmmiv_set_error("NULL context or model"); return GMMIV_ERR_ARG; }
+    if (g->ctx != c) { gmmiv_set_error("model belongs to a different context"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    return GMMIV_OK;
+}
+
+// ---- frame moments -------------------------------------------------------------------------
+int gmmiv_frame_moments(gmmiv_ctx *c, const void *x, int dt, int64_t T, int64_t ldx, int D, double *acc)
+{
+    if (!c || !acc || T < 0 || D <= 0) { gmmiv_set_error("frame_moments: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    XView xv;
+    int rc = xv.init(c, x, dt, T, ldx, D);
+    if (rc) return rc;
+    DevOut<double> o;
+    if ((rc = o.init(c, WS_T0, acc, 2 * D + 1, true))) return rc;
+    const int maxb = 2048;
+    void *part;
+    if ((rc = c->scratch(WS_PART, (size_t)maxb * 2 * D * sizeof(double), &part))) return rc;
+    c->t_begin("k_frame_moments");
+    GCHK(gmmk_frame_moments(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, D, (double *)part, maxb, o.d));
+    c->t_end();
+    GCHK(gmmk_add_scalar(c->stream, o.d + 2 * D, (double)T));
+    return o.finish();
+}
+
+// ---- LLK ---------------------------------------------------------------------------------
+static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, double **lse_out)
+{
+    void *lse;
+    int rc = c->scratch(WS_LSE, (size_t)(T > 0 ? T : 1) * sizeof(double), &lse);
+    if (rc) return rc;
+    c->t_begin("k_llk_mfma");
+    GCHK(gmmk_llk(c->stream, g->KS, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->Pt, g->nct, (double *)lse, (int)c->use_glds));
+    c->t_end();
+    *lse_out = (double *)lse;
+    return GMMIV_OK;
+}
+
+int gmmiv_llk(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, double min_llk,
+              double max_llk, double *llk_out, double *sums)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0) { gmmiv_set_error("llk: T < 0"); return GMMIV_ERR_ARG; }
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    double *lse;
+    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
+    DevOut<double> o_llk, o_sum;
+    if ((rc = o_llk.init(c, WS_T0, llk_out, (size_t)T, false))) return rc;
+    if ((rc = o_sum.init(c, WS_T1, sums, 2, true))) return rc;
+    void *part;
+    if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &part))) return rc;
+    GCHK(gmmk_llk_finalize(c->stream, lse, T, min_llk, max_llk, o_llk.d, (double *)part, 1.0, 0.0,
+                           sums ? o_sum.d : nullptr, nullptr));
+    if (sums) GCHK(gmmk_add_scalar(c->stream, o_sum.d + 1, (double)T));
+    if ((rc = o_llk.finish())) return rc;
+    return o_sum.finish();
+}
+
+int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, int ctop,
+                            int mode, double min_llk, double max_llk, int32_t *idx, double *lk, double *nontop_lk,
+                            double *nontop_llk, double *nontop_w, double *llk_out)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0 || !idx || ctop <= 0) { gmmiv_set_error("determine_top: bad argument"); return GMMIV_ERR_ARG; }
+    if (ctop > g->C) ctop = g->C;
+    if (ctop > 64) { gmmiv_set_error("determine_top: topDistribsCount %d > 64 not supported", ctop); return GMMIV_ERR_UNSUPPORTED; }
+    if (!gmmk_topc_frames_per_block(g->Cp64, g->D)) { gmmiv_set_error("determine_top: mixtureDistribCount %d too large for the LDS selection kernel", g->C); return GMMIV_ERR_UNSUPPORTED; }
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    DevOut<int32_t> o_idx;
+    DevOut<double> o_lk, o_nlk, o_nllk, o_nw, o_llk;
+    if ((rc = o_idx.init(c, WS_T0, idx, (size_t)T * ctop, false))) return rc;
+    if ((rc = o_lk.init(c, WS_T1, lk, (size_t)T * ctop, false))) return rc;
+    if ((rc = o_nlk.init(c, WS_T2, nontop_lk, (size_t)T, false))) return rc;
+    if ((rc = o_nllk.init(c, WS_T3, nontop_llk, (size_t)T, false))) return rc;
+    if ((rc = o_nw.init(c, WS_T4, nontop_w, (size_t)T, false))) return rc;
+    if ((rc = o_llk.init(c, WS_T5, llk_out, (size_t)T, false))) return rc;
+    c->t_begin("k_topc_determine");
+    GCHK(gmmk_topc_determine(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc,
+                             g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_idx.d, o_lk.d, o_nlk.d,
+                             o_nllk.d, o_nw.d, o_llk.d));
+    c->t_end();
+    if ((rc = o_idx.finish())) return rc;
+    if ((rc = o_lk.finish())) return rc;
+    if ((rc = o_nlk.finish())) return rc;
+    if ((rc = o_nllk.finish())) return rc;
+    if ((rc = o_nw.finish())) return rc;
+    return o_llk.finish();
+}
+
+int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, int ctop,
+                      const int32_t *idx, const double *nontop_llk, int mode, double min_llk, double max_llk,
+                      double *llk_out)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0 || !idx || !llk_out || ctop <= 0 || ctop > 64) { gmmiv_set_error("use_top: bad argument"); return GMMIV_ERR_ARG; }
+    if (mode == GMMIV_TOP_COMPLETE && !nontop_llk) { gmmiv_set_error("use_top: COMPLETE mode needs nontop_llk"); return GMMIV_ERR_ARG; }
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    DevIn<int32_t> i_idx;
+    DevIn<double> i_n;
+    DevOut<double> o_llk;
+    if ((rc = i_idx.init(c, WS_T0, idx, (size_t)T * ctop))) return rc;
+    if ((rc = i_n.init(c, WS_T1, nontop_llk, (size_t)T))) return rc;
+    if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T, false))) return rc;
+    c->t_begin("k_topc_use");
+    GCHK(gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, ctop, i_idx.d, i_n.d,
+                       mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d));
+    c->t_end();
+    return o_llk.finish();
+}
+
+// ---- EM ----------------------------------------------------------------------------------
+size_t gmmiv_em_acc_len(int C, int D) { return (size_t)C * (1 + 2 * (size_t)D) + 2; }
+
+// frame segments [0,T) -> nseg pieces aligned to the 64-frame tile; device array in WS_SEG
+static int make_chunks(gmmiv_ctx *c, int64_t T, int nseg, long **dev)
+{
+    std::vector<long> h(nseg + 1);
+    const int64_t per = ((T + nseg - 1) / nseg + 63) / 64 * 64;
+    for (int i = 0; i <= nseg; ++i) { int64_t b = (int64_t)i * per; h[i] = (long)(b < T ? b : T); }
+    void *buf;
+    int rc = c->scratch(WS_SEG, (nseg + 1) * sizeof(long), &buf);
+    if (rc) return rc;
+    GCHK(hipMemcpyAsync(buf, h.data(), (nseg + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    GCHK(hipStreamSynchronize(c->stream)); // h is a stack-lifetime vector
+    *dev = (long *)buf;
+    return GMMIV_OK;
+}
+
+int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, double weight,
+                        double *acc)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0 || !acc || !(weight > 0.0)) { gmmiv_set_error("em_accumulate: bad argument (T >= 0, weight > 0, acc != NULL)"); return GMMIV_ERR_ARG; }
+    const size_t nacc = gmmiv_em_acc_len(g->C, g->D);
+    DevOut<double> o;
+    if ((rc = o.init(c, WS_T0, acc, nacc, true))) return rc;
+    if (T == 0) return o.finish();
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    double *lse;
+    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
+    void *small;
+    if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
+    // sum_t weight * log lk_t  and  sum_t weight
+    GCHK(gmmk_llk_finalize(c->stream, lse, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
+                           o.d + nacc - 2));
+    GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
+    // frame chunks: enough workgroups to fill the chip about twice, each >= 4096 frames
+    const int ngrp = (g->nct + 7) / 8;
+    int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (2 * c->n_cu + ngrp - 1) / ngrp;
+    nseg = (nseg + 7) / 8 * 8;
+    const int64_t cap = (T + 4095) / 4096;
+    if (nseg > cap) nseg = (int)cap;
+    if (nseg < 1) nseg = 1;
+    long *seg;
+    if ((rc = make_chunks(c, T, nseg, &seg))) return rc;
+    const int RL = gmmk_rl_for_ks(g->KS);
+    const size_t Cp = (size_t)g->nct * 16;
+    void *part;
+    if ((rc = c->scratch(WS_PART, (size_t)nseg * Cp * 2 * RL * sizeof(double), &part))) return rc;
+    c->t_begin("k_stats_mfma");
+    GCHK(gmmk_stats(c->stream, g->KS, 1, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, -log(weight), seg,
+                    nseg, (double *)part, nullptr, 0));
+    c->t_end();
+    GCHK(gmmk_em_reduce(c->stream, (const double *)part, nseg, g->C, (int)Cp, g->D, g->KS, o.d));
+    return o.finish();
+}
+
+int gmmiv_em_get(gmmiv_ctx *c, int C, int D, const double *acc, const double *prev_mean, const double *prev_cov,
+                 double *w, double *mean, double *cov)
+{
+    if (!c || !acc || !prev_mean || !prev_cov || !w || !mean || !cov || C <= 0 || D <= 0) { gmmiv_set_error("em_get: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t CD = (size_t)C * D;
+    DevIn<double> i_acc, i_pm, i_pc;
+    DevOut<double> o_w, o_m, o_c;
+    int rc;
+    if ((rc = i_acc.init(c, WS_T0, acc, gmmiv_em_acc_len(C, D)))) return rc;
+    if ((rc = i_pm.init(c, WS_T1, prev_mean, CD))) return rc;
+    if ((rc = i_pc.init(c, WS_T2, prev_cov, CD))) return rc;
+    if ((rc = o_w.init(c, WS_T3, w, C, false))) return rc;
+    if ((rc = o_m.init(c, WS_T4, mean, CD, false))) return rc;
+    if ((rc = o_c.init(c, WS_T5, cov, CD, false))) return rc;
+    GCHK(gmmk_em_get(c->stream, C, D, i_acc.d, i_pm.d, i_pc.d, o_w.d, o_m.d, o_c.d));
+    if ((rc = o_w.finish())) return rc;
+    if ((rc = o_m.finish())) return rc;
+    return o_c.finish();
+}
+
+// ---- Baum-Welch N / F ----------------------------------------------------------------------
+int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx,
+                   const int64_t *utt_begin, int64_t U, double *N, double *F)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0 || U < 0 || !utt_begin || !N || !F) { gmmiv_set_error("tv_stats: bad argument"); return GMMIV_ERR_ARG; }
+    if (gmmiv_is_device_ptr(utt_begin)) { gmmiv_set_error("tv_stats: utt_begin must be a host array"); return GMMIV_ERR_ARG; }
+    if (U == 0) return GMMIV_OK;
+    if (utt_begin[0] < 0 || utt_begin[U] > T) { gmmiv_set_error("tv_stats: utt_begin out of range"); return GMMIV_ERR_ARG; }
+    for (int64_t u = 0; u < U; ++u)
+        if (utt_begin[u + 1] < utt_begin[u]) { gmmiv_set_error("tv_stats: utt_begin must be non-decreasing"); return GMMIV_ERR_ARG; }
+    if (U > 0x7fffffff / 64) { gmmiv_set_error("tv_stats: too many utterances in one call"); return GMMIV_ERR_UNSUPPORTED; }
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    double *lse;
+    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
+    std::vector<long> h(utt_begin, utt_begin + U + 1);
+    void *seg;
+    if ((rc = c->scratch(WS_SEG, (U + 1) * sizeof(long), &seg))) return rc;
+    GCHK(hipMemcpyAsync(seg, h.data(), (U + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    GCHK(hipStreamSynchronize(c->stream));
+    const size_t SV = (size_t)g->C * g->D;
+    DevOut<double> o_n, o_f;
+    if ((rc = o_n.init(c, WS_T0, N, (size_t)U * g->C, false))) return rc;
+    if ((rc = o_f.init(c, WS_T1, F, (size_t)U * SV, false))) return rc;
+    // every (u, c < C) row is written by exactly one wave (zeros for an empty utterance)
+    c->t_begin("k_stats_mfma");
+    GCHK(gmmk_stats(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, 0.0,
+                    (const long *)seg, (int)U, o_n.d, o_f.d, 1));
+    c->t_end();
+    if ((rc = o_n.finish())) return rc;
+    return o_f.finish();
+}
+
+} // extern "C"

@@ -1,0 +1,488 @@
+// capi_tv.hip -- C ABI (include/gmmiv.h): total-variability (i-vector) maths and i-vector scoring.
+#include <math.h>
+
+#include <map>
+
+#include "ctx.h"
+#include "tv_kernels.h"
+
+namespace {
+
+// Small dense host helpers for the O(R^3)-once-per-call pieces (min-divergence factor, PLDA K_n).
+bool host_cholesky_upper(int n, const std::vector<double> &a, std::vector<double> &ch)
+{
+    ch.assign((size_t)n * n, 0.0); // R = Ch^T Ch, Ch upper
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            double s = a[(size_t)i * n + j];
+            for (int k = 0; k < i; ++k) s -= ch[(size_t)k * n + i] * ch[(size_t)k * n + j];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                ch[(size_t)i * n + i] = sqrt(s);
+            } else
+                ch[(size_t)i * n + j] = s / ch[(size_t)i * n + i];
+        }
+    return true;
+}
+
+// SPD inverse + log det through the Cholesky factor (host)
+bool host_spd_inverse(int n, const std::vector<double> &a, std::vector<double> &inv, double *logdet)
+{
+    std::vector<double> u;
+    if (!host_cholesky_upper(n, a, u)) return false;
+    double ld = 0.0;
+    for (int i = 0; i < n; ++i) ld += log(u[(size_t)i * n + i]);
+    if (logdet) *logdet = 2.0 * ld;
+    // Ui = U^-1 (upper), then A^-1 = Ui Ui^T
+    std::vector<double> ui((size_t)n * n, 0.0);
+    for (int c = 0; c < n; ++c) {
+        ui[(size_t)c * n + c] = 1.0 / u[(size_t)c * n + c];
+        for (int i = c - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int k = i + 1; k <= c; ++k) s += u[(size_t)i * n + k] * ui[(size_t)k * n + c];
+            ui[(size_t)i * n + c] = -s / u[(size_t)i * n + i];
+        }
+    }
+    inv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            double s = 0.0;
+            for (int k = j; k < n; ++k) s += ui[(size_t)i * n + k] * ui[(size_t)j * n + k];
+            inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = s;
+        }
+    return true;
+}
+
+int check_status(gmmiv_ctx *c, int *dstatus, int nb, const char *what)
+{
+    std::vector<int> h(nb);
+    GCHK(hipMemcpyAsync(h.data(), dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    GCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nb; ++i)
+        if (h[i]) { gmmiv_set_error("%s: matrix %d of the batch is not positive definite", what, i); return GMMIV_ERR_NUMERIC; }
+    return GMMIV_OK;
+}
+
+// Scratch set of the batched SPD inverse for nb matrices of order n
+struct InvWs {
+    double *full = nullptr, *inv = nullptr, *X = nullptr, *invd = nullptr, *panel = nullptr;
+    int *status = nullptr;
+    int init(gmmiv_ctx *c, int n, int nb)
+    {
+        const size_t nn = (size_t)n * n;
+        const int nblk = (n + 31) / 32;
+        void *p;
+        int rc;
+        if ((rc = c->scratch(WS_T4, nb * nn * 8, &p))) return rc; full = (double *)p;
+        if ((rc = c->scratch(WS_T5, nb * nn * 8, &p))) return rc; inv = (double *)p;
+        if ((rc = c->scratch(WS_T6, nb * nn * 8, &p))) return rc; X = (double *)p;
+        if ((rc = c->scratch(WS_T7, (size_t)nb * nblk * 1024 * 8, &p))) return rc; invd = (double *)p;
+        if ((rc = c->scratch(WS_T8, (size_t)nb * n * 32 * 8, &p))) return rc; panel = (double *)p;
+        if ((rc = c->scratch(WS_SMALL, (size_t)nb * sizeof(int) + 64, &p))) return rc; status = (int *)p;
+        return GMMIV_OK;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+size_t gmmiv_tv_packed_len(int R) { return (size_t)R * (R + 1) / 2; }
+
+int gmmiv_tv_subtract_m(gmmiv_ctx *c, int64_t U, int C, int D, const double *N, double *F, const double *means)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || !N || !F || !means) { gmmiv_set_error("tv_subtract_m: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_m;
+    DevOut<double> o_f;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C))) return rc;
+    if ((rc = i_m.init(c, WS_T1, means, SV))) return rc;
+    if ((rc = o_f.init(c, WS_T2, F, (size_t)U * SV, true))) return rc;
+    c->t_begin("k_subtract_m");
+    GCHK(tvk_subtract_m(c->stream, U, C, D, i_n.d, o_f.d, i_m.d));
+    c->t_end();
+    return o_f.finish();
+}
+
+int gmmiv_tv_tett(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *invvar, double *tett_packed)
+{
+    if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !invvar || !tett_packed) { gmmiv_set_error("tv_tett: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D, P = gmmiv_tv_packed_len(R), RR = (size_t)R * R;
+    DevIn<double> i_t, i_iv;
+    DevOut<double> o;
+    int rc;
+    if ((rc = i_t.init(c, WS_T0, Tm, (size_t)R * SV))) return rc;
+    if ((rc = i_iv.init(c, WS_T1, invvar, SV))) return rc;
+    if ((rc = o.init(c, WS_T2, tett_packed, (size_t)C * P, false))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_T3, (size_t)R * SV * 8, &p))) return rc;
+    double *Tiv = (double *)p;
+    GCHK(tvk_scale_cols(c->stream, R, (long)SV, i_t.d, i_iv.d, Tiv));
+    const int CH = 128;
+    if ((rc = c->scratch(WS_T4, (size_t)CH * RR * 8, &p))) return rc;
+    double *G = (double *)p;
+    c->t_begin("k_dgemm(tett)");
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        const int nb = (C - c0) < CH ? (C - c0) : CH;
+        GCHK(tvk_dgemm(c->stream, false, true, R, R, D, 1.0, i_t.d + (size_t)c0 * D, (long)SV, D, Tiv + (size_t)c0 * D, (long)SV, D,
+                       0.0, G, R, (long)RR, nb));
+        GCHK(tvk_pack_sym(c->stream, R, nb, G, (long)RR, nullptr, o.d + (size_t)c0 * P, (long)P));
+    }
+    c->t_end();
+    return o.finish();
+}
+
+// shared body of estimateW / estimateAandC
+static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *N, const double *F, const double *Tm,
+                    const double *invvar, const double *tett, double *W, double *A_packed, double *Cmx, double *Rm,
+                    double *r, double *meanW, bool accumulate)
+{
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D, P = gmmiv_tv_packed_len(R), RR = (size_t)R * R;
+    int rc;
+    DevIn<double> i_n, i_f, i_t, i_iv, i_te;
+    DevOut<double> o_w;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C))) return rc;
+    if ((rc = i_f.init(c, WS_T1, F, (size_t)U * SV))) return rc;
+    if ((rc = i_t.init(c, WS_T2, Tm, (size_t)R * SV))) return rc;
+    if ((rc = i_iv.init(c, WS_PART, invvar, SV))) return rc;
+    if ((rc = i_te.init(c, WS_X, tett, (size_t)C * P))) return rc;
+    if ((rc = o_w.init(c, WS_LSE, W, (size_t)U * R, false))) return rc;
+    // accumulators: keep device-side copies when the caller passed host arrays
+    void *p;
+    double *d_a = nullptr, *d_c = nullptr, *d_rm = nullptr, *d_r = nullptr, *d_mw = nullptr, *d_rp = nullptr;
+    std::vector<void *> owned;
+    auto dev_acc = [&](double *user, size_t n, double **dev) -> int {
+        if (gmmiv_is_device_ptr(user)) { *dev = user; return GMMIV_OK; }
+        GCHK(hipMalloc(&p, n * 8));
+        owned.push_back(p);
+        GCHK(hipMemcpyAsync(p, user, n * 8, hipMemcpyHostToDevice, c->stream));
+        *dev = (double *)p;
+        return GMMIV_OK;
+    };
+    auto free_owned = [&]() { (void)hipStreamSynchronize(c->stream); for (void *q : owned) (void)hipFree(q); owned.clear(); };
+    if (accumulate) {
+        if ((rc = dev_acc(A_packed, (size_t)C * P, &d_a)) || (rc = dev_acc(Cmx, (size_t)R * SV, &d_c)) ||
+            (rc = dev_acc(Rm, RR, &d_rm)) || (rc = dev_acc(r, R, &d_r)) || (rc = dev_acc(meanW, R, &d_mw))) { free_owned(); return rc; }
+        GCHK(hipMalloc(&p, P * 8));
+        owned.push_back(p);
+        d_rp = (double *)p;
+        GCHK(hipMemsetAsync(d_rp, 0, P * 8, c->stream));
+    }
+    GCHK(hipMalloc(&p, (size_t)R * SV * 8));
+    owned.push_back(p);
+    double *Tiv = (double *)p;
+    GCHK(tvk_scale_cols(c->stream, R, (long)SV, i_t.d, i_iv.d, Tiv));
+
+    int BC = 256;
+    if (U < BC) BC = (int)U;
+    GCHK(hipMalloc(&p, (size_t)BC * P * 8));
+    owned.push_back(p);
+    double *Lp = (double *)p;
+    GCHK(hipMalloc(&p, (size_t)BC * R * 8));
+    owned.push_back(p);
+    double *aux = (double *)p;
+    InvWs ws;
+    if ((rc = ws.init(c, R, BC))) { free_owned(); return rc; }
+
+    for (int64_t u0 = 0; u0 < U; u0 += BC) {
+        const int nb = (int)((U - u0) < BC ? (U - u0) : BC);
+        const double *Nc = i_n.d + (size_t)u0 * C;
+        const double *Fc = i_f.d + (size_t)u0 * SV;
+        double *Wc = o_w.d + (size_t)u0 * R;
+        GCHK(hipMemsetAsync(ws.status, 0, nb * sizeof(int), c->stream));
+        // L (packed) = N * TETt ; + I on unpack
+        c->t_begin("k_dgemm(L)");
+        GCHK(tvk_dgemm(c->stream, false, false, nb, (int)P, C, 1.0, Nc, C, 0, i_te.d, (long)P, 0, 0.0, Lp, (long)P, 0, 1));
+        c->t_end();
+        GCHK(tvk_unpack_sym(c->stream, R, nb, Lp, (long)P, ws.full, 1.0));
+        GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+        // aux = F Sigma^-1 T^T ; w = L^-1 aux
+        GCHK(tvk_dgemm(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, 0, Tiv, (long)SV, 0, 0.0, aux, R, 0, 1));
+        GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
+        if ((rc = check_status(c, ws.status, nb, "tv: L"))) { free_owned(); return rc; }
+        if (accumulate) {
+            // E = L^-1 + w w^T (packed, reusing Lp) ; A += N^T E ; Cmx += W^T F ; R += sum E ; r, meanW += sum w
+            GCHK(tvk_pack_sym(c->stream, R, nb, ws.inv, (long)RR, Wc, Lp, (long)P));
+            GCHK(tvk_dgemm(c->stream, true, false, C, (int)P, nb, 1.0, Nc, C, 0, Lp, (long)P, 0, 1.0, d_a, (long)P, 0, 1));
+            GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, nb, 1.0, Wc, R, 0, Fc, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
+            GCHK(tvk_batch_sum(c->stream, (long)P, nb, Lp, (long)P, d_rp));
+            GCHK(tvk_batch_sum(c->stream, R, nb, Wc, R, d_r));
+            GCHK(tvk_batch_sum(c->stream, R, nb, Wc, R, d_mw));
+        }
+    }
+    if (accumulate) {
+        GCHK(tvk_add_unpacked(c->stream, R, d_rp, d_rm));
+        auto back = [&](double *user, double *dev, size_t n) -> int {
+            if (dev != user) GCHK(hipMemcpyAsync(user, dev, n * 8, hipMemcpyDeviceToHost, c->stream));
+            return GMMIV_OK;
+        };
+        if ((rc = back(A_packed, d_a, (size_t)C * P)) || (rc = back(Cmx, d_c, (size_t)R * SV)) || (rc = back(Rm, d_rm, RR)) ||
+            (rc = back(r, d_r, R)) || (rc = back(meanW, d_mw, R))) { free_owned(); return rc; }
+    }
+    rc = o_w.finish();
+    free_owned();
+    return rc;
+}
+
+int gmmiv_tv_estimate_w(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *N, const double *F, const double *Tm,
+                        const double *invvar, const double *tett_packed, double *W)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !Tm || !invvar || !tett_packed || !W) { gmmiv_set_error("tv_estimate_w: bad argument"); return GMMIV_ERR_ARG; }
+    if (U == 0) return GMMIV_OK;
+    return tv_estep(c, U, C, D, R, N, F, Tm, invvar, tett_packed, W, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+}
+
+int gmmiv_tv_estimate_a_and_c(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *N, const double *F,
+                              const double *Tm, const double *invvar, const double *tett_packed, double *W,
+                              double *A_packed, double *Cmx, double *Rm, double *r, double *meanW)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !Tm || !invvar || !tett_packed || !W || !A_packed || !Cmx || !Rm || !r || !meanW) { gmmiv_set_error("tv_estimate_a_and_c: bad argument"); return GMMIV_ERR_ARG; }
+    if (U == 0) return GMMIV_OK;
+    return tv_estep(c, U, C, D, R, N, F, Tm, invvar, tett_packed, W, A_packed, Cmx, Rm, r, meanW, true);
+}
+
+int gmmiv_tv_update_t(gmmiv_ctx *c, int C, int D, int R, const double *A_packed, const double *Cmx, double *Tm)
+{
+    if (!c || C <= 0 || D <= 0 || R <= 0 || !A_packed || !Cmx || !Tm) { gmmiv_set_error("tv_update_t: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D, P = gmmiv_tv_packed_len(R), RR = (size_t)R * R;
+    int rc;
+    DevIn<double> i_a, i_c;
+    DevOut<double> o_t;
+    if ((rc = i_a.init(c, WS_T0, A_packed, (size_t)C * P))) return rc;
+    if ((rc = i_c.init(c, WS_T1, Cmx, (size_t)R * SV))) return rc;
+    if ((rc = o_t.init(c, WS_T2, Tm, (size_t)R * SV, false))) return rc;
+    int CH = 128;
+    if (C < CH) CH = C;
+    InvWs ws;
+    if ((rc = ws.init(c, R, CH))) return rc;
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        const int nb = (C - c0) < CH ? (C - c0) : CH;
+        GCHK(hipMemsetAsync(ws.status, 0, nb * sizeof(int), c->stream));
+        GCHK(tvk_unpack_sym(c->stream, R, nb, i_a.d + (size_t)c0 * P, (long)P, ws.full, 0.0));
+        GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+        // T_c = A_c^-1 Cmx_c
+        GCHK(tvk_dgemm(c->stream, false, false, R, D, R, 1.0, ws.inv, R, (long)RR, i_c.d + (size_t)c0 * D, (long)SV, D, 0.0,
+                       o_t.d + (size_t)c0 * D, (long)SV, D, nb));
+        if ((rc = check_status(c, ws.status, nb, "tv_update_t: A_c"))) return rc;
+    }
+    return o_t.finish();
+}
+
+int gmmiv_tv_min_divergence(gmmiv_ctx *c, int C, int D, int R, double n_sessions, double *Rm, double *r,
+                            const double *meanW, double *ubm_means, double *Tm)
+{
+    if (!c || C <= 0 || D <= 0 || R <= 0 || !(n_sessions > 0) || !Rm || !r || !meanW || !ubm_means || !Tm) { gmmiv_set_error("tv_min_divergence: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D, RR = (size_t)R * R;
+    int rc;
+    DevOut<double> o_rm, o_r, o_mean, o_t;
+    DevIn<double> i_mw;
+    if ((rc = o_rm.init(c, WS_T0, Rm, RR, true))) return rc;
+    if ((rc = o_r.init(c, WS_T1, r, R, true))) return rc;
+    if ((rc = i_mw.init(c, WS_T2, meanW, R))) return rc;
+    if ((rc = o_mean.init(c, WS_T3, ubm_means, SV, true))) return rc;
+    if ((rc = o_t.init(c, WS_T4, Tm, (size_t)R * SV, true))) return rc;
+    // R x R normalisation + Cholesky on the host (O(R^3) once per EM iteration)
+    std::vector<double> hR(RR), hr(R), ch;
+    GCHK(hipMemcpyAsync(hR.data(), o_rm.d, RR * 8, hipMemcpyDeviceToHost, c->stream));
+    GCHK(hipMemcpyAsync(hr.data(), o_r.d, R * 8, hipMemcpyDeviceToHost, c->stream));
+    GCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < R; ++i) hr[i] /= n_sessions;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < R; ++j) hR[(size_t)i * R + j] = hR[(size_t)i * R + j] / n_sessions - hr[i] * hr[j];
+    if (!host_cholesky_upper(R, hR, ch)) { gmmiv_set_error("tv_min_divergence: R is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    GCHK(hipMemcpyAsync(o_rm.d, hR.data(), RR * 8, hipMemcpyHostToDevice, c->stream));
+    GCHK(hipMemcpyAsync(o_r.d, hr.data(), R * 8, hipMemcpyHostToDevice, c->stream));
+    void *p;
+    if ((rc = c->scratch(WS_T5, RR * 8, &p))) return rc;
+    double *dCh = (double *)p;
+    GCHK(hipMemcpyAsync(dCh, ch.data(), RR * 8, hipMemcpyHostToDevice, c->stream));
+    // mean += T^T meanW (old T), then T <- Ch T
+    GCHK(tvk_vecmat_add(c->stream, R, (long)SV, i_mw.d, o_t.d, o_mean.d));
+    if ((rc = c->scratch(WS_T6, (size_t)R * SV * 8, &p))) return rc;
+    double *Tn = (double *)p;
+    GCHK(tvk_dgemm(c->stream, false, false, R, (int)SV, R, 1.0, dCh, R, 0, o_t.d, (long)SV, 0, 0.0, Tn, (long)SV, 0, 1));
+    GCHK(hipMemcpyAsync(o_t.d, Tn, (size_t)R * SV * 8, hipMemcpyDeviceToDevice, c->stream));
+    GCHK(hipStreamSynchronize(c->stream)); // host vectors above go out of scope
+    if ((rc = o_rm.finish()) || (rc = o_r.finish()) || (rc = o_mean.finish())) return rc;
+    return o_t.finish();
+}
+
+// ---- scoring -----------------------------------------------------------------------------
+struct ScoreArgs {
+    DevIn<double> m, s;
+    DevOut<double> sc;
+    double *qm = nullptr, *qs = nullptr;
+    int init(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs, double *scores)
+    {
+        int rc;
+        if ((rc = m.init(c, WS_T0, models, (size_t)dim * M))) return rc;
+        if ((rc = s.init(c, WS_T1, segs, (size_t)dim * S))) return rc;
+        if ((rc = sc.init(c, WS_T2, scores, (size_t)M * S, false))) return rc;
+        void *p;
+        if ((rc = c->scratch(WS_T3, (size_t)(M + S) * 8, &p))) return rc;
+        qm = (double *)p;
+        qs = qm + M;
+        return GMMIV_OK;
+    }
+};
+
+static int score_check(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const void *a, const void *b, const void *o, const char *what)
+{
+    if (!c || dim <= 0 || M < 0 || S < 0 || !a || !b || !o) { gmmiv_set_error("%s: bad argument", what); return GMMIV_ERR_ARG; }
+    if (M > 0x7fffffff || S > 0x7fffffff) { gmmiv_set_error("%s: too many vectors", what); return GMMIV_ERR_UNSUPPORTED; }
+    GCHK(hipSetDevice(c->device));
+    return GMMIV_OK;
+}
+
+int gmmiv_score_cosine(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs, double *scores)
+{
+    int rc = score_check(c, dim, M, S, models, segs, scores, "score_cosine");
+    if (rc) return rc;
+    if (M == 0 || S == 0) return GMMIV_OK;
+    ScoreArgs a;
+    if ((rc = a.init(c, dim, M, S, models, segs, scores))) return rc;
+    GCHK(tvk_coldot(c->stream, dim, M, a.m.d, a.m.d, a.qm));
+    GCHK(tvk_coldot(c->stream, dim, S, a.s.d, a.s.d, a.qs));
+    c->t_begin("k_dgemm(score)");
+    GCHK(tvk_dgemm(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, M, 0, a.s.d, S, 0, 0.0, a.sc.d, S, 0, 1));
+    c->t_end();
+    GCHK(tvk_score_cosnorm(c->stream, M, S, a.sc.d, a.qm, a.qs));
+    return a.sc.finish();
+}
+
+// scores = Mt (Q + Q^T) S * half_cross + bm * diag(Mt Qm M) + bs * diag(St Qs S)
+static int quad_score(gmmiv_ctx *c, ScoreArgs &a, int dim, int64_t M, int64_t S, const double *Qcross, double ccross,
+                      const double *Qm, double bm, const double *Qs, double bs, double cst)
+{
+    int rc;
+    void *p;
+    const size_t nn = (size_t)dim * dim;
+    if ((rc = c->scratch(WS_T4, nn * 8, &p))) return rc;
+    double *Qsym = (double *)p;
+    const size_t mx = (size_t)dim * (M > S ? M : S);
+    if ((rc = c->scratch(WS_T5, mx * 8, &p))) return rc;
+    double *Y = (double *)p;
+    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)M, dim, 1.0, Qm, dim, 0, a.m.d, M, 0, 0.0, Y, M, 0, 1));
+    GCHK(tvk_coldot(c->stream, dim, M, a.m.d, Y, a.qm));
+    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qs, dim, 0, a.s.d, S, 0, 0.0, Y, S, 0, 1));
+    GCHK(tvk_coldot(c->stream, dim, S, a.s.d, Y, a.qs));
+    GCHK(tvk_add_transpose(c->stream, dim, Qcross, Qcross, Qsym));
+    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qsym, dim, 0, a.s.d, S, 0, 0.0, Y, S, 0, 1));
+    c->t_begin("k_dgemm(score)");
+    GCHK(tvk_dgemm(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, M, 0, Y, S, 0, 0.0, a.sc.d, S, 0, 1));
+    c->t_end();
+    GCHK(tvk_score_combine(c->stream, M, S, a.sc.d, ccross, a.qm, bm, a.qs, bs, cst));
+    return GMMIV_OK;
+}
+
+int gmmiv_score_mahalanobis(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs,
+                            const double *Mah, double *scores)
+{
+    int rc = score_check(c, dim, M, S, models, segs, scores, "score_mahalanobis");
+    if (rc) return rc;
+    if (!Mah) { gmmiv_set_error("score_mahalanobis: Mah == NULL"); return GMMIV_ERR_ARG; }
+    if (M == 0 || S == 0) return GMMIV_OK;
+    ScoreArgs a;
+    if ((rc = a.init(c, dim, M, S, models, segs, scores))) return rc;
+    DevIn<double> q;
+    if ((rc = q.init(c, WS_T6, Mah, (size_t)dim * dim))) return rc;
+    // -1/2 (m-s)' Q (m-s) = -1/2 m'Qm - 1/2 s'Qs + 1/2 m'(Q+Q')s
+    if ((rc = quad_score(c, a, dim, M, S, q.d, 0.5, q.d, -0.5, q.d, -0.5, 0.0))) return rc;
+    return a.sc.finish();
+}
+
+int gmmiv_score_twocov(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs,
+                       const double *G, const double *H, double *scores)
+{
+    int rc = score_check(c, dim, M, S, models, segs, scores, "score_twocov");
+    if (rc) return rc;
+    if (!G || !H) { gmmiv_set_error("score_twocov: G/H == NULL"); return GMMIV_ERR_ARG; }
+    if (M == 0 || S == 0) return GMMIV_OK;
+    ScoreArgs a;
+    if ((rc = a.init(c, dim, M, S, models, segs, scores))) return rc;
+    DevIn<double> g, h;
+    const size_t nn = (size_t)dim * dim;
+    if ((rc = g.init(c, WS_T6, G, nn))) return rc;
+    if ((rc = h.init(c, WS_T7, H, nn))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_T8, nn * 8, &p))) return rc;
+    double *GmH = (double *)p; // G - H: (m+s)'G(m+s) - m'Hm - s'Hs = m'(G-H)m + s'(G-H)s + m'(G+G')s
+    GCHK(tvk_axpby(c->stream, (long)nn, 1.0, g.d, -1.0, h.d, GmH));
+    if ((rc = quad_score(c, a, dim, M, S, g.d, 1.0, GmH, 1.0, GmH, 1.0, 0.0))) return rc;
+    return a.sc.finish();
+}
+
+int gmmiv_score_plda(gmmiv_ctx *c, int rf, int64_t M, int64_t S, const double *models_sum, const int64_t *nsess,
+                     const double *segs, const double *FTJF, double *scores)
+{
+    int rc = score_check(c, rf, M, S, models_sum, segs, scores, "score_plda");
+    if (rc) return rc;
+    if (!nsess || !FTJF) { gmmiv_set_error("score_plda: nsess/FTJF == NULL"); return GMMIV_ERR_ARG; }
+    if (gmmiv_is_device_ptr(nsess)) { gmmiv_set_error("score_plda: nsess must be a host array"); return GMMIV_ERR_ARG; }
+    if (M == 0 || S == 0) return GMMIV_OK;
+    ScoreArgs a;
+    if ((rc = a.init(c, rf, M, S, models_sum, segs, scores))) return rc;
+    const size_t nn = (size_t)rf * rf;
+    std::vector<double> hF(nn);
+    GCHK(hipMemcpy(hF.data(), FTJF, nn * 8, gmmiv_is_device_ptr(FTJF) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+    // K_n = (n FTJF + I)^-1 and alpha_n = log det K_n on the host, cached per n
+    struct KN { std::vector<double> K; double alpha; };
+    std::map<int64_t, KN> cache;
+    auto getK = [&](int64_t n) -> const KN * {
+        auto it = cache.find(n);
+        if (it != cache.end()) return &it->second;
+        std::vector<double> t(nn);
+        for (size_t e = 0; e < nn; ++e) t[e] = (double)n * hF[e];
+        for (int i = 0; i < rf; ++i) t[(size_t)i * rf + i] += 1.0;
+        KN kn;
+        double ld;
+        if (!host_spd_inverse(rf, t, kn.K, &ld)) return nullptr;
+        kn.alpha = -ld; // log det K = -log det (nFTJF + I)
+        return &cache.emplace(n, std::move(kn)).first->second;
+    };
+    const KN *K1 = getK(1);
+    if (!K1) { gmmiv_set_error("score_plda: FTJF + I is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    void *p;
+    if ((rc = c->scratch(WS_T6, 3 * nn * 8, &p))) return rc;
+    double *dQc = (double *)p, *dQm = dQc + nn, *dQs = dQm + nn;
+    // runs of consecutive models with the same session count (PldaTools.cpp:4186-4250)
+    for (int64_t m0 = 0; m0 < M;) {
+        int64_t m1 = m0;
+        const int64_t L = nsess[m0];
+        while (m1 < M && nsess[m1] == L) ++m1;
+        if (L < 1) { gmmiv_set_error("score_plda: nsess[%ld] < 1", (long)m0); return GMMIV_ERR_ARG; }
+        const KN *KL = getK(L), *KL1 = getK(L + 1);
+        if (!KL || !KL1) { gmmiv_set_error("score_plda: K_n not positive definite"); return GMMIV_ERR_NUMERIC; }
+        // score = 1/2[(s+m)'K_{L+1}(s+m) - m'K_L m - s'K_1 s] + (a_{L+1} - a_L - a_1)/2
+        //       = 1/2 m'(K_{L+1}-K_L)m + 1/2 s'(K_{L+1}-K_1)s + 1/2 m'(K_{L+1}+K_{L+1}')s + cst
+        std::vector<double> qm(nn), qs(nn);
+        for (size_t e = 0; e < nn; ++e) { qm[e] = KL1->K[e] - KL->K[e]; qs[e] = KL1->K[e] - K1->K[e]; }
+        GCHK(hipMemcpyAsync(dQc, KL1->K.data(), nn * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipMemcpyAsync(dQm, qm.data(), nn * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipMemcpyAsync(dQs, qs.data(), nn * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        const double cst = (KL1->alpha - KL->alpha - K1->alpha) / 2.0;
+        // operate on the column range [m0, m1) of models (ld = M) and the row range of scores
+        ScoreArgs sub = a;
+        const int64_t Mr = m1 - m0;
+        // gather the run's columns into a compact [rf x Mr] block (keeps the GEMM helpers simple)
+        void *q;
+        if ((rc = c->scratch(WS_T7, (size_t)rf * Mr * 8, &q))) return rc;
+        GCHK(hipMemcpy2DAsync(q, Mr * 8, a.m.d + m0, M * 8, Mr * 8, rf, hipMemcpyDeviceToDevice, c->stream));
+        sub.m.d = (const double *)q;
+        sub.sc.d = a.sc.d + (size_t)m0 * S;
+        sub.qm = a.qm + m0;
+        if ((rc = quad_score(c, sub, rf, Mr, S, dQc, 0.5, dQm, 0.5, dQs, 0.5, cst))) return rc;
+        GCHK(hipStreamSynchronize(c->stream));
+        m0 = m1;
+    }
+    return a.sc.finish();
+}
+
+} // extern "C"

@@ -1,0 +1,124 @@
+// ctx.h -- context, workspace and host/device pointer plumbing behind include/gmmiv.h (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gmmiv.h"
+
+void gmmiv_set_error(const char *fmt, ...);
+
+#define GCHK(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t _e = (hipError_t)(expr);                                                         \
+        if (_e != hipSuccess) {                                                                     \
+            gmmiv_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+            return GMMIV_ERR_HIP;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
+       WS_T9, WS_COUNT };
+
+struct gmmiv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *ws[WS_COUNT] = {};
+    size_t ws_size[WS_COUNT] = {};
+    // options
+    long use_glds = 1;
+    long em_chunks = 0; // 0 = auto
+    long timing = 0;
+    int n_cu = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    const char *ev_name = "";
+
+    // grow-only device scratch; contents are NOT preserved across a growth
+    int scratch(int slot, size_t bytes, void **out)
+    {
+        if (bytes == 0) bytes = 8;
+        if (ws_size[slot] < bytes) {
+            if (ws[slot]) {
+                GCHK(hipStreamSynchronize(stream));
+                GCHK(hipFree(ws[slot]));
+                ws[slot] = nullptr;
+                ws_size[slot] = 0;
+            }
+            size_t want = bytes + bytes / 8;
+            GCHK(hipMalloc(&ws[slot], want));
+            ws_size[slot] = want;
+        }
+        *out = ws[slot];
+        return GMMIV_OK;
+    }
+    void t_begin(const char *name)
+    {
+        if (timing) { (void)hipEventRecord(ev0, stream); ev_name = name; }
+    }
+    void t_end()
+    {
+        if (timing) { (void)hipEventRecord(ev1, stream); ev_valid = true; }
+    }
+};
+
+bool gmmiv_is_device_ptr(const void *p);
+
+// Read-only argument: device view of a host-or-device array (copies host data into a scratch slot).
+template <typename T> struct DevIn {
+    const T *d = nullptr;
+    int init(gmmiv_ctx *c, int slot, const T *p, size_t n)
+    {
+        if (!p || n == 0) { d = p; return GMMIV_OK; }
+        if (gmmiv_is_device_ptr(p)) { d = p; return GMMIV_OK; }
+        void *buf;
+        int rc = c->scratch(slot, n * sizeof(T), &buf);
+        if (rc) return rc;
+        GCHK(hipMemcpyAsync(buf, p, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        d = (const T *)buf;
+        return GMMIV_OK;
+    }
+};
+
+// Output (optionally read-modify-write) argument.
+template <typename T> struct DevOut {
+    T *d = nullptr;
+    T *host = nullptr;
+    size_t n = 0;
+    gmmiv_ctx *c = nullptr;
+    int init(gmmiv_ctx *ctx, int slot, T *p, size_t count, bool load)
+    {
+        c = ctx; n = count;
+        if (!p || count == 0) { d = p; return GMMIV_OK; }
+        if (gmmiv_is_device_ptr(p)) { d = p; return GMMIV_OK; }
+        void *buf;
+        int rc = ctx->scratch(slot, count * sizeof(T), &buf);
+        if (rc) return rc;
+        d = (T *)buf;
+        host = p;
+        if (load) GCHK(hipMemcpyAsync(buf, p, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        return GMMIV_OK;
+    }
+    int finish()
+    {
+        if (host) {
+            GCHK(hipMemcpyAsync(host, d, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+            GCHK(hipStreamSynchronize(c->stream));
+        }
+        return GMMIV_OK;
+    }
+};
+
+struct gmmiv_gmm {
+    gmmiv_ctx *ctx = nullptr;
+    int C = 0, D = 0, KS = 0, nct = 0, Cp64 = 0;
+    double *w = nullptr, *mean = nullptr, *iv = nullptr; // row-major copies
+    double *a = nullptr, *lwc = nullptr;                 // a_c, log(w cst) (padded)
+    double *Pt = nullptr;                                // MFMA-ordered operands
+    double *meanT = nullptr, *ivT = nullptr;             // [D][Cp64]
+};

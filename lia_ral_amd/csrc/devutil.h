@@ -1,0 +1,75 @@
+// devutil.h -- device-side helpers shared by the gfx950 kernels (wave64, fp64 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] * B[4x16], one f64 per lane for A and B.
+//   A: lane l holds A[i = l&15][k = l>>4]      B: lane l holds B[k = l>>4][j = l&15]
+//   C/D: lane l, reg r holds D[row = (l>>4) + 4r][col = l&15]   (f64 layout, NOT the f32 one)
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+#define GMMIV_NEG_BIG (-1.0e300)
+
+// exp(x) for x <= ~700, branch-free, no special cases: arguments below -750 give ~0.
+// n = rint(x log2 e); r = x - n ln2 (Cody-Waite, two steps); exp(r) by a degree-13 Taylor
+// polynomial in Horner form (|r| <= 0.347 -> truncation 4e-18); result scaled with ldexp.
+__device__ __forceinline__ double gexp(double x)
+{
+    x = fmax(x, -750.0);
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;              // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);   // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);  // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);  // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);   // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);  // 1/7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);  // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_f64(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, shfl_xor_f64(v, o));
+    return v;
+}
+
+// XOR swizzle of the column index inside one row of the frame tile held in LDS (row length a
+// multiple of 32 doubles).  g(t) = ((2t) ^ (16 (t&1))) & 31 makes both access patterns of the
+// statistics kernel conflict-free for ds_read_b64 (64 banks x 4 B, two 32-lane groups):
+//   (L) 16 consecutive rows x 2 adjacent columns   (MFMA A operand of the logit GEMM)
+//   (S) 2 consecutive rows x 16 consecutive columns (MFMA B operand of the statistics GEMM)
+__device__ __forceinline__ int xswz(int t) { return ((t << 1) ^ ((t & 1) << 4)) & 31; }
+
+template <typename T> struct feat_load;
+template <> struct feat_load<float> {
+    static __device__ __forceinline__ double get(const void *p, long i) { return (double)((const float *)p)[i]; }
+};
+template <> struct feat_load<double> {
+    static __device__ __forceinline__ double get(const void *p, long i) { return ((const double *)p)[i]; }
+};

@@ -1,0 +1,30 @@
+// gmm_kernels.h -- host-callable launchers of gmm_kernels.hip (internal; the public surface is
+// include/gmmiv.h).  All pointers are device pointers; every function returns a hipError_t value.
+#pragma once
+#include <hip/hip_runtime.h>
+
+int gmmk_ks_for_dim(int D);   // k-steps (of 4 dims) of the compiled instantiation serving D, 0 = unsupported
+int gmmk_rl_for_ks(int KS);   // row length (doubles) of the LDS frame tile / half-width of an EM partial row
+int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, const double *w, const double *mean,
+                    const double *iv, double *a, double *lwc, double *Pt, double *meanT, double *ivT);
+int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
+             double *lse, int use_glds);
+int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, double hi, double *llk_out,
+                      double *partial, double scale_c, double scale_r, double *dst_clamped, double *dst_raw);
+int gmmk_add_scalar(hipStream_t st, double *dst, double v);
+int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
+               int nct, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
+               double *out1, int mode);
+int gmmk_em_reduce(hipStream_t st, const double *part, int nseg, int C, int Cp, int D, int KS, double *acc);
+int gmmk_em_get(hipStream_t st, int C, int D, const double *acc, const double *prev_mean, const double *prev_cov,
+                double *w, double *mean, double *cov);
+int gmmk_topc_frames_per_block(int Cp64, int D);
+int gmmk_topc_determine(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp,
+                        const double *meanT, const double *ivT, const double *lwc, const double *w, int ctop,
+                        int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                        double *nw, double *llk);
+int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
+                  const double *iv, const double *lwc, int ctop, const int *idx, const double *nllk, int complete,
+                  double lo, double hi, double *llk);
+int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, double *partial,
+                       int max_blocks, double *acc);

@@ -1,0 +1,803 @@
+// gmm_kernels.hip -- diagonal-GMM kernels for gfx950 (MI355X): log-likelihood, top-C selection,
+// full-posterior sufficient statistics (EM and Baum-Welch N/F), frame moments.
+//
+// The frame x Gaussian logit
+//     z_tc = log w_c + log cst_c - 1/2 sum_d (x_td - mu_cd)^2 iv_cd
+//          = a_c + sum_d x_td (mu_cd iv_cd) + sum_d x_td^2 (-iv_cd / 2)
+// is a [T x 2D] . [2D x C] contraction; the statistics sum_t g_tc [1 | x_t | x_t^2] are a second
+// one, [C x T] . [T x (1+2D)].  Both run on v_mfma_f64_16x16x4_f64 -- the D-layout of the first
+// (lane = Gaussian column, registers = frame rows) is exactly the A-operand layout of the second,
+// so posteriors never leave registers and the T x C matrix is never materialised.
+// The top-C kernels evaluate the direct form (x-mu)^2 iv on the VALU like the reference does.
+#include "devutil.h"
+#include "gmm_kernels.h"
+
+// -------------------------------------------------------------------------------------------
+// Model packing
+// -------------------------------------------------------------------------------------------
+// a_c = log w_c - D/2 log 2pi + 1/2 sum log iv - 1/2 sum mu^2 iv   (log(w cst) - mu'S^-1mu/2)
+__global__ void k_gmm_const(int C, int Cp, int D, const double *__restrict__ w,
+                            const double *__restrict__ mean, const double *__restrict__ iv,
+                            double *__restrict__ a, double *__restrict__ logwcst)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    if (c >= C) { a[c] = GMMIV_NEG_BIG; logwcst[c] = GMMIV_NEG_BIG; return; }
+    double sl = 0.0, sm = 0.0;
+    for (int d = 0; d < D; ++d) {
+        double v = iv[(size_t)c * D + d], m = mean[(size_t)c * D + d];
+        sl += log(v);
+        sm += m * m * v;
+    }
+    double lw = (w[c] > 0.0) ? log(w[c]) : GMMIV_NEG_BIG;
+    double lc = lw - 0.5 * D * 1.8378770664093454836 + 0.5 * sl; // log(2 pi)
+    lc = fmax(lc, GMMIV_NEG_BIG);
+    logwcst[c] = lc;
+    a[c] = fmax(lc - 0.5 * sm, GMMIV_NEG_BIG);
+}
+
+// Pt[ct][row][lane]: B operands of the logit GEMM in MFMA lane order (lane = 16 q + j:
+// Gaussian c = 16 ct + j, contraction index k = 4 s + q).
+//   rows 0..KS-1      mu iv      (x part)        rows KS..2KS-1   -iv/2   (x^2 part)
+//   row 2KS           a_c replicated over q (accumulator init of the LLK kernel)
+//   row 2KS+1         const step of the statistics kernel: q=0 -> a_c, q=1 -> -1, else 0
+__global__ void k_gmm_pack(int C, int D, int KS, int nct, const double *__restrict__ mean,
+                           const double *__restrict__ iv, const double *__restrict__ a,
+                           double *__restrict__ Pt)
+{
+    const int NR = 2 * KS + 2;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)nct * NR * 64;
+    if (e >= total) return;
+    int lane = e & 63;
+    int row = (e >> 6) % NR;
+    int ct = (e >> 6) / NR;
+    int j = lane & 15, q = lane >> 4;
+    int c = ct * 16 + j;
+    double v = 0.0;
+    if (row < 2 * KS) {
+        int s = row < KS ? row : row - KS;
+        int k = 4 * s + q;
+        if (c < C && k < D) {
+            double ivv = iv[(size_t)c * D + k];
+            v = row < KS ? mean[(size_t)c * D + k] * ivv : -0.5 * ivv;
+        }
+    } else if (row == 2 * KS) {
+        v = c < C ? a[c] : GMMIV_NEG_BIG;
+    } else {
+        v = q == 0 ? (c < C ? a[c] : GMMIV_NEG_BIG) : (q == 1 ? -1.0 : 0.0);
+    }
+    Pt[e] = v;
+}
+
+// transposed copies for the VALU top-C kernel: meanT[d][Cp], ivT[d][Cp] (pads: mean 0, iv 0)
+__global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__ mean,
+                                const double *__restrict__ iv, double *__restrict__ meanT,
+                                double *__restrict__ ivT)
+{
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)D * Cp) return;
+    int c = e % Cp, d = e / Cp;
+    meanT[e] = c < C ? mean[(size_t)c * D + d] : 0.0;
+    ivT[e] = c < C ? iv[(size_t)c * D + d] : 0.0;
+}
+
+// -------------------------------------------------------------------------------------------
+// K1: per-frame log-sum-exp over all Gaussians (MFMA).  One workgroup = 8 waves x 32 frames.
+// Frame operands stay in registers; the packed model streams through a double-buffered LDS
+// tile (2 c-tiles = 32 Gaussians per stage), by LDS-DMA when use_glds.
+// -------------------------------------------------------------------------------------------
+template <int KS, typename XT>
+__global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
+                                                  const double *__restrict__ Pt, int nct,
+                                                  double *__restrict__ lse_out, int use_glds)
+{
+    constexpr int NR = 2 * KS + 2;
+    constexpr int GT = 2;
+    constexpr int TILE_D = GT * NR * 64;       // doubles per LDS stage
+    constexpr int PIECES = TILE_D * 8 / 1024;  // 1 KiB pieces per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *buf0 = (double *)smem;
+    double *buf1 = buf0 + TILE_D;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q = lane >> 4;
+    const long tb = (long)blockIdx.x * 256 + wave * 32;
+
+    double A[2][2 * KS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const long t = tb + h * 16 + i16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + q;
+            double v = 0.0;
+            if (t < T && k < D) v = feat_load<XT>::get(x, t * ldx + k);
+            A[h][s] = v;
+            A[h][KS + s] = v * v;
+        }
+    }
+
+    const int ntiles = nct / GT; // nct is padded to a multiple of GT by the host
+    auto stage = [&](double *dst, int tile) {
+        const char *src = (const char *)(Pt + (size_t)tile * TILE_D);
+        if (use_glds) {
+            for (int p = wave; p < PIECES; p += 8)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void *)((char *)dst + p * 1024), 16, 0, 0);
+        } else {
+            for (int p = wave; p < PIECES; p += 8) {
+                uint4 v = *(const uint4 *)(src + p * 1024 + lane * 16);
+                *(uint4 *)((char *)dst + p * 1024 + lane * 16) = v;
+            }
+        }
+    };
+
+    double m[2][4], sacc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m[h][r] = GMMIV_NEG_BIG; sacc[h][r] = 0.0; }
+
+    stage(buf0, 0);
+    __syncthreads();
+    for (int tl = 0; tl < ntiles; ++tl) {
+        double *cur = (tl & 1) ? buf1 : buf0;
+        double *nxt = (tl & 1) ? buf0 : buf1;
+        if (tl + 1 < ntiles) stage(nxt, tl + 1);
+
+        d4 acc[GT][2];
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const double a = cur[(g * NR + 2 * KS) * 64 + lane];
+            acc[g][0] = (d4){a, a, a, a};
+            acc[g][1] = acc[g][0];
+        }
+#pragma unroll
+        for (int s = 0; s < 2 * KS; ++s) {
+            const double b0 = cur[(0 * NR + s) * 64 + lane];
+            const double b1 = cur[(1 * NR + s) * 64 + lane];
+            acc[0][0] = MFMA_F64(A[0][s], b0, acc[0][0]);
+            acc[1][0] = MFMA_F64(A[0][s], b1, acc[1][0]);
+            acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
+            acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
+        }
+        // online log-sum-exp per (lane, frame row): reference point m moves only when a logit
+        // exceeds it by more than 64 (rare after the first tile), so one exp per logit.
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double z0 = acc[0][h][r], z1 = acc[1][h][r];
+                const double mx = fmax(z0, z1);
+                if (mx > m[h][r] + 64.0) {
+                    sacc[h][r] *= gexp(m[h][r] - mx);
+                    m[h][r] = mx;
+                }
+                sacc[h][r] += gexp(z0 - m[h][r]) + gexp(z1 - m[h][r]);
+            }
+        __syncthreads();
+    }
+    // combine the 16 lanes (Gaussian columns) that share a frame row
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double M = m[h][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) M = fmax(M, shfl_xor_f64(M, o));
+            double sv = sacc[h][r] * gexp(m[h][r] - M);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sv += shfl_xor_f64(sv, o);
+            const long t = tb + h * 16 + q + 4 * r;
+            if (i16 == 0 && t < T) lse_out[t] = M + log(sv);
+        }
+}
+
+// clamp + sums: out[t] = clamp(lse[t]); partial[b] = {sum clamped, sum raw}
+__global__ __launch_bounds__(256) void k_llk_finalize(const double *__restrict__ lse, long T, double lo,
+                                                     double hi, double *__restrict__ llk_out,
+                                                     double *__restrict__ partial)
+{
+    __shared__ double red[2][4];
+    double sc = 0.0, sr = 0.0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
+        const double v = lse[t];
+        const double c = fmin(fmax(v, lo), hi);
+        if (llk_out) llk_out[t] = c;
+        sc += c;
+        sr += v;
+    }
+    sc = wave_sum_f64(sc);
+    sr = wave_sum_f64(sr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = sc; red[1][wave] = sr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// dst[i] += scale[i] * sum_b partial[b*n + i]   (single block, deterministic order)
+__global__ void k_reduce_partials(const double *__restrict__ partial, int nb, int n, double s0, double s1,
+                                  double *__restrict__ dst0, double *__restrict__ dst1)
+{
+    if (threadIdx.x < n) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += partial[(size_t)b * n + threadIdx.x];
+        if (threadIdx.x == 0 && dst0) *dst0 += s0 * s;
+        if (threadIdx.x == 1 && dst1) *dst1 += s1 * s;
+    }
+}
+
+__global__ void k_add_scalar(double *dst, double v) { *dst += v; }
+
+// -------------------------------------------------------------------------------------------
+// K2/K3: posterior statistics (MFMA).  Workgroup = 8 waves = 8 c-tiles (128 Gaussians) x one
+// frame segment; frames stream through a double-buffered, XOR-swizzled LDS tile of 64 rows
+// [x_0..x_{D-1}, 0.., 1, lse_t, 0..]; packed model operands live in registers.
+//   mode 0 (EM):  out[seg][c][2 RL] partial sums  (cols: x | x^2 halves; col Dp = occupancy)
+//   mode 1 (TV):  N[seg][c], F[seg][c][D] written directly
+// -------------------------------------------------------------------------------------------
+template <int KS, bool SQ, typename XT>
+__global__ __launch_bounds__(512) void k_stats_mfma(const void *__restrict__ x, long ldx, int D, int C,
+                                                    const double *__restrict__ Pt, int nct,
+                                                    const double *__restrict__ lse, double lse_shift,
+                                                    const long *__restrict__ seg_begin, int nseg, int ngrp,
+                                                    double *__restrict__ out0, double *__restrict__ out1,
+                                                    int mode)
+{
+    constexpr int NR = 2 * KS + 2;
+    constexpr int Dp = 4 * KS;
+    constexpr int RL = ((Dp + 2 + 31) / 32) * 32;
+    constexpr int JT = RL / 16;
+    constexpr int FT = 64;
+    constexpr int NLD = (FT * Dp + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *buf0 = (double *)smem;
+    double *buf1 = buf0 + FT * RL;
+
+    // XCD-aware decode: the 8 consecutive block ids that land on the 8 XCDs carry 8 different
+    // segments, and all Gaussian groups of one segment share an XCD (its L2 then serves the
+    // frame stream to every group).
+    const int b = blockIdx.x;
+    const int seg_lo = b & 7;
+    const int rest = b >> 3;
+    const int grp = rest % ngrp;
+    const int seg = (rest / ngrp) * 8 + seg_lo;
+    if (seg >= nseg) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int ct = grp * 8 + wave;
+    const bool active = ct < nct;
+
+    double Pr[2 * KS + 1];
+#pragma unroll
+    for (int s = 0; s < 2 * KS + 1; ++s) {
+        const int row = s < 2 * KS ? s : 2 * KS + 1;
+        Pr[s] = active ? Pt[((size_t)ct * NR + row) * 64 + lane] : 0.0;
+    }
+
+    const long f0 = seg_begin[seg], f1 = seg_begin[seg + 1];
+    const int ntiles = (int)((f1 - f0 + FT - 1) / FT);
+
+    d4 S[JT], S2[SQ ? JT : 1];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) S[j] = (d4){0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < (SQ ? JT : 1); ++j) S2[j] = (d4){0, 0, 0, 0};
+
+    XT stg[NLD];
+    double stg_lse = 0.0;
+    const int npad = FT * (RL - D); // pad entries per tile (cols D..RL-1)
+    auto load_tile = [&](int tl) {
+        const long fb = f0 + (long)tl * FT;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 512 * i;
+            const int fr = e / D, d = e - fr * D;
+            XT v = 0;
+            if (fr < FT && fb + fr < f1) v = ((const XT *)x)[(fb + fr) * ldx + d];
+            stg[i] = v;
+        }
+        // out-of-range rows get lse = +1e300 -> posterior exp(z - lse) = 0
+        if (tid < FT) stg_lse = (fb + tid < f1) ? lse[fb + tid] + lse_shift : 1.0e300;
+    };
+    auto write_tile = [&](double *dst) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 512 * i;
+            const int fr = e / D, d = e - fr * D;
+            if (fr < FT) dst[fr * RL + (d ^ xswz(fr))] = (double)stg[i];
+        }
+        for (int e = tid; e < npad; e += 512) { // pad columns: 1.0 at Dp, zeros elsewhere
+            const int fr = e / (RL - D), d = D + (e - fr * (RL - D));
+            if (d != Dp + 1) dst[fr * RL + (d ^ xswz(fr))] = (d == Dp) ? 1.0 : 0.0;
+        }
+        if (tid < FT) dst[tid * RL + ((Dp + 1) ^ xswz(tid))] = stg_lse;
+    };
+
+    const int gi = xswz(i16); // swizzle of this lane's A-operand row (rows t0 + i16, t0 % 16 == 0)
+    if (ntiles > 0) {
+        load_tile(0);
+        write_tile(buf0);
+    }
+    __syncthreads();
+    for (int tl = 0; tl < ntiles; ++tl) {
+        const double *cur = (tl & 1) ? buf1 : buf0;
+        double *nxt = (tl & 1) ? buf0 : buf1;
+        if (tl + 1 < ntiles) load_tile(tl + 1);
+        if (active) {
+#pragma unroll 1
+            for (int fs = 0; fs < FT / 16; ++fs) {
+                // logits z_tc - lse_t for 16 frames x 16 Gaussians: two independent MFMA chains
+                d4 zx = (d4){0, 0, 0, 0}, zq = (d4){0, 0, 0, 0};
+                const double *rowp = cur + (fs * 16 + i16) * RL;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double a = rowp[(4 * s + q) ^ gi];
+                    zx = MFMA_F64(a, Pr[s], zx);
+                    zq = MFMA_F64(a * a, Pr[KS + s], zq);
+                }
+                {   // const step: + a_c - lse_t
+                    const double a = rowp[(Dp + q) ^ gi];
+                    zx = MFMA_F64(a, Pr[2 * KS], zx);
+                }
+                double gam[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gam[r] = gexp(zx[r] + zq[r]);
+                // statistics: S[c][j] += sum_t gamma[t][c] * row_t[j]; gamma is already in A layout
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int trow = fs * 16 + 4 * r + q;
+                    const double *rp = cur + trow * RL;
+                    const int gs = xswz(trow);
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) {
+                        const double bv = rp[(16 * j + i16) ^ gs];
+                        S[j] = MFMA_F64(gam[r], bv, S[j]);
+                        if (SQ) S2[j] = MFMA_F64(gam[r], bv * bv, S2[j]);
+                    }
+                }
+            }
+        }
+        if (tl + 1 < ntiles) write_tile(nxt);
+        __syncthreads();
+    }
+    if (!active) return;
+    // D layout: lane holds column j = 16 jt + i16, rows (Gaussians) q + 4 r
+    if (mode == 0) {
+        const size_t Cp = (size_t)nct * 16;
+        double *o = out0 + (size_t)seg * Cp * (2 * RL);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t c = (size_t)ct * 16 + q + 4 * r;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                o[c * (2 * RL) + 16 * j + i16] = S[j][r];
+                if (SQ) o[c * (2 * RL) + RL + 16 * j + i16] = S2[j][r];
+            }
+        }
+    } else {
+        double *N = out0 + (size_t)seg * C;
+        double *F = out1 + (size_t)seg * C * D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = ct * 16 + q + 4 * r;
+            if (c >= C) continue;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int col = 16 * j + i16;
+                if (col < D) F[(size_t)c * D + col] = S[j][r];
+                else if (col == Dp) N[c] = S[j][r];
+            }
+        }
+    }
+}
+
+// acc[occ | sx | sxx] += sum_seg partial[seg][c][...]
+__global__ void k_em_reduce(const double *__restrict__ part, int nseg, int C, int Cp, int D, int Dp, int RL,
+                            double *__restrict__ acc)
+{
+    const long n = (long)C * (1 + 2 * D);
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int c, col;
+    if (e < C) { c = (int)e; col = Dp; }
+    else if (e < (long)C * (1 + D)) { long k = e - C; c = (int)(k / D); col = (int)(k % D); }
+    else { long k = e - (long)C * (1 + D); c = (int)(k / D); col = RL + (int)(k % D); }
+    double s = 0.0;
+    for (int g = 0; g < nseg; ++g) s += part[((size_t)g * Cp + c) * (2 * RL) + col];
+    acc[e] += s;
+}
+
+// MixtureStat::getEM on the device copy of the accumulator
+__global__ void k_em_get(int C, int D, const double *__restrict__ acc, const double *__restrict__ prev_mean,
+                         const double *__restrict__ prev_cov, double *__restrict__ w,
+                         double *__restrict__ mean, double *__restrict__ cov)
+{
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * D) return;
+    const int c = (int)(e / D);
+    const double occ = acc[c];
+    const double count = acc[(size_t)C * (1 + 2 * D) + 1];
+    if (e % D == 0) w[c] = occ / count;
+    if (occ > 0.0) {
+        const double m = acc[C + e] / occ;
+        mean[e] = m;
+        cov[e] = acc[(size_t)C * (1 + D) + e] / occ - m * m;
+    } else {
+        mean[e] = prev_mean[e];
+        cov[e] = prev_cov[e];
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// K1t: DETERMINE_TOP_DISTRIBS (VALU, direct form like DistribGD::computeLK).  One workgroup =
+// FT frames; the 4 waves split the Gaussians for the evaluation, then each wave selects for
+// FT/4 frames with wave-wide arg-max rounds over the logits kept in LDS.
+// -------------------------------------------------------------------------------------------
+template <int FT, typename XT>
+__global__ __launch_bounds__(256) void k_topc_determine(
+    const void *__restrict__ x, long T, long ldx, int D, int C, int Cp, const double *__restrict__ meanT,
+    const double *__restrict__ ivT, const double *__restrict__ lwc, const double *__restrict__ w, int ctop,
+    int complete, double lo, double hi, int *__restrict__ idx_out, double *__restrict__ lk_out,
+    double *__restrict__ nontop_lk, double *__restrict__ nontop_llk, double *__restrict__ nontop_w,
+    double *__restrict__ llk_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *zs = (double *)smem;          // [FT][Cp]
+    double *xs = zs + (size_t)FT * Cp;    // [FT][D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tb = (long)blockIdx.x * FT;
+
+    for (int e = tid; e < FT * D; e += 256) {
+        const int f = e / D, d = e - f * D;
+        xs[e] = (tb + f < T) ? feat_load<XT>::get(x, (tb + f) * ldx + d) : 0.0;
+    }
+    __syncthreads();
+    for (int c = tid; c < Cp; c += 256) {
+        double acc[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) acc[f] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double mu = meanT[(size_t)d * Cp + c], iv = ivT[(size_t)d * Cp + c];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                const double dx = xs[f * D + d] - mu;
+                acc[f] = __builtin_fma(dx * dx, iv, acc[f]);
+            }
+        }
+        const double a = lwc[c];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) zs[(size_t)f * Cp + c] = __builtin_fma(-0.5, acc[f], a);
+    }
+    __syncthreads();
+
+    const double NINF = -__builtin_inf();
+    for (int f = wave; f < FT; f += 4) {
+        const long t = tb + f;
+        if (t >= T) break;
+        double *z = zs + (size_t)f * Cp;
+        double topv = 0.0; // lane j keeps the j-th selected logit
+        int topi = 0;
+        double M = 0.0;
+        for (int k = 0; k < ctop; ++k) {
+            double bv = NINF;
+            int bc = 0x7fffffff;
+            for (int c = lane; c < Cp; c += 64) {
+                const double v = z[c];
+                if (v > bv) { bv = v; bc = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = shfl_xor_f64(bv, o);
+                const int oc = __shfl_xor(bc, o, 64);
+                if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+            }
+            if (k == 0) M = bv;
+            if (lane == k) { topv = bv; topi = bc; }
+            if (lane == (bc & 63)) z[bc] = NINF;
+        }
+        // non-selected remainder and selected sum, both relative to the largest logit M
+        double sr = 0.0;
+        for (int c = lane; c < Cp; c += 64) sr += gexp(z[c] - M);
+        sr = wave_sum_f64(sr);
+        double st = (lane < ctop) ? gexp(topv - M) : 0.0;
+        st = wave_sum_f64(st);
+        if (lane < ctop) {
+            idx_out[t * ctop + lane] = topi;
+            if (lk_out) lk_out[t * ctop + lane] = exp(topv);
+        }
+        if (lane == 0) {
+            const double rest_llk = sr > 0.0 ? M + log(sr) : NINF;
+            if (nontop_llk) nontop_llk[t] = rest_llk;
+            if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+            if (llk_out) {
+                const double tot = complete ? st + sr : st;
+                llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+            }
+        }
+        if (nontop_w) { // 1 - sum of selected weights, subtracted in selection order (TopGauss.cpp:183-186)
+            double snsw = 1.0;
+            for (int k = 0; k < ctop; ++k) {
+                const int c = __shfl(topi, k, 64);
+                snsw -= w[c];
+            }
+            if (lane == 0) nontop_w[t] = snsw;
+        }
+    }
+}
+
+// K1u: USE_TOP_DISTRIBS for a client model; one wave per frame, lane j evaluates Gaussian idx[t][j].
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_use(const void *__restrict__ x, long T, long ldx, int D,
+                                                  const double *__restrict__ mean, const double *__restrict__ iv,
+                                                  const double *__restrict__ lwc, int ctop,
+                                                  const int *__restrict__ idx, const double *__restrict__ nontop_llk,
+                                                  int complete, double lo, double hi, double *__restrict__ llk_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long t = (long)blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    double z = -__builtin_inf();
+    if (lane < ctop) {
+        const int c = idx[t * ctop + lane];
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double dx = feat_load<XT>::get(x, t * ldx + d) - mean[(size_t)c * D + d];
+            acc = __builtin_fma(dx * dx, iv[(size_t)c * D + d], acc);
+        }
+        z = __builtin_fma(-0.5, acc, lwc[c]);
+    }
+    double r = (complete && nontop_llk) ? nontop_llk[t] : -__builtin_inf();
+    double M = wave_max_f64(fmax(z, r));
+    double s = (lane < ctop) ? gexp(z - M) : 0.0;
+    s = wave_sum_f64(s);
+    if (lane == 0) {
+        if (r > -__builtin_inf()) s += gexp(r - M);
+        llk_out[t] = fmin(fmax(M + log(s), lo), hi);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// K4: frame moments sum x, sum x^2 (FrameAccGD).  HBM-bound stream; per-block partials.
+// -------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256) void k_frame_moments(const void *__restrict__ x, long T, long ldx, int D,
+                                                       double *__restrict__ partial)
+{
+    // thread -> (row slot rs, column d); columns padded to 64 per wave row
+    __shared__ double red[2][4][64];
+    const int d = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    double s = 0.0, ss = 0.0;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        s = 0.0; ss = 0.0;
+        const int dd = d0 + d;
+        if (dd < D)
+            for (long t = (long)blockIdx.x * 4 + rs; t < T; t += (long)gridDim.x * 4) {
+                const double v = feat_load<XT>::get(x, t * ldx + dd);
+                s += v;
+                ss = __builtin_fma(v, v, ss);
+            }
+        red[0][rs][d] = s;
+        red[1][rs][d] = ss;
+        __syncthreads();
+        if (rs == 0 && dd < D) {
+            partial[(size_t)blockIdx.x * 2 * D + dd] = red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d];
+            partial[(size_t)blockIdx.x * 2 * D + D + dd] = red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d];
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_moments_reduce(const double *__restrict__ partial, int nb, int n, double *__restrict__ acc)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * n + e];
+    acc[e] += s;
+}
+
+// -------------------------------------------------------------------------------------------
+// Host-side launchers
+// -------------------------------------------------------------------------------------------
+#define HIPCHK(e)                                                         \
+    do {                                                                  \
+        hipError_t _e = (e);                                              \
+        if (_e != hipSuccess) return (int)_e;                             \
+    } while (0)
+
+int gmmk_ks_for_dim(int D)
+{
+    if (D <= 16) return 4;
+    if (D <= 32) return 8;
+    if (D <= 60) return 15;
+    if (D <= 80) return 20;
+    return 0;
+}
+int gmmk_rl_for_ks(int KS) { return ((4 * KS + 2 + 31) / 32) * 32; }
+
+int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, const double *w, const double *mean,
+                    const double *iv, double *a, double *lwc, double *Pt, double *meanT, double *ivT)
+{
+    const int Cp = Cp64 > nct * 16 ? Cp64 : nct * 16;
+    k_gmm_const<<<(Cp + 255) / 256, 256, 0, st>>>(C, Cp, D, w, mean, iv, a, lwc);
+    long total = (long)nct * (2 * KS + 2) * 64;
+    k_gmm_pack<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(C, D, KS, nct, mean, iv, a, Pt);
+    long tt = (long)D * Cp64;
+    k_gmm_transpose<<<(unsigned)((tt + 255) / 256), 256, 0, st>>>(C, Cp64, D, mean, iv, meanT, ivT);
+    return (int)hipGetLastError();
+}
+
+template <int KS, typename XT>
+static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, const double *Pt, int nct,
+                      double *lse, int use_glds)
+{
+    constexpr int NR = 2 * KS + 2;
+    const size_t lds = 2 * 2 * NR * 64 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((T + 255) / 256);
+    k_llk_mfma<KS, XT><<<grid, 512, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds);
+    return (int)hipGetLastError();
+}
+
+int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
+             double *lse, int use_glds)
+{
+    if (T <= 0) return 0;
+#define CASE(K)                                                                                      \
+    case K:                                                                                          \
+        return x_f64 ? launch_llk<K, double>(st, x, T, ldx, D, Pt, nct, lse, use_glds)               \
+                     : launch_llk<K, float>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
+    switch (KS) {
+        CASE(4) CASE(8) CASE(15) CASE(20)
+    }
+#undef CASE
+    return -1;
+}
+
+int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, double hi, double *llk_out,
+                      double *partial /* >= 2*256 doubles */, double scale_c, double scale_r, double *dst_clamped,
+                      double *dst_raw)
+{
+    if (T <= 0) return 0;
+    int nb = (int)((T + 255) / 256);
+    if (nb > 256) nb = 256;
+    k_llk_finalize<<<nb, 256, 0, st>>>(lse, T, lo, hi, llk_out, partial);
+    k_reduce_partials<<<1, 64, 0, st>>>(partial, nb, 2, scale_c, scale_r, dst_clamped, dst_raw);
+    return (int)hipGetLastError();
+}
+
+int gmmk_add_scalar(hipStream_t st, double *dst, double v)
+{
+    k_add_scalar<<<1, 1, 0, st>>>(dst, v);
+    return (int)hipGetLastError();
+}
+
+template <int KS, bool SQ, typename XT>
+static int launch_stats(hipStream_t st, const void *x, long ldx, int D, int C, const double *Pt, int nct,
+                        const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
+                        double *out1, int mode)
+{
+    constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
+    const size_t lds = 2 * 64 * RL * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_stats_mfma<KS, SQ, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int ngrp = (nct + 7) / 8;
+    const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
+    k_stats_mfma<KS, SQ, XT><<<grid, 512, lds, st>>>(x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, ngrp,
+                                                     out0, out1, mode);
+    return (int)hipGetLastError();
+}
+
+int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
+               int nct, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
+               double *out1, int mode)
+{
+    if (nseg <= 0) return 0;
+#define CASE(K)                                                                                                  \
+    case K:                                                                                                      \
+        if (sq)                                                                                                  \
+            return x_f64 ? launch_stats<K, true, double>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode) \
+                         : launch_stats<K, true, float>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode); \
+        else                                                                                                     \
+            return x_f64 ? launch_stats<K, false, double>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode) \
+                         : launch_stats<K, false, float>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode);
+    switch (KS) {
+        CASE(4) CASE(8) CASE(15) CASE(20)
+    }
+#undef CASE
+    return -1;
+}
+
+int gmmk_em_reduce(hipStream_t st, const double *part, int nseg, int C, int Cp, int D, int KS, double *acc)
+{
+    const long n = (long)C * (1 + 2 * D);
+    k_em_reduce<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, nseg, C, Cp, D, 4 * KS, gmmk_rl_for_ks(KS), acc);
+    return (int)hipGetLastError();
+}
+
+int gmmk_em_get(hipStream_t st, int C, int D, const double *acc, const double *prev_mean, const double *prev_cov,
+                double *w, double *mean, double *cov)
+{
+    const long n = (long)C * D;
+    k_em_get<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(C, D, acc, prev_mean, prev_cov, w, mean, cov);
+    return (int)hipGetLastError();
+}
+
+int gmmk_topc_frames_per_block(int Cp64, int D)
+{
+    // LDS budget 160 KiB: FT * (Cp + D) doubles
+    if ((size_t)8 * (Cp64 + D) * 8 <= 150 * 1024) return 8;
+    if ((size_t)4 * (Cp64 + D) * 8 <= 150 * 1024) return 4;
+    return 0;
+}
+
+template <int FT, typename XT>
+static int launch_topc(hipStream_t st, const void *x, long T, long ldx, int D, int C, int Cp, const double *meanT,
+                       const double *ivT, const double *lwc, const double *w, int ctop, int complete, double lo,
+                       double hi, int *idx, double *lk, double *nlk, double *nllk, double *nw, double *llk)
+{
+    const size_t lds = (size_t)FT * (Cp + D) * sizeof(double);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_topc_determine<FT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const unsigned grid = (unsigned)((T + FT - 1) / FT);
+    k_topc_determine<FT, XT><<<grid, 256, lds, st>>>(x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi,
+                                                     idx, lk, nlk, nllk, nw, llk);
+    return (int)hipGetLastError();
+}
+
+int gmmk_topc_determine(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp,
+                        const double *meanT, const double *ivT, const double *lwc, const double *w, int ctop,
+                        int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                        double *nw, double *llk)
+{
+    if (T <= 0) return 0;
+    const int ft = gmmk_topc_frames_per_block(Cp, D);
+    if (ft == 8)
+        return x_f64 ? launch_topc<8, double>(st, x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk)
+                     : launch_topc<8, float>(st, x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk);
+    if (ft == 4)
+        return x_f64 ? launch_topc<4, double>(st, x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk)
+                     : launch_topc<4, float>(st, x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk);
+    return -1;
+}
+
+int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
+                  const double *iv, const double *lwc, int ctop, const int *idx, const double *nllk, int complete,
+                  double lo, double hi, double *llk)
+{
+    if (T <= 0) return 0;
+    const unsigned grid = (unsigned)((T + 3) / 4);
+    if (x_f64)
+        k_topc_use<double><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+    else
+        k_topc_use<float><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+    return (int)hipGetLastError();
+}
+
+int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, double *partial,
+                       int max_blocks, double *acc)
+{
+    if (T <= 0) return 0;
+    int nb = (int)((T + 3) / 4);
+    if (nb > max_blocks) nb = max_blocks;
+    if (x_f64) k_frame_moments<double><<<nb, 256, 0, st>>>(x, T, ldx, D, partial);
+    else k_frame_moments<float><<<nb, 256, 0, st>>>(x, T, ldx, D, partial);
+    k_moments_reduce<<<(2 * D + 255) / 256, 256, 0, st>>>(partial, nb, 2 * D, acc);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,23 @@
+// tv_kernels.h -- launchers of tv_kernels.hip (internal). Device pointers only; return hipError_t values.
+#pragma once
+#include <hip/hip_runtime.h>
+
+int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, long sA,
+              const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC, int batch);
+int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, double *panel, int *status);
+int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,
+                            double *panel, int *status);
+int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means);
+int tvk_scale_cols(hipStream_t st, long rows, long cols, const double *in, const double *scale, double *out);
+int tvk_unpack_sym(hipStream_t st, int n, int nb, const double *packed, long sp, double *full, double diag_add);
+int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, const double *w, double *packed, long sp);
+int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst);
+int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full);
+int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y);
+int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const double *Mx, double *y);
+int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv);
+int tvk_score_combine(hipStream_t st, long M, long S, double *scores, double a, const double *qm, double bm,
+                      const double *qs, double bs, double cst);
+int tvk_score_cosnorm(hipStream_t st, long M, long S, double *scores, const double *qm, const double *qs);
+int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out);
+int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const double *y, double *out);

@@ -1,0 +1,497 @@
+// tv_kernels.hip -- fp64 building blocks of the i-vector path on gfx950: a strided-batched MFMA
+// GEMM (v_mfma_f64_16x16x4_f64, LDS-tiled 128x128x16), a batched blocked Cholesky / SPD inverse
+// built from it, and the small element-wise / packing kernels around them.
+#include "devutil.h"
+#include "tv_kernels.h"
+
+// -------------------------------------------------------------------------------------------
+// C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]       (row-major, element strides)
+//   op(A)[m][k] = TA ? A[k*lda + m] : A[m*lda + k]     op(B)[k][n] = TB ? B[n*ldb + k] : B[k*ldb + n]
+// Workgroup = 4 waves, tile 128 x 128, each wave 64 x 64 (4 x 4 MFMA tiles), BK = 16.
+// Both operand tiles live k-major in LDS, column index XOR-swizzled by
+//   f(k) = (k & 15) ^ ((k & 1) << 4)
+// which keeps the MFMA operand reads (16 consecutive columns x 2 adjacent k) and both staging
+// write patterns (along columns, or transposing along k) free of bank conflicts without padding.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
+                                               long lda, long sA, const double *__restrict__ B, long ldb, long sB,
+                                               double beta, double *__restrict__ C, long ldc, long sC)
+{
+    constexpr int BM = 128, BN = 128, BK = 16;
+    __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) double Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+    A += (size_t)blockIdx.z * sA;
+    B += (size_t)blockIdx.z * sB;
+    C += (size_t)blockIdx.z * sC;
+
+    double ra[8], rb[8];
+    auto gload = [&](int kt) {
+        const long k0 = (long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int k, m;
+            if (TA) { m = e & 127; k = e >> 7; } else { k = e & 15; m = e >> 4; }
+            const long gm = m0 + m, gk = k0 + k;
+            double v = 0.0;
+            if (gm < M && gk < K) v = TA ? A[gk * lda + gm] : A[gm * lda + gk];
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int k, n;
+            if (TB) { k = e & 15; n = e >> 4; } else { n = e & 127; k = e >> 7; }
+            const long gn = n0 + n, gk = k0 + k;
+            double v = 0.0;
+            if (gn < N && gk < K) v = TB ? B[gn * ldb + gk] : B[gk * ldb + gn];
+            rb[i] = v;
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int k, m;
+            if (TA) { m = e & 127; k = e >> 7; } else { k = e & 15; m = e >> 4; }
+            As[buf][k][m ^ kswz(k)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int k, n;
+            if (TB) { k = e & 15; n = e >> 4; } else { n = e & 127; k = e >> 7; }
+            Bs[buf][k][n ^ kswz(k)] = rb[i];
+        }
+    };
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (d4){0, 0, 0, 0};
+
+    const int nkt = (K + BK - 1) / BK;
+    if (nkt > 0) { gload(0); swrite(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + q;
+            const int sw = kswz(k);
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[cur][k][(wr * 64 + a * 16 + i16) ^ sw];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[cur][k][(wc * 64 + b * 16 + i16) ^ sw];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);
+        }
+        if (kt + 1 < nkt) swrite(cur ^ 1);
+        __syncthreads();
+    }
+    // D layout: lane holds rows q + 4r, column i16 of every 16x16 tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long gm = m0 + wr * 64 + a * 16 + q + 4 * r;
+            if (gm >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long gn = n0 + wc * 64 + b * 16 + i16;
+                if (gn >= N) continue;
+                double v = alpha * acc[a][b][r];
+                if (beta != 0.0) v += beta * C[gm * ldc + gn];
+                C[gm * ldc + gn] = v;
+            }
+        }
+}
+
+int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, long sA,
+              const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC, int batch)
+{
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
+    if (!ta && !tb) k_dgemm<false, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    else if (!ta && tb) k_dgemm<false, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    else if (ta && !tb) k_dgemm<true, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    else k_dgemm<true, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    return (int)hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// element-wise / packing kernels
+// -------------------------------------------------------------------------------------------
+// F[u,c,:] -= mean[c,:] * N[u,c]      (TVAcc::substractM)
+__global__ void k_subtract_m(long U, int C, int D, const double *__restrict__ N, double *__restrict__ F,
+                             const double *__restrict__ means)
+{
+    const size_t SV = (size_t)C * D;
+    const size_t tot = (size_t)U * SV;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t u = e / SV, k = e - u * SV;
+        F[e] -= means[k] * N[u * C + k / D];
+    }
+}
+
+// out[i][k] = in[i][k] * scale[k]
+__global__ void k_scale_cols(long rows, long cols, const double *__restrict__ in, const double *__restrict__ scale,
+                             double *__restrict__ out)
+{
+    const size_t tot = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = in[e] * scale[e % cols];
+}
+
+// full[b][i][j] (n x n) <- packed lower [b][i(i+1)/2 + j] mirrored, + diag_add on the diagonal
+__global__ void k_unpack_sym(int n, const double *__restrict__ packed, long sp, double *__restrict__ full,
+                             double diag_add)
+{
+    const double *p = packed + (size_t)blockIdx.y * sp;
+    double *f = full + (size_t)blockIdx.y * n * n;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        const int a = i > j ? i : j, b = i > j ? j : i;
+        f[e] = p[(size_t)a * (a + 1) / 2 + b] + (i == j ? diag_add : 0.0);
+    }
+}
+
+// packed[b][i(i+1)/2 + j] <- full[b][i][j] (lower) [+ w[b][i] w[b][j] when w != NULL]
+__global__ void k_pack_sym(int n, const double *__restrict__ full, long sf, const double *__restrict__ w,
+                           double *__restrict__ packed, long sp)
+{
+    const double *f = full + (size_t)blockIdx.y * sf;
+    double *p = packed + (size_t)blockIdx.y * sp;
+    const double *wv = w ? w + (size_t)blockIdx.y * n : nullptr;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        if (j > i) continue;
+        double v = f[e];
+        if (wv) v += wv[i] * wv[j];
+        p[(size_t)i * (i + 1) / 2 + j] = v;
+    }
+}
+
+// dst[e] += sum_b src[b*stride + e]   (column sums over a batch)
+__global__ void k_batch_sum(long n, int nb, const double *__restrict__ src, long stride, double *__restrict__ dst)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += src[(size_t)b * stride + e];
+        dst[e] += s;
+    }
+}
+
+// full symmetric [n x n] += unpack(packed lower [n(n+1)/2])
+__global__ void k_add_unpacked(int n, const double *__restrict__ packed, double *__restrict__ full)
+{
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        const int a = i > j ? i : j, b = i > j ? j : i;
+        full[e] += packed[(size_t)a * (a + 1) / 2 + b];
+    }
+}
+
+// y[b][i] = sum_k Mx[b][i][k] x[b][k]   (one workgroup per matrix; n <= a few thousand)
+__global__ __launch_bounds__(256) void k_batched_matvec(int n, const double *__restrict__ Mx, const double *__restrict__ x,
+                                                        double *__restrict__ y)
+{
+    const double *m = Mx + (size_t)blockIdx.x * n * n;
+    const double *xv = x + (size_t)blockIdx.x * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < n; i += 4) {
+        double s = 0.0;
+        for (int k = lane; k < n; k += 64) s = __builtin_fma(m[(size_t)i * n + k], xv[k], s);
+        s = wave_sum_f64(s);
+        if (lane == 0) y[(size_t)blockIdx.x * n + i] = s;
+    }
+}
+
+// y[j] += sum_k x[k] Mx[k][j]   (Mx: rows x cols; used for mean += T^T meanW)
+__global__ void k_vecmat_add(int rows, long cols, const double *__restrict__ x, const double *__restrict__ Mx,
+                             double *__restrict__ y)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < (size_t)cols; j += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < rows; ++k) s = __builtin_fma(x[k], Mx[(size_t)k * cols + j], s);
+        y[j] += s;
+    }
+}
+
+// strided 2-D copy: dst[b][i][j] = src[b][i][j], i < rows, j < cols
+__global__ void k_copy2d(int rows, int cols, const double *__restrict__ src, long lds_, long ss,
+                         double *__restrict__ dst, long ldd, long sd)
+{
+    const double *s = src + (size_t)blockIdx.y * ss;
+    double *d = dst + (size_t)blockIdx.y * sd;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += gridDim.x * blockDim.x) {
+        const int i = e / cols, j = e - i * cols;
+        d[(size_t)i * ldd + j] = s[(size_t)i * lds_ + j];
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Diagonal block of the blocked Cholesky: factor the w x w block (w <= 32) in LDS, write the
+// lower factor back (upper part zeroed) and its inverse to invd[b][kb][32][32].
+// status[b] = 1 when a non-positive pivot is met.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_potf2_inv(int n, int kk, int w, double *__restrict__ Afull,
+                                                   double *__restrict__ invd, long sinv, int kb, int *__restrict__ status)
+{
+    __shared__ double a[32][33];
+    __shared__ double x[32][33];
+    __shared__ int bad;
+    double *A = Afull + (size_t)blockIdx.x * n * n + (size_t)kk * n + kk;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        a[i][j] = (i < w && j < w) ? A[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
+        x[i][j] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < w; ++j) {
+        if (tid == 0) {
+            double d = a[j][j];
+            if (!(d > 0.0)) { bad = 1; d = 1.0; }
+            a[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        const double dj = a[j][j];
+        if (tid > j && tid < w) a[tid][j] /= dj;
+        __syncthreads();
+        // trailing update of the lower triangle: a[i][k] -= a[i][j] a[k][j], j < k <= i
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int i = e >> 5, k = e & 31;
+            if (k > j && k <= i && i < w) a[i][k] -= a[i][j] * a[k][j];
+        }
+        __syncthreads();
+    }
+    // inverse of the lower-triangular factor, one column per thread (forward substitution)
+    if (tid < w) {
+        const int c = tid;
+        x[c][c] = 1.0 / a[c][c];
+        for (int i = c + 1; i < w; ++i) {
+            double s = 0.0;
+            for (int k = c; k < i; ++k) s = __builtin_fma(a[i][k], x[k][c], s);
+            x[i][c] = -s / a[i][i];
+        }
+    }
+    __syncthreads();
+    double *iv = invd + (size_t)blockIdx.x * sinv + (size_t)kb * 1024;
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int i = e >> 5, j = e & 31;
+        if (i < w && j < w) A[(size_t)i * n + j] = (j <= i) ? a[i][j] : 0.0;
+        iv[e] = (i < w && j < w && j <= i) ? x[i][j] : 0.0;
+    }
+    if (tid == 0 && bad) status[blockIdx.x] = 1;
+}
+
+#define TVCHK(e)                     \
+    do {                             \
+        int _r = (e);                \
+        if (_r) return _r;           \
+    } while (0)
+
+// In-place batched Cholesky (lower) of nb SPD matrices [n x n]; invd receives the inverses of the
+// 32 x 32 diagonal blocks; panel: scratch nb*n*32 doubles. Upper triangles end up unspecified
+// except inside diagonal blocks (zeroed).
+int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, double *panel, int *status)
+{
+    const int nblk = (n + 31) / 32;
+    const long sinv = (long)nblk * 1024, sa = (long)n * n, spn = (long)n * 32;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int kk = kb * 32, w = (n - kk) < 32 ? (n - kk) : 32, m = n - kk - w;
+        k_potf2_inv<<<nb, 256, 0, st>>>(n, kk, w, Afull, invd, sinv, kb, status);
+        if (m > 0) {
+            // L21 = A21 * inv(L11)^T
+            TVCHK(tvk_dgemm(st, false, true, m, w, w, 1.0, Afull + (size_t)(kk + w) * n + kk, n, sa, invd + (size_t)kb * 1024,
+                            32, sinv, 0.0, panel, 32, spn, nb));
+            dim3 g((m * w + 255) / 256, nb);
+            k_copy2d<<<g, 256, 0, st>>>(m, w, panel, 32, spn, Afull + (size_t)(kk + w) * n + kk, n, sa);
+            // A22 -= L21 * L21^T
+            TVCHK(tvk_dgemm(st, false, true, m, m, w, -1.0, panel, 32, spn, panel, 32, spn, 1.0,
+                            Afull + (size_t)(kk + w) * n + (kk + w), n, sa, nb));
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// inv[b] = A[b]^-1 for nb SPD matrices; A is destroyed (holds the Cholesky factor afterwards).
+// X: scratch nb*n*n, invd: nb*nblk*1024, panel: nb*n*32 doubles.
+int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,
+                            double *panel, int *status)
+{
+    TVCHK(tvk_chol_batched(st, n, nb, Afull, invd, panel, status));
+    const int nblk = (n + 31) / 32;
+    const long sinv = (long)nblk * 1024, sa = (long)n * n, spn = (long)n * 32;
+    if (hipMemsetAsync(X, 0, (size_t)nb * sa * sizeof(double), st) != hipSuccess) return (int)hipGetLastError();
+    for (int ib = 0; ib < nblk; ++ib) {
+        const int r0 = ib * 32, w = (n - r0) < 32 ? (n - r0) : 32;
+        dim3 g((w * w + 255) / 256, nb);
+        k_copy2d<<<g, 256, 0, st>>>(w, w, invd + (size_t)ib * 1024, 32, sinv, X + (size_t)r0 * n + r0, n, sa);
+        if (ib > 0) {
+            // tmp = L[ib, 0:r0] * X[0:r0, 0:r0]          (panel reused as [32 x n] scratch, ld = n)
+            TVCHK(tvk_dgemm(st, false, false, w, r0, r0, 1.0, Afull + (size_t)r0 * n, n, sa, X, n, sa, 0.0, panel, n, spn, nb));
+            // X[ib, 0:r0] = -inv(L_ii) * tmp
+            TVCHK(tvk_dgemm(st, false, false, w, r0, w, -1.0, invd + (size_t)ib * 1024, 32, sinv, panel, n, spn, 0.0,
+                            X + (size_t)r0 * n, n, sa, nb));
+        }
+    }
+    // A^-1 = X^T X
+    TVCHK(tvk_dgemm(st, true, false, n, n, n, 1.0, X, n, sa, X, n, sa, 0.0, inv, n, sa, nb));
+    return (int)hipGetLastError();
+}
+
+int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means)
+{
+    if (U <= 0) return 0;
+    k_subtract_m<<<2048, 256, 0, st>>>(U, C, D, N, F, means);
+    return (int)hipGetLastError();
+}
+int tvk_scale_cols(hipStream_t st, long rows, long cols, const double *in, const double *scale, double *out)
+{
+    k_scale_cols<<<2048, 256, 0, st>>>(rows, cols, in, scale, out);
+    return (int)hipGetLastError();
+}
+int tvk_unpack_sym(hipStream_t st, int n, int nb, const double *packed, long sp, double *full, double diag_add)
+{
+    if (nb <= 0) return 0;
+    dim3 g((n * n + 255) / 256 > 512 ? 512 : (n * n + 255) / 256, nb);
+    k_unpack_sym<<<g, 256, 0, st>>>(n, packed, sp, full, diag_add);
+    return (int)hipGetLastError();
+}
+int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, const double *w, double *packed, long sp)
+{
+    if (nb <= 0) return 0;
+    dim3 g((n * n + 255) / 256 > 512 ? 512 : (n * n + 255) / 256, nb);
+    k_pack_sym<<<g, 256, 0, st>>>(n, full, sf, w, packed, sp);
+    return (int)hipGetLastError();
+}
+int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    k_batch_sum<<<blocks, 256, 0, st>>>(n, nb, src, stride, dst);
+    return (int)hipGetLastError();
+}
+int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full)
+{
+    k_add_unpacked<<<(n * n + 255) / 256, 256, 0, st>>>(n, packed, full);
+    return (int)hipGetLastError();
+}
+int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y)
+{
+    if (nb <= 0) return 0;
+    k_batched_matvec<<<nb, 256, 0, st>>>(n, Mx, x, y);
+    return (int)hipGetLastError();
+}
+int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const double *Mx, double *y)
+{
+    const int blocks = (int)((cols + 255) / 256 > 4096 ? 4096 : (cols + 255) / 256);
+    k_vecmat_add<<<blocks, 256, 0, st>>>(rows, cols, x, Mx, y);
+    return (int)hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// scoring helpers
+// -------------------------------------------------------------------------------------------
+// q[j] = sum_i X[i][j] * Y[i][j]  for column-vectors matrices [dim x n] (diag(X^T Y))
+__global__ void k_coldot(int dim, long n, const double *__restrict__ X, const double *__restrict__ Y,
+                         double *__restrict__ qv)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < (size_t)n; j += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int i = 0; i < dim; ++i) s = __builtin_fma(X[(size_t)i * n + j], Y[(size_t)i * n + j], s);
+        qv[j] = s;
+    }
+}
+// scores[m][s] = a * scores[m][s] + bm * qm[m] + bs * qs[s] + cst
+__global__ void k_score_combine(long M, long S, double *__restrict__ scores, double a, const double *__restrict__ qm,
+                                double bm, const double *__restrict__ qs, double bs, double cst)
+{
+    const size_t tot = (size_t)M * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = e / S, s = e - m * S;
+        scores[e] = a * scores[e] + bm * qm[m] + bs * qs[s] + cst;
+    }
+}
+// scores[m][s] /= (sqrt(qm[m]) * sqrt(qs[s]))
+__global__ void k_score_cosnorm(long M, long S, double *__restrict__ scores, const double *__restrict__ qm,
+                                const double *__restrict__ qs)
+{
+    const size_t tot = (size_t)M * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = e / S, s = e - m * S;
+        scores[e] = scores[e] / (sqrt(qm[m]) * sqrt(qs[s]));
+    }
+}
+// out[i][j] = a[i][j] + b[j][i]   (square n x n)
+__global__ void k_add_transpose(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
+{
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        out[e] = a[e] + b[(size_t)j * n + i];
+    }
+}
+// out[i][j] = X[i][j] + v[i]  ([dim x n])
+__global__ void k_add_colvec(int dim, long n, const double *__restrict__ X, const double *__restrict__ v,
+                             double *__restrict__ out)
+{
+    const size_t tot = (size_t)dim * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = X[e] + v[e / n];
+}
+
+__global__ void k_axpby(long n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
+                        double *__restrict__ out)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = a * x[e] + b * y[e];
+}
+int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const double *y, double *out)
+{
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    k_axpby<<<blocks, 256, 0, st>>>(n, a, x, b, y, out);
+    return (int)hipGetLastError();
+}
+
+int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv)
+{
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    k_coldot<<<blocks, 256, 0, st>>>(dim, n, X, Y, qv);
+    return (int)hipGetLastError();
+}
+int tvk_score_combine(hipStream_t st, long M, long S, double *scores, double a, const double *qm, double bm,
+                      const double *qs, double bs, double cst)
+{
+    if (M <= 0 || S <= 0) return 0;
+    k_score_combine<<<4096, 256, 0, st>>>(M, S, scores, a, qm, bm, qs, bs, cst);
+    return (int)hipGetLastError();
+}
+int tvk_score_cosnorm(hipStream_t st, long M, long S, double *scores, const double *qm, const double *qs)
+{
+    if (M <= 0 || S <= 0) return 0;
+    k_score_cosnorm<<<4096, 256, 0, st>>>(M, S, scores, qm, qs);
+    return (int)hipGetLastError();
+}
+int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out)
+{
+    k_add_transpose<<<(n * n + 255) / 256, 256, 0, st>>>(n, a, b, out);
+    return (int)hipGetLastError();
+}

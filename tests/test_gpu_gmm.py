@@ -1,0 +1,199 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64 path; the reference itself is built -ffast-math so relative, not bitwise):
+  per-frame llk            abs 1e-9   (|llk| ~ 1e2 -> ~1e-11 relative)
+  posterior statistics     1e-9 relative to the largest magnitude of the compared array
+  top-C indices            exact
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_frames, make_gmm
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lia_ral_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+CASES = [(8, 60, 1), (8, 60, 64), (128, 60, 1000), (2048, 60, 300), (37, 13, 257), (1024, 32, 50), (300, 75, 130)]
+
+
+@pytest.mark.parametrize("C,D,T", CASES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_llk_matches_oracle(ctx, C, D, T, dtype):
+    w, mean, iv = make_gmm(C, D, seed=C + D)
+    x = make_frames(w, mean, iv, T, seed=T, dtype=dtype)
+    g = ctx.gmm(w, mean, iv)
+    sums = np.zeros(2)
+    got = g.llk(x, -1e9, 1e9, sums=sums)
+    ref = orc.llk(orc.Gmm(w, mean, iv), x.astype(np.float64), -1e9, 1e9)
+    assert np.max(np.abs(got - ref)) < 1e-9
+    assert sums[1] == T and abs(sums[0] - ref.sum()) < 1e-8 * T
+    # both staging paths of the LLK kernel (LDS-DMA and through registers) give the same bits
+    ctx.set_option("glds", 0)
+    got2 = g.llk(x, -1e9, 1e9)
+    ctx.set_option("glds", 1)
+    assert np.array_equal(got, got2)
+
+
+def test_llk_clamp_and_device_pointers(ctx):
+    import torch
+    w, mean, iv = make_gmm(128, 60, seed=3)
+    x = make_frames(w, mean, iv, 500, seed=4)
+    x[7] += 40.0   # an outlier far from every Gaussian: llk << -200 -> clamped like minLLK
+    g = ctx.gmm(w, mean, iv)
+    ref = orc.llk(orc.Gmm(w, mean, iv), x.astype(np.float64), -200.0, 200.0)
+    got = g.llk(x, -200.0, 200.0)
+    assert got[7] == -200.0 == ref[7]
+    assert np.max(np.abs(got - ref)) < 1e-9
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty(500, dtype=torch.float64, device="cuda")
+    g.llk(xd, -200.0, 200.0, out=out)
+    torch.cuda.synchronize(); ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("C,D,T,ctop", [(128, 60, 1000, 10), (2048, 60, 64, 10), (1024, 32, 50, 10), (8, 60, 33, 20), (300, 13, 100, 5)])
+@pytest.mark.parametrize("complete", [True, False])
+def test_top_c_matches_oracle(ctx, C, D, T, ctop, complete):
+    w, mean, iv = make_gmm(C, D, seed=C)
+    x = make_frames(w, mean, iv, T, seed=T + 1)
+    wc, meanc, ivc = w, mean + np.random.default_rng(5).normal(0, 0.1, mean.shape), iv   # client: shifted means
+    world, client = ctx.gmm(w, mean, iv), ctx.gmm(wc, meanc, ivc)
+    d = world.llk_determine_top(x, ctop, complete)
+    xo = x.astype(np.float64)
+    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), xo, ctop, complete)
+    assert np.array_equal(d["idx"], do["idx"])
+    assert relerr(d["lk"], do["lk"]) < 1e-10
+    assert np.max(np.abs(d["llk"] - do["llk"])) < 1e-9
+    assert np.max(np.abs(d["nontop_w"] - do["nontop_w"])) < 1e-12
+    big = do["nontop_lk"] > 1e-250
+    assert relerr(d["nontop_lk"][big], do["nontop_lk"][big]) < 1e-9 if big.any() else True
+    lc = client.llk_use_top(x, d["idx"], d["nontop_llk"], complete)
+    lco = orc.llk_use_top(orc.Gmm(wc, meanc, ivc), xo, do["idx"], do["nontop_lk"], complete)
+    assert np.max(np.abs(lc - lco)) < 1e-9
+
+
+def test_kat1_on_gpu(ctx, golden_dir):
+    """ComputeTest golden LLRs (test1.validate.res) through the HIP path."""
+    k = np.load(os.path.join(golden_dir, "kat1_computetest.npz"))
+    world = ctx.gmm(k["w"], k["mean_world"], k["covinv"])
+    client = ctx.gmm(k["w_client"], k["mean_client"], k["covinv_client"])
+    got = []
+    for b, n in zip(k["seg_begin"], k["seg_len"]):
+        xs = k["x"][b:b + n]
+        d = world.llk_determine_top(xs, int(k["top_c"]), True)
+        lc = client.llk_use_top(xs, d["idx"], d["nontop_llk"], True)
+        got.append(lc.mean() - d["llk"].mean())
+    assert np.allclose(got, k["expected_llr"], atol=float(k["abs_tol"]), rtol=0), got
+
+
+@pytest.mark.parametrize("C,D,T", CASES)
+def test_em_stats_match_oracle(ctx, C, D, T):
+    w, mean, iv = make_gmm(C, D, seed=C + 1)
+    x = make_frames(w, mean, iv, T, seed=T + 2)
+    g = ctx.gmm(w, mean, iv)
+    acc = g.em_accumulate(x)
+    a = g.split_acc(acc)
+    ref = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
+    assert a["count"] == T
+    assert abs(a["llk"] - ref["llk"]) < 1e-9 * max(1, T)
+    assert abs(a["occ"].sum() - T) < 1e-9 * T
+    assert relerr(a["occ"], ref["occ"]) < 1e-9
+    assert relerr(a["sx"], ref["sx"]) < 1e-9
+    assert relerr(a["sxx"], ref["sxx"]) < 1e-9
+
+
+def test_em_accumulates_weights_and_chunks(ctx):
+    w, mean, iv = make_gmm(256, 60, seed=9)
+    x = make_frames(w, mean, iv, 9000, seed=10)
+    g = ctx.gmm(w, mean, iv)
+    og = orc.Gmm(w, mean, iv)
+    acc = g.em_accumulate(x[:5000])
+    acc = g.em_accumulate(x[5000:], weight=0.5, acc=acc)       # weighted EM (AccumulateStat.cpp:143-152)
+    ref = orc.em_accumulate(og, x[:5000].astype(np.float64))
+    ref2 = orc.em_accumulate(og, x[5000:].astype(np.float64), weight=0.5)
+    a = g.split_acc(acc)
+    assert abs(a["count"] - (5000 + 0.5 * 4000)) < 1e-9
+    assert relerr(a["sx"], ref["sx"] + ref2["sx"]) < 1e-9
+    assert abs(a["llk"] - (ref["llk"] + 0.5 * ref2["llk"])) < 1e-6
+    # different chunking of the frame stream -> same sums up to rounding
+    ctx.set_option("em_chunks", 8)
+    acc8 = g.em_accumulate(x)
+    ctx.set_option("em_chunks", 1)
+    acc1 = g.em_accumulate(x)
+    ctx.set_option("em_chunks", 0)
+    assert relerr(acc8, acc1) < 1e-12
+    # M-step on the device copy == oracle getEM
+    wn, mn, cn = g.em_get(acc1, mean, 1.0 / iv)
+    refa = orc.em_accumulate(og, x.astype(np.float64))
+    wo, mo, co = orc.em_get(refa, mean, 1.0 / iv)
+    assert relerr(wn, wo) < 1e-9 and relerr(mn, mo) < 1e-9 and relerr(cn, co) < 1e-8
+
+
+def test_em_zero_frames_and_ragged_edges(ctx):
+    w, mean, iv = make_gmm(64, 60, seed=2)
+    g = ctx.gmm(w, mean, iv)
+    acc = g.em_accumulate(np.zeros((0, 60), np.float32))
+    assert not acc.any()
+    for T in (1, 63, 64, 65, 255, 256, 257):
+        x = make_frames(w, mean, iv, T, seed=T)
+        a = g.split_acc(g.em_accumulate(x))
+        ref = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
+        assert relerr(a["sxx"], ref["sxx"]) < 1e-9, T
+
+
+@pytest.mark.parametrize("C,D", [(128, 60), (2048, 60), (37, 13)])
+def test_tv_stats_match_oracle(ctx, C, D):
+    w, mean, iv = make_gmm(C, D, seed=C + 7)
+    lens = [70, 0, 131, 64, 1]
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=11)
+    g = ctx.gmm(w, mean, iv)
+    N, F = g.tv_stats(x, ub)
+    utt = np.repeat(np.arange(len(lens)), lens)
+    No, Fo = orc.tv_stats(orc.Gmm(w, mean, iv), x.astype(np.float64), utt, len(lens))
+    assert relerr(N, No) < 1e-9 and relerr(F, Fo) < 1e-9
+    assert not N[1].any() and not F[1].any()
+
+
+def test_frame_moments(ctx):
+    rng = np.random.default_rng(0)
+    for T, D in [(1, 60), (1000, 60), (4097, 34), (50, 130)]:
+        x = rng.normal(1.0, 2.0, (T, D)).astype(np.float32)
+        acc = ctx.frame_moments(x)
+        s, ss, n = orc.frame_acc(x.astype(np.float64))
+        assert acc[2 * D] == T == n
+        assert relerr(acc[:D], s) < 1e-12 and relerr(acc[D:2 * D], ss) < 1e-12
+
+
+def test_linearity_property_full_size(ctx):
+    """Size-independent property at the BASELINE model size (2048 x 60): statistics of a
+    concatenation are the sum of the statistics of the parts; occupancies sum to T."""
+    import torch
+    w, mean, iv = make_gmm(2048, 60, seed=1)
+    x = torch.from_numpy(make_frames(w, mean, iv, 200_000, seed=2)).cuda()
+    g = ctx.gmm(w, mean, iv)
+    n = g.em_acc_len()
+    full = torch.zeros(n, dtype=torch.float64, device="cuda")
+    parts = torch.zeros(n, dtype=torch.float64, device="cuda")
+    g.em_accumulate(x, acc=full)
+    g.em_accumulate(x[:70_001], acc=parts)
+    g.em_accumulate(x[70_001:], acc=parts)
+    ctx.sync()
+    f, p = full.cpu().numpy(), parts.cpu().numpy()
+    assert relerr(p, f) < 1e-11
+    assert abs(f[:2048].sum() - 200_000) < 1e-6

@@ -1,0 +1,104 @@
+"""GPU parity for the i-vector path (TVAcc maths) and i-vector scoring vs the CPU oracle.
+Tolerance: 1e-6 relative on i-vectors (north_star), tighter where conditioning allows."""
+import numpy as np
+import pytest
+
+from conftest import make_frames, make_gmm
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lia_ral_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def tv_problem(C, D, R, U, seed=0, frames=200):
+    rng = np.random.default_rng(seed)
+    w, mean, iv = make_gmm(C, D, seed=seed)
+    lens = rng.integers(frames // 2, frames, U)
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=seed + 1).astype(np.float64)
+    utt = np.repeat(np.arange(U), lens)
+    N, F = orc.tv_stats(orc.Gmm(w, mean, iv), x, utt, U)
+    Tm = rng.normal(0, 0.05, (R, C * D))
+    return dict(w=w, mean=mean, iv=iv, N=N, F=F, Tm=Tm, C=C, D=D, R=R, U=U)
+
+
+@pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 5), (64, 60, 50, 9), (32, 20, 100, 40), (128, 60, 400, 3)])
+def test_ivector_extraction(ctx, C, D, R, U):
+    p = tv_problem(C, D, R, U, seed=R)
+    F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
+    Fg = ctx.tv_subtract_m(p["N"], p["F"].copy(), p["mean"].ravel(), C, D)
+    assert relerr(Fg, F0) < 1e-13
+    invvar = p["iv"].ravel()
+    te_o = orc.tv_tett(p["Tm"], invvar, C, D)
+    te_g = ctx.tv_tett(p["Tm"], invvar, C, D)
+    il = np.tril_indices(R)
+    assert relerr(te_g, te_o[:, il[0], il[1]]) < 1e-12
+    W_o = orc.tv_estimate_w(p["N"], F0, p["Tm"], invvar, te_o)
+    W_g = ctx.tv_estimate_w(p["N"], F0, p["Tm"], invvar, te_g, C, D)
+    assert relerr(W_g, W_o) < 1e-9          # north_star bar is 1e-6
+
+
+@pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 30), (32, 20, 40, 300)])
+def test_tv_em_iteration(ctx, C, D, R, U):
+    p = tv_problem(C, D, R, U, seed=7, frames=120)
+    invvar = p["iv"].ravel()
+    F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
+    te_o = orc.tv_tett(p["Tm"], invvar, C, D)
+    te_g = ctx.tv_tett(p["Tm"], invvar, C, D)
+    o = orc.tv_estimate_a_and_c(p["N"], F0, p["Tm"], invvar, te_o)
+    # two calls on disjoint utterance halves accumulate like one (what ranks do before the all-reduce)
+    h = U // 2
+    g = ctx.tv_estimate_a_and_c(p["N"][:h], F0[:h], p["Tm"], invvar, te_g, C, D)
+    W1 = g["W"].copy()
+    g = ctx.tv_estimate_a_and_c(p["N"][h:], F0[h:], p["Tm"], invvar, te_g, C, D, acc=g)
+    W = np.vstack([W1, g["W"]])
+    il = np.tril_indices(R)
+    A_o = o["A"].reshape(C, R, R)[:, il[0], il[1]]
+    assert relerr(W, o["W"]) < 1e-9
+    assert relerr(g["A"], A_o) < 1e-9
+    assert relerr(g["Cmx"], o["Cmx"]) < 1e-9
+    assert relerr(g["Rm"], o["Rm"]) < 1e-9
+    assert relerr(g["r"], o["r"]) < 1e-9
+    assert relerr(g["meanW"] / U, o["meanW"]) < 1e-9
+    T_o = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+    T_g = ctx.tv_update_t(g["A"], g["Cmx"], C, D)
+    assert relerr(T_g, T_o) < 1e-7
+    m_o, Tm_o = orc.tv_min_divergence(o["Rm"], o["r"], o["meanW"], p["mean"].ravel(), T_o, U, C, D)
+    means = p["mean"].ravel().copy()
+    m_g, Tm_g = ctx.tv_min_divergence(g["Rm"].copy(), g["r"].copy(), g["meanW"] / U, means, T_g.copy(), U, C, D)
+    assert relerr(m_g, m_o) < 1e-7 and relerr(Tm_g, Tm_o) < 1e-7
+
+
+def test_dgemm_shapes_through_scoring(ctx):
+    """The MFMA GEMM behind every TV step: odd sizes, all transposes exercised via the score rules."""
+    rng = np.random.default_rng(1)
+    for dim, M, S in [(5, 3, 7), (50, 130, 129), (400, 260, 17), (33, 1, 300)]:
+        m = rng.normal(size=(dim, M)); s = rng.normal(size=(dim, S))
+        assert relerr(ctx.score_cosine(m, s), orc.score_cosine(m, s)) < 1e-12
+        Q = rng.normal(size=(dim, dim)); Mah = Q @ Q.T / dim + np.eye(dim)
+        assert relerr(ctx.score_mahalanobis(m, s, Mah), orc.score_mahalanobis(m, s, Mah)) < 1e-11
+        G = rng.normal(size=(dim, dim)) / dim; H = rng.normal(size=(dim, dim)) / dim
+        assert relerr(ctx.score_twocov(m, s, G, H), orc.score_twocov(m, s, G, H)) < 1e-11
+
+
+def test_plda_scoring(ctx):
+    rng = np.random.default_rng(2)
+    rf, M, S = 40, 37, 53
+    Fm = rng.normal(size=(60, rf))
+    FTJF = Fm.T @ Fm / 60
+    models = rng.normal(size=(rf, M)); segs = rng.normal(size=(rf, S))
+    nsess = np.array([1] * 10 + [3] * 20 + [1] * 7)
+    got = ctx.score_plda(models, nsess, segs, FTJF)
+    ref = orc.score_plda(models, nsess, segs, FTJF)
+    assert relerr(got, ref) < 1e-10

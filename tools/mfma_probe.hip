@@ -1,0 +1,130 @@
+// mfma_probe.hip -- gfx950 micro-benchmarks that the kernel design rests on (run on the GPU box):
+//   1. lane layout of v_mfma_f64_16x16x4_f64 (A, B, C/D maps assumed by gmm_kernels.hip)
+//   2. issue rate of the f64 MFMA, of v_fma_f64, and of the software exp, alone and mixed
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_probe tools/mfma_probe.hip
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <vector>
+#include "../lia_ral_amd/csrc/devutil.h"
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); return 1; } } while (0)
+
+__global__ void k_layout(const double *A /*16x4*/, const double *B /*4x16*/, double *Dm /*16x16*/)
+{
+    const int l = threadIdx.x;
+    const double a = A[(l & 15) * 4 + (l >> 4)];
+    const double b = B[(l >> 4) * 16 + (l & 15)];
+    d4 acc = {0, 0, 0, 0};
+    acc = MFMA_F64(a, b, acc);
+    for (int r = 0; r < 4; ++r) Dm[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+template <int MODE>  // 0: mfma only, 1: fma only, 2: exp only, 3: mfma + exp interleaved in one wave
+__global__ __launch_bounds__(256) void k_rate(double *out, int iters, double seed)
+{
+    d4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (d4){seed, seed, seed, seed};
+    double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
+    double v[8];
+    for (int i = 0; i < 8; ++i) v[i] = -1.0 - 0.01 * i - 1e-6 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0 || MODE == 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = MFMA_F64(a, b, acc[i]);
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_fma(v[i], 0.999999, 1e-9);
+        }
+        if (MODE == 2 || MODE == 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = gexp(v[i]) - 1.5;
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// half the waves of a block run MFMA, the other half exp: do the pipes overlap?
+__global__ __launch_bounds__(512) void k_mixed(double *out, int iters, double seed)
+{
+    const int wave = threadIdx.x >> 6;
+    d4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (d4){seed, seed, seed, seed};
+    double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
+    double v[8];
+    for (int i = 0; i < 8; ++i) v[i] = -1.0 - 0.01 * i - 1e-6 * threadIdx.x;
+    if (wave & 1) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = MFMA_F64(a, b, acc[i]);
+    } else {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = gexp(v[i]) - 1.5;
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <typename F> static float time_ms(F f)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    f();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    f();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    printf("device %s, CUs %d, clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+    // ---- layout
+    std::vector<double> hA(64), hB(64), hD(256), ref(256, 0.0);
+    for (int i = 0; i < 16; ++i) for (int k = 0; k < 4; ++k) hA[i * 4 + k] = 1 + i + 0.1 * k;
+    for (int k = 0; k < 4; ++k) for (int j = 0; j < 16; ++j) hB[k * 16 + j] = 2 + 0.01 * j * j - 0.3 * k;
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) for (int k = 0; k < 4; ++k) ref[i * 16 + j] += hA[i * 4 + k] * hB[k * 16 + j];
+    double *dA, *dB, *dD;
+    CK(hipMalloc(&dA, 64 * 8)); CK(hipMalloc(&dB, 64 * 8)); CK(hipMalloc(&dD, 256 * 8));
+    CK(hipMemcpy(dA, hA.data(), 64 * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), 64 * 8, hipMemcpyHostToDevice));
+    k_layout<<<1, 64>>>(dA, dB, dD);
+    CK(hipMemcpy(hD.data(), dD, 256 * 8, hipMemcpyDeviceToHost));
+    double err = 0;
+    for (int e = 0; e < 256; ++e) err = fmax(err, fabs(hD[e] - ref[e]));
+    printf("LAYOUT f64 16x16x4: max |D - ref| = %.3e  -> %s\n", err, err < 1e-9 ? "OK" : "MISMATCH");
+    // ---- rates
+    const int blocks = p.multiProcessorCount * 2, iters = 20000;
+    double *out;
+    CK(hipMalloc(&out, (size_t)blocks * 512 * 8));
+    const double waves = (double)blocks * 4;
+    float ms = time_ms([&] { k_rate<0><<<blocks, 256>>>(out, iters, 1e-3); });
+    double nm = waves * iters * 8.0;
+    printf("MFMA f64 only   : %.3f ms  %.1f TFLOP/s  (%.1f cycles/MFMA/SIMD @2.4GHz, 2 waves/SIMD)\n", ms, nm * 2048 / ms / 1e9,
+           ms * 1e-3 * 2.4e9 / (iters * 8.0 * 2));
+    ms = time_ms([&] { k_rate<1><<<blocks, 256>>>(out, iters, 1e-3); });
+    printf("v_fma_f64 only  : %.3f ms  %.1f TFLOP/s\n", ms, waves * iters * 32.0 * 64 * 2 / ms / 1e9);
+    ms = time_ms([&] { k_rate<2><<<blocks, 256>>>(out, iters, 1e-3); });
+    printf("gexp only       : %.3f ms  %.2f Gexp/s  (%.1f cycles/wave-exp @2.4GHz per SIMD)\n", ms, waves * iters * 8.0 * 64 / ms / 1e6,
+           ms * 1e-3 * 2.4e9 / (iters * 8.0 * 2));
+    ms = time_ms([&] { k_rate<3><<<blocks, 256>>>(out, iters, 1e-3); });
+    printf("MFMA+gexp 1 wave: %.3f ms  (same counts as the two lines above, interleaved in each wave)\n", ms);
+    float ms2 = time_ms([&] { k_mixed<<<p.multiProcessorCount, 512>>>(out, iters, 1e-3); });
+    printf("MFMA || gexp    : %.3f ms  (4 MFMA waves + 4 exp waves per CU, %d iters each)\n", ms2, iters);
+    float ms3 = time_ms([&] { k_rate<0><<<p.multiProcessorCount, 256>>>(out, iters, 1e-3); });
+    float ms4 = time_ms([&] { k_rate<2><<<p.multiProcessorCount, 256>>>(out, iters, 1e-3); });
+    printf("  reference: 4 MFMA waves/CU alone %.3f ms, 4 exp waves/CU alone %.3f ms\n", ms3, ms4);
+    return 0;
+}
