@@ -105,8 +105,8 @@ def main():
         acc.zero_()
         g.em_accumulate(x, acc=acc)                         # K1 (lse) + K2 (statistics) + reduce
         if record:
-            ms, name = ctx.last_kernel_ms()
-            kern_ms.setdefault(name, []).append(ms)
+            for name in ("k_llk_mfma", "k_stats_mfma"):
+                kern_ms.setdefault(name, []).append(ctx.kernel_ms(name))
         if world > 1:
             dist.all_reduce(acc)                            # EM sufficient statistics, 1.98 MB fp64
         # M-step (MixtureStat::getEM) + variance flooring + re-pack of the device model
@@ -161,9 +161,15 @@ def main():
                            "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
                            "traffic": traffic, "kernel_ms": ms,
                            "algorithmic_flop_per_launch": FLOP_PER_PAIR_STATS * T * C}
+        ms1 = float(np.mean(kern_ms.get("k_llk_mfma", [float("nan")])))
+        out["kernels"] = {"k_llk_mfma": {"ms": ms1, "tflops": FLOP_PER_PAIR_LLK * T * C / (ms1 * 1e-3) / 1e12,
+                                         "gpairs_per_s": T * C / (ms1 * 1e-3) / 1e9},
+                          "k_stats_mfma": {"ms": ms, "tflops": achieved, "gpairs_per_s": T * C / (ms * 1e-3) / 1e9}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, mean, iv, seed=99)
         print(json.dumps(out), flush=True)
+    g.close()
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -52,6 +52,8 @@ const char *gmmiv_version(void);
 long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);
 /* Duration (ms, HIP events on the context's stream) of the last call's dominant kernel. */
 double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *ctx, const char **kernel_name);
+/* Same, for the most recent launch of a named kernel ("k_llk_mfma", "k_stats_mfma", ...); -1 if none. */
+double gmmiv_ctx_kernel_ms(gmmiv_ctx *ctx, const char *kernel_name);
 
 /* ---- model: MixtureGD / DistribGD ----------------------------------------------------------
  * w[C], mean[C*D], covinv[C*D] (DistribGD::getMeanVect / getCovInvVect, MixtureGD::weight(c);

@@ -2,8 +2,14 @@
 (device, used in place).  Raises GmmivError on any non-zero status -- never falls back to a CPU path."""
 import ctypes as ct
 import os
+import sys
 
 import numpy as np
+
+try:  # PyTorch-ROCm bundles its own HIP runtime: load it first so the process holds ONE runtime
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the binding itself
+    torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgmmiv.so")
@@ -26,6 +32,7 @@ def _load():
     lib.gmmiv_em_acc_len.restype = ct.c_size_t
     lib.gmmiv_tv_packed_len.restype = ct.c_size_t
     lib.gmmiv_ctx_last_kernel_ms.restype = ct.c_double
+    lib.gmmiv_ctx_kernel_ms.restype = ct.c_double
     lib.gmmiv_ctx_set_option.restype = ct.c_long
     return lib
 
@@ -85,10 +92,15 @@ class Context:
             self._h = ct.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():   # the HIP runtime may already be gone at interpreter exit
+            return
         try:
             self.close()
         except Exception:
             pass
+
+    def kernel_ms(self, name):
+        return lib.gmmiv_ctx_kernel_ms(self._h, name.encode())
 
     def sync(self):
         _chk(lib.gmmiv_ctx_sync(self._h))
@@ -215,6 +227,8 @@ class Gmm:
             self._h = ct.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

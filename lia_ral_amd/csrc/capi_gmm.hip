@@ -48,8 +48,6 @@ int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out)
     c->device = device;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { GCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    GCHK(hipEventCreate(&c->ev0));
-    GCHK(hipEventCreate(&c->ev1));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     *out = c;
@@ -63,8 +61,10 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < WS_COUNT; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < gmmiv_ctx::NSLOT; ++i) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -91,12 +91,17 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
 
 double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *c, const char **name)
 {
-    if (!c || !c->ev_valid) return -1.0;
-    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
-    if (name) *name = c->ev_name;
-    return (double)ms;
+    if (!c || c->ev_last < 0) return -1.0;
+    if (name) *name = c->ev_name[c->ev_last];
+    return c->t_query(c->ev_last);
+}
+
+double gmmiv_ctx_kernel_ms(gmmiv_ctx *c, const char *name)
+{
+    if (!c || !name) return -1.0;
+    for (int i = 0; i < gmmiv_ctx::NSLOT; ++i)
+        if (c->ev_name[i] && !strcmp(c->ev_name[i], name)) return c->t_query(i);
+    return -1.0;
 }
 
 // ---- model -------------------------------------------------------------------------------

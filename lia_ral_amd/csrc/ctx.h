@@ -35,9 +35,12 @@ struct gmmiv_ctx {
     long em_chunks = 0; // 0 = auto
     long timing = 0;
     int n_cu = 256;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
-    const char *ev_name = "";
+    // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name
+    enum { NSLOT = 6 };
+    hipEvent_t ev0[NSLOT] = {}, ev1[NSLOT] = {};
+    const char *ev_name[NSLOT] = {};
+    bool ev_valid[NSLOT] = {};
+    int ev_cur = -1, ev_last = -1;
 
     // grow-only device scratch; contents are NOT preserved across a growth
     int scratch(int slot, size_t bytes, void **out)
@@ -59,11 +62,35 @@ struct gmmiv_ctx {
     }
     void t_begin(const char *name)
     {
-        if (timing) { (void)hipEventRecord(ev0, stream); ev_name = name; }
+        if (!timing) return;
+        int s = -1;
+        for (int i = 0; i < NSLOT; ++i)
+            if (ev_name[i] && !strcmp(ev_name[i], name)) { s = i; break; }
+        if (s < 0)
+            for (int i = 0; i < NSLOT; ++i)
+                if (!ev_name[i]) { s = i; break; }
+        if (s < 0) s = NSLOT - 1;
+        if (!ev0[s]) { (void)hipEventCreate(&ev0[s]); (void)hipEventCreate(&ev1[s]); }
+        ev_name[s] = name;
+        ev_valid[s] = false;
+        ev_cur = s;
+        (void)hipEventRecord(ev0[s], stream);
     }
     void t_end()
     {
-        if (timing) { (void)hipEventRecord(ev1, stream); ev_valid = true; }
+        if (!timing || ev_cur < 0) return;
+        (void)hipEventRecord(ev1[ev_cur], stream);
+        ev_valid[ev_cur] = true;
+        ev_last = ev_cur;
+        ev_cur = -1;
+    }
+    double t_query(int s)
+    {
+        if (s < 0 || s >= NSLOT || !ev_valid[s]) return -1.0;
+        if (hipEventSynchronize(ev1[s]) != hipSuccess) return -1.0;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev0[s], ev1[s]) != hipSuccess) return -1.0;
+        return (double)ms;
     }
 };
 

@@ -72,6 +72,21 @@ __global__ __launch_bounds__(512) void k_mixed(double *out, int iters, double se
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_n(double *out, int iters, double seed)
+{
+    d4 acc[NACC];
+    double a[NACC], b[NACC];
+    for (int i = 0; i < NACC; ++i) { acc[i] = (d4){seed, seed, seed, seed}; a[i] = seed + i + threadIdx.x * 1e-9; b[i] = seed * 0.5 - i; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = MFMA_F64(a[i], b[i], acc[i]);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F> static float time_ms(F f)
 {
     hipEvent_t e0, e1;
@@ -126,5 +141,19 @@ int main()
     float ms3 = time_ms([&] { k_rate<0><<<p.multiProcessorCount, 256>>>(out, iters, 1e-3); });
     float ms4 = time_ms([&] { k_rate<2><<<p.multiProcessorCount, 256>>>(out, iters, 1e-3); });
     printf("  reference: 4 MFMA waves/CU alone %.3f ms, 4 exp waves/CU alone %.3f ms\n", ms3, ms4);
+    // ---- MFMA f64 issue-rate sweep: waves per SIMD x independent accumulators
+    {
+        const int it2 = 40000;
+        for (int wps = 1; wps <= 4; wps *= 2) {
+            const int nblk = p.multiProcessorCount * wps;   // 256-thread blocks: 1 wave per SIMD each
+            float t1 = time_ms([&] { k_mfma_n<1><<<nblk, 256>>>(out, it2, 1e-3); });
+            float t2 = time_ms([&] { k_mfma_n<2><<<nblk, 256>>>(out, it2, 1e-3); });
+            float t4 = time_ms([&] { k_mfma_n<4><<<nblk, 256>>>(out, it2, 1e-3); });
+            float t8 = time_ms([&] { k_mfma_n<8><<<nblk, 256>>>(out, it2, 1e-3); });
+            const double fl = (double)nblk * 4 * it2 * 2048.0;
+            printf("MFMA f64 sweep, %d wave(s)/SIMD: 1 acc %.1f TF | 2 acc %.1f TF | 4 acc %.1f TF | 8 acc %.1f TF\n", wps,
+                   fl * 1 / t1 / 1e9, fl * 2 / t2 / 1e9, fl * 4 / t4 / 1e9, fl * 8 / t8 / 1e9);
+        }
+    }
     return 0;
 }
