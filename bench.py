@@ -96,7 +96,7 @@ def main():
     w_d = torch.empty(C, dtype=torch.float64, device=dev)
     nm_d = torch.empty_like(mean_d)
     nc_d = torch.empty_like(cov_d)
-    floor = 1e-3 * cov_d.mean(0, keepdim=True)
+    cov_signal = cov_d.mean(0).contiguous()       # stands in for the global covariance of computeMeanCov
 
     kern_ms = {}
 
@@ -112,8 +112,8 @@ def main():
         # M-step (MixtureStat::getEM) + variance flooring + re-pack of the device model
         capi._chk(capi.lib.gmmiv_em_get(ctx._h, C, D, capi._ptr(acc), capi._ptr(mean_d), capi._ptr(cov_d),
                                         capi._ptr(w_d), capi._ptr(nm_d), capi._ptr(nc_d)))
-        torch.maximum(nc_d, floor, out=nc_d)
-        g.set(w_d, nm_d, 1.0 / nc_d)
+        ctx.variance_control(nc_d, 1e-3, 10.0, cov_signal, C, D, count=False)
+        g.set_cov(w_d, nm_d, nc_d)
         mean_d, nm_d = nm_d, mean_d
         cov_d, nc_d = nc_d, cov_d
 

@@ -61,6 +61,8 @@ double gmmiv_ctx_kernel_ms(gmmiv_ctx *ctx, const char *kernel_name);
 int gmmiv_gmm_create(gmmiv_ctx *ctx, int C, int D, const double *w, const double *mean,
                      const double *covinv, gmmiv_gmm **out);
 int gmmiv_gmm_set(gmmiv_gmm *g, const double *w, const double *mean, const double *covinv);
+/* Same from covariances (DistribGD::setCov + computeAll, TrainTools.cpp:577-582): covInv = 1/cov. */
+int gmmiv_gmm_set_cov(gmmiv_gmm *g, const double *w, const double *mean, const double *cov);
 void gmmiv_gmm_destroy(gmmiv_gmm *g);
 
 /* ---- FrameAccGD::accumulate loop (LIA_SpkTools/src/AccumulateStat.cpp:387-396) ---------------
@@ -105,6 +107,12 @@ int gmmiv_em_accumulate(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x
  * the device copy; components with occ == 0 keep prev_mean / prev_cov).  Outputs [C],[C*D],[C*D]. */
 int gmmiv_em_get(gmmiv_ctx *ctx, int C, int D, const double *acc, const double *prev_mean,
                  const double *prev_cov, double *w, double *mean, double *cov);
+
+/* varianceControl (LIA_SpkTools/src/TrainTools.cpp:567-587): cov[c,d] clamped to
+ * [flooring*cov_signal[d], ceiling*cov_signal[d]] in place (floor test first, then ceiling);
+ * counts (HOST, nullable): [0] += floored entries, [1] += ceiled entries. */
+int gmmiv_variance_control(gmmiv_ctx *ctx, int C, int D, double *cov, double flooring, double ceiling,
+                           const double *cov_signal, int64_t *counts);
 
 /* ---- TVAcc::computeAndAccumulateTVStat (LIA_SpkTools/src/AccumulateTVStat.cpp:281-351) ---------
  * Frames of statistics row u are x[utt_begin[u] .. utt_begin[u+1]) (utt_begin: U+1 HOST offsets).

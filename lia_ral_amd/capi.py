@@ -126,6 +126,12 @@ class Context:
         _chk(lib.gmmiv_frame_moments(self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), D, _ptr(acc)))
         return acc
 
+    def variance_control(self, cov, flooring, ceiling, cov_signal, C, D, count=True):
+        counts = np.zeros(2, np.int64) if count else None
+        _chk(lib.gmmiv_variance_control(self._h, C, D, _ptr(cov), ct.c_double(flooring), ct.c_double(ceiling),
+                                        _ptr(_f64(cov_signal)), _ptr(counts)))
+        return cov, counts
+
     # ---- TVAcc maths
     def tv_subtract_m(self, N, F, means, C, D):
         U = N.shape[0]
@@ -220,6 +226,9 @@ class Gmm:
 
     def set(self, w, mean, covinv):
         _chk(lib.gmmiv_gmm_set(self._h, _ptr(_f64(w)), _ptr(_f64(mean)), _ptr(_f64(covinv))))
+
+    def set_cov(self, w, mean, cov):
+        _chk(lib.gmmiv_gmm_set_cov(self._h, _ptr(_f64(w)), _ptr(_f64(mean)), _ptr(_f64(cov))))
 
     def close(self):
         if self._h:

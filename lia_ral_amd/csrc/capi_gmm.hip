@@ -153,6 +153,21 @@ int gmmiv_gmm_set(gmmiv_gmm *g, const double *w, const double *mean, const doubl
     return gmm_upload(g, w, mean, covinv);
 }
 
+int gmmiv_gmm_set_cov(gmmiv_gmm *g, const double *w, const double *mean, const double *cov)
+{
+    if (!g || !w || !mean || !cov) { gmmiv_set_error("gmm_set_cov: bad argument"); return GMMIV_ERR_ARG; }
+    gmmiv_ctx *c = g->ctx;
+    GCHK(hipSetDevice(c->device));
+    const size_t CD = (size_t)g->C * g->D;
+    DevIn<double> i_cov;
+    int rc = i_cov.init(c, WS_T0, cov, CD);
+    if (rc) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_T1, CD * sizeof(double), &p))) return rc;
+    GCHK(gmmk_reciprocal(c->stream, (long)CD, i_cov.d, (double *)p));   // covInv = 1 / cov (DistribGD::computeAll)
+    return gmm_upload(g, w, mean, (const double *)p);
+}
+
 void gmmiv_gmm_destroy(gmmiv_gmm *g)
 {
     if (!g) return;
@@ -384,6 +399,35 @@ int gmmiv_em_get(gmmiv_ctx *c, int C, int D, const double *acc, const double *pr
     if ((rc = o_w.finish())) return rc;
     if ((rc = o_m.finish())) return rc;
     return o_c.finish();
+}
+
+int gmmiv_variance_control(gmmiv_ctx *c, int C, int D, double *cov, double flooring, double ceiling,
+                           const double *cov_signal, int64_t *counts)
+{
+    if (!c || C <= 0 || D <= 0 || !cov || !cov_signal) { gmmiv_set_error("variance_control: bad argument"); return GMMIV_ERR_ARG; }
+    if (counts && gmmiv_is_device_ptr(counts)) { gmmiv_set_error("variance_control: counts must be a host array"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    DevOut<double> o;
+    DevIn<double> i_cs;
+    int rc;
+    if ((rc = o.init(c, WS_T0, cov, (size_t)C * D, true))) return rc;
+    if ((rc = i_cs.init(c, WS_T1, cov_signal, D))) return rc;
+    unsigned long long *dc = nullptr;
+    if (counts) {
+        void *p;
+        if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &p))) return rc;
+        dc = (unsigned long long *)p;
+        GCHK(hipMemsetAsync(dc, 0, 2 * sizeof(unsigned long long), c->stream));
+    }
+    GCHK(gmmk_variance_control(c->stream, C, D, o.d, flooring, ceiling, i_cs.d, dc));
+    if (counts) {
+        unsigned long long h[2];
+        GCHK(hipMemcpyAsync(h, dc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        counts[0] = (int64_t)h[0];
+        counts[1] = (int64_t)h[1];
+    }
+    return o.finish();
 }
 
 // ---- Baum-Welch N / F ----------------------------------------------------------------------

@@ -28,3 +28,6 @@ int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, in
                   double lo, double hi, double *llk);
 int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, double *partial,
                        int max_blocks, double *acc);
+int gmmk_variance_control(hipStream_t st, int C, int D, double *cov, double flooring, double ceiling,
+                          const double *cov_signal, unsigned long long *counts);
+int gmmk_reciprocal(hipStream_t st, long n, const double *in, double *out);

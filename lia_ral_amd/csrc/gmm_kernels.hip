@@ -435,6 +435,24 @@ __global__ void k_em_get(int C, int D, const double *__restrict__ acc, const dou
     }
 }
 
+// varianceControl (TrainTools.cpp:567-587): floor first, then ceiling; counts[0/1] += hits
+__global__ void k_variance_control(int C, int D, double *__restrict__ cov, double flooring, double ceiling,
+                                   const double *__restrict__ cov_signal, unsigned long long *__restrict__ counts)
+{
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * D) return;
+    const double cs = cov_signal[e % D];
+    double cv = cov[e];
+    if (cv <= flooring * cs) { cv = flooring * cs; if (counts) atomicAdd(&counts[0], 1ULL); }
+    if (cv >= ceiling * cs) { cv = ceiling * cs; if (counts) atomicAdd(&counts[1], 1ULL); }
+    cov[e] = cv;
+}
+__global__ void k_reciprocal(long n, const double *__restrict__ in, double *__restrict__ out)
+{
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = 1.0 / in[e];
+}
+
 // -------------------------------------------------------------------------------------------
 // K1t: DETERMINE_TOP_DISTRIBS (VALU, direct form like DistribGD::computeLK).  One workgroup =
 // FT frames; the 4 waves split the Gaussians for the evaluation, then each wave selects for
@@ -733,6 +751,19 @@ int gmmk_em_get(hipStream_t st, int C, int D, const double *acc, const double *p
 {
     const long n = (long)C * D;
     k_em_get<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(C, D, acc, prev_mean, prev_cov, w, mean, cov);
+    return (int)hipGetLastError();
+}
+
+int gmmk_variance_control(hipStream_t st, int C, int D, double *cov, double flooring, double ceiling,
+                          const double *cov_signal, unsigned long long *counts)
+{
+    const long n = (long)C * D;
+    k_variance_control<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(C, D, cov, flooring, ceiling, cov_signal, counts);
+    return (int)hipGetLastError();
+}
+int gmmk_reciprocal(hipStream_t st, long n, const double *in, double *out)
+{
+    k_reciprocal<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(n, in, out);
     return (int)hipGetLastError();
 }
 

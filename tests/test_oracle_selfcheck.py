@@ -1,0 +1,91 @@
+"""The i-vector / scoring rows have no reference fixture ("parity unpinned"); the
+C oracle for them is cross-checked here against an independent numpy restatement of the same
+formulas, so that a slip in the oracle cannot silently become the GPU's target."""
+import numpy as np
+
+from conftest import make_frames, make_gmm
+from oracle import oracle as orc
+
+
+def test_posteriors_and_stats_against_numpy():
+    w, mean, iv = make_gmm(24, 10, seed=3)
+    x = make_frames(w, mean, iv, 200, seed=4).astype(np.float64)
+    D = 10
+    logn = (np.log(w) - 0.5 * D * np.log(2 * np.pi) + 0.5 * np.log(iv).sum(1)
+            - 0.5 * (((x[:, None, :] - mean[None]) ** 2) * iv[None]).sum(-1))
+    lse = np.logaddexp.reduce(logn, axis=1)
+    gam = np.exp(logn - lse[:, None])
+    g = orc.Gmm(w, mean, iv)
+    assert np.allclose(orc.llk(g, x, -1e9, 1e9), lse, rtol=0, atol=1e-10)
+    assert np.allclose(orc.occ(g, x), gam, atol=1e-12)
+    a = orc.em_accumulate(g, x)
+    assert np.allclose(a["occ"], gam.sum(0)) and np.allclose(a["sx"], gam.T @ x) and np.allclose(a["sxx"], gam.T @ x ** 2)
+    utt = np.repeat([0, 1, 2], [50, 70, 80])
+    N, F = orc.tv_stats(g, x, utt, 3)
+    for u in range(3):
+        assert np.allclose(N[u], gam[utt == u].sum(0))
+        assert np.allclose(F[u].reshape(24, 10), gam[utt == u].T @ x[utt == u])
+
+
+def test_tv_maths_against_numpy():
+    rng = np.random.default_rng(0)
+    C, D, R, U = 6, 5, 7, 11
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D); means = rng.normal(size=C * D)
+    F0 = orc.tv_subtract_m(N, F, means)
+    assert np.allclose(F0, F - np.repeat(N, D, axis=1) * means)
+    te = orc.tv_tett(T, iv, C, D)
+    for c in range(C):
+        Tc = T[:, c * D:(c + 1) * D]
+        assert np.allclose(te[c], (Tc * iv[c * D:(c + 1) * D]) @ Tc.T)
+    W = orc.tv_estimate_w(N, F0, T, iv, te)
+    o = orc.tv_estimate_a_and_c(N, F0, T, iv, te)
+    A = np.zeros((C, R, R)); Cm = np.zeros((R, C * D)); Rm = np.zeros((R, R))
+    for u in range(U):
+        L = np.eye(R) + np.einsum("c,cij->ij", N[u], te)
+        wv = np.linalg.solve(L, T @ (iv * F0[u]))
+        assert np.allclose(W[u], wv, rtol=1e-10) and np.allclose(o["W"][u], wv, rtol=1e-10)
+        E = np.linalg.inv(L) + np.outer(wv, wv)
+        A += N[u][:, None, None] * E; Cm += np.outer(wv, F0[u]); Rm += E
+    assert np.allclose(o["A"].reshape(C, R, R), A) and np.allclose(o["Cmx"], Cm) and np.allclose(o["Rm"], Rm)
+    assert np.allclose(o["r"], W.sum(0)) and np.allclose(o["meanW"], W.mean(0))
+    Tn = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+    for c in range(C):
+        assert np.allclose(Tn[:, c * D:(c + 1) * D], np.linalg.solve(A[c], Cm[:, c * D:(c + 1) * D]))
+    m2, T2 = orc.tv_min_divergence(o["Rm"], o["r"], o["meanW"], means, Tn, U, C, D)
+    rbar = o["r"] / U
+    Ch = np.linalg.cholesky(o["Rm"] / U - np.outer(rbar, rbar)).T          # upper, R = Ch^T Ch
+    assert np.allclose(T2, Ch @ Tn) and np.allclose(m2, means + Tn.T @ o["meanW"])
+    Q = orc.tv_orthonormalize_t(T)
+    assert np.allclose(Q @ Q.T, np.eye(R), atol=1e-10)
+
+
+def test_scoring_against_numpy():
+    rng = np.random.default_rng(1)
+    d, M, S = 9, 6, 8
+    m = rng.normal(size=(d, M)); s = rng.normal(size=(d, S))
+    cos = (m.T @ s) / np.outer(np.linalg.norm(m, axis=0), np.linalg.norm(s, axis=0))
+    assert np.allclose(orc.score_cosine(m, s), cos)
+    tr = rng.random((M, S)) > 0.5
+    assert np.allclose(orc.score_cosine(m, s, tr), np.where(tr, cos, 0))
+    Q = rng.normal(size=(d, d)); Mah = Q @ Q.T + np.eye(d)
+    diff = m[:, :, None] - s[:, None, :]
+    assert np.allclose(orc.score_mahalanobis(m, s, Mah), -0.5 * np.einsum("ims,ij,jms->ms", diff, Mah, diff))
+    Wm = Q @ Q.T / d + np.eye(d); Bm = 2 * np.eye(d) + 0.1 * (Q + Q.T) @ (Q + Q.T).T / d
+    G, H = orc.twocov_model(Wm, Bm)
+    iW, iB = np.linalg.inv(Wm), np.linalg.inv(Bm)
+    assert np.allclose(G, iW @ np.linalg.inv(iB + 2 * iW) @ iW) and np.allclose(H, iW @ np.linalg.inv(iB + iW) @ iW)
+    sm = m[:, :, None] + s[:, None, :]
+    ref = np.einsum("ims,ij,jms->ms", sm, G, sm) - np.einsum("im,ij,jm->m", m, H, m)[:, None] - np.einsum("is,ij,js->s", s, H, s)[None]
+    assert np.allclose(orc.score_twocov(m, s, G, H), ref)
+    Fm = rng.normal(size=(20, d)); FTJF = Fm.T @ Fm / 20
+    nsess = np.array([1, 1, 2, 2, 2, 1])
+    K = lambda n: np.linalg.inv(n * FTJF + np.eye(d))
+    al = lambda n: np.linalg.slogdet(K(n))[1]
+    ref = np.empty((M, S))
+    for i in range(M):
+        L = nsess[i]
+        for j in range(S):
+            v = s[:, j] + m[:, i]
+            ref[i, j] = 0.5 * (v @ K(L + 1) @ v - m[:, i] @ K(L) @ m[:, i] - s[:, j] @ K(1) @ s[:, j]) + 0.5 * (al(L + 1) - al(L) - al(1))
+    assert np.allclose(orc.score_plda(m, nsess, s, FTJF), ref)
