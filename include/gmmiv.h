@@ -70,6 +70,13 @@ void gmmiv_gmm_destroy(gmmiv_gmm *g);
 int gmmiv_frame_moments(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t T, int64_t ldx, int D,
                         double *acc);
 
+/* ---- frame selection on the device: out[i][0..D) = x[frame_idx[i]][0..D) ----------------------
+ * Replaces the seekFeature/readFeature walk over a SegCluster (label selection, bagging:
+ * LIA_SpkTools/src/AccumulateStat.cpp:121-128, GeneralTools.cpp:455-510) for features that stay
+ * resident in HBM.  x, out: DEVICE arrays (out has ld = D); frame_idx: host or device. */
+int gmmiv_gather_frames(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t ldx, int D,
+                        const int64_t *frame_idx, int64_t n, void *out);
+
 /* ---- MixtureStat::computeAndAccumulateLLK(f,1.0,TOP_DISTRIBS_NO_ACTION) loop -------------------
  * (LIA_SpkTools/src/AccumulateStat.cpp:69-94, :344-379; AccumulateTVStat.cpp:1644-1648)
  * llk_out[T] (nullable) = clamp(log sum_c w_c lk_c(x_t), min_llk, max_llk);

@@ -230,6 +230,23 @@ int gmmiv_frame_moments(gmmiv_ctx *c, const void *x, int dt, int64_t T, int64_t 
     return o.finish();
 }
 
+// ---- frame selection -------------------------------------------------------------------------
+int gmmiv_gather_frames(gmmiv_ctx *c, const void *x, int dt, int64_t ldx, int D, const int64_t *frame_idx, int64_t n,
+                        void *out)
+{
+    if (!c || !x || !out || !frame_idx || n < 0 || D <= 0 || ldx < D) { gmmiv_set_error("gather_frames: bad argument"); return GMMIV_ERR_ARG; }
+    if (!gmmiv_is_device_ptr(x) || !gmmiv_is_device_ptr(out)) { gmmiv_set_error("gather_frames: x and out must be device arrays"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    DevIn<int64_t> i_idx;
+    int rc = i_idx.init(c, WS_T0, frame_idx, (size_t)n);
+    if (rc) return rc;
+    c->t_begin("k_gather_frames");
+    GCHK(gmmk_gather_frames(c->stream, dt == GMMIV_F64, x, ldx, D, (const long *)i_idx.d, n, out));
+    c->t_end();
+    if (!gmmiv_is_device_ptr(frame_idx)) GCHK(hipStreamSynchronize(c->stream)); // host index list may be freed
+    return GMMIV_OK;
+}
+
 // ---- LLK ---------------------------------------------------------------------------------
 static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, double **lse_out)
 {

@@ -31,3 +31,4 @@ int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ld
 int gmmk_variance_control(hipStream_t st, int C, int D, double *cov, double flooring, double ceiling,
                           const double *cov_signal, unsigned long long *counts);
 int gmmk_reciprocal(hipStream_t st, long n, const double *in, double *out);
+int gmmk_gather_frames(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *idx, long n, void *out);

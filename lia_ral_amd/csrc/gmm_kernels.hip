@@ -435,6 +435,19 @@ __global__ void k_em_get(int C, int D, const double *__restrict__ acc, const dou
     }
 }
 
+// out[i][0..D) = x[idx[i]][0..D)   (frame selection: label segments / bagging, on the device)
+template <typename XT>
+__global__ __launch_bounds__(256) void k_gather_frames(const XT *__restrict__ x, long ldx, int D,
+                                                       const long *__restrict__ idx, long n, XT *__restrict__ out)
+{
+    const long tot = n * D;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / D;
+        const int d = (int)(e - i * D);
+        out[e] = x[idx[i] * ldx + d];
+    }
+}
+
 // varianceControl (TrainTools.cpp:567-587): floor first, then ceiling; counts[0/1] += hits
 __global__ void k_variance_control(int C, int D, double *__restrict__ cov, double flooring, double ceiling,
                                    const double *__restrict__ cov_signal, unsigned long long *__restrict__ counts)
@@ -751,6 +764,16 @@ int gmmk_em_get(hipStream_t st, int C, int D, const double *acc, const double *p
 {
     const long n = (long)C * D;
     k_em_get<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(C, D, acc, prev_mean, prev_cov, w, mean, cov);
+    return (int)hipGetLastError();
+}
+
+int gmmk_gather_frames(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *idx, long n, void *out)
+{
+    if (n <= 0) return 0;
+    const long tot = n * D;
+    const unsigned blocks = (unsigned)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256);
+    if (x_f64) k_gather_frames<double><<<blocks, 256, 0, st>>>((const double *)x, ldx, D, idx, n, (double *)out);
+    else k_gather_frames<float><<<blocks, 256, 0, st>>>((const float *)x, ldx, D, idx, n, (float *)out);
     return (int)hipGetLastError();
 }
 

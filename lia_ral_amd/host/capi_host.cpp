@@ -1,0 +1,136 @@
+// capi_host.cpp -- flat C entry points over liatools_gpu (used by the Python tests / tools; a C++
+// caller includes liatools_gpu.h directly).  Every function returns 0 or -1 (+ liagpu_last_error()),
+// mirroring the reference tools' "catch, print, carry on" drivers.
+#include <string.h>
+
+#include "liatools_gpu.h"
+
+using namespace liagpu;
+
+static thread_local std::string g_err;
+#define GUARD(...)                                          \
+    try { __VA_ARGS__; return 0; }                              \
+    catch (const std::exception &e) { g_err = e.what(); return -1; }
+
+static SegCluster make_cluster(const long *begin, const long *len, long n)
+{
+    SegCluster c(n);
+    for (long i = 0; i < n; ++i) { c[i].begin = (unsigned long)begin[i]; c[i].length = (unsigned long)len[i]; c[i].source = 0; }
+    return c;
+}
+static MixtureGD make_mixture(int C, int D, const double *w, const double *mean, const double *cov)
+{
+    MixtureGD m(C, D);
+    m.weights().assign(w, w + C);
+    m.means().assign(mean, mean + (size_t)C * D);
+    m.covs().assign(cov, cov + (size_t)C * D);
+    m.computeAll();
+    return m;
+}
+
+extern "C" {
+
+const char *liagpu_last_error(void) { return g_err.c_str(); }
+
+// TrainWorld: computeMeanCov -> trainModelStream (TrainWorld.cpp:101-191 minus file I/O and mixtureInit)
+int liagpu_train_world(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                       int C, double *w, double *mean, double *cov, int nbTrainIt, double baggedFrameProbability,
+                       double initVarFloor, double finalVarFloor, double initVarCeil, double finalVarCeil,
+                       long initRand, double *global_mean_out, double *global_cov_out, double *llk_it_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        std::vector<double> gm, gc;
+        computeMeanCov(fs, segs, gm, gc);
+        if (global_mean_out) memcpy(global_mean_out, gm.data(), D * sizeof(double));
+        if (global_cov_out) memcpy(global_cov_out, gc.data(), D * sizeof(double));
+        MixtureGD world = make_mixture(C, D, w, mean, cov);
+        TrainCfg cfg;
+        cfg.nbTrainIt = nbTrainIt; cfg.baggedFrameProbability = baggedFrameProbability;
+        cfg.initVarianceFlooring = initVarFloor; cfg.finalVarianceFlooring = finalVarFloor;
+        cfg.initVarianceCeiling = initVarCeil; cfg.finalVarianceCeiling = finalVarCeil;
+        cfg.initRand = (unsigned long)initRand;
+        std::vector<double> llk = trainModelStream(cfg, fs, segs, gc, world);
+        memcpy(w, world.weights().data(), C * sizeof(double));
+        memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
+        if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
+    })
+}
+
+// ComputeTest for one test file: world + nClients models (same C, D), covariances given as covInv
+int liagpu_compute_test(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                        int C, const double *w_world, const double *mean_world, const double *cov_world, int nClients,
+                        const double *w_cl, const double *mean_cl, const double *cov_cl, int topDistribsCount,
+                        int complete, double minLLK, double maxLLK, int segmentalMode, double *llr_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD world = make_mixture(C, D, w_world, mean_world, cov_world);
+        DeviceMixture dworld(srv, world);
+        std::vector<DeviceMixture *> cl;
+        const size_t CD = (size_t)C * D;
+        for (int i = 0; i < nClients; ++i)
+            cl.push_back(new DeviceMixture(srv, make_mixture(C, D, w_cl + (size_t)i * C, mean_cl + i * CD, cov_cl + i * CD)));
+        std::vector<double> out;
+        try { out = computeTestLLR(fs, segs, dworld, cl, topDistribsCount, complete != 0, minLLK, maxLLK, segmentalMode != 0); }
+        catch (...) { for (auto p : cl) delete p; throw; }
+        for (auto p : cl) delete p;
+        memcpy(llr_out, out.data(), out.size() * sizeof(double));
+    })
+}
+
+// IvExtractor (IvExtractor.cpp:70-148): stats -> substractM -> estimateTETt -> estimateW
+int liagpu_iv_extract(int device, const float *x, long T, int D, const long *utt_begin, long U, int C, const double *w,
+                      const double *mean, const double *cov, int R, const double *Tmat, double *W_out, double *N_out,
+                      double *F_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        TVAcc tv(srv, ubm, (unsigned long)R, (unsigned long)U);
+        std::vector<SegCluster> lines(U);
+        for (long u = 0; u < U; ++u) {
+            Seg s; s.begin = (unsigned long)utt_begin[u]; s.length = (unsigned long)(utt_begin[u + 1] - utt_begin[u]); s.source = 0;
+            if (s.length) lines[u].push_back(s);
+        }
+        tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
+        tv.computeAndAccumulateTVStat(fs, lines);
+        if (N_out) memcpy(N_out, tv.getN().data(), tv.getN().size() * sizeof(double));
+        if (F_out) memcpy(F_out, tv.getF().data(), tv.getF().size() * sizeof(double));
+        tv.substractM();
+        tv.estimateTETt();
+        tv.estimateW();
+        memcpy(W_out, tv.getW().data(), tv.getW().size() * sizeof(double));
+    })
+}
+
+// TotalVariability (TotalVariability.cpp:118-169): nbIt iterations on precomputed N, F
+int liagpu_tv_train(int device, long U, int C, int D, const double *w, const double *mean, const double *cov, int R,
+                    const double *N, const double *F, double *Tmat, int nbIt, int minDiv, double *mean_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        TVAcc tv(srv, ubm, (unsigned long)R, (unsigned long)U);
+        tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
+        const std::vector<double> N0(N, N + (size_t)U * C), F0(F, F + (size_t)U * C * D);
+        for (int it = 0; it < nbIt; ++it) {
+            tv.setStats(N0, F0);   // the reference reloads N and F every iteration (:152-153)
+            tv.substractM();
+            tv.estimateTETt();
+            tv.estimateAandC();
+            tv.updateTestimate();
+            if (minDiv) tv.minDivergence();
+        }
+        memcpy(Tmat, tv.getT().data(), tv.getT().size() * sizeof(double));
+        if (mean_out) memcpy(mean_out, tv.getUbmMeans().data(), tv.getUbmMeans().size() * sizeof(double));
+    })
+}
+
+} // extern "C"

@@ -1,0 +1,391 @@
+// liatools_gpu.cpp -- see liatools_gpu.h.  Host control flow of the LIA_SpkTools hot-path drivers;
+// all frame x Gaussian arithmetic happens in libgmmiv (HIP kernels).
+#include "liatools_gpu.h"
+
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace liagpu {
+
+static void hipcheck(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) throw Exception(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+unsigned long totalFrame(const SegCluster &c)
+{
+    unsigned long n = 0;
+    for (const Seg &s : c) n += s.length;
+    return n;
+}
+
+Seg segFromLabel(double begin_s, double end_s, double frameLength, unsigned long source)
+{
+    // SegTools.cpp:265-271: frame index = time / frameLength (rounded), end frame INCLUSIVE
+    Seg s;
+    const unsigned long b = (unsigned long)(begin_s / frameLength + 0.5), e = (unsigned long)(end_s / frameLength + 0.5);
+    s.begin = b;
+    s.length = e - b + 1;
+    s.source = source;
+    return s;
+}
+
+// ---- GpuServer ---------------------------------------------------------------------------------
+GpuServer::GpuServer(int device)
+{
+    if (gmmiv_ctx_create(device, nullptr, &_ctx) != 0) throw Exception(gmmiv_last_error());
+}
+GpuServer::~GpuServer() { gmmiv_ctx_destroy(_ctx); }
+void GpuServer::check(int rc) const
+{
+    if (rc != 0) throw Exception(gmmiv_last_error());
+}
+
+// ---- FeatureBuffer -----------------------------------------------------------------------------
+FeatureBuffer::FeatureBuffer(GpuServer &srv, const float *frames, unsigned long nFrames, unsigned long vectSize,
+                             const std::vector<unsigned long> &sourceFirstFrame)
+    : _srv(srv), _n(nFrames), _d(vectSize), _first(sourceFirstFrame)
+{
+    const size_t bytes = (size_t)(nFrames ? nFrames : 1) * vectSize * sizeof(float);
+    hipcheck(hipMalloc((void **)&_dev, bytes), "FeatureBuffer: hipMalloc");
+    if (nFrames) hipcheck(hipMemcpy(_dev, frames, (size_t)nFrames * vectSize * sizeof(float), hipMemcpyHostToDevice), "FeatureBuffer: upload");
+}
+FeatureBuffer::~FeatureBuffer()
+{
+    if (_dev) (void)hipFree(_dev);
+    if (_sel) (void)hipFree(_sel);
+}
+
+const float *FeatureBuffer::select(const SegCluster &c, unsigned long &nSelected)
+{
+    // expand the cluster into the frame index list the reference walks with seekFeature/readFeature
+    std::vector<int64_t> idx;
+    idx.reserve(totalFrame(c));
+    bool contiguous = true;
+    for (const Seg &s : c) {
+        const unsigned long b = s.begin + getFirstFeatureIndexOfASource(s.source);
+        if (b + s.length > _n) throw Exception("segment ends after the last frame of the feature buffer");
+        if (!idx.empty() && (unsigned long)idx.back() + 1 != b) contiguous = false;
+        for (unsigned long i = 0; i < s.length; ++i) idx.push_back((int64_t)(b + i));
+    }
+    nSelected = idx.size();
+    if (nSelected == 0) return _dev;
+    if (contiguous) return _dev + (size_t)idx[0] * _d; // one contiguous run: no copy
+    if (_selCap < nSelected) {
+        if (_sel) hipcheck(hipFree(_sel), "FeatureBuffer: hipFree");
+        _selCap = nSelected + nSelected / 8;
+        hipcheck(hipMalloc((void **)&_sel, (size_t)_selCap * _d * sizeof(float)), "FeatureBuffer: hipMalloc(select)");
+    }
+    _srv.check(gmmiv_gather_frames(_srv.ctx(), _dev, GMMIV_F32, (int64_t)_d, (int)_d, idx.data(), (int64_t)nSelected, _sel));
+    return _sel;
+}
+
+// ---- MixtureGD ---------------------------------------------------------------------------------
+MixtureGD::MixtureGD(unsigned long distribCount, unsigned long vectSize)
+    : _c(distribCount), _d(vectSize), _w(distribCount, 1.0 / distribCount), _mean(distribCount * vectSize, 0.0),
+      _cov(distribCount * vectSize, 1.0), _covInv(distribCount * vectSize, 1.0)
+{
+}
+void MixtureGD::computeAll()
+{
+    for (size_t i = 0; i < _cov.size(); ++i) _covInv[i] = 1.0 / _cov[i];
+}
+
+DeviceMixture::DeviceMixture(GpuServer &srv, const MixtureGD &m) : _srv(srv)
+{
+    MixtureGD &mm = const_cast<MixtureGD &>(m);
+    srv.check(gmmiv_gmm_create(srv.ctx(), (int)m.getDistribCount(), (int)m.getVectSize(), mm.weights().data(), mm.means().data(),
+                               m.covInvs().data(), &_g));
+}
+DeviceMixture::~DeviceMixture() { gmmiv_gmm_destroy(_g); }
+void DeviceMixture::update(const MixtureGD &m)
+{
+    MixtureGD &mm = const_cast<MixtureGD &>(m);
+    _srv.check(gmmiv_gmm_set(_g, mm.weights().data(), mm.means().data(), m.covInvs().data()));
+}
+
+// ---- EMAcc -------------------------------------------------------------------------------------
+EMAcc::EMAcc(DeviceMixture &dm, const MixtureGD &model)
+    : _dm(dm), _model(model), _acc(gmmiv_em_acc_len((int)model.getDistribCount(), (int)model.getVectSize()), 0.0)
+{
+}
+void EMAcc::resetEM() { std::fill(_acc.begin(), _acc.end(), 0.0); }
+void EMAcc::addAccEM(const EMAcc &o)
+{
+    for (size_t i = 0; i < _acc.size(); ++i) _acc[i] += o._acc[i];
+}
+MixtureGD EMAcc::getEM() const
+{
+    MixtureGD out = _model;
+    MixtureGD &m = const_cast<MixtureGD &>(_model);
+    GpuServer &srv = const_cast<DeviceMixture &>(_dm).server();
+    srv.check(gmmiv_em_get(srv.ctx(), (int)m.getDistribCount(), (int)m.getVectSize(), _acc.data(), m.means().data(), m.covs().data(),
+                           out.weights().data(), out.means().data(), out.covs().data()));
+    out.computeAll();
+    return out;
+}
+
+std::vector<double> FrameAccGD::getMeanVect() const
+{
+    std::vector<double> m(vectSize);
+    for (unsigned long i = 0; i < vectSize; ++i) m[i] = acc[i] / acc[2 * vectSize];
+    return m;
+}
+std::vector<double> FrameAccGD::getCovVect() const
+{
+    std::vector<double> c(vectSize);
+    const double n = acc[2 * vectSize];
+    for (unsigned long i = 0; i < vectSize; ++i) {
+        const double m = acc[i] / n;
+        c[i] = acc[vectSize + i] / n - m * m;
+    }
+    return c;
+}
+
+// ---- AccumulateStat ------------------------------------------------------------------------------
+double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments, double weight)
+{
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    std::vector<double> &a = emAcc.flat();
+    const double before = a[a.size() - 2];
+    srv.check(gmmiv_em_accumulate(srv.ctx(), emAcc.mixture().handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), weight, a.data()));
+    return a[a.size() - 2] - before; // weight * sum log lk of this call (AccumulateStat.cpp:143-152)
+}
+double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments)
+{
+    return accumulateStatEM(fs, emAcc, selectedSegments, 1.0);
+}
+
+double accumulateStatLLK(FeatureBuffer &fs, DeviceMixture &m, const SegCluster &selectedSegments, double minLLK, double maxLLK)
+{
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    double sums[2] = {0.0, 0.0};
+    srv.check(gmmiv_llk(srv.ctx(), m.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), minLLK, maxLLK, nullptr, sums));
+    return sums[1] > 0 ? sums[0] / sums[1] : 0.0;
+}
+
+void accumulateStatFrame(FrameAccGD &frameAcc, FeatureBuffer &fs, const SegCluster &selectedSegments)
+{
+    if (frameAcc.acc.empty()) {
+        frameAcc.vectSize = fs.getVectSize();
+        frameAcc.acc.assign(2 * frameAcc.vectSize + 1, 0.0);
+    }
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    srv.check(gmmiv_frame_moments(srv.ctx(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), (int)fs.getVectSize(), frameAcc.acc.data()));
+}
+
+// ---- TrainTools ------------------------------------------------------------------------------------
+double setItParameter(double begin, double end, int nbIt, int it)
+{
+    if (nbIt < 2) return begin;
+    const double itVal = (begin - end) / ((double)nbIt - 1);
+    return begin - itVal * it;
+}
+
+void varianceControl(MixtureGD &model, double flooring, double ceiling, const std::vector<double> &covSignal)
+{
+    const unsigned long C = model.getDistribCount(), D = model.getVectSize();
+    for (unsigned long c = 0; c < C; ++c)
+        for (unsigned long v = 0; v < D; ++v) {
+            double cov = model.getCov(c, v);
+            if (cov <= flooring * covSignal[v]) cov = flooring * covSignal[v];
+            if (cov >= ceiling * covSignal[v]) cov = ceiling * covSignal[v];
+            model.setCov(c, cov, v);
+        }
+    model.computeAll();
+}
+
+unsigned long computeMeanCov(FeatureBuffer &fs, const SegCluster &seg, std::vector<double> &mean, std::vector<double> &cov)
+{
+    FrameAccGD acc;
+    accumulateStatFrame(acc, fs, seg);
+    mean = acc.getMeanVect();
+    cov = acc.getCovVect();
+    return acc.getCount();
+}
+
+static bool baggedFrame(double p) { return ((double)rand() / (double)RAND_MAX) < p; }
+
+void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedFrameSegment, double baggedProbability,
+                    unsigned long minimumLength, unsigned long maximumLength)
+{
+    size_t cur = 0;
+    bool end = selectedSegments.empty();
+    unsigned long beginSeg = 0, lengthSeg = 0;
+    if (!end) { beginSeg = selectedSegments[0].begin; lengthSeg = selectedSegments[0].length; }
+    while (!end) {
+        unsigned long verifyLength = lengthSeg;
+        if (verifyLength < minimumLength) verifyLength = minimumLength;
+        if (verifyLength > maximumLength) verifyLength = maximumLength;
+        bool moveSeg;
+        unsigned long length;
+        if (lengthSeg <= verifyLength) { moveSeg = true; length = lengthSeg; }
+        else { moveSeg = false; length = verifyLength; }
+        if (length > 0 && baggedFrame(baggedProbability)) {
+            Seg s;
+            s.begin = beginSeg; s.length = length; s.source = selectedSegments[cur].source;
+            baggedFrameSegment.push_back(s);
+        }
+        if (moveSeg) {
+            ++cur;
+            end = cur >= selectedSegments.size();
+            if (!end) { beginSeg = selectedSegments[cur].begin; lengthSeg = selectedSegments[cur].length; }
+        } else {
+            lengthSeg -= length;
+            beginSeg += length;
+        }
+    }
+}
+
+std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
+                                     const std::vector<double> &globalCov, MixtureGD &world, AllReduceFn allReduce, void *user)
+{
+    std::vector<double> llkIt;
+    DeviceMixture dworld(fs.server(), world);
+    const unsigned long stream = 0;
+    for (unsigned long trainIt = 0; trainIt < cfg.nbTrainIt; ++trainIt) {
+        EMAcc emAcc(dworld, world);
+        const double varianceFlooring = setItParameter(cfg.initVarianceFlooring, cfg.finalVarianceFlooring, (int)cfg.nbTrainIt, (int)trainIt);
+        const double varianceCeiling = setItParameter(cfg.initVarianceCeiling, cfg.finalVarianceCeiling, (int)cfg.nbTrainIt, (int)trainIt);
+        const unsigned long nbTotalFrame = totalFrame(selectedSegments);
+        const double nbFrameToSelect = cfg.baggedFrameProbability * nbTotalFrame;
+        emAcc.resetEM();
+        double llkPreviousIt = 0.0;
+        unsigned long nbBaggedIt = 1;
+        double baggedProba = nbFrameToSelect / (double)nbTotalFrame;
+        if (baggedProba > 1) {
+            nbBaggedIt = (unsigned long)baggedProba + 1;
+            baggedProba /= nbBaggedIt;
+        }
+        for (unsigned long baggedIt = 0; baggedIt < nbBaggedIt; ++baggedIt) {
+            SegCluster baggedFramesCluster;
+            srand((unsigned)(((trainIt + 1 + cfg.initRand) * 200) + (((stream + 1) * 20) + (baggedIt + 1)))); // TrainTools.cpp:1070
+            baggedSegments(selectedSegments, baggedFramesCluster, baggedProba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
+            llkPreviousIt += accumulateStatEM(fs, emAcc, baggedFramesCluster);
+        }
+        if (allReduce) allReduce(emAcc.flat().data(), emAcc.flat().size(), user); // sum over ranks == addAccEM over threads
+        llkPreviousIt = emAcc.getAccumulatedLLK() / emAcc.getEMFeatureCount();
+        world = emAcc.getEM();
+        varianceControl(world, varianceFlooring, varianceCeiling, globalCov);
+        dworld.update(world);
+        llkIt.push_back(llkPreviousIt);
+    }
+    return llkIt;
+}
+
+// ---- ComputeTest -------------------------------------------------------------------------------------
+std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selectedSegments, DeviceMixture &world,
+                                   std::vector<DeviceMixture *> &clients, int topDistribsCount, bool complete,
+                                   double minLLK, double maxLLK, bool segmentalMode)
+{
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
+    std::vector<int32_t> idx((size_t)n * topDistribsCount);
+    std::vector<double> nllk(n), llkw(n), llkc(n);
+    // world: DETERMINE_TOP_DISTRIBS on every frame (worldDecime = 1)
+    srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount, mode,
+                                      minLLK, maxLLK, idx.data(), nullptr, nullptr, nllk.data(), nullptr, llkw.data()));
+    const size_t nseg = segmentalMode ? selectedSegments.size() : 1;
+    std::vector<double> out(nseg * clients.size(), 0.0);
+    auto meanOver = [&](const std::vector<double> &v, size_t b, size_t e) {
+        double s = 0.0;
+        for (size_t i = b; i < e; ++i) s += v[i];
+        return e > b ? s / (double)(e - b) : 0.0;
+    };
+    for (size_t ci = 0; ci < clients.size(); ++ci) {
+        // clients: USE_TOP_DISTRIBS with the world's indices (+ the world's non-top remainder if COMPLETE)
+        srv.check(gmmiv_llk_use_top(srv.ctx(), clients[ci]->handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount,
+                                    idx.data(), nllk.data(), mode, minLLK, maxLLK, llkc.data()));
+        size_t off = 0;
+        for (size_t s = 0; s < nseg; ++s) {
+            const size_t len = segmentalMode ? selectedSegments[s].length : n;
+            out[s * clients.size() + ci] = meanOver(llkc, off, off + len) - meanOver(llkw, off, off + len);
+            off += len;
+        }
+    }
+    return out;
+}
+
+// ---- TVAcc -----------------------------------------------------------------------------------------
+TVAcc::TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned long nSpeakers)
+    : _srv(srv), _ubm(ubm), _dubm(srv, ubm), _rankT(rankT), _n_speakers(nSpeakers), _n_distrib(ubm.getDistribCount()),
+      _vectSize(ubm.getVectSize()), _svSize(ubm.getDistribCount() * ubm.getVectSize())
+{
+    _ubm_means = _ubm.means();          // supervector of means / inverse variances (AccumulateTVStat.cpp:154-162)
+    _ubm_invvar = _ubm.covInvs();
+    _statN.assign(_n_speakers * _n_distrib, 0.0);
+    _statF.assign(_n_speakers * _svSize, 0.0);
+    _T.assign(_rankT * _svSize, 0.0);
+    _W.assign(_n_speakers * _rankT, 0.0);
+    _TETt.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankT), 0.0);
+    resetTmpAcc();
+}
+
+void TVAcc::resetTmpAcc()
+{
+    _A.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankT), 0.0);
+    _Cmx.assign(_rankT * _svSize, 0.0);
+    _R.assign(_rankT * _rankT, 0.0);
+    _r.assign(_rankT, 0.0);
+    _meanW.assign(_rankT, 0.0);
+}
+
+void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerLine)
+{
+    if (segsPerLine.size() != _n_speakers) throw Exception("computeAndAccumulateTVStat: one SegCluster per ndx line expected");
+    // all selected frames, line after line, then one batched call (rows are overwritten)
+    SegCluster all;
+    std::vector<int64_t> uttBegin(_n_speakers + 1, 0);
+    for (unsigned long u = 0; u < _n_speakers; ++u) {
+        for (const Seg &s : segsPerLine[u]) all.push_back(s);
+        uttBegin[u + 1] = uttBegin[u] + (int64_t)totalFrame(segsPerLine[u]);
+    }
+    unsigned long n = 0;
+    const float *x = fs.select(all, n);
+    _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), uttBegin.data(),
+                              (int64_t)_n_speakers, _statN.data(), _statF.data()));
+}
+
+void TVAcc::substractM()
+{
+    _srv.check(gmmiv_tv_subtract_m(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.data(), _statF.data(), _ubm_means.data()));
+}
+void TVAcc::estimateTETt()
+{
+    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), _ubm_invvar.data(), _TETt.data()));
+}
+void TVAcc::estimateW()
+{
+    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(), _statF.data(),
+                                   _T.data(), _ubm_invvar.data(), _TETt.data(), _W.data()));
+}
+void TVAcc::estimateAandC()
+{
+    resetTmpAcc(); // the reference zeroes A, C, R, r, meanW at entry (:1712-1722)
+    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
+                                         _statF.data(), _T.data(), _ubm_invvar.data(), _TETt.data(), _W.data(), _A.data(), _Cmx.data(),
+                                         _R.data(), _r.data(), _meanW.data()));
+    for (double &v : _meanW) v /= (double)_n_speakers; // :1791-1794
+}
+void TVAcc::updateTestimate()
+{
+    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _A.data(), _Cmx.data(), _T.data()));
+}
+void TVAcc::minDivergence()
+{
+    // _n_sessions == number of statistics rows in TotalVariability (one session per line)
+    _srv.check(gmmiv_tv_min_divergence(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, (double)_n_speakers, _R.data(), _r.data(),
+                                       _meanW.data(), _ubm_means.data(), _T.data()));
+}
+
+} // namespace liagpu

@@ -1,0 +1,203 @@
+// liatools_gpu.h -- C++ host side above the C ABI (include/gmmiv.h): the LIA_SpkTools driver
+// functions of the hot path, same names / argument meaning / error behaviour as the reference,
+// with the per-frame ALIZE calls replaced by batched calls into libgmmiv (HIP, gfx950).
+//
+// The ALIZE container types are not available (alize-core is external to LIA_RAL), so minimal
+// stand-ins carry the same information: Seg/SegCluster (begin, length, source), FeatureBuffer
+// (a FeatureServer with featureServerBufferSize = ALL_FEATURES, resident in HBM), MixtureGD
+// (weights, means, covariances + computeAll()).  Errors throw liagpu::Exception, which a tool
+// driver catches and prints exactly like `catch (Exception& e) { cout << e.toString(); }`
+// (LIA_SpkDet/TrainWorld/src/TrainWorld.cpp:187-190).
+#pragma once
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gmmiv.h"
+
+namespace liagpu {
+
+struct Exception : std::runtime_error {
+    explicit Exception(const std::string &m) : std::runtime_error(m) {}
+    std::string toString() const { return std::string("[gmmiv::Exception] ") + what(); }
+};
+
+// SegTools.cpp:265-271: a label "begin_s end_s" selects frames begin..end INCLUSIVE (length = end-begin+1)
+struct Seg {
+    unsigned long begin = 0, length = 0;
+    unsigned long source = 0; // index of the feature file in the FeatureBuffer
+};
+typedef std::vector<Seg> SegCluster;
+unsigned long totalFrame(const SegCluster &c);
+Seg segFromLabel(double begin_s, double end_s, double frameLength, unsigned long source = 0);
+
+class GpuServer; // context owner (the StatServer/MixtureServer pair of the reference)
+
+// FeatureServer(ALL_FEATURES): all frames of all sources, float32 like SPro files, device resident.
+class FeatureBuffer {
+  public:
+    FeatureBuffer(GpuServer &srv, const float *frames, unsigned long nFrames, unsigned long vectSize,
+                  const std::vector<unsigned long> &sourceFirstFrame = std::vector<unsigned long>(1, 0));
+    ~FeatureBuffer();
+    unsigned long getVectSize() const { return _d; }
+    unsigned long getFeatureCount() const { return _n; }
+    unsigned long getFirstFeatureIndexOfASource(unsigned long s) const { return _first.at(s); }
+    const float *device() const { return _dev; }
+    // device matrix [n x D] of the frames selected by the cluster, in cluster order
+    const float *select(const SegCluster &c, unsigned long &nSelected);
+    GpuServer &server() { return _srv; }
+
+  private:
+    GpuServer &_srv;
+    float *_dev = nullptr, *_sel = nullptr;
+    unsigned long _n, _d, _selCap = 0;
+    std::vector<unsigned long> _first;
+};
+
+// MixtureGD / DistribGD: weight(c), getMean/getCov/getCovInv, setMean/setCov, computeAll()
+class MixtureGD {
+  public:
+    MixtureGD(unsigned long distribCount, unsigned long vectSize);
+    unsigned long getDistribCount() const { return _c; }
+    unsigned long getVectSize() const { return _d; }
+    double &weight(unsigned long c) { return _w[c]; }
+    double weight(unsigned long c) const { return _w[c]; }
+    double getMean(unsigned long c, unsigned long i) const { return _mean[c * _d + i]; }
+    double getCov(unsigned long c, unsigned long i) const { return _cov[c * _d + i]; }
+    double getCovInv(unsigned long c, unsigned long i) const { return _covInv[c * _d + i]; }
+    void setMean(unsigned long c, double v, unsigned long i) { _mean[c * _d + i] = v; }
+    void setCov(unsigned long c, double v, unsigned long i) { _cov[c * _d + i] = v; }
+    void computeAll(); // covInv = 1/cov (cst, det are derived on the device)
+    std::vector<double> &weights() { return _w; }
+    std::vector<double> &means() { return _mean; }
+    std::vector<double> &covs() { return _cov; }
+    const std::vector<double> &covInvs() const { return _covInv; }
+
+  private:
+    unsigned long _c, _d;
+    std::vector<double> _w, _mean, _cov, _covInv;
+};
+
+// Owns the gmmiv context (one per GPU).  createAndStoreMixtureStat() -> EMAcc / LLKAcc below.
+class GpuServer {
+  public:
+    explicit GpuServer(int device = 0);
+    ~GpuServer();
+    gmmiv_ctx *ctx() { return _ctx; }
+    void check(int rc) const; // throws Exception(gmmiv_last_error()) on rc != 0
+
+  private:
+    gmmiv_ctx *_ctx = nullptr;
+};
+
+// Device copy of a MixtureGD
+class DeviceMixture {
+  public:
+    DeviceMixture(GpuServer &srv, const MixtureGD &m);
+    ~DeviceMixture();
+    void update(const MixtureGD &m);
+    gmmiv_gmm *handle() const { return _g; }
+    GpuServer &server() { return _srv; }
+
+  private:
+    GpuServer &_srv;
+    gmmiv_gmm *_g = nullptr;
+};
+
+// MixtureStat in EM mode: resetEM / computeAndAccumulateEM (batched) / getEM / getEMFeatureCount / addAccEM
+class EMAcc {
+  public:
+    EMAcc(DeviceMixture &dm, const MixtureGD &model);
+    void resetEM();
+    double getEMFeatureCount() const { return _acc.back(); }
+    double getAccumulatedLLK() const { return _acc[_acc.size() - 2]; }
+    MixtureGD getEM() const; // ML weights / means / covariances; occ == 0 keeps the model's values
+    void addAccEM(const EMAcc &o);
+    std::vector<double> &flat() { return _acc; } // the all-reduce payload
+    DeviceMixture &mixture() { return _dm; }
+
+  private:
+    DeviceMixture &_dm;
+    MixtureGD _model;
+    std::vector<double> _acc;
+};
+
+// FrameAccGD
+struct FrameAccGD {
+    std::vector<double> acc; // [sum | sumsq | n]
+    unsigned long vectSize = 0;
+    unsigned long getCount() const { return acc.empty() ? 0 : (unsigned long)acc.back(); }
+    std::vector<double> getMeanVect() const;
+    std::vector<double> getCovVect() const; // biased: sumsq/n - mean^2
+};
+
+// ---- AccumulateStat.h --------------------------------------------------------------------------
+// accumulateStatEM (AccumulateStat.cpp:103-152): returns sum_t log lk_t over the cluster
+double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments);
+double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments, double weight);
+// accumulateStatLLK (AccumulateStat.cpp:69-94): mean clamped llk over the cluster (getMeanLLK)
+double accumulateStatLLK(FeatureBuffer &fs, DeviceMixture &m, const SegCluster &selectedSegments, double minLLK,
+                         double maxLLK);
+// accumulateStatFrame (AccumulateStat.cpp:387-410)
+void accumulateStatFrame(FrameAccGD &frameAcc, FeatureBuffer &fs, const SegCluster &selectedSegments);
+
+// ---- TrainTools.h ------------------------------------------------------------------------------
+struct TrainCfg { // TrainTools.cpp:67-93
+    double initVarianceFlooring = 0.0, initVarianceCeiling = 10.0, finalVarianceFlooring = 0.0, finalVarianceCeiling = 10.0;
+    unsigned long nbTrainIt = 1;
+    double baggedFrameProbability = 1.0;
+    unsigned long baggedMinimalLength = 3, baggedMaximalLength = 7, initRand = 0;
+};
+double setItParameter(double begin, double end, int nbIt, int it);                                 // :560-564
+void varianceControl(MixtureGD &model, double flooring, double ceiling, const std::vector<double> &covSignal); // :567-587
+unsigned long computeMeanCov(FeatureBuffer &fs, const SegCluster &seg, std::vector<double> &mean, std::vector<double> &cov); // :593-611
+// GeneralTools.cpp:455-510 with glibc rand() (baggedFrame :309-314); caller seeds with srand()
+void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedFrameSegment, double baggedProbability,
+                    unsigned long minimumLength, unsigned long maximumLength);
+// trainModelStream (TrainTools.cpp:1030-1110), single stream; returns the per-iteration mean llk
+// ("llkPreviousIt").  allReduce, when given, sums the flat accumulator over ranks (RCCL/xGMI).
+typedef void (*AllReduceFn)(double *buf, size_t n, void *user);
+std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
+                                     const std::vector<double> &globalCov, MixtureGD &world,
+                                     AllReduceFn allReduce = nullptr, void *user = nullptr);
+
+// ---- ComputeTest (LIA_SpkDet/ComputeTest/src/ComputeTest.cpp:129-215) -----------------------------
+// LLR of each client against the world for one test file: per segment when segmentalMode, else one
+// per file.  out[(seg or 0) * nClients + i] = mean llk_client - mean llk_world.
+std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selectedSegments, DeviceMixture &world,
+                                   std::vector<DeviceMixture *> &clients, int topDistribsCount, bool complete,
+                                   double minLLK, double maxLLK, bool segmentalMode);
+
+// ---- AccumulateTVStat.h ----------------------------------------------------------------------------
+class TVAcc {
+  public:
+    // ndx lines = statistics rows; row u owns the frames of segs[u] (TVAcc::_init, :129-196)
+    TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned long nSpeakers);
+    void computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerLine); // :281-351
+    void substractM();                 // :1088-1105
+    void estimateTETt();               // :777-805
+    void estimateW();                  // :2114-2169
+    void estimateAandC();              // :1702-1795
+    void updateTestimate();            // :974-1005
+    void minDivergence();              // :2056-2099
+    void resetTmpAcc();                // :620-629
+    void loadT(const std::vector<double> &T) { _T = T; }
+    void setStats(const std::vector<double> &N, const std::vector<double> &F) { _statN = N; _statF = F; }
+    std::vector<double> &getT() { return _T; }
+    std::vector<double> &getW() { return _W; }
+    std::vector<double> &getN() { return _statN; }
+    std::vector<double> &getF() { return _statF; }
+    std::vector<double> &getUbmMeans() { return _ubm_means; }
+    unsigned long getRankT() const { return _rankT; }
+
+  private:
+    GpuServer &_srv;
+    MixtureGD _ubm;
+    DeviceMixture _dubm;
+    unsigned long _rankT, _n_speakers, _n_distrib, _vectSize, _svSize;
+    std::vector<double> _ubm_means, _ubm_invvar, _statN, _statF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
+};
+
+} // namespace liagpu

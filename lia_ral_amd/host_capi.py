@@ -1,0 +1,103 @@
+"""ctypes binding of host/libliatools_gpu.so -- the C++ mirror of the LIA_SpkTools hot-path drivers
+(trainModelStream, ComputeTest's LLR loop, IvExtractor, TotalVariability) over libgmmiv."""
+import ctypes as ct
+import os
+
+import numpy as np
+
+from . import capi  # noqa: F401  (loads torch's HIP runtime first, then libgmmiv.so)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "host", "libliatools_gpu.so")
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HostError("libliatools_gpu.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+    lib = ct.CDLL(LIB_PATH)
+    lib.liagpu_last_error.restype = ct.c_char_p
+    return lib
+
+
+lib = _load()
+_dp = ct.POINTER(ct.c_double)
+_lp = ct.POINTER(ct.c_long)
+_fp = ct.POINTER(ct.c_float)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HostError(lib.liagpu_last_error().decode())
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _segs(seg_begin, seg_len):
+    b = np.ascontiguousarray(seg_begin, np.int64); l = np.ascontiguousarray(seg_len, np.int64)
+    return b, l, b.ctypes.data_as(_lp), l.ctypes.data_as(_lp)
+
+
+def train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, bagged_p=1.0, init_floor=0.0, final_floor=0.0,
+                init_ceil=10.0, final_ceil=10.0, init_rand=0, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w = np.array(w, np.float64); mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
+    C = len(w)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    gm = np.empty(D); gc = np.empty(D); llk = np.empty(nb_it)
+    _chk(lib.liagpu_train_world(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(w), _d(mean),
+                                _d(cov), nb_it, ct.c_double(bagged_p), ct.c_double(init_floor), ct.c_double(final_floor),
+                                ct.c_double(init_ceil), ct.c_double(final_ceil), ct.c_long(init_rand), _d(gm), _d(gc), _d(llk)))
+    return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk)
+
+
+def compute_test(x, seg_begin, seg_len, world, clients, top_c=10, complete=True, min_llk=-200.0, max_llk=200.0,
+                 segmental=False, device=0):
+    """world = (w, mean, cov); clients = list of (w, mean, cov).  Returns LLR[n_seg_or_1, n_clients]."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    ww, mw, cw = [np.ascontiguousarray(a, np.float64) for a in world]
+    C = len(ww)
+    wc = np.ascontiguousarray(np.stack([c[0] for c in clients]), np.float64)
+    mc = np.ascontiguousarray(np.stack([c[1] for c in clients]), np.float64)
+    cc = np.ascontiguousarray(np.stack([c[2] for c in clients]), np.float64)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    nout = (len(b) if segmental else 1) * len(clients)
+    out = np.empty(nout)
+    _chk(lib.liagpu_compute_test(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(ww), _d(mw),
+                                 _d(cw), len(clients), _d(wc), _d(mc), _d(cc), top_c, int(complete), ct.c_double(min_llk),
+                                 ct.c_double(max_llk), int(segmental), _d(out)))
+    return out.reshape(-1, len(clients))
+
+
+def iv_extract(x, utt_begin, ubm, Tmat, device=0, return_stats=False):
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C = len(w)
+    Tm = np.ascontiguousarray(Tmat, np.float64)
+    R = Tm.shape[0]
+    ub = np.ascontiguousarray(utt_begin, np.int64)
+    U = len(ub) - 1
+    W = np.empty((U, R)); N = np.empty((U, C)); F = np.empty((U, C * D))
+    _chk(lib.liagpu_iv_extract(device, x.ctypes.data_as(_fp), ct.c_long(T), D, ub.ctypes.data_as(_lp), ct.c_long(U), C, _d(w),
+                               _d(mean), _d(cov), R, _d(Tm), _d(W), _d(N), _d(F)))
+    return (W, N, F) if return_stats else W
+
+
+def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    N = np.ascontiguousarray(N, np.float64); F = np.ascontiguousarray(F, np.float64)
+    Tm = np.array(Tmat, np.float64)
+    R = Tm.shape[0]
+    means = np.empty(C * D)
+    _chk(lib.liagpu_tv_train(device, ct.c_long(N.shape[0]), C, D, _d(w), _d(mean), _d(cov), R, _d(N), _d(F), _d(Tm), nb_it,
+                             int(min_div), _d(means)))
+    return Tm, means

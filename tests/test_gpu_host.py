@@ -1,0 +1,107 @@
+"""GPU parity of the C++ host layer (lia_ral_amd/host: trainModelStream, ComputeTest LLR loop,
+IvExtractor, TotalVariability mirrors) against the same pipelines composed from oracle primitives."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_frames, make_gmm
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def oracle_train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, p, fl0, fl1, ce0, ce1, init_rand=0):
+    """TrainWorld.cpp:101-191 / TrainTools.cpp:1030-1110 from oracle pieces (single stream)."""
+    x = x.astype(np.float64)
+    sel = np.concatenate([np.arange(b, b + n) for b, n in zip(seg_begin, seg_len)])
+    s, ss, n = orc.frame_acc(x[sel])
+    gmean, gcov = orc.frame_mean_cov(s, ss, n)
+    llks = []
+    for it in range(nb_it):
+        floor = orc.set_it_parameter(fl0, fl1, nb_it, it)
+        ceil = orc.set_it_parameter(ce0, ce1, nb_it, it)
+        seed = ((it + 1 + init_rand) * 200) + ((0 + 1) * 20) + (0 + 1)
+        bb, bl, _ = orc.bagged_segments(seed, seg_begin, seg_len, p, 3, 7)
+        fr = np.concatenate([np.arange(b, b + n) for b, n in zip(bb, bl)]) if len(bb) else np.zeros(0, int)
+        acc = orc.em_accumulate(orc.Gmm(w, mean, 1.0 / cov), x[fr])
+        llks.append(acc["llk"] / acc["count"])
+        w, mean, cov = orc.em_get(acc, mean, cov)
+        cov, _, _ = orc.variance_control(cov, floor, ceil, gcov)
+    return dict(w=w, mean=mean, cov=cov, llk=np.array(llks), global_mean=gmean, global_cov=gcov)
+
+
+@pytest.mark.parametrize("p", [1.0, 0.4])
+def test_train_model_stream(p):
+    from lia_ral_amd import host_capi as h
+    C, D, T = 32, 20, 6000
+    w, mean, iv = make_gmm(C, D, seed=5)
+    x = make_frames(w, mean, iv, T, seed=6)
+    rng = np.random.default_rng(0)
+    w0 = np.full(C, 1.0 / C); mean0 = mean + rng.normal(0, 0.5, mean.shape); cov0 = np.ones((C, D)) * 2.0
+    seg_begin = [0, 2500, 4000]; seg_len = [2000, 1400, 2000]          # label segments (gaps are not selected)
+    args = dict(nb_it=3, bagged_p=p, init_floor=0.5, final_floor=0.05, init_ceil=5.0, final_ceil=10.0)
+    got = h.train_world(x, seg_begin, seg_len, w0, mean0, cov0, **args)
+    ref = oracle_train_world(x, np.array(seg_begin), np.array(seg_len), w0, mean0, cov0, 3, p, 0.5, 0.05, 5.0, 10.0)
+    assert relerr(got["global_cov"], ref["global_cov"]) < 1e-12
+    assert np.max(np.abs(got["llk"] - ref["llk"])) < 1e-9
+    assert relerr(got["w"], ref["w"]) < 1e-8 and relerr(got["mean"], ref["mean"]) < 1e-8 and relerr(got["cov"], ref["cov"]) < 1e-8
+
+
+def test_compute_test_kat1_through_host_layer(golden_dir):
+    """LIA_SpkDet/ComputeTest/test/test1.validate.res via computeTestLLR (segmental mode)."""
+    from lia_ral_amd import host_capi as h
+    k = np.load(os.path.join(golden_dir, "kat1_computetest.npz"))
+    world = (k["w"], k["mean_world"], 1.0 / k["covinv"])
+    cl1 = (k["w_client"], k["mean_client"], 1.0 / k["covinv_client"])
+    llr = h.compute_test(k["x"], k["seg_begin"], k["seg_len"], world, [cl1, world], top_c=int(k["top_c"]), complete=True,
+                         segmental=True)
+    assert np.allclose(llr[:, 0], k["expected_llr"], atol=float(k["abs_tol"]), rtol=0), llr
+    assert np.all(np.abs(llr[:, 1]) < 1e-12)            # client == world -> 0 (validate.res lines 2,4)
+    # file mode: one LLR over all selected frames == frame-weighted mean of the segment LLRs
+    one = h.compute_test(k["x"], k["seg_begin"], k["seg_len"], world, [cl1], top_c=int(k["top_c"]), complete=True)
+    wts = k["seg_len"] / k["seg_len"].sum()
+    assert abs(one[0, 0] - (llr[:, 0] * wts).sum()) < 1e-9
+
+
+def test_iv_extractor_and_tv_training():
+    from lia_ral_amd import host_capi as h
+    C, D, R, U = 32, 20, 24, 40
+    rng = np.random.default_rng(3)
+    w, mean, iv = make_gmm(C, D, seed=8)
+    lens = rng.integers(80, 160, U)
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=9)
+    Tm = rng.normal(0, 0.05, (R, C * D))
+    ubm = (w, mean, 1.0 / iv)
+    W, N, F = h.iv_extract(x, ub, ubm, Tm, return_stats=True)
+    og = orc.Gmm(w, mean, iv)
+    utt = np.repeat(np.arange(U), lens)
+    No, Fo = orc.tv_stats(og, x.astype(np.float64), utt, U)
+    assert relerr(N, No) < 1e-9 and relerr(F, Fo) < 1e-9
+    F0 = orc.tv_subtract_m(No, Fo, mean.ravel())
+    te = orc.tv_tett(Tm, iv.ravel(), C, D)
+    Wo = orc.tv_estimate_w(No, F0, Tm, iv.ravel(), te)
+    assert relerr(W, Wo) < 1e-8                      # i-vectors: north_star bar 1e-6
+    # two T-matrix EM iterations with minimum divergence (TotalVariability.cpp:118-169)
+    Tg, mg = h.tv_train(No, Fo, ubm, Tm, 2, min_div=True)
+    To, mo = Tm.copy(), mean.ravel().copy()
+    for _ in range(2):
+        F0 = orc.tv_subtract_m(No, Fo, mo)
+        te = orc.tv_tett(To, iv.ravel(), C, D)
+        o = orc.tv_estimate_a_and_c(No, F0, To, iv.ravel(), te)
+        To = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+        mo, To = orc.tv_min_divergence(o["Rm"], o["r"], o["meanW"], mo, To, U, C, D)
+    assert relerr(Tg, To) < 1e-6 and relerr(mg, mo) < 1e-8
+
+
+def test_host_layer_reports_errors_like_the_reference():
+    from lia_ral_amd import host_capi as h
+    w, mean, iv = make_gmm(8, 12, seed=1)
+    x = make_frames(w, mean, iv, 100, seed=2)
+    with pytest.raises(h.HostError, match="segment ends after"):
+        h.train_world(x, [50], [100], w, mean, 1.0 / iv, 1)      # verifyClusterFile-style failure
