@@ -172,19 +172,19 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         d_rp = (double *)p;
         GCHK(hipMemsetAsync(d_rp, 0, P * 8, c->stream));
     }
-    GCHK(hipMalloc(&p, (size_t)R * SV * 8));
-    owned.push_back(p);
+    if ((rc = c->scratch(WS_TIV, (size_t)R * SV * 8, &p))) { free_owned(); return rc; }
     double *Tiv = (double *)p;
     GCHK(tvk_scale_cols(c->stream, R, (long)SV, i_t.d, i_iv.d, Tiv));
 
     int BC = 256;
     if (U < BC) BC = (int)U;
-    GCHK(hipMalloc(&p, (size_t)BC * P * 8));
-    owned.push_back(p);
+    if ((rc = c->scratch(WS_LP, (size_t)BC * P * 8, &p))) { free_owned(); return rc; }
     double *Lp = (double *)p;
-    GCHK(hipMalloc(&p, (size_t)BC * R * 8));
-    owned.push_back(p);
+    if ((rc = c->scratch(WS_AUX, (size_t)BC * R * 8, &p))) { free_owned(); return rc; }
     double *aux = (double *)p;
+    const int nz = tvk_splitk_count(BC, R, (int)SV, c->n_cu);
+    if ((rc = c->scratch(WS_SLAB, (size_t)nz * BC * R * 8, &p))) { free_owned(); return rc; }
+    double *slabs = (double *)p;
     InvWs ws;
     if ((rc = ws.init(c, R, BC))) { free_owned(); return rc; }
 
@@ -201,7 +201,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         GCHK(tvk_unpack_sym(c->stream, R, nb, Lp, (long)P, ws.full, 1.0));
         GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
         // aux = F Sigma^-1 T^T ; w = L^-1 aux
-        GCHK(tvk_dgemm(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, 0, Tiv, (long)SV, 0, 0.0, aux, R, 0, 1));
+        GCHK(tvk_dgemm_splitk(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, Tiv, (long)SV, 0.0, aux, R, nz, slabs));
         GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
         if ((rc = check_status(c, ws.status, nb, "tv: L"))) { free_owned(); return rc; }
         if (accumulate) {

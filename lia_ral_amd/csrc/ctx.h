@@ -22,7 +22,7 @@ void gmmiv_set_error(const char *fmt, ...);
     } while (0)
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
-       WS_T9, WS_COUNT };
+       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_COUNT };
 
 struct gmmiv_ctx {
     int device = 0;

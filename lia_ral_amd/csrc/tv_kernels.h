@@ -21,3 +21,6 @@ int tvk_score_combine(hipStream_t st, long M, long S, double *scores, double a, 
 int tvk_score_cosnorm(hipStream_t st, long M, long S, double *scores, const double *qm, const double *qs);
 int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out);
 int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const double *y, double *out);
+int tvk_splitk_count(int M, int N, int K, int n_cu);
+int tvk_dgemm_splitk(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda,
+                     const double *B, long ldb, double beta, double *C, long ldc, int nz, double *slabs);

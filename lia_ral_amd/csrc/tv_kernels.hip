@@ -18,7 +18,7 @@ __device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                long lda, long sA, const double *__restrict__ B, long ldb, long sB,
-                                               double beta, double *__restrict__ C, long ldc, long sC)
+                                               double beta, double *__restrict__ C, long ldc, long sC, int ksplit)
 {
     constexpr int BM = 128, BN = 128, BK = 16;
     __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
@@ -28,13 +28,21 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
     const int i16 = lane & 15, q = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
     const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
-    A += (size_t)blockIdx.z * sA;
-    B += (size_t)blockIdx.z * sB;
+    // ksplit > 0: blockIdx.z selects a K range [kb, ke) and C is the z-th partial slab (stride sC);
+    // otherwise blockIdx.z is the batch index.
+    long kb = 0, ke = K;
+    if (ksplit > 0) {
+        kb = (long)blockIdx.z * ksplit;
+        ke = kb + ksplit < K ? kb + ksplit : K;
+    } else {
+        A += (size_t)blockIdx.z * sA;
+        B += (size_t)blockIdx.z * sB;
+    }
     C += (size_t)blockIdx.z * sC;
 
     double ra[8], rb[8];
     auto gload = [&](int kt) {
-        const long k0 = (long)kt * BK;
+        const long k0 = kb + (long)kt * BK;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
             if (TA) { m = e & 127; k = e >> 7; } else { k = e & 15; m = e >> 4; }
             const long gm = m0 + m, gk = k0 + k;
             double v = 0.0;
-            if (gm < M && gk < K) v = TA ? A[gk * lda + gm] : A[gm * lda + gk];
+            if (gm < M && gk < ke) v = TA ? A[gk * lda + gm] : A[gm * lda + gk];
             ra[i] = v;
         }
 #pragma unroll
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
             if (TB) { k = e & 15; n = e >> 4; } else { n = e & 127; k = e >> 7; }
             const long gn = n0 + n, gk = k0 + k;
             double v = 0.0;
-            if (gn < N && gk < K) v = TB ? B[gn * ldb + gk] : B[gk * ldb + gn];
+            if (gn < N && gk < ke) v = TB ? B[gn * ldb + gk] : B[gk * ldb + gn];
             rb[i] = v;
         }
     };
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (d4){0, 0, 0, 0};
 
-    const int nkt = (K + BK - 1) / BK;
+    const int nkt = (int)((ke - kb + BK - 1) / BK);
     if (nkt > 0) { gload(0); swrite(0); }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -120,15 +128,59 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
         }
 }
 
+static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
+                         long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
+                         int ksplit)
+{
+    if (!ta && !tb) k_dgemm<false, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
+    else if (!ta && tb) k_dgemm<false, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
+    else if (ta && !tb) k_dgemm<true, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
+    else k_dgemm<true, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
+}
+
 int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, long sA,
               const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC, int batch)
 {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
-    if (!ta && !tb) k_dgemm<false, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
-    else if (!ta && tb) k_dgemm<false, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
-    else if (ta && !tb) k_dgemm<true, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
-    else k_dgemm<true, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, 0);
+    return (int)hipGetLastError();
+}
+
+// C = beta C + sum_z slab[z]   (split-K epilogue)
+__global__ void k_splitk_reduce(int M, int N, int nz, const double *__restrict__ slab, double beta, double *__restrict__ C, long ldc)
+{
+    const long tot = (long)M * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int z = 0; z < nz; ++z) s += slab[(size_t)z * tot + e];
+        const long m = e / N, n = e - m * N;
+        C[m * ldc + n] = (beta != 0.0 ? beta * C[m * ldc + n] : 0.0) + s;
+    }
+}
+
+// Few output tiles, long K: split K over nz = tvk_splitk_count(...) workgroup layers writing slabs
+// (nz * M * N doubles of workspace), then reduce.  Deterministic (no atomics).
+int tvk_splitk_count(int M, int N, int K, int n_cu)
+{
+    const long tiles = (long)((N + 127) / 128) * ((M + 127) / 128);
+    if (tiles >= 2L * n_cu || K < 2048) return 1;
+    long nz = (4L * n_cu + tiles - 1) / tiles;
+    const long maxz = K / 512 > 1 ? K / 512 : 1;
+    if (nz > maxz) nz = maxz;
+    return (int)(nz < 1 ? 1 : nz);
+}
+int tvk_dgemm_splitk(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda,
+                     const double *B, long ldb, double beta, double *C, long ldc, int nz, double *slabs)
+{
+    if (M <= 0 || N <= 0) return 0;
+    if (nz <= 1) return tvk_dgemm(st, ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
+    int kc = ((K + nz - 1) / nz + 15) / 16 * 16;
+    nz = (K + kc - 1) / kc;
+    dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
+    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, slabs, N, (long)M * N, kc);
+    const long tot = (long)M * N;
+    k_splitk_reduce<<<(unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256), 256, 0, st>>>(M, N, nz, slabs, beta, C, ldc);
     return (int)hipGetLastError();
 }
 

@@ -87,6 +87,24 @@ __global__ __launch_bounds__(256) void k_mfma_n(double *out, int iters, double s
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// same sweep with the MFMA pinned to VGPR accumulators by inline asm (hipcc otherwise shuttles the
+// accumulators through AGPRs inside the loop of the plain-builtin probe above)
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_asm(double *out, int iters, double seed)
+{
+    d4 acc[NACC];
+    double a[NACC], b[NACC];
+    for (int i = 0; i < NACC; ++i) { acc[i] = (d4){seed, seed, seed, seed}; a[i] = seed + i + threadIdx.x * 1e-9; b[i] = seed * 0.5 - i; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]));
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F> static float time_ms(F f)
 {
     hipEvent_t e0, e1;
@@ -152,6 +170,19 @@ int main()
             float t8 = time_ms([&] { k_mfma_n<8><<<nblk, 256>>>(out, it2, 1e-3); });
             const double fl = (double)nblk * 4 * it2 * 2048.0;
             printf("MFMA f64 sweep, %d wave(s)/SIMD: 1 acc %.1f TF | 2 acc %.1f TF | 4 acc %.1f TF | 8 acc %.1f TF\n", wps,
+                   fl * 1 / t1 / 1e9, fl * 2 / t2 / 1e9, fl * 4 / t4 / 1e9, fl * 8 / t8 / 1e9);
+        }
+    }
+    {
+        const int it2 = 40000;
+        for (int wps = 1; wps <= 4; wps *= 2) {
+            const int nblk = p.multiProcessorCount * wps;
+            float t1 = time_ms([&] { k_mfma_asm<1><<<nblk, 256>>>(out, it2, 1e-3); });
+            float t2 = time_ms([&] { k_mfma_asm<2><<<nblk, 256>>>(out, it2, 1e-3); });
+            float t4 = time_ms([&] { k_mfma_asm<4><<<nblk, 256>>>(out, it2, 1e-3); });
+            float t8 = time_ms([&] { k_mfma_asm<8><<<nblk, 256>>>(out, it2, 1e-3); });
+            const double fl = (double)nblk * 4 * it2 * 2048.0;
+            printf("MFMA f64 (asm, VGPR acc) %d wave(s)/SIMD: 1 acc %.1f TF | 2 acc %.1f TF | 4 acc %.1f TF | 8 acc %.1f TF\n", wps,
                    fl * 1 / t1 / 1e9, fl * 2 / t2 / 1e9, fl * 4 / t4 / 1e9, fl * 8 / t8 / 1e9);
         }
     }
