@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--mean-spread", type=float, default=2.0,
+                    help="std of the synthetic UBM means (SURVEY 8(d): 2.0; smaller = overlapping Gaussians)")
+    ap.add_argument("--wg-waves", type=int, default=0, help="A/B knob: waves per workgroup of the MFMA kernels (4 or 8)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,11 +128,13 @@ def main():
     from conftest import make_gmm
     from lia_ral_amd import capi
 
-    w, mean, iv = make_gmm(C, D, seed=0)
+    w, mean, iv = make_gmm(C, D, seed=0, spread=args.mean_spread)
     T = args.frames
     x = synth_frames(w, mean, iv, T, dev, seed=1234 + rank)
     ctx = capi.Context(local, torch.cuda.current_stream().cuda_stream)
     ctx.set_option("timing", 1)
+    if args.wg_waves:
+        ctx.set_option("wg_waves", args.wg_waves)
     g = ctx.gmm(w, mean, iv)
     nacc = g.em_acc_len()
     acc = torch.zeros(nacc, dtype=torch.float64, device=dev)

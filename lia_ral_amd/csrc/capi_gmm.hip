@@ -83,6 +83,8 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     if (!strcmp(key, "glds")) slot = &c->use_glds;
     else if (!strcmp(key, "em_chunks")) slot = &c->em_chunks;
     else if (!strcmp(key, "timing")) slot = &c->timing;
+    else if (!strcmp(key, "wg_waves")) slot = &c->wg_waves;
+    else if (!strcmp(key, "dbg")) slot = &c->dbg;
     if (!slot) return -1;
     long prev = *slot;
     *slot = value;
@@ -254,7 +256,7 @@ static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, in
     int rc = c->scratch(WS_LSE, (size_t)(T > 0 ? T : 1) * sizeof(double), &lse);
     if (rc) return rc;
     c->t_begin("k_llk_mfma");
-    GCHK(gmmk_llk(c->stream, g->KS, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->Pt, g->nct, (double *)lse, (int)c->use_glds));
+    GCHK(gmmk_llk(c->stream, g->KS, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->Pt, g->nct, (double *)lse, (int)(c->use_glds | (c->dbg << 8)), (int)c->wg_waves));
     c->t_end();
     *lse_out = (double *)lse;
     return GMMIV_OK;
@@ -377,8 +379,9 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
                            o.d + nacc - 2));
     GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
     // frame chunks: enough workgroups to fill the chip about twice, each >= 4096 frames
-    const int ngrp = (g->nct + 7) / 8;
-    int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (2 * c->n_cu + ngrp - 1) / ngrp;
+    const int nw = c->wg_waves == 8 ? 8 : 4;
+    const int ngrp = (g->nct + nw - 1) / nw;
+    int nseg = c->em_chunks > 0 ? (int)c->em_chunks : ((nw == 8 ? 2 : 4) * c->n_cu + ngrp - 1) / ngrp;
     nseg = (nseg + 7) / 8 * 8;
     const int64_t cap = (T + 4095) / 4096;
     if (nseg > cap) nseg = (int)cap;
@@ -391,7 +394,7 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if ((rc = c->scratch(WS_PART, (size_t)nseg * Cp * 2 * RL * sizeof(double), &part))) return rc;
     c->t_begin("k_stats_mfma");
     GCHK(gmmk_stats(c->stream, g->KS, 1, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, -log(weight), seg,
-                    nseg, (double *)part, nullptr, 0));
+                    nseg, (double *)part, nullptr, 0, (int)c->wg_waves));
     c->t_end();
     GCHK(gmmk_em_reduce(c->stream, (const double *)part, nseg, g->C, (int)Cp, g->D, g->KS, o.d));
     return o.finish();
@@ -476,7 +479,7 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     // every (u, c < C) row is written by exactly one wave (zeros for an empty utterance)
     c->t_begin("k_stats_mfma");
     GCHK(gmmk_stats(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, 0.0,
-                    (const long *)seg, (int)U, o_n.d, o_f.d, 1));
+                    (const long *)seg, (int)U, o_n.d, o_f.d, 1, (int)c->wg_waves));
     c->t_end();
     if ((rc = o_n.finish())) return rc;
     return o_f.finish();

@@ -34,6 +34,8 @@ struct gmmiv_ctx {
     long use_glds = 1;
     long em_chunks = 0; // 0 = auto
     long timing = 0;
+    long dbg = 0; // timing experiments (wrong results when != 0)
+    long wg_waves = 8; // waves per workgroup of the two MFMA GMM kernels (8, or 4 for A/B runs)
     int n_cu = 256;
     // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name
     enum { NSLOT = 6 };

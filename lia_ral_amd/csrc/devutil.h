@@ -38,6 +38,33 @@ __device__ __forceinline__ double gexp(double x)
     return __builtin_ldexp(p, (int)n);
 }
 
+// Table-driven variant: exp(x) = 2^n * T[j] * (1 + p(r)), k = rint(x 32/ln2), j = k & 31, n = k >> 5,
+// r = x - k ln2/32 (|r| <= 0.0109), p = r + r^2/2 + ... + r^7/5040 (truncation 3e-18).  `tab` is the
+// 32-entry table 2^(j/32) in LDS (filled by gexp_table_init).  13 fp64 ops instead of 20: on gfx950
+// every fp64 VALU op takes issue time away from the fp64 MFMA pipe, so this is MFMA throughput.
+__device__ __forceinline__ void gexp_table_init(double *tab, int tid)
+{
+    if (tid < 32) tab[tid] = exp2((double)tid * 0.03125);
+}
+__device__ __forceinline__ double gexp_t(double x, const double *tab)
+{
+    x = fmax(x, -750.0);
+    const double k = __builtin_rint(x * 46.16624130844683);
+    double r = __builtin_fma(k, -0.021660849219188094, x);
+    r = __builtin_fma(k, -1.733101967801894e-10, r);
+    const int ki = (int)k;
+    const double tj = tab[ki & 31];
+    double p = 1.984126984126984e-04;               // 1/5040
+    p = __builtin_fma(p, r, 1.388888888888889e-03);  // 1/720
+    p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/120
+    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/24
+    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/6
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), ki >> 5);
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -65,6 +92,13 @@ __device__ __forceinline__ double wave_max_f64(double v)
 //   (L) 16 consecutive rows x 2 adjacent columns   (MFMA A operand of the logit GEMM)
 //   (S) 2 consecutive rows x 16 consecutive columns (MFMA B operand of the statistics GEMM)
 __device__ __forceinline__ int xswz(int t) { return ((t << 1) ^ ((t & 1) << 4)) & 31; }
+
+// Additive variant used by the statistics kernel: element (t, col) of the frame tile lives at
+// t * RLp + xrot(t) + col with RLp = RL + 32 and RLp % 32 == 0.  Same two conflict-free patterns
+// (rows t, t+1 sit 16 bank-pairs apart; 16 consecutive rows cover all 32 bank-pairs two by two),
+// but the column enters the address as a plain sum, so every LDS read of the inner loops is
+// "lane base + compile-time immediate" and costs no VALU address arithmetic.
+__device__ __forceinline__ int xrot(int t) { return ((t & 1) << 4) + (((t >> 1) & 7) << 1); }
 
 template <typename T> struct feat_load;
 template <> struct feat_load<float> {

@@ -8,13 +8,13 @@ int gmmk_rl_for_ks(int KS);   // row length (doubles) of the LDS frame tile / ha
 int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, const double *w, const double *mean,
                     const double *iv, double *a, double *lwc, double *Pt, double *meanT, double *ivT);
 int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
-             double *lse, int use_glds);
+             double *lse, int use_glds, int wg_waves);
 int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, double hi, double *llk_out,
                       double *partial, double scale_c, double scale_r, double *dst_clamped, double *dst_raw);
 int gmmk_add_scalar(hipStream_t st, double *dst, double v);
 int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
                int nct, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
-               double *out1, int mode);
+               double *out1, int mode, int wg_waves);
 int gmmk_em_reduce(hipStream_t st, const double *part, int nseg, int C, int Cp, int D, int KS, double *acc);
 int gmmk_em_get(hipStream_t st, int C, int D, const double *acc, const double *prev_mean, const double *prev_cov,
                 double *w, double *mean, double *cov);

@@ -87,11 +87,13 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // Frame operands stay in registers; the packed model streams through a double-buffered LDS
 // tile (2 c-tiles = 32 Gaussians per stage), by LDS-DMA when use_glds.
 // -------------------------------------------------------------------------------------------
-template <int KS, typename XT>
-__global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
+template <int KS, typename XT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ Pt, int nct,
-                                                  double *__restrict__ lse_out, int use_glds)
+                                                  double *__restrict__ lse_out, int use_glds, int dbg)
 {
+    // dbg (timing experiments only, results are wrong when != 0): 1 = no log-sum-exp epilogue,
+    // 2 = additionally no per-tile staging / barrier, 3 = additionally B operands not re-read from LDS
     constexpr int NR = 2 * KS + 2;
     constexpr int GT = 2;
     constexpr int TILE_D = GT * NR * 64;       // doubles per LDS stage
@@ -99,10 +101,12 @@ __global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, lo
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *buf0 = (double *)smem;
     double *buf1 = buf0 + TILE_D;
+    double *etab = buf1 + TILE_D; // 32-entry exp table
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
-    const long tb = (long)blockIdx.x * 256 + wave * 32;
+    const long tb = (long)blockIdx.x * (NW * 32) + wave * 32;
+    gexp_table_init(etab, tid);
 
     double A[2][2 * KS];
 #pragma unroll
@@ -122,12 +126,12 @@ __global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, lo
     auto stage = [&](double *dst, int tile) {
         const char *src = (const char *)(Pt + (size_t)tile * TILE_D);
         if (use_glds) {
-            for (int p = wave; p < PIECES; p += 8)
+            for (int p = wave; p < PIECES; p += NW)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
                     (__attribute__((address_space(3))) void *)((char *)dst + p * 1024), 16, 0, 0);
         } else {
-            for (int p = wave; p < PIECES; p += 8) {
+            for (int p = wave; p < PIECES; p += NW) {
                 uint4 v = *(const uint4 *)(src + p * 1024 + lane * 16);
                 *(uint4 *)((char *)dst + p * 1024 + lane * 16) = v;
             }
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, lo
     for (int tl = 0; tl < ntiles; ++tl) {
         double *cur = (tl & 1) ? buf1 : buf0;
         double *nxt = (tl & 1) ? buf0 : buf1;
-        if (tl + 1 < ntiles) stage(nxt, tl + 1);
+        if (tl + 1 < ntiles && dbg < 2) stage(nxt, tl + 1);
 
         d4 acc[GT][2];
 #pragma unroll
@@ -163,20 +167,59 @@ __global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, lo
             acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
             acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
         }
-        // online log-sum-exp per (lane, frame row): reference point m moves only when a logit
-        // exceeds it by more than 64 (rare after the first tile), so one exp per logit.
+        // Online log-sum-exp per (lane, frame row).  The reference point m moves only when a logit
+        // exceeds it by more than 64 (first tile, then rare), so each logit costs one exp -- and none
+        // at all when it is more than 40 below m: sacc >= 1 once a lane has seen a logit (m is one of
+        // its logits), so a term below e^-40 < 2^-54 cannot change sacc; skipping it is bit-exact.
+        // All branches are wave-uniform (ballots).  With few dominant Gaussians per frame most
+        // (row, tile) pairs take no exp; with overlapping mixtures all 16 run branch-free.
+        if (dbg >= 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[h][r] += acc[0][h][r] + acc[1][h][r];
+            if (dbg < 2) __syncthreads();
+            continue;
+        }
+        double mx[2][4];
+        bool grow = false;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double z0 = acc[0][h][r], z1 = acc[1][h][r];
-                const double mx = fmax(z0, z1);
-                if (mx > m[h][r] + 64.0) {
-                    sacc[h][r] *= gexp(m[h][r] - mx);
-                    m[h][r] = mx;
-                }
-                sacc[h][r] += gexp(z0 - m[h][r]) + gexp(z1 - m[h][r]);
+                mx[h][r] = fmax(acc[0][h][r], acc[1][h][r]);
+                grow |= mx[h][r] > m[h][r] + 64.0;
             }
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mx[h][r] > m[h][r] + 64.0) {
+                        sacc[h][r] *= gexp_t(m[h][r] - mx[h][r], etab);
+                        m[h][r] = mx[h][r];
+                    }
+        }
+        unsigned need = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                need |= (__builtin_amdgcn_ballot_w64(mx[h][r] > m[h][r] - 40.0) != 0 ? 1u : 0u) << (h * 4 + r);
+        if (__builtin_popcount(need) > 3) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sacc[h][r] += gexp_t(acc[0][h][r] - m[h][r], etab) + gexp_t(acc[1][h][r] - m[h][r], etab);
+        } else if (need) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (need & (1u << (h * 4 + r)))
+                        sacc[h][r] += gexp_t(acc[0][h][r] - m[h][r], etab) + gexp_t(acc[1][h][r] - m[h][r], etab);
+        }
         __syncthreads();
     }
     // combine the 16 lanes (Gaussian columns) that share a frame row
@@ -187,7 +230,7 @@ __global__ __launch_bounds__(512) void k_llk_mfma(const void *__restrict__ x, lo
             double M = m[h][r];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) M = fmax(M, shfl_xor_f64(M, o));
-            double sv = sacc[h][r] * gexp(m[h][r] - M);
+            double sv = sacc[h][r] * gexp_t(m[h][r] - M, etab);
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) sv += shfl_xor_f64(sv, o);
             const long t = tb + h * 16 + q + 4 * r;
@@ -241,23 +284,27 @@ __global__ void k_add_scalar(double *dst, double v) { *dst += v; }
 //   mode 0 (EM):  out[seg][c][2 RL] partial sums  (cols: x | x^2 halves; col Dp = occupancy)
 //   mode 1 (TV):  N[seg][c], F[seg][c][D] written directly
 // -------------------------------------------------------------------------------------------
-template <int KS, bool SQ, typename XT>
-__global__ __launch_bounds__(512) void k_stats_mfma(const void *__restrict__ x, long ldx, int D, int C,
+template <int KS, bool SQ, typename XT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_stats_mfma(const void *__restrict__ x, long ldx, int D, int C,
                                                     const double *__restrict__ Pt, int nct,
                                                     const double *__restrict__ lse, double lse_shift,
                                                     const long *__restrict__ seg_begin, int nseg, int ngrp,
                                                     double *__restrict__ out0, double *__restrict__ out1,
-                                                    int mode)
+                                                    int mode, unsigned magicD)
 {
     constexpr int NR = 2 * KS + 2;
     constexpr int Dp = 4 * KS;
     constexpr int RL = ((Dp + 2 + 31) / 32) * 32;
     constexpr int JT = RL / 16;
     constexpr int FT = 64;
-    constexpr int NLD = (FT * Dp + 511) / 512;
+    constexpr int NT = NW * 64;
+    constexpr int NLD = (FT * Dp + NT - 1) / NT;
+    constexpr int RLp = RL + 32; // padded row: additive rotation xrot(t) < 32
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *buf0 = (double *)smem;
-    double *buf1 = buf0 + FT * RL;
+    double *buf1 = buf0 + FT * RLp;
+    double *etab = buf1 + FT * RLp; // 32-entry exp table
+    gexp_table_init(etab, threadIdx.x);
 
     // XCD-aware decode: the 8 consecutive block ids that land on the 8 XCDs carry 8 different
     // segments, and all Gaussian groups of one segment share an XCD (its L2 then serves the
@@ -271,7 +318,7 @@ __global__ __launch_bounds__(512) void k_stats_mfma(const void *__restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
-    const int ct = grp * 8 + wave;
+    const int ct = grp * NW + wave;
     const bool active = ct < nct;
 
     double Pr[2 * KS + 1];
@@ -293,14 +340,29 @@ __global__ __launch_bounds__(512) void k_stats_mfma(const void *__restrict__ x, 
     XT stg[NLD];
     double stg_lse = 0.0;
     const int npad = FT * (RL - D); // pad entries per tile (cols D..RL-1)
+    // Staging plan, fixed for the whole kernel: element i of this thread is tile entry e = tid + NT i
+    // = (row fr, column d).  pk[i] = fr << 16 | byte offset of (fr, d) in the LDS tile (< 65536), so
+    // the per-tile work per element is one compare, one address add and the load / convert / store:
+    // every VALU instruction issued here is time the fp64 MFMA pipe of this SIMD stands still.
+    unsigned pk[NLD];
+    const bool contig = (ldx == D);
+    unsigned goff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + NT * i;
+        const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D; // e / D by reciprocal
+        pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
+        goff[i] = (unsigned)(fr * (int)ldx + d);
+    }
     auto load_tile = [&](int tl) {
         const long fb = f0 + (long)tl * FT;
+        const long rem = f1 - fb;
+        const unsigned lim = rem >= FT ? (unsigned)FT << 16 : (unsigned)rem << 16; // rows fr < lim >> 16 exist
+        const XT *xt = (const XT *)x + fb * ldx;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 512 * i;
-            const int fr = e / D, d = e - fr * D;
             XT v = 0;
-            if (fr < FT && fb + fr < f1) v = ((const XT *)x)[(fb + fr) * ldx + d];
+            if (pk[i] < lim) v = contig ? xt[tid + NT * i] : xt[goff[i]];
             stg[i] = v;
         }
         // out-of-range rows get lse = +1e300 -> posterior exp(z - lse) = 0
@@ -308,19 +370,18 @@ __global__ __launch_bounds__(512) void k_stats_mfma(const void *__restrict__ x, 
     };
     auto write_tile = [&](double *dst) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + 512 * i;
-            const int fr = e / D, d = e - fr * D;
-            if (fr < FT) dst[fr * RL + (d ^ xswz(fr))] = (double)stg[i];
-        }
-        for (int e = tid; e < npad; e += 512) { // pad columns: 1.0 at Dp, zeros elsewhere
+        for (int i = 0; i < NLD; ++i)
+            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = (double)stg[i];
+        for (int e = tid; e < npad; e += NT) { // pad columns: 1.0 at Dp, zeros elsewhere
             const int fr = e / (RL - D), d = D + (e - fr * (RL - D));
-            if (d != Dp + 1) dst[fr * RL + (d ^ xswz(fr))] = (d == Dp) ? 1.0 : 0.0;
+            if (d != Dp + 1) dst[fr * RLp + xrot(fr) + d] = (d == Dp) ? 1.0 : 0.0;
         }
-        if (tid < FT) dst[tid * RL + ((Dp + 1) ^ xswz(tid))] = stg_lse;
+        if (tid < FT) dst[tid * RLp + xrot(tid) + Dp + 1] = stg_lse;
     };
 
-    const int gi = xswz(i16); // swizzle of this lane's A-operand row (rows t0 + i16, t0 % 16 == 0)
+    // per-lane LDS offsets (doubles); everything else in the inner loops is a compile-time immediate
+    const int offL = i16 * RLp + xrot(i16) + q;                         // logit GEMM A operand: row i16, col q
+    const int offS = q * RLp + ((q & 1) << 4) + ((q >> 1) << 1) + i16;  // statistics GEMM B operand: row q, col i16
     if (ntiles > 0) {
         load_tile(0);
         write_tile(buf0);
@@ -331,33 +392,31 @@ __global__ __launch_bounds__(512) void k_stats_mfma(const void *__restrict__ x, 
         double *nxt = (tl & 1) ? buf0 : buf1;
         if (tl + 1 < ntiles) load_tile(tl + 1);
         if (active) {
-#pragma unroll 1
+            const double *pL = cur + offL, *pS = cur + offS;
+#pragma unroll
             for (int fs = 0; fs < FT / 16; ++fs) {
                 // logits z_tc - lse_t for 16 frames x 16 Gaussians: two independent MFMA chains
                 d4 zx = (d4){0, 0, 0, 0}, zq = (d4){0, 0, 0, 0};
-                const double *rowp = cur + (fs * 16 + i16) * RL;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const double a = rowp[(4 * s + q) ^ gi];
+                    const double a = pL[fs * 16 * RLp + 4 * s];
                     zx = MFMA_F64(a, Pr[s], zx);
                     zq = MFMA_F64(a * a, Pr[KS + s], zq);
                 }
                 {   // const step: + a_c - lse_t
-                    const double a = rowp[(Dp + q) ^ gi];
+                    const double a = pL[fs * 16 * RLp + Dp];
                     zx = MFMA_F64(a, Pr[2 * KS], zx);
                 }
                 double gam[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gam[r] = gexp(zx[r] + zq[r]);
-                // statistics: S[c][j] += sum_t gamma[t][c] * row_t[j]; gamma is already in A layout
+                for (int r = 0; r < 4; ++r) gam[r] = gexp_t(zx[r] + zq[r], etab);
+                // statistics: S[c][j] += sum_t gamma[t][c] * row_t[j]; gamma is already in A layout.
+                // row t = fs*16 + 4r + q: xrot(t) = 16 (q&1) + 2 (q>>1) + 4r  (lane part in offS)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int trow = fs * 16 + 4 * r + q;
-                    const double *rp = cur + trow * RL;
-                    const int gs = xswz(trow);
 #pragma unroll
                     for (int j = 0; j < JT; ++j) {
-                        const double bv = rp[(16 * j + i16) ^ gs];
+                        const double bv = pS[(fs * 16 + 4 * r) * RLp + 4 * r + 16 * j];
                         S[j] = MFMA_F64(gam[r], bv, S[j]);
                         if (SQ) S2[j] = MFMA_F64(gam[r], bv * bv, S2[j]);
                     }
@@ -664,30 +723,35 @@ int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, con
     return (int)hipGetLastError();
 }
 
-template <int KS, typename XT>
+template <int KS, typename XT, int NW>
 static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, const double *Pt, int nct,
                       double *lse, int use_glds)
 {
     constexpr int NR = 2 * KS + 2;
-    const size_t lds = 2 * 2 * NR * 64 * sizeof(double);
+    const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + 32 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((T + 255) / 256);
-    k_llk_mfma<KS, XT><<<grid, 512, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds);
+    const unsigned grid = (unsigned)((T + NW * 32 - 1) / (NW * 32));
+    k_llk_mfma<KS, XT, NW><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8);
     return (int)hipGetLastError();
 }
 
+// wg_waves: 4 -> two independent 4-wave workgroups per CU (their MFMA and VALU phases drift apart
+// and overlap), 8 -> one 8-wave workgroup per CU (its two waves per SIMD run in barrier lockstep)
 int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
-             double *lse, int use_glds)
+             double *lse, int use_glds, int wg_waves)
 {
     if (T <= 0) return 0;
 #define CASE(K)                                                                                      \
     case K:                                                                                          \
-        return x_f64 ? launch_llk<K, double>(st, x, T, ldx, D, Pt, nct, lse, use_glds)               \
-                     : launch_llk<K, float>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
+        if (wg_waves == 8)                                                                           \
+            return x_f64 ? launch_llk<K, double, 8>(st, x, T, ldx, D, Pt, nct, lse, use_glds)        \
+                         : launch_llk<K, float, 8>(st, x, T, ldx, D, Pt, nct, lse, use_glds);        \
+        return x_f64 ? launch_llk<K, double, 4>(st, x, T, ldx, D, Pt, nct, lse, use_glds)            \
+                     : launch_llk<K, float, 4>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
     switch (KS) {
         CASE(4) CASE(8) CASE(15) CASE(20)
     }
@@ -713,38 +777,45 @@ int gmmk_add_scalar(hipStream_t st, double *dst, double v)
     return (int)hipGetLastError();
 }
 
-template <int KS, bool SQ, typename XT>
+template <int KS, bool SQ, typename XT, int NW>
 static int launch_stats(hipStream_t st, const void *x, long ldx, int D, int C, const double *Pt, int nct,
                         const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
                         double *out1, int mode)
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
-    const size_t lds = 2 * 64 * RL * sizeof(double);
+    const size_t lds = (2 * 64 * (RL + 32) + 32) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_stats_mfma<KS, SQ, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_stats_mfma<KS, SQ, XT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int ngrp = (nct + 7) / 8;
+    const int ngrp = (nct + NW - 1) / NW;
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
-    k_stats_mfma<KS, SQ, XT><<<grid, 512, lds, st>>>(x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, ngrp,
-                                                     out0, out1, mode);
+    const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1); // floor(e/D) == umulhi(e, magicD) for e < 2^16
+    k_stats_mfma<KS, SQ, XT, NW><<<grid, NW * 64, lds, st>>>(x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, ngrp,
+                                                     out0, out1, mode, magicD);
     return (int)hipGetLastError();
+}
+
+#define STATS_ARGS st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode
+template <int KS, int NW>
+static int dispatch_stats(int sq, int x_f64, hipStream_t st, const void *x, long ldx, int D, int C, const double *Pt, int nct,
+                          const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0, double *out1,
+                          int mode)
+{
+    if (sq) return x_f64 ? launch_stats<KS, true, double, NW>(STATS_ARGS) : launch_stats<KS, true, float, NW>(STATS_ARGS);
+    return x_f64 ? launch_stats<KS, false, double, NW>(STATS_ARGS) : launch_stats<KS, false, float, NW>(STATS_ARGS);
 }
 
 int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
                int nct, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
-               double *out1, int mode)
+               double *out1, int mode, int wg_waves)
 {
     if (nseg <= 0) return 0;
-#define CASE(K)                                                                                                  \
-    case K:                                                                                                      \
-        if (sq)                                                                                                  \
-            return x_f64 ? launch_stats<K, true, double>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode) \
-                         : launch_stats<K, true, float>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode); \
-        else                                                                                                     \
-            return x_f64 ? launch_stats<K, false, double>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode) \
-                         : launch_stats<K, false, float>(st, x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, out0, out1, mode);
+#define CASE(K)                                                                       \
+    case K:                                                                           \
+        return wg_waves == 8 ? dispatch_stats<K, 8>(sq, x_f64, STATS_ARGS)            \
+                             : dispatch_stats<K, 4>(sq, x_f64, STATS_ARGS);
     switch (KS) {
         CASE(4) CASE(8) CASE(15) CASE(20)
     }

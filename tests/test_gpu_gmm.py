@@ -49,6 +49,23 @@ def test_llk_matches_oracle(ctx, C, D, T, dtype):
     assert np.array_equal(got, got2)
 
 
+@pytest.mark.parametrize("spread", [0.05, 0.3, 1.0])
+def test_overlapping_mixture_dense_paths(ctx, spread):
+    """Heavily overlapping Gaussians: every logit matters (no exp can be skipped), posteriors are
+    spread over hundreds of components -- exercises the dense branches of both MFMA kernels."""
+    C, D, T = 512, 60, 700
+    w, mean, iv = make_gmm(C, D, seed=11, spread=spread)
+    x = make_frames(w, mean, iv, T, seed=12)
+    g = ctx.gmm(w, mean, iv)
+    og = orc.Gmm(w, mean, iv)
+    got = g.llk(x, -1e9, 1e9)
+    ref = orc.llk(og, x.astype(np.float64), -1e9, 1e9)
+    assert np.max(np.abs(got - ref)) < 1e-9
+    a = g.split_acc(g.em_accumulate(x))
+    r = orc.em_accumulate(og, x.astype(np.float64))
+    assert relerr(a["occ"], r["occ"]) < 1e-9 and relerr(a["sx"], r["sx"]) < 1e-9 and relerr(a["sxx"], r["sxx"]) < 1e-9
+
+
 def test_llk_clamp_and_device_pointers(ctx):
     import torch
     w, mean, iv = make_gmm(128, 60, seed=3)
@@ -142,6 +159,20 @@ def test_em_accumulates_weights_and_chunks(ctx):
     refa = orc.em_accumulate(og, x.astype(np.float64))
     wo, mo, co = orc.em_get(refa, mean, 1.0 / iv)
     assert relerr(wn, wo) < 1e-9 and relerr(mn, mo) < 1e-9 and relerr(cn, co) < 1e-8
+
+
+def test_workgroup_shapes_agree(ctx):
+    """4-wave and 8-wave workgroup variants of the two MFMA kernels compute the same sums."""
+    w, mean, iv = make_gmm(2048, 60, seed=21)
+    x = make_frames(w, mean, iv, 3000, seed=22)
+    g = ctx.gmm(w, mean, iv)
+    res = {}
+    for nw in (4, 8):
+        ctx.set_option("wg_waves", nw)
+        res[nw] = (g.llk(x, -1e9, 1e9), g.em_accumulate(x))
+    ctx.set_option("wg_waves", 8)
+    assert np.array_equal(res[4][0], res[8][0])
+    assert relerr(res[4][1], res[8][1]) < 1e-12
 
 
 def test_em_zero_frames_and_ragged_edges(ctx):

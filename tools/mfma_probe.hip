@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void k_mixed(double *out, int iters, double se
     if (wave & 1) {
         for (int it = 0; it < iters; ++it)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = MFMA_F64(a, b, acc[i]);
+            for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     } else {
         for (int it = 0; it < iters; ++it)
 #pragma unroll
@@ -102,6 +102,56 @@ __global__ __launch_bounds__(256) void k_mfma_asm(double *out, int iters, double
     }
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// one wave: each MFMA is followed by NV independent v_fma_f64 -- how many hide under a 64-cycle MFMA?
+template <int NV>
+__global__ __launch_bounds__(256) void k_mfma_valu(double *out, int iters, double seed)
+{
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4){seed, seed, seed, seed};
+    double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
+    double v[16];
+    for (int i = 0; i < 16; ++i) v[i] = 1.0 + 0.01 * i + 1e-6 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int k = 0; k < NV; ++k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[k]) : "v"(b), "v"(a));
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0];
+    for (int i = 0; i < 16; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// same with f32 FMAs / integer adds: do 32-bit VALU ops hide under the fp64 MFMA?
+template <int NV, int KIND>
+__global__ __launch_bounds__(256) void k_mfma_valu32(double *out, int iters, double seed)
+{
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4){seed, seed, seed, seed};
+    double a = seed + threadIdx.x * 1e-9, b = seed * 0.5;
+    float v[16]; int u[16];
+    for (int i = 0; i < 16; ++i) { v[i] = 1.0f + 0.01f * i; u[i] = i + threadIdx.x; }
+    const float fb = 0.999f, fa = 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(fb), "v"(fa));
+                else asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[k]) : "v"(it));
+            }
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0];
+    for (int i = 0; i < 16; ++i) s += v[i] + u[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -172,6 +222,19 @@ int main()
             printf("MFMA f64 sweep, %d wave(s)/SIMD: 1 acc %.1f TF | 2 acc %.1f TF | 4 acc %.1f TF | 8 acc %.1f TF\n", wps,
                    fl * 1 / t1 / 1e9, fl * 2 / t2 / 1e9, fl * 4 / t4 / 1e9, fl * 8 / t8 / 1e9);
         }
+    }
+    {
+        const int it2 = 20000, nblk = p.multiProcessorCount * 2;
+        float t0 = time_ms([&] { k_mfma_valu<0><<<nblk, 256>>>(out, it2, 1e-3); });
+        float t4 = time_ms([&] { k_mfma_valu<4><<<nblk, 256>>>(out, it2, 1e-3); });
+        float t8 = time_ms([&] { k_mfma_valu<8><<<nblk, 256>>>(out, it2, 1e-3); });
+        float t16 = time_ms([&] { k_mfma_valu<16><<<nblk, 256>>>(out, it2, 1e-3); });
+        printf("MFMA + N x v_fma_f64 per MFMA in one wave (2 waves/SIMD): N=0 %.3f ms | N=4 %.3f | N=8 %.3f | N=16 %.3f\n", t0, t4, t8, t16);
+        float f8 = time_ms([&] { k_mfma_valu32<8, 0><<<nblk, 256>>>(out, it2, 1e-3); });
+        float f16 = time_ms([&] { k_mfma_valu32<16, 0><<<nblk, 256>>>(out, it2, 1e-3); });
+        float i8 = time_ms([&] { k_mfma_valu32<8, 1><<<nblk, 256>>>(out, it2, 1e-3); });
+        float i16 = time_ms([&] { k_mfma_valu32<16, 1><<<nblk, 256>>>(out, it2, 1e-3); });
+        printf("MFMA + N x v_fma_f32: N=8 %.3f ms | N=16 %.3f ;  MFMA + N x v_add_u32: N=8 %.3f ms | N=16 %.3f\n", f8, f16, i8, i16);
     }
     {
         const int it2 = 40000;
