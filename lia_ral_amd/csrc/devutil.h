@@ -65,6 +65,35 @@ __device__ __forceinline__ double gexp_t(double x, const double *tab)
     return __builtin_ldexp(__builtin_fma(tj, p, tj), ki >> 5);
 }
 
+// exp(x) * 2^-E with the binary exponent applied in ONE ldexp, so x may be far outside exp()'s range
+// (logits of -5000 against a running exponent E of -7200 are fine).  x >= -4e7 (int32 range of k).
+__device__ __forceinline__ double gexp_scaled(double x, int E, const double *tab)
+{
+    x = fmax(x, -4.0e7);
+    const double k = __builtin_rint(x * 46.16624130844683);
+    double r = __builtin_fma(k, -0.021660849219188094, x);
+    r = __builtin_fma(k, -1.733101967801894e-10, r);
+    const int ki = (int)k;
+    const double tj = tab[ki & 31];
+    double p = 1.984126984126984e-04;
+    p = __builtin_fma(p, r, 1.388888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    int n = (ki >> 5) - E;
+    n = n < -2000 ? -2000 : n;
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
+}
+// floor(x log2 e) as used by gexp_scaled (the binary exponent of exp(x))
+__device__ __forceinline__ int gexp_exponent(double x)
+{
+    x = fmax(x, -4.0e7);
+    return ((int)__builtin_rint(x * 46.16624130844683)) >> 5;
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);

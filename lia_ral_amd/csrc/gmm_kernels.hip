@@ -138,11 +138,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         }
     };
 
-    double m[2][4], sacc[2][4];
+    // running sum per (lane, frame row): sum_c exp(z_c) = sacc * 2^E, nref = largest binary exponent seen
+    double sacc[2][4];
+    int E[2][4], nref[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { m[h][r] = GMMIV_NEG_BIG; sacc[h][r] = 0.0; }
+        for (int r = 0; r < 4; ++r) { sacc[h][r] = 0.0; E[h][r] = -(1 << 30); nref[h][r] = -(1 << 30); }
 
     stage(buf0, 0);
     __syncthreads();
@@ -167,74 +169,72 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
             acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
         }
-        // Online log-sum-exp per (lane, frame row).  The reference point m moves only when a logit
-        // exceeds it by more than 64 (first tile, then rare), so each logit costs one exp -- and none
-        // at all when it is more than 40 below m: sacc >= 1 once a lane has seen a logit (m is one of
-        // its logits), so a term below e^-40 < 2^-54 cannot change sacc; skipping it is bit-exact.
-        // All branches are wave-uniform (ballots).  With few dominant Gaussians per frame most
-        // (row, tile) pairs take no exp; with overlapping mixtures all 16 run branch-free.
-        if (dbg >= 1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sacc[h][r] += acc[0][h][r] + acc[1][h][r];
-            if (dbg < 2) __syncthreads();
-            continue;
-        }
-        double mx[2][4];
+        // Online log-sum-exp per (lane, frame row) with an INTEGER reference: the sum is kept as
+        // sacc * 2^E.  exp(z) = t * 2^n (t in [1,2)) is added as ldexp(t, n - E); when a logit's n
+        // exceeds E by 64 or more the reference moves with one ldexp (no exp, no fp64 compare
+        // chain).  A pair whose n is 57 or more below the largest n seen in its row is skipped:
+        // sacc * 2^E >= 2^nref already, so such a term (both of its terms together) is < 2^-54 of the sum -- skipping is bit-exact.
+        // All branches are wave-uniform (ballots): every VALU instruction here is MFMA time.
+        int nm[2][4];
         bool grow = false;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mx[h][r] = fmax(acc[0][h][r], acc[1][h][r]);
-                grow |= mx[h][r] > m[h][r] + 64.0;
+                nm[h][r] = gexp_exponent(fmax(acc[0][h][r], acc[1][h][r]));
+                grow |= nm[h][r] - E[h][r] >= 64;
             }
         if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (mx[h][r] > m[h][r] + 64.0) {
-                        sacc[h][r] *= gexp_t(m[h][r] - mx[h][r], etab);
-                        m[h][r] = mx[h][r];
+                    if (nm[h][r] - E[h][r] >= 64) {
+                        int sh = E[h][r] - nm[h][r];
+                        sh = sh < -2000 ? -2000 : sh;
+                        sacc[h][r] = __builtin_ldexp(sacc[h][r], sh);
+                        E[h][r] = nm[h][r];
                     }
         }
         unsigned need = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                need |= (__builtin_amdgcn_ballot_w64(mx[h][r] > m[h][r] - 40.0) != 0 ? 1u : 0u) << (h * 4 + r);
+            for (int r = 0; r < 4; ++r) {
+                nref[h][r] = nm[h][r] > nref[h][r] ? nm[h][r] : nref[h][r];
+                need |= (__builtin_amdgcn_ballot_w64(nm[h][r] > nref[h][r] - 57) != 0 ? 1u : 0u) << (h * 4 + r);
+            }
         if (__builtin_popcount(need) > 3) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    sacc[h][r] += gexp_t(acc[0][h][r] - m[h][r], etab) + gexp_t(acc[1][h][r] - m[h][r], etab);
+                    sacc[h][r] += gexp_scaled(acc[0][h][r], E[h][r], etab) + gexp_scaled(acc[1][h][r], E[h][r], etab);
         } else if (need) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (need & (1u << (h * 4 + r)))
-                        sacc[h][r] += gexp_t(acc[0][h][r] - m[h][r], etab) + gexp_t(acc[1][h][r] - m[h][r], etab);
+                        sacc[h][r] += gexp_scaled(acc[0][h][r], E[h][r], etab) + gexp_scaled(acc[1][h][r], E[h][r], etab);
         }
         __syncthreads();
     }
-    // combine the 16 lanes (Gaussian columns) that share a frame row
+    // combine the 16 lanes (Gaussian columns) that share a frame row: common exponent, then sum
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double M = m[h][r];
+            int Em = E[h][r];
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) M = fmax(M, shfl_xor_f64(M, o));
-            double sv = sacc[h][r] * gexp_t(m[h][r] - M, etab);
+            for (int o = 1; o < 16; o <<= 1) { const int oe = __shfl_xor(Em, o, 64); Em = oe > Em ? oe : Em; }
+            int sh = E[h][r] - Em;
+            sh = sh < -2000 ? -2000 : sh;
+            double sv = __builtin_ldexp(sacc[h][r], sh);
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) sv += shfl_xor_f64(sv, o);
             const long t = tb + h * 16 + q + 4 * r;
-            if (i16 == 0 && t < T) lse_out[t] = M + log(sv);
+            if (i16 == 0 && t < T) lse_out[t] = log(sv) + (double)Em * 0.693147180559945309417;
         }
 }
 
