@@ -85,6 +85,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "timing")) slot = &c->timing;
     else if (!strcmp(key, "wg_waves")) slot = &c->wg_waves;
     else if (!strcmp(key, "dbg")) slot = &c->dbg;
+    else if (!strcmp(key, "prune_log2")) slot = &c->prune_log2;
     if (!slot) return -1;
     long prev = *slot;
     *slot = value;
@@ -394,7 +395,7 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if ((rc = c->scratch(WS_PART, (size_t)nseg * Cp * 2 * RL * sizeof(double), &part))) return rc;
     c->t_begin("k_stats_mfma");
     GCHK(gmmk_stats(c->stream, g->KS, 1, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, -log(weight), seg,
-                    nseg, (double *)part, nullptr, 0, (int)c->wg_waves));
+                    nseg, (double *)part, nullptr, 0, (int)c->wg_waves, c->prune_arg()));
     c->t_end();
     GCHK(gmmk_em_reduce(c->stream, (const double *)part, nseg, g->C, (int)Cp, g->D, g->KS, o.d));
     return o.finish();
@@ -479,7 +480,7 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     // every (u, c < C) row is written by exactly one wave (zeros for an empty utterance)
     c->t_begin("k_stats_mfma");
     GCHK(gmmk_stats(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, 0.0,
-                    (const long *)seg, (int)U, o_n.d, o_f.d, 1, (int)c->wg_waves));
+                    (const long *)seg, (int)U, o_n.d, o_f.d, 1, (int)c->wg_waves, c->prune_arg()));
     c->t_end();
     if ((rc = o_n.finish())) return rc;
     return o_f.finish();

@@ -35,6 +35,13 @@ struct gmmiv_ctx {
     long em_chunks = 0; // 0 = auto
     long timing = 0;
     long dbg = 0; // timing experiments (wrong results when != 0)
+    // statistics kernels, OPT-IN: groups of 4 frames x 16 Gaussians whose posteriors are ALL below
+    // 2^-prune_log2 are skipped (exp + MFMAs).  0 (default) = never skip: every pair is accumulated
+    // like the reference does.  With 100, at most 2e10 pairs x 2^-100 = 1.6e-20 of posterior mass is
+    // dropped per 10 M-frame pass -- invisible in any live Gaussian, but a DEAD Gaussian (occupancy
+    // ~1e-60) gets a different ML mean than the reference's sum of denormal-scale terms.
+    long prune_log2 = 0;
+    double prune_arg() const { return prune_log2 > 0 ? -(double)prune_log2 * 0.6931471805599453 : -__builtin_inf(); }
     long wg_waves = 8; // waves per workgroup of the two MFMA GMM kernels (8, or 4 for A/B runs)
     int n_cu = 256;
     // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name

@@ -14,7 +14,7 @@ int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, doub
 int gmmk_add_scalar(hipStream_t st, double *dst, double v);
 int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
                int nct, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,
-               double *out1, int mode, int wg_waves);
+               double *out1, int mode, int wg_waves, double prune_arg);
 int gmmk_em_reduce(hipStream_t st, const double *part, int nseg, int C, int Cp, int D, int KS, double *acc);
 int gmmk_em_get(hipStream_t st, int C, int D, const double *acc, const double *prev_mean, const double *prev_cov,
                 double *w, double *mean, double *cov);

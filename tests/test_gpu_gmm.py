@@ -175,6 +175,23 @@ def test_workgroup_shapes_agree(ctx):
     assert relerr(res[4][1], res[8][1]) < 1e-12
 
 
+@pytest.mark.parametrize("spread", [2.0, 0.3])
+def test_posterior_pruning_is_invisible(ctx, spread):
+    """Opt-in pruning: groups whose posteriors are all below 2^-100 are skipped by the statistics
+    kernels; against the default (every pair accumulated) the sums agree to rounding."""
+    w, mean, iv = make_gmm(1024, 60, seed=31, spread=spread)
+    x = make_frames(w, mean, iv, 5000, seed=32)
+    g = ctx.gmm(w, mean, iv)
+    ub = np.array([0, 1234, 5000])
+    a_off = g.em_accumulate(x)
+    n_off, f_off = g.tv_stats(x, ub)
+    ctx.set_option("prune_log2", 100)
+    a_on = g.em_accumulate(x)
+    n_on, f_on = g.tv_stats(x, ub)
+    ctx.set_option("prune_log2", 0)
+    assert relerr(a_on, a_off) < 1e-14 and relerr(n_on, n_off) < 1e-14 and relerr(f_on, f_off) < 1e-14
+
+
 def test_em_zero_frames_and_ragged_edges(ctx):
     w, mean, iv = make_gmm(64, 60, seed=2)
     g = ctx.gmm(w, mean, iv)
