@@ -154,6 +154,17 @@ int gmmiv_tv_update_t(gmmiv_ctx *ctx, int C, int D, int R, const double *A_packe
                       double *Tm);
 int gmmiv_tv_min_divergence(gmmiv_ctx *ctx, int C, int D, int R, double n_sessions, double *Rm,
                             double *r, const double *meanW, double *ubm_means, double *Tm);
+/* orthonormalizeT (AccumulateTVStat.cpp:1548-1596): classical Gram-Schmidt over the rows of
+ * T[R x SV], in place (coefficients taken against the ORIGINAL row, zero rows stay zero). */
+int gmmiv_tv_orthonormalize_t(gmmiv_ctx *ctx, int R, int64_t SV, double *Tm);
+
+/* ---- PldaTest::center / rotateLeft / lengthNorm (PldaTools.cpp:3706-3790); one iteration of
+ * sphericalNuisanceNormalization (:3793-3839) = all three ------------------------------------------
+ * Y[dim_out x n] = lengthNorm( M[dim_out x dim_in] * (X[dim_in x n] - mean[dim_in]) ), vectors as
+ * columns.  mean == NULL: no centring; M == NULL: no rotation (dim_out == dim_in);
+ * length_norm == 0: columns are not normalised.  Y may alias X when M == NULL. */
+int gmmiv_iv_normalize(gmmiv_ctx *ctx, int dim_in, int dim_out, int64_t n, const double *X,
+                       const double *mean, const double *M, int length_norm, double *Y);
 
 /* ---- PldaTest scoring (LIA_SpkTools/src/PldaTools.cpp) ------------------------------------------
  * models[dim x M], segs[dim x S]: one vector per COLUMN like PldaTest::_models/_segments;

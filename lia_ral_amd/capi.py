@@ -181,6 +181,20 @@ class Context:
                                          _ptr(means), _ptr(Tm)))
         return means, Tm
 
+    def tv_orthonormalize_t(self, Tm):
+        R, SV = Tm.shape
+        _chk(lib.gmmiv_tv_orthonormalize_t(self._h, R, ct.c_int64(SV), _ptr(Tm)))
+        return Tm
+
+    def iv_normalize(self, X, mean=None, M=None, length_norm=True, out=None):
+        dim_in, n = X.shape
+        dim_out = M.shape[0] if M is not None else dim_in
+        if out is None:
+            out = np.empty((dim_out, n))
+        _chk(lib.gmmiv_iv_normalize(self._h, dim_in, dim_out, ct.c_int64(n), _ptr(X), _ptr(_f64(mean)), _ptr(_f64(M)),
+                                    int(bool(length_norm)), _ptr(out)))
+        return out
+
     # ---- scoring (vectors as columns: models[dim, M], segs[dim, S])
     def _score_out(self, models, segs, out):
         M, S = models.shape[1], segs.shape[1]

@@ -313,6 +313,63 @@ int gmmiv_tv_min_divergence(gmmiv_ctx *c, int C, int D, int R, double n_sessions
     return o_t.finish();
 }
 
+int gmmiv_tv_orthonormalize_t(gmmiv_ctx *c, int R, int64_t SV, double *Tm)
+{
+    if (!c || R <= 0 || SV <= 0 || !Tm) { gmmiv_set_error("tv_orthonormalize_t: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    DevOut<double> o;
+    int rc;
+    if ((rc = o.init(c, WS_T0, Tm, (size_t)R * SV, true))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_T1, (size_t)R * SV * 8, &p))) return rc;
+    double *Q = (double *)p;
+    if ((rc = c->scratch(WS_T2, ((size_t)SV + R + 512) * 8, &p))) return rc;
+    double *v = (double *)p, *rv = v + SV, *partial = rv + R;
+    GCHK(tvk_orthonormalize(c->stream, R, (long)SV, o.d, Q, rv, v, partial));
+    GCHK(hipMemcpyAsync(o.d, Q, (size_t)R * SV * 8, hipMemcpyDeviceToDevice, c->stream));
+    return o.finish();
+}
+
+// ---- i-vector normalisation ------------------------------------------------------------------
+int gmmiv_iv_normalize(gmmiv_ctx *c, int dim_in, int dim_out, int64_t n, const double *X, const double *mean,
+                       const double *M, int length_norm, double *Y)
+{
+    if (!c || dim_in <= 0 || dim_out <= 0 || n < 0 || !X || !Y) { gmmiv_set_error("iv_normalize: bad argument"); return GMMIV_ERR_ARG; }
+    if (!M && dim_in != dim_out) { gmmiv_set_error("iv_normalize: dim_out must equal dim_in without a rotation matrix"); return GMMIV_ERR_ARG; }
+    if (n > 0x7fffffff) { gmmiv_set_error("iv_normalize: too many vectors"); return GMMIV_ERR_UNSUPPORTED; }
+    if (n == 0) return GMMIV_OK;
+    GCHK(hipSetDevice(c->device));
+    DevIn<double> i_x, i_mu, i_m;
+    DevOut<double> o;
+    int rc;
+    if ((rc = i_x.init(c, WS_T0, X, (size_t)dim_in * n))) return rc;
+    if ((rc = i_mu.init(c, WS_T1, mean, dim_in))) return rc;
+    if ((rc = i_m.init(c, WS_T2, M, (size_t)dim_out * dim_in))) return rc;
+    if ((rc = o.init(c, WS_T3, Y, (size_t)dim_out * n, false))) return rc;
+    const double *cur = i_x.d;
+    void *p;
+    if (mean) { // PldaTest::center (PldaTools.cpp:3754-3767)
+        double *dst = o.d;
+        if (M || cur == o.d) {
+            if ((rc = c->scratch(WS_T4, (size_t)dim_in * n * 8, &p))) return rc;
+            dst = (double *)p;
+        }
+        GCHK(tvk_sub_colvec(c->stream, dim_in, n, cur, i_mu.d, dst));
+        cur = dst;
+    }
+    if (M) { // PldaTest::rotateLeft (:3770-3790): Y = M X
+        GCHK(tvk_dgemm(c->stream, false, false, dim_out, (int)n, dim_in, 1.0, i_m.d, dim_in, 0, cur, n, 0, 0.0, o.d, n, 0, 1));
+        cur = o.d;
+    }
+    if (cur != o.d) GCHK(hipMemcpyAsync(o.d, cur, (size_t)dim_out * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (length_norm) { // PldaTest::lengthNorm (:3706-3751)
+        if ((rc = c->scratch(WS_T5, (size_t)n * 8, &p))) return rc;
+        GCHK(tvk_coldot(c->stream, dim_out, n, o.d, o.d, (double *)p));
+        GCHK(tvk_scale_cols_rsqrt(c->stream, dim_out, n, o.d, (const double *)p));
+    }
+    return o.finish();
+}
+
 // ---- scoring -----------------------------------------------------------------------------
 struct ScoreArgs {
     DevIn<double> m, s;

@@ -24,3 +24,6 @@ int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const
 int tvk_splitk_count(int M, int N, int K, int n_cu);
 int tvk_dgemm_splitk(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda,
                      const double *B, long ldb, double beta, double *C, long ldc, int nz, double *slabs);
+int tvk_sub_colvec(hipStream_t st, int dim, long n, const double *X, const double *v, double *out);
+int tvk_scale_cols_rsqrt(hipStream_t st, int dim, long n, double *X, const double *qv);
+int tvk_orthonormalize(hipStream_t st, int R, long SV, const double *Tm, double *Q, double *rv, double *v, double *partial);

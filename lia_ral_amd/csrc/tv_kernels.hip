@@ -547,3 +547,87 @@ int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, d
     k_add_transpose<<<(n * n + 255) / 256, 256, 0, st>>>(n, a, b, out);
     return (int)hipGetLastError();
 }
+
+// -------------------------------------------------------------------------------------------
+// i-vector normalisation (PldaTest::center / rotateLeft / lengthNorm) and classical Gram-Schmidt
+// -------------------------------------------------------------------------------------------
+__global__ void k_sub_colvec(int dim, long n, const double *__restrict__ X, const double *__restrict__ v,
+                             double *__restrict__ out)
+{
+    const size_t tot = (size_t)dim * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = X[e] - v[e / n];
+}
+// X[:, j] /= sqrt(q[j])
+__global__ void k_scale_cols_rsqrt(int dim, long n, double *__restrict__ X, const double *__restrict__ qv)
+{
+    const size_t tot = (size_t)dim * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x)
+        X[e] = X[e] / sqrt(qv[e % n]);
+}
+int tvk_sub_colvec(hipStream_t st, int dim, long n, const double *X, const double *v, double *out)
+{
+    if (n <= 0) return 0;
+    k_sub_colvec<<<4096, 256, 0, st>>>(dim, n, X, v, out);
+    return (int)hipGetLastError();
+}
+int tvk_scale_cols_rsqrt(hipStream_t st, int dim, long n, double *X, const double *qv)
+{
+    if (n <= 0) return 0;
+    k_scale_cols_rsqrt<<<4096, 256, 0, st>>>(dim, n, X, qv);
+    return (int)hipGetLastError();
+}
+
+// rv[i] = <Q_i, t>  for i < j   (one workgroup per i)
+__global__ __launch_bounds__(256) void k_gs_project(long SV, const double *__restrict__ Q, const double *__restrict__ t,
+                                                    double *__restrict__ rv)
+{
+    __shared__ double red[4];
+    const double *qi = Q + (size_t)blockIdx.x * SV;
+    double s = 0.0;
+    for (long k = threadIdx.x; k < SV; k += 256) s = __builtin_fma(qi[k], t[k], s);
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rv[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// v[k] = t[k] - sum_{i<j} rv[i] Q[i][k] ; partial[b] = sum_k v[k]^2 over this block's k
+__global__ __launch_bounds__(256) void k_gs_update(long SV, int j, const double *__restrict__ Q, const double *__restrict__ t,
+                                                   const double *__restrict__ rv, double *__restrict__ v,
+                                                   double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double nv = 0.0;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < SV; k += (long)gridDim.x * 256) {
+        double a = t[k];
+        for (int i = 0; i < j; ++i) a -= rv[i] * Q[(size_t)i * SV + k];
+        v[k] = a;
+        nv = __builtin_fma(a, a, nv);
+    }
+    nv = wave_sum_f64(nv);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nv;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// q[k] = norm > 0 ? v[k] / norm : 0, norm = sqrt(sum partial)
+__global__ void k_gs_finish(long SV, int nb, const double *__restrict__ v, const double *__restrict__ partial,
+                            double *__restrict__ qrow)
+{
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[b];
+    const double nrm = sqrt(s);
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < SV; k += (long)gridDim.x * blockDim.x)
+        qrow[k] = nrm == 0.0 ? 0.0 : v[k] / nrm;
+}
+// TVAcc::orthonormalizeT: Q (R x SV, output), T (input), scratch: rv[R], v[SV], partial[nb]
+int tvk_orthonormalize(hipStream_t st, int R, long SV, const double *Tm, double *Q, double *rv, double *v, double *partial)
+{
+    const int nb = 512;
+    for (int j = 0; j < R; ++j) {
+        const double *tj = Tm + (size_t)j * SV;
+        if (j > 0) k_gs_project<<<j, 256, 0, st>>>(SV, Q, tj, rv);
+        k_gs_update<<<nb, 256, 0, st>>>(SV, j, Q, tj, rv, v, partial);
+        k_gs_finish<<<512, 256, 0, st>>>(SV, nb, v, partial, Q + (size_t)j * SV);
+    }
+    return (int)hipGetLastError();
+}

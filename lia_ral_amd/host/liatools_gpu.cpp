@@ -388,4 +388,9 @@ void TVAcc::minDivergence()
                                        _meanW.data(), _ubm_means.data(), _T.data()));
 }
 
+void TVAcc::orthonormalizeT()
+{
+    _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankT, (int64_t)_svSize, _T.data()));
+}
+
 } // namespace liagpu

@@ -182,6 +182,7 @@ class TVAcc {
     void estimateAandC();              // :1702-1795
     void updateTestimate();            // :974-1005
     void minDivergence();              // :2056-2099
+    void orthonormalizeT();            // :1548-1596
     void resetTmpAcc();                // :620-629
     void loadT(const std::vector<double> &T) { _T = T; }
     void setStats(const std::vector<double> &N, const std::vector<double> &F) { _statN = N; _statF = F; }

@@ -589,6 +589,32 @@ void orc_tv_orthonormalize_t(int R, size_t SV, double *Tm)
  * the reference's _models/_segments; scores[M x S]; trials mask (NULL = all).
  * ------------------------------------------------------------------------------------------- */
 
+/* PldaTest::center -> rotateLeft -> lengthNorm: LIA_SpkTools/src/PldaTools.cpp:3754-3767, 3770-3790,
+ * 3706-3751 (one iteration of sphericalNuisanceNormalization :3793-3839).  X[din x n] vectors as
+ * columns; mean / M may be NULL; Y[dout x n]. */
+void orc_iv_normalize(int din, int dout, long n, const double *X, const double *mean, const double *Mx,
+                      int length_norm, double *Y)
+{
+    double *c = malloc(sizeof(double) * din * n);
+    for (int k = 0; k < din; ++k)
+        for (long s = 0; s < n; ++s) c[k * n + s] = X[k * n + s] - (mean ? mean[k] : 0.0);
+    for (int i = 0; i < dout; ++i)
+        for (long s = 0; s < n; ++s) {
+            double a = 0.0;
+            if (Mx) for (int k = 0; k < din; ++k) a += Mx[(size_t)i * din + k] * c[k * n + s];
+            else a = c[i * n + s];
+            Y[i * n + s] = a;
+        }
+    if (length_norm)
+        for (long s = 0; s < n; ++s) {
+            double t = 0.0;
+            for (int k = 0; k < dout; ++k) t += Y[k * n + s] * Y[k * n + s];
+            t = sqrt(t);
+            for (int k = 0; k < dout; ++k) Y[k * n + s] /= t;
+        }
+    free(c);
+}
+
 /* cosineDistance: LIA_SpkTools/src/PldaTools.cpp:3842-3879 */
 void orc_score_cosine(int dim, long M, long S, const double *models, const double *segs,
                       const unsigned char *trials, double *scores)

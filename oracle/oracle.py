@@ -293,6 +293,18 @@ def _trials(tr):
     return tr, tr.ctypes.data_as(ct.POINTER(ct.c_ubyte))
 
 
+def iv_normalize(X, mean=None, M=None, length_norm=True):
+    X, xp = _d(X)
+    din, n = X.shape
+    dout = M.shape[0] if M is not None else din
+    Y = np.empty((dout, n))
+    mp = _d(mean)[1] if mean is not None else None
+    Mp = _d(M)[1] if M is not None else None
+    _lib().orc_iv_normalize(ct.c_int(din), ct.c_int(dout), ct.c_long(n), xp, mp, Mp, ct.c_int(int(length_norm)),
+                            Y.ctypes.data_as(c_dp))
+    return Y
+
+
 def score_cosine(models, segs, trials=None):
     m, mp = _d(models); s, sp = _d(segs)
     dim, M = m.shape; S = s.shape[1]

@@ -102,3 +102,27 @@ def test_plda_scoring(ctx):
     got = ctx.score_plda(models, nsess, segs, FTJF)
     ref = orc.score_plda(models, nsess, segs, FTJF)
     assert relerr(got, ref) < 1e-10
+
+
+def test_iv_normalisation_and_orthonormalize(ctx):
+    rng = np.random.default_rng(5)
+    din, dout, n = 60, 40, 333
+    X = rng.normal(size=(din, n)) + 0.5; mu = X.mean(1); M = rng.normal(size=(dout, din))
+    for mean, rot, ln in [(mu, M, True), (mu, None, False), (None, M, False), (None, None, True), (mu, None, True)]:
+        got = ctx.iv_normalize(X, mean, rot, ln)
+        ref = orc.iv_normalize(X, mean, rot, ln)
+        assert relerr(got, ref) < 1e-12
+    # sphericalNuisanceNormalization, 2 iterations == numpy
+    M2 = rng.normal(size=(dout, dout)); mu2 = rng.normal(size=dout) * 0.01
+    Y = ctx.iv_normalize(ctx.iv_normalize(X, mu, M, True), mu2, M2, True)
+    Z = M @ (X - mu[:, None]); Z /= np.linalg.norm(Z, axis=0)
+    Z = M2 @ (Z - mu2[:, None]); Z /= np.linalg.norm(Z, axis=0)
+    assert relerr(Y, Z) < 1e-12 and np.allclose(np.linalg.norm(Y, axis=0), 1.0, atol=1e-13)
+    # classical Gram-Schmidt of T rows
+    T = rng.normal(size=(24, 1000))
+    T[5] = 0.0                                     # a zero row stays zero (AccumulateTVStat.cpp:1577-1581)
+    Q = ctx.tv_orthonormalize_t(T.copy())
+    Qo = orc.tv_orthonormalize_t(T)
+    assert relerr(Q, Qo) < 1e-10
+    keep = [i for i in range(24) if i != 5]
+    assert np.allclose(Q[keep] @ Q[keep].T, np.eye(23), atol=1e-10) and not Q[5].any()

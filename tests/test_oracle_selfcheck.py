@@ -68,6 +68,9 @@ def test_scoring_against_numpy():
     assert np.allclose(orc.score_cosine(m, s), cos)
     tr = rng.random((M, S)) > 0.5
     assert np.allclose(orc.score_cosine(m, s, tr), np.where(tr, cos, 0))
+    mu = m.mean(1); Mr = rng.normal(size=(5, d))
+    y = Mr @ (m - mu[:, None]); y /= np.linalg.norm(y, axis=0)
+    assert np.allclose(orc.iv_normalize(m, mu, Mr, True), y)
     Q = rng.normal(size=(d, d)); Mah = Q @ Q.T + np.eye(d)
     diff = m[:, :, None] - s[:, None, :]
     assert np.allclose(orc.score_mahalanobis(m, s, Mah), -0.5 * np.einsum("ims,ij,jms->ms", diff, Mah, diff))
