@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "liatools_gpu.h"
+#include "io.h"
 
 using namespace liagpu;
 
@@ -130,6 +131,68 @@ int liagpu_tv_train(int device, long U, int C, int D, const double *w, const dou
         }
         memcpy(Tmat, tv.getT().data(), tv.getT().size() * sizeof(double));
         if (mean_out) memcpy(mean_out, tv.getUbmMeans().data(), tv.getUbmMeans().size() * sizeof(double));
+    })
+}
+
+// ComputeTest from FILES for one ndx line (test file + client list): RAW models, .prm features with
+// featureServerMask, .lbl selection.  Writes the NIST-style result lines (segmental mode) into out_text
+// and the LLRs into llr_out[nseg x nClients].  ComputeTest.cpp:129-215 + the format readers of io.h.
+int liagpu_compute_test_files(int device, const char *world_path, int nClients, const char **client_paths,
+                              const char **client_names, const char *prm_path, const char *lbl_path, const char *mask,
+                              const char *label, double frameLength, int topDistribsCount, int complete, double minLLK,
+                              double maxLLK, const char *gender, const char *testName, double threshold, double *llr_out,
+                              long max_llr, char *out_text, long out_cap)
+{
+    GUARD({
+        GpuServer srv(device);
+        MixtureGD world = readMixtureRAW(world_path);
+        FeatureFile ff = readFeatureFile(prm_path, mask ? mask : "");
+        if (ff.vectSize != world.getVectSize()) throw Exception("vectSize of features and world model differ");
+        FeatureBuffer fs(srv, ff.data.data(), ff.nFrames, ff.vectSize);
+        SegCluster segs = selectSegments(readLabelFile(lbl_path), label, frameLength);
+        DeviceMixture dworld(srv, world);
+        std::vector<DeviceMixture *> cl;
+        std::vector<double> out;
+        try {
+            for (int i = 0; i < nClients; ++i) cl.push_back(new DeviceMixture(srv, readMixtureRAW(client_paths[i])));
+            out = computeTestLLR(fs, segs, dworld, cl, topDistribsCount, complete != 0, minLLK, maxLLK, true);
+        } catch (...) { for (auto p : cl) delete p; throw; }
+        for (auto p : cl) delete p;
+        if ((long)out.size() > max_llr) throw Exception("llr_out too small");
+        memcpy(llr_out, out.data(), out.size() * sizeof(double));
+        std::string text;
+        for (size_t s = 0; s < segs.size(); ++s)
+            for (int i = 0; i < nClients; ++i)   // frameIdxToTime(begin), frameIdxToTime(begin + length) (ComputeTest.cpp:186)
+                text += resultLine(out[s * nClients + i], client_names[i], testName, gender, threshold, true,
+                                   segs[s].begin * frameLength, (segs[s].begin + segs[s].length) * frameLength) + "\n";
+        if ((long)text.size() + 1 > out_cap) throw Exception("out_text too small");
+        memcpy(out_text, text.c_str(), text.size() + 1);
+    })
+}
+
+// format round trips used by the CPU tests (no GPU involved)
+int liagpu_io_roundtrip(const char *raw_in, const char *raw_out, const char *prm_in, const char *prm_out, const char *mask,
+                        long *dims /* C, D, nFrames, vectSize */, double *first_mean, float *first_frame)
+{
+    GUARD({
+        MixtureGD m = readMixtureRAW(raw_in);
+        writeMixtureRAW(raw_out, m);
+        FeatureFile f = readFeatureFile(prm_in, "");
+        writeFeatureFile(prm_out, f);
+        FeatureFile fm = readFeatureFile(prm_in, mask);
+        dims[0] = (long)m.getDistribCount(); dims[1] = (long)m.getVectSize(); dims[2] = (long)fm.nFrames; dims[3] = (long)fm.vectSize;
+        for (unsigned long d = 0; d < m.getVectSize(); ++d) first_mean[d] = m.getMean(0, d);
+        for (unsigned long d = 0; d < fm.vectSize; ++d) first_frame[d] = fm.data[d];
+    })
+}
+
+int liagpu_label_segments(const char *lbl_path, const char *label, double frameLength, long *begin, long *len, long cap, long *n)
+{
+    GUARD({
+        SegCluster c = selectSegments(readLabelFile(lbl_path), label, frameLength);
+        if ((long)c.size() > cap) throw Exception("segment buffer too small");
+        for (size_t i = 0; i < c.size(); ++i) { begin[i] = (long)c[i].begin; len[i] = (long)c[i].length; }
+        *n = (long)c.size();
     })
 }
 

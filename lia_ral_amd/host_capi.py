@@ -101,3 +101,34 @@ def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     _chk(lib.liagpu_tv_train(device, ct.c_long(N.shape[0]), C, D, _d(w), _d(mean), _d(cov), R, _d(N), _d(F), _d(Tm), nb_it,
                              int(min_div), _d(means)))
     return Tm, means
+
+
+def compute_test_files(world_path, client_paths, client_names, prm_path, lbl_path, mask="", label="male", frame_length=0.01,
+                       top_c=10, complete=True, min_llk=-200.0, max_llk=200.0, gender="M", test_name="test", threshold=0.0,
+                       device=0):
+    """ComputeTest (segmental mode) driven from RAW model / .prm / .lbl files; returns (LLR[nseg, nclients], text)."""
+    n = len(client_paths)
+    cp = (ct.c_char_p * n)(*[p.encode() for p in client_paths])
+    cn = (ct.c_char_p * n)(*[p.encode() for p in client_names])
+    llr = np.empty(4096)
+    text = ct.create_string_buffer(1 << 16)
+    _chk(lib.liagpu_compute_test_files(device, world_path.encode(), n, cp, cn, prm_path.encode(), lbl_path.encode(), mask.encode(),
+                                       label.encode(), ct.c_double(frame_length), top_c, int(complete), ct.c_double(min_llk),
+                                       ct.c_double(max_llk), gender.encode(), test_name.encode(), ct.c_double(threshold),
+                                       llr.ctypes.data_as(_dp), ct.c_long(len(llr)), text, ct.c_long(len(text))))
+    lines = text.value.decode().strip().split("\n")
+    return llr[:len(lines)].reshape(-1, n), lines
+
+
+def io_roundtrip(raw_in, raw_out, prm_in, prm_out, mask):
+    dims = np.zeros(4, np.int64); mean0 = np.zeros(512); frame0 = np.zeros(512, np.float32)
+    _chk(lib.liagpu_io_roundtrip(raw_in.encode(), raw_out.encode(), prm_in.encode(), prm_out.encode(), mask.encode(),
+                                 dims.ctypes.data_as(_lp), mean0.ctypes.data_as(_dp), frame0.ctypes.data_as(_fp)))
+    return dims, mean0[:dims[1]], frame0[:dims[3]]
+
+
+def label_segments(lbl_path, label, frame_length=0.01):
+    b = np.zeros(1024, np.int64); l = np.zeros(1024, np.int64); n = ct.c_long(0)
+    _chk(lib.liagpu_label_segments(lbl_path.encode(), label.encode(), ct.c_double(frame_length), b.ctypes.data_as(_lp),
+                                   l.ctypes.data_as(_lp), ct.c_long(1024), ct.byref(n)))
+    return b[:n.value].copy(), l[:n.value].copy()

@@ -1,0 +1,52 @@
+"""File formats either side of the hot path against genuine files written by
+ALIZE / LIA_RAL and shipped as the reference's test data (tests/golden/ref_files/)."""
+import filecmp
+import os
+import struct
+
+import numpy as np
+import pytest
+
+REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_files")
+
+
+def test_raw_mixture_and_prm_roundtrip(tmp_path, golden_dir):
+    from lia_ral_amd import host_capi as h
+    raw = os.path.join(REF, "traintarget_wld.raw.gmm")
+    prm = os.path.join(REF, "test1.prm")
+    out_raw, out_prm = str(tmp_path / "w.gmm"), str(tmp_path / "f.prm")
+    dims, mean0, frame0 = h.io_roundtrip(raw, out_raw, prm, out_prm, "0-15,17-32")
+    assert tuple(dims) == (128, 32, 50, 32)
+    k = np.load(os.path.join(golden_dir, "kat2_traintarget.npz"))
+    assert np.array_equal(mean0, k["mean_world"][0])                # reader == fixture extraction
+    assert np.array_equal(frame0, k["x"][0])                        # mask 0-15,17-32 drops column 16
+    assert filecmp.cmp(prm, out_prm, shallow=False)                 # feature file re-written bit for bit
+    a, b = open(raw, "rb").read(), open(out_raw, "rb").read()
+    assert len(a) == len(b) and a[:8 + 8 * 128] == b[:8 + 8 * 128]  # header + weights identical
+    # cst / det are recomputed (computeAll) and covInv goes through cov = 1/covInv: equal to rounding
+    # (the stored cst/det may carry a substituted low mantissa byte -- SURVEY.md F3 -- hence 1e-6)
+    rec = 17 + 16 * 32
+    for c in (0, 17, 127):
+        off = 8 + 8 * 128 + c * rec
+        ca, da = struct.unpack_from("<dd", a, off); cb, db = struct.unpack_from("<dd", b, off)
+        assert abs(ca - cb) <= 1e-6 * abs(ca) and abs(da - db) <= 1e-6 * abs(da)
+        ia = np.frombuffer(a, "<f8", 64, off + 17); ib = np.frombuffer(b, "<f8", 64, off + 17)
+        assert np.allclose(ia[:32], ib[:32], rtol=1e-15, atol=0) and np.array_equal(ia[32:], ib[32:])
+
+
+def test_label_selection_inclusive_end():
+    from lia_ral_amd import host_capi as h
+    b, l = h.label_segments(os.path.join(REF, "computetest_test1.lbl"), "male")     # "0 0.25 male" / "0.3 0.4 male"
+    assert list(b) == [0, 30] and list(l) == [26, 11]                               # SegTools.cpp:265-271
+    b, l = h.label_segments(os.path.join(REF, "traintarget_test1.lbl"), "speech")   # "0 0.1" / "0.2 0.4"
+    assert list(b) == [0, 20] and list(l) == [11, 21]
+    b, l = h.label_segments(os.path.join(REF, "computetest_test1.lbl"), "female")
+    assert len(b) == 0
+
+
+def test_damaged_file_is_reported(tmp_path):
+    from lia_ral_amd import host_capi as h
+    bad = tmp_path / "short.gmm"
+    bad.write_bytes(open(os.path.join(REF, "traintarget_wld.raw.gmm"), "rb").read()[:-3])
+    with pytest.raises(h.HostError, match="text-mode damaged"):
+        h.io_roundtrip(str(bad), str(tmp_path / "o.gmm"), os.path.join(REF, "test1.prm"), str(tmp_path / "o.prm"), "")
