@@ -37,3 +37,17 @@ def em_iteration(accumulate, n_frames, acc, rank=0, world=1):
     b, e = shard_range(n_frames, rank, world)
     accumulate(b, e, acc)
     return all_reduce_sum(acc)
+
+
+def tv_estep(estimate, n_utt, acc, rank=0, world=1):
+    """One distributed E-step of the T-matrix EM (TVAcc::estimateAandC, AccumulateTVStat.cpp:1702-1795):
+    `estimate(begin, end, acc)` adds the utterances [begin, end) of this rank into the accumulators
+    acc = {"A", "Cmx", "Rm", "r", "meanW"} (gmmiv_tv_estimate_a_and_c on a GPU rank; meanW is the SUM
+    of the i-vectors), then every accumulator is summed over ranks -- the collective twin of the
+    mutex-guarded `+=` of the reference's threads (:1920-1937, :2036-2044).  A (packed, 1.31 GB at
+    C=2048, R=400) and Cmx (393 MB) dominate the payload; the M-step is replicated on every rank."""
+    b, e = shard_range(n_utt, rank, world)
+    estimate(b, e, acc)
+    for k in ("A", "Cmx", "Rm", "r", "meanW"):
+        all_reduce_sum(acc[k])
+    return acc

@@ -61,6 +61,26 @@ int liagpu_train_world(int device, const float *x, long T, int D, const long *se
     })
 }
 
+// TrainTarget (TrainTarget.cpp:73-278 minus file I/O): client = MAP-adapt(world) on the selected frames
+int liagpu_train_target(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                        int C, const double *w, const double *mean, const double *cov, int nbTrainIt, double meanReg,
+                        double *w_out, double *mean_out, double *cov_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD world = make_mixture(C, D, w, mean, cov);
+        MixtureGD client = world;
+        MAPCfg cfg;
+        cfg.nbTrainIt = nbTrainIt; cfg.meanReg = meanReg;
+        adaptModel(fs, segs, world, client, cfg);
+        memcpy(w_out, client.weights().data(), C * sizeof(double));
+        memcpy(mean_out, client.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov_out, client.covs().data(), (size_t)C * D * sizeof(double));
+    })
+}
+
 // ComputeTest for one test file: world + nClients models (same C, D), covariances given as covInv
 int liagpu_compute_test(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
                         int C, const double *w_world, const double *mean_world, const double *cov_world, int nClients,

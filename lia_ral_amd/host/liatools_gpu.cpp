@@ -281,6 +281,56 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, con
     return llkIt;
 }
 
+// ---- TrainTarget -------------------------------------------------------------------------------------
+void computeMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount)
+{
+    const unsigned long C = initModel.getDistribCount(), D = initModel.getVectSize();
+    MixtureGD tmp = initModel;
+    if (cfg.meanAdapt || cfg.varAdapt)
+        for (unsigned long c = 0; c < C; ++c) {
+            const double alpha = client.weight(c) * frameCount; // occupation of the component
+            if (cfg.meanAdapt) {
+                const double a = alpha / (alpha + cfg.meanReg);
+                for (unsigned long i = 0; i < D; ++i) tmp.setMean(c, (1 - a) * initModel.getMean(c, i) + a * client.getMean(c, i), i);
+            }
+            if (cfg.varAdapt) {
+                const double a = alpha / (alpha + cfg.varReg);
+                for (unsigned long i = 0; i < D; ++i) {
+                    const double dm = initModel.getMean(c, i) - client.getMean(c, i);
+                    tmp.setCov(c, (1 - a) * initModel.getCov(c, i) + a * client.getCov(c, i) + (1 - a) * a * dm * dm, i);
+                }
+            }
+        }
+    if (cfg.weightAdapt) {
+        double sum = 0.0;
+        for (unsigned long c = 0; c < C; ++c) {
+            const double alpha = client.weight(c) * frameCount, a = alpha / (alpha + cfg.weightReg);
+            tmp.weight(c) = a * client.weight(c) + (1 - a) * initModel.weight(c);
+            sum += tmp.weight(c);
+        }
+        for (unsigned long c = 0; c < C; ++c) tmp.weight(c) /= sum;
+    }
+    tmp.computeAll();
+    client = tmp;
+}
+
+void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const MixtureGD &aprioriModel, MixtureGD &clientMixture,
+                const MAPCfg &mapCfg)
+{
+    DeviceMixture dclient(fs.server(), clientMixture);
+    for (unsigned long trainIt = 0; trainIt < mapCfg.nbTrainIt; ++trainIt) {
+        EMAcc emAcc(dclient, clientMixture);
+        SegCluster bagged;
+        baggedSegments(selectedSegments, bagged, mapCfg.baggedFrameProbability, 3, 7); // before srand(), as the reference
+        emAcc.resetEM();
+        srand((unsigned)trainIt);
+        accumulateStatEM(fs, emAcc, bagged);
+        clientMixture = emAcc.getEM();
+        computeMAPOccDep(aprioriModel, clientMixture, mapCfg, (double)(unsigned long)emAcc.getEMFeatureCount());
+        dclient.update(clientMixture);
+    }
+}
+
 // ---- ComputeTest -------------------------------------------------------------------------------------
 std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selectedSegments, DeviceMixture &world,
                                    std::vector<DeviceMixture *> &clients, int topDistribsCount, bool complete,

@@ -163,6 +163,18 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, con
                                      const std::vector<double> &globalCov, MixtureGD &world,
                                      AllReduceFn allReduce = nullptr, void *user = nullptr);
 
+// ---- TrainTarget: MAP adaptation (TrainTools.cpp:445-489 computeMAPOccDep, :871-904 adaptModel) ----
+struct MAPCfg { // MAPCfg::MAPCfg, TrainTools.cpp:95-140 (subset: method MAPOccDep)
+    unsigned long nbTrainIt = 1;
+    double baggedFrameProbability = 1.0;
+    bool meanAdapt = true, varAdapt = false, weightAdapt = false;
+    double meanReg = 16.0, varReg = 16.0, weightReg = 16.0; // MAPRegFactorMean / Var / Weight
+};
+void computeMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount);
+// client model = MAP(aprioriModel, EM estimate on the selected frames), nbTrainIt times
+void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const MixtureGD &aprioriModel,
+                MixtureGD &clientMixture, const MAPCfg &mapCfg);
+
 // ---- ComputeTest (LIA_SpkDet/ComputeTest/src/ComputeTest.cpp:129-215) -----------------------------
 // LLR of each client against the world for one test file: per segment when segmentalMode, else one
 // per file.  out[(seg or 0) * nClients + i] = mean llk_client - mean llk_world.

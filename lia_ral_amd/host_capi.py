@@ -57,6 +57,19 @@ def train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, bagged_p=1.0, init_f
     return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk)
 
 
+def train_target(x, seg_begin, seg_len, world, nb_it=1, mean_reg=16.0, device=0):
+    """TrainTarget: mean-only MAPOccDep adaptation of the world model; returns (w, mean, cov)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in world]
+    C = len(w)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    wo = np.empty(C); mo = np.empty((C, D)); co = np.empty((C, D))
+    _chk(lib.liagpu_train_target(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(w), _d(mean),
+                                 _d(cov), nb_it, ct.c_double(mean_reg), _d(wo), _d(mo), _d(co)))
+    return wo, mo, co
+
+
 def compute_test(x, seg_begin, seg_len, world, clients, top_c=10, complete=True, min_llk=-200.0, max_llk=200.0,
                  segmental=False, device=0):
     """world = (w, mean, cov); clients = list of (w, mean, cov).  Returns LLR[n_seg_or_1, n_clients]."""

@@ -90,6 +90,53 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _tv_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lia_ral_amd.dist import tv_estep
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    C, D, R, U = 6, 5, 7, 11
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D)
+    te = orc.tv_tett(T, iv, C, D)
+    acc = dict(A=np.zeros((C, R * R)), Cmx=np.zeros((R, C * D)), Rm=np.zeros((R, R)), r=np.zeros(R), meanW=np.zeros(R))
+
+    def estimate(b, e, a):      # CPU stand-in for gmmiv_tv_estimate_a_and_c on this rank's utterances
+        o = orc.tv_estimate_a_and_c(N[b:e], F[b:e], T, iv, te)
+        a["A"] += o["A"]; a["Cmx"] += o["Cmx"]; a["Rm"] += o["Rm"]; a["r"] += o["r"]; a["meanW"] += o["meanW"] * (e - b)
+
+    tv_estep(estimate, U, acc, rank, world)
+    q.put((rank, acc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tv_estep_allreduce_gloo():
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    C, D, R, U = 6, 5, 7, 11
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D)
+    o = orc.tv_estimate_a_and_c(N, F, T, iv, orc.tv_tett(T, iv, C, D))
+    for k in ("A", "Cmx", "Rm", "r"):
+        assert np.array_equal(res[0][k], res[1][k])
+        assert np.allclose(res[0][k], o[k], rtol=1e-12, atol=1e-12), k
+    assert np.allclose(res[0]["meanW"] / U, o["meanW"], rtol=1e-12)
+
+
 def test_two_rank_em_statistics_allreduce_gloo():
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -68,6 +68,17 @@ def test_compute_test_kat1_through_host_layer(golden_dir):
     assert abs(one[0, 0] - (llr[:, 0] * wts).sum()) < 1e-9
 
 
+def test_train_target_kat2_through_host_layer(golden_dir):
+    """LIA_SpkDet/TrainTarget/test/test1.validate.gmm: adaptModel + computeMAPOccDep on the HIP path."""
+    from lia_ral_amd import host_capi as h
+    k = np.load(os.path.join(golden_dir, "kat2_traintarget.npz"))
+    world = (k["w"], k["mean_world"], 1.0 / k["covinv"])
+    w, mean, cov = h.train_target(k["x"], k["seg_begin"], k["seg_len"], world, nb_it=1, mean_reg=float(k["reg_factor"]))
+    diff = np.abs(mean - k["mean_expected"])
+    assert np.median(diff) < float(k["median_tol"]) and diff.max() < float(k["max_tol"])
+    assert np.array_equal(w, k["w"]) and np.allclose(cov, 1.0 / k["covinv"], rtol=1e-15)   # mean-only adaptation
+
+
 def test_iv_extractor_and_tv_training():
     from lia_ral_amd import host_capi as h
     C, D, R, U = 32, 20, 24, 40
