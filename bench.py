@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--mean-spread", type=float, default=2.0,
                     help="std of the synthetic UBM means (SURVEY 8(d): 2.0; smaller = overlapping Gaussians)")
+    ap.add_argument("--em-fused", type=int, default=-1, help="A/B knob: 1 = single-pass cooperative EM kernel, 0 = two-kernel path")
     ap.add_argument("--wg-waves", type=int, default=0, help="A/B knob: waves per workgroup of the MFMA kernels (4 or 8)")
     args = ap.parse_args()
 
@@ -135,6 +136,8 @@ def main():
     ctx.set_option("timing", 1)
     if args.wg_waves:
         ctx.set_option("wg_waves", args.wg_waves)
+    if args.em_fused >= 0:
+        ctx.set_option("em_fused", args.em_fused)
     g = ctx.gmm(w, mean, iv)
     nacc = g.em_acc_len()
     acc = torch.zeros(nacc, dtype=torch.float64, device=dev)
@@ -152,7 +155,7 @@ def main():
         acc.zero_()
         g.em_accumulate(x, acc=acc)                         # K1 (lse) + K2 (statistics) + reduce
         if record:
-            for name in ("k_llk_mfma", "k_stats_mfma"):
+            for name in ("k_llk_mfma", "k_stats_mfma", "k_em_fused"):
                 kern_ms.setdefault(name, []).append(ctx.kernel_ms(name))
         if world > 1:
             dist.all_reduce(acc)                            # EM sufficient statistics, 1.98 MB fp64

@@ -92,9 +92,9 @@ class Context:
             self._h = ct.c_void_p()
 
     def __del__(self):
-        if sys.is_finalizing():   # the HIP runtime may already be gone at interpreter exit
-            return
         try:
+            if sys is None or sys.is_finalizing():   # the HIP runtime may already be gone at interpreter exit
+                return
             self.close()
         except Exception:
             pass
@@ -250,9 +250,9 @@ class Gmm:
             self._h = ct.c_void_p()
 
     def __del__(self):
-        if sys.is_finalizing():
-            return
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass

@@ -85,6 +85,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "timing")) slot = &c->timing;
     else if (!strcmp(key, "wg_waves")) slot = &c->wg_waves;
     else if (!strcmp(key, "dbg")) slot = &c->dbg;
+    else if (!strcmp(key, "em_fused")) slot = &c->em_fused;
     else if (!strcmp(key, "prune_log2")) slot = &c->prune_log2;
     if (!slot) return -1;
     long prev = *slot;
@@ -371,6 +372,47 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if (T == 0) return o.finish();
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 64) {
+        // single-pass path: teams of (nct/8) workgroups, one team per contiguous frame range
+        const int ngrp = (g->nct + 7) / 8;
+        int nteams = c->n_cu / ngrp;
+        const int64_t cap = (T + 2047) / 2048;
+        if (nteams > cap) nteams = (int)cap;
+        if (nteams >= 1) {
+            std::vector<long> h(nteams + 1);
+            const int64_t per = ((T + nteams - 1) / nteams + 31) / 32 * 32;
+            for (int i = 0; i <= nteams; ++i) { int64_t b = (int64_t)i * per; h[i] = (long)(b < T ? b : T); }
+            void *seg, *lsew, *part, *slots, *flags, *small;
+            if ((rc = c->scratch(WS_SEG, (nteams + 1) * sizeof(long), &seg))) return rc;
+            GCHK(hipMemcpyAsync(seg, h.data(), (nteams + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
+            GCHK(hipStreamSynchronize(c->stream));
+            if ((rc = c->scratch(WS_LSE, (size_t)T * sizeof(double), &lsew))) return rc;
+            const int RL = gmmk_rl_for_ks(g->KS);
+            const size_t Cp = (size_t)g->nct * 16;
+            if ((rc = c->scratch(WS_PART, (size_t)nteams * Cp * 2 * RL * sizeof(double), &part))) return rc;
+            if ((rc = c->scratch(WS_SLOTS, gmmk_em_fused_slot_doubles(nteams, ngrp) * sizeof(double), &slots))) return rc;
+            const size_t fw = gmmk_em_fused_flag_words(nteams);
+            if ((rc = c->scratch(WS_FLAGS, fw * sizeof(unsigned), &flags))) return rc;
+            if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
+            GCHK(hipMemsetAsync(flags, 0, fw * sizeof(unsigned), c->stream));
+            c->t_begin("k_em_fused");
+            int krc = gmmk_em_fused(c->stream, g->KS, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->Pt, g->nct, -log(weight), (const long *)seg,
+                                    nteams, ngrp, (double *)part, (double *)lsew, (double *)slots, (unsigned *)flags, c->n_cu);
+            c->t_end();
+            if (krc == (int)hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); goto two_pass; }
+            GCHK(krc);
+            unsigned herr = 0;
+            GCHK(hipMemcpyAsync(&herr, (unsigned *)flags + fw - 16, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            GCHK(hipStreamSynchronize(c->stream));
+            if (herr) { gmmiv_set_error("em_accumulate(fused): a workgroup of the team never arrived (grid not resident?)"); return GMMIV_ERR_HIP; }
+            GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
+                                   o.d + nacc - 2));
+            GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
+            GCHK(gmmk_em_reduce(c->stream, (const double *)part, nteams, g->C, (int)Cp, g->D, g->KS, o.d));
+            return o.finish();
+        }
+    }
+two_pass:
     double *lse;
     if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     void *small;

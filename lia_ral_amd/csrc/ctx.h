@@ -22,7 +22,7 @@ void gmmiv_set_error(const char *fmt, ...);
     } while (0)
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
-       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_COUNT };
+       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_COUNT };
 
 struct gmmiv_ctx {
     int device = 0;
@@ -35,6 +35,7 @@ struct gmmiv_ctx {
     long em_chunks = 0; // 0 = auto
     long timing = 0;
     long dbg = 0; // timing experiments (wrong results when != 0)
+    long em_fused = 0; // 1: single-pass cooperative EM kernel (em_fused.hip) instead of k_llk + k_stats
     // statistics kernels, OPT-IN: groups of 4 frames x 16 Gaussians whose posteriors are ALL below
     // 2^-prune_log2 are skipped (exp + MFMAs).  0 (default) = never skip: every pair is accumulated
     // like the reference does.  With 100, at most 2e10 pairs x 2^-100 = 1.6e-20 of posterior mass is

@@ -32,3 +32,9 @@ int gmmk_variance_control(hipStream_t st, int C, int D, double *cov, double floo
                           const double *cov_signal, unsigned long long *counts);
 int gmmk_reciprocal(hipStream_t st, long n, const double *in, double *out);
 int gmmk_gather_frames(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *idx, long n, void *out);
+// em_fused.hip: single-pass EM statistics by teams of cooperating workgroups
+size_t gmmk_em_fused_slot_doubles(int nteams, int ngrp);
+size_t gmmk_em_fused_flag_words(int nteams);
+int gmmk_em_fused(hipStream_t st, int KS, int x_f64, const void *x, long ldx, int D, const double *Pt, int nct,
+                  double lse_shift, const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
+                  unsigned *flags, int n_cu);

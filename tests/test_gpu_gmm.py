@@ -192,6 +192,24 @@ def test_posterior_pruning_is_invisible(ctx, spread):
     assert relerr(a_on, a_off) < 1e-14 and relerr(n_on, n_off) < 1e-14 and relerr(f_on, f_off) < 1e-14
 
 
+@pytest.mark.parametrize("C,D,T", [(2048, 60, 70000), (128, 60, 5000), (300, 32, 4097), (2048, 60, 31), (37, 13, 257)])
+def test_fused_single_pass_em_matches_two_pass(ctx, C, D, T):
+    """em_fused: teams of cooperating workgroups compute every logit once (em_fused.hip)."""
+    w, mean, iv = make_gmm(C, D, seed=C + 3)
+    x = make_frames(w, mean, iv, T, seed=T + 5)
+    g = ctx.gmm(w, mean, iv)
+    ref = g.em_accumulate(x, weight=0.75)
+    ctx.set_option("em_fused", 1)
+    try:
+        got = g.em_accumulate(x, weight=0.75)
+        got2 = g.em_accumulate(x, weight=0.75)
+    finally:
+        ctx.set_option("em_fused", 0)
+    assert relerr(got, ref) < 1e-12
+    assert np.array_equal(got, got2)          # deterministic: no atomics in the data path
+    assert abs(got[-2] - ref[-2]) < 1e-9 * max(1, T) and got[-1] == ref[-1]
+
+
 def test_em_zero_frames_and_ragged_edges(ctx):
     w, mean, iv = make_gmm(64, 60, seed=2)
     g = ctx.gmm(w, mean, iv)
