@@ -372,7 +372,7 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if (T == 0) return o.finish();
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 64) {
+    if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
         // single-pass path: teams of (nct/8) workgroups, one team per contiguous frame range
         const int ngrp = (g->nct + 7) / 8;
         int nteams = c->n_cu / ngrp;
@@ -397,14 +397,17 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
             GCHK(hipMemsetAsync(flags, 0, fw * sizeof(unsigned), c->stream));
             c->t_begin("k_em_fused");
             int krc = gmmk_em_fused(c->stream, g->KS, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->Pt, g->nct, -log(weight), (const long *)seg,
-                                    nteams, ngrp, (double *)part, (double *)lsew, (double *)slots, (unsigned *)flags, c->n_cu);
+                                    nteams, ngrp, (double *)part, (double *)lsew, (double *)slots, (unsigned *)flags, c->n_cu, (int)c->dbg);
             c->t_end();
             if (krc == (int)hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); goto two_pass; }
             GCHK(krc);
             unsigned herr = 0;
             GCHK(hipMemcpyAsync(&herr, (unsigned *)flags + fw - 16, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             GCHK(hipStreamSynchronize(c->stream));
-            if (herr) { gmmiv_set_error("em_accumulate(fused): a workgroup of the team never arrived (grid not resident?)"); return GMMIV_ERR_HIP; }
+            if (herr) { // a peer never arrived (grid not fully resident): redo the block with the two-kernel path
+                gmmiv_set_error("em_accumulate(fused): hand-off timed out, fell back to the two-kernel path");
+                goto two_pass;
+            }
             GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
                                    o.d + nacc - 2));
             GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));

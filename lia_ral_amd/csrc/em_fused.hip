@@ -65,8 +65,9 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
                                                      int nct, double lse_shift, const long *__restrict__ seg_begin, int nteams,
                                                      int ngrp, double *__restrict__ part, double *__restrict__ lse_out,
                                                      double *__restrict__ slots, unsigned *__restrict__ flags,
-                                                     unsigned *__restrict__ err, unsigned magicD)
+                                                     unsigned *__restrict__ err, unsigned magicD, int dbg)
 {
+    // dbg (timing experiments, wrong results): 1 = no inter-workgroup exchange
     constexpr int NR = 2 * KS + 2;
     constexpr int Dp = 4 * KS;
     constexpr int RL = ((Dp + 2 + 31) / 32) * 32;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
     double *red = xb + NXB * FT * RLp;             // 8 waves x FT x (m, s)
     double *lse_t = red + 8 * FT * 2;              // FT
     double *etab = lse_t + FT;                     // 32
+    double *gat = etab + 32;                       // 16 groups x FT x (m, s): the team's partials of one tile
     gexp_table_init(etab, threadIdx.x);
 
     // XCD-aware decode (see k_stats_mfma): the workgroups of a team share an XCD when b % 8 is the XCD
@@ -110,15 +112,13 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
 
     // staging plan (see k_stats_mfma)
     XT stg[NLD];
-    unsigned pk[NLD], goff[NLD];
-    const bool contig = (ldx == D);
+    unsigned pk[NLD]; // rows are contiguous (ldx == D): the host falls back to the two-kernel path otherwise
     const int npad = FT * (RL - D);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + NT * i;
         const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
         pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
-        goff[i] = (unsigned)(fr * (int)ldx + d);
     }
     auto load_tile = [&](int tl) {
         const long fb = f0 + (long)tl * FT;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             XT v = 0;
-            if (pk[i] < lim) v = contig ? xt[tid + NT * i] : xt[goff[i]];
+            if (pk[i] < lim) v = xt[tid + NT * i];
             stg[i] = v;
         }
     };
@@ -149,8 +149,33 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
     double *my_slots = slots + (size_t)team * EMF_NBUF * ngrp * FT * 2;
     unsigned *my_flags = flags + (size_t)team * EMF_NBUF * EMF_MAXGRP;
 
-    // ---- phase A: logits of tile k (kept in z), partial log-sum-exp published to the team -------
-    auto phaseA = [&](int k, d4 (&z)[2]) {
+    // ---- exchange, step 1 (start of a step): every wave polls the flags of the two groups it
+    // gathers for tile k (published by the peers one step ago) and ISSUES the loads of their
+    // (max, sum) pairs; the values are consumed after this step's logit MFMAs, which hide the latency.
+    double gm = GMMIV_NEG_BIG, gs = 0.0;
+    auto gather_issue = [&](int k) {
+        if (dbg & 1) return;
+        const int gsel = 2 * wave + (lane >> 5); // group gathered by this half-wave
+        if ((lane & 31) == 0 && gsel < ngrp) {
+            const unsigned want = (unsigned)(k + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&my_flags[(k % EMF_NBUF) * EMF_MAXGRP + gsel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { atomicOr(err, 1u); break; } // bounded: a non-resident peer must not hang the GPU
+            }
+        }
+        // no acquire fence: the payload is written with sc1 stores and read with sc1 (L1-bypassing)
+        // loads, the form Guideline 16 allows in place of an agent-scope acquire (saves ~1.7 us per step)
+        gm = GMMIV_NEG_BIG; gs = 0.0;
+        if (gsel < ngrp) {
+            const double *sl = my_slots + (((size_t)(k % EMF_NBUF) * ngrp + gsel) * FT + (lane & 31)) * 2;
+            gm = ld_agent(sl);
+            gs = ld_agent(sl + 1);
+        }
+    };
+
+    // ---- phase A: logits of tile k (kept in z), per-wave partial log-sum-exp into LDS -------------
+    auto phaseA = [&](int k, double (&z)[2][4]) {
         const double *cur = xb + (k % NXB) * FT * RLp;
         const double *pL = cur + offL;
         if (active) {
@@ -170,7 +195,9 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
             }
         } else {
 #pragma unroll
-            for (int fs = 0; fs < 2; ++fs) z[fs] = (d4){GMMIV_NEG_BIG, GMMIV_NEG_BIG, GMMIV_NEG_BIG, GMMIV_NEG_BIG};
+            for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[fs][r] = GMMIV_NEG_BIG;
         }
         // per wave and frame row: reference = f32 row maximum (any value within a few hundred of the
         // true maximum works), sum of exp(z - reference) over the wave's 16 Gaussians
@@ -186,8 +213,12 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
                     red[(wave * FT + row) * 2 + 1] = sw;
                 }
             }
-        __syncthreads();
-        if (wave == 0) {
+    };
+
+    // ---- exchange, step 2 (after the barrier that completes `red`): wave 0 publishes this
+    // workgroup's partials of tile k; every wave drops the pairs it gathered for tile kprev into LDS
+    auto publish_and_stash = [&](int k, bool do_pub, bool do_stash) {
+        if (do_pub && wave == 0 && !(dbg & 1)) {
             if (lane < FT) {
                 double M = red[lane * 2];
 #pragma unroll
@@ -199,39 +230,45 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
                 st_agent(sl, M);
                 st_agent(sl + 1, Ssum);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains (this is the only one)
+        }
+        if (do_stash) {
+            const int gsel = 2 * wave + (lane >> 5);
+            gat[(gsel * FT + (lane & 31)) * 2] = gm;
+            gat[(gsel * FT + (lane & 31)) * 2 + 1] = gs;
+        }
+    };
+
+    // the flag follows the payload: the storing wave drains its stores, then ONE lane raises the flag.
+    // Called after the next barrier, so the drain has usually nothing left to wait for.
+    auto publish_flag = [&](int k) {
+        if (wave == 0 && !(dbg & 1)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&my_flags[(k % EMF_NBUF) * EMF_MAXGRP + grp], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
-    // ---- phase C: gather the team's partials of tile k, posteriors from z, statistics ------------
-    auto phaseC = [&](int k, const d4 (&z)[2]) {
-        if (wave == 0) {
-            bool ok = true;
-            if (lane < ngrp) {
-                const unsigned want = (unsigned)(k + 1);
-                unsigned spins = 0;
-                while (__hip_atomic_load(&my_flags[(k % EMF_NBUF) * EMF_MAXGRP + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 24)) { ok = false; break; } // bounded: a non-resident peer must not hang the GPU
-                }
-            }
-            if (!ok) atomicOr(err, 1u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (lane < FT) {
-                const double *sl = my_slots + ((size_t)(k % EMF_NBUF) * ngrp * FT + lane) * 2;
-                double M = GMMIV_NEG_BIG;
-                for (int g = 0; g < ngrp; ++g) M = fmax(M, ld_agent(sl + (size_t)g * FT * 2));
-                double Ssum = 0.0;
-                for (int g = 0; g < ngrp; ++g)
-                    Ssum += ld_agent(sl + (size_t)g * FT * 2 + 1) * gexp_t(ld_agent(sl + (size_t)g * FT * 2) - M, etab);
+    // ---- exchange, step 3: wave w combines the 16 group partials of frames 4w..4w+3 -> lse_t ------
+    auto combine_lse = [&](int k) {
+        if (lane < 32) {
+            const int tl = 4 * wave + (lane >> 3), p = lane & 7;
+            const double m0 = gat[((2 * p) * FT + tl) * 2], s0 = gat[((2 * p) * FT + tl) * 2 + 1];
+            const double m1 = gat[((2 * p + 1) * FT + tl) * 2], s1 = gat[((2 * p + 1) * FT + tl) * 2 + 1];
+            double M = fmax(m0, m1);
+            // 8-lane all-reduce (lanes of one frame are contiguous): xor 1, 2, 4
+            M = fmax(M, shfl_xor_f64(M, 1)); M = fmax(M, shfl_xor_f64(M, 2)); M = fmax(M, shfl_xor_f64(M, 4));
+            double Ssum = s0 * gexp_t(m0 - M, etab) + s1 * gexp_t(m1 - M, etab);
+            Ssum += shfl_xor_f64(Ssum, 1); Ssum += shfl_xor_f64(Ssum, 2); Ssum += shfl_xor_f64(Ssum, 4);
+            if (p == 0) {
                 const double lse = M + log(Ssum);
-                lse_t[lane] = lse + lse_shift;
-                const long fr = f0 + (long)k * FT + lane;
+                lse_t[tl] = lse + lse_shift;
+                const long fr = f0 + (long)k * FT + tl;
                 if (grp == 0 && fr < f1) lse_out[fr] = lse;
             }
         }
-        __syncthreads();
+    };
+
+    // ---- phase C: posteriors of tile k from z and lse_t, statistics MFMAs -------------------------
+    auto phaseC = [&](int k, const double (&z)[2][4]) {
         if (active) {
             const double *cur = xb + (k % NXB) * FT * RLp;
             const double *pS = cur + offS;
@@ -250,24 +287,45 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
         }
     };
 
+    // one pipeline step: A(ka) into za, C(kc = ka - 1) from zc.  Two barriers:
+    //   B1 closes `red` (phase A partials) and `gat` (gathered team partials of tile kc);
+    //   B2 closes lse_t and the freshly staged frame tile ka+1.
+    // Reuse is safe without a third barrier: red/gat are next written after B2, lse_t and the frame
+    // buffer of tile kc are next written after the following B1, which every wave reaches only after
+    // finishing its phase C.
+    auto step = [&](int ka, double (&za)[2][4], double (&zc)[2][4]) {
+        const int kc = ka - 1;
+        const bool doA = ka < ntiles, doC = kc >= 0 && kc < ntiles;
+        if (ka + 1 < ntiles) load_tile(ka + 1);
+        if (doC) gather_issue(kc);
+        if (doA) phaseA(ka, za);
+        if (doC && !(dbg & 1)) {
+            const int gsel = 2 * wave + (lane >> 5);
+            gat[(gsel * FT + (lane & 31)) * 2] = gm;
+            gat[(gsel * FT + (lane & 31)) * 2 + 1] = gs;
+        }
+        __syncthreads();                       // B1
+        publish_and_stash(ka, doA, false);
+        if (doC) combine_lse(kc);
+        if (ka + 1 < ntiles) write_tile(ka + 1);
+        __syncthreads();                       // B2
+        if (doA) publish_flag(ka);
+        if (doC) phaseC(kc, zc);
+    };
+
     // ---- software pipeline over the tiles (look-ahead 1) ------------------------------------------
-    d4 zA[2], zB[2];
+    double zA[2][4], zB[2][4];
+#pragma unroll
+    for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zA[fs][r] = 0.0; zB[fs][r] = 0.0; }
     if (ntiles > 0) { load_tile(0); write_tile(0); }
     __syncthreads();
     for (int k = 0; k <= ntiles; k += 2) {
-        // even step: A(k) into zA, C(k-1) from zB
-        if (k + 1 < ntiles) load_tile(k + 1);
-        if (k < ntiles) phaseA(k, zA);
-        if (k >= 1 && k - 1 < ntiles) phaseC(k - 1, zB);
-        if (k + 1 < ntiles) write_tile(k + 1);
-        __syncthreads();
-        // odd step: A(k+1) into zB, C(k) from zA
-        if (k + 2 < ntiles) load_tile(k + 2);
-        if (k + 1 < ntiles) phaseA(k + 1, zB);
-        if (k < ntiles) phaseC(k, zA);
-        if (k + 2 < ntiles) write_tile(k + 2);
-        __syncthreads();
+        step(k, zA, zB);
+        step(k + 1, zB, zA);
     }
+    __syncthreads();
 
     if (!active) return;
     const size_t Cp = (size_t)nct * 16;
@@ -295,10 +353,10 @@ size_t gmmk_em_fused_flag_words(int nteams) { return (size_t)nteams * EMF_NBUF *
 template <int KS, typename XT>
 static int launch_fused(hipStream_t st, const void *x, long ldx, int D, const double *Pt, int nct, double lse_shift,
                         const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
-                        unsigned *flags, int n_cu)
+                        unsigned *flags, int n_cu, int dbg)
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
-    const size_t lds = ((size_t)3 * EMF_FT * (RL + 32) + 8 * EMF_FT * 2 + EMF_FT + 32) * sizeof(double);
+    const size_t lds = ((size_t)3 * EMF_FT * (RL + 32) + 8 * EMF_FT * 2 + EMF_FT + 32 + 16 * EMF_FT * 2) * sizeof(double);
     static int blocks_per_cu = -1;
     if (blocks_per_cu < 0) {
         HIPCHK(hipFuncSetAttribute((const void *)k_em_fused<KS, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -310,7 +368,7 @@ static int launch_fused(hipStream_t st, const void *x, long ldx, int D, const do
     const unsigned grid = (unsigned)(8 * ngrp * ((nteams + 7) / 8));
     const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);
     k_em_fused<KS, XT><<<grid, 512, lds, st>>>(x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots,
-                                                flags, flags + gmmk_em_fused_flag_words(nteams) - 16, magicD);
+                                                flags, flags + gmmk_em_fused_flag_words(nteams) - 16, magicD, dbg);
     return (int)hipGetLastError();
 }
 
@@ -318,14 +376,14 @@ static int launch_fused(hipStream_t st, const void *x, long ldx, int D, const do
 // last 16 words, the error word.
 int gmmk_em_fused(hipStream_t st, int KS, int x_f64, const void *x, long ldx, int D, const double *Pt, int nct,
                   double lse_shift, const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
-                  unsigned *flags, int n_cu)
+                  unsigned *flags, int n_cu, int dbg)
 {
     if (nteams <= 0) return 0;
-    if (ngrp > EMF_MAXGRP) return (int)hipErrorInvalidValue;
+    if (ngrp > 16) return (int)hipErrorCooperativeLaunchTooLarge; // each wave gathers two groups
 #define CASE(K)                                                                                                              \
     case K:                                                                                                                  \
-        return x_f64 ? launch_fused<K, double>(st, x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots, flags, n_cu) \
-                     : launch_fused<K, float>(st, x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots, flags, n_cu);
+        return x_f64 ? launch_fused<K, double>(st, x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots, flags, n_cu, dbg) \
+                     : launch_fused<K, float>(st, x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots, flags, n_cu, dbg);
     switch (KS) {
         CASE(4) CASE(8) CASE(15)
     }

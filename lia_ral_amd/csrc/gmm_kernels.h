@@ -37,4 +37,4 @@ size_t gmmk_em_fused_slot_doubles(int nteams, int ngrp);
 size_t gmmk_em_fused_flag_words(int nteams);
 int gmmk_em_fused(hipStream_t st, int KS, int x_f64, const void *x, long ldx, int D, const double *Pt, int nct,
                   double lse_shift, const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
-                  unsigned *flags, int n_cu);
+                  unsigned *flags, int n_cu, int dbg);

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from conftest import make_gmm
+from lia_ral_amd import capi
+import bench
+C, D, T = 2048, 60, 2_000_000
+w, mean, iv = make_gmm(C, D, seed=0)
+x = bench.synth_frames(w, mean, iv, T, torch.device("cuda", 0), seed=1)
+ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+ctx.set_option("em_fused", 1)
+g = ctx.gmm(w, mean, iv)
+acc = torch.zeros(g.em_acc_len(), dtype=torch.float64, device="cuda")
+for _ in range(2):
+    g.em_accumulate(x, acc=acc)
+torch.cuda.synchronize()
+g.close(); ctx.close()
