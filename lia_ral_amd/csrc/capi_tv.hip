@@ -199,10 +199,15 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         GCHK(tvk_dgemm(c->stream, false, false, nb, (int)P, C, 1.0, Nc, C, 0, i_te.d, (long)P, 0, 0.0, Lp, (long)P, 0, 1));
         c->t_end();
         GCHK(tvk_unpack_sym(c->stream, R, nb, Lp, (long)P, ws.full, 1.0));
-        GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
-        // aux = F Sigma^-1 T^T ; w = L^-1 aux
+        // aux = F Sigma^-1 T^T
         GCHK(tvk_dgemm_splitk(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, Tiv, (long)SV, 0.0, aux, R, nz, slabs));
-        GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
+        if (accumulate) { // the T-matrix EM needs L^-1 itself (E = L^-1 + w w^T): explicit inverse like the reference
+            GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+            GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
+        } else {          // extraction only needs w = L^-1 aux: Cholesky + two triangular solves
+            GCHK(tvk_chol_batched(c->stream, R, nb, ws.full, ws.invd, ws.panel, ws.status));
+            GCHK(tvk_chol_solve_batched(c->stream, R, nb, ws.full, ws.invd, aux, Wc));
+        }
         if ((rc = check_status(c, ws.status, nb, "tv: L"))) { free_owned(); return rc; }
         if (accumulate) {
             // E = L^-1 + w w^T (packed, reusing Lp) ; A += N^T E ; Cmx += W^T F ; R += sum E ; r, meanW += sum w

@@ -27,3 +27,4 @@ int tvk_dgemm_splitk(hipStream_t st, bool ta, bool tb, int M, int N, int K, doub
 int tvk_sub_colvec(hipStream_t st, int dim, long n, const double *X, const double *v, double *out);
 int tvk_scale_cols_rsqrt(hipStream_t st, int dim, long n, double *X, const double *qv);
 int tvk_orthonormalize(hipStream_t st, int R, long SV, const double *Tm, double *Q, double *rv, double *v, double *partial);
+int tvk_chol_solve_batched(hipStream_t st, int n, int nb, const double *Lf, const double *invd, const double *b, double *w);

@@ -408,6 +408,64 @@ int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double
     return (int)hipGetLastError();
 }
 
+// w = A^-1 b through the Cholesky factor (lower, from tvk_chol_batched) and the inverses of its
+// 32 x 32 diagonal blocks: blocked forward then backward substitution, one workgroup per matrix.
+// 256 threads = 32 rows (or columns) x 8 partial-sum lanes.
+__global__ __launch_bounds__(256) void k_chol_solve(int n, const double *__restrict__ Lf, const double *__restrict__ invd,
+                                                    long sinv, const double *__restrict__ bvec, double *__restrict__ wvec)
+{
+    extern __shared__ double sm[];      // y[npad] | r[32]
+    const int nblk = (n + 31) / 32, npad = nblk * 32;
+    double *y = sm, *rr = sm + npad;
+    const double *L = Lf + (size_t)blockIdx.x * n * n;
+    const double *iv = invd + (size_t)blockIdx.x * sinv;
+    const double *bb = bvec + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, row = tid >> 3, l8 = tid & 7;
+    for (int i = tid; i < npad; i += 256) y[i] = 0.0;
+    __syncthreads();
+    // forward: L y = b
+    for (int ib = 0; ib < nblk; ++ib) {
+        const int r0 = ib * 32, gr = r0 + row;
+        double s = 0.0;
+        if (gr < n)
+            for (int k = l8; k < r0; k += 8) s = __builtin_fma(L[(size_t)gr * n + k], y[k], s);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (l8 == 0) rr[row] = gr < n ? bb[gr] - s : 0.0;
+        __syncthreads();
+        double t = 0.0;
+        for (int k = l8; k < 32; k += 8) t = __builtin_fma(iv[(size_t)ib * 1024 + row * 32 + k], rr[k], t); // inv(L_ii) is lower
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+        __syncthreads();
+        if (l8 == 0) y[r0 + row] = t;
+        __syncthreads();
+    }
+    // backward: L^T w = y   (w overwrites y block by block, from the last block up)
+    for (int ib = nblk - 1; ib >= 0; --ib) {
+        const int c0 = ib * 32, gc = c0 + row; // `row` indexes a column of the block here
+        double s = 0.0;
+        if (gc < n)
+            for (int k = c0 + 32 + l8; k < n; k += 8) s = __builtin_fma(L[(size_t)k * n + gc], y[k], s);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (l8 == 0) rr[row] = gc < n ? y[gc] - s : 0.0;
+        __syncthreads();
+        double t = 0.0;
+        for (int k = l8; k < 32; k += 8) t = __builtin_fma(iv[(size_t)ib * 1024 + k * 32 + row], rr[k], t); // inv(L_ii)^T
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+        __syncthreads();
+        if (l8 == 0) y[c0 + row] = t;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) wvec[(size_t)blockIdx.x * n + i] = y[i];
+}
+
+int tvk_chol_solve_batched(hipStream_t st, int n, int nb, const double *Lf, const double *invd, const double *b, double *w)
+{
+    if (nb <= 0) return 0;
+    const int nblk = (n + 31) / 32;
+    k_chol_solve<<<nb, 256, (size_t)(nblk * 32 + 32) * sizeof(double), st>>>(n, Lf, invd, (long)nblk * 1024, b, w);
+    return (int)hipGetLastError();
+}
+
 int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means)
 {
     if (U <= 0) return 0;
