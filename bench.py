@@ -23,8 +23,11 @@ import numpy as np
 import torch
 
 C, D = 2048, 60
-FLOP_PER_PAIR_STATS = 480.0   # 240 (logits) + 242 (statistics) per frame-Gaussian pair
-FLOP_PER_PAIR_LLK = 240.0
+FLOP_PER_PAIR_LLK = 240.0     # logit of one frame-Gaussian pair, 2 flop x 2D
+FLOP_PER_PAIR_ACC = 242.0     # statistics of one pair: 2 flop x (1 + D + D)
+FLOP_PER_PAIR_STATS = 480.0   # the recomputing k_stats_mfma (stats_z = 0): logits again + statistics
+KERNEL_FLOP = {"k_llk_mfma": FLOP_PER_PAIR_LLK, "k_stats_z": FLOP_PER_PAIR_ACC, "k_stats_mfma": FLOP_PER_PAIR_STATS,
+               "k_em_fused": FLOP_PER_PAIR_LLK + FLOP_PER_PAIR_ACC}
 PEAK_F64_TFLOPS = 78.6        # MI355X fp64 matrix = vector peak (AMD datasheet; measured ceiling in DESIGN.md)
 
 
@@ -93,6 +96,19 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
 
     run()                      # warm-up (workspace allocation)
     dt = min(run(), run())
+    # the same statistics through the single-pass cooperative kernel (opt-in, em_fused.hip)
+    fused = {}
+    try:
+        ctx.set_option("em_fused", 1)
+        N2 = torch.empty_like(N); F2 = torch.empty_like(F)
+        g.tv_stats(x, ub, N2, F2); torch.cuda.synchronize()
+        t0 = time.perf_counter(); g.tv_stats(x, ub, N2, F2); torch.cuda.synchronize()
+        fused["stats_ms"] = (time.perf_counter() - t0) * 1e3
+        ctx.tv_subtract_m(N2, F2, means, C, D)
+        fused["max_rel_diff_F"] = float(((F2 - F).abs().max() / F.abs().max()).item())
+        fused["i-vectors/s"] = U * world / (fused["stats_ms"] * 1e-3 + times["solve_ms"] * 1e-3)
+    finally:
+        ctx.set_option("em_fused", 0)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -100,7 +116,7 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         dt = float(tt.item())
     return {"metric": "i-vectors/s (IvExtractor end-to-end, 2048-g UBM, rank 400, 3000-frame utterances)",
             "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "stats_ms": times["stats_ms"],
-            "solve_ms": times["solve_ms"], "finite": bool(torch.isfinite(W).all().item())}
+            "solve_ms": times["solve_ms"], "finite": bool(torch.isfinite(W).all().item()), "fused_stats": fused}
 
 
 def main():
@@ -155,8 +171,9 @@ def main():
         acc.zero_()
         g.em_accumulate(x, acc=acc)                         # K1 (lse) + K2 (statistics) + reduce
         if record:
-            for name in ("k_llk_mfma", "k_stats_mfma", "k_em_fused"):
-                kern_ms.setdefault(name, []).append(ctx.kernel_ms(name))
+            for name in KERNEL_FLOP:
+                if ctx.kernel_launches(name) > 0:
+                    kern_ms.setdefault(name, []).append((ctx.kernel_ms(name), ctx.kernel_launches(name)))
         if world > 1:
             dist.all_reduce(acc)                            # EM sufficient statistics, 1.98 MB fp64
         # M-step (MixtureStat::getEM) + variance flooring + re-pack of the device model
@@ -214,7 +231,8 @@ def main():
             g.em_accumulate(xd, acc=accd)
         torch.cuda.synchronize()
         dd = (time.perf_counter() - t1) / 2
-        dense_k = (ctx.kernel_ms("k_llk_mfma"), ctx.kernel_ms("k_stats_mfma"))
+        sname = "k_stats_z" if ctx.kernel_launches("k_stats_z") > 0 else "k_stats_mfma"
+        dense_k = (ctx.kernel_ms("k_llk_mfma"), ctx.kernel_ms(sname))
         ctx.set_option("prune_log2", 100)      # opt-in pruning on the SURVEY-spec data (one dominant Gaussian per frame)
         g.set(w, mean, iv)
         xs = x[:Td]
@@ -227,12 +245,12 @@ def main():
         torch.cuda.synchronize()
         dp = (time.perf_counter() - t1) / 2
         pruned = {"value": Td * C / dp / 1e9, "unit": "Gframe-Gaussian/s per GPU", "frames": Td, "prune_log2": 100,
-                  "k_stats_ms": ctx.kernel_ms("k_stats_mfma"),
+                  "k_stats_ms": ctx.kernel_ms(sname),
                   "note": "opt-in: groups of 4 frames x 16 Gaussians with all posteriors < 2^-100 skip exp + statistics MFMAs"}
         ctx.set_option("prune_log2", 0)
         dense = {"pruned_posteriors": pruned, "value": Td * C / dd / 1e9, "unit": "Gframe-Gaussian/s per GPU", "frames": Td, "mean_spread": 0.3,
                  "k_llk_ms": dense_k[0], "k_stats_ms": dense_k[1],
-                 "k_stats_tflops": FLOP_PER_PAIR_STATS * Td * C / (dense_k[1] * 1e-3) / 1e12}
+                 "k_stats_tflops": KERNEL_FLOP[sname] * Td * C / (dense_k[1] * 1e-3) / 1e12}
         del xd, accd
     secondary = None
     if not args.no_secondary:
@@ -243,23 +261,28 @@ def main():
             out["secondary"] = secondary
         if dense:
             out["dense_data"] = dense
-        ms = float(np.mean(kern_ms.get("k_stats_mfma", [float("nan")])))
-        achieved = FLOP_PER_PAIR_STATS * T * C / (ms * 1e-3) / 1e12
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("k_stats_mfma_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "k_stats_mfma<15,true,float>", "achieved": achieved,
-                           "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
-                           "traffic": traffic, "kernel_ms": ms,
-                           "algorithmic_flop_per_launch": FLOP_PER_PAIR_STATS * T * C}
-        ms1 = float(np.mean(kern_ms.get("k_llk_mfma", [float("nan")])))
-        out["kernels"] = {"k_llk_mfma": {"ms": ms1, "tflops": FLOP_PER_PAIR_LLK * T * C / (ms1 * 1e-3) / 1e12,
-                                         "gpairs_per_s": T * C / (ms1 * 1e-3) / 1e9},
-                          "k_stats_mfma": {"ms": ms, "tflops": achieved, "gpairs_per_s": T * C / (ms * 1e-3) / 1e9}}
+        # per kernel: total ms per step, launches per step (frame chunks), algorithmic TFLOP/s
+        kernels = {}
+        for name, recs in kern_ms.items():
+            ms = float(np.mean([r[0] for r in recs])); nl = int(recs[-1][1])
+            kernels[name] = {"ms_per_step": ms, "launches_per_step": nl, "ms_per_launch": ms / nl,
+                             "tflops": KERNEL_FLOP[name] * T * C / (ms * 1e-3) / 1e12,
+                             "gpairs_per_s": T * C / (ms * 1e-3) / 1e9}
+        out["kernels"] = kernels
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])     # the dominant kernel of the step
+            kd = kernels[dom]
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(dom + "_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kd["tflops"], "peak": PEAK_F64_TFLOPS,
+                               "unit": "TFLOP/s", "frac": kd["tflops"] / PEAK_F64_TFLOPS, "traffic": traffic,
+                               "kernel_ms": kd["ms_per_launch"], "launches_per_step": kd["launches_per_step"],
+                               "algorithmic_flop_per_launch": KERNEL_FLOP[dom] * T * C / kd["launches_per_step"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, mean, iv, seed=99)
         print(json.dumps(out), flush=True)

@@ -52,8 +52,11 @@ const char *gmmiv_version(void);
 long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);
 /* Duration (ms, HIP events on the context's stream) of the last call's dominant kernel. */
 double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *ctx, const char **kernel_name);
-/* Same, for the most recent launch of a named kernel ("k_llk_mfma", "k_stats_mfma", ...); -1 if none. */
+/* Same for a named kernel ("k_llk_mfma", "k_stats_z", "k_stats_mfma", ...): TOTAL over its launches
+ * inside the most recent call that used it (a call may process its frames in several chunks);
+ * -1 if none.  gmmiv_ctx_kernel_launches gives that number of launches. */
 double gmmiv_ctx_kernel_ms(gmmiv_ctx *ctx, const char *kernel_name);
+long gmmiv_ctx_kernel_launches(gmmiv_ctx *ctx, const char *kernel_name);
 
 /* ---- model: MixtureGD / DistribGD ----------------------------------------------------------
  * w[C], mean[C*D], covinv[C*D] (DistribGD::getMeanVect / getCovInvVect, MixtureGD::weight(c);

@@ -33,6 +33,7 @@ def _load():
     lib.gmmiv_tv_packed_len.restype = ct.c_size_t
     lib.gmmiv_ctx_last_kernel_ms.restype = ct.c_double
     lib.gmmiv_ctx_kernel_ms.restype = ct.c_double
+    lib.gmmiv_ctx_kernel_launches.restype = ct.c_long
     lib.gmmiv_ctx_set_option.restype = ct.c_long
     return lib
 
@@ -101,6 +102,9 @@ class Context:
 
     def kernel_ms(self, name):
         return lib.gmmiv_ctx_kernel_ms(self._h, name.encode())
+
+    def kernel_launches(self, name):
+        return lib.gmmiv_ctx_kernel_launches(self._h, name.encode())
 
     def sync(self):
         _chk(lib.gmmiv_ctx_sync(self._h))

@@ -62,8 +62,8 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
     for (int i = 0; i < WS_COUNT; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     for (int i = 0; i < gmmiv_ctx::NSLOT; ++i) {
-        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
-        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+        for (hipEvent_t e : c->ev0[i]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->ev1[i]) (void)hipEventDestroy(e);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -87,6 +87,8 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "dbg")) slot = &c->dbg;
     else if (!strcmp(key, "em_fused")) slot = &c->em_fused;
     else if (!strcmp(key, "prune_log2")) slot = &c->prune_log2;
+    else if (!strcmp(key, "stats_z")) slot = &c->stats_z;
+    else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
     if (!slot) return -1;
     long prev = *slot;
     *slot = value;
@@ -106,6 +108,14 @@ double gmmiv_ctx_kernel_ms(gmmiv_ctx *c, const char *name)
     for (int i = 0; i < gmmiv_ctx::NSLOT; ++i)
         if (c->ev_name[i] && !strcmp(c->ev_name[i], name)) return c->t_query(i);
     return -1.0;
+}
+
+long gmmiv_ctx_kernel_launches(gmmiv_ctx *c, const char *name)
+{
+    if (!c || !name) return -1;
+    for (int i = 0; i < gmmiv_ctx::NSLOT; ++i)
+        if (c->ev_name[i] && !strcmp(c->ev_name[i], name)) return c->ev_used[i];
+    return -1;
 }
 
 // ---- model -------------------------------------------------------------------------------
@@ -360,6 +370,74 @@ static int make_chunks(gmmiv_ctx *c, int64_t T, int nseg, long **dev)
     return GMMIV_OK;
 }
 
+// ---- stored-logit path (k_llk_mfma<WZ> + k_stats_z) -------------------------------------------
+// frames per chunk that fit the logit scratch budget (multiple of 64), 0 when the path does not apply
+static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g)
+{
+    if (!c->stats_z || g->KS > 15 || c->wg_waves != 8) return 0;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+    size_t have = c->ws_size[WS_Z];
+    size_t budget = (size_t)(c->z_scratch_mb > 0 ? c->z_scratch_mb : 0) << 20;
+    const size_t avail = have + fr / 2; // never take more than half of what is free now
+    if (budget > avail) budget = avail;
+    const size_t per_frame = (size_t)g->nct * 16 * sizeof(double);
+    int64_t tc = (int64_t)(budget / per_frame / 1.2); // scratch() over-allocates by 1/8
+    // whole rounds of the log-likelihood kernel: 2 resident workgroups per CU x 256 frames
+    const int64_t round = (int64_t)c->n_cu * 2 * 256;
+    tc = tc >= round ? tc / round * round : tc / 64 * 64;
+    return tc >= 4096 ? tc : 0;
+}
+static const void *x_at(const XView &xv, int dt, int64_t frame) { return (const char *)xv.d + (size_t)frame * xv.ldx * esize(dt); }
+
+// EM statistics of frames [0, T) into the partial blocks part[nseg] (summed by the caller)
+static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, int64_t Tc, double lse_shift,
+                      double *lse, int *nseg_out, void **part_out)
+{
+    int rc;
+    const int ngrp = gmmk_stats_z_groups(g->nct);
+    int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (c->n_cu + ngrp - 1) / ngrp;
+    nseg = (nseg + 7) / 8 * 8;
+    const int64_t first = T < Tc ? T : Tc;
+    const int64_t cap = (first + 2047) / 2048;
+    if (nseg > cap) nseg = (int)((cap + 7) / 8 * 8);
+    const int64_t nchunk = (T + Tc - 1) / Tc;
+    // segment bounds relative to the chunk start: one table for full chunks, one for the last chunk
+    std::vector<long> h(2 * (nseg + 1));
+    auto fill = [&](long *dst, int64_t n) {
+        const int64_t per = ((n + nseg - 1) / nseg + 63) / 64 * 64;
+        for (int i = 0; i <= nseg; ++i) { int64_t b = (int64_t)i * per; dst[i] = (long)(b < n ? b : n); }
+    };
+    const int64_t lastn = T - (nchunk - 1) * Tc;
+    fill(h.data(), first);
+    fill(h.data() + nseg + 1, lastn);
+    void *seg, *zb, *part;
+    if ((rc = c->scratch(WS_SEG, h.size() * sizeof(long), &seg))) return rc;
+    GCHK(hipMemcpyAsync(seg, h.data(), h.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    GCHK(hipStreamSynchronize(c->stream));
+    const long nfb = 16 * ((first + 255) / 256); // the log-likelihood kernel writes whole workgroups (256 frames)
+    if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
+    const int RL = gmmk_rl_for_ks(g->KS);
+    const size_t Cp = (size_t)g->nct * 16;
+    if ((rc = c->scratch(WS_PART, (size_t)nseg * Cp * 2 * RL * sizeof(double), &part))) return rc;
+    for (int64_t k = 0; k < nchunk; ++k) {
+        const int64_t c0 = k * Tc, n = (k == nchunk - 1) ? lastn : Tc;
+        c->t_begin("k_llk_mfma", k == 0);
+        GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, lse + c0,
+                        (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb));
+        c->t_end();
+        gmmk_stats_z_set_ablation((int)(c->dbg >> 4));
+        c->t_begin("k_stats_z", k == 0);
+        GCHK(gmmk_stats_z(c->stream, g->KS, 1, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb, nfb,
+                          lse + c0, lse_shift, (const long *)seg + (k == nchunk - 1 ? nseg + 1 : 0), nseg, (double *)part, nullptr, 0,
+                          k > 0, c->prune_arg()));
+        c->t_end();
+    }
+    *nseg_out = nseg;
+    *part_out = part;
+    return GMMIV_OK;
+}
+
 int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, double weight,
                         double *acc)
 {
@@ -375,14 +453,17 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
         // single-pass path: teams of (nct/8) workgroups, one team per contiguous frame range
         const int ngrp = (g->nct + 7) / 8;
-        int nteams = c->n_cu / ngrp;
+        int wg_per_cu = 0;
+        GCHK(gmmk_em_fused(c->stream, g->KS, 1, dt == GMMIV_F64, nullptr, 0, g->D, g->C, nullptr, g->nct, 0.0, nullptr, 0, 0, ngrp, 0,
+                           nullptr, nullptr, nullptr, nullptr, c->n_cu, 0, &wg_per_cu));
+        int nteams = c->n_cu * wg_per_cu / ngrp;
         const int64_t cap = (T + 2047) / 2048;
         if (nteams > cap) nteams = (int)cap;
         if (nteams >= 1) {
             std::vector<long> h(nteams + 1);
             const int64_t per = ((T + nteams - 1) / nteams + 31) / 32 * 32;
             for (int i = 0; i <= nteams; ++i) { int64_t b = (int64_t)i * per; h[i] = (long)(b < T ? b : T); }
-            void *seg, *lsew, *part, *slots, *flags, *small;
+            void *seg, *lsew, *part, *slots, *small;
             if ((rc = c->scratch(WS_SEG, (nteams + 1) * sizeof(long), &seg))) return rc;
             GCHK(hipMemcpyAsync(seg, h.data(), (nteams + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
             GCHK(hipStreamSynchronize(c->stream));
@@ -390,19 +471,19 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
             const int RL = gmmk_rl_for_ks(g->KS);
             const size_t Cp = (size_t)g->nct * 16;
             if ((rc = c->scratch(WS_PART, (size_t)nteams * Cp * 2 * RL * sizeof(double), &part))) return rc;
-            if ((rc = c->scratch(WS_SLOTS, gmmk_em_fused_slot_doubles(nteams, ngrp) * sizeof(double), &slots))) return rc;
-            const size_t fw = gmmk_em_fused_flag_words(nteams);
-            if ((rc = c->scratch(WS_FLAGS, fw * sizeof(unsigned), &flags))) return rc;
+            const size_t sw = gmmk_em_fused_slot_words(nteams, ngrp);
+            if ((rc = c->scratch(WS_SLOTS, sw * 8, &slots))) return rc;
             if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
-            GCHK(hipMemsetAsync(flags, 0, fw * sizeof(unsigned), c->stream));
+            GCHK(hipMemsetAsync(slots, 0, sw * 8, c->stream));
             c->t_begin("k_em_fused");
-            int krc = gmmk_em_fused(c->stream, g->KS, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->Pt, g->nct, -log(weight), (const long *)seg,
-                                    nteams, ngrp, (double *)part, (double *)lsew, (double *)slots, (unsigned *)flags, c->n_cu, (int)c->dbg);
+            int krc = gmmk_em_fused(c->stream, g->KS, 1, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, -log(weight),
+                                    (const long *)seg, nteams, nteams, ngrp, 0, (double *)part, nullptr, (double *)lsew,
+                                    (double *)slots, c->n_cu, (int)c->dbg, nullptr);
             c->t_end();
             if (krc == (int)hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); goto two_pass; }
             GCHK(krc);
             unsigned herr = 0;
-            GCHK(hipMemcpyAsync(&herr, (unsigned *)flags + fw - 16, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            GCHK(hipMemcpyAsync(&herr, (char *)slots + (sw - 2) * 8, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             GCHK(hipStreamSynchronize(c->stream));
             if (herr) { // a peer never arrived (grid not fully resident): redo the block with the two-kernel path
                 gmmiv_set_error("em_accumulate(fused): hand-off timed out, fell back to the two-kernel path");
@@ -416,6 +497,19 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
         }
     }
 two_pass:
+    const int64_t Tc = z_chunk_frames(c, g);
+    if (Tc > 0) { // logits written once, statistics from the stored logits
+        void *lsew, *small, *part;
+        int nseg = 0;
+        if ((rc = c->scratch(WS_LSE, (size_t)T * sizeof(double), &lsew))) return rc;
+        if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
+        if ((rc = em_stats_z(c, g, xv, dt, T, Tc, -log(weight), (double *)lsew, &nseg, &part))) return rc;
+        GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
+                               o.d + nacc - 2));
+        GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
+        GCHK(gmmk_em_reduce(c->stream, (const double *)part, nseg, g->C, g->nct * 16, g->D, g->KS, o.d));
+        return o.finish();
+    }
     double *lse;
     if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     void *small;
@@ -511,8 +605,6 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     if (U > 0x7fffffff / 64) { gmmiv_set_error("tv_stats: too many utterances in one call"); return GMMIV_ERR_UNSUPPORTED; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    double *lse;
-    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     std::vector<long> h(utt_begin, utt_begin + U + 1);
     void *seg;
     if ((rc = c->scratch(WS_SEG, (U + 1) * sizeof(long), &seg))) return rc;
@@ -522,6 +614,82 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     DevOut<double> o_n, o_f;
     if ((rc = o_n.init(c, WS_T0, N, (size_t)U * g->C, false))) return rc;
     if ((rc = o_f.init(c, WS_T1, F, (size_t)U * SV, false))) return rc;
+    if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
+        // single pass: each team of workgroups walks utterances team, team + nteams, ...
+        const int ngrp = (g->nct + 7) / 8;
+        int wg_per_cu = 0;
+        GCHK(gmmk_em_fused(c->stream, g->KS, 0, dt == GMMIV_F64, nullptr, 0, g->D, g->C, nullptr, g->nct, 0.0, nullptr, 0, 0, ngrp, 1,
+                           nullptr, nullptr, nullptr, nullptr, c->n_cu, 0, &wg_per_cu));
+        int nteams = c->n_cu * wg_per_cu / ngrp;
+        if (nteams > U) nteams = (int)U;
+        if (nteams >= 1) {
+            void *slots;
+            const size_t sw = gmmk_em_fused_slot_words(nteams, ngrp);
+            if ((rc = c->scratch(WS_SLOTS, sw * 8, &slots))) return rc;
+            GCHK(hipMemsetAsync(slots, 0, sw * 8, c->stream));
+            c->t_begin("k_em_fused");
+            int krc = gmmk_em_fused(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, 0.0, (const long *)seg,
+                                    (int)U, nteams, ngrp, 1, o_n.d, o_f.d, nullptr, (double *)slots, c->n_cu, (int)c->dbg, nullptr);
+            c->t_end();
+            if (krc == (int)hipErrorCooperativeLaunchTooLarge) (void)hipGetLastError();
+            else {
+                GCHK(krc);
+                unsigned herr = 0;
+                GCHK(hipMemcpyAsync(&herr, (char *)slots + (sw - 2) * 8, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                GCHK(hipStreamSynchronize(c->stream));
+                if (!herr) {
+                    if ((rc = o_n.finish())) return rc;
+                    return o_f.finish();
+                }
+                gmmiv_set_error("tv_stats(fused): hand-off timed out, fell back to the two-kernel path");
+            }
+        }
+    }
+    const int64_t Tcz = z_chunk_frames(c, g);
+    if (Tcz > 0) {
+        // chunks of whole utterances whose frames fit the logit scratch; an utterance longer than
+        // that sends the call to the recomputing kernel below
+        std::vector<int64_t> cu(1, 0); // chunk k = utterances [cu[k], cu[k+1])
+        bool fits = true;
+        int64_t maxn = 0;
+        for (int64_t u = 0; u < U;) {
+            int64_t v = u;
+            while (v < U && utt_begin[v + 1] - utt_begin[u] <= Tcz) ++v;
+            if (v == u) { fits = false; break; }
+            if (utt_begin[v] - utt_begin[u] > maxn) maxn = utt_begin[v] - utt_begin[u];
+            cu.push_back(v);
+            u = v;
+        }
+        if (fits) {
+            // relative segment bounds, chunk after chunk: chunk k occupies cu[k] + k .. cu[k+1] + k
+            std::vector<long> rel;
+            for (size_t k = 0; k + 1 < cu.size(); ++k)
+                for (int64_t u = cu[k]; u <= cu[k + 1]; ++u) rel.push_back((long)(utt_begin[u] - utt_begin[cu[k]]));
+            void *zb, *lsew;
+            if ((rc = c->scratch(WS_SEG, rel.size() * sizeof(long), &seg))) return rc;
+            GCHK(hipMemcpyAsync(seg, rel.data(), rel.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
+            GCHK(hipStreamSynchronize(c->stream));
+            const long nfb = 16 * ((maxn + 255) / 256);
+            if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
+            if ((rc = c->scratch(WS_LSE, (size_t)(maxn > 0 ? maxn : 1) * sizeof(double), &lsew))) return rc;
+            for (size_t k = 0; k + 1 < cu.size(); ++k) {
+                const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;
+                c->t_begin("k_llk_mfma", k == 0);
+                GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,
+                                (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb));
+                c->t_end();
+                c->t_begin("k_stats_z", k == 0);
+                GCHK(gmmk_stats_z(c->stream, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb,
+                                  nfb, (const double *)lsew, 0.0, (const long *)seg + u0 + k, (int)(u1 - u0), o_n.d + (size_t)u0 * g->C,
+                                  o_f.d + (size_t)u0 * SV, 1, 0, c->prune_arg()));
+                c->t_end();
+            }
+            if ((rc = o_n.finish())) return rc;
+            return o_f.finish();
+        }
+    }
+    double *lse;
+    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     // every (u, c < C) row is written by exactly one wave (zeros for an empty utterance)
     c->t_begin("k_stats_mfma");
     GCHK(gmmk_stats(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, 0.0,

@@ -22,7 +22,7 @@ void gmmiv_set_error(const char *fmt, ...);
     } while (0)
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
-       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_COUNT };
+       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_COUNT };
 
 struct gmmiv_ctx {
     int device = 0;
@@ -44,12 +44,20 @@ struct gmmiv_ctx {
     long prune_log2 = 0;
     double prune_arg() const { return prune_log2 > 0 ? -(double)prune_log2 * 0.6931471805599453 : -__builtin_inf(); }
     long wg_waves = 8; // waves per workgroup of the two MFMA GMM kernels (8, or 4 for A/B runs)
+    // 1 (default): the log-likelihood kernel leaves the logits in HBM and the statistics kernel reads
+    // them back (stats_z.hip) instead of recomputing them; 0: the recomputing k_stats_mfma
+    long stats_z = 1;
+    // logit scratch budget (MiB): frames are processed in chunks that fit.  Sized for a 288 GB part --
+    // fewer, larger launches (64 GiB = 3.4 M frames of a 2048-Gaussian model per chunk); never more
+    // than half of the memory that is free when the scratch is first needed.
+    long z_scratch_mb = 65536;
     int n_cu = 256;
-    // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name
+    // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name,
+    // one event pair per launch of that kernel inside the call
     enum { NSLOT = 6 };
-    hipEvent_t ev0[NSLOT] = {}, ev1[NSLOT] = {};
+    std::vector<hipEvent_t> ev0[NSLOT], ev1[NSLOT];
     const char *ev_name[NSLOT] = {};
-    bool ev_valid[NSLOT] = {};
+    int ev_used[NSLOT] = {};
     int ev_cur = -1, ev_last = -1;
 
     // grow-only device scratch; contents are NOT preserved across a growth
@@ -70,7 +78,8 @@ struct gmmiv_ctx {
         *out = ws[slot];
         return GMMIV_OK;
     }
-    void t_begin(const char *name)
+    // first = true starts a new measurement of `name` (first launch of an API call), false adds a launch
+    void t_begin(const char *name, bool first = true)
     {
         if (!timing) return;
         int s = -1;
@@ -80,27 +89,36 @@ struct gmmiv_ctx {
             for (int i = 0; i < NSLOT; ++i)
                 if (!ev_name[i]) { s = i; break; }
         if (s < 0) s = NSLOT - 1;
-        if (!ev0[s]) { (void)hipEventCreate(&ev0[s]); (void)hipEventCreate(&ev1[s]); }
+        if (ev_name[s] == nullptr || strcmp(ev_name[s], name) != 0 || first) ev_used[s] = 0;
         ev_name[s] = name;
-        ev_valid[s] = false;
+        if ((int)ev0[s].size() <= ev_used[s]) {
+            hipEvent_t a = nullptr, b = nullptr;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            ev0[s].push_back(a); ev1[s].push_back(b);
+        }
         ev_cur = s;
-        (void)hipEventRecord(ev0[s], stream);
+        (void)hipEventRecord(ev0[s][ev_used[s]], stream);
     }
     void t_end()
     {
         if (!timing || ev_cur < 0) return;
-        (void)hipEventRecord(ev1[ev_cur], stream);
-        ev_valid[ev_cur] = true;
+        (void)hipEventRecord(ev1[ev_cur][ev_used[ev_cur]], stream);
+        ev_used[ev_cur]++;
         ev_last = ev_cur;
         ev_cur = -1;
     }
+    // total milliseconds over the launches of the last call
     double t_query(int s)
     {
-        if (s < 0 || s >= NSLOT || !ev_valid[s]) return -1.0;
-        if (hipEventSynchronize(ev1[s]) != hipSuccess) return -1.0;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev0[s], ev1[s]) != hipSuccess) return -1.0;
-        return (double)ms;
+        if (s < 0 || s >= NSLOT || ev_used[s] <= 0) return -1.0;
+        double tot = 0.0;
+        for (int i = 0; i < ev_used[s]; ++i) {
+            if (hipEventSynchronize(ev1[s][i]) != hipSuccess) return -1.0;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev0[s][i], ev1[s][i]) != hipSuccess) return -1.0;
+            tot += (double)ms;
+        }
+        return tot;
     }
 };
 

@@ -9,18 +9,23 @@
 //                       reductions + one LDS pass), published to the team through global memory
 //   phase C (tile k-1)  gather the 16 partials of the tile -> lse_t; gamma = exp(z - lse_t) from the
 //                       registers of phase A; statistics MFMAs exactly as in k_stats_mfma
-// so 63 instead of 93 MFMAs per 256 pairs.  The hand-off is the write-through payload + flag recipe
-// of cdna_hip_programming.md Guideline 16 (8-byte agent-scope relaxed atomic stores = sc1 stores,
-// every storing wave drains vmcnt before ONE lane stores the flag; consumers poll relaxed, then one
-// agent-scope acquire).  One tile of look-ahead hides the hand-off latency.  Correctness does not
-// depend on placement; liveness needs all workgroups of the grid resident (grid <= CUs, one 512-thread
-// workgroup with ~100 KB LDS per CU) -- every spin is bounded and reports through `err`.
+// so 63 instead of 93 MFMAs per 256 pairs (47 instead of 77 without the x^2 statistics).
+// The hand-off uses self-validating 8-byte words like the LL protocol of RCCL: every word carries
+// 32 bits of payload and the 32-bit sequence number (tile + 1) of the tile it belongs to, written
+// and read with agent-scope relaxed 8-byte atomics (sc1, L1-bypassing).  A reader simply re-loads a
+// word until its sequence number is the one it wants -- no separate flag, no store drain, no fence
+// (8-byte atomics cannot tear, and every word validates itself).  Per (frame, group): the partial
+// maximum as f32 (it is only a reference exponent) and the f64 partial sum in two words.
+// One tile of look-ahead hides the hand-off latency: the loads of tile k-1's partials are issued
+// before the logit MFMAs of tile k and checked after them.  Correctness does not depend on
+// placement; liveness needs all workgroups of the grid resident (grid <= CUs x resident workgroups
+// per CU) -- every spin is bounded and reports through `err`, and the host then falls back.
 #include "devutil.h"
 #include "gmm_kernels.h"
 
 #define EMF_NBUF 4      // hand-off slots (>= 2 * lookahead + 2 with lookahead 1)
 #define EMF_FT 32       // frames per tile
-#define EMF_MAXGRP 64   // Gaussian groups per team (lanes of the polling wave)
+#define EMF_MAXGRP 16   // Gaussian groups per team (one DPP row of the gathering wave)
 
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
 {
@@ -51,21 +56,23 @@ __device__ __forceinline__ double row_sum_f64(double v)
 }
 
 typedef unsigned long long u64;
-__device__ __forceinline__ void st_agent(double *p, double v)
+__device__ __forceinline__ void ll_store(u64 *p, unsigned data, unsigned seq)
 {
-    __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, ((u64)seq << 32) | (u64)data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double ld_agent(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load((const u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+__device__ __forceinline__ u64 ll_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int KS, typename XT>
-__global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x, long ldx, int D, const double *__restrict__ Pt,
-                                                     int nct, double lse_shift, const long *__restrict__ seg_begin, int nteams,
-                                                     int ngrp, double *__restrict__ part, double *__restrict__ lse_out,
-                                                     double *__restrict__ slots, unsigned *__restrict__ flags,
-                                                     unsigned *__restrict__ err, unsigned magicD, int dbg)
+// SQ: also accumulate sum gamma x^2 (EM); without it only N and F (Baum-Welch statistics).
+// mode 0: segment sg -> partial block out0[sg] (summed later); mode 1: segment sg = utterance, its
+// statistics go straight to N = out0[sg][C], F = out1[sg][C*D].  A team walks segments team,
+// team + nteams, ...; the tile counter of the exchange keeps running across segments (kbase).
+template <int KS, typename XT, bool SQ>
+__global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x, long ldx, int D, int C, const double *__restrict__ Pt,
+                                                     int nct, double lse_shift, const long *__restrict__ seg_begin, int nseg,
+                                                     int nteams, int ngrp, int mode, double *__restrict__ out0,
+                                                     double *__restrict__ out1, double *__restrict__ lse_out,
+                                                     u64 *__restrict__ slots, unsigned *__restrict__ err, unsigned magicD,
+                                                     int dbg)
 {
     // dbg (timing experiments, wrong results): 1 = no inter-workgroup exchange
     constexpr int NR = 2 * KS + 2;
@@ -82,7 +89,6 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
     double *red = xb + NXB * FT * RLp;             // 8 waves x FT x (m, s)
     double *lse_t = red + 8 * FT * 2;              // FT
     double *etab = lse_t + FT;                     // 32
-    double *gat = etab + 32;                       // 16 groups x FT x (m, s): the team's partials of one tile
     gexp_table_init(etab, threadIdx.x);
 
     // XCD-aware decode (see k_stats_mfma): the workgroups of a team share an XCD when b % 8 is the XCD
@@ -103,12 +109,9 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
         const int row = s < 2 * KS ? s : 2 * KS + 1;
         Pr[s] = active ? Pt[((size_t)ct * NR + row) * 64 + lane] : 0.0;
     }
-    const long f0 = seg_begin[team], f1 = seg_begin[team + 1];
-    const int ntiles = (int)((f1 - f0 + FT - 1) / FT);
-
-    d4 S[JT], S2[JT];
-#pragma unroll
-    for (int j = 0; j < JT; ++j) { S[j] = (d4){0, 0, 0, 0}; S2[j] = (d4){0, 0, 0, 0}; }
+    long f0 = 0, f1 = 0;
+    int ntiles = 0, kbase = 0;
+    d4 S[JT], S2[SQ ? JT : 1];
 
     // staging plan (see k_stats_mfma)
     XT stg[NLD];
@@ -146,31 +149,44 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
 
     const int offL = i16 * RLp + xrot(i16) + q;
     const int offS = q * RLp + ((q & 1) << 4) + ((q >> 1) << 1) + i16;
-    double *my_slots = slots + (size_t)team * EMF_NBUF * ngrp * FT * 2;
-    unsigned *my_flags = flags + (size_t)team * EMF_NBUF * EMF_MAXGRP;
+    u64 *my_slots = slots + (size_t)team * EMF_NBUF * ngrp * 3 * FT; // [NBUF][ngrp][3 words][FT frames]
 
-    // ---- exchange, step 1 (start of a step): every wave polls the flags of the two groups it
-    // gathers for tile k (published by the peers one step ago) and ISSUES the loads of their
-    // (max, sum) pairs; the values are consumed after this step's logit MFMAs, which hide the latency.
-    double gm = GMMIV_NEG_BIG, gs = 0.0;
+    // ---- exchange, step 1 (start of a step): wave w gathers the partials of ALL groups for its
+    // four frames 4w..4w+3 of tile k (lane = 16 * frame + group) and only ISSUES the loads here;
+    // they are checked after this step's logit MFMAs, which hide the latency.
+    u64 g0 = 0, g1 = 0, g2 = 0;
     auto gather_issue = [&](int k) {
         if (dbg & 1) return;
-        const int gsel = 2 * wave + (lane >> 5); // group gathered by this half-wave
-        if ((lane & 31) == 0 && gsel < ngrp) {
-            const unsigned want = (unsigned)(k + 1);
-            unsigned spins = 0;
-            while (__hip_atomic_load(&my_flags[(k % EMF_NBUF) * EMF_MAXGRP + gsel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) { atomicOr(err, 1u); break; } // bounded: a non-resident peer must not hang the GPU
-            }
+        if (i16 < ngrp) {
+            const u64 *sl = my_slots + ((size_t)((kbase + k) % EMF_NBUF) * ngrp + i16) * 3 * FT + 4 * wave + q;
+            g0 = ll_load(sl); g1 = ll_load(sl + FT); g2 = ll_load(sl + 2 * FT);
         }
-        // no acquire fence: the payload is written with sc1 stores and read with sc1 (L1-bypassing)
-        // loads, the form Guideline 16 allows in place of an agent-scope acquire (saves ~1.7 us per step)
-        gm = GMMIV_NEG_BIG; gs = 0.0;
-        if (gsel < ngrp) {
-            const double *sl = my_slots + (((size_t)(k % EMF_NBUF) * ngrp + gsel) * FT + (lane & 31)) * 2;
-            gm = ld_agent(sl);
-            gs = ld_agent(sl + 1);
+    };
+    // ---- exchange, step 3 (after the logit MFMAs): validate / re-load, combine the groups -> lse_t
+    auto combine_lse = [&](int k) {
+        double m = GMMIV_NEG_BIG, sg = 0.0;
+        if (!(dbg & 1)) {
+            if (i16 < ngrp) {
+                const unsigned want = (unsigned)(kbase + k + 1);
+                const u64 *sl = my_slots + ((size_t)((kbase + k) % EMF_NBUF) * ngrp + i16) * 3 * FT + 4 * wave + q;
+                unsigned spins = 0;
+                while ((unsigned)(g0 >> 32) != want || (unsigned)(g1 >> 32) != want || (unsigned)(g2 >> 32) != want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    g0 = ll_load(sl); g1 = ll_load(sl + FT); g2 = ll_load(sl + 2 * FT);
+                    if (++spins > (1u << 22)) { atomicOr(err, 1u); break; } // bounded: a non-resident peer must not hang the GPU
+                }
+                m = (double)__uint_as_float((unsigned)g0);
+                sg = __longlong_as_double((long long)(((g2 & 0xffffffffull) << 32) | (g1 & 0xffffffffull)));
+            }
+        } else if (i16 == 0) { m = 0.0; sg = 1.0; }
+        const double M = (double)row_max_f32((float)fmax(m, -3.0e38));
+        const double Ssum = row_sum_f64(sg * gexp_t(m - M, etab));
+        if (i16 == 0) {
+            const double lse = M + log(Ssum);
+            const int tl = 4 * wave + q;
+            lse_t[tl] = lse + lse_shift;
+            const long fr = f0 + (long)k * FT + tl;
+            if (lse_out && grp == 0 && fr < f1) lse_out[fr] = lse;
         }
     };
 
@@ -216,54 +232,21 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
     };
 
     // ---- exchange, step 2 (after the barrier that completes `red`): wave 0 publishes this
-    // workgroup's partials of tile k; every wave drops the pairs it gathered for tile kprev into LDS
-    auto publish_and_stash = [&](int k, bool do_pub, bool do_stash) {
-        if (do_pub && wave == 0 && !(dbg & 1)) {
-            if (lane < FT) {
-                double M = red[lane * 2];
+    // workgroup's partials of tile k.  The per-wave maxima are f32 values, so M is exact in f32.
+    auto publish = [&](int k) {
+        if (wave == 0 && !(dbg & 1) && lane < FT) {
+            double M = red[lane * 2];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) M = fmax(M, red[(w * FT + lane) * 2]);
-                double Ssum = 0.0;
+            for (int w = 1; w < 8; ++w) M = fmax(M, red[(w * FT + lane) * 2]);
+            double Ssum = 0.0;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) Ssum += red[(w * FT + lane) * 2 + 1] * gexp_t(red[(w * FT + lane) * 2] - M, etab);
-                double *sl = my_slots + (((size_t)(k % EMF_NBUF) * ngrp + grp) * FT + lane) * 2;
-                st_agent(sl, M);
-                st_agent(sl + 1, Ssum);
-            }
-        }
-        if (do_stash) {
-            const int gsel = 2 * wave + (lane >> 5);
-            gat[(gsel * FT + (lane & 31)) * 2] = gm;
-            gat[(gsel * FT + (lane & 31)) * 2 + 1] = gs;
-        }
-    };
-
-    // the flag follows the payload: the storing wave drains its stores, then ONE lane raises the flag.
-    // Called after the next barrier, so the drain has usually nothing left to wait for.
-    auto publish_flag = [&](int k) {
-        if (wave == 0 && !(dbg & 1)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&my_flags[(k % EMF_NBUF) * EMF_MAXGRP + grp], (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-
-    // ---- exchange, step 3: wave w combines the 16 group partials of frames 4w..4w+3 -> lse_t ------
-    auto combine_lse = [&](int k) {
-        if (lane < 32) {
-            const int tl = 4 * wave + (lane >> 3), p = lane & 7;
-            const double m0 = gat[((2 * p) * FT + tl) * 2], s0 = gat[((2 * p) * FT + tl) * 2 + 1];
-            const double m1 = gat[((2 * p + 1) * FT + tl) * 2], s1 = gat[((2 * p + 1) * FT + tl) * 2 + 1];
-            double M = fmax(m0, m1);
-            // 8-lane all-reduce (lanes of one frame are contiguous): xor 1, 2, 4
-            M = fmax(M, shfl_xor_f64(M, 1)); M = fmax(M, shfl_xor_f64(M, 2)); M = fmax(M, shfl_xor_f64(M, 4));
-            double Ssum = s0 * gexp_t(m0 - M, etab) + s1 * gexp_t(m1 - M, etab);
-            Ssum += shfl_xor_f64(Ssum, 1); Ssum += shfl_xor_f64(Ssum, 2); Ssum += shfl_xor_f64(Ssum, 4);
-            if (p == 0) {
-                const double lse = M + log(Ssum);
-                lse_t[tl] = lse + lse_shift;
-                const long fr = f0 + (long)k * FT + tl;
-                if (grp == 0 && fr < f1) lse_out[fr] = lse;
-            }
+            for (int w = 0; w < 8; ++w) Ssum += red[(w * FT + lane) * 2 + 1] * gexp_t(red[(w * FT + lane) * 2] - M, etab);
+            const unsigned seq = (unsigned)(kbase + k + 1);
+            u64 *sl = my_slots + ((size_t)((kbase + k) % EMF_NBUF) * ngrp + grp) * 3 * FT + lane;
+            const u64 sb = (u64)__double_as_longlong(Ssum);
+            ll_store(sl, __float_as_uint((float)M), seq);
+            ll_store(sl + FT, (unsigned)sb, seq);
+            ll_store(sl + 2 * FT, (unsigned)(sb >> 32), seq);
         }
     };
 
@@ -281,36 +264,28 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
                     for (int j = 0; j < JT; ++j) {
                         const double bv = pS[(fs * 16 + 4 * r) * RLp + 4 * r + 16 * j];
                         S[j] = MFMA_F64(gam, bv, S[j]);
-                        S2[j] = MFMA_F64(gam, bv * bv, S2[j]);
+                        if (SQ) S2[j] = MFMA_F64(gam, bv * bv, S2[j]);
                     }
                 }
         }
     };
 
     // one pipeline step: A(ka) into za, C(kc = ka - 1) from zc.  Two barriers:
-    //   B1 closes `red` (phase A partials) and `gat` (gathered team partials of tile kc);
-    //   B2 closes lse_t and the freshly staged frame tile ka+1.
-    // Reuse is safe without a third barrier: red/gat are next written after B2, lse_t and the frame
-    // buffer of tile kc are next written after the following B1, which every wave reaches only after
-    // finishing its phase C.
+    //   B1 closes `red` (phase A partials of tile ka) and lse_t (tile kc), and frees frame buffer ka+1
+    //      (= ka-2, last read by the phase C of the previous step);
+    //   B2 closes the freshly staged frame tile ka+1 and frees red / lse_t for the next step.
     auto step = [&](int ka, double (&za)[2][4], double (&zc)[2][4]) {
         const int kc = ka - 1;
         const bool doA = ka < ntiles, doC = kc >= 0 && kc < ntiles;
         if (ka + 1 < ntiles) load_tile(ka + 1);
         if (doC) gather_issue(kc);
         if (doA) phaseA(ka, za);
-        if (doC && !(dbg & 1)) {
-            const int gsel = 2 * wave + (lane >> 5);
-            gat[(gsel * FT + (lane & 31)) * 2] = gm;
-            gat[(gsel * FT + (lane & 31)) * 2 + 1] = gs;
-        }
-        __syncthreads();                       // B1
-        publish_and_stash(ka, doA, false);
         if (doC) combine_lse(kc);
+        __syncthreads();                       // B1
+        if (doA) publish(ka);
+        if (doC) phaseC(kc, zc);
         if (ka + 1 < ntiles) write_tile(ka + 1);
         __syncthreads();                       // B2
-        if (doA) publish_flag(ka);
-        if (doC) phaseC(kc, zc);
     };
 
     // ---- software pipeline over the tiles (look-ahead 1) ------------------------------------------
@@ -319,24 +294,51 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
     for (int fs = 0; fs < 2; ++fs)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { zA[fs][r] = 0.0; zB[fs][r] = 0.0; }
-    if (ntiles > 0) { load_tile(0); write_tile(0); }
-    __syncthreads();
-    for (int k = 0; k <= ntiles; k += 2) {
-        step(k, zA, zB);
-        step(k + 1, zB, zA);
-    }
-    __syncthreads();
+    for (int sg = team; sg < nseg; sg += nteams) {
+        f0 = seg_begin[sg]; f1 = seg_begin[sg + 1];
+        ntiles = (int)((f1 - f0 + FT - 1) / FT);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) S[j] = (d4){0, 0, 0, 0};
+        if (SQ) {
+#pragma unroll
+            for (int j = 0; j < JT; ++j) S2[j] = (d4){0, 0, 0, 0};
+        }
+        if (ntiles > 0) { load_tile(0); write_tile(0); }
+        __syncthreads();
+        for (int k = 0; k <= ntiles; k += 2) {
+            step(k, zA, zB);
+            step(k + 1, zB, zA);
+        }
+        __syncthreads();
+        kbase += ntiles;
 
-    if (!active) return;
-    const size_t Cp = (size_t)nct * 16;
-    double *o = part + (size_t)team * Cp * (2 * RL);
+        if (!active) continue;
+        if (mode == 0) {
+            const size_t Cp = (size_t)nct * 16;
+            double *o = out0 + (size_t)sg * Cp * (2 * RL);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const size_t c = (size_t)ct * 16 + q + 4 * r;
+            for (int r = 0; r < 4; ++r) {
+                const size_t c = (size_t)ct * 16 + q + 4 * r;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            o[c * (2 * RL) + 16 * j + i16] = S[j][r];
-            o[c * (2 * RL) + RL + 16 * j + i16] = S2[j][r];
+                for (int j = 0; j < JT; ++j) {
+                    o[c * (2 * RL) + 16 * j + i16] = S[j][r];
+                    if (SQ) o[c * (2 * RL) + RL + 16 * j + i16] = S2[j][r];
+                }
+            }
+        } else {
+            double *N = out0 + (size_t)sg * C;
+            double *F = out1 + (size_t)sg * C * D;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = ct * 16 + q + 4 * r;
+                if (c >= C) continue;
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const int col = 16 * j + i16;
+                    if (col < D) F[(size_t)c * D + col] = S[j][r];
+                    else if (col == Dp) N[c] = S[j][r];
+                }
+            }
         }
     }
 }
@@ -347,46 +349,51 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
         if (_e != hipSuccess) return (int)_e;                             \
     } while (0)
 
-size_t gmmk_em_fused_slot_doubles(int nteams, int ngrp) { return (size_t)nteams * EMF_NBUF * ngrp * EMF_FT * 2; }
-size_t gmmk_em_fused_flag_words(int nteams) { return (size_t)nteams * EMF_NBUF * EMF_MAXGRP + 16; }
+// hand-off words (8 bytes each, zeroed by the caller on the stream before every launch) + error word
+size_t gmmk_em_fused_slot_words(int nteams, int ngrp) { return (size_t)nteams * EMF_NBUF * ngrp * 3 * EMF_FT + 2; }
 
-template <int KS, typename XT>
-static int launch_fused(hipStream_t st, const void *x, long ldx, int D, const double *Pt, int nct, double lse_shift,
-                        const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
-                        unsigned *flags, int n_cu, int dbg)
+template <int KS, typename XT, bool SQ>
+static int launch_fused(hipStream_t st, const void *x, long ldx, int D, int C, const double *Pt, int nct, double lse_shift,
+                        const long *seg_begin, int nseg, int nteams, int ngrp, int mode, double *out0, double *out1,
+                        double *lse_out, double *slots, int n_cu, int dbg, int *query_blocks)
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
-    const size_t lds = ((size_t)3 * EMF_FT * (RL + 32) + 8 * EMF_FT * 2 + EMF_FT + 32 + 16 * EMF_FT * 2) * sizeof(double);
+    const size_t lds = ((size_t)3 * EMF_FT * (RL + 32) + 8 * EMF_FT * 2 + EMF_FT + 32) * sizeof(double);
     static int blocks_per_cu = -1;
     if (blocks_per_cu < 0) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_em_fused<KS, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_em_fused<KS, XT, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_em_fused<KS, XT>, 512, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_em_fused<KS, XT, SQ>, 512, lds));
         blocks_per_cu = nb;
     }
+    if (query_blocks) { *query_blocks = blocks_per_cu; return 0; }
     if (blocks_per_cu < 1 || nteams * ngrp > n_cu * blocks_per_cu) return (int)hipErrorCooperativeLaunchTooLarge;
     const unsigned grid = (unsigned)(8 * ngrp * ((nteams + 7) / 8));
     const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);
-    k_em_fused<KS, XT><<<grid, 512, lds, st>>>(x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots,
-                                                flags, flags + gmmk_em_fused_flag_words(nteams) - 16, magicD, dbg);
+    k_em_fused<KS, XT, SQ><<<grid, 512, lds, st>>>(x, ldx, D, C, Pt, nct, lse_shift, seg_begin, nseg, nteams, ngrp, mode, out0, out1,
+                                                    lse_out, (u64 *)slots,
+                                                    (unsigned *)((u64 *)slots + gmmk_em_fused_slot_words(nteams, ngrp) - 2), magicD, dbg);
     return (int)hipGetLastError();
 }
 
-// flags (zeroed by the caller on the stream before every launch) hold the hand-off flags and, in the
-// last 16 words, the error word.
-int gmmk_em_fused(hipStream_t st, int KS, int x_f64, const void *x, long ldx, int D, const double *Pt, int nct,
-                  double lse_shift, const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
-                  unsigned *flags, int n_cu, int dbg)
+// slots: gmmk_em_fused_slot_words() 8-byte words, zeroed by the caller on the stream before every
+// launch; the last two hold the error word.  sq = 1: EM statistics (occ, sum x, sum x^2); sq = 0: N and F.
+// query_blocks != NULL: only report the resident workgroups per CU of the instantiation.
+int gmmk_em_fused(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt, int nct,
+                  double lse_shift, const long *seg_begin, int nseg, int nteams, int ngrp, int mode, double *out0, double *out1,
+                  double *lse_out, double *slots, int n_cu, int dbg, int *query_blocks)
 {
-    if (nteams <= 0) return 0;
-    if (ngrp > 16) return (int)hipErrorCooperativeLaunchTooLarge; // each wave gathers two groups
-#define CASE(K)                                                                                                              \
-    case K:                                                                                                                  \
-        return x_f64 ? launch_fused<K, double>(st, x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots, flags, n_cu, dbg) \
-                     : launch_fused<K, float>(st, x, ldx, D, Pt, nct, lse_shift, seg_begin, nteams, ngrp, part, lse_out, slots, flags, n_cu, dbg);
+    if (!query_blocks && (nteams <= 0 || nseg <= 0)) return 0;
+    if (ngrp > EMF_MAXGRP) return (int)hipErrorCooperativeLaunchTooLarge; // a DPP row gathers the groups
+#define ARGS st, x, ldx, D, C, Pt, nct, lse_shift, seg_begin, nseg, nteams, ngrp, mode, out0, out1, lse_out, slots, n_cu, dbg, query_blocks
+#define CASE(K)                                                                                           \
+    case K:                                                                                               \
+        if (sq) return x_f64 ? launch_fused<K, double, true>(ARGS) : launch_fused<K, float, true>(ARGS);  \
+        return x_f64 ? launch_fused<K, double, false>(ARGS) : launch_fused<K, float, false>(ARGS);
     switch (KS) {
         CASE(4) CASE(8) CASE(15)
     }
 #undef CASE
+#undef ARGS
     return (int)hipErrorInvalidValue;
 }

@@ -33,8 +33,16 @@ int gmmk_variance_control(hipStream_t st, int C, int D, double *cov, double floo
 int gmmk_reciprocal(hipStream_t st, long n, const double *in, double *out);
 int gmmk_gather_frames(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *idx, long n, void *out);
 // em_fused.hip: single-pass EM statistics by teams of cooperating workgroups
-size_t gmmk_em_fused_slot_doubles(int nteams, int ngrp);
-size_t gmmk_em_fused_flag_words(int nteams);
-int gmmk_em_fused(hipStream_t st, int KS, int x_f64, const void *x, long ldx, int D, const double *Pt, int nct,
-                  double lse_shift, const long *seg_begin, int nteams, int ngrp, double *part, double *lse_out, double *slots,
-                  unsigned *flags, int n_cu, int dbg);
+size_t gmmk_em_fused_slot_words(int nteams, int ngrp);
+int gmmk_em_fused(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt, int nct,
+                  double lse_shift, const long *seg_begin, int nseg, int nteams, int ngrp, int mode, double *out0, double *out1,
+                  double *lse_out, double *slots, int n_cu, int dbg, int *query_blocks);
+
+// stats_z.hip / k_llk_mfma<WZ>: logits written once by the log-likelihood kernel, statistics from the stored logits
+int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
+               double *lse, int use_glds, double *zbuf, long nfb);
+int gmmk_stats_z_groups(int nct);
+void gmmk_stats_z_set_ablation(int a);
+int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
+                 long nfb, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0, double *out1,
+                 int mode, int accum, double prune_arg);

@@ -87,10 +87,14 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // Frame operands stay in registers; the packed model streams through a double-buffered LDS
 // tile (2 c-tiles = 32 Gaussians per stage), by LDS-DMA when use_glds.
 // -------------------------------------------------------------------------------------------
-template <int KS, typename XT, int NW>
+// WZ: also write every logit z[t][c] to zbuf for the statistics kernel that follows (stats_z.hip), in
+// the register layout of the MFMA result = A-operand layout of the statistics MFMA: 2 KB blocks
+// [Gaussian tile ct][16-frame block fb][lane][4 rows], so both sides move 32 contiguous bytes per lane.
+template <int KS, typename XT, int NW, bool WZ>
 __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ Pt, int nct,
-                                                  double *__restrict__ lse_out, int use_glds, int dbg)
+                                                  double *__restrict__ lse_out, int use_glds, int dbg,
+                                                  double *__restrict__ zbuf, long nfb)
 {
     // dbg (timing experiments only, results are wrong when != 0): 1 = no log-sum-exp epilogue,
     // 2 = additionally no per-tile staging / barrier, 3 = additionally B operands not re-read from LDS
@@ -169,6 +173,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
             acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
         }
+        if (WZ) { // unconditional: zbuf covers the whole grid (nfb = 16 blocks per workgroup), so the
+                  // number of stores behind this iteration's LDS-DMA is fixed (counted wait below)
+            double *zw = zbuf + ((((size_t)(tl * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
+#pragma unroll
+            for (int g = 0; g < GT; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) __builtin_nontemporal_store(acc[g][h], (d4 *)(zw + ((size_t)g * nfb + h) * 256)); // streamed: keep the model tiles in L2
+        }
         // Online log-sum-exp per (lane, frame row) with an INTEGER reference: the sum is kept as
         // sacc * 2^E.  exp(z) = t * 2^n (t in [1,2)) is added as ldexp(t, n - E); when a logit's n
         // exceeds E by 64 or more the reference moves with one ldexp (no exp, no fp64 compare
@@ -218,7 +230,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     if (need & (1u << (h * 4 + r)))
                         sacc[h][r] += gexp_scaled(acc[0][h][r], E[h][r], etab) + gexp_scaled(acc[1][h][r], E[h][r], etab);
         }
-        __syncthreads();
+        if (WZ && NW == 8) {
+            // __syncthreads() would wait vmcnt(0) (an LDS-DMA is pending) and with it drain this
+            // iteration's 8 logit stores -- a full HBM write round trip per tile.  VMEM operations of
+            // a wave retire in issue order on gfx9-family parts, so vmcnt(8) retires the LDS-DMA of
+            // the next tile (issued before the stores) and leaves the stores in flight.
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
     }
     // combine the 16 lanes (Gaussian columns) that share a frame row: common exponent, then sum
 #pragma unroll
@@ -727,19 +747,19 @@ int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, con
     return (int)hipGetLastError();
 }
 
-template <int KS, typename XT, int NW>
+template <int KS, typename XT, int NW, bool WZ>
 static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, const double *Pt, int nct,
-                      double *lse, int use_glds)
+                      double *lse, int use_glds, double *zbuf = nullptr, long nfb = 0)
 {
     constexpr int NR = 2 * KS + 2;
     const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + 32 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, WZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const unsigned grid = (unsigned)((T + NW * 32 - 1) / (NW * 32));
-    k_llk_mfma<KS, XT, NW><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8);
+    k_llk_mfma<KS, XT, NW, WZ><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb);
     return (int)hipGetLastError();
 }
 
@@ -752,12 +772,29 @@ int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx,
 #define CASE(K)                                                                                      \
     case K:                                                                                          \
         if (wg_waves == 8)                                                                           \
-            return x_f64 ? launch_llk<K, double, 8>(st, x, T, ldx, D, Pt, nct, lse, use_glds)        \
-                         : launch_llk<K, float, 8>(st, x, T, ldx, D, Pt, nct, lse, use_glds);        \
-        return x_f64 ? launch_llk<K, double, 4>(st, x, T, ldx, D, Pt, nct, lse, use_glds)            \
-                     : launch_llk<K, float, 4>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
+            return x_f64 ? launch_llk<K, double, 8, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds) \
+                         : launch_llk<K, float, 8, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds); \
+        return x_f64 ? launch_llk<K, double, 4, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds)     \
+                     : launch_llk<K, float, 4, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
     switch (KS) {
         CASE(4) CASE(8) CASE(15) CASE(20)
+    }
+#undef CASE
+    return -1;
+}
+
+// the same kernel, additionally writing the logits of frames [0, T) to zbuf (nct * nfb blocks of 2 KB,
+// nfb = 16 * ceil(T / 256): whole workgroups are written); 8-wave workgroups
+int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
+               double *lse, int use_glds, double *zbuf, long nfb)
+{
+    if (T <= 0) return 0;
+#define CASE(K)                                                                                                   \
+    case K:                                                                                                       \
+        return x_f64 ? launch_llk<K, double, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb)        \
+                     : launch_llk<K, float, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb);
+    switch (KS) {
+        CASE(4) CASE(8) CASE(15)
     }
 #undef CASE
     return -1;

@@ -236,6 +236,90 @@ def test_tv_stats_match_oracle(ctx, C, D):
     assert not N[1].any() and not F[1].any()
 
 
+@pytest.mark.parametrize("C,D,U", [(128, 60, 7), (2048, 60, 40), (37, 13, 5), (512, 24, 70)])
+def test_tv_stats_fused_single_pass_matches_two_pass(ctx, C, D, U):
+    """tv_stats through em_fused.hip: a team of workgroups walks several utterances (ragged, some
+    empty, more utterances than teams); same N and F as the two-kernel path."""
+    rng = np.random.default_rng(U)
+    lens = rng.integers(0, 400, U)
+    lens[1] = 0
+    lens[-1] = 1
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    w, mean, iv = make_gmm(C, D, seed=C + 9)
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=13)
+    g = ctx.gmm(w, mean, iv)
+    N0, F0 = g.tv_stats(x, ub)
+    ctx.set_option("em_fused", 1)
+    try:
+        N1, F1 = g.tv_stats(x, ub)
+        N2, F2 = g.tv_stats(x, ub)
+    finally:
+        ctx.set_option("em_fused", 0)
+    assert relerr(N1, N0) < 1e-12 and relerr(F1, F0) < 1e-12
+    assert np.array_equal(N1, N2) and np.array_equal(F1, F2)
+    assert not N1[1].any() and not F1[1].any()
+    assert np.allclose(N1.sum(1), lens, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("C,D,T,mb", [(128, 60, 20000, 8), (2048, 60, 9000, 100), (37, 13, 7001, 4), (300, 24, 15000, 16)])
+def test_stored_logit_path_chunked_matches_recompute(ctx, C, D, T, mb):
+    """Default EM path (k_llk_mfma<WZ> + k_stats_z, frames in chunks that fit the logit scratch) against
+    the recomputing kernel (stats_z = 0) and the oracle."""
+    w, mean, iv = make_gmm(C, D, seed=C + 21)
+    x = make_frames(w, mean, iv, T, seed=T + 1)
+    g = ctx.gmm(w, mean, iv)
+    ctx.set_option("stats_z", 0)
+    try:
+        ref = g.em_accumulate(x, weight=0.5)
+    finally:
+        ctx.set_option("stats_z", 1)
+    one = g.em_accumulate(x, weight=0.5)
+    prev = ctx.set_option("z_scratch_mb", mb)
+    try:
+        ctx.set_option("timing", 1)
+        got = g.em_accumulate(x, weight=0.5)
+        nl = ctx.kernel_launches("k_stats_z")
+        ctx.set_option("timing", 0)
+    finally:
+        ctx.set_option("z_scratch_mb", prev)
+    assert nl >= 2, nl                      # really chunked
+    assert relerr(one, ref) < 1e-12 and relerr(got, ref) < 1e-12
+    a = g.split_acc(got)
+    o = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
+    assert relerr(a["occ"], 0.5 * o["occ"]) < 1e-9 and relerr(a["sxx"], 0.5 * o["sxx"]) < 1e-9
+
+
+@pytest.mark.parametrize("C,D,U,mb", [(128, 60, 30, 8), (2048, 60, 12, 100), (37, 13, 20, 4)])
+def test_tv_stats_stored_logit_path_chunks_of_utterances(ctx, C, D, U, mb):
+    rng = np.random.default_rng(U + C)
+    lens = rng.integers(0, 1500, U)
+    lens[2] = 0
+    lens[-1] = 1
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    w, mean, iv = make_gmm(C, D, seed=C + 17)
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=3)
+    g = ctx.gmm(w, mean, iv)
+    ctx.set_option("stats_z", 0)
+    try:
+        N0, F0 = g.tv_stats(x, ub)
+    finally:
+        ctx.set_option("stats_z", 1)
+    N1, F1 = g.tv_stats(x, ub)
+    prev = ctx.set_option("z_scratch_mb", mb)
+    try:
+        ctx.set_option("timing", 1)
+        N2, F2 = g.tv_stats(x, ub)
+        nl = ctx.kernel_launches("k_stats_z")
+        ctx.set_option("timing", 0)
+    finally:
+        ctx.set_option("z_scratch_mb", prev)
+    assert nl >= 2, nl
+    for N, F in ((N1, F1), (N2, F2)):
+        assert relerr(N, N0) < 1e-12 and relerr(F, F0) < 1e-12
+        assert not N[2].any() and not F[2].any()
+        assert np.allclose(N.sum(1), lens, rtol=1e-10, atol=1e-10)
+
+
 def test_frame_moments(ctx):
     rng = np.random.default_rng(0)
     for T, D in [(1, 60), (1000, 60), (4097, 34), (50, 130)]:

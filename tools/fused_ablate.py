@@ -14,7 +14,7 @@ ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
 ctx.set_option("timing", 1); ctx.set_option("em_fused", 1)
 g = ctx.gmm(w, mean, iv)
 acc = torch.zeros(g.em_acc_len(), dtype=torch.float64, device="cuda")
-for dbg in (0, 1, 2, 3, 4, 5, 7):
+for dbg in (0, 1):
     ctx.set_option("dbg", dbg)
     g.em_accumulate(x, acc=acc); g.em_accumulate(x, acc=acc)
     ms = ctx.kernel_ms("k_em_fused")
