@@ -89,6 +89,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "prune_log2")) slot = &c->prune_log2;
     else if (!strcmp(key, "stats_z")) slot = &c->stats_z;
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
+    else if (!strcmp(key, "z_waves")) slot = &c->z_waves;
     if (!slot) return -1;
     long prev = *slot;
     *slot = value;
@@ -370,7 +371,19 @@ static int make_chunks(gmmiv_ctx *c, int64_t T, int nseg, long **dev)
     return GMMIV_OK;
 }
 
-// ---- stored-logit path (k_llk_mfma<WZ> + k_stats_z) -------------------------------------------
+// ---- stored-likelihood path (k_llk_mfma<WZ> + k_stats_z) ----------------------------------------
+// Blocks (2 KB) per Gaussian tile of the likelihood scratch for n frames: whole workgroups of the
+// log-likelihood kernel (256 frames), then padded so that the tile stride is an ODD number of 4 KB
+// granules.  A statistics workgroup reads 16 tiles at the same frame position at once; with a stride
+// that is a multiple of the HBM channel interleave (a large power of two) all 16 streams -- and those
+// of every other workgroup of the segment -- would sit on the same channel.
+static long z_tile_blocks(int64_t n)
+{
+    long nfb = 16 * ((n + 255) / 256);
+    if ((nfb / 2) % 2 == 0) nfb += 2;
+    return nfb;
+}
+
 // frames per chunk that fit the logit scratch budget (multiple of 64), 0 when the path does not apply
 static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g)
 {
@@ -381,7 +394,7 @@ static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g)
     size_t budget = (size_t)(c->z_scratch_mb > 0 ? c->z_scratch_mb : 0) << 20;
     const size_t avail = have + fr / 2; // never take more than half of what is free now
     if (budget > avail) budget = avail;
-    const size_t per_frame = (size_t)g->nct * 16 * sizeof(double);
+    const size_t per_frame = (size_t)g->nct * 16 * sizeof(double) + (size_t)g->nct * 2 + 16; // likelihoods + exponents
     int64_t tc = (int64_t)(budget / per_frame / 1.2); // scratch() over-allocates by 1/8
     // whole rounds of the log-likelihood kernel: 2 resident workgroups per CU x 256 frames
     const int64_t round = (int64_t)c->n_cu * 2 * 256;
@@ -391,12 +404,13 @@ static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g)
 static const void *x_at(const XView &xv, int dt, int64_t frame) { return (const char *)xv.d + (size_t)frame * xv.ldx * esize(dt); }
 
 // EM statistics of frames [0, T) into the partial blocks part[nseg] (summed by the caller)
-static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, int64_t Tc, double lse_shift,
+static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, int64_t Tc, double weight,
                       double *lse, int *nseg_out, void **part_out)
 {
     int rc;
+    gmmk_stats_z_set_waves((int)c->z_waves);
     const int ngrp = gmmk_stats_z_groups(g->nct);
-    int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (c->n_cu + ngrp - 1) / ngrp;
+    int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (c->n_cu * gmmk_stats_z_wg_per_cu() + ngrp - 1) / ngrp;
     nseg = (nseg + 7) / 8 * 8;
     const int64_t first = T < Tc ? T : Tc;
     const int64_t cap = (first + 2047) / 2048;
@@ -411,12 +425,15 @@ static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt,
     const int64_t lastn = T - (nchunk - 1) * Tc;
     fill(h.data(), first);
     fill(h.data() + nseg + 1, lastn);
-    void *seg, *zb, *part;
+    void *seg, *zb, *part, *eit, *inv;
     if ((rc = c->scratch(WS_SEG, h.size() * sizeof(long), &seg))) return rc;
     GCHK(hipMemcpyAsync(seg, h.data(), h.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
     GCHK(hipStreamSynchronize(c->stream));
-    const long nfb = 16 * ((first + 255) / 256); // the log-likelihood kernel writes whole workgroups (256 frames)
+    const long nfb = c->dbg & 64 ? 16 * ((first + 255) / 256) : z_tile_blocks(first);
     if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
+    if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
+    if ((rc = c->scratch(WS_INV, (size_t)first * (sizeof(double) + sizeof(int)), &inv))) return rc;
+    int *efin = (int *)((double *)inv + first);
     const int RL = gmmk_rl_for_ks(g->KS);
     const size_t Cp = (size_t)g->nct * 16;
     if ((rc = c->scratch(WS_PART, (size_t)nseg * Cp * 2 * RL * sizeof(double), &part))) return rc;
@@ -424,13 +441,12 @@ static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt,
         const int64_t c0 = k * Tc, n = (k == nchunk - 1) ? lastn : Tc;
         c->t_begin("k_llk_mfma", k == 0);
         GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, lse + c0,
-                        (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb));
+                        (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb, (int *)eit, (double *)inv, efin));
         c->t_end();
-        gmmk_stats_z_set_ablation((int)(c->dbg >> 4));
         c->t_begin("k_stats_z", k == 0);
         GCHK(gmmk_stats_z(c->stream, g->KS, 1, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb, nfb,
-                          lse + c0, lse_shift, (const long *)seg + (k == nchunk - 1 ? nseg + 1 : 0), nseg, (double *)part, nullptr, 0,
-                          k > 0, c->prune_arg()));
+                          (const int *)eit, (const double *)inv, efin, weight, (const long *)seg + (k == nchunk - 1 ? nseg + 1 : 0), nseg,
+                          (double *)part, nullptr, 0, k > 0, c->prune_thr()));
         c->t_end();
     }
     *nseg_out = nseg;
@@ -503,7 +519,7 @@ two_pass:
         int nseg = 0;
         if ((rc = c->scratch(WS_LSE, (size_t)T * sizeof(double), &lsew))) return rc;
         if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
-        if ((rc = em_stats_z(c, g, xv, dt, T, Tc, -log(weight), (double *)lsew, &nseg, &part))) return rc;
+        if ((rc = em_stats_z(c, g, xv, dt, T, Tc, weight, (double *)lsew, &nseg, &part))) return rc;
         GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
                                o.d + nacc - 2));
         GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
@@ -665,23 +681,27 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
             std::vector<long> rel;
             for (size_t k = 0; k + 1 < cu.size(); ++k)
                 for (int64_t u = cu[k]; u <= cu[k + 1]; ++u) rel.push_back((long)(utt_begin[u] - utt_begin[cu[k]]));
-            void *zb, *lsew;
+            void *zb, *lsew, *eit, *inv;
             if ((rc = c->scratch(WS_SEG, rel.size() * sizeof(long), &seg))) return rc;
             GCHK(hipMemcpyAsync(seg, rel.data(), rel.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
             GCHK(hipStreamSynchronize(c->stream));
-            const long nfb = 16 * ((maxn + 255) / 256);
+            const long nfb = z_tile_blocks(maxn);
             if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
             if ((rc = c->scratch(WS_LSE, (size_t)(maxn > 0 ? maxn : 1) * sizeof(double), &lsew))) return rc;
+            if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
+            if ((rc = c->scratch(WS_INV, (size_t)(maxn > 0 ? maxn : 1) * (sizeof(double) + sizeof(int)), &inv))) return rc;
+            int *efin = (int *)((double *)inv + (maxn > 0 ? maxn : 1));
+            gmmk_stats_z_set_waves((int)c->z_waves);
             for (size_t k = 0; k + 1 < cu.size(); ++k) {
                 const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;
                 c->t_begin("k_llk_mfma", k == 0);
                 GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,
-                                (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb));
+                                (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb, (int *)eit, (double *)inv, efin));
                 c->t_end();
                 c->t_begin("k_stats_z", k == 0);
                 GCHK(gmmk_stats_z(c->stream, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb,
-                                  nfb, (const double *)lsew, 0.0, (const long *)seg + u0 + k, (int)(u1 - u0), o_n.d + (size_t)u0 * g->C,
-                                  o_f.d + (size_t)u0 * SV, 1, 0, c->prune_arg()));
+                                  nfb, (const int *)eit, (const double *)inv, efin, 1.0, (const long *)seg + u0 + k, (int)(u1 - u0),
+                                  o_n.d + (size_t)u0 * g->C, o_f.d + (size_t)u0 * SV, 1, 0, c->prune_thr()));
                 c->t_end();
             }
             if ((rc = o_n.finish())) return rc;

@@ -22,7 +22,7 @@ void gmmiv_set_error(const char *fmt, ...);
     } while (0)
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
-       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_COUNT };
+       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_EIT, WS_INV, WS_COUNT };
 
 struct gmmiv_ctx {
     int device = 0;
@@ -43,10 +43,12 @@ struct gmmiv_ctx {
     // ~1e-60) gets a different ML mean than the reference's sum of denormal-scale terms.
     long prune_log2 = 0;
     double prune_arg() const { return prune_log2 > 0 ? -(double)prune_log2 * 0.6931471805599453 : -__builtin_inf(); }
+    double prune_thr() const { return prune_log2 > 0 ? __builtin_ldexp(1.0, -(int)prune_log2) : 0.0; } // as a posterior
     long wg_waves = 8; // waves per workgroup of the two MFMA GMM kernels (8, or 4 for A/B runs)
     // 1 (default): the log-likelihood kernel leaves the logits in HBM and the statistics kernel reads
     // them back (stats_z.hip) instead of recomputing them; 0: the recomputing k_stats_mfma
     long stats_z = 1;
+    long z_waves = 8; // waves per workgroup of k_stats_z: 8 (one workgroup per CU) or 4 (two per CU)
     // logit scratch budget (MiB): frames are processed in chunks that fit.  Sized for a 288 GB part --
     // fewer, larger launches (64 GiB = 3.4 M frames of a 2048-Gaussian model per chunk); never more
     // than half of the memory that is free when the scratch is first needed.

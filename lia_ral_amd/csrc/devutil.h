@@ -118,6 +118,18 @@ __device__ __forceinline__ int gexp_exponent(double x)
     return ((int)__builtin_rint(x * 46.16624130844683)) >> 5;
 }
 
+// all-reduce over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1): every lane gets the result
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_max_i32(int v)
+{
+    int o;
+    o = dpp_i32<0x128>(v); v = o > v ? o : v;
+    o = dpp_i32<0x124>(v); v = o > v ? o : v;
+    o = dpp_i32<0x122>(v); v = o > v ? o : v;
+    o = dpp_i32<0x121>(v); v = o > v ? o : v;
+    return v;
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);

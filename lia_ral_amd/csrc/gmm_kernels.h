@@ -38,11 +38,12 @@ int gmmk_em_fused(hipStream_t st, int KS, int sq, int x_f64, const void *x, long
                   double lse_shift, const long *seg_begin, int nseg, int nteams, int ngrp, int mode, double *out0, double *out1,
                   double *lse_out, double *slots, int n_cu, int dbg, int *query_blocks);
 
-// stats_z.hip / k_llk_mfma<WZ>: logits written once by the log-likelihood kernel, statistics from the stored logits
+// stats_z.hip / k_llk_mfma<WZ>: scaled likelihoods written once by the log-likelihood kernel, statistics from them
 int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
-               double *lse, int use_glds, double *zbuf, long nfb);
+               double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin);
 int gmmk_stats_z_groups(int nct);
-void gmmk_stats_z_set_ablation(int a);
+void gmmk_stats_z_set_waves(int w);
+int gmmk_stats_z_wg_per_cu(void);
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
-                 long nfb, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0, double *out1,
-                 int mode, int accum, double prune_arg);
+                 long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,
+                 double *out0, double *out1, int mode, int accum, double prune_thr);

@@ -87,14 +87,19 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // Frame operands stay in registers; the packed model streams through a double-buffered LDS
 // tile (2 c-tiles = 32 Gaussians per stage), by LDS-DMA when use_glds.
 // -------------------------------------------------------------------------------------------
-// WZ: also write every logit z[t][c] to zbuf for the statistics kernel that follows (stats_z.hip), in
-// the register layout of the MFMA result = A-operand layout of the statistics MFMA: 2 KB blocks
+// WZ: also leave every SCALED LIKELIHOOD e[t][c] = exp(z[t][c]) * 2^-E in zbuf for the statistics
+// kernel that follows (stats_z.hip) -- the log-sum-exp needs these exponentials anyway, so the
+// statistics kernel gets its posteriors with one multiply: gamma = e * 2^(E - Efin) / S_t.  E is the
+// running binary exponent of the frame's row at that tile pair (eit[tile pair][frame]); Efin and
+// 1 / S_t (the sum is S_t 2^Efin) are written per frame at the end.  zbuf keeps the register layout
+// of the MFMA result = A-operand layout of the statistics MFMA: 2 KB blocks
 // [Gaussian tile ct][16-frame block fb][lane][4 rows], so both sides move 32 contiguous bytes per lane.
 template <int KS, typename XT, int NW, bool WZ>
 __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ Pt, int nct,
                                                   double *__restrict__ lse_out, int use_glds, int dbg,
-                                                  double *__restrict__ zbuf, long nfb)
+                                                  double *__restrict__ zbuf, long nfb, int *__restrict__ eit,
+                                                  double *__restrict__ inv_out, int *__restrict__ efin_out)
 {
     // dbg (timing experiments only, results are wrong when != 0): 1 = no log-sum-exp epilogue,
     // 2 = additionally no per-tile staging / barrier, 3 = additionally B operands not re-read from LDS
@@ -173,20 +178,66 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
             acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
         }
-        if (WZ) { // unconditional: zbuf covers the whole grid (nfb = 16 blocks per workgroup), so the
-                  // number of stores behind this iteration's LDS-DMA is fixed (counted wait below)
-            double *zw = zbuf + ((((size_t)(tl * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
-#pragma unroll
-            for (int g = 0; g < GT; ++g)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) __builtin_nontemporal_store(acc[g][h], (d4 *)(zw + ((size_t)g * nfb + h) * 256)); // streamed: keep the model tiles in L2
-        }
         // Online log-sum-exp per (lane, frame row) with an INTEGER reference: the sum is kept as
         // sacc * 2^E.  exp(z) = t * 2^n (t in [1,2)) is added as ldexp(t, n - E); when a logit's n
         // exceeds E by 64 or more the reference moves with one ldexp (no exp, no fp64 compare
         // chain).  A pair whose n is 57 or more below the largest n seen in its row is skipped:
         // sacc * 2^E >= 2^nref already, so such a term (both of its terms together) is < 2^-54 of the sum -- skipping is bit-exact.
         // All branches are wave-uniform (ballots): every VALU instruction here is MFMA time.
+        if (WZ) {
+            // stored-likelihood variant: E is shared by the 16 lanes of a frame row (DPP row maximum
+            // of the exponents), every pair's exponential is evaluated and kept
+            int nm[2][4];
+            bool grow = false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    nm[h][r] = row_max_i32(gexp_exponent(fmax(acc[0][h][r], acc[1][h][r])));
+                    grow |= nm[h][r] - E[h][r] >= 64;
+                }
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nm[h][r] - E[h][r] >= 64) {
+                            int sh = E[h][r] - nm[h][r];
+                            sh = sh < -2000 ? -2000 : sh;
+                            sacc[h][r] = __builtin_ldexp(sacc[h][r], sh);
+                            E[h][r] = nm[h][r];
+                        }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double e0 = gexp_scaled(acc[0][h][r], E[h][r], etab), e1 = gexp_scaled(acc[1][h][r], E[h][r], etab);
+                    sacc[h][r] += e0 + e1;
+                    acc[0][h][r] = e0;
+                    acc[1][h][r] = e1;
+                }
+            // The LDS-DMA of the next tile (issued at the top of this iteration) and the stores of the
+            // previous iteration have had a whole iteration to land: wait for them HERE, before this
+            // iteration's stores are issued, so that those stay in flight across the barrier.
+            // (__syncthreads() would wait vmcnt(0) after the stores: an HBM write round trip per tile.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // unconditional stores: zbuf / eit cover the whole grid (nfb = 16 blocks per workgroup)
+            double *zw = zbuf + ((((size_t)(tl * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
+#pragma unroll
+            for (int g = 0; g < GT; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) __builtin_nontemporal_store(acc[g][h], (d4 *)(zw + ((size_t)g * nfb + h) * 256)); // streamed: keep the model tiles in L2
+            if (i16 == 0) {
+                int *ew = eit + (size_t)tl * (nfb * 16) + tb + q;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ew[h * 16 + 4 * r] = E[h][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            continue;
+        }
         int nm[2][4];
         bool grow = false;
 #pragma unroll
@@ -230,15 +281,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     if (need & (1u << (h * 4 + r)))
                         sacc[h][r] += gexp_scaled(acc[0][h][r], E[h][r], etab) + gexp_scaled(acc[1][h][r], E[h][r], etab);
         }
-        if (WZ && NW == 8) {
-            // __syncthreads() would wait vmcnt(0) (an LDS-DMA is pending) and with it drain this
-            // iteration's 8 logit stores -- a full HBM write round trip per tile.  VMEM operations of
-            // a wave retire in issue order on gfx9-family parts, so vmcnt(8) retires the LDS-DMA of
-            // the next tile (issued before the stores) and leaves the stores in flight.
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
-            __syncthreads();
-        }
+        __syncthreads();
     }
     // combine the 16 lanes (Gaussian columns) that share a frame row: common exponent, then sum
 #pragma unroll
@@ -254,7 +297,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) sv += shfl_xor_f64(sv, o);
             const long t = tb + h * 16 + q + 4 * r;
-            if (i16 == 0 && t < T) lse_out[t] = log(sv) + (double)Em * 0.693147180559945309417;
+            if (i16 == 0 && t < T) {
+                lse_out[t] = log(sv) + (double)Em * 0.693147180559945309417;
+                if (WZ) { inv_out[t] = 1.0 / sv; efin_out[t] = Em; }
+            }
         }
 }
 
@@ -749,7 +795,8 @@ int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, con
 
 template <int KS, typename XT, int NW, bool WZ>
 static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, const double *Pt, int nct,
-                      double *lse, int use_glds, double *zbuf = nullptr, long nfb = 0)
+                      double *lse, int use_glds, double *zbuf = nullptr, long nfb = 0, int *eit = nullptr, double *inv = nullptr,
+                      int *efin = nullptr)
 {
     constexpr int NR = 2 * KS + 2;
     const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + 32 * sizeof(double);
@@ -759,7 +806,7 @@ static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, co
         attr_set = true;
     }
     const unsigned grid = (unsigned)((T + NW * 32 - 1) / (NW * 32));
-    k_llk_mfma<KS, XT, NW, WZ><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb);
+    k_llk_mfma<KS, XT, NW, WZ><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb, eit, inv, efin);
     return (int)hipGetLastError();
 }
 
@@ -783,16 +830,17 @@ int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx,
     return -1;
 }
 
-// the same kernel, additionally writing the logits of frames [0, T) to zbuf (nct * nfb blocks of 2 KB,
-// nfb = 16 * ceil(T / 256): whole workgroups are written); 8-wave workgroups
+// the same kernel, additionally leaving the scaled likelihoods of frames [0, T) in zbuf (nct * nfb
+// blocks of 2 KB, nfb = 16 * ceil(T / 256): whole workgroups are written), the running exponents in
+// eit[(nct / 2) * nfb * 16] and 1 / S_t, Efin per frame in inv[T], efin[T]; 8-wave workgroups
 int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
-               double *lse, int use_glds, double *zbuf, long nfb)
+               double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin)
 {
     if (T <= 0) return 0;
-#define CASE(K)                                                                                                   \
-    case K:                                                                                                       \
-        return x_f64 ? launch_llk<K, double, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb)        \
-                     : launch_llk<K, float, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb);
+#define CASE(K)                                                                                                              \
+    case K:                                                                                                                  \
+        return x_f64 ? launch_llk<K, double, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin)   \
+                     : launch_llk<K, float, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin);
     switch (KS) {
         CASE(4) CASE(8) CASE(15)
     }

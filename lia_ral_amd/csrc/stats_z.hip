@@ -1,28 +1,39 @@
-// stats_z.hip -- posterior statistics from STORED logits.
+// stats_z.hip -- posterior statistics from STORED scaled likelihoods.
 //
-// k_llk_mfma (WZ) evaluates every frame x Gaussian logit once and leaves it in HBM (fp64, in the
-// MFMA register layout); this kernel streams the logits back, turns them into posteriors
-// gamma = exp(z - lse_t) and runs only the statistics MFMAs.  The two-kernel path that recomputes the
-// logits in the statistics kernel issues 31 + (31 + 32) fp64 MFMAs per 16 frames x 16 Gaussians, this
-// one 31 + 32 -- the MFMA pipe is the bound (MI355X_MICROARCH: 78.6 TFLOP/s fp64), HBM is not: the
-// logit stream is 2 KB per 32 MFMAs = 1 byte per cycle per SIMD (~2.4 TB/s at full MFMA rate).
+// k_llk_mfma (WZ) evaluates every frame x Gaussian logit once; its log-sum-exp needs
+// e = exp(z) 2^-E of every pair anyway, and it leaves those in HBM (fp64, in the MFMA register
+// layout) together with the running exponent E of each (frame, tile pair) and, per frame, the final
+// exponent Efin and 1 / S_t (sum_c exp(z_tc) = S_t 2^Efin).  This kernel streams them back, forms the
+// posterior with ONE multiply, gamma = e * [2^(E - Efin) / S_t], and runs only the statistics MFMAs.
+// The path that recomputes the logits in the statistics kernel issues 31 + (31 + 32) fp64 MFMAs per
+// 16 frames x 16 Gaussians and two exponentials per pair; this one 31 + 32 MFMAs and one exponential.
+// The MFMA pipe is the bound (MI355X_MICROARCH: 78.6 TFLOP/s fp64), HBM is not: the stream is 2 KB
+// per 32 MFMAs = 1 byte per cycle per SIMD (~2.4 TB/s at full MFMA rate).
 //
-// Workgroup = 8 waves; wave w owns TWO Gaussian tiles (32 Gaussians), so every x operand read from
-// LDS (and every x^2) feeds 4 MFMAs.  Frames stream through the same rotated LDS tile as
-// k_stats_mfma (64 rows [x_0..x_{D-1}, 0.., 1, lse_t, 0..], double buffered, register staged).
+// Workgroup = 8 waves; wave w owns TWO Gaussian tiles (32 Gaussians = one tile pair of k_llk_mfma), so
+// every x operand read from LDS (and every x^2) feeds 4 MFMAs.  Frames stream through the same rotated
+// LDS tile as k_stats_mfma (64 rows [x_0..x_{D-1}, 0.., 1, scale / S_t, Efin, 0..], double buffered,
+// register staged).
 //   mode 0 (EM):  out0[seg][c][2 RL] partial sums (cols: x | x^2 halves; col Dp = occupancy);
 //                 accum != 0 adds to what is there (frame chunks processed by successive launches)
 //   mode 1 (TV):  N = out0[seg][C], F = out1[seg][C*D] written directly
-// Segment bounds are frame indices relative to x / lse / zbuf block 0; a segment may start anywhere:
-// its first tile starts at the 16-frame block holding f0 and rows before f0 are masked (lse = 1e300).
+// Segment bounds are frame indices relative to x / inv / efin / zbuf block 0; a segment may start
+// anywhere: its first tile starts at the 16-frame block holding f0 and rows before f0 are masked
+// (1 / S_t = 0).
 #include "devutil.h"
 #include "gmm_kernels.h"
 
-// ABL (timing experiments only, wrong results): 1 = no exp, 2 = no logit loads, 3 = no staging / barrier per tile
-template <int KS, bool SQ, typename XT, bool PRUNE, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void k_stats_z(const void *__restrict__ x, long ldx, int D, int C, int nct,
-                                                    const double *__restrict__ zbuf, long nfb,
-                                                    const double *__restrict__ lse, double lse_shift,
+// NW = 8: one 8-wave workgroup per CU, 64-frame tiles; NW = 4: two independent 4-wave workgroups per
+// CU with 32-frame tiles (their barriers and staging phases drift apart).
+// Shapes (NW waves, TPW Gaussian tiles per wave, FT frames per LDS tile):
+//   <8, 2, 64>   one workgroup per CU, 2 waves per SIMD, 256 VGPRs (default)
+//   <4, 2, 32>   two independent workgroups per CU
+//   <16, 1, 64>  one workgroup per CU, 4 waves per SIMD at 128 VGPRs: more waves to cover a stalled one,
+//                half the operand reuse (every x operand feeds 2 MFMAs)
+template <int KS, bool SQ, typename XT, bool PRUNE, int NW = 8, int TPW = 2, int FT = 64>
+__global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const void *__restrict__ x, long ldx, int D, int C, int nct,
+                                                    const double *__restrict__ zbuf, long nfb, const int *__restrict__ eit,
+                                                    const double *__restrict__ inv, const int *__restrict__ efin, double scale,
                                                     const long *__restrict__ seg_begin, int nseg, int ngrp,
                                                     double *__restrict__ out0, double *__restrict__ out1, int mode, int accum,
                                                     unsigned magicD, double prune_arg)
@@ -30,15 +41,13 @@ __global__ __launch_bounds__(512, 2) void k_stats_z(const void *__restrict__ x, 
     constexpr int Dp = 4 * KS;
     constexpr int RL = ((Dp + 2 + 31) / 32) * 32;
     constexpr int JT = RL / 16;
-    constexpr int FT = 64;
-    constexpr int NT = 512;
+    constexpr int NT = NW * 64;
+    constexpr int BPT = FT / 16; // logit blocks per frame tile
     constexpr int NLD = (FT * Dp + NT - 1) / NT;
     constexpr int RLp = RL + 32; // padded row: additive rotation xrot(t) < 32
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *buf0 = (double *)smem;
     double *buf1 = buf0 + FT * RLp;
-    double *etab = buf1 + FT * RLp; // 64-entry exp table
-    gexp_table64_init(etab, threadIdx.x);
 
     // XCD-aware decode (see k_stats_mfma): all Gaussian groups of one segment share an XCD
     const int b = blockIdx.x;
@@ -50,130 +59,171 @@ __global__ __launch_bounds__(512, 2) void k_stats_z(const void *__restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
-    const int ct0 = (grp * 8 + wave) * 2; // nct is even (host pads the packed model to pairs of tiles)
+    const int ct0 = (grp * NW + wave) * TPW; // nct is even (host pads the packed model to pairs of tiles)
     const bool active = ct0 < nct;
 
     const long f0 = seg_begin[seg], f1 = seg_begin[seg + 1];
     const long fa = f0 & ~15L;                                  // first tile starts on a logit block
     const int nblk = f1 > f0 ? (int)((f1 - fa + 15) >> 4) : 0;  // 16-frame blocks
-    const int ntiles = (nblk + 3) >> 2;
+    const int ntiles = (nblk + BPT - 1) / BPT;
 
-    d4 S[2][JT], S2[2][SQ ? JT : 1];
+    d4 S[TPW][JT], S2[TPW][SQ ? JT : 1];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TPW; ++t) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) S[t][j] = (d4){0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < (SQ ? JT : 1); ++j) S2[t][j] = (d4){0, 0, 0, 0};
     }
 
-    // staging plan (see k_stats_mfma)
+    // ---- vector memory: nothing in flight across the loop back-edge --------------------------------
+    // hipcc (ROCm 7.2) keeps exact vmcnt counts only inside straight-line code: a load that is issued
+    // in one iteration of the tile loop and consumed in the next makes it wait vmcnt(0..3) at the top
+    // of every block -- for the prefetch it has just issued (measured: -15 % on this kernel).  So the
+    // per-block operands that used to come from global memory (the running exponents) are staged
+    // through LDS with the frame tile, and the one prefetch that spans the back-edge (the first
+    // likelihood block of the next tile) is pinned at the END of the tile: it was issued a whole block
+    // earlier, so the wait is free, and the loop head sees an empty VMEM queue.
+    typedef double d2 __attribute__((ext_vector_type(2)));
     XT stg[NLD];
-    double stg_lse = 0.0;
+    double stg_inv = 0.0;
+    int stg_ef = 0, stg_e = 0;
     const int npad = FT * (RL - D);
-    unsigned pk[NLD];
+    unsigned pk[NLD], goff[NLD];
     const bool contig = (ldx == D);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + NT * i;
         const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
         pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
+        goff[i] = fr < FT ? (contig ? (unsigned)e : (unsigned)(fr * (int)ldx + d)) : 0u;
     }
-    auto load_tile = [&](int tl) {
+    int *etile = (int *)(buf1 + FT * RLp); // [2][NW][FT] running exponents of the wave's tile pair
+    const int *epair = eit + (size_t)(active ? ct0 >> 1 : 0) * (nfb * 16) + fa;
+    const int srow = tid & (FT - 1);
+    auto issue_stage = [&](int tl) { // exactly SL loads
         const long fb = fa + (long)tl * FT;
         const long rem = f1 - fb;
         const unsigned lim = rem >= FT ? (unsigned)FT << 16 : (unsigned)rem << 16; // rows fr < lim >> 16 exist
         const XT *xt = (const XT *)x + fb * ldx;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            XT v = 0;
-            if (pk[i] < lim) {
-                if (contig) v = xt[tid + NT * i];
-                else { const unsigned fr = pk[i] >> 16; v = xt[(long)fr * ldx + (tid + NT * i - (int)fr * D)]; }
-            }
-            stg[i] = v;
+            stg[i] = xt[pk[i] < lim ? goff[i] : 0u]; // unconditional (clamped, masked at use): no branch per element
         }
-        // rows outside [f0, f1) get lse = +1e300 -> posterior exp(z - lse) = 0
-        if (tid < FT) { const long t = fb + tid; stg_lse = (t >= f0 && t < f1) ? lse[t] + lse_shift : 1.0e300; }
+        const long t = fb + srow < f1 ? fb + srow : f1 - 1;
+        stg_inv = inv[t];
+        stg_ef = efin[t];
+        stg_e = epair[(long)tl * FT + (lane & (FT - 1))];
     };
-    auto write_tile = [&](double *dst) {
+    auto finish_stage = [&](double *dst, int buf, int tl) {
+        const long fb = fa + (long)tl * FT;
+        const long rem = f1 - fb;
+        const unsigned lim = rem >= FT ? (unsigned)FT << 16 : (unsigned)rem << 16;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = (double)stg[i];
-        if (tid < FT) dst[tid * RLp + xrot(tid) + Dp + 1] = stg_lse;
+            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = pk[i] < lim ? (double)stg[i] : 0.0;
+        if (tid < FT) { // rows outside [f0, f1) get 1 / S_t = 0 -> posterior 0
+            const long t = fb + tid;
+            dst[tid * RLp + xrot(tid) + Dp + 1] = (t >= f0 && t < f1) ? stg_inv * scale : 0.0;
+            *(int *)(dst + tid * RLp + xrot(tid) + Dp + 2) = stg_ef; // RL >= Dp + 3 for every KS instantiated
+        }
+        if (lane < FT) etile[(buf * NW + wave) * FT + lane] = stg_e;
     };
-    // pad columns (1.0 at Dp, zeros elsewhere; Dp + 1 is the lse column) never change: written once
+    // pad columns (1.0 at Dp, zeros elsewhere; Dp + 1, Dp + 2 carry 1 / S_t and Efin) never change: written once
     for (int e = tid; e < 2 * npad; e += NT) {
         double *dst = e < npad ? buf0 : buf1;
         const int ee = e < npad ? e : e - npad;
         const int fr = ee / (RL - D), d = D + (ee - fr * (RL - D));
-        if (d != Dp + 1) dst[fr * RLp + xrot(fr) + d] = (d == Dp) ? 1.0 : 0.0;
+        if (d != Dp + 1 && d != Dp + 2) dst[fr * RLp + xrot(fr) + d] = (d == Dp) ? 1.0 : 0.0;
     }
 
-    // per-lane LDS offsets (doubles): statistics B operand (row q, col i16) and the lse column of row q
+    // per-lane LDS offsets (doubles): statistics B operand (row q, col i16) and the 1 / S_t column of row q
     const int offS = q * RLp + ((q & 1) << 4) + ((q >> 1) << 1) + i16;
     const int offE = q * RLp + ((q & 1) << 4) + ((q >> 1) << 1) + Dp + 1;
 
-    // logit stream: block n of tile t is 2 KB at zp[t] + n * 256 doubles, 32 bytes per lane
-    const double *zp[2];
+    // likelihood stream: block n of tile t is 2 KB at zp[t] + n * 256 doubles, 32 bytes per lane.
+    // Two register sets, alternating between even and odd blocks (the tile loop is unrolled).
+    const double *zp[TPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) zp[t] = zbuf + ((((size_t)(active ? ct0 + t : 0)) * nfb + (fa >> 4)) * 64 + lane) * 4;
-    // two register sets, alternating between even and odd blocks (the tile loop is unrolled by 4)
-    d4 zA[2], zB[2];
-    zA[0] = (d4){0, 0, 0, 0}; zA[1] = zA[0]; zB[0] = zA[0]; zB[1] = zA[0];
-    if (active && nblk > 0) { zA[0] = __builtin_nontemporal_load((const d4 *)zp[0]); zA[1] = __builtin_nontemporal_load((const d4 *)zp[1]); }
+    for (int t = 0; t < TPW; ++t) zp[t] = zbuf + ((((size_t)(active ? ct0 + t : 0)) * nfb + (fa >> 4)) * 64 + lane) * 4;
+    d2 zA[TPW][2], zB[TPW][2];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) { zA[t][0] = (d2){0, 0}; zA[t][1] = zA[t][0]; zB[t][0] = zA[t][0]; zB[t][1] = zA[t][0]; }
+    auto issue_z = [&](d2 (&z)[TPW][2], int n) { // streamed once, kept out of the caches (nt)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const d2 *pz = (const d2 *)(zp[t] + (size_t)n * 256);
+            z[t][0] = __builtin_nontemporal_load(pz);
+            z[t][1] = __builtin_nontemporal_load(pz + 1);
+        }
+    };
+    // "this value is needed now": the compiler places the (exactly counted) wait for its load here
+    static_assert(TPW <= 2, "operand list of PIN_Z");
+#define PIN_Z(z)                                                                                              \
+    do {                                                                                                      \
+        if constexpr (TPW == 1) asm volatile("" : "+v"(z[0][0]), "+v"(z[0][1]));                             \
+        else asm volatile("" : "+v"(z[0][0]), "+v"(z[0][1]), "+v"(z[TPW - 1][0]), "+v"(z[TPW - 1][1]));     \
+    } while (0)
 
     if (ntiles > 0) {
-        load_tile(0);
-        write_tile(buf0);
+        issue_stage(0);
+        if (active) issue_z(zA, 0);
+        finish_stage(buf0, 0, 0);
+        PIN_Z(zA);
     }
     __syncthreads();
     for (int tl = 0; tl < ntiles; ++tl) {
         const double *cur = (tl & 1) ? buf1 : buf0;
         double *nxt = (tl & 1) ? buf0 : buf1;
-        if (ABL == 3) { cur = buf0; nxt = buf1; }
-        if (tl + 1 < ntiles && ABL != 3) load_tile(tl + 1);
+        const bool staged = tl + 1 < ntiles;
+        if (staged) issue_stage(tl + 1);
         if (active) {
             const double *pS = cur + offS, *pE = cur + offE;
-            auto block = [&](int fs, const d4 (&zc)[2], d4 (&zn)[2]) {
-                const int n = tl * 4 + fs;
-                if (n + 1 < nblk && ABL != 2) { // logits of the next block: streamed once, keep them out of the caches
-                    zn[0] = __builtin_nontemporal_load((const d4 *)(zp[0] + (size_t)(n + 1) * 256));
-                    zn[1] = __builtin_nontemporal_load((const d4 *)(zp[1] + (size_t)(n + 1) * 256));
-                }
+            const int *pX = etile + ((tl & 1) * NW + wave) * FT + q;
+            auto block = [&](int fs, d2 (&zc)[TPW][2], d2 (&zn)[TPW][2], bool always) {
+                const int n = tl * BPT + fs;
+                if (always || n + 1 < nblk) issue_z(zn, n + 1);
                 // register r holds rows (frames) fs*16 + 4r + q of 16 Gaussians: already the A operand
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double le = pE[(fs * 16 + 4 * r) * RLp + 4 * r];
-                    const double a0 = zc[0][r] - le, a1 = zc[1][r] - le;
-                    if (PRUNE && __builtin_amdgcn_ballot_w64(a0 > prune_arg || a1 > prune_arg) == 0) continue;
-                    const double g0 = ABL == 1 ? a0 : gexp_t64(a0, etab), g1 = ABL == 1 ? a1 : gexp_t64(a1, etab);
+                    const double iv_t = pE[(fs * 16 + 4 * r) * RLp + 4 * r];
+                    const int ef = *(const int *)(pE + (fs * 16 + 4 * r) * RLp + 4 * r + 1);
+                    const double f = __builtin_ldexp(iv_t, pX[fs * 16 + 4 * r] - ef); // 2^(E - Efin) / S_t (x EM weight)
+                    double gm[TPW];
+                    bool keep = false;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) { gm[t] = zc[t][r >> 1][r & 1] * f; keep |= gm[t] > prune_arg; }
+                    if (PRUNE && __builtin_amdgcn_ballot_w64(keep) == 0) continue;
 #pragma unroll
                     for (int j = 0; j < JT; ++j) {
                         const double bv = pS[(fs * 16 + 4 * r) * RLp + 4 * r + 16 * j];
-                        S[0][j] = MFMA_F64(g0, bv, S[0][j]);
-                        S[1][j] = MFMA_F64(g1, bv, S[1][j]);
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t) S[t][j] = MFMA_F64(gm[t], bv, S[t][j]);
                         if (SQ) {
                             const double b2 = bv * bv;
-                            S2[0][j] = MFMA_F64(g0, b2, S2[0][j]);
-                            S2[1][j] = MFMA_F64(g1, b2, S2[1][j]);
+#pragma unroll
+                            for (int t = 0; t < TPW; ++t) S2[t][j] = MFMA_F64(gm[t], b2, S2[t][j]);
                         }
                     }
                 }
             };
-            const int nb = nblk - tl * 4; // blocks of this tile that exist (wave-uniform)
-            block(0, zA, zB);
-            if (nb > 1) block(1, zB, zA);
-            if (nb > 2) block(2, zA, zB);
-            if (nb > 3) block(3, zB, zA);
+            const int nb = nblk - tl * BPT; // blocks of this tile that exist (wave-uniform)
+            block(0, zA, zB, false);
+            if (nb > 1) block(1, zB, zA, false);
+            if (BPT > 2) {
+                if (nb > 2) block(2, zA, zB, false);
+                if (nb > 3) block(3, zB, zA, false);
+            }
+            PIN_Z(zA); // the next tile's first block (issued by the last block above) has landed
         }
-        if (tl + 1 < ntiles && ABL != 3) write_tile(nxt);
-        if (ABL != 3) __syncthreads();
+        if (staged) finish_stage(nxt, (tl + 1) & 1, tl + 1);
+        __syncthreads();
     }
+#undef PIN_Z
     if (!active) return;
     // D layout: lane holds column j = 16 jt + i16, rows (Gaussians) q + 4 r
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         const int ct = ct0 + t;
         if (mode == 0) {
             const size_t Cp = (size_t)nct * 16;
@@ -212,49 +262,50 @@ __global__ __launch_bounds__(512, 2) void k_stats_z(const void *__restrict__ x, 
         if (_e != hipSuccess) return (int)_e;                             \
     } while (0)
 
-static int g_stats_z_abl = 0;
-void gmmk_stats_z_set_ablation(int a) { g_stats_z_abl = a; }
+static int g_stats_z_waves = 8;
+void gmmk_stats_z_set_waves(int w) { g_stats_z_waves = (w == 4 || w == 16) ? w : 8; }
+// Gaussian tiles per workgroup: 16 for <8,2> and <16,1>, 8 for <4,2>
+int gmmk_stats_z_groups(int nct) { const int tpg = g_stats_z_waves == 4 ? 8 : 16; return (nct + tpg - 1) / tpg; }
+int gmmk_stats_z_wg_per_cu(void) { return g_stats_z_waves == 4 ? 2 : 1; }
 
-template <int KS, bool SQ, typename XT, bool PRUNE, int ABL = 0>
-static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int nct, const double *zbuf, long nfb, const double *lse,
-                    double lse_shift, const long *seg_begin, int nseg, double *out0, double *out1, int mode, int accum,
-                    double prune_arg)
+template <int KS, bool SQ, typename XT, bool PRUNE, int NW, int TPW, int FT>
+static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int nct, const double *zbuf, long nfb, const int *eit,
+                    const double *inv, const int *efin, double scale, const long *seg_begin, int nseg, double *out0, double *out1,
+                    int mode, int accum, double prune_thr)
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
-    const size_t lds = (2 * 64 * (RL + 32) + 64) * sizeof(double); // two frame tiles + the 64-entry exp table
+    static_assert(RL >= 4 * KS + 3, "the frame tile needs columns Dp + 1 and Dp + 2");
+    const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * FT * sizeof(int); // two frame tiles + exponents
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int ngrp = gmmk_stats_z_groups(nct);
+    const int ngrp = (nct + TPW * NW - 1) / (TPW * NW);
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
     const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);
-    k_stats_z<KS, SQ, XT, PRUNE, ABL><<<grid, 512, lds, st>>>(x, ldx, D, C, nct, zbuf, nfb, lse, lse_shift, seg_begin, nseg, ngrp, out0, out1,
-                                                          mode, accum, magicD, prune_arg);
+    k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT><<<grid, NW * 64, lds, st>>>(x, ldx, D, C, nct, zbuf, nfb, eit, inv, efin, scale, seg_begin, nseg, ngrp,
+                                                              out0, out1, mode, accum, magicD, prune_thr);
     return (int)hipGetLastError();
 }
 
-int gmmk_stats_z_groups(int nct) { return (nct + 15) / 16; }
-
-#define ZARGS st, x, ldx, D, C, nct, zbuf, nfb, lse, lse_shift, seg_begin, nseg, out0, out1, mode, accum, prune_arg
+#define ZARGS st, x, ldx, D, C, nct, zbuf, nfb, eit, inv, efin, scale, seg_begin, nseg, out0, out1, mode, accum, prune_thr
 template <int KS, bool SQ, typename XT>
-static int launch_z_p(hipStream_t st, const void *x, long ldx, int D, int C, int nct, const double *zbuf, long nfb, const double *lse,
-                      double lse_shift, const long *seg_begin, int nseg, double *out0, double *out1, int mode, int accum,
-                      double prune_arg)
+static int launch_z_p(hipStream_t st, const void *x, long ldx, int D, int C, int nct, const double *zbuf, long nfb, const int *eit,
+                      const double *inv, const int *efin, double scale, const long *seg_begin, int nseg, double *out0, double *out1,
+                      int mode, int accum, double prune_thr)
 {
-    if (prune_arg > -1.0e300) return launch_z<KS, SQ, XT, true>(ZARGS);
-    if (KS == 15 && SQ && sizeof(XT) == 4 && g_stats_z_abl) { // ablation builds exist for the bench shape only
-        if (g_stats_z_abl == 1) return launch_z<15, true, float, false, 1>(ZARGS);
-        if (g_stats_z_abl == 2) return launch_z<15, true, float, false, 2>(ZARGS);
-        if (g_stats_z_abl == 3) return launch_z<15, true, float, false, 3>(ZARGS);
-    }
-    return launch_z<KS, SQ, XT, false>(ZARGS);
+    if (prune_thr > 0.0) return launch_z<KS, SQ, XT, true, 8, 2, 64>(ZARGS);
+    if (g_stats_z_waves == 4) return launch_z<KS, SQ, XT, false, 4, 2, 32>(ZARGS);
+    if (g_stats_z_waves == 16) return launch_z<KS, SQ, XT, false, 16, 1, 64>(ZARGS);
+    return launch_z<KS, SQ, XT, false, 8, 2, 64>(ZARGS);
 }
 
+// scale multiplies every posterior (the EM frame weight); prune_thr > 0: groups of 4 frames x 32
+// Gaussians whose posteriors are all below prune_thr are skipped (opt-in, see ctx.h)
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
-                 long nfb, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0, double *out1,
-                 int mode, int accum, double prune_arg)
+                 long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,
+                 double *out0, double *out1, int mode, int accum, double prune_thr)
 {
     if (nseg <= 0) return 0;
 #define CASE(K)                                                                                      \

@@ -155,6 +155,72 @@ __global__ __launch_bounds__(256) void k_mfma_valu32(double *out, int iters, dou
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The statistics-kernel inner loop in isolation: 16 accumulators (4 x [S0 S1 S2_0 S2_1]), per "row" r
+// 4 B operands, each feeding 4 MFMAs.  MODE 0: B operands stay in registers; 1: every B operand is a
+// fresh ds_read_b64; 2: additionally b2 = b * b on the VALU; 3: additionally the A operand is a
+// fresh VALU product; 4: additionally the A operands stream from global memory (2 x 32 B per lane and
+// 16-frame block, prefetched one block ahead, like k_stats_z); 5: additionally a __syncthreads() and a
+// register-staged LDS tile write per 4 blocks.  One 8-wave workgroup per CU like k_stats_z.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_lds_mfma(double *out, int iters, double seed, const double *stream)
+{
+    __shared__ double tile[2][64 * 96];
+    for (int i = threadIdx.x; i < 2 * 64 * 96; i += 512) tile[0][i] = seed * (1 + (i & 7));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i16 = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    d4 S[2][4], S2[2][4];
+    for (int t = 0; t < 2; ++t)
+        for (int j = 0; j < 4; ++j) { S[t][j] = (d4){seed, seed, seed, seed}; S2[t][j] = S[t][j]; }
+    double g0 = seed + lane * 1e-9, g1 = seed * 0.5, f = 1.0 + seed;
+    double breg[4] = {seed, seed * 2, seed * 3, seed * 4};
+    // wave-private stream: iters * 4 blocks of 2 x 2 KB
+    const double *zp = stream + ((size_t)(blockIdx.x * 8 + wave) * iters * 4 * 2 * 64 + lane) * 4;
+    d4 zn0 = (d4){seed, seed, seed, seed}, zn1 = zn0;
+    if (MODE >= 4) { zn0 = __builtin_nontemporal_load((const d4 *)zp); zn1 = __builtin_nontemporal_load((const d4 *)(zp + 256)); }
+    float stg[8];
+    for (int it = 0; it < iters; ++it) {
+        const double *pS = tile[it & 1] + q * 96 + ((q & 1) << 4) + ((q >> 1) << 1) + i16;
+        if (MODE >= 5)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stg[i] = ((const float *)stream)[(size_t)(blockIdx.x * iters + it) * 4096 + threadIdx.x + 512 * i];
+#pragma unroll
+        for (int fs = 0; fs < 4; ++fs) {
+            d4 zc0 = zn0, zc1 = zn1;
+            if (MODE >= 4) {
+                const size_t n = (size_t)it * 4 + fs + 1;
+                if (n < (size_t)iters * 4) {
+                    zn0 = __builtin_nontemporal_load((const d4 *)(zp + n * 512));
+                    zn1 = __builtin_nontemporal_load((const d4 *)(zp + n * 512 + 256));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double a0 = g0, a1 = g1;
+                if (MODE == 3) { a0 = g0 * f; a1 = g1 * f; g0 = a1; g1 = a0; }
+                if (MODE >= 4) { a0 = zc0[r] * f; a1 = zc1[r] * f; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double bv = MODE >= 1 ? pS[(fs * 16 + 4 * r) * 96 + 4 * r + 16 * j] : breg[j];
+                    S[0][j] = MFMA_F64(a0, bv, S[0][j]);
+                    S[1][j] = MFMA_F64(a1, bv, S[1][j]);
+                    const double b2 = MODE >= 2 ? bv * bv : bv;
+                    S2[0][j] = MFMA_F64(a0, b2, S2[0][j]);
+                    S2[1][j] = MFMA_F64(a1, b2, S2[1][j]);
+                }
+            }
+        }
+        if (MODE >= 5) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tile[(it + 1) & 1][(threadIdx.x + 512 * i) % (64 * 96)] = (double)stg[i];
+            __syncthreads();
+        } else if (MODE >= 1) asm volatile("" ::: "memory"); // keep the LDS reads inside the loop
+    }
+    double s = g0 + g1;
+    for (int t = 0; t < 2; ++t)
+        for (int j = 0; j < 4; ++j) s += S[t][j][0] + S[t][j][1] + S[t][j][2] + S[t][j][3] + S2[t][j][0] + S2[t][j][1] + S2[t][j][2] + S2[t][j][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F> static float time_ms(F f)
 {
     hipEvent_t e0, e1;
@@ -248,6 +314,24 @@ int main()
             printf("MFMA f64 (asm, VGPR acc) %d wave(s)/SIMD: 1 acc %.1f TF | 2 acc %.1f TF | 4 acc %.1f TF | 8 acc %.1f TF\n", wps,
                    fl * 1 / t1 / 1e9, fl * 2 / t2 / 1e9, fl * 4 / t4 / 1e9, fl * 8 / t8 / 1e9);
         }
+    }
+    {
+        const int it2 = 400, nblk = p.multiProcessorCount;
+        auto tf = [&](float ms) { return (double)nblk * 8 * it2 * 256.0 * 2048.0 / ms / 1e9; };
+        double *stream = nullptr;
+        const size_t sbytes = (size_t)nblk * 8 * it2 * 4 * 4096 + (1 << 20);
+        if (hipMalloc(&stream, sbytes) != hipSuccess) { printf("stream alloc failed\n"); return 1; }
+        hipMemset(stream, 0, sbytes);
+        float t0 = time_ms([&] { k_lds_mfma<0><<<nblk, 512>>>(out, it2, 1e-3, stream); });
+        float t1 = time_ms([&] { k_lds_mfma<1><<<nblk, 512>>>(out, it2, 1e-3, stream); });
+        float t2 = time_ms([&] { k_lds_mfma<2><<<nblk, 512>>>(out, it2, 1e-3, stream); });
+        float t3 = time_ms([&] { k_lds_mfma<3><<<nblk, 512>>>(out, it2, 1e-3, stream); });
+        float t4 = time_ms([&] { k_lds_mfma<4><<<nblk, 512>>>(out, it2, 1e-3, stream); });
+        float t5 = time_ms([&] { k_lds_mfma<5><<<nblk, 512>>>(out, it2, 1e-3, stream); });
+        printf("statistics inner loop (8 waves/CU, 16 accumulators): regs only %.1f TF | + ds_read B %.1f TF | + b*b %.1f TF | + A product %.1f TF"
+               " | + A streamed from HBM (%.1f GB) %.1f TF | + staged tile and barrier per 4 blocks %.1f TF\n",
+               tf(t0), tf(t1), tf(t2), tf(t3), sbytes / 1e9, tf(t4), tf(t5));
+        hipFree(stream);
     }
     return 0;
 }
