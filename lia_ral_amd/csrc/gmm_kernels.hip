@@ -155,29 +155,32 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sacc[h][r] = 0.0; E[h][r] = -(1 << 30); nref[h][r] = -(1 << 30); }
 
-    stage(buf0, 0);
-    __syncthreads();
-    for (int tl = 0; tl < ntiles; ++tl) {
-        double *cur = (tl & 1) ? buf1 : buf0;
-        double *nxt = (tl & 1) ? buf0 : buf1;
-        if (tl + 1 < ntiles && dbg < 2) stage(nxt, tl + 1);
-
-        d4 acc[GT][2];
+    // The two waves that share a SIMD (w and w + 4 of an 8-wave workgroup) run the two phases of a
+    // tile in opposite order: waves 0..3 do the logit MFMAs of tile tl and then its log-sum-exp
+    // epilogue, waves 4..7 first do the epilogue of the PREVIOUS tile (their accumulators are still in
+    // registers) and then the MFMAs of tile tl.  Between two barriers every SIMD therefore has one wave
+    // in its MFMA phase while the other is in its VALU phase: VALU work of a different wave overlaps
+    // the fp64 MFMA pipe partially (tools/mfma_probe), work of the same wave never does.
+    const bool late = NW == 8 && ((wave >> 1) & 1);
+    d4 acc[GT][2];
+    auto mfma_phase = [&](const double *cur) {
 #pragma unroll
-        for (int g = 0; g < GT; ++g) {
-            const double a = cur[(g * NR + 2 * KS) * 64 + lane];
-            acc[g][0] = (d4){a, a, a, a};
-            acc[g][1] = acc[g][0];
-        }
+    for (int g = 0; g < GT; ++g) {
+        const double a = cur[(g * NR + 2 * KS) * 64 + lane];
+        acc[g][0] = (d4){a, a, a, a};
+        acc[g][1] = acc[g][0];
+    }
 #pragma unroll
-        for (int s = 0; s < 2 * KS; ++s) {
-            const double b0 = cur[(0 * NR + s) * 64 + lane];
-            const double b1 = cur[(1 * NR + s) * 64 + lane];
-            acc[0][0] = MFMA_F64(A[0][s], b0, acc[0][0]);
-            acc[1][0] = MFMA_F64(A[0][s], b1, acc[1][0]);
-            acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
-            acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
-        }
+    for (int s = 0; s < 2 * KS; ++s) {
+        const double b0 = cur[(0 * NR + s) * 64 + lane];
+        const double b1 = cur[(1 * NR + s) * 64 + lane];
+        acc[0][0] = MFMA_F64(A[0][s], b0, acc[0][0]);
+        acc[1][0] = MFMA_F64(A[0][s], b1, acc[1][0]);
+        acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
+        acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
+    }
+    };
+    auto epi_phase = [&](int te) {
         // Online log-sum-exp per (lane, frame row) with an INTEGER reference: the sum is kept as
         // sacc * 2^E.  exp(z) = t * 2^n (t in [1,2)) is added as ldexp(t, n - E); when a logit's n
         // exceeds E by 64 or more the reference moves with one ldexp (no exp, no fp64 compare
@@ -221,22 +224,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             // previous iteration have had a whole iteration to land: wait for them HERE, before this
             // iteration's stores are issued, so that those stay in flight across the barrier.
             // (__syncthreads() would wait vmcnt(0) after the stores: an HBM write round trip per tile.)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // unconditional stores: zbuf / eit cover the whole grid (nfb = 16 blocks per workgroup)
-            double *zw = zbuf + ((((size_t)(tl * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
+            double *zw = zbuf + ((((size_t)(te * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
 #pragma unroll
             for (int g = 0; g < GT; ++g)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) __builtin_nontemporal_store(acc[g][h], (d4 *)(zw + ((size_t)g * nfb + h) * 256)); // streamed: keep the model tiles in L2
             if (i16 == 0) {
-                int *ew = eit + (size_t)tl * (nfb * 16) + tb + q;
+                int *ew = eit + (size_t)te * (nfb * 16) + tb + q;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ew[h * 16 + 4 * r] = E[h][r];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            continue;
+            return;
         }
         int nm[2][4];
         bool grow = false;
@@ -281,8 +283,33 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     if (need & (1u << (h * 4 + r)))
                         sacc[h][r] += gexp_scaled(acc[0][h][r], E[h][r], etab) + gexp_scaled(acc[1][h][r], E[h][r], etab);
         }
-        __syncthreads();
+    };
+    stage(buf0, 0);
+    __syncthreads();
+    for (int tl = 0; tl < ntiles; ++tl) {
+        double *cur = (tl & 1) ? buf1 : buf0;
+        double *nxt = (tl & 1) ? buf0 : buf1;
+        if (tl + 1 < ntiles && dbg < 2) stage(nxt, tl + 1);
+        if (!late) {
+            mfma_phase(cur);
+            epi_phase(tl);
+        } else {
+            if (tl > 0) epi_phase(tl - 1);
+            mfma_phase(cur);
+        }
+        if (WZ) {
+            // The LDS-DMA of the next tile must have landed before the barrier; the stores of the
+            // epilogue should stay in flight across it (__syncthreads() would drain them: an HBM write
+            // round trip per tile).  Early waves wait inside their epilogue, BEFORE they issue the
+            // stores (the DMA was issued a whole MFMA phase earlier); late waves issued their stores a
+            // whole MFMA phase ago, so draining everything here costs them nothing.
+            if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
     }
+    if (late && ntiles > 0) epi_phase(ntiles - 1);
     // combine the 16 lanes (Gaussian columns) that share a frame row: common exponent, then sum
 #pragma unroll
     for (int h = 0; h < 2; ++h)
