@@ -48,7 +48,17 @@ void gmmiv_ctx_destroy(gmmiv_ctx *ctx);
 int gmmiv_ctx_sync(gmmiv_ctx *ctx);
 const char *gmmiv_last_error(void);
 const char *gmmiv_version(void);
-/* Runtime knobs for A/B measurements ("glds", "em_chunks", ...); returns previous value. */
+/* Runtime knobs; returns the previous value (-1: unknown key).
+ *   "stats_z" 1        EM / Baum-Welch statistics from stored scaled likelihoods (k_llk_mfma<WZ> + k_stats_z);
+ *                      0: the recomputing k_stats_mfma (also used for D > 60 or when the scratch does not fit)
+ *   "z_scratch_mb"     likelihood scratch budget in MiB (default 65536, at most half of the free memory):
+ *                      frames are processed in chunks that fit
+ *   "z_waves" 8        workgroup shape of k_stats_z (8, 16 or 4 waves)
+ *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
+ *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
+ *                      for dead Gaussians; off by default)
+ *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)
+ *   "glds", "wg_waves", "em_chunks", "dbg": A/B switches of the measurement tools */
 long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);
 /* Duration (ms, HIP events on the context's stream) of the last call's dominant kernel. */
 double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *ctx, const char **kernel_name);
