@@ -115,6 +115,12 @@ int gmmiv_llk_use_top(gmmiv_ctx *ctx, const gmmiv_gmm *client, const void *x, in
                       int64_t ldx, int ctop, const int32_t *idx, const double *nontop_llk, int mode,
                       double min_llk, double max_llk, double *llk_out);
 
+/* ---- MixtureGDStat::computeAndAccumulateOcc + getOccVect (AccumulateTVStat.cpp:302,334-335;
+ * FactorAnalysis.cpp:204-205): the full posterior vector of every frame,
+ * gamma[t*C + c] = w_c lk_c(x_t) / sum_c' w_c' lk_c'(x_t)   (row-major [T x C]). */
+int gmmiv_occ(gmmiv_ctx *ctx, const gmmiv_gmm *gmm, const void *x, int x_dtype, int64_t T, int64_t ldx,
+              double *gamma);
+
 /* ---- MixtureStat::computeAndAccumulateEM loop (accumulateStatEM, AccumulateStat.cpp:103-152) ---
  * acc is the flat EM accumulator, length gmmiv_em_acc_len(C,D) = C*(1+2D)+2 doubles:
  *   [ occ[C] | sum g x [C*D] | sum g x^2 [C*D] | sum_t weight*log lk_t | sum_t weight ].
@@ -171,6 +177,29 @@ int gmmiv_tv_min_divergence(gmmiv_ctx *ctx, int C, int D, int R, double n_sessio
  * T[R x SV], in place (coefficients taken against the ORIGINAL row, zero rows stay zero). */
 int gmmiv_tv_orthonormalize_t(gmmiv_ctx *ctx, int R, int64_t SV, double *Tm);
 
+/* ---- approximate extractors (IvExtractor modes ubmWeight / eigenDecomposition, IvExtractor.cpp:150-360) ----
+ * normStatistics (AccumulateTVStat.cpp:1225-1242): F[u,c,d] = (F - mean[c,d] N[u,c]) sqrt(invvar[c,d]), in place.
+ * substractMplusTW (:1379-1399, getMplusTW :964-971): F[u,c,d] -= (mean[c,d] + sum_i T[i,cD+d] W[u,i]) N[u,c].
+ * normTMatrix (:1600-1609): T[j,k] *= sqrt(invvar[k]), in place.
+ * getWeightedCov (:2837-2855): Wm[R x R] = sum_c weight[c] T_c T_c^T.
+ * approximateTcTc (:3116-3136): Dm[c,i] += || (T_c^T Q)[:, i] ||^2, Dm [C x R], Q [R x R]; accumulates like the
+ *   reference (zero Dm first for a fresh result).  Q comes from computeEigenProblem (:2997-3102, Eigen / LAPACK
+ *   on the host in the reference; its column order is the solver's, so Q is an input here).
+ * estimateWUbmWeight (:2348-2396): W[u] += (I + (sum_c N[u,c]) Wm)^-1 (T F[u]); T, F normalised as above.
+ * estimateWEigenDecomposition (:2566-2609): W[u] += Q diag(1 / (1 + N[u] Dm)) Q^T (T F[u]).
+ * W is accumulated into (the reference zeroes _W in ubmWeight mode only: pass zeros for a fresh result). */
+int gmmiv_tv_norm_statistics(gmmiv_ctx *ctx, int64_t U, int C, int D, const double *N, double *F,
+                             const double *ubm_means, const double *invvar);
+int gmmiv_tv_subtract_m_plus_tw(gmmiv_ctx *ctx, int64_t U, int C, int D, int R, const double *N, double *F,
+                                const double *ubm_means, const double *Tm, const double *W);
+int gmmiv_tv_norm_t(gmmiv_ctx *ctx, int C, int D, int R, double *Tm, const double *invvar);
+int gmmiv_tv_weighted_cov(gmmiv_ctx *ctx, int C, int D, int R, const double *Tm, const double *weight, double *Wm);
+int gmmiv_tv_approximate_tctc(gmmiv_ctx *ctx, int C, int D, int R, const double *Tm, const double *Q, double *Dm);
+int gmmiv_tv_estimate_w_ubm_weight(gmmiv_ctx *ctx, int64_t U, int C, int D, int R, const double *N, const double *F,
+                                   const double *Tm, const double *Wm, double *W);
+int gmmiv_tv_estimate_w_eigen(gmmiv_ctx *ctx, int64_t U, int C, int D, int R, const double *N, const double *F,
+                              const double *Tm, const double *Dm, const double *Q, double *W);
+
 /* ---- PldaTest::center / rotateLeft / lengthNorm (PldaTools.cpp:3706-3790); one iteration of
  * sphericalNuisanceNormalization (:3793-3839) = all three ------------------------------------------
  * Y[dim_out x n] = lengthNorm( M[dim_out x dim_in] * (X[dim_in x n] - mean[dim_in]) ), vectors as
@@ -179,6 +208,12 @@ int gmmiv_tv_orthonormalize_t(gmmiv_ctx *ctx, int R, int64_t SV, double *Tm);
 int gmmiv_iv_normalize(gmmiv_ctx *ctx, int dim_in, int dim_out, int64_t n, const double *X,
                        const double *mean, const double *M, int length_norm, double *Y);
 
+/* PldaModel::preComputation + FTJ / FTJF of pldaNativeScoring (PldaTools.cpp:2950-2972, 4494-4496):
+ *   FTJ[rf x dim] = F^T S^-1 - F^T S^-1 G (G^T S^-1 G + I)^-1 G^T S^-1,  FTJF[rf x rf] = FTJ F
+ * F [dim x rf], G [dim x rg] (rg may be 0), Sigma [dim x dim] symmetric positive definite, all row-major.
+ * rotateLeft(FTJ) is gmmiv_iv_normalize with FTJ as the matrix; FTJF feeds gmmiv_score_plda. */
+int gmmiv_plda_precompute(gmmiv_ctx *ctx, int dim, int rf, int rg, const double *F, const double *G,
+                          const double *Sigma, double *FTJ, double *FTJF);
 /* ---- PldaTest scoring (LIA_SpkTools/src/PldaTools.cpp) ------------------------------------------
  * models[dim x M], segs[dim x S]: one vector per COLUMN like PldaTest::_models/_segments;
  * scores[M x S].

@@ -157,6 +157,56 @@ class Context:
                                      _ptr(tett), _ptr(out)))
         return out
 
+    # ---- approximate extractors (IvExtractor modes ubmWeight / eigenDecomposition); in-place on numpy / torch arrays
+    def tv_norm_statistics(self, N, F, means, invvar, C, D):
+        _chk(lib.gmmiv_tv_norm_statistics(self._h, ct.c_int64(N.shape[0]), C, D, _ptr(N), _ptr(F), _ptr(means), _ptr(invvar)))
+        return F
+
+    def tv_subtract_m_plus_tw(self, N, F, means, Tm, W, C, D):
+        _chk(lib.gmmiv_tv_subtract_m_plus_tw(self._h, ct.c_int64(N.shape[0]), C, D, Tm.shape[0], _ptr(N), _ptr(F), _ptr(means),
+                                             _ptr(Tm), _ptr(W)))
+        return F
+
+    def tv_norm_t(self, Tm, invvar, C, D):
+        _chk(lib.gmmiv_tv_norm_t(self._h, C, D, Tm.shape[0], _ptr(Tm), _ptr(invvar)))
+        return Tm
+
+    def tv_weighted_cov(self, Tm, weight, C, D, out=None):
+        R = Tm.shape[0]
+        if out is None:
+            out = np.empty((R, R))
+        _chk(lib.gmmiv_tv_weighted_cov(self._h, C, D, R, _ptr(Tm), _ptr(weight), _ptr(out)))
+        return out
+
+    def tv_approximate_tctc(self, Tm, Q, C, D, out=None):
+        R = Tm.shape[0]
+        if out is None:
+            out = np.zeros((C, R))
+        _chk(lib.gmmiv_tv_approximate_tctc(self._h, C, D, R, _ptr(Tm), _ptr(Q), _ptr(out)))
+        return out
+
+    def tv_estimate_w_ubm_weight(self, N, F, Tm, Wm, C, D, out=None):
+        U, R = N.shape[0], Tm.shape[0]
+        if out is None:
+            out = np.zeros((U, R))
+        _chk(lib.gmmiv_tv_estimate_w_ubm_weight(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(Wm), _ptr(out)))
+        return out
+
+    def tv_estimate_w_eigen(self, N, F, Tm, Dm, Q, C, D, out=None):
+        U, R = N.shape[0], Tm.shape[0]
+        if out is None:
+            out = np.zeros((U, R))
+        _chk(lib.gmmiv_tv_estimate_w_eigen(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(Dm), _ptr(Q), _ptr(out)))
+        return out
+
+    def plda_precompute(self, F, G, Sigma):
+        """-> (FTJ [rf x dim], FTJF [rf x rf]); G may be None."""
+        dim, rf = F.shape
+        rg = 0 if G is None else G.shape[1]
+        FTJ = np.empty((rf, dim)); FTJF = np.empty((rf, rf))
+        _chk(lib.gmmiv_plda_precompute(self._h, dim, rf, rg, _ptr(_f64(F)), _ptr(_f64(G)), _ptr(_f64(Sigma)), _ptr(FTJ), _ptr(FTJF)))
+        return FTJ, FTJF
+
     def tv_estimate_a_and_c(self, N, F, Tm, invvar, tett, C, D, acc=None):
         U, R = N.shape[0], Tm.shape[0]
         P = lib.gmmiv_tv_packed_len(R)
@@ -287,6 +337,13 @@ class Gmm:
         _chk(lib.gmmiv_llk_use_top(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), idx.shape[1],
                                    _ptr(idx), _ptr(_f64(nontop_llk)), TOP_COMPLETE if complete else TOP_PARTIAL,
                                    ct.c_double(min_llk), ct.c_double(max_llk), _ptr(out)))
+        return out
+
+    def occ(self, x):
+        """Posterior vectors [T x C] (computeAndAccumulateOcc / getOccVect)."""
+        x, dt, T, ldx = _feat(x)
+        out = np.empty((T, self.C))
+        _chk(lib.gmmiv_occ(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), _ptr(out)))
         return out
 
     def em_acc_len(self):

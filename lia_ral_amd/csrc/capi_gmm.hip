@@ -353,6 +353,24 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     return o_llk.finish();
 }
 
+int gmmiv_occ(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, double *gamma)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0 || !gamma) { gmmiv_set_error("occ: bad argument"); return GMMIV_ERR_ARG; }
+    if (T > 0x7fffffff) { gmmiv_set_error("occ: too many frames in one call"); return GMMIV_ERR_UNSUPPORTED; }
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    double *lse;
+    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
+    DevOut<double> o;
+    if ((rc = o.init(c, WS_T0, gamma, (size_t)T * g->C, false))) return rc;
+    c->t_begin("k_posteriors");
+    GCHK(gmmk_posteriors(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc, lse, o.d));
+    c->t_end();
+    return o.finish();
+}
+
 // ---- EM ----------------------------------------------------------------------------------
 size_t gmmiv_em_acc_len(int C, int D) { return (size_t)C * (1 + 2 * (size_t)D) + 2; }
 

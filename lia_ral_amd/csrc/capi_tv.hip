@@ -318,6 +318,163 @@ int gmmiv_tv_min_divergence(gmmiv_ctx *c, int C, int D, int R, double n_sessions
     return o_t.finish();
 }
 
+// ---- approximate extractors ------------------------------------------------------------------
+int gmmiv_tv_norm_statistics(gmmiv_ctx *c, int64_t U, int C, int D, const double *N, double *F, const double *means,
+                             const double *invvar)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || !N || !F || !means || !invvar) { gmmiv_set_error("tv_norm_statistics: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_m, i_v;
+    DevOut<double> o_f;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_m.init(c, WS_T2, means, SV)) || (rc = i_v.init(c, WS_T3, invvar, SV)) ||
+        (rc = o_f.init(c, WS_T1, F, (size_t)U * SV, true))) return rc;
+    GCHK(tvk_norm_stats(c->stream, (long)U, C, D, i_n.d, o_f.d, i_m.d, i_v.d));
+    return o_f.finish();
+}
+
+int gmmiv_tv_subtract_m_plus_tw(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *N, double *F, const double *means,
+                                const double *Tm, const double *W)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !means || !Tm || !W) { gmmiv_set_error("tv_subtract_m_plus_tw: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_m, i_t, i_w;
+    DevOut<double> o_f;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_m.init(c, WS_T2, means, SV)) || (rc = i_t.init(c, WS_T3, Tm, (size_t)R * SV)) ||
+        (rc = i_w.init(c, WS_LSE, W, (size_t)U * R)) || (rc = o_f.init(c, WS_T1, F, (size_t)U * SV, true))) return rc;
+    const int BC = U < 256 ? (int)(U > 0 ? U : 1) : 256;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)BC * SV * 8, &p))) return rc;
+    double *TW = (double *)p;
+    for (int64_t u0 = 0; u0 < U; u0 += BC) {
+        const int nb = (int)((U - u0) < BC ? (U - u0) : BC);
+        GCHK(tvk_dgemm(c->stream, false, false, nb, (int)SV, R, 1.0, i_w.d + (size_t)u0 * R, R, 0, i_t.d, (long)SV, 0, 0.0, TW, (long)SV, 0, 1));
+        GCHK(tvk_sub_mtw(c->stream, nb, C, D, i_n.d + (size_t)u0 * C, o_f.d + (size_t)u0 * SV, i_m.d, TW));
+    }
+    return o_f.finish();
+}
+
+int gmmiv_tv_norm_t(gmmiv_ctx *c, int C, int D, int R, double *Tm, const double *invvar)
+{
+    if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !invvar) { gmmiv_set_error("tv_norm_t: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_v;
+    DevOut<double> o_t;
+    int rc;
+    if ((rc = i_v.init(c, WS_T0, invvar, SV)) || (rc = o_t.init(c, WS_T1, Tm, (size_t)R * SV, true))) return rc;
+    GCHK(tvk_scale_cols_fn(c->stream, R, (long)SV, D, 0, o_t.d, i_v.d, o_t.d));
+    return o_t.finish();
+}
+
+int gmmiv_tv_weighted_cov(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *weight, double *Wm)
+{
+    if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !weight || !Wm) { gmmiv_set_error("tv_weighted_cov: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_t, i_w;
+    DevOut<double> o;
+    int rc;
+    if ((rc = i_t.init(c, WS_T1, Tm, (size_t)R * SV)) || (rc = i_w.init(c, WS_T0, weight, C)) || (rc = o.init(c, WS_T2, Wm, (size_t)R * R, false))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)R * SV * 8, &p))) return rc;
+    double *Ts = (double *)p;
+    GCHK(tvk_scale_cols_fn(c->stream, R, (long)SV, D, 1, i_t.d, i_w.d, Ts));
+    const int nz = tvk_splitk_count(R, R, (int)SV, c->n_cu);
+    if ((rc = c->scratch(WS_SLAB, (size_t)nz * R * R * 8, &p))) return rc;
+    GCHK(tvk_dgemm_splitk(c->stream, false, true, R, R, (int)SV, 1.0, Ts, (long)SV, i_t.d, (long)SV, 0.0, o.d, R, nz, (double *)p));
+    return o.finish();
+}
+
+int gmmiv_tv_approximate_tctc(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *Q, double *Dm)
+{
+    if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !Q || !Dm) { gmmiv_set_error("tv_approximate_tctc: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_t, i_q;
+    DevOut<double> o;
+    int rc;
+    if ((rc = i_t.init(c, WS_T1, Tm, (size_t)R * SV)) || (rc = i_q.init(c, WS_T0, Q, (size_t)R * R)) || (rc = o.init(c, WS_T2, Dm, (size_t)C * R, true))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, SV * R * 8, &p))) return rc;
+    double *A = (double *)p; // [SV x R] = T^T Q
+    GCHK(tvk_dgemm(c->stream, true, false, (int)SV, R, R, 1.0, i_t.d, (long)SV, 0, i_q.d, R, 0, 0.0, A, R, 0, 1));
+    GCHK(tvk_block_colnorm(c->stream, C, D, R, A, o.d));
+    return o.finish();
+}
+
+// shared front end of the two approximate estimators: aux[nb x R] = F_chunk T^T (T and F normalised, no invvar)
+static int approx_aux(gmmiv_ctx *c, int nb, int R, size_t SV, const double *Fc, const double *Td, double *aux, int nz, double *slabs)
+{
+    GCHK(tvk_dgemm_splitk(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, Td, (long)SV, 0.0, aux, R, nz, slabs));
+    return GMMIV_OK;
+}
+
+int gmmiv_tv_estimate_w_ubm_weight(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *N, const double *F, const double *Tm,
+                                   const double *Wm, double *W)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !Tm || !Wm || !W) { gmmiv_set_error("tv_estimate_w_ubm_weight: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_f, i_t, i_w;
+    DevOut<double> o;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_f.init(c, WS_T1, F, (size_t)U * SV)) || (rc = i_t.init(c, WS_T2, Tm, (size_t)R * SV)) ||
+        (rc = i_w.init(c, WS_T3, Wm, (size_t)R * R)) || (rc = o.init(c, WS_LSE, W, (size_t)U * R, true))) return rc;
+    const int BC = U < 256 ? (int)(U > 0 ? U : 1) : 256;
+    void *p;
+    if ((rc = c->scratch(WS_AUX, (size_t)2 * BC * R * 8, &p))) return rc;
+    double *aux = (double *)p, *wc = aux + (size_t)BC * R;
+    const int nz = tvk_splitk_count(BC, R, (int)SV, c->n_cu);
+    if ((rc = c->scratch(WS_SLAB, (size_t)nz * BC * R * 8, &p))) return rc;
+    double *slabs = (double *)p;
+    InvWs ws;
+    if ((rc = ws.init(c, R, BC))) return rc;
+    for (int64_t u0 = 0; u0 < U; u0 += BC) {
+        const int nb = (int)((U - u0) < BC ? (U - u0) : BC);
+        GCHK(hipMemsetAsync(ws.status, 0, nb * sizeof(int), c->stream));
+        GCHK(tvk_build_l_ubm(c->stream, R, C, nb, i_n.d + (size_t)u0 * C, i_w.d, ws.full));
+        if ((rc = approx_aux(c, nb, R, SV, i_f.d + (size_t)u0 * SV, i_t.d, aux, nz, slabs))) return rc;
+        GCHK(tvk_chol_batched(c->stream, R, nb, ws.full, ws.invd, ws.panel, ws.status));
+        GCHK(tvk_chol_solve_batched(c->stream, R, nb, ws.full, ws.invd, aux, wc));
+        if ((rc = check_status(c, ws.status, nb, "tv_estimate_w_ubm_weight: L"))) return rc;
+        GCHK(tvk_axpby(c->stream, (long)nb * R, 1.0, wc, 1.0, o.d + (size_t)u0 * R, o.d + (size_t)u0 * R));
+    }
+    return o.finish();
+}
+
+int gmmiv_tv_estimate_w_eigen(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *N, const double *F, const double *Tm,
+                              const double *Dm, const double *Q, double *W)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !Tm || !Dm || !Q || !W) { gmmiv_set_error("tv_estimate_w_eigen: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_f, i_t, i_d, i_q;
+    DevOut<double> o;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_f.init(c, WS_T1, F, (size_t)U * SV)) || (rc = i_t.init(c, WS_T2, Tm, (size_t)R * SV)) ||
+        (rc = i_d.init(c, WS_T3, Dm, (size_t)C * R)) || (rc = i_q.init(c, WS_T4, Q, (size_t)R * R)) || (rc = o.init(c, WS_LSE, W, (size_t)U * R, true))) return rc;
+    const int BC = U < 256 ? (int)(U > 0 ? U : 1) : 256;
+    void *p;
+    if ((rc = c->scratch(WS_AUX, (size_t)3 * BC * R * 8, &p))) return rc;
+    double *aux = (double *)p, *nd = aux + (size_t)BC * R, *b = nd + (size_t)BC * R;
+    const int nz = tvk_splitk_count(BC, R, (int)SV, c->n_cu);
+    if ((rc = c->scratch(WS_SLAB, (size_t)nz * BC * R * 8, &p))) return rc;
+    double *slabs = (double *)p;
+    for (int64_t u0 = 0; u0 < U; u0 += BC) {
+        const int nb = (int)((U - u0) < BC ? (U - u0) : BC);
+        if ((rc = approx_aux(c, nb, R, SV, i_f.d + (size_t)u0 * SV, i_t.d, aux, nz, slabs))) return rc;
+        GCHK(tvk_dgemm(c->stream, false, false, nb, R, C, 1.0, i_n.d + (size_t)u0 * C, C, 0, i_d.d, R, 0, 0.0, nd, R, 0, 1));   // N Dm
+        GCHK(tvk_dgemm(c->stream, false, false, nb, R, R, 1.0, aux, R, 0, i_q.d, R, 0, 0.0, b, R, 0, 1));                          // (Q^T aux)^T = aux Q
+        GCHK(tvk_mul_recip1p(c->stream, (long)nb * R, b, nd));
+        GCHK(tvk_dgemm(c->stream, false, true, nb, R, R, 1.0, b, R, 0, i_q.d, R, 0, 1.0, o.d + (size_t)u0 * R, R, 0, 1));         // += b Q^T
+    }
+    return o.finish();
+}
+
 int gmmiv_tv_orthonormalize_t(gmmiv_ctx *c, int R, int64_t SV, double *Tm)
 {
     if (!c || R <= 0 || SV <= 0 || !Tm) { gmmiv_set_error("tv_orthonormalize_t: bad argument"); return GMMIV_ERR_ARG; }
@@ -478,6 +635,49 @@ int gmmiv_score_twocov(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double
     GCHK(tvk_axpby(c->stream, (long)nn, 1.0, g.d, -1.0, h.d, GmH));
     if ((rc = quad_score(c, a, dim, M, S, g.d, 1.0, GmH, 1.0, GmH, 1.0, 0.0))) return rc;
     return a.sc.finish();
+}
+
+int gmmiv_plda_precompute(gmmiv_ctx *c, int dim, int rf, int rg, const double *Fm, const double *Gm, const double *Sigma, double *FTJ,
+                          double *FTJF)
+{
+    if (!c || dim <= 0 || rf <= 0 || rg < 0 || !Fm || (rg > 0 && !Gm) || !Sigma || !FTJ || !FTJF) { gmmiv_set_error("plda_precompute: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    DevIn<double> i_f, i_g, i_s;
+    DevOut<double> o_j, o_jf;
+    int rc;
+    if ((rc = i_f.init(c, WS_T0, Fm, (size_t)dim * rf)) || (rc = i_g.init(c, WS_T1, Gm, (size_t)dim * rg)) || (rc = i_s.init(c, WS_T2, Sigma, (size_t)dim * dim)) ||
+        (rc = o_j.init(c, WS_T3, FTJ, (size_t)rf * dim, false)) || (rc = o_jf.init(c, WS_T9, FTJF, (size_t)rf * rf, false))) return rc;
+    const int big = dim > rg ? dim : rg;
+    InvWs ws;
+    if ((rc = ws.init(c, big, 1))) return rc;
+    void *p;
+    const size_t need = (size_t)dim * dim + (size_t)rf * dim + (size_t)rg * dim + (size_t)rg * rg * 2 + (size_t)rf * rg * 2;
+    if ((rc = c->scratch(WS_AUX, need * 8, &p))) return rc;
+    double *Si = (double *)p, *Ftw = Si + (size_t)dim * dim, *Gtw = Ftw + (size_t)rf * dim, *GG = Gtw + (size_t)rg * dim;
+    double *Mi = GG + (size_t)rg * rg, *FtwG = Mi + (size_t)rg * rg, *t1 = FtwG + (size_t)rf * rg;
+    hipStream_t st = c->stream;
+    // S^-1 (the inverse routine factors its input in place: work on a copy)
+    GCHK(hipMemcpyAsync(ws.full, i_s.d, (size_t)dim * dim * 8, hipMemcpyDeviceToDevice, st));
+    GCHK(hipMemsetAsync(ws.status, 0, sizeof(int), st));
+    GCHK(tvk_spd_inverse_batched(st, dim, 1, ws.full, Si, ws.X, ws.invd, ws.panel, ws.status));
+    if ((rc = check_status(c, ws.status, 1, "plda_precompute: Sigma"))) return rc;
+    GCHK(tvk_dgemm(st, true, false, rf, dim, dim, 1.0, i_f.d, rf, 0, Si, dim, 0, 0.0, Ftw, dim, 0, 1));          // F^T S^-1
+    GCHK(hipMemcpyAsync(o_j.d, Ftw, (size_t)rf * dim * 8, hipMemcpyDeviceToDevice, st));
+    if (rg > 0) {
+        GCHK(tvk_dgemm(st, true, false, rg, dim, dim, 1.0, i_g.d, rg, 0, Si, dim, 0, 0.0, Gtw, dim, 0, 1));      // G^T S^-1
+        GCHK(tvk_dgemm(st, false, false, rg, rg, dim, 1.0, Gtw, dim, 0, i_g.d, rg, 0, 0.0, GG, rg, 0, 1));        // G^T S^-1 G
+        GCHK(tvk_add_identity(st, rg, GG));
+        GCHK(tvk_dgemm(st, false, false, rf, rg, dim, 1.0, Ftw, dim, 0, i_g.d, rg, 0, 0.0, FtwG, rg, 0, 1));      // F^T S^-1 G
+        GCHK(hipMemcpyAsync(ws.full, GG, (size_t)rg * rg * 8, hipMemcpyDeviceToDevice, st));
+        GCHK(hipMemsetAsync(ws.status, 0, sizeof(int), st));
+        GCHK(tvk_spd_inverse_batched(st, rg, 1, ws.full, Mi, ws.X, ws.invd, ws.panel, ws.status));
+        if ((rc = check_status(c, ws.status, 1, "plda_precompute: G^T S^-1 G + I"))) return rc;
+        GCHK(tvk_dgemm(st, false, false, rf, rg, rg, 1.0, FtwG, rg, 0, Mi, rg, 0, 0.0, t1, rg, 0, 1));
+        GCHK(tvk_dgemm(st, false, false, rf, dim, rg, -1.0, t1, rg, 0, Gtw, dim, 0, 1.0, o_j.d, dim, 0, 1));       // FTJ -= t1 Gtw
+    }
+    GCHK(tvk_dgemm(st, false, false, rf, rf, dim, 1.0, o_j.d, dim, 0, i_f.d, rf, 0, 0.0, o_jf.d, rf, 0, 1));
+    if ((rc = o_j.finish())) return rc;
+    return o_jf.finish();
 }
 
 int gmmiv_score_plda(gmmiv_ctx *c, int rf, int64_t M, int64_t S, const double *models_sum, const int64_t *nsess,

@@ -41,6 +41,8 @@ int gmmk_em_fused(hipStream_t st, int KS, int sq, int x_f64, const void *x, long
 // stats_z.hip / k_llk_mfma<WZ>: scaled likelihoods written once by the log-likelihood kernel, statistics from them
 int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
                double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin);
+int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp, const double *meanT,
+                    const double *ivT, const double *lwc, const double *lse, double *gamma);
 int gmmk_stats_z_groups(int nct);
 void gmmk_stats_z_set_waves(int w);
 int gmmk_stats_z_wg_per_cu(void);

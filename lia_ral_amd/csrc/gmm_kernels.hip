@@ -750,6 +750,30 @@ __global__ __launch_bounds__(256) void k_topc_use(const void *__restrict__ x, lo
     }
 }
 
+// Posterior vector of every frame (computeAndAccumulateOcc + getOccVect): gamma[t][c] =
+// exp(z_tc - lse_t) in the reference's direct form z = log(w cst) - 0.5 sum (x - mu)^2 iv.  One
+// workgroup per frame, threads over Gaussians (coalesced reads of the transposed model).
+template <typename XT>
+__global__ __launch_bounds__(256) void k_posteriors(const void *__restrict__ x, long ldx, int D, int C, int Cp,
+                                                    const double *__restrict__ meanT, const double *__restrict__ ivT,
+                                                    const double *__restrict__ lwc, const double *__restrict__ lse,
+                                                    double *__restrict__ gamma)
+{
+    extern __shared__ double xs[];
+    const long t = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) xs[d] = feat_load<XT>::get(x, t * ldx + d);
+    __syncthreads();
+    const double l = lse[t];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double dx = xs[d] - meanT[(size_t)d * Cp + c];
+            acc = __builtin_fma(dx * dx, ivT[(size_t)d * Cp + c], acc);
+        }
+        gamma[t * C + c] = exp(__builtin_fma(-0.5, acc, lwc[c]) - l);
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // K4: frame moments sum x, sum x^2 (FrameAccGD).  HBM-bound stream; per-block partials.
 // -------------------------------------------------------------------------------------------
@@ -1038,6 +1062,15 @@ int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, in
         k_topc_use<double><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
     else
         k_topc_use<float><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+    return (int)hipGetLastError();
+}
+
+int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp, const double *meanT,
+                    const double *ivT, const double *lwc, const double *lse, double *gamma)
+{
+    if (T <= 0) return 0;
+    if (x_f64) k_posteriors<double><<<(unsigned)T, 256, D * sizeof(double), st>>>(x, ldx, D, C, Cp, meanT, ivT, lwc, lse, gamma);
+    else k_posteriors<float><<<(unsigned)T, 256, D * sizeof(double), st>>>(x, ldx, D, C, Cp, meanT, ivT, lwc, lse, gamma);
     return (int)hipGetLastError();
 }
 

@@ -28,3 +28,10 @@ int tvk_sub_colvec(hipStream_t st, int dim, long n, const double *X, const doubl
 int tvk_scale_cols_rsqrt(hipStream_t st, int dim, long n, double *X, const double *qv);
 int tvk_orthonormalize(hipStream_t st, int R, long SV, const double *Tm, double *Q, double *rv, double *v, double *partial);
 int tvk_chol_solve_batched(hipStream_t st, int n, int nb, const double *Lf, const double *invd, const double *b, double *w);
+int tvk_norm_stats(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means, const double *invvar);
+int tvk_sub_mtw(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means, const double *TW);
+int tvk_scale_cols_fn(hipStream_t st, long rows, long cols, int D, int mode, const double *in, const double *v, double *out);
+int tvk_block_colnorm(hipStream_t st, int C, int D, int R, const double *A, double *Dm);
+int tvk_build_l_ubm(hipStream_t st, int R, int C, int nb, const double *N, const double *Wm, double *full);
+int tvk_mul_recip1p(hipStream_t st, long n, double *B, const double *X);
+int tvk_add_identity(hipStream_t st, int n, double *A);

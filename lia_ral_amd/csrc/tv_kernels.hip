@@ -466,6 +466,114 @@ int tvk_chol_solve_batched(hipStream_t st, int n, int nb, const double *Lf, cons
     return (int)hipGetLastError();
 }
 
+// ---- approximate extractors (normStatistics, substractMplusTW, normTMatrix, getWeightedCov, approximateTcTc) ----
+// F[u,c,d] = (F - mean[c,d] N[u,c]) * sqrt(invvar[c,d])
+__global__ void k_norm_stats(long U, int C, int D, const double *__restrict__ N, double *__restrict__ F,
+                             const double *__restrict__ means, const double *__restrict__ invvar)
+{
+    const long SV = (long)C * D, n = U * SV;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long u = e / SV, k = e - u * SV;
+        F[e] = (F[e] - means[k] * N[u * C + k / D]) * sqrt(invvar[k]);
+    }
+}
+// F[u,c,d] -= (mean[c,d] + TW[u, cD+d]) * N[u,c]
+__global__ void k_sub_mtw(long U, int C, int D, const double *__restrict__ N, double *__restrict__ F,
+                          const double *__restrict__ means, const double *__restrict__ TW)
+{
+    const long SV = (long)C * D, n = U * SV;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long u = e / SV, k = e - u * SV;
+        F[e] -= (means[k] + TW[e]) * N[u * C + k / D];
+    }
+}
+// out[r][k] = in[r][k] * (mode 0: sqrt(v[k]); mode 1: v[k / D])
+__global__ void k_scale_cols_fn(long rows, long cols, int D, int mode, const double *__restrict__ in,
+                                const double *__restrict__ v, double *__restrict__ out)
+{
+    const long n = rows * cols;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long k = e % cols;
+        out[e] = in[e] * (mode == 0 ? sqrt(v[k]) : v[k / D]);
+    }
+}
+// Dm[c,i] += sum_k A[(cD+k), i]^2   (A is [SV x R])
+__global__ void k_block_colnorm(int C, int D, int R, const double *__restrict__ A, double *__restrict__ Dm)
+{
+    const long n = (long)C * R;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long c = e / R, i = e - c * R;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) { const double a = A[((size_t)c * D + k) * R + i]; s = __builtin_fma(a, a, s); }
+        Dm[e] += s;
+    }
+}
+// full[b] = I + (sum_c N[b,c]) * Wm   (one workgroup per matrix)
+__global__ __launch_bounds__(256) void k_build_l_ubm(int R, int C, const double *__restrict__ N, const double *__restrict__ Wm,
+                                                     double *__restrict__ full)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) s += N[(size_t)blockIdx.x * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const double ns = red[0];
+    double *L = full + (size_t)blockIdx.x * R * R;
+    for (int e = threadIdx.x; e < R * R; e += 256) L[e] = ns * Wm[e] + ((e / R) == (e % R) ? 1.0 : 0.0);
+}
+// B[e] *= 1 / (1 + X[e])
+__global__ void k_mul_recip1p(long n, double *__restrict__ B, const double *__restrict__ X)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) B[e] *= 1.0 / (1.0 + X[e]);
+}
+__global__ void k_add_identity(int n, double *__restrict__ A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(size_t)i * n + i] += 1.0;
+}
+
+static unsigned ew_blocks(long n) { long b = (n + 255) / 256; return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+int tvk_norm_stats(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means, const double *invvar)
+{
+    if (U <= 0) return 0;
+    k_norm_stats<<<ew_blocks(U * C * D), 256, 0, st>>>(U, C, D, N, F, means, invvar);
+    return (int)hipGetLastError();
+}
+int tvk_sub_mtw(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means, const double *TW)
+{
+    if (U <= 0) return 0;
+    k_sub_mtw<<<ew_blocks(U * C * D), 256, 0, st>>>(U, C, D, N, F, means, TW);
+    return (int)hipGetLastError();
+}
+int tvk_scale_cols_fn(hipStream_t st, long rows, long cols, int D, int mode, const double *in, const double *v, double *out)
+{
+    k_scale_cols_fn<<<ew_blocks(rows * cols), 256, 0, st>>>(rows, cols, D, mode, in, v, out);
+    return (int)hipGetLastError();
+}
+int tvk_block_colnorm(hipStream_t st, int C, int D, int R, const double *A, double *Dm)
+{
+    k_block_colnorm<<<ew_blocks((long)C * R), 256, 0, st>>>(C, D, R, A, Dm);
+    return (int)hipGetLastError();
+}
+int tvk_build_l_ubm(hipStream_t st, int R, int C, int nb, const double *N, const double *Wm, double *full)
+{
+    if (nb <= 0) return 0;
+    k_build_l_ubm<<<nb, 256, 0, st>>>(R, C, N, Wm, full);
+    return (int)hipGetLastError();
+}
+int tvk_mul_recip1p(hipStream_t st, long n, double *B, const double *X)
+{
+    if (n <= 0) return 0;
+    k_mul_recip1p<<<ew_blocks(n), 256, 0, st>>>(n, B, X);
+    return (int)hipGetLastError();
+}
+int tvk_add_identity(hipStream_t st, int n, double *A)
+{
+    k_add_identity<<<(n + 255) / 256, 256, 0, st>>>(n, A);
+    return (int)hipGetLastError();
+}
+
 int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means)
 {
     if (U <= 0) return 0;

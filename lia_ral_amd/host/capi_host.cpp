@@ -131,6 +131,43 @@ int liagpu_iv_extract(int device, const float *x, long T, int D, const long *utt
     })
 }
 
+// IvExtractorUbmWeigth / IvExtractorEigenDecomposition (IvExtractor.cpp:150-250, 254-360): the approximate
+// extractors.  mode 1 = ubmWeight, 2 = eigenDecomposition.  Q_out [R x R] / D_out [C x R] (mode 2) and Wcov_out
+// [R x R] receive the intermediate matrices when given.
+int liagpu_iv_extract_approx(int device, int mode, const float *x, long T, int D, const long *utt_begin, long U, int C, const double *w,
+                             const double *mean, const double *cov, int R, const double *Tmat, double *W_out, double *Wcov_out,
+                             double *Q_out, double *D_out)
+{
+    GUARD({
+        if (mode != 1 && mode != 2) throw Exception("iv_extract_approx: mode must be 1 (ubmWeight) or 2 (eigenDecomposition)");
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        TVAcc tv(srv, ubm, (unsigned long)R, (unsigned long)U);
+        std::vector<SegCluster> lines(U);
+        for (long u = 0; u < U; ++u) {
+            Seg s; s.begin = (unsigned long)utt_begin[u]; s.length = (unsigned long)(utt_begin[u + 1] - utt_begin[u]); s.source = 0;
+            if (s.length) lines[u].push_back(s);
+        }
+        tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
+        tv.normTMatrix();
+        std::vector<double> Wc, Q, ev, Dm;
+        tv.getWeightedCov(Wc, std::vector<double>(w, w + C));
+        if (Wcov_out) memcpy(Wcov_out, Wc.data(), Wc.size() * sizeof(double));
+        if (mode == 2) {
+            computeEigenProblem(Wc, (unsigned long)R, Q, ev, (unsigned long)R);
+            tv.approximateTcTc(Dm, Q);
+            if (Q_out) memcpy(Q_out, Q.data(), Q.size() * sizeof(double));
+            if (D_out) memcpy(D_out, Dm.data(), Dm.size() * sizeof(double));
+        }
+        tv.computeAndAccumulateTVStat(fs, lines);
+        tv.normStatistics();
+        if (mode == 1) tv.estimateWUbmWeight(Wc);
+        else { std::fill(tv.getW().begin(), tv.getW().end(), 0.0); tv.estimateWEigenDecomposition(Dm, Q); }
+        memcpy(W_out, tv.getW().data(), tv.getW().size() * sizeof(double));
+    })
+}
+
 // TotalVariability (TotalVariability.cpp:118-169): nbIt iterations on precomputed N, F
 int liagpu_tv_train(int device, long U, int C, int D, const double *w, const double *mean, const double *cov, int R,
                     const double *N, const double *F, double *Tmat, int nbIt, int minDiv, double *mean_out)

@@ -2,6 +2,8 @@
 // all frame x Gaussian arithmetic happens in libgmmiv (HIP kernels).
 #include "liatools_gpu.h"
 
+#include <algorithm>
+
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdlib.h>
@@ -441,6 +443,94 @@ void TVAcc::minDivergence()
 void TVAcc::orthonormalizeT()
 {
     _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankT, (int64_t)_svSize, _T.data()));
+}
+
+void TVAcc::normStatistics()
+{
+    _srv.check(gmmiv_tv_norm_statistics(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.data(), _statF.data(),
+                                        _ubm_means.data(), _ubm_invvar.data()));
+}
+void TVAcc::substractMplusTW()
+{
+    _srv.check(gmmiv_tv_subtract_m_plus_tw(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
+                                           _statF.data(), _ubm_means.data(), _T.data(), _W.data()));
+}
+void TVAcc::normTMatrix()
+{
+    _srv.check(gmmiv_tv_norm_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), _ubm_invvar.data()));
+}
+void TVAcc::getWeightedCov(std::vector<double> &W, const std::vector<double> &weight)
+{
+    if (weight.size() != _n_distrib) throw Exception("getWeightedCov: one weight per distribution expected");
+    W.assign(_rankT * _rankT, 0.0);
+    _srv.check(gmmiv_tv_weighted_cov(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), weight.data(), W.data()));
+}
+void TVAcc::approximateTcTc(std::vector<double> &D, const std::vector<double> &Q)
+{
+    if (Q.size() != _rankT * _rankT) throw Exception("approximateTcTc: Q must be rankT x rankT");
+    if (D.size() != _n_distrib * _rankT) D.assign(_n_distrib * _rankT, 0.0);
+    _srv.check(gmmiv_tv_approximate_tctc(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), Q.data(), D.data()));
+}
+void TVAcc::estimateWUbmWeight(const std::vector<double> &W)
+{
+    if (W.size() != _rankT * _rankT) throw Exception("estimateWUbmWeight: W must be rankT x rankT");
+    std::fill(_W.begin(), _W.end(), 0.0); // _W.setAllValues(0.0), :2353
+    _srv.check(gmmiv_tv_estimate_w_ubm_weight(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
+                                              _statF.data(), _T.data(), W.data(), _W.data()));
+}
+void TVAcc::estimateWEigenDecomposition(const std::vector<double> &D, const std::vector<double> &Q)
+{
+    if (D.size() != _n_distrib * _rankT || Q.size() != _rankT * _rankT) throw Exception("estimateWEigenDecomposition: D is C x rankT, Q rankT x rankT");
+    _srv.check(gmmiv_tv_estimate_w_eigen(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
+                                         _statF.data(), _T.data(), D.data(), Q.data(), _W.data()));
+}
+
+void computeEigenProblem(const std::vector<double> &EP, unsigned long n, std::vector<double> &eigenVect, std::vector<double> &eigenVal,
+                         unsigned long rank)
+{
+    if (EP.size() != n * n || rank > n) throw Exception("computeEigenProblem: EP must be n x n and rank <= n");
+    std::vector<double> a(EP), v(n * n, 0.0);
+    for (unsigned long i = 0; i < n; ++i) v[i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (unsigned long i = 0; i < n; ++i) {
+            diag += a[i * n + i] * a[i * n + i];
+            for (unsigned long j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
+        }
+        if (off <= 1e-30 * (diag + off)) break;
+        for (unsigned long p = 0; p + 1 < n; ++p)
+            for (unsigned long q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (unsigned long k = 0; k < n; ++k) { // columns p, q
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = cs * akp - sn * akq;
+                    a[k * n + q] = sn * akp + cs * akq;
+                }
+                for (unsigned long k = 0; k < n; ++k) { // rows p, q
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = cs * apk - sn * aqk;
+                    a[q * n + k] = sn * apk + cs * aqk;
+                }
+                for (unsigned long k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = cs * vkp - sn * vkq;
+                    v[k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    std::vector<unsigned long> order(n);
+    for (unsigned long i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](unsigned long x, unsigned long y) { return a[x * n + x] > a[y * n + y]; });
+    eigenVect.assign(n * rank, 0.0);
+    eigenVal.assign(rank, 0.0);
+    for (unsigned long j = 0; j < rank; ++j) {
+        eigenVal[j] = a[order[j] * n + order[j]];
+        for (unsigned long k = 0; k < n; ++k) eigenVect[k * rank + j] = v[k * n + order[j]];
+    }
 }
 
 } // namespace liagpu

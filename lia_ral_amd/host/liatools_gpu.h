@@ -195,6 +195,14 @@ class TVAcc {
     void updateTestimate();            // :974-1005
     void minDivergence();              // :2056-2099
     void orthonormalizeT();            // :1548-1596
+    // approximate extractors (IvExtractor modes ubmWeight / eigenDecomposition, IvExtractor.cpp:150-360)
+    void normStatistics();             // :1225-1242
+    void substractMplusTW();           // :1379-1399
+    void normTMatrix();                // :1600-1609
+    void getWeightedCov(std::vector<double> &W, const std::vector<double> &weight);       // :2837-2855, W [R x R]
+    void approximateTcTc(std::vector<double> &D, const std::vector<double> &Q);            // :3116-3136, D [C x R] accumulated
+    void estimateWUbmWeight(const std::vector<double> &W);                                 // :2348-2396 (zeroes _W first)
+    void estimateWEigenDecomposition(const std::vector<double> &D, const std::vector<double> &Q); // :2566-2609 (accumulates into _W)
     void resetTmpAcc();                // :620-629
     void loadT(const std::vector<double> &T) { _T = T; }
     void setStats(const std::vector<double> &N, const std::vector<double> &F) { _statN = N; _statF = F; }
@@ -212,5 +220,12 @@ class TVAcc {
     unsigned long _rankT, _n_speakers, _n_distrib, _vectSize, _svSize;
     std::vector<double> _ubm_means, _ubm_invvar, _statN, _statF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
 };
+
+// TVAcc::computeEigenProblem (AccumulateTVStat.cpp:2997-3102) for the SYMMETRIC matrices it is used on (the weighted
+// covariance W): cyclic Jacobi on the host, eigenvalues sorted descending, eigenVect[k*rank + j] = component k of
+// the j-th eigenvector (the reference's Eigen / LAPACK solver returns its own column order and sign; any orthonormal
+// eigenbasis gives the same approximate i-vectors).  eigenVal [rank] holds the diagonal.
+void computeEigenProblem(const std::vector<double> &EP, unsigned long n, std::vector<double> &eigenVect,
+                         std::vector<double> &eigenVal, unsigned long rank);
 
 } // namespace liagpu

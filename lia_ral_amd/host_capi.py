@@ -104,6 +104,22 @@ def iv_extract(x, utt_begin, ubm, Tmat, device=0, return_stats=False):
     return (W, N, F) if return_stats else W
 
 
+def iv_extract_approx(x, utt_begin, ubm, Tmat, mode, device=0):
+    """IvExtractor --mode ubmWeight (mode=1) / eigenDecomposition (mode=2).  -> dict(W, Wcov, Q, D)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C = len(w)
+    Tm = np.ascontiguousarray(Tmat, np.float64)
+    R = Tm.shape[0]
+    ub = np.ascontiguousarray(utt_begin, np.int64)
+    U = len(ub) - 1
+    W = np.empty((U, R)); Wc = np.empty((R, R)); Q = np.zeros((R, R)); Dm = np.zeros((C, R))
+    _chk(lib.liagpu_iv_extract_approx(device, int(mode), x.ctypes.data_as(_fp), ct.c_long(T), D, ub.ctypes.data_as(_lp), ct.c_long(U), C,
+                                      _d(w), _d(mean), _d(cov), R, _d(Tm), _d(W), _d(Wc), _d(Q), _d(Dm)))
+    return dict(W=W, Wcov=Wc, Q=Q, D=Dm)
+
+
 def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
     C, D = mean.shape

@@ -562,6 +562,181 @@ int orc_tv_min_divergence(int C, int D, int R, double n_sessions, double *Rm, do
     return 0;
 }
 
+/* ---- approximate i-vector extractors (IvExtractor --mode ubmWeight / eigenDecomposition) ----------
+ * TVAcc::normStatisticsUnThreaded, LIA_SpkTools/src/AccumulateTVStat.cpp:1225-1242:
+ * F[u,c,d] = (F[u,c,d] - mean[c,d] N[u,c]) * sqrt(invvar[c,d]) */
+void orc_tv_norm_statistics(long U, int C, int D, const double *N, double *F, const double *ubm_means, const double *invvar)
+{
+    const size_t SV = (size_t)C * D;
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < D; ++j) {
+            const double s = sqrt(invvar[(size_t)i * D + j]);
+            for (long u = 0; u < U; ++u) {
+                F[u * SV + (size_t)i * D + j] -= ubm_means[(size_t)i * D + j] * N[u * C + i];
+                F[u * SV + (size_t)i * D + j] *= s;
+            }
+        }
+}
+
+/* TVAcc::substractMplusTWUnThreaded + getMplusTW, AccumulateTVStat.cpp:1379-1399, 964-971:
+ * F[u,c,d] -= (mean[c,d] + sum_i T[i, cD+d] W[u,i]) * N[u,c] */
+void orc_tv_subtract_m_plus_tw(long U, int C, int D, int R, const double *N, double *F, const double *ubm_means,
+                               const double *Tm, const double *W)
+{
+    const size_t SV = (size_t)C * D;
+    double *m = malloc(sizeof(double) * SV);
+    for (long u = 0; u < U; ++u) {
+        for (size_t k = 0; k < SV; ++k) {
+            double v = 0.0;
+            for (int i = 0; i < R; ++i) v += Tm[(size_t)i * SV + k] * W[u * R + i];
+            m[k] = ubm_means[k] + v;
+        }
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < D; ++j) F[u * SV + (size_t)i * D + j] -= m[(size_t)i * D + j] * N[u * C + i];
+    }
+    free(m);
+}
+
+/* TVAcc::normTMatrix, AccumulateTVStat.cpp:1600-1609: T[j,i] *= sqrt(invvar[i]) */
+void orc_tv_norm_t(int C, int D, int R, double *Tm, const double *invvar)
+{
+    const size_t SV = (size_t)C * D;
+    for (size_t i = 0; i < SV; ++i) {
+        const double s = sqrt(invvar[i]);
+        for (int j = 0; j < R; ++j) Tm[(size_t)j * SV + i] *= s;
+    }
+}
+
+/* TVAcc::getWeightedCovUnThreaded, AccumulateTVStat.cpp:2837-2855: W = sum_c weight_c T_c T_c^T (R x R, symmetric) */
+void orc_tv_weighted_cov(int C, int D, int R, const double *Tm, const double *weight, double *Wm)
+{
+    const size_t SV = (size_t)C * D;
+    memset(Wm, 0, sizeof(double) * (size_t)R * R);
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < D; ++k) v += Tm[(size_t)i * SV + (size_t)c * D + k] * Tm[(size_t)j * SV + (size_t)c * D + k];
+                Wm[(size_t)i * R + j] += weight[c] * v;
+            }
+    for (int i = 0; i < R; ++i)
+        for (int j = i; j < R; ++j) Wm[(size_t)i * R + j] = Wm[(size_t)j * R + i];
+}
+
+/* TVAcc::approximateTcTcUnThreaded, AccumulateTVStat.cpp:3116-3136: A_c = T_c^T Q (D x R);
+ * Dm[c,i] += sum_k A_c[k,i]^2 (accumulating like the reference: zero Dm for a fresh result) */
+void orc_tv_approximate_tctc(int C, int D, int R, const double *Tm, const double *Q, double *Dm)
+{
+    const size_t SV = (size_t)C * D;
+    double *A = malloc(sizeof(double) * (size_t)D * R);
+    for (int c = 0; c < C; ++c) {
+        memset(A, 0, sizeof(double) * (size_t)D * R);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < R; ++j)
+                for (int k = 0; k < R; ++k) A[(size_t)i * R + j] += Tm[(size_t)k * SV + (size_t)c * D + i] * Q[(size_t)k * R + j];
+        for (int i = 0; i < R; ++i)
+            for (int k = 0; k < D; ++k) Dm[(size_t)c * R + i] += A[(size_t)k * R + i] * A[(size_t)k * R + i];
+    }
+    free(A);
+}
+
+/* TVAcc::estimateWUbmWeightUnThreaded, AccumulateTVStat.cpp:2348-2396: L_u = I + (sum_c N[u,c]) Wm;
+ * aux = F[u] T^T (T pre-normalised, no invvar); W[u] += L_u^-1 aux.  Wout is accumulated into, like _W. */
+int orc_tv_estimate_w_ubm_weight(long U, int C, int D, int R, const double *N, const double *F, const double *Tm,
+                                 const double *Wm, double *Wout)
+{
+    const size_t SV = (size_t)C * D;
+    double *L = malloc(sizeof(double) * (size_t)R * R), *Li = malloc(sizeof(double) * (size_t)R * R);
+    double *aux = malloc(sizeof(double) * R);
+    int rc = 0;
+    for (long u = 0; u < U && !rc; ++u) {
+        double ns = 0.0;
+        for (int c = 0; c < C; ++c) ns += N[u * C + c];
+        for (int i = 0; i < R; ++i) {
+            for (int j = 0; j < R; ++j) L[(size_t)i * R + j] = ns * Wm[(size_t)i * R + j];
+            L[(size_t)i * R + i] += 1.0;
+        }
+        rc = orc_invert(R, L, Li);
+        for (int i = 0; i < R; ++i) {
+            double v = 0.0;
+            for (size_t k = 0; k < SV; ++k) v += F[u * SV + k] * Tm[(size_t)i * SV + k];
+            aux[i] = v;
+        }
+        for (int i = 0; i < R; ++i)
+            for (int k = 0; k < R; ++k) Wout[u * R + i] += aux[k] * Li[(size_t)i * R + k];
+    }
+    free(L); free(Li); free(aux);
+    return rc;
+}
+
+/* TVAcc::estimateWEigenDecompositionUnThreaded, AccumulateTVStat.cpp:2566-2609:
+ * invL_i = 1 / (1 + sum_c N[u,c] Dm[c,i]); aux = F[u] T^T; appL = Q diag(invL) Q^T; W[u] += appL aux */
+void orc_tv_estimate_w_eigen(long U, int C, int D, int R, const double *N, const double *F, const double *Tm,
+                             const double *Dm, const double *Q, double *Wout)
+{
+    const size_t SV = (size_t)C * D;
+    double *il = malloc(sizeof(double) * R), *aux = malloc(sizeof(double) * R), *app = malloc(sizeof(double) * (size_t)R * R);
+    for (long u = 0; u < U; ++u) {
+        for (int i = 0; i < R; ++i) {
+            double t = 1.0;
+            for (int c = 0; c < C; ++c) t += N[u * C + c] * Dm[(size_t)c * R + i];
+            il[i] = 1 / t;
+        }
+        for (int i = 0; i < R; ++i) {
+            double v = 0.0;
+            for (size_t k = 0; k < SV; ++k) v += F[u * SV + k] * Tm[(size_t)i * SV + k];
+            aux[i] = v;
+        }
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < R; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < R; ++k) v += Q[(size_t)i * R + k] * il[k] * Q[(size_t)j * R + k];
+                app[(size_t)i * R + j] = v;
+            }
+        for (int i = 0; i < R; ++i)
+            for (int k = 0; k < R; ++k) Wout[u * R + i] += aux[k] * app[(size_t)i * R + k];
+    }
+    free(il); free(aux); free(app);
+}
+
+/* PldaModel::preComputation + the first lines of PldaTest::pldaNativeScoring, LIA_SpkTools/src/PldaTools.cpp:2950-2972,
+ * 4494-4496.  F [dim x rf], G [dim x rg], Sigma [dim x dim] (row-major):
+ *   FTJ  = F^T S^-1 - F^T S^-1 G (G^T S^-1 G + I)^-1 G^T S^-1      [rf x dim]
+ *   FTJF = FTJ F                                                    [rf x rf]   */
+static void mm(int M, int N, int K, const double *A, int ta, const double *B, int tb, double *Cm)
+{   /* C[M x N] = op(A) op(B); op(A) is M x K */
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < K; ++k) v += (ta ? A[(size_t)k * M + i] : A[(size_t)i * K + k]) * (tb ? B[(size_t)j * K + k] : B[(size_t)k * N + j]);
+            Cm[(size_t)i * N + j] = v;
+        }
+}
+int orc_plda_precompute(int dim, int rf, int rg, const double *F, const double *G, const double *Sigma, double *FTJ, double *FTJF)
+{
+    double *Si = malloc(sizeof(double) * (size_t)dim * dim), *Ftw = malloc(sizeof(double) * (size_t)rf * dim);
+    int rc = orc_invert(dim, Sigma, Si);
+    mm(rf, dim, dim, F, 1, Si, 0, Ftw);
+    memcpy(FTJ, Ftw, sizeof(double) * (size_t)rf * dim);
+    if (rg > 0 && !rc) {
+        double *Gtw = malloc(sizeof(double) * (size_t)rg * dim), *GtwG = malloc(sizeof(double) * (size_t)rg * rg);
+        double *Mi = malloc(sizeof(double) * (size_t)rg * rg), *FtwG = malloc(sizeof(double) * (size_t)rf * rg);
+        double *t1 = malloc(sizeof(double) * (size_t)rf * rg), *t2 = malloc(sizeof(double) * (size_t)rf * dim);
+        mm(rg, dim, dim, G, 1, Si, 0, Gtw);
+        mm(rg, rg, dim, Gtw, 0, G, 0, GtwG);
+        mm(rf, rg, dim, Ftw, 0, G, 0, FtwG);
+        for (int i = 0; i < rg; ++i) GtwG[(size_t)i * rg + i] += 1.0;
+        rc = orc_invert(rg, GtwG, Mi);
+        mm(rf, rg, rg, FtwG, 0, Mi, 0, t1);
+        mm(rf, dim, rg, t1, 0, Gtw, 0, t2);
+        for (size_t i = 0; i < (size_t)rf * dim; ++i) FTJ[i] -= t2[i];
+        free(Gtw); free(GtwG); free(Mi); free(FtwG); free(t1); free(t2);
+    }
+    mm(rf, rf, dim, FTJ, 0, F, 0, FTJF);
+    free(Si); free(Ftw);
+    return rc;
+}
+
 /* orthonormalizeT: classical Gram-Schmidt over the rows of T, AccumulateTVStat.cpp:1548-1596 */
 void orc_tv_orthonormalize_t(int R, size_t SV, double *Tm)
 {

@@ -349,3 +349,76 @@ def score_plda(models_sum, nsess, segs, FTJF):
                                out.ctypes.data_as(c_dp))
     assert rc == 0
     return out
+
+
+# ---- approximate extractors / PLDA pre-computation ---------------------------------------------
+def tv_norm_statistics(N, F, means, invvar):
+    N, Np = _d(N); F = np.array(F, np.float64, order="C", copy=True); m, mp = _d(means); iv, ivp = _d(invvar)
+    U, C = N.shape
+    D = F.shape[1] // C
+    _lib().orc_tv_norm_statistics(ct.c_long(U), ct.c_int(C), ct.c_int(D), Np, F.ctypes.data_as(c_dp), mp, ivp)
+    return F
+
+
+def tv_subtract_m_plus_tw(N, F, means, Tm, W):
+    N, Np = _d(N); F = np.array(F, np.float64, order="C", copy=True); m, mp = _d(means); Tm, tp = _d(Tm); W, wp = _d(W)
+    U, C = N.shape
+    D = F.shape[1] // C
+    _lib().orc_tv_subtract_m_plus_tw(ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(Tm.shape[0]), Np, F.ctypes.data_as(c_dp), mp, tp, wp)
+    return F
+
+
+def tv_norm_t(Tm, invvar, C):
+    Tm = np.array(Tm, np.float64, order="C", copy=True); iv, ivp = _d(invvar)
+    _lib().orc_tv_norm_t(ct.c_int(C), ct.c_int(Tm.shape[1] // C), ct.c_int(Tm.shape[0]), Tm.ctypes.data_as(c_dp), ivp)
+    return Tm
+
+
+def tv_weighted_cov(Tm, weight):
+    Tm, tp = _d(Tm); w, wp = _d(weight)
+    R = Tm.shape[0]; C = w.shape[0]
+    out = np.zeros((R, R))
+    _lib().orc_tv_weighted_cov(ct.c_int(C), ct.c_int(Tm.shape[1] // C), ct.c_int(R), tp, wp, out.ctypes.data_as(c_dp))
+    return out
+
+
+def tv_approximate_tctc(Tm, Q, C):
+    Tm, tp = _d(Tm); Q, qp = _d(Q)
+    R = Tm.shape[0]
+    out = np.zeros((C, R))
+    _lib().orc_tv_approximate_tctc(ct.c_int(C), ct.c_int(Tm.shape[1] // C), ct.c_int(R), tp, qp, out.ctypes.data_as(c_dp))
+    return out
+
+
+def tv_estimate_w_ubm_weight(N, F, Tm, Wm):
+    N, Np = _d(N); F, Fp = _d(F); Tm, tp = _d(Tm); Wm, wp = _d(Wm)
+    U, C = N.shape
+    R = Tm.shape[0]
+    out = np.zeros((U, R))
+    rc = _lib().orc_tv_estimate_w_ubm_weight(ct.c_long(U), ct.c_int(C), ct.c_int(Tm.shape[1] // C), ct.c_int(R), Np, Fp, tp, wp,
+                                             out.ctypes.data_as(c_dp))
+    assert rc == 0
+    return out
+
+
+def tv_estimate_w_eigen(N, F, Tm, Dm, Q):
+    N, Np = _d(N); F, Fp = _d(F); Tm, tp = _d(Tm); Dm, dp = _d(Dm); Q, qp = _d(Q)
+    U, C = N.shape
+    R = Tm.shape[0]
+    out = np.zeros((U, R))
+    _lib().orc_tv_estimate_w_eigen(ct.c_long(U), ct.c_int(C), ct.c_int(Tm.shape[1] // C), ct.c_int(R), Np, Fp, tp, dp, qp,
+                                   out.ctypes.data_as(c_dp))
+    return out
+
+
+def plda_precompute(F, G, Sigma):
+    F, fp = _d(F); Sigma, sp = _d(Sigma)
+    dim, rf = F.shape
+    if G is None or G.size == 0:
+        rg = 0; G = np.zeros((dim, 1)); gp = G.ctypes.data_as(c_dp)
+    else:
+        G, gp = _d(G); rg = G.shape[1]
+    FTJ = np.zeros((rf, dim)); FTJF = np.zeros((rf, rf))
+    rc = _lib().orc_plda_precompute(ct.c_int(dim), ct.c_int(rf), ct.c_int(rg), fp, gp, sp, FTJ.ctypes.data_as(c_dp), FTJF.ctypes.data_as(c_dp))
+    assert rc == 0
+    return FTJ, FTJF

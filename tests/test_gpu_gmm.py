@@ -320,6 +320,19 @@ def test_tv_stats_stored_logit_path_chunks_of_utterances(ctx, C, D, U, mb):
         assert np.allclose(N.sum(1), lens, rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize("C,D,T", [(128, 60, 300), (37, 13, 65), (2048, 60, 40)])
+def test_posterior_vectors_match_oracle(ctx, C, D, T):
+    """gmmiv_occ = computeAndAccumulateOcc + getOccVect: gamma[t][c], rows sum to 1."""
+    w, mean, iv = make_gmm(C, D, seed=C + 31)
+    x = make_frames(w, mean, iv, T, seed=T + 2)
+    g = ctx.gmm(w, mean, iv)
+    got = g.occ(x)
+    ref = orc.occ(orc.Gmm(w, mean, iv), x.astype(np.float64))
+    assert np.max(np.abs(got - ref)) < 1e-12
+    assert np.allclose(got.sum(1), 1.0, atol=1e-12)
+    assert g.occ(np.zeros((0, D), np.float32)).shape == (0, C)
+
+
 def test_frame_moments(ctx):
     rng = np.random.default_rng(0)
     for T, D in [(1, 60), (1000, 60), (4097, 34), (50, 130)]:

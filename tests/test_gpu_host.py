@@ -146,3 +146,37 @@ def test_computetest_from_files_reproduces_validate_res(tmp_path, golden_dir):
     assert f[:6] == ["M", "test1", "1", "test3", "0", "0.26"] and abs(float(f[6]) - 5.06601) < 5e-5
     assert g[:6] == ["M", "test1", "1", "test3", "0.3", "0.41"] and abs(float(g[6]) - 4.26793) < 5e-5
     assert lines[1].split()[1] == "test2" and abs(float(lines[1].split()[6])) < 1e-12
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_iv_extractor_approximate_modes(mode):
+    """IvExtractorUbmWeigth / IvExtractorEigenDecomposition (IvExtractor.cpp:150-360) through the C++ host layer
+    against the oracle chain; the eigenbasis of mode 2 comes from the host Jacobi solver (any orthonormal
+    eigenbasis of W gives the same D-approximation up to the ordering of its columns)."""
+    from lia_ral_amd import host_capi as host
+    C, D, R, U = 64, 20, 12, 6
+    w, mean, iv = make_gmm(C, D, seed=3)
+    lens = [150, 80, 0, 200, 33, 64]
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=4)
+    rng = np.random.default_rng(9)
+    T = 0.02 * rng.normal(size=(R, C * D))
+    res = host.iv_extract_approx(x, ub, (w, mean, 1.0 / iv), T, mode)
+    utt = np.repeat(np.arange(U), lens)
+    N, F = orc.tv_stats(orc.Gmm(w, mean, iv), x.astype(np.float64), utt, U)
+    Tn = orc.tv_norm_t(T, iv.ravel(), C)
+    Wc = orc.tv_weighted_cov(Tn, w)
+    assert np.max(np.abs(res["Wcov"] - Wc)) < 1e-12 * np.max(np.abs(Wc))
+    Fn = orc.tv_norm_statistics(N, F, mean.ravel(), iv.ravel())
+    if mode == 1:
+        ref = orc.tv_estimate_w_ubm_weight(N, Fn, Tn, Wc)
+    else:
+        Q = res["Q"]
+        assert np.max(np.abs(Q.T @ Q - np.eye(R))) < 1e-12                       # orthonormal
+        lam = np.diag(Q.T @ Wc @ Q)
+        assert np.max(np.abs(Q.T @ Wc @ Q - np.diag(lam))) < 1e-12 * lam.max()   # diagonalises W
+        assert np.all(np.diff(lam) <= 1e-15)                                     # sorted descending
+        Dm = orc.tv_approximate_tctc(Tn, Q, C)
+        assert np.max(np.abs(res["D"] - Dm)) < 1e-11 * np.max(np.abs(Dm))
+        ref = orc.tv_estimate_w_eigen(N, Fn, Tn, Dm, Q)
+    assert np.max(np.abs(res["W"] - ref)) < 1e-9 * max(np.max(np.abs(ref)), 1e-30)

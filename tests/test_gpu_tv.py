@@ -126,3 +126,54 @@ def test_iv_normalisation_and_orthonormalize(ctx):
     assert relerr(Q, Qo) < 1e-10
     keep = [i for i in range(24) if i != 5]
     assert np.allclose(Q[keep] @ Q[keep].T, np.eye(23), atol=1e-10) and not Q[5].any()
+
+
+@pytest.mark.parametrize("U,C,D,R", [(7, 16, 12, 20), (300, 64, 60, 40), (3, 128, 60, 100)])
+def test_approximate_extractors_match_oracle(ctx, U, C, D, R):
+    """IvExtractor modes ubmWeight and eigenDecomposition (AccumulateTVStat.cpp:1225-1242, 1600-1609, 2837-2855,
+    3116-3136, 2348-2396, 2566-2609) and substractMplusTW (:1379-1399) against the oracle."""
+    rng = np.random.default_rng(U + R)
+    SV = C * D
+    N = rng.uniform(0.0, 40.0, (U, C)); F = rng.normal(size=(U, SV)) * 5
+    means = rng.normal(size=SV); iv = rng.uniform(0.5, 2.0, SV); T = 0.05 * rng.normal(size=(R, SV))
+    wgt = rng.dirichlet(np.ones(C)); Wv = rng.normal(size=(U, R))
+    Fn = ctx.tv_norm_statistics(N, F.copy(), means, iv, C, D)
+    assert relerr(Fn, orc.tv_norm_statistics(N, F, means, iv)) < 1e-13
+    Fs = ctx.tv_subtract_m_plus_tw(N, F.copy(), means, T, Wv, C, D)
+    assert relerr(Fs, orc.tv_subtract_m_plus_tw(N, F, means, T, Wv)) < 1e-12
+    Tn = ctx.tv_norm_t(T.copy(), iv, C, D)
+    assert relerr(Tn, orc.tv_norm_t(T, iv, C)) < 1e-14
+    Wm = ctx.tv_weighted_cov(Tn, wgt, C, D)
+    Wo = orc.tv_weighted_cov(Tn, wgt)
+    assert relerr(Wm, Wo) < 1e-12
+    Q = np.linalg.qr(rng.normal(size=(R, R)))[0]
+    Dm = ctx.tv_approximate_tctc(Tn, Q, C, D)
+    Do = orc.tv_approximate_tctc(Tn, Q, C)
+    assert relerr(Dm, Do) < 1e-12
+    assert relerr(ctx.tv_approximate_tctc(Tn, Q, C, D, out=Dm.copy()), 2 * Do) < 1e-12   # accumulates like the reference
+    w1 = ctx.tv_estimate_w_ubm_weight(N, Fn, Tn, Wo, C, D)
+    assert relerr(w1, orc.tv_estimate_w_ubm_weight(N, Fn, Tn, Wo)) < 1e-9
+    w2 = ctx.tv_estimate_w_eigen(N, Fn, Tn, Do, Q, C, D)
+    assert relerr(w2, orc.tv_estimate_w_eigen(N, Fn, Tn, Do, Q)) < 1e-9
+    acc = np.ones((U, R))
+    assert relerr(ctx.tv_estimate_w_eigen(N, Fn, Tn, Do, Q, C, D, out=acc) - 1.0, w2) < 1e-9
+
+
+@pytest.mark.parametrize("dim,rf,rg", [(40, 10, 6), (200, 50, 0), (400, 100, 80)])
+def test_plda_precompute_and_native_scoring(ctx, dim, rf, rg):
+    """PldaModel::preComputation + FTJ / FTJF (PldaTools.cpp:2950-2972, 4494-4496), then the native scoring chain
+    rotateLeft(FTJ) -> pldaScoring against the oracle."""
+    rng = np.random.default_rng(dim)
+    F = rng.normal(size=(dim, rf)) / np.sqrt(dim); G = rng.normal(size=(dim, rg)) / np.sqrt(dim) if rg else None
+    A = rng.normal(size=(dim, dim)); S = A @ A.T / dim + np.eye(dim)
+    FTJ, FTJF = ctx.plda_precompute(F, G, S)
+    oJ, oJF = orc.plda_precompute(F, G, S)
+    assert relerr(FTJ, oJ) < 1e-10 and relerr(FTJF, oJF) < 1e-10
+    M, Sg = 9, 14
+    models = rng.normal(size=(dim, M)); segs = rng.normal(size=(dim, Sg))
+    pm = ctx.iv_normalize(np.ascontiguousarray(models), None, FTJ, length_norm=False)
+    ps = ctx.iv_normalize(np.ascontiguousarray(segs), None, FTJ, length_norm=False)
+    ns = np.array([1, 1, 2, 2, 2, 3, 1, 1, 4])
+    got = ctx.score_plda(np.ascontiguousarray(pm * ns), ns, ps, FTJF)
+    ref = orc.score_plda((oJ @ models) * ns, ns, oJ @ segs, oJF)
+    assert relerr(got, ref) < 1e-9

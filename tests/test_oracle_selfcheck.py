@@ -92,3 +92,40 @@ def test_scoring_against_numpy():
             v = s[:, j] + m[:, i]
             ref[i, j] = 0.5 * (v @ K(L + 1) @ v - m[:, i] @ K(L) @ m[:, i] - s[:, j] @ K(1) @ s[:, j]) + 0.5 * (al(L + 1) - al(L) - al(1))
     assert np.allclose(orc.score_plda(m, nsess, s, FTJF), ref)
+
+
+def test_approximate_extractors_and_plda_precompute_against_numpy():
+    """Independent numpy restatement of the approximate i-vector extractors (AccumulateTVStat.cpp:1225-1242,
+    1379-1399, 1600-1609, 2348-2396, 2566-2609, 2837-2855, 3116-3136) and of PldaModel::preComputation
+    (PldaTools.cpp:2950-2972, 4494-4496); no reference fixture exists for them."""
+    rng = np.random.default_rng(5)
+    U, C, D, R = 5, 6, 4, 7
+    SV = C * D
+    N = rng.uniform(0.1, 30.0, (U, C)); F = rng.normal(size=(U, SV)); means = rng.normal(size=SV)
+    iv = rng.uniform(0.5, 2.0, SV); T = 0.3 * rng.normal(size=(R, SV)); W = rng.normal(size=(U, R)); wgt = rng.dirichlet(np.ones(C))
+    Nrep = np.repeat(N, D, axis=1)
+    assert np.allclose(orc.tv_norm_statistics(N, F, means, iv), (F - means * Nrep) * np.sqrt(iv), rtol=1e-13, atol=1e-13)
+    assert np.allclose(orc.tv_subtract_m_plus_tw(N, F, means, T, W), F - (means + W @ T) * Nrep, rtol=1e-12, atol=1e-12)
+    Tn = orc.tv_norm_t(T, iv, C)
+    assert np.allclose(Tn, T * np.sqrt(iv), rtol=1e-14)
+    Wm = orc.tv_weighted_cov(Tn, wgt)
+    assert np.allclose(Wm, (Tn * np.repeat(wgt, D)) @ Tn.T, rtol=1e-12, atol=1e-14)
+    Q = np.linalg.qr(rng.normal(size=(R, R)))[0]
+    Dm = orc.tv_approximate_tctc(Tn, Q, C)
+    ref = np.stack([((Tn[:, c * D:(c + 1) * D].T @ Q) ** 2).sum(0) for c in range(C)])
+    assert np.allclose(Dm, ref, rtol=1e-12)
+    Fn = orc.tv_norm_statistics(N, F, means, iv)
+    w1 = orc.tv_estimate_w_ubm_weight(N, Fn, Tn, Wm)
+    ref1 = np.stack([np.linalg.solve(np.eye(R) + N[u].sum() * Wm, Tn @ Fn[u]) for u in range(U)])
+    assert np.allclose(w1, ref1, rtol=1e-10, atol=1e-12)
+    w2 = orc.tv_estimate_w_eigen(N, Fn, Tn, Dm, Q)
+    ref2 = np.stack([Q @ ((Q.T @ (Tn @ Fn[u])) / (1.0 + N[u] @ Dm)) for u in range(U)])
+    assert np.allclose(w2, ref2, rtol=1e-10, atol=1e-12)
+    dim, rf, rg = 9, 4, 3
+    Fm = rng.normal(size=(dim, rf)); G = rng.normal(size=(dim, rg)); A = rng.normal(size=(dim, dim)); S = A @ A.T + dim * np.eye(dim)
+    FTJ, FTJF = orc.plda_precompute(Fm, G, S)
+    Si = np.linalg.inv(S)
+    ref = Fm.T @ Si - Fm.T @ Si @ G @ np.linalg.inv(G.T @ Si @ G + np.eye(rg)) @ G.T @ Si
+    assert np.allclose(FTJ, ref, rtol=1e-10, atol=1e-12) and np.allclose(FTJF, ref @ Fm, rtol=1e-10, atol=1e-12)
+    FTJ0, _ = orc.plda_precompute(Fm, None, S)
+    assert np.allclose(FTJ0, Fm.T @ Si, rtol=1e-10, atol=1e-12)
