@@ -208,6 +208,35 @@ int gmmiv_tv_estimate_w_eigen(gmmiv_ctx *ctx, int64_t U, int C, int D, int R, co
 int gmmiv_iv_normalize(gmmiv_ctx *ctx, int dim_in, int dim_out, int64_t n, const double *X,
                        const double *mean, const double *M, int length_norm, double *Y);
 
+/* ---- i-vector back-end estimation on a development set: PldaDev (LIA_SpkTools/src/PldaTools.cpp) ----------------
+ * X [dim x n], one vector per column like PldaDev::_data; sessions are grouped by speaker and
+ * sessions_per_speaker[nspk] (host array, PldaDev::_session_per_speaker) gives the group sizes (sum = n, all > 0).
+ *   gmmiv_dev_means        computeAll                 :353-387   mean[dim], spk_means[dim x nspk]
+ *   gmmiv_dev_cov_mat      computeCovMat              :527-566   Sigma, W, B [dim x dim], all divided by n
+ *   gmmiv_dev_wccn_chol    computeWccnChol            :1124-1176 upperCholesky((mean_c cov_c / n_c)^-1)
+ *   gmmiv_dev_mahalanobis  computeMahalanobis         :1366-1378 W^-1
+ *   gmmiv_dev_scatter_mat  computeScatterMat          :1610-1644 as written in the reference (SB unweighted and
+ *                          unnormalised; SW = matrix of the LAST speaker, built from the first n_c sessions of the set)
+ *   gmmiv_sym_eigen        computeEigenProblem        :1490-1535 for a SYMMETRIC matrix: vect[n x rank] (columns =
+ *                          eigenvectors), val[rank] descending (host Jacobi; the reference calls Eigen / LAPACK)
+ *   gmmiv_dev_efr_matrix   sphericalNuisanceNormalization :1852-1902: (V diag(lambda^-1/2))^T of Sigma (EFR) or W (sphNorm)
+ *   gmmiv_dev_lda          computeLDA                 :1381-1413 rank leading eigenvectors (unit norm) of W^-1 B as rows
+ * Any null output pointer is skipped.  The O(dim^3) pieces (eigen problems, the WCCN Cholesky) run on the host like
+ * the reference's; the O(dim^2 n) covariance GEMMs run on the device. */
+int gmmiv_dev_means(gmmiv_ctx *ctx, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sessions_per_speaker,
+                    double *mean, double *spk_means);
+int gmmiv_dev_cov_mat(gmmiv_ctx *ctx, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sessions_per_speaker,
+                      double *Sigma, double *W, double *B);
+int gmmiv_dev_wccn_chol(gmmiv_ctx *ctx, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sessions_per_speaker,
+                        double *WCCN);
+int gmmiv_dev_mahalanobis(gmmiv_ctx *ctx, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sessions_per_speaker,
+                          double *M);
+int gmmiv_dev_scatter_mat(gmmiv_ctx *ctx, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sessions_per_speaker,
+                          double *SB, double *SW);
+int gmmiv_sym_eigen(gmmiv_ctx *ctx, int n, const double *A, int rank, double *vect, double *val);
+int gmmiv_dev_efr_matrix(gmmiv_ctx *ctx, int dim, const double *Cov, double *M);
+int gmmiv_dev_lda(gmmiv_ctx *ctx, int dim, const double *W, const double *B, int rank, double *ldaMat, double *eigval);
+
 /* PldaModel::preComputation + FTJ / FTJF of pldaNativeScoring (PldaTools.cpp:2950-2972, 4494-4496):
  *   FTJ[rf x dim] = F^T S^-1 - F^T S^-1 G (G^T S^-1 G + I)^-1 G^T S^-1,  FTJF[rf x rf] = FTJ F
  * F [dim x rf], G [dim x rg] (rg may be 0), Sigma [dim x dim] symmetric positive definite, all row-major.

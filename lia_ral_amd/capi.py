@@ -199,6 +199,58 @@ class Context:
         _chk(lib.gmmiv_tv_estimate_w_eigen(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(Dm), _ptr(Q), _ptr(out)))
         return out
 
+    # ---- PldaDev: back-end estimation on a development set X[dim, n], sessions grouped by speaker
+    def _dev_args(self, X, sps):
+        sps = np.ascontiguousarray(sps, dtype=np.int64)
+        return X.shape[0], ct.c_int64(X.shape[1]), _ptr(X), ct.c_int64(len(sps)), sps.ctypes.data_as(ct.c_void_p), sps
+
+    def dev_means(self, X, sps):
+        dim, n, xp, k, sp, keep = self._dev_args(X, sps)
+        mean = np.empty(dim); sm = np.empty((dim, len(keep)))
+        _chk(lib.gmmiv_dev_means(self._h, dim, n, xp, k, sp, _ptr(mean), _ptr(sm)))
+        return mean, sm
+
+    def dev_cov_mat(self, X, sps):
+        dim, n, xp, k, sp, keep = self._dev_args(X, sps)
+        S = np.empty((dim, dim)); W = np.empty((dim, dim)); B = np.empty((dim, dim))
+        _chk(lib.gmmiv_dev_cov_mat(self._h, dim, n, xp, k, sp, _ptr(S), _ptr(W), _ptr(B)))
+        return S, W, B
+
+    def dev_wccn_chol(self, X, sps):
+        dim, n, xp, k, sp, keep = self._dev_args(X, sps)
+        out = np.empty((dim, dim))
+        _chk(lib.gmmiv_dev_wccn_chol(self._h, dim, n, xp, k, sp, _ptr(out)))
+        return out
+
+    def dev_mahalanobis(self, X, sps):
+        dim, n, xp, k, sp, keep = self._dev_args(X, sps)
+        out = np.empty((dim, dim))
+        _chk(lib.gmmiv_dev_mahalanobis(self._h, dim, n, xp, k, sp, _ptr(out)))
+        return out
+
+    def dev_scatter_mat(self, X, sps):
+        dim, n, xp, k, sp, keep = self._dev_args(X, sps)
+        SB = np.empty((dim, dim)); SW = np.empty((dim, dim))
+        _chk(lib.gmmiv_dev_scatter_mat(self._h, dim, n, xp, k, sp, _ptr(SB), _ptr(SW)))
+        return SB, SW
+
+    def sym_eigen(self, A, rank=None):
+        n = A.shape[0]; rank = n if rank is None else rank
+        vect = np.empty((n, rank)); val = np.empty(rank)
+        _chk(lib.gmmiv_sym_eigen(self._h, n, _ptr(_f64(A)), rank, _ptr(vect), _ptr(val)))
+        return vect, val
+
+    def dev_efr_matrix(self, Cov):
+        out = np.empty_like(Cov)
+        _chk(lib.gmmiv_dev_efr_matrix(self._h, Cov.shape[0], _ptr(_f64(Cov)), _ptr(out)))
+        return out
+
+    def dev_lda(self, W, B, rank):
+        dim = W.shape[0]
+        out = np.empty((rank, dim)); val = np.empty(rank)
+        _chk(lib.gmmiv_dev_lda(self._h, dim, _ptr(_f64(W)), _ptr(_f64(B)), rank, _ptr(out), _ptr(val)))
+        return out, val
+
     def plda_precompute(self, F, G, Sigma):
         """-> (FTJ [rf x dim], FTJF [rf x rf]); G may be None."""
         dim, rf = F.shape

@@ -1,5 +1,6 @@
 // capi_tv.hip -- C ABI (include/gmmiv.h): total-variability (i-vector) maths and i-vector scoring.
 #include <math.h>
+#include <string.h>
 
 #include <map>
 
@@ -51,6 +52,66 @@ bool host_spd_inverse(int n, const std::vector<double> &a, std::vector<double> &
             inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = s;
         }
     return true;
+}
+
+// cyclic Jacobi for a symmetric matrix (host): eigenvalues descending, vect[k*rank + j] = component k of vector j
+void host_sym_eigen(int n, const std::vector<double> &A, int rank, std::vector<double> &vect, std::vector<double> &val)
+{
+    std::vector<double> a(A), v((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; ++i) {
+            dg += a[(size_t)i * n + i] * a[(size_t)i * n + i];
+            for (int j = i + 1; j < n; ++j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+        }
+        if (off <= 1e-30 * (dg + off)) break;
+        for (int p = 0; p + 1 < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double th = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) { const double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q]; a[(size_t)k * n + p] = cs * x - sn * y; a[(size_t)k * n + q] = sn * x + cs * y; }
+                for (int k = 0; k < n; ++k) { const double x = a[(size_t)p * n + k], y = a[(size_t)q * n + k]; a[(size_t)p * n + k] = cs * x - sn * y; a[(size_t)q * n + k] = sn * x + cs * y; }
+                for (int k = 0; k < n; ++k) { const double x = v[(size_t)k * n + p], y = v[(size_t)k * n + q]; v[(size_t)k * n + p] = cs * x - sn * y; v[(size_t)k * n + q] = sn * x + cs * y; }
+            }
+    }
+    std::vector<int> ord(n);
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    for (int i = 1; i < n; ++i) { // stable insertion sort, descending
+        const int o = ord[i];
+        int j = i - 1;
+        while (j >= 0 && a[(size_t)ord[j] * n + ord[j]] < a[(size_t)o * n + o]) { ord[j + 1] = ord[j]; --j; }
+        ord[j + 1] = o;
+    }
+    vect.assign((size_t)n * rank, 0.0);
+    val.assign(rank, 0.0);
+    for (int j = 0; j < rank; ++j) {
+        val[j] = a[(size_t)ord[j] * n + ord[j]];
+        for (int k = 0; k < n; ++k) vect[(size_t)k * rank + j] = v[(size_t)k * n + ord[j]];
+    }
+}
+
+// host copy of a host-or-device array / store of a host vector into a host-or-device array
+int fetch_host(gmmiv_ctx *c, const double *p, size_t n, std::vector<double> &out)
+{
+    out.resize(n);
+    if (gmmiv_is_device_ptr(p)) {
+        GCHK(hipMemcpyAsync(out.data(), p, n * 8, hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+    } else memcpy(out.data(), p, n * 8);
+    return GMMIV_OK;
+}
+int store_out(gmmiv_ctx *c, double *p, const std::vector<double> &v)
+{
+    if (!p) return GMMIV_OK;
+    if (gmmiv_is_device_ptr(p)) {
+        GCHK(hipMemcpyAsync(p, v.data(), v.size() * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+    } else memcpy(p, v.data(), v.size() * 8);
+    return GMMIV_OK;
 }
 
 int check_status(gmmiv_ctx *c, int *dstatus, int nb, const char *what)
@@ -635,6 +696,228 @@ int gmmiv_score_twocov(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double
     GCHK(tvk_axpby(c->stream, (long)nn, 1.0, g.d, -1.0, h.d, GmH));
     if ((rc = quad_score(c, a, dim, M, S, g.d, 1.0, GmH, 1.0, GmH, 1.0, 0.0))) return rc;
     return a.sc.finish();
+}
+
+// ---- PldaDev: development-set statistics ---------------------------------------------------------
+namespace {
+struct DevSet { // device views shared by the gmmiv_dev_* entry points
+    DevIn<double> x;
+    long *off = nullptr;   // [nspk + 1] session offsets
+    int *cls = nullptr;    // [n] speaker of each session
+    double *ssum = nullptr, *mean = nullptr, *smean = nullptr;
+    std::vector<long> hoff;
+    int init(gmmiv_ctx *c, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sps, const char *what)
+    {
+        if (!c || dim <= 0 || n <= 0 || nspk <= 0 || !X || !sps) { gmmiv_set_error("%s: bad argument", what); return GMMIV_ERR_ARG; }
+        if (gmmiv_is_device_ptr(sps)) { gmmiv_set_error("%s: sessions_per_speaker must be a host array", what); return GMMIV_ERR_ARG; }
+        GCHK(hipSetDevice(c->device));
+        hoff.assign(nspk + 1, 0);
+        for (int64_t i = 0; i < nspk; ++i) {
+            if (sps[i] <= 0) { gmmiv_set_error("%s: speaker %ld has no session", what, (long)i); return GMMIV_ERR_ARG; }
+            hoff[i + 1] = hoff[i] + (long)sps[i];
+        }
+        if (hoff[nspk] != n) { gmmiv_set_error("%s: sessions_per_speaker sums to %ld, n = %ld", what, hoff[nspk], (long)n); return GMMIV_ERR_ARG; }
+        std::vector<int> hc(n);
+        for (int64_t i = 0; i < nspk; ++i) for (long s = hoff[i]; s < hoff[i + 1]; ++s) hc[s] = (int)i;
+        int rc;
+        if ((rc = x.init(c, WS_T0, X, (size_t)dim * n))) return rc;
+        void *p;
+        if ((rc = c->scratch(WS_SEG, (nspk + 1) * sizeof(long) + n * sizeof(int), &p))) return rc;
+        off = (long *)p; cls = (int *)(off + nspk + 1);
+        GCHK(hipMemcpyAsync(off, hoff.data(), (nspk + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
+        GCHK(hipMemcpyAsync(cls, hc.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        GCHK(hipStreamSynchronize(c->stream)); // hc is a stack-lifetime vector
+        if ((rc = c->scratch(WS_T1, ((size_t)2 * dim * nspk + dim) * 8, &p))) return rc;
+        ssum = (double *)p; smean = ssum + (size_t)dim * nspk; mean = smean + (size_t)dim * nspk;
+        GCHK(tvk_dev_means(c->stream, dim, (long)n, x.d, (long)nspk, off, ssum, mean, smean));
+        return GMMIV_OK;
+    }
+};
+// out[dim x dim] = alpha * Y Y^T for Y [dim x m] (row-major, ld = m)
+int dev_gram(gmmiv_ctx *c, int dim, long m, const double *Y, double alpha, double *out)
+{
+    const int nz = tvk_splitk_count(dim, dim, (int)m, c->n_cu);
+    void *p;
+    int rc;
+    if ((rc = c->scratch(WS_SLAB, (size_t)nz * dim * dim * 8, &p))) return rc;
+    GCHK(tvk_dgemm_splitk(c->stream, false, true, dim, dim, (int)m, alpha, Y, m, Y, m, 0.0, out, dim, nz, (double *)p));
+    return GMMIV_OK;
+}
+} // namespace
+
+int gmmiv_dev_means(gmmiv_ctx *c, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sps, double *mean, double *spk_means)
+{
+    DevSet ds;
+    int rc = ds.init(c, dim, n, X, nspk, sps, "dev_means");
+    if (rc) return rc;
+    DevOut<double> o_m, o_s;
+    if ((rc = o_m.init(c, WS_T2, mean, dim, false)) || (rc = o_s.init(c, WS_T3, spk_means, (size_t)dim * nspk, false))) return rc;
+    if (mean) GCHK(hipMemcpyAsync(o_m.d, ds.mean, dim * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (spk_means) GCHK(hipMemcpyAsync(o_s.d, ds.smean, (size_t)dim * nspk * 8, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = o_m.finish())) return rc;
+    return o_s.finish();
+}
+
+int gmmiv_dev_cov_mat(gmmiv_ctx *c, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sps, double *Sigma, double *W, double *B)
+{
+    DevSet ds;
+    int rc = ds.init(c, dim, n, X, nspk, sps, "dev_cov_mat");
+    if (rc) return rc;
+    const size_t dd = (size_t)dim * dim;
+    DevOut<double> o_s, o_w, o_b;
+    if ((rc = o_s.init(c, WS_T2, Sigma, dd, false)) || (rc = o_w.init(c, WS_T3, W, dd, false)) || (rc = o_b.init(c, WS_T4, B, dd, false))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)dim * (n > nspk ? n : nspk) * 8, &p))) return rc;
+    double *Y = (double *)p;
+    const double inv_n = 1.0 / (double)n;
+    if (Sigma) {
+        GCHK(tvk_dev_center(c->stream, dim, (long)n, 0, ds.x.d, ds.mean, ds.smean, (long)nspk, ds.off, ds.cls, Y));
+        if ((rc = dev_gram(c, dim, (long)n, Y, inv_n, o_s.d))) return rc;
+    }
+    if (W) {
+        GCHK(tvk_dev_center(c->stream, dim, (long)n, 1, ds.x.d, ds.mean, ds.smean, (long)nspk, ds.off, ds.cls, Y));
+        if ((rc = dev_gram(c, dim, (long)n, Y, inv_n, o_w.d))) return rc;
+    }
+    if (B) {
+        GCHK(tvk_dev_between(c->stream, dim, (long)nspk, 1, ds.mean, ds.smean, ds.off, Y));
+        if ((rc = dev_gram(c, dim, (long)nspk, Y, inv_n, o_b.d))) return rc;
+    }
+    if ((rc = o_s.finish()) || (rc = o_w.finish())) return rc;
+    return o_b.finish();
+}
+
+int gmmiv_dev_mahalanobis(gmmiv_ctx *c, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sps, double *M)
+{
+    if (!M) { gmmiv_set_error("dev_mahalanobis: bad argument"); return GMMIV_ERR_ARG; }
+    DevSet ds;
+    int rc = ds.init(c, dim, n, X, nspk, sps, "dev_mahalanobis");
+    if (rc) return rc;
+    DevOut<double> o;
+    if ((rc = o.init(c, WS_T2, M, (size_t)dim * dim, false))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)dim * n * 8, &p))) return rc;
+    InvWs ws;
+    if ((rc = ws.init(c, dim, 1))) return rc;
+    GCHK(tvk_dev_center(c->stream, dim, (long)n, 1, ds.x.d, ds.mean, ds.smean, (long)nspk, ds.off, ds.cls, (double *)p));
+    if ((rc = dev_gram(c, dim, (long)n, (double *)p, 1.0 / (double)n, ws.full))) return rc;
+    GCHK(hipMemsetAsync(ws.status, 0, sizeof(int), c->stream));
+    GCHK(tvk_spd_inverse_batched(c->stream, dim, 1, ws.full, o.d, ws.X, ws.invd, ws.panel, ws.status));
+    if ((rc = check_status(c, ws.status, 1, "dev_mahalanobis: W"))) return rc;
+    return o.finish();
+}
+
+int gmmiv_dev_wccn_chol(gmmiv_ctx *c, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sps, double *WCCN)
+{
+    if (!WCCN) { gmmiv_set_error("dev_wccn_chol: bad argument"); return GMMIV_ERR_ARG; }
+    DevSet ds;
+    int rc = ds.init(c, dim, n, X, nspk, sps, "dev_wccn_chol");
+    if (rc) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)dim * n * 8, &p))) return rc;
+    InvWs ws;
+    if ((rc = ws.init(c, dim, 1))) return rc;
+    GCHK(tvk_dev_center(c->stream, dim, (long)n, 2, ds.x.d, ds.mean, ds.smean, (long)nspk, ds.off, ds.cls, (double *)p));
+    if ((rc = dev_gram(c, dim, (long)n, (double *)p, 1.0 / (double)nspk, ws.full))) return rc;
+    GCHK(hipMemsetAsync(ws.status, 0, sizeof(int), c->stream));
+    GCHK(tvk_spd_inverse_batched(c->stream, dim, 1, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+    if ((rc = check_status(c, ws.status, 1, "dev_wccn_chol: W"))) return rc;
+    std::vector<double> iw, ch; // upperCholesky on the host (O(dim^3) once, like min-divergence)
+    if ((rc = fetch_host(c, ws.inv, (size_t)dim * dim, iw))) return rc;
+    if (!host_cholesky_upper(dim, iw, ch)) { gmmiv_set_error("dev_wccn_chol: W^-1 is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    return store_out(c, WCCN, ch);
+}
+
+int gmmiv_dev_scatter_mat(gmmiv_ctx *c, int dim, int64_t n, const double *X, int64_t nspk, const int64_t *sps, double *SB, double *SW)
+{
+    DevSet ds;
+    int rc = ds.init(c, dim, n, X, nspk, sps, "dev_scatter_mat");
+    if (rc) return rc;
+    const size_t dd = (size_t)dim * dim;
+    DevOut<double> o_b, o_w;
+    if ((rc = o_b.init(c, WS_T2, SB, dd, false)) || (rc = o_w.init(c, WS_T3, SW, dd, false))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)dim * (n > nspk ? n : nspk) * 8, &p))) return rc;
+    double *Y = (double *)p;
+    if (SB) {
+        GCHK(tvk_dev_between(c->stream, dim, (long)nspk, 0, ds.mean, ds.smean, ds.off, Y));
+        if ((rc = dev_gram(c, dim, (long)nspk, Y, 1.0, o_b.d))) return rc;
+    }
+    if (SW) { // the reference's loop: the first n_last sessions of the set, centred per speaker, / n_last
+        const long nl = (long)sps[nspk - 1];
+        GCHK(tvk_dev_center(c->stream, dim, (long)n, 1, ds.x.d, ds.mean, ds.smean, (long)nspk, ds.off, ds.cls, Y));
+        const int nz = tvk_splitk_count(dim, dim, (int)nl, c->n_cu);
+        if ((rc = c->scratch(WS_SLAB, (size_t)nz * dd * 8, &p))) return rc;
+        GCHK(tvk_dgemm_splitk(c->stream, false, true, dim, dim, (int)nl, 1.0 / (double)nl, Y, (long)n, Y, (long)n, 0.0, o_w.d, dim, nz, (double *)p));
+    }
+    if ((rc = o_b.finish())) return rc;
+    return o_w.finish();
+}
+
+int gmmiv_sym_eigen(gmmiv_ctx *c, int n, const double *A, int rank, double *vect, double *val)
+{
+    if (!c || n <= 0 || rank <= 0 || rank > n || !A) { gmmiv_set_error("sym_eigen: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    std::vector<double> a, v, l;
+    int rc;
+    if ((rc = fetch_host(c, A, (size_t)n * n, a))) return rc;
+    host_sym_eigen(n, a, rank, v, l);
+    if ((rc = store_out(c, vect, v))) return rc;
+    return store_out(c, val, l);
+}
+
+int gmmiv_dev_efr_matrix(gmmiv_ctx *c, int dim, const double *Cov, double *M)
+{
+    if (!c || dim <= 0 || !Cov || !M) { gmmiv_set_error("dev_efr_matrix: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    std::vector<double> a, v, l, m((size_t)dim * dim);
+    int rc;
+    if ((rc = fetch_host(c, Cov, (size_t)dim * dim, a))) return rc;
+    host_sym_eigen(dim, a, dim, v, l);
+    for (int j = 0; j < dim; ++j) {
+        if (!(l[j] > 0.0)) { gmmiv_set_error("dev_efr_matrix: eigenvalue %d = %g is not positive", j, l[j]); return GMMIV_ERR_NUMERIC; }
+        for (int k = 0; k < dim; ++k) m[(size_t)j * dim + k] = v[(size_t)k * dim + j] / sqrt(l[j]);
+    }
+    return store_out(c, M, m);
+}
+
+int gmmiv_dev_lda(gmmiv_ctx *c, int dim, const double *W, const double *B, int rank, double *ldaMat, double *eigval)
+{
+    if (!c || dim <= 0 || rank <= 0 || rank > dim || !W || !B || !ldaMat) { gmmiv_set_error("dev_lda: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    std::vector<double> w, b, U;
+    int rc;
+    if ((rc = fetch_host(c, W, (size_t)dim * dim, w)) || (rc = fetch_host(c, B, (size_t)dim * dim, b))) return rc;
+    if (!host_cholesky_upper(dim, w, U)) { gmmiv_set_error("dev_lda: W is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    // symmetric form of W^-1 B: Cm = L^-1 B L^-T with W = L L^T, L = U^T
+    std::vector<double> T1((size_t)dim * dim), Cm((size_t)dim * dim), vect, val, out((size_t)rank * dim);
+    for (int j = 0; j < dim; ++j)
+        for (int i = 0; i < dim; ++i) {
+            double v = b[(size_t)i * dim + j];
+            for (int k = 0; k < i; ++k) v -= U[(size_t)k * dim + i] * T1[(size_t)k * dim + j];
+            T1[(size_t)i * dim + j] = v / U[(size_t)i * dim + i];
+        }
+    for (int j = 0; j < dim; ++j)
+        for (int i = 0; i < dim; ++i) {
+            double v = T1[(size_t)j * dim + i];
+            for (int k = 0; k < i; ++k) v -= U[(size_t)k * dim + i] * Cm[(size_t)j * dim + k];
+            Cm[(size_t)j * dim + i] = v / U[(size_t)i * dim + i];
+        }
+    for (int i = 0; i < dim; ++i)
+        for (int j = i + 1; j < dim; ++j) { const double m = 0.5 * (Cm[(size_t)i * dim + j] + Cm[(size_t)j * dim + i]); Cm[(size_t)i * dim + j] = Cm[(size_t)j * dim + i] = m; }
+    host_sym_eigen(dim, Cm, rank, vect, val);
+    for (int j = 0; j < rank; ++j) { // v = U^-1 y, unit norm (Eigen::EigenSolver normalises its eigenvectors)
+        double nrm = 0.0;
+        for (int i = dim - 1; i >= 0; --i) {
+            double v = vect[(size_t)i * rank + j];
+            for (int k = i + 1; k < dim; ++k) v -= U[(size_t)i * dim + k] * out[(size_t)j * dim + k];
+            out[(size_t)j * dim + i] = v / U[(size_t)i * dim + i];
+        }
+        for (int i = 0; i < dim; ++i) nrm += out[(size_t)j * dim + i] * out[(size_t)j * dim + i];
+        nrm = sqrt(nrm);
+        for (int i = 0; i < dim; ++i) out[(size_t)j * dim + i] /= nrm;
+    }
+    if ((rc = store_out(c, ldaMat, out))) return rc;
+    return store_out(c, eigval, val);
 }
 
 int gmmiv_plda_precompute(gmmiv_ctx *c, int dim, int rf, int rg, const double *Fm, const double *Gm, const double *Sigma, double *FTJ,

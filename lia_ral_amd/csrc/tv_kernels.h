@@ -35,3 +35,7 @@ int tvk_block_colnorm(hipStream_t st, int C, int D, int R, const double *A, doub
 int tvk_build_l_ubm(hipStream_t st, int R, int C, int nb, const double *N, const double *Wm, double *full);
 int tvk_mul_recip1p(hipStream_t st, long n, double *B, const double *X);
 int tvk_add_identity(hipStream_t st, int n, double *A);
+int tvk_dev_means(hipStream_t st, int dim, long n, const double *X, long nspk, const long *off, double *ssum, double *mean, double *smean);
+int tvk_dev_center(hipStream_t st, int dim, long n, int mode, const double *X, const double *mean, const double *smean, long nspk,
+                   const long *off, const int *cls, double *out);
+int tvk_dev_between(hipStream_t st, int dim, long nspk, int weighted, const double *mean, const double *smean, const long *off, double *out);

@@ -533,6 +533,77 @@ __global__ void k_add_identity(int n, double *__restrict__ A)
     if (i < n) A[(size_t)i * n + i] += 1.0;
 }
 
+// ---- development-set statistics (PldaDev): X [dim x n], one vector per column, sessions grouped by speaker ----
+// ssum[k, c] = sum of row k over the sessions of speaker c (off[c] .. off[c+1])
+__global__ void k_dev_spk_sums(int dim, long n, const double *__restrict__ X, long nspk, const long *__restrict__ off,
+                               double *__restrict__ ssum)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)dim * nspk) return;
+    const long k = e / nspk, c = e - k * nspk;
+    double s = 0.0;
+    for (long j = off[c]; j < off[c + 1]; ++j) s += X[k * n + j];
+    ssum[e] = s;
+}
+// mean[k] = sum_c ssum[k,c] / n ; smean[k,c] = ssum[k,c] / count_c
+__global__ void k_dev_means(int dim, long n, long nspk, const long *__restrict__ off, const double *__restrict__ ssum,
+                            double *__restrict__ mean, double *__restrict__ smean)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= dim) return;
+    double s = 0.0;
+    for (long c = 0; c < nspk; ++c) {
+        const double v = ssum[(size_t)k * nspk + c];
+        s += v;
+        smean[(size_t)k * nspk + c] = v / (double)(off[c + 1] - off[c]);
+    }
+    mean[k] = s / (double)n;
+}
+// mode 0: out = X - mean ; 1: out = X - smean[class] ; 2: out = (X - smean[class]) / sqrt(count[class])
+__global__ void k_dev_center(int dim, long n, int mode, const double *__restrict__ X, const double *__restrict__ mean,
+                             const double *__restrict__ smean, long nspk, const long *__restrict__ off, const int *__restrict__ cls,
+                             double *__restrict__ out)
+{
+    const long tot = (long)dim * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const long k = e / n, s = e - k * n;
+        if (mode == 0) out[e] = X[e] - mean[k];
+        else {
+            const int c = cls[s];
+            const double v = X[e] - smean[(size_t)k * nspk + c];
+            out[e] = mode == 1 ? v : v / sqrt((double)(off[c + 1] - off[c]));
+        }
+    }
+}
+// out[k,c] = (smean[k,c] - mean[k]) * (weighted ? sqrt(count_c) : 1)
+__global__ void k_dev_between(int dim, long nspk, int weighted, const double *__restrict__ mean, const double *__restrict__ smean,
+                              const long *__restrict__ off, double *__restrict__ out)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)dim * nspk) return;
+    const long k = e / nspk, c = e - k * nspk;
+    out[e] = (smean[e] - mean[k]) * (weighted ? sqrt((double)(off[c + 1] - off[c])) : 1.0);
+}
+int tvk_dev_means(hipStream_t st, int dim, long n, const double *X, long nspk, const long *off, double *ssum, double *mean, double *smean)
+{
+    k_dev_spk_sums<<<(unsigned)(((long)dim * nspk + 255) / 256), 256, 0, st>>>(dim, n, X, nspk, off, ssum);
+    k_dev_means<<<(dim + 255) / 256, 256, 0, st>>>(dim, n, nspk, off, ssum, mean, smean);
+    return (int)hipGetLastError();
+}
+static unsigned ew_blocks(long n);
+int tvk_dev_center(hipStream_t st, int dim, long n, int mode, const double *X, const double *mean, const double *smean, long nspk,
+                   const long *off, const int *cls, double *out)
+{
+    if (n <= 0) return 0;
+    k_dev_center<<<ew_blocks((long)dim * n), 256, 0, st>>>(dim, n, mode, X, mean, smean, nspk, off, cls, out);
+    return (int)hipGetLastError();
+}
+int tvk_dev_between(hipStream_t st, int dim, long nspk, int weighted, const double *mean, const double *smean, const long *off, double *out)
+{
+    k_dev_between<<<(unsigned)(((long)dim * nspk + 255) / 256), 256, 0, st>>>(dim, nspk, weighted, mean, smean, off, out);
+    return (int)hipGetLastError();
+}
+
 static unsigned ew_blocks(long n) { long b = (n + 255) / 256; return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 int tvk_norm_stats(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means, const double *invvar)
 {

@@ -168,6 +168,29 @@ int liagpu_iv_extract_approx(int device, int mode, const float *x, long T, int D
     })
 }
 
+// PldaDev::sphericalNuisanceNormalization (PldaTools.cpp:1822-1929): EFR (sph_norm 0) / sphNorm (1) training on a
+// development set X [dim x n] (normalised in place); mats [nb_it x dim x dim], means [nb_it x dim].  Optional
+// outputs after the last iteration: the WCCN Cholesky factor, the Mahalanobis matrix and lda_rank LDA rows.
+int liagpu_backend_train(int device, int dim, long n, double *X, long nspk, const long *sps, int sph_norm, int nb_it, double *mats,
+                         double *means, double *wccn, double *mahalanobis, int lda_rank, double *lda)
+{
+    GUARD({
+        GpuServer srv(device);
+        PldaDev dev(srv, (unsigned long)dim, std::vector<double>(X, X + (size_t)dim * n), std::vector<unsigned long>(sps, sps + nspk));
+        std::vector<std::vector<double> > M, mu;
+        dev.sphericalNuisanceNormalization((unsigned long)nb_it, sph_norm != 0, M, mu);
+        for (int it = 0; it < nb_it; ++it) {
+            memcpy(mats + (size_t)it * dim * dim, M[it].data(), (size_t)dim * dim * sizeof(double));
+            memcpy(means + (size_t)it * dim, mu[it].data(), (size_t)dim * sizeof(double));
+        }
+        memcpy(X, dev.getData().data(), (size_t)dim * n * sizeof(double));
+        std::vector<double> t;
+        if (wccn) { dev.computeWccnChol(t); memcpy(wccn, t.data(), t.size() * sizeof(double)); }
+        if (mahalanobis) { dev.computeMahalanobis(t); memcpy(mahalanobis, t.data(), t.size() * sizeof(double)); }
+        if (lda && lda_rank > 0) { dev.computeLDA(t, (unsigned long)lda_rank); memcpy(lda, t.data(), t.size() * sizeof(double)); }
+    })
+}
+
 // TotalVariability (TotalVariability.cpp:118-169): nbIt iterations on precomputed N, F
 int liagpu_tv_train(int device, long U, int C, int D, const double *w, const double *mean, const double *cov, int R,
                     const double *N, const double *F, double *Tmat, int nbIt, int minDiv, double *mean_out)

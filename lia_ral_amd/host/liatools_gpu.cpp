@@ -485,6 +485,119 @@ void TVAcc::estimateWEigenDecomposition(const std::vector<double> &D, const std:
                                          _statF.data(), _T.data(), D.data(), Q.data(), _W.data()));
 }
 
+// ---- PldaDev ---------------------------------------------------------------------------------------
+PldaDev::PldaDev(GpuServer &srv, unsigned long vectSize, const std::vector<double> &data, const std::vector<unsigned long> &sessionPerSpeaker)
+    : _srv(srv), _vectSize(vectSize), _n_sessions(0), _data(data), _session_per_speaker(sessionPerSpeaker)
+{
+    for (unsigned long v : sessionPerSpeaker) {
+        if (v == 0) throw Exception("PldaDev: a speaker without session");
+        _n_sessions += v;
+    }
+    if (_vectSize == 0 || _data.size() != _vectSize * _n_sessions) throw Exception("PldaDev: data must be vectSize x n_sessions");
+    computeAll();
+}
+std::vector<int64_t> PldaDev::sps64() const { return std::vector<int64_t>(_session_per_speaker.begin(), _session_per_speaker.end()); }
+void PldaDev::computeAll()
+{
+    const std::vector<int64_t> sp = sps64();
+    _mean.assign(_vectSize, 0.0);
+    _speaker_means.assign(_vectSize * sp.size(), 0.0);
+    _srv.check(gmmiv_dev_means(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), _mean.data(),
+                               _speaker_means.data()));
+}
+void PldaDev::lengthNorm()
+{
+    std::vector<double> out(_data.size());
+    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)_vectSize, (int64_t)_n_sessions, _data.data(), nullptr, nullptr, 1, out.data()));
+    _data.swap(out);
+    computeAll();
+}
+void PldaDev::center(const std::vector<double> &mu)
+{
+    if (mu.size() != _vectSize) throw Exception("PldaDev::center: mean of the wrong size");
+    std::vector<double> out(_data.size());
+    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)_vectSize, (int64_t)_n_sessions, _data.data(), mu.data(), nullptr, 0, out.data()));
+    _data.swap(out);
+    computeAll();
+}
+void PldaDev::centerPerSpeaker()
+{
+    const unsigned long k = _session_per_speaker.size();
+    unsigned long s = 0;
+    for (unsigned long c = 0; c < k; ++c)
+        for (unsigned long e = 0; e < _session_per_speaker[c]; ++e, ++s)
+            for (unsigned long d = 0; d < _vectSize; ++d) _data[d * _n_sessions + s] -= _speaker_means[d * k + c];
+}
+void PldaDev::rotateLeft(const std::vector<double> &M, unsigned long rows)
+{
+    if (M.size() != rows * _vectSize) throw Exception("Rotation dimension mismatch !");
+    std::vector<double> out(rows * _n_sessions);
+    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)rows, (int64_t)_n_sessions, _data.data(), nullptr, M.data(), 0, out.data()));
+    _data.swap(out);
+    _vectSize = rows;
+    computeAll();
+}
+void PldaDev::computeCovMat(std::vector<double> &Sigma, std::vector<double> &W, std::vector<double> &B)
+{
+    const std::vector<int64_t> sp = sps64();
+    const size_t dd = _vectSize * _vectSize;
+    Sigma.assign(dd, 0.0); W.assign(dd, 0.0); B.assign(dd, 0.0);
+    _srv.check(gmmiv_dev_cov_mat(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), Sigma.data(),
+                                 W.data(), B.data()));
+}
+void PldaDev::computeWccnChol(std::vector<double> &WCCN)
+{
+    const std::vector<int64_t> sp = sps64();
+    WCCN.assign(_vectSize * _vectSize, 0.0);
+    _srv.check(gmmiv_dev_wccn_chol(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), WCCN.data()));
+}
+void PldaDev::computeMahalanobis(std::vector<double> &M)
+{
+    const std::vector<int64_t> sp = sps64();
+    M.assign(_vectSize * _vectSize, 0.0);
+    _srv.check(gmmiv_dev_mahalanobis(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), M.data()));
+}
+void PldaDev::computeScatterMat(std::vector<double> &SB, std::vector<double> &SW)
+{
+    const std::vector<int64_t> sp = sps64();
+    SB.assign(_vectSize * _vectSize, 0.0); SW.assign(_vectSize * _vectSize, 0.0);
+    _srv.check(gmmiv_dev_scatter_mat(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), SB.data(),
+                                     SW.data()));
+}
+void PldaDev::computeLDA(std::vector<double> &ldaMat, unsigned long ldaRank, bool scatterMatrices)
+{
+    std::vector<double> Sigma, W, B;
+    if (scatterMatrices) computeScatterMat(B, W); // ldaMode scatterMatrices, :1389-1392
+    else computeCovMat(Sigma, W, B);
+    ldaMat.assign(ldaRank * _vectSize, 0.0);
+    _srv.check(gmmiv_dev_lda(_srv.ctx(), (int)_vectSize, W.data(), B.data(), (int)ldaRank, ldaMat.data(), nullptr));
+}
+void PldaDev::sphericalNuisanceNormalization(unsigned long nbIt, bool sphNorm, std::vector<std::vector<double> > &mats,
+                                             std::vector<std::vector<double> > &means)
+{
+    mats.clear(); means.clear();
+    for (unsigned long it = 0; it < nbIt; ++it) {
+        std::vector<double> Sigma, W, B, M(_vectSize * _vectSize);
+        computeCovMat(Sigma, W, B);
+        _srv.check(gmmiv_dev_efr_matrix(_srv.ctx(), (int)_vectSize, sphNorm ? W.data() : Sigma.data(), M.data()));
+        mats.push_back(M);
+        means.push_back(_mean);
+        const std::vector<double> mu(_mean); // center() recomputes _mean
+        center(mu);
+        rotateLeft(M, _vectSize);
+        lengthNorm();
+    }
+}
+void PldaDev::applySphericalNuisanceNormalization(const std::vector<std::vector<double> > &mats, const std::vector<std::vector<double> > &means)
+{
+    if (mats.size() != means.size()) throw Exception("applySphericalNuisanceNormalization: one mean per matrix expected");
+    for (size_t it = 0; it < mats.size(); ++it) {
+        center(means[it]);
+        rotateLeft(mats[it], mats[it].size() / _vectSize);
+        lengthNorm();
+    }
+}
+
 void computeEigenProblem(const std::vector<double> &EP, unsigned long n, std::vector<double> &eigenVect, std::vector<double> &eigenVal,
                          unsigned long rank)
 {

@@ -221,6 +221,43 @@ class TVAcc {
     std::vector<double> _ubm_means, _ubm_invvar, _statN, _statF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
 };
 
+// ---- PldaTools.h: PldaDev, the development set of the i-vector back-end (PldaTools.cpp:274-2005) -------------
+// _data [vectSize x n_sessions] (one i-vector per column), sessions grouped by speaker.
+class PldaDev {
+  public:
+    PldaDev(GpuServer &srv, unsigned long vectSize, const std::vector<double> &data, const std::vector<unsigned long> &sessionPerSpeaker);
+    unsigned long getVectSize() const { return _vectSize; }
+    unsigned long getSpeakerNumber() const { return _session_per_speaker.size(); }
+    unsigned long getSessionNumber() const { return _n_sessions; }
+    unsigned long getSpeakerSessionNumber(unsigned long spk) const { return _session_per_speaker.at(spk); }
+    std::vector<double> &getData() { return _data; }
+    const std::vector<double> &getMean() const { return _mean; }
+    const std::vector<double> &getSpeakerMeans() const { return _speaker_means; } // [vectSize x n_speakers]
+    void computeAll();                                   // :353-387
+    void lengthNorm();                                   // :436-463
+    void center(const std::vector<double> &mu);          // :466-474
+    void centerPerSpeaker();                             // :488-495 (means are NOT recomputed, like the reference)
+    void rotateLeft(const std::vector<double> &M, unsigned long rows); // :498-513, M [rows x vectSize]
+    void computeCovMat(std::vector<double> &Sigma, std::vector<double> &W, std::vector<double> &B);   // :527-566
+    void computeWccnChol(std::vector<double> &WCCN);     // :1124-1176
+    void computeMahalanobis(std::vector<double> &M);     // :1366-1378
+    void computeScatterMat(std::vector<double> &SB, std::vector<double> &SW);                          // :1610-1644
+    void computeLDA(std::vector<double> &ldaMat, unsigned long ldaRank, bool scatterMatrices = false);  // :1381-1413, [rank x vectSize]
+    // :1822-1929: nbIt iterations of {covariances, EFR (Sigma) or sphNorm (W) matrix, center, rotate, lengthNorm};
+    // the matrices and means of every iteration are returned instead of being written to files
+    void sphericalNuisanceNormalization(unsigned long nbIt, bool sphNorm, std::vector<std::vector<double> > &mats,
+                                        std::vector<std::vector<double> > &means);
+    // :1931-2005: apply stored matrices / means
+    void applySphericalNuisanceNormalization(const std::vector<std::vector<double> > &mats, const std::vector<std::vector<double> > &means);
+
+  private:
+    std::vector<int64_t> sps64() const;
+    GpuServer &_srv;
+    unsigned long _vectSize, _n_sessions;
+    std::vector<double> _data, _mean, _speaker_means;
+    std::vector<unsigned long> _session_per_speaker;
+};
+
 // TVAcc::computeEigenProblem (AccumulateTVStat.cpp:2997-3102) for the SYMMETRIC matrices it is used on (the weighted
 // covariance W): cyclic Jacobi on the host, eigenvalues sorted descending, eigenVect[k*rank + j] = component k of
 // the j-th eigenvector (the reference's Eigen / LAPACK solver returns its own column order and sign; any orthonormal

@@ -120,6 +120,18 @@ def iv_extract_approx(x, utt_begin, ubm, Tmat, mode, device=0):
     return dict(W=W, Wcov=Wc, Q=Q, D=Dm)
 
 
+def backend_train(X, sps, nb_it=2, sph_norm=False, lda_rank=0, device=0):
+    """PldaDev EFR / sphNorm training (+ WCCN, Mahalanobis, LDA on the normalised set). X[dim, n] -> dict."""
+    X = np.array(X, np.float64, order="C", copy=True)
+    dim, n = X.shape
+    sps = np.ascontiguousarray(sps, np.int64)
+    mats = np.empty((nb_it, dim, dim)); means = np.empty((nb_it, dim)); wccn = np.empty((dim, dim)); mah = np.empty((dim, dim))
+    lda = np.empty((max(lda_rank, 1), dim))
+    _chk(lib.liagpu_backend_train(device, dim, ct.c_long(n), _d(X), ct.c_long(len(sps)), sps.ctypes.data_as(_lp), int(sph_norm), nb_it,
+                                  _d(mats), _d(means), _d(wccn), _d(mah), lda_rank, _d(lda)))
+    return dict(X=X, mats=mats, means=means, wccn=wccn, mahalanobis=mah, lda=lda[:lda_rank])
+
+
 def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
     C, D = mean.shape

@@ -699,6 +699,178 @@ void orc_tv_estimate_w_eigen(long U, int C, int D, int R, const double *N, const
     free(il); free(aux); free(app);
 }
 
+/* ---- i-vector back-end estimation on a development set (PldaDev, LIA_SpkTools/src/PldaTools.cpp) --------------
+ * data X [dim x n] (one vector per column); sessions are grouped by speaker, sps[c] = sessions of speaker c
+ * (PldaDev::_session_per_speaker; _class[s] is then the non-decreasing speaker index of session s).
+ * PldaDev::computeAll, :353-387: global mean and per-speaker means. */
+void orc_dev_means(int dim, long n, const double *X, long nspk, const long *sps, double *mean, double *spk_means /* dim x nspk */)
+{
+    memset(mean, 0, sizeof(double) * dim);
+    memset(spk_means, 0, sizeof(double) * (size_t)dim * nspk);
+    long s = 0;
+    for (long c = 0; c < nspk; ++c)
+        for (long e = 0; e < sps[c]; ++e, ++s)
+            for (int k = 0; k < dim; ++k) { spk_means[(size_t)k * nspk + c] += X[(size_t)k * n + s]; mean[k] += X[(size_t)k * n + s]; }
+    for (int k = 0; k < dim; ++k) {
+        mean[k] /= (double)n;
+        for (long c = 0; c < nspk; ++c) spk_means[(size_t)k * nspk + c] /= (double)sps[c];
+    }
+}
+static long *dev_classes(long n, long nspk, const long *sps)
+{
+    long *cls = malloc(sizeof(long) * (n > 0 ? n : 1)), s = 0;
+    for (long c = 0; c < nspk; ++c) for (long e = 0; e < sps[c]; ++e) cls[s++] = c;
+    return cls;
+}
+/* PldaDev::computeCovMatUnThreaded, :527-566: total, within and between covariance, all divided by n_sessions */
+void orc_dev_cov_mat(int dim, long n, const double *X, long nspk, const long *sps, double *Sigma, double *W, double *B)
+{
+    double *mean = malloc(sizeof(double) * dim), *sm = malloc(sizeof(double) * (size_t)dim * nspk);
+    long *cls = dev_classes(n, nspk, sps);
+    orc_dev_means(dim, n, X, nspk, sps, mean, sm);
+    for (int i = 0; i < dim; ++i)
+        for (int j = i; j < dim; ++j) {
+            double sg = 0.0, w = 0.0, b = 0.0;
+            for (long s = 0; s < n; ++s) {
+                sg += (X[(size_t)i * n + s] - mean[i]) * (X[(size_t)j * n + s] - mean[j]);
+                w += (X[(size_t)i * n + s] - sm[(size_t)i * nspk + cls[s]]) * (X[(size_t)j * n + s] - sm[(size_t)j * nspk + cls[s]]);
+            }
+            for (long c = 0; c < nspk; ++c) b += sps[c] * (sm[(size_t)i * nspk + c] - mean[i]) * (sm[(size_t)j * nspk + c] - mean[j]);
+            Sigma[(size_t)i * dim + j] = Sigma[(size_t)j * dim + i] = sg / n;
+            W[(size_t)i * dim + j] = W[(size_t)j * dim + i] = w / n;
+            B[(size_t)i * dim + j] = B[(size_t)j * dim + i] = b / n;
+        }
+    free(mean); free(sm); free(cls);
+}
+/* PldaDev::computeWccnCholUnThreaded, :1124-1176: W = mean over speakers of the per-speaker covariance
+ * (each divided by its session count); WCCN = upperCholesky(W^-1) */
+int orc_dev_wccn_chol(int dim, long n, const double *X, long nspk, const long *sps, double *WCCN)
+{
+    double *mean = malloc(sizeof(double) * dim), *sm = malloc(sizeof(double) * (size_t)dim * nspk);
+    double *W = calloc((size_t)dim * dim, sizeof(double)), *iW = malloc(sizeof(double) * (size_t)dim * dim);
+    orc_dev_means(dim, n, X, nspk, sps, mean, sm);
+    long s0 = 0;
+    for (long c = 0; c < nspk; ++c) {
+        for (int i = 0; i < dim; ++i)
+            for (int j = i; j < dim; ++j) {
+                double v = 0.0;
+                for (long s = s0; s < s0 + sps[c]; ++s)
+                    v += (X[(size_t)i * n + s] - sm[(size_t)i * nspk + c]) * (X[(size_t)j * n + s] - sm[(size_t)j * nspk + c]);
+                W[(size_t)i * dim + j] += v / (double)sps[c];
+            }
+        s0 += sps[c];
+    }
+    for (int i = 0; i < dim; ++i)
+        for (int j = i; j < dim; ++j) { W[(size_t)i * dim + j] /= nspk; W[(size_t)j * dim + i] = W[(size_t)i * dim + j]; }
+    int rc = orc_invert(dim, W, iW);
+    if (!rc) rc = orc_upper_cholesky(dim, iW, WCCN);
+    free(mean); free(sm); free(W); free(iW);
+    return rc;
+}
+/* PldaDev::computeScatterMatUnThreaded, :1610-1644, AS WRITTEN: SB = sum_c (m_c - m)(m_c - m)^T (no weights, no
+ * normalisation); SW is ASSIGNED per speaker, so it ends as the last speaker's matrix, and that matrix is built from
+ * the FIRST sps[c] sessions of the whole set (index s restarts at 0), each centred on its own speaker mean. */
+void orc_dev_scatter_mat(int dim, long n, const double *X, long nspk, const long *sps, double *SB, double *SW)
+{
+    double *mean = malloc(sizeof(double) * dim), *sm = malloc(sizeof(double) * (size_t)dim * nspk);
+    long *cls = dev_classes(n, nspk, sps);
+    orc_dev_means(dim, n, X, nspk, sps, mean, sm);
+    memset(SB, 0, sizeof(double) * (size_t)dim * dim);
+    memset(SW, 0, sizeof(double) * (size_t)dim * dim);
+    for (long c = 0; c < nspk; ++c)
+        for (int i = 0; i < dim; ++i)
+            for (int j = 0; j < dim; ++j) {
+                SB[(size_t)i * dim + j] += (sm[(size_t)i * nspk + c] - mean[i]) * (sm[(size_t)j * nspk + c] - mean[j]);
+                double t = 0.0;
+                for (long s = 0; s < sps[c]; ++s)
+                    t += (X[(size_t)i * n + s] - sm[(size_t)i * nspk + cls[s]]) * (X[(size_t)j * n + s] - sm[(size_t)j * nspk + cls[s]]);
+                SW[(size_t)i * dim + j] = t / (double)sps[c];
+            }
+    free(mean); free(sm); free(cls);
+}
+/* cyclic Jacobi for a symmetric matrix: eigenvalues descending in val[rank], vect[k*rank + j] = component k of the
+ * j-th eigenvector -- the layout PldaDev::computeEigenProblem (:1490-1535) fills from Eigen::EigenSolver */
+void orc_sym_eigen(int n, const double *A, int rank, double *vect, double *val)
+{
+    double *a = malloc(sizeof(double) * (size_t)n * n), *v = calloc((size_t)n * n, sizeof(double));
+    memcpy(a, A, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; ++i) { dg += a[(size_t)i * n + i] * a[(size_t)i * n + i]; for (int j = i + 1; j < n; ++j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j]; }
+        if (off <= 1e-30 * (dg + off)) break;
+        for (int p = 0; p + 1 < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double th = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) { double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q]; a[(size_t)k * n + p] = cs * x - sn * y; a[(size_t)k * n + q] = sn * x + cs * y; }
+                for (int k = 0; k < n; ++k) { double x = a[(size_t)p * n + k], y = a[(size_t)q * n + k]; a[(size_t)p * n + k] = cs * x - sn * y; a[(size_t)q * n + k] = sn * x + cs * y; }
+                for (int k = 0; k < n; ++k) { double x = v[(size_t)k * n + p], y = v[(size_t)k * n + q]; v[(size_t)k * n + p] = cs * x - sn * y; v[(size_t)k * n + q] = sn * x + cs * y; }
+            }
+    }
+    int *ord = malloc(sizeof(int) * n);
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    for (int i = 1; i < n; ++i) { int o = ord[i], j = i - 1; while (j >= 0 && a[(size_t)ord[j] * n + ord[j]] < a[(size_t)o * n + o]) { ord[j + 1] = ord[j]; --j; } ord[j + 1] = o; }
+    for (int j = 0; j < rank; ++j) {
+        val[j] = a[(size_t)ord[j] * n + ord[j]];
+        for (int k = 0; k < n; ++k) vect[(size_t)k * rank + j] = v[(size_t)k * n + ord[j]];
+    }
+    free(a); free(v); free(ord);
+}
+/* EFR / sphNorm matrix of PldaDev::sphericalNuisanceNormalization, :1852-1902: (V diag(1/sqrt(lambda)))^T for the
+ * eigen-decomposition of the covariance (Sigma for EFR, W for sphNorm) */
+void orc_dev_efr_matrix(int dim, const double *Cov, double *Mout)
+{
+    double *vect = malloc(sizeof(double) * (size_t)dim * dim), *val = malloc(sizeof(double) * dim);
+    orc_sym_eigen(dim, Cov, dim, vect, val);
+    for (int j = 0; j < dim; ++j)
+        for (int k = 0; k < dim; ++k) Mout[(size_t)j * dim + k] = vect[(size_t)k * dim + j] / sqrt(val[j]);
+    free(vect); free(val);
+}
+/* PldaDev::computeLDA, :1381-1413: the ldaRank leading eigenvectors (unit norm, as Eigen::EigenSolver returns them)
+ * of W^-1 B as the ROWS of ldaMat [rank x dim].  Solved through the symmetric form L^-1 B L^-T with W = L L^T. */
+int orc_dev_lda(int dim, const double *W, const double *B, int rank, double *ldaMat, double *eigval)
+{
+    double *U = malloc(sizeof(double) * (size_t)dim * dim);
+    int rc = orc_upper_cholesky(dim, W, U); /* W = U^T U, L = U^T */
+    if (rc) { free(U); return rc; }
+    double *Cm = malloc(sizeof(double) * (size_t)dim * dim), *T1 = malloc(sizeof(double) * (size_t)dim * dim);
+    /* T1 = L^-1 B : forward substitution on columns of B with L = U^T */
+    for (int j = 0; j < dim; ++j)
+        for (int i = 0; i < dim; ++i) {
+            double v = B[(size_t)i * dim + j];
+            for (int k = 0; k < i; ++k) v -= U[(size_t)k * dim + i] * T1[(size_t)k * dim + j];
+            T1[(size_t)i * dim + j] = v / U[(size_t)i * dim + i];
+        }
+    /* Cm = T1 L^-T  <=>  Cm^T = L^-1 T1^T */
+    for (int j = 0; j < dim; ++j)
+        for (int i = 0; i < dim; ++i) {
+            double v = T1[(size_t)j * dim + i];
+            for (int k = 0; k < i; ++k) v -= U[(size_t)k * dim + i] * Cm[(size_t)j * dim + k];
+            Cm[(size_t)j * dim + i] = v / U[(size_t)i * dim + i];
+        }
+    for (int i = 0; i < dim; ++i) for (int j = i + 1; j < dim; ++j) { double m = 0.5 * (Cm[(size_t)i * dim + j] + Cm[(size_t)j * dim + i]); Cm[(size_t)i * dim + j] = Cm[(size_t)j * dim + i] = m; }
+    double *vect = malloc(sizeof(double) * (size_t)dim * rank), *val = malloc(sizeof(double) * rank);
+    orc_sym_eigen(dim, Cm, rank, vect, val);
+    for (int j = 0; j < rank; ++j) { /* v = L^-T y = U^-1 y (back substitution), then unit norm */
+        double nrm = 0.0;
+        for (int i = dim - 1; i >= 0; --i) {
+            double v = vect[(size_t)i * rank + j];
+            for (int k = i + 1; k < dim; ++k) v -= U[(size_t)i * dim + k] * ldaMat[(size_t)j * dim + k];
+            ldaMat[(size_t)j * dim + i] = v / U[(size_t)i * dim + i];
+        }
+        for (int i = 0; i < dim; ++i) nrm += ldaMat[(size_t)j * dim + i] * ldaMat[(size_t)j * dim + i];
+        nrm = sqrt(nrm);
+        for (int i = 0; i < dim; ++i) ldaMat[(size_t)j * dim + i] /= nrm;
+        if (eigval) eigval[j] = val[j];
+    }
+    free(U); free(Cm); free(T1); free(vect); free(val);
+    return 0;
+}
+
 /* PldaModel::preComputation + the first lines of PldaTest::pldaNativeScoring, LIA_SpkTools/src/PldaTools.cpp:2950-2972,
  * 4494-4496.  F [dim x rf], G [dim x rg], Sigma [dim x dim] (row-major):
  *   FTJ  = F^T S^-1 - F^T S^-1 G (G^T S^-1 G + I)^-1 G^T S^-1      [rf x dim]

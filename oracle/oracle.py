@@ -422,3 +422,60 @@ def plda_precompute(F, G, Sigma):
     rc = _lib().orc_plda_precompute(ct.c_int(dim), ct.c_int(rf), ct.c_int(rg), fp, gp, sp, FTJ.ctypes.data_as(c_dp), FTJF.ctypes.data_as(c_dp))
     assert rc == 0
     return FTJ, FTJF
+
+
+# ---- i-vector back-end estimation (PldaDev) -----------------------------------------------------
+def _dev(X, sps):
+    X, xp = _d(X); sps, sp = _l(sps)
+    return X, xp, sps, sp, X.shape[0], X.shape[1], len(sps)
+
+
+def dev_means(X, sps):
+    X, xp, sps, sp, dim, n, k = _dev(X, sps)
+    mean = np.zeros(dim); sm = np.zeros((dim, k))
+    _lib().orc_dev_means(ct.c_int(dim), ct.c_long(n), xp, ct.c_long(k), sp, mean.ctypes.data_as(c_dp), sm.ctypes.data_as(c_dp))
+    return mean, sm
+
+
+def dev_cov_mat(X, sps):
+    X, xp, sps, sp, dim, n, k = _dev(X, sps)
+    S = np.zeros((dim, dim)); W = np.zeros((dim, dim)); B = np.zeros((dim, dim))
+    _lib().orc_dev_cov_mat(ct.c_int(dim), ct.c_long(n), xp, ct.c_long(k), sp, S.ctypes.data_as(c_dp), W.ctypes.data_as(c_dp), B.ctypes.data_as(c_dp))
+    return S, W, B
+
+
+def dev_wccn_chol(X, sps):
+    X, xp, sps, sp, dim, n, k = _dev(X, sps)
+    out = np.zeros((dim, dim))
+    assert _lib().orc_dev_wccn_chol(ct.c_int(dim), ct.c_long(n), xp, ct.c_long(k), sp, out.ctypes.data_as(c_dp)) == 0
+    return out
+
+
+def dev_scatter_mat(X, sps):
+    X, xp, sps, sp, dim, n, k = _dev(X, sps)
+    SB = np.zeros((dim, dim)); SW = np.zeros((dim, dim))
+    _lib().orc_dev_scatter_mat(ct.c_int(dim), ct.c_long(n), xp, ct.c_long(k), sp, SB.ctypes.data_as(c_dp), SW.ctypes.data_as(c_dp))
+    return SB, SW
+
+
+def sym_eigen(A, rank=None):
+    A, ap = _d(A)
+    n = A.shape[0]; rank = n if rank is None else rank
+    vect = np.zeros((n, rank)); val = np.zeros(rank)
+    _lib().orc_sym_eigen(ct.c_int(n), ap, ct.c_int(rank), vect.ctypes.data_as(c_dp), val.ctypes.data_as(c_dp))
+    return vect, val
+
+
+def dev_efr_matrix(Cov):
+    Cov, cp = _d(Cov)
+    out = np.zeros_like(Cov)
+    _lib().orc_dev_efr_matrix(ct.c_int(Cov.shape[0]), cp, out.ctypes.data_as(c_dp))
+    return out
+
+
+def dev_lda(W, B, rank):
+    W, wp = _d(W); B, bp = _d(B)
+    dim = W.shape[0]
+    out = np.zeros((rank, dim)); val = np.zeros(rank)
+    assert _lib().orc_dev_lda(ct.c_int(dim), wp, bp, ct.c_int(rank), out.ctypes.data_as(c_dp), val.ctypes.data_as(c_dp)) == 0
+    return out, val

@@ -180,3 +180,30 @@ def test_iv_extractor_approximate_modes(mode):
         assert np.max(np.abs(res["D"] - Dm)) < 1e-11 * np.max(np.abs(Dm))
         ref = orc.tv_estimate_w_eigen(N, Fn, Tn, Dm, Q)
     assert np.max(np.abs(res["W"] - ref)) < 1e-9 * max(np.max(np.abs(ref)), 1e-30)
+
+
+@pytest.mark.parametrize("sph_norm", [False, True])
+def test_backend_training_chain(sph_norm):
+    """PldaDev::sphericalNuisanceNormalization (PldaTools.cpp:1822-1929) + WCCN / Mahalanobis / LDA through the C++
+    host layer against a numpy restatement of the same loop built from the oracle pieces."""
+    from lia_ral_amd import host_capi as host
+    rng = np.random.default_rng(4)
+    dim, sps = 16, rng.integers(3, 8, 30)
+    k, n = len(sps), int(sps.sum())
+    cls = np.repeat(np.arange(k), sps)
+    X = (rng.normal(size=(dim, k)) * 1.2)[:, cls] + rng.normal(size=(dim, n)) * (1 + np.arange(dim))[:, None] * 0.2
+    res = host.backend_train(X, sps, nb_it=2, sph_norm=sph_norm, lda_rank=3)
+    Y = X.copy()
+    for it in range(2):
+        S, W, B = orc.dev_cov_mat(Y, sps)
+        M = orc.dev_efr_matrix(W if sph_norm else S)
+        assert relerr(np.abs(res["mats"][it]), np.abs(M)) < 1e-7 and relerr(res["means"][it], Y.mean(1)) < 1e-10
+        M = res["mats"][it]                    # eigenvector signs are the solver's: continue with the product's matrix
+        Y = M @ (Y - Y.mean(1)[:, None])
+        Y /= np.linalg.norm(Y, axis=0)
+    assert relerr(res["X"], Y) < 1e-9
+    S, W, B = orc.dev_cov_mat(Y, sps)
+    assert relerr(res["mahalanobis"], np.linalg.inv(W)) < 1e-7
+    assert relerr(res["wccn"], orc.dev_wccn_chol(Y, sps)) < 1e-7
+    oL, lam = orc.dev_lda(W, B, 3)
+    assert relerr(np.abs(res["lda"]), np.abs(oL)) < 1e-6

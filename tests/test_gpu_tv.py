@@ -177,3 +177,62 @@ def test_plda_precompute_and_native_scoring(ctx, dim, rf, rg):
     got = ctx.score_plda(np.ascontiguousarray(pm * ns), ns, ps, FTJF)
     ref = orc.score_plda((oJ @ models) * ns, ns, oJ @ segs, oJF)
     assert relerr(got, ref) < 1e-9
+
+
+def _dev_set(dim, sps, seed):
+    rng = np.random.default_rng(seed)
+    k, n = len(sps), int(np.sum(sps))
+    cls = np.repeat(np.arange(k), sps)
+    X = np.ascontiguousarray((rng.normal(size=(dim, k)) * 1.5)[:, cls] + rng.normal(size=(dim, n)))
+    return X
+
+
+@pytest.mark.parametrize("dim,nspk,seed", [(10, 6, 1), (64, 40, 2), (400, 300, 3)])
+def test_backend_estimation_matches_oracle(ctx, dim, nspk, seed):
+    """PldaDev::computeAll / computeCovMat / computeWccnChol / computeMahalanobis / computeScatterMat
+    (PldaTools.cpp:353-387, 527-566, 1124-1176, 1366-1378, 1610-1644) on the device against the oracle."""
+    rng = np.random.default_rng(seed)
+    sps = rng.integers(2, 9, nspk)
+    sps[0] = 1
+    X = _dev_set(dim, sps, seed)
+    mean, sm = ctx.dev_means(X, sps)
+    om, osm = orc.dev_means(X, sps)
+    assert relerr(mean, om) < 1e-13 and relerr(sm, osm) < 1e-13
+    S, W, B = ctx.dev_cov_mat(X, sps)
+    oS, oW, oB = orc.dev_cov_mat(X, sps)
+    assert relerr(S, oS) < 1e-12 and relerr(W, oW) < 1e-12 and relerr(B, oB) < 1e-12
+    SB, SW = ctx.dev_scatter_mat(X, sps)
+    oSB, oSW = orc.dev_scatter_mat(X, sps)
+    assert relerr(SB, oSB) < 1e-12 and relerr(SW, oSW) < 1e-12
+    if X.shape[1] > 2 * dim:   # W must be invertible
+        assert relerr(ctx.dev_mahalanobis(X, sps), np.linalg.inv(oW)) < 1e-8
+        U = ctx.dev_wccn_chol(X, sps)
+        assert relerr(U, orc.dev_wccn_chol(X, sps)) < 1e-8 and np.allclose(U, np.triu(U))
+
+
+@pytest.mark.parametrize("dim", [12, 100])
+def test_efr_lda_and_eigen(ctx, dim):
+    """computeEigenProblem on symmetric input, the EFR / sphNorm matrix and LDA (PldaTools.cpp:1490-1535, 1852-1902,
+    1381-1413): same results as the oracle, and the defining properties."""
+    sps = np.full(6 * dim // 4, 4)
+    X = _dev_set(dim, sps, dim)
+    S, W, B = orc.dev_cov_mat(X, sps)
+    vect, val = ctx.sym_eigen(S)
+    assert np.all(np.diff(val) <= 0) and np.allclose(vect @ np.diag(val) @ vect.T, S, atol=1e-10 * val[0])
+    ov, ol = orc.sym_eigen(S)
+    assert relerr(val, ol) < 1e-12 and relerr(np.abs(vect), np.abs(ov)) < 1e-8
+    M = ctx.dev_efr_matrix(S)
+    assert np.allclose(M @ S @ M.T, np.eye(dim), atol=1e-9)
+    assert relerr(np.abs(M), np.abs(orc.dev_efr_matrix(S))) < 1e-8
+    rank = min(5, dim - 1)
+    L, lam = ctx.dev_lda(W, B, rank)
+    oL, olam = orc.dev_lda(W, B, rank)
+    assert relerr(lam, olam) < 1e-10 and relerr(np.abs(L), np.abs(oL)) < 1e-7
+    EP = np.linalg.inv(W) @ B
+    for j in range(rank):
+        assert np.allclose(EP @ L[j], lam[j] * L[j], atol=1e-8 * lam[0])
+    # the EFR training loop of PldaDev::sphericalNuisanceNormalization: covariance -> matrix -> center / rotate / lengthNorm
+    Y = ctx.iv_normalize(X, X.mean(1), M, length_norm=True)
+    assert np.allclose(np.linalg.norm(Y, axis=0), 1.0)
+    Yo = M @ (X - X.mean(1)[:, None]); Yo /= np.linalg.norm(Yo, axis=0)
+    assert relerr(Y, Yo) < 1e-10

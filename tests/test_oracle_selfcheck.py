@@ -129,3 +129,35 @@ def test_approximate_extractors_and_plda_precompute_against_numpy():
     assert np.allclose(FTJ, ref, rtol=1e-10, atol=1e-12) and np.allclose(FTJF, ref @ Fm, rtol=1e-10, atol=1e-12)
     FTJ0, _ = orc.plda_precompute(Fm, None, S)
     assert np.allclose(FTJ0, Fm.T @ Si, rtol=1e-10, atol=1e-12)
+
+
+def test_backend_estimation_against_numpy():
+    """PldaDev (PldaTools.cpp:353-387, 527-566, 1124-1176, 1381-1413, 1610-1644, 1852-1902) restated with numpy."""
+    rng = np.random.default_rng(11)
+    dim, sps = 7, np.array([3, 1, 5, 2, 4])
+    n, k = int(sps.sum()), len(sps)
+    spk = rng.normal(size=(dim, k)) * 2
+    cls = np.repeat(np.arange(k), sps)
+    X = spk[:, cls] + rng.normal(size=(dim, n))
+    mean, sm = orc.dev_means(X, sps)
+    assert np.allclose(mean, X.mean(1)) and np.allclose(sm, np.stack([X[:, cls == c].mean(1) for c in range(k)], 1))
+    S, W, B = orc.dev_cov_mat(X, sps)
+    Xc = X - mean[:, None]; Xw = X - sm[:, cls]; Mb = (sm - mean[:, None]) * np.sqrt(sps)
+    assert np.allclose(S, Xc @ Xc.T / n) and np.allclose(W, Xw @ Xw.T / n) and np.allclose(B, Mb @ Mb.T / n)
+    assert np.allclose(S, W + B)
+    Wc = sum((Xw[:, cls == c] @ Xw[:, cls == c].T) / sps[c] for c in range(k)) / k
+    U = orc.dev_wccn_chol(X, sps)
+    assert np.allclose(U, np.triu(U)) and np.allclose(U.T @ U, np.linalg.inv(Wc), rtol=1e-9)
+    SB, SW = orc.dev_scatter_mat(X, sps)
+    assert np.allclose(SB, (sm - mean[:, None]) @ (sm - mean[:, None]).T)
+    assert np.allclose(SW, Xw[:, :sps[-1]] @ Xw[:, :sps[-1]].T / sps[-1])          # the reference's quirk, kept
+    vect, val = orc.sym_eigen(S)
+    assert np.all(np.diff(val) <= 0) and np.allclose(vect @ np.diag(val) @ vect.T, S) and np.allclose(vect.T @ vect, np.eye(dim))
+    M = orc.dev_efr_matrix(S)
+    assert np.allclose(M @ S @ M.T, np.eye(dim), atol=1e-10)                         # whitening
+    L, lam = orc.dev_lda(W, B, 3)
+    EP = np.linalg.inv(W) @ B
+    for j in range(3):
+        assert np.allclose(EP @ L[j], lam[j] * L[j], atol=1e-9 * abs(lam[0])) and abs(np.linalg.norm(L[j]) - 1) < 1e-12
+    ev = np.sort(np.linalg.eigvals(EP).real)[::-1]
+    assert np.allclose(lam, ev[:3], rtol=1e-9, atol=1e-12)
