@@ -237,6 +237,16 @@ int gmmiv_sym_eigen(gmmiv_ctx *ctx, int n, const double *A, int rank, double *ve
 int gmmiv_dev_efr_matrix(gmmiv_ctx *ctx, int dim, const double *Cov, double *M);
 int gmmiv_dev_lda(gmmiv_ctx *ctx, int dim, const double *W, const double *B, int rank, double *ldaMat, double *eigval);
 
+/* PldaModel::em_iteration (PldaTools.cpp:2329-2343 = center(Delta) + computeCovMatEigen :931-950 +
+ * getExpectedValues :2359-2484 + mStep :2790-2815): one EM iteration of the PLDA model
+ *   x = mu + F h_spk + G w_session + eps,  eps ~ N(0, Sigma)
+ * on the development set X [dim x n] (sessions grouped by speaker; X is centred IN PLACE by the incoming Delta, like
+ * _Dev.center(_Delta)).  F [dim x rf], G [dim x rg], Sigma [dim x dim], Delta [dim] are updated in place (M-step with
+ * the minimum-divergence re-scaling of F and G).  The O(dim n r) products run on the device, the per-speaker
+ * r x r algebra on the host like the reference's Eigen code. */
+int gmmiv_plda_em_iteration(gmmiv_ctx *ctx, int dim, int64_t n, double *X, int64_t nspk, const int64_t *sessions_per_speaker,
+                            int rf, int rg, double *F, double *G, double *Sigma, double *Delta);
+
 /* PldaModel::preComputation + FTJ / FTJF of pldaNativeScoring (PldaTools.cpp:2950-2972, 4494-4496):
  *   FTJ[rf x dim] = F^T S^-1 - F^T S^-1 G (G^T S^-1 G + I)^-1 G^T S^-1,  FTJF[rf x rf] = FTJ F
  * F [dim x rf], G [dim x rg] (rg may be 0), Sigma [dim x dim] symmetric positive definite, all row-major.

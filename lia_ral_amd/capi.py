@@ -251,6 +251,12 @@ class Context:
         _chk(lib.gmmiv_dev_lda(self._h, dim, _ptr(_f64(W)), _ptr(_f64(B)), rank, _ptr(out), _ptr(val)))
         return out, val
 
+    def plda_em_iteration(self, X, sps, F, G, Sigma, Delta):
+        """One PldaModel::em_iteration, in place on X (centred by Delta), F, G, Sigma, Delta (numpy float64 arrays)."""
+        dim, n, xp, k, sp, keep = self._dev_args(X, sps)
+        _chk(lib.gmmiv_plda_em_iteration(self._h, dim, n, xp, k, sp, F.shape[1], G.shape[1], _ptr(F), _ptr(G), _ptr(Sigma), _ptr(Delta)))
+        return X, F, G, Sigma, Delta
+
     def plda_precompute(self, F, G, Sigma):
         """-> (FTJ [rf x dim], FTJF [rf x rf]); G may be None."""
         dim, rf = F.shape

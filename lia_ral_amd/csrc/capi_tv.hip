@@ -920,6 +920,139 @@ int gmmiv_dev_lda(gmmiv_ctx *c, int dim, const double *W, const double *B, int r
     return store_out(c, eigval, val);
 }
 
+namespace {
+// C[M x N] (+)= op(A) op(B) on the host, op(A) is M x K; row-major, i-k-j order
+void hmm(int M, int N, int K, const double *A, bool ta, const double *B, bool tb, double *Cm, bool accumulate = false)
+{
+    if (!accumulate) memset(Cm, 0, sizeof(double) * (size_t)M * N);
+    for (int i = 0; i < M; ++i)
+        for (int k = 0; k < K; ++k) {
+            const double a = ta ? A[(size_t)k * M + i] : A[(size_t)i * K + k];
+            if (a == 0.0) continue;
+            double *cr = Cm + (size_t)i * N;
+            if (!tb) { const double *br = B + (size_t)k * N; for (int j = 0; j < N; ++j) cr[j] += a * br[j]; }
+            else for (int j = 0; j < N; ++j) cr[j] += a * B[(size_t)j * K + k];
+        }
+}
+} // namespace
+
+int gmmiv_plda_em_iteration(gmmiv_ctx *c, int dim, int64_t n, double *X, int64_t nspk, const int64_t *sps, int rf, int rg, double *Fm,
+                            double *Gm, double *Sigma, double *Delta)
+{
+    if (rf <= 0 || rg <= 0 || !Fm || !Gm || !Sigma || !Delta) { gmmiv_set_error("plda_em_iteration: bad argument"); return GMMIV_ERR_ARG; }
+    DevSet ds; // validates the arguments, uploads X (when it is a host array), builds cls / off
+    int rc = ds.init(c, dim, n, X, nspk, sps, "plda_em_iteration");
+    if (rc) return rc;
+    const int rh = rf + rg;
+    const size_t dd = (size_t)dim * dim;
+    hipStream_t st = c->stream;
+    std::vector<double> F, G, Sg, Dl;
+    if ((rc = fetch_host(c, Fm, (size_t)dim * rf, F)) || (rc = fetch_host(c, Gm, (size_t)dim * rg, G)) || (rc = fetch_host(c, Sigma, dd, Sg)) ||
+        (rc = fetch_host(c, Delta, dim, Dl))) return rc;
+    // device scratch: centred X (in place when X is a device array), small operands, Eh
+    void *p;
+    double *Xd = const_cast<double *>(ds.x.d); // DevIn's staging copy or the caller's device array
+    if ((rc = c->scratch(WS_T2, ((size_t)rh * dim + (size_t)rg * rg + (size_t)rh * nspk + dim + dd + (size_t)rh * rh + (size_t)dim * rh) * 8, &p))) return rc;
+    double *dFG = (double *)p, *dIGG = dFG + (size_t)rh * dim, *dH = dIGG + (size_t)rg * rg, *dDelta = dH + (size_t)rh * nspk;
+    double *dOut = dDelta + dim; // sigObs [dd] | gram [rh x rh] | xh [dim x rh]
+    if ((rc = c->scratch(WS_TIV, (size_t)2 * rh * n * 8, &p))) return rc;
+    double *FGX = (double *)p, *Eh = FGX + (size_t)rh * n; // [rh x n] each: (Ftw; Gtw) X, then the expected latent variables
+    // 1. centre by Delta, total second moment
+    GCHK(hipMemcpyAsync(dDelta, Dl.data(), dim * 8, hipMemcpyHostToDevice, st));
+    GCHK(tvk_sub_colvec(st, dim, (long)n, Xd, dDelta, Xd));
+    if ((rc = dev_gram(c, dim, (long)n, Xd, 1.0, dOut))) return rc;
+    // 2. preComputation on the host (PldaTools.cpp:2950-2972)
+    std::vector<double> Si, FGtw((size_t)rh * dim), GtwG((size_t)rg * rg), iGG, FtwG((size_t)rf * rg), FtwF((size_t)rf * rf), S((size_t)rg * rf),
+        A((size_t)rf * rf), t1((size_t)rf * rg);
+    if (!host_spd_inverse(dim, Sg, Si, nullptr)) { gmmiv_set_error("plda_em_iteration: Sigma is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    double *Ftw = FGtw.data(), *Gtw = FGtw.data() + (size_t)rf * dim;
+    hmm(rf, dim, dim, F.data(), true, Si.data(), false, Ftw);
+    hmm(rg, dim, dim, G.data(), true, Si.data(), false, Gtw);
+    hmm(rg, rg, dim, Gtw, false, G.data(), false, GtwG.data());
+    hmm(rf, rg, dim, Ftw, false, G.data(), false, FtwG.data());
+    for (int i = 0; i < rg; ++i) GtwG[(size_t)i * rg + i] += 1.0;
+    if (!host_spd_inverse(rg, GtwG, iGG, nullptr)) { gmmiv_set_error("plda_em_iteration: G^T S^-1 G + I is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    hmm(rf, rf, dim, Ftw, false, F.data(), false, FtwF.data());
+    hmm(rg, rf, rg, iGG.data(), false, FtwG.data(), true, S.data());
+    hmm(rf, rg, rg, FtwG.data(), false, iGG.data(), false, t1.data());
+    hmm(rf, rf, rg, t1.data(), false, FtwG.data(), true, A.data());
+    for (size_t i = 0; i < A.size(); ++i) A[i] = FtwF[i] - A[i];
+    // 3. (Ftw; Gtw) X on the device, per-speaker sums back to the host
+    GCHK(hipMemcpyAsync(dFG, FGtw.data(), FGtw.size() * 8, hipMemcpyHostToDevice, st));
+    GCHK(hipMemcpyAsync(dIGG, iGG.data(), iGG.size() * 8, hipMemcpyHostToDevice, st));
+    GCHK(tvk_dgemm(st, false, false, rh, (int)n, dim, 1.0, dFG, dim, 0, Xd, (long)n, 0, 0.0, FGX, (long)n, 0, 1));
+    void *q;
+    if ((rc = c->scratch(WS_T3, ((size_t)2 * rh * nspk + rh) * 8, &q))) return rc;
+    double *dsum = (double *)q, *dsm = dsum + (size_t)rh * nspk, *dmn = dsm + (size_t)rh * nspk;
+    GCHK(tvk_dev_means(st, rh, (long)n, FGX, (long)nspk, ds.off, dsum, dmn, dsm));
+    std::vector<double> fg;
+    if ((rc = fetch_host(c, dsum, (size_t)rh * nspk, fg))) return rc; // rows 0..rf-1: f_s, rows rf..: g_s
+    // 4. per-speaker expectations on the host (:2417-2477)
+    std::vector<double> Hs((size_t)rh * nspk), Ehh((size_t)rh * rh, 0.0), U(rh, 0.0), M, MsT((size_t)rf * rg), SMsT((size_t)rg * rg), tmpM((size_t)rh * rh),
+        J((size_t)rf * rf), v(rf), gsum(rg, 0.0);
+    std::map<int64_t, std::pair<std::vector<double>, std::vector<double> > > cache; // session count -> (M, tmpM)
+    for (int64_t spk = 0; spk < nspk; ++spk) {
+        const int64_t ns = sps[spk];
+        auto it = cache.find(ns);
+        if (it == cache.end()) {
+            for (size_t i = 0; i < J.size(); ++i) J[i] = (double)ns * A[i];
+            for (int i = 0; i < rf; ++i) J[(size_t)i * rf + i] += 1.0;
+            if (!host_spd_inverse(rf, J, M, nullptr)) { gmmiv_set_error("plda_em_iteration: n A + I is not positive definite"); return GMMIV_ERR_NUMERIC; }
+            hmm(rf, rg, rf, M.data(), false, S.data(), true, MsT.data());
+            hmm(rg, rg, rf, S.data(), false, MsT.data(), false, SMsT.data());
+            for (int i = 0; i < rf; ++i) for (int j = 0; j < rf; ++j) tmpM[(size_t)i * rh + j] = M[(size_t)i * rf + j];
+            for (int i = 0; i < rf; ++i) for (int j = 0; j < rg; ++j) { tmpM[(size_t)i * rh + rf + j] = -MsT[(size_t)i * rg + j]; tmpM[(size_t)(rf + j) * rh + i] = -MsT[(size_t)i * rg + j]; }
+            for (int i = 0; i < rg; ++i) for (int j = 0; j < rg; ++j) tmpM[(size_t)(rf + i) * rh + rf + j] = iGG[(size_t)i * rg + j] + SMsT[(size_t)i * rg + j];
+            it = cache.emplace(ns, std::make_pair(M, tmpM)).first;
+        }
+        const std::vector<double> &Mn = it->second.first, &Tn = it->second.second;
+        for (int r = 0; r < rf; ++r) { double a = fg[(size_t)r * nspk + spk]; for (int k = 0; k < rg; ++k) a -= S[(size_t)k * rf + r] * fg[(size_t)(rf + k) * nspk + spk]; v[r] = a; }
+        for (int r = 0; r < rf; ++r) { double a = 0.0; for (int k = 0; k < rf; ++k) a += Mn[(size_t)r * rf + k] * v[k]; Hs[(size_t)r * nspk + spk] = a; U[r] += (double)ns * a; }
+        for (int r = 0; r < rg; ++r) { double a = 0.0; for (int k = 0; k < rf; ++k) a += S[(size_t)r * rf + k] * Hs[(size_t)k * nspk + spk]; Hs[(size_t)(rf + r) * nspk + spk] = a; U[rf + r] -= (double)ns * a; gsum[r] += fg[(size_t)(rf + r) * nspk + spk]; }
+        for (size_t i = 0; i < Ehh.size(); ++i) Ehh[i] += (double)ns * Tn[i];
+    }
+    for (int r = 0; r < rg; ++r) { double a = 0.0; for (int k = 0; k < rg; ++k) a += iGG[(size_t)r * rg + k] * gsum[k]; U[rf + r] += a; }
+    // 5. Eh = [h_spk ; iGG g_i - S h_spk] per session, its Gram matrix and X Eh^T on the device
+    GCHK(hipMemcpyAsync(dH, Hs.data(), Hs.size() * 8, hipMemcpyHostToDevice, st));
+    GCHK(tvk_dev_expand(st, rf, (long)n, (long)nspk, dH, ds.cls, Eh));
+    GCHK(tvk_dgemm(st, false, false, rg, (int)n, rg, 1.0, dIGG, rg, 0, FGX + (size_t)rf * n, (long)n, 0, 0.0, Eh + (size_t)rf * n, (long)n, 0, 1));
+    GCHK(tvk_dev_center(st, rg, (long)n, 1, Eh + (size_t)rf * n, nullptr, dH + (size_t)rf * nspk, (long)nspk, ds.off, ds.cls, Eh + (size_t)rf * n));
+    double *dGram = dOut + dd, *dXh = dGram + (size_t)rh * rh;
+    if ((rc = dev_gram(c, rh, (long)n, Eh, 1.0, dGram))) return rc;
+    {
+        const int nz = tvk_splitk_count(dim, rh, (int)n, c->n_cu);
+        if ((rc = c->scratch(WS_SLAB, (size_t)nz * dim * rh * 8, &q))) return rc;
+        GCHK(tvk_dgemm_splitk(st, false, true, dim, rh, (int)n, 1.0, Xd, (long)n, Eh, (long)n, 0.0, dXh, rh, nz, (double *)q));
+    }
+    std::vector<double> outv;
+    if ((rc = fetch_host(c, dOut, dd + (size_t)rh * rh + (size_t)dim * rh, outv))) return rc;
+    const double *sigObs = outv.data(), *gram = sigObs + dd, *xh = gram + (size_t)rh * rh;
+    for (size_t i = 0; i < Ehh.size(); ++i) Ehh[i] += gram[i];
+    // 6. mStep on the host (:2790-2815)
+    std::vector<double> iE, FG((size_t)dim * rh), SL(dd), cF((size_t)rf * rf), cG((size_t)rg * rg), Rh, Rw;
+    if (!host_spd_inverse(rh, Ehh, iE, nullptr)) { gmmiv_set_error("plda_em_iteration: sum E[hh^T] is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    hmm(dim, rh, rh, xh, false, iE.data(), false, FG.data());
+    hmm(dim, dim, rh, FG.data(), false, xh, true, SL.data());
+    for (size_t i = 0; i < dd; ++i) Sg[i] = (sigObs[i] - SL[i]) / (double)n;
+    for (int i = 0; i < rh; ++i) U[i] /= (double)n;
+    for (int i = 0; i < rf; ++i) for (int j = 0; j < rf; ++j) cF[(size_t)i * rf + j] = Ehh[(size_t)i * rh + j] / (double)n - U[i] * U[j];
+    for (int i = 0; i < rg; ++i) for (int j = 0; j < rg; ++j) cG[(size_t)i * rg + j] = Ehh[(size_t)(rf + i) * rh + rf + j] / (double)n - U[rf + i] * U[rf + j];
+    if (!host_cholesky_upper(rf, cF, Rh) || !host_cholesky_upper(rg, cG, Rw)) { gmmiv_set_error("plda_em_iteration: minimum-divergence covariance is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    for (int i = 0; i < dim; ++i) {
+        for (int j = 0; j < rf; ++j) { double a = 0.0; for (int k = 0; k < rf; ++k) a += FG[(size_t)i * rh + k] * Rh[(size_t)j * rf + k]; F[(size_t)i * rf + j] = a; }
+        for (int j = 0; j < rg; ++j) { double a = 0.0; for (int k = 0; k < rg; ++k) a += FG[(size_t)i * rh + rf + k] * Rw[(size_t)j * rg + k]; G[(size_t)i * rg + j] = a; }
+        double d = 0.0;
+        for (int k = 0; k < rh; ++k) d += FG[(size_t)i * rh + k] * U[k];
+        Dl[i] += d;
+    }
+    if ((rc = store_out(c, Fm, F)) || (rc = store_out(c, Gm, G)) || (rc = store_out(c, Sigma, Sg)) || (rc = store_out(c, Delta, Dl))) return rc;
+    if (!gmmiv_is_device_ptr(X)) { // the centred data goes back to the caller's host array
+        GCHK(hipMemcpyAsync(X, Xd, (size_t)dim * n * 8, hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+    }
+    return GMMIV_OK;
+}
+
 int gmmiv_plda_precompute(gmmiv_ctx *c, int dim, int rf, int rg, const double *Fm, const double *Gm, const double *Sigma, double *FTJ,
                           double *FTJF)
 {

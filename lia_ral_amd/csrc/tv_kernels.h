@@ -39,3 +39,4 @@ int tvk_dev_means(hipStream_t st, int dim, long n, const double *X, long nspk, c
 int tvk_dev_center(hipStream_t st, int dim, long n, int mode, const double *X, const double *mean, const double *smean, long nspk,
                    const long *off, const int *cls, double *out);
 int tvk_dev_between(hipStream_t st, int dim, long nspk, int weighted, const double *mean, const double *smean, const long *off, double *out);
+int tvk_dev_expand(hipStream_t st, int rows, long n, long nspk, const double *H, const int *cls, double *out);

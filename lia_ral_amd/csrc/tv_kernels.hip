@@ -584,6 +584,15 @@ __global__ void k_dev_between(int dim, long nspk, int weighted, const double *__
     const long k = e / nspk, c = e - k * nspk;
     out[e] = (smean[e] - mean[k]) * (weighted ? sqrt((double)(off[c + 1] - off[c])) : 1.0);
 }
+// out[r, s] = H[r, cls[s]]   (H [rows x nspk])
+__global__ void k_dev_expand(int rows, long n, long nspk, const double *__restrict__ H, const int *__restrict__ cls, double *__restrict__ out)
+{
+    const long tot = (long)rows * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / n, s = e - r * n;
+        out[e] = H[r * nspk + cls[s]];
+    }
+}
 int tvk_dev_means(hipStream_t st, int dim, long n, const double *X, long nspk, const long *off, double *ssum, double *mean, double *smean)
 {
     k_dev_spk_sums<<<(unsigned)(((long)dim * nspk + 255) / 256), 256, 0, st>>>(dim, n, X, nspk, off, ssum);
@@ -596,6 +605,12 @@ int tvk_dev_center(hipStream_t st, int dim, long n, int mode, const double *X, c
 {
     if (n <= 0) return 0;
     k_dev_center<<<ew_blocks((long)dim * n), 256, 0, st>>>(dim, n, mode, X, mean, smean, nspk, off, cls, out);
+    return (int)hipGetLastError();
+}
+int tvk_dev_expand(hipStream_t st, int rows, long n, long nspk, const double *H, const int *cls, double *out)
+{
+    if (n <= 0) return 0;
+    k_dev_expand<<<ew_blocks((long)rows * n), 256, 0, st>>>(rows, n, nspk, H, cls, out);
     return (int)hipGetLastError();
 }
 int tvk_dev_between(hipStream_t st, int dim, long nspk, int weighted, const double *mean, const double *smean, const long *off, double *out)

@@ -191,6 +191,26 @@ int liagpu_backend_train(int device, int dim, long n, double *X, long nspk, cons
     })
 }
 
+// PLDA training (LIA_SpkDet/PLDA/src/PLDA.cpp:80-95): nb_it EM iterations from given F, G, Sigma; X is left centred by
+// the accumulated minimum-divergence shifts like the reference's _Dev.
+int liagpu_plda_train(int device, int dim, long n, double *X, long nspk, const long *sps, int rf, int rg, int nb_it, double *F, double *G,
+                      double *Sigma, double *Delta, double *original_mean)
+{
+    GUARD({
+        GpuServer srv(device);
+        PldaDev dev(srv, (unsigned long)dim, std::vector<double>(X, X + (size_t)dim * n), std::vector<unsigned long>(sps, sps + nspk));
+        PldaModel plda(dev, (unsigned long)rf, (unsigned long)rg, std::vector<double>(F, F + (size_t)dim * rf),
+                       std::vector<double>(G, G + (size_t)dim * rg), std::vector<double>(Sigma, Sigma + (size_t)dim * dim));
+        for (int it = 0; it < nb_it; ++it) plda.em_iteration();
+        memcpy(F, plda.getF().data(), plda.getF().size() * sizeof(double));
+        memcpy(G, plda.getG().data(), plda.getG().size() * sizeof(double));
+        memcpy(Sigma, plda.getSigma().data(), plda.getSigma().size() * sizeof(double));
+        memcpy(Delta, plda.getDelta().data(), plda.getDelta().size() * sizeof(double));
+        if (original_mean) memcpy(original_mean, plda.getOriginalMean().data(), (size_t)dim * sizeof(double));
+        memcpy(X, dev.getData().data(), (size_t)dim * n * sizeof(double));
+    })
+}
+
 // TotalVariability (TotalVariability.cpp:118-169): nbIt iterations on precomputed N, F
 int liagpu_tv_train(int device, long U, int C, int D, const double *w, const double *mean, const double *cov, int R,
                     const double *N, const double *F, double *Tmat, int nbIt, int minDiv, double *mean_out)

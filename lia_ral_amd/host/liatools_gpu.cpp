@@ -588,6 +588,13 @@ void PldaDev::sphericalNuisanceNormalization(unsigned long nbIt, bool sphNorm, s
         lengthNorm();
     }
 }
+void PldaDev::emIteration(unsigned long rankF, unsigned long rankG, std::vector<double> &F, std::vector<double> &G, std::vector<double> &Sigma,
+                          std::vector<double> &Delta, const std::vector<int64_t> &sp)
+{
+    _srv.check(gmmiv_plda_em_iteration(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), (int)rankF,
+                                       (int)rankG, F.data(), G.data(), Sigma.data(), Delta.data()));
+    computeAll(); // _Dev.center(_Delta) ends with computeAll(), :466-474
+}
 void PldaDev::applySphericalNuisanceNormalization(const std::vector<std::vector<double> > &mats, const std::vector<std::vector<double> > &means)
 {
     if (mats.size() != means.size()) throw Exception("applySphericalNuisanceNormalization: one mean per matrix expected");
@@ -596,6 +603,24 @@ void PldaDev::applySphericalNuisanceNormalization(const std::vector<std::vector<
         rotateLeft(mats[it], mats[it].size() / _vectSize);
         lengthNorm();
     }
+}
+
+// ---- PldaModel (training) --------------------------------------------------------------------------
+PldaModel::PldaModel(PldaDev &dev, unsigned long rankF, unsigned long rankG, const std::vector<double> &F, const std::vector<double> &G,
+                     const std::vector<double> &Sigma)
+    : _Dev(dev), _rankF(rankF), _rankG(rankG), _vectSize(dev.getVectSize()), _F(F), _G(G), _Sigma(Sigma), _Delta(dev.getVectSize(), 0.0),
+      _originalMean(dev.getMean())
+{
+    if (_F.size() != _vectSize * _rankF || _G.size() != _vectSize * _rankG || _Sigma.size() != _vectSize * _vectSize)
+        throw Exception("PldaModel: F is vectSize x rankF, G vectSize x rankG, Sigma vectSize x vectSize");
+}
+void PldaModel::em_iteration()
+{
+    std::vector<int64_t> sp(_Dev.getSpeakerNumber());
+    for (unsigned long i = 0; i < sp.size(); ++i) sp[i] = (int64_t)_Dev.getSpeakerSessionNumber(i);
+    // gmmiv_plda_em_iteration centres the data by Delta in place (_Dev.center(_Delta)); the reference recomputes the
+    // means of _Dev there, which nothing in the iteration reads
+    _Dev.emIteration(_rankF, _rankG, _F, _G, _Sigma, _Delta, sp);
 }
 
 void computeEigenProblem(const std::vector<double> &EP, unsigned long n, std::vector<double> &eigenVect, std::vector<double> &eigenVal,

@@ -247,6 +247,9 @@ class PldaDev {
     // the matrices and means of every iteration are returned instead of being written to files
     void sphericalNuisanceNormalization(unsigned long nbIt, bool sphNorm, std::vector<std::vector<double> > &mats,
                                         std::vector<std::vector<double> > &means);
+    // one PldaModel::em_iteration on this set (used by PldaModel; the data is centred by Delta in place)
+    void emIteration(unsigned long rankF, unsigned long rankG, std::vector<double> &F, std::vector<double> &G, std::vector<double> &Sigma,
+                     std::vector<double> &Delta, const std::vector<int64_t> &sessionsPerSpeaker);
     // :1931-2005: apply stored matrices / means
     void applySphericalNuisanceNormalization(const std::vector<std::vector<double> > &mats, const std::vector<std::vector<double> > &means);
 
@@ -256,6 +259,28 @@ class PldaDev {
     unsigned long _vectSize, _n_sessions;
     std::vector<double> _data, _mean, _speaker_means;
     std::vector<unsigned long> _session_per_speaker;
+};
+
+// PldaModel in training mode (PldaTools.cpp:2043-2120, 2329-2343, 2790-2815).  The reference draws F and G at
+// random when pldaLoadInitMatrices is false (initF / initG, glibc rand()); here they are always given, like its
+// pldaLoadInitMatrices branch.
+class PldaModel {
+  public:
+    PldaModel(PldaDev &dev, unsigned long rankF, unsigned long rankG, const std::vector<double> &F, const std::vector<double> &G,
+              const std::vector<double> &Sigma);
+    void em_iteration();                                        // :2329-2343
+    std::vector<double> &getF() { return _F; }                  // [vectSize x rankF]
+    std::vector<double> &getG() { return _G; }                  // [vectSize x rankG]
+    std::vector<double> &getSigma() { return _Sigma; }          // [vectSize x vectSize]
+    std::vector<double> &getDelta() { return _Delta; }          // minimum-divergence mean shift
+    const std::vector<double> &getOriginalMean() const { return _originalMean; }
+    unsigned long getRankF() const { return _rankF; }
+    unsigned long getRankG() const { return _rankG; }
+
+  private:
+    PldaDev &_Dev;
+    unsigned long _rankF, _rankG, _vectSize;
+    std::vector<double> _F, _G, _Sigma, _Delta, _originalMean;
 };
 
 // TVAcc::computeEigenProblem (AccumulateTVStat.cpp:2997-3102) for the SYMMETRIC matrices it is used on (the weighted

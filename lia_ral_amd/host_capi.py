@@ -132,6 +132,18 @@ def backend_train(X, sps, nb_it=2, sph_norm=False, lda_rank=0, device=0):
     return dict(X=X, mats=mats, means=means, wccn=wccn, mahalanobis=mah, lda=lda[:lda_rank])
 
 
+def plda_train(X, sps, F, G, Sigma, nb_it, device=0):
+    """PLDA.cpp training loop: nb_it x PldaModel::em_iteration.  -> dict(X, F, G, Sigma, Delta, original_mean)."""
+    X = np.array(X, np.float64, order="C", copy=True); F = np.array(F, np.float64, order="C", copy=True)
+    G = np.array(G, np.float64, order="C", copy=True); Sigma = np.array(Sigma, np.float64, order="C", copy=True)
+    dim, n = X.shape
+    sps = np.ascontiguousarray(sps, np.int64)
+    Delta = np.zeros(dim); om = np.zeros(dim)
+    _chk(lib.liagpu_plda_train(device, dim, ct.c_long(n), _d(X), ct.c_long(len(sps)), sps.ctypes.data_as(_lp), F.shape[1], G.shape[1], nb_it,
+                               _d(F), _d(G), _d(Sigma), _d(Delta), _d(om)))
+    return dict(X=X, F=F, G=G, Sigma=Sigma, Delta=Delta, original_mean=om)
+
+
 def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
     C, D = mean.shape

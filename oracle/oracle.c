@@ -871,6 +871,113 @@ int orc_dev_lda(int dim, const double *W, const double *B, int rank, double *lda
     return 0;
 }
 
+static void mm(int M, int N, int K, const double *A, int ta, const double *B, int tb, double *Cm);
+/* PldaModel::em_iteration = center(Delta) + computeCovMatEigen + getExpectedValuesUnThreaded + mStep,
+ * LIA_SpkTools/src/PldaTools.cpp:2329-2343, 931-950, 2359-2484, 2790-2815.  X [dim x n] (centred in place by Delta,
+ * like _Dev.center), sessions grouped by speaker; F [dim x rf], G [dim x rg], Sigma [dim x dim], Delta [dim] updated.
+ * The reference builds M = V (n D + I)^-1 V^T from the eigen-decomposition of A; that is (n A + I)^-1, restated here
+ * with the explicit inverse (no dependence on the eigen-solver's ordering). */
+int orc_plda_em_iteration(int dim, long n, double *X, long nspk, const long *sps, int rf, int rg, double *F, double *G,
+                          double *Sigma, double *Delta)
+{
+    const int rh = rf + rg;
+    int rc = 0;
+    for (long s = 0; s < n; ++s) for (int k = 0; k < dim; ++k) X[(size_t)k * n + s] -= Delta[k];
+    double *sigObs = calloc((size_t)dim * dim, sizeof(double));
+    for (int i = 0; i < dim; ++i)
+        for (int j = i; j < dim; ++j) {
+            double v = 0.0;
+            for (long s = 0; s < n; ++s) v += X[(size_t)i * n + s] * X[(size_t)j * n + s];
+            sigObs[(size_t)i * dim + j] = sigObs[(size_t)j * dim + i] = v;
+        }
+    /* preComputation */
+    double *Si = malloc(sizeof(double) * (size_t)dim * dim), *Ftw = malloc(sizeof(double) * (size_t)rf * dim), *Gtw = malloc(sizeof(double) * (size_t)rg * dim);
+    double *GtwG = malloc(sizeof(double) * (size_t)rg * rg), *FtwG = malloc(sizeof(double) * (size_t)rf * rg), *iGG = malloc(sizeof(double) * (size_t)rg * rg);
+    double *FtwF = malloc(sizeof(double) * (size_t)rf * rf), *Sm = malloc(sizeof(double) * (size_t)rg * rf), *A = malloc(sizeof(double) * (size_t)rf * rf);
+    double *t1 = malloc(sizeof(double) * (size_t)rf * rg);
+    rc |= orc_invert(dim, Sigma, Si);
+    mm(rf, dim, dim, F, 1, Si, 0, Ftw);
+    mm(rg, dim, dim, G, 1, Si, 0, Gtw);
+    mm(rg, rg, dim, Gtw, 0, G, 0, GtwG);
+    mm(rf, rg, dim, Ftw, 0, G, 0, FtwG);
+    for (int i = 0; i < rg; ++i) GtwG[(size_t)i * rg + i] += 1.0;
+    rc |= orc_invert(rg, GtwG, iGG);
+    mm(rf, rf, dim, Ftw, 0, F, 0, FtwF);
+    mm(rg, rf, rg, iGG, 0, FtwG, 1, Sm);                 /* S = iGG FtwG^T  [rg x rf] */
+    mm(rf, rg, rg, FtwG, 0, iGG, 0, t1);
+    mm(rf, rf, rg, t1, 0, FtwG, 1, A);
+    for (size_t i = 0; i < (size_t)rf * rf; ++i) A[i] = FtwF[i] - A[i];
+    double *Ehh = calloc((size_t)rh * rh, sizeof(double)), *xh = calloc((size_t)dim * rh, sizeof(double)), *U = calloc(rh, sizeof(double));
+    double *M = malloc(sizeof(double) * (size_t)rf * rf), *MsT = malloc(sizeof(double) * (size_t)rf * rg), *J = malloc(sizeof(double) * (size_t)rf * rf);
+    double *tmpM = malloc(sizeof(double) * (size_t)rh * rh), *SMsT = malloc(sizeof(double) * (size_t)rg * rg);
+    long cur = 0, s0 = 0;
+    for (long spk = 0; spk < nspk && !rc; ++spk) {
+        const long ns = sps[spk];
+        if (ns != cur) {
+            cur = ns;
+            for (size_t i = 0; i < (size_t)rf * rf; ++i) J[i] = (double)ns * A[i];
+            for (int i = 0; i < rf; ++i) J[(size_t)i * rf + i] += 1.0;
+            rc |= orc_invert(rf, J, M);
+            mm(rf, rg, rf, M, 0, Sm, 1, MsT);            /* M S^T */
+            mm(rg, rg, rf, Sm, 0, MsT, 0, SMsT);
+            for (int i = 0; i < rf; ++i) for (int j = 0; j < rf; ++j) tmpM[(size_t)i * rh + j] = M[(size_t)i * rf + j];
+            for (int i = 0; i < rf; ++i) for (int j = 0; j < rg; ++j) { tmpM[(size_t)i * rh + rf + j] = -MsT[(size_t)i * rg + j]; tmpM[(size_t)(rf + j) * rh + i] = -MsT[(size_t)i * rg + j]; }
+            for (int i = 0; i < rg; ++i) for (int j = 0; j < rg; ++j) tmpM[(size_t)(rf + i) * rh + rf + j] = iGG[(size_t)i * rg + j] + SMsT[(size_t)i * rg + j];
+        }
+        double *fi = malloc(sizeof(double) * (size_t)rf * ns), *gi = malloc(sizeof(double) * (size_t)rg * ns);
+        double *f = calloc(rf, sizeof(double)), *g = calloc(rg, sizeof(double)), *h = malloc(sizeof(double) * rf), *Eh = malloc(sizeof(double) * (size_t)rh * ns);
+        for (long j = 0; j < ns; ++j) {
+            for (int r = 0; r < rf; ++r) { double v = 0.0; for (int k = 0; k < dim; ++k) v += Ftw[(size_t)r * dim + k] * X[(size_t)k * n + s0 + j]; fi[(size_t)r * ns + j] = v; f[r] += v; }
+            for (int r = 0; r < rg; ++r) { double v = 0.0; for (int k = 0; k < dim; ++k) v += Gtw[(size_t)r * dim + k] * X[(size_t)k * n + s0 + j]; gi[(size_t)r * ns + j] = v; g[r] += v; }
+        }
+        for (int r = 0; r < rf; ++r) { double v = f[r]; for (int k = 0; k < rg; ++k) v -= Sm[(size_t)k * rf + r] * g[k]; fi[(size_t)r * ns] = v; } /* reuse column 0 of fi as (f - S^T g) */
+        for (int r = 0; r < rf; ++r) { double v = 0.0; for (int k = 0; k < rf; ++k) v += M[(size_t)r * rf + k] * fi[(size_t)k * ns]; h[r] = v; }
+        for (long j = 0; j < ns; ++j) {
+            for (int r = 0; r < rf; ++r) Eh[(size_t)r * ns + j] = h[r];
+            for (int r = 0; r < rg; ++r) {
+                double v = 0.0;
+                for (int k = 0; k < rg; ++k) v += iGG[(size_t)r * rg + k] * gi[(size_t)k * ns + j];
+                for (int k = 0; k < rf; ++k) v -= Sm[(size_t)r * rf + k] * h[k];
+                Eh[(size_t)(rf + r) * ns + j] = v;
+            }
+        }
+        for (int i = 0; i < rh; ++i)
+            for (int j = 0; j < rh; ++j) {
+                double v = (double)ns * tmpM[(size_t)i * rh + j];
+                for (long k = 0; k < ns; ++k) v += Eh[(size_t)i * ns + k] * Eh[(size_t)j * ns + k];
+                Ehh[(size_t)i * rh + j] += v;
+            }
+        for (int i = 0; i < dim; ++i)
+            for (int j = 0; j < rh; ++j) { double v = 0.0; for (long k = 0; k < ns; ++k) v += X[(size_t)i * n + s0 + k] * Eh[(size_t)j * ns + k]; xh[(size_t)i * rh + j] += v; }
+        for (long k = 0; k < ns; ++k) for (int i = 0; i < rh; ++i) U[i] += Eh[(size_t)i * ns + k];
+        free(fi); free(gi); free(f); free(g); free(h); free(Eh);
+        s0 += ns;
+    }
+    /* mStep */
+    double *iE = malloc(sizeof(double) * (size_t)rh * rh), *FG = malloc(sizeof(double) * (size_t)dim * rh), *SL = malloc(sizeof(double) * (size_t)dim * dim);
+    rc |= orc_invert(rh, Ehh, iE);
+    mm(dim, rh, rh, xh, 0, iE, 0, FG);
+    mm(dim, dim, rh, FG, 0, xh, 1, SL);
+    for (size_t i = 0; i < (size_t)dim * dim; ++i) Sigma[i] = (sigObs[i] - SL[i]) / (double)n;
+    for (int i = 0; i < rh; ++i) U[i] /= (double)n;
+    double *cF = malloc(sizeof(double) * (size_t)rf * rf), *cG = malloc(sizeof(double) * (size_t)rg * rg), *Rh = malloc(sizeof(double) * (size_t)rf * rf), *Rw = malloc(sizeof(double) * (size_t)rg * rg);
+    for (int i = 0; i < rf; ++i) for (int j = 0; j < rf; ++j) cF[(size_t)i * rf + j] = Ehh[(size_t)i * rh + j] / (double)n - U[i] * U[j];
+    for (int i = 0; i < rg; ++i) for (int j = 0; j < rg; ++j) cG[(size_t)i * rg + j] = Ehh[(size_t)(rf + i) * rh + rf + j] / (double)n - U[rf + i] * U[rf + j];
+    rc |= orc_upper_cholesky(rf, cF, Rh);
+    rc |= orc_upper_cholesky(rg, cG, Rw);
+    for (int i = 0; i < dim; ++i) {   /* F = FGEst[:, :rf] Rh^T ; G = FGEst[:, rf:] Rw^T ; Delta += FGEst U */
+        for (int j = 0; j < rf; ++j) { double v = 0.0; for (int k = 0; k < rf; ++k) v += FG[(size_t)i * rh + k] * Rh[(size_t)j * rf + k]; F[(size_t)i * rf + j] = v; }
+        for (int j = 0; j < rg; ++j) { double v = 0.0; for (int k = 0; k < rg; ++k) v += FG[(size_t)i * rh + rf + k] * Rw[(size_t)j * rg + k]; G[(size_t)i * rg + j] = v; }
+        double d = 0.0;
+        for (int k = 0; k < rh; ++k) d += FG[(size_t)i * rh + k] * U[k];
+        Delta[i] += d;
+    }
+    free(sigObs); free(Si); free(Ftw); free(Gtw); free(GtwG); free(FtwG); free(iGG); free(FtwF); free(Sm); free(A); free(t1);
+    free(Ehh); free(xh); free(U); free(M); free(MsT); free(J); free(tmpM); free(SMsT); free(iE); free(FG); free(SL);
+    free(cF); free(cG); free(Rh); free(Rw);
+    return rc;
+}
+
 /* PldaModel::preComputation + the first lines of PldaTest::pldaNativeScoring, LIA_SpkTools/src/PldaTools.cpp:2950-2972,
  * 4494-4496.  F [dim x rf], G [dim x rg], Sigma [dim x dim] (row-major):
  *   FTJ  = F^T S^-1 - F^T S^-1 G (G^T S^-1 G + I)^-1 G^T S^-1      [rf x dim]

@@ -479,3 +479,17 @@ def dev_lda(W, B, rank):
     out = np.zeros((rank, dim)); val = np.zeros(rank)
     assert _lib().orc_dev_lda(ct.c_int(dim), wp, bp, ct.c_int(rank), out.ctypes.data_as(c_dp), val.ctypes.data_as(c_dp)) == 0
     return out, val
+
+
+def plda_em_iteration(X, sps, F, G, Sigma, Delta):
+    """One PldaModel::em_iteration; returns updated copies (X centred by the incoming Delta)."""
+    X = np.array(X, np.float64, order="C", copy=True); F = np.array(F, np.float64, order="C", copy=True)
+    G = np.array(G, np.float64, order="C", copy=True); Sigma = np.array(Sigma, np.float64, order="C", copy=True)
+    Delta = np.array(Delta, np.float64, order="C", copy=True)
+    sps, sp = _l(sps)
+    dim, n = X.shape
+    rc = _lib().orc_plda_em_iteration(ct.c_int(dim), ct.c_long(n), X.ctypes.data_as(c_dp), ct.c_long(len(sps)), sp, ct.c_int(F.shape[1]),
+                                      ct.c_int(G.shape[1]), F.ctypes.data_as(c_dp), G.ctypes.data_as(c_dp), Sigma.ctypes.data_as(c_dp),
+                                      Delta.ctypes.data_as(c_dp))
+    assert rc == 0
+    return X, F, G, Sigma, Delta

@@ -207,3 +207,21 @@ def test_backend_training_chain(sph_norm):
     assert relerr(res["wccn"], orc.dev_wccn_chol(Y, sps)) < 1e-7
     oL, lam = orc.dev_lda(W, B, 3)
     assert relerr(np.abs(res["lda"]), np.abs(oL)) < 1e-6
+
+
+def test_plda_training_loop():
+    """PLDA.cpp:80-95 through liagpu::PldaModel: 4 EM iterations against the oracle loop."""
+    from lia_ral_amd import host_capi as host
+    rng = np.random.default_rng(8)
+    dim, rf, rg, nspk = 24, 6, 4, 60
+    sps = rng.integers(2, 6, nspk)
+    cls = np.repeat(np.arange(nspk), sps); n = int(sps.sum())
+    X = rng.normal(size=(dim, rf)) @ rng.normal(size=(rf, nspk))[:, cls] + 0.5 * rng.normal(size=(dim, n)) + 1.0
+    F = rng.normal(size=(dim, rf)); G = 0.3 * rng.normal(size=(dim, rg)); Sigma = np.cov(X) + 0.1 * np.eye(dim)
+    res = host.plda_train(X, sps, F, G, Sigma, nb_it=4)
+    ref = (X, F, G, Sigma, np.zeros(dim))
+    for it in range(4):
+        ref = orc.plda_em_iteration(ref[0], sps, *ref[1:])
+    assert relerr(res["F"], ref[1]) < 1e-7 and relerr(res["G"], ref[2]) < 1e-7 and relerr(res["Sigma"], ref[3]) < 1e-7
+    assert relerr(res["Delta"], ref[4]) < 1e-7 and relerr(res["X"], ref[0]) < 1e-8
+    assert relerr(res["original_mean"], X.mean(1)) < 1e-12

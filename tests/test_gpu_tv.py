@@ -236,3 +236,27 @@ def test_efr_lda_and_eigen(ctx, dim):
     assert np.allclose(np.linalg.norm(Y, axis=0), 1.0)
     Yo = M @ (X - X.mean(1)[:, None]); Yo /= np.linalg.norm(Yo, axis=0)
     assert relerr(Y, Yo) < 1e-10
+
+
+@pytest.mark.parametrize("dim,rf,rg,nspk", [(8, 3, 2, 8), (60, 20, 10, 120), (200, 60, 40, 400)])
+def test_plda_em_iterations_match_oracle(ctx, dim, rf, rg, nspk):
+    """PldaModel::em_iteration (PldaTools.cpp:2329-2343, 2359-2484, 2790-2815): three iterations, every quantity
+    (centred data, F, G, Sigma, Delta) against the oracle; numpy arrays in place and a device-resident X."""
+    import torch
+    rng = np.random.default_rng(dim)
+    sps = rng.integers(1, 6, nspk)
+    k, n = nspk, int(sps.sum())
+    cls = np.repeat(np.arange(k), sps)
+    Ft = rng.normal(size=(dim, rf)); Gt = 0.5 * rng.normal(size=(dim, rg))
+    X = Ft @ rng.normal(size=(rf, k))[:, cls] + Gt @ rng.normal(size=(rg, n)) + 0.3 * rng.normal(size=(dim, n)) + 0.2
+    F = rng.normal(size=(dim, rf)); G = 0.5 * rng.normal(size=(dim, rg)); Sigma = np.cov(X) + 0.1 * np.eye(dim); Delta = np.zeros(dim)
+    ref = (X.copy(), F.copy(), G.copy(), Sigma.copy(), Delta.copy())
+    Xg = np.ascontiguousarray(X.copy()); Xd = torch.from_numpy(X.copy()).cuda()
+    Fd, Gd, Sd, Dd = F.copy(), G.copy(), Sigma.copy(), Delta.copy()
+    for it in range(3):
+        ref = orc.plda_em_iteration(ref[0], sps, *ref[1:])
+        ctx.plda_em_iteration(Xg, sps, F, G, Sigma, Delta)
+        ctx.plda_em_iteration(Xd, sps, Fd, Gd, Sd, Dd)
+        for got, want in zip((Xg, F, G, Sigma, Delta), ref):
+            assert relerr(got, want) < 1e-8, it
+        assert relerr(Xd.cpu().numpy(), ref[0]) < 1e-8 and relerr(Fd, ref[1]) < 1e-8 and relerr(Sd, ref[3]) < 1e-8

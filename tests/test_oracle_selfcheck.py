@@ -161,3 +161,47 @@ def test_backend_estimation_against_numpy():
         assert np.allclose(EP @ L[j], lam[j] * L[j], atol=1e-9 * abs(lam[0])) and abs(np.linalg.norm(L[j]) - 1) < 1e-12
     ev = np.sort(np.linalg.eigvals(EP).real)[::-1]
     assert np.allclose(lam, ev[:3], rtol=1e-9, atol=1e-12)
+
+
+def _plda_em_numpy(X, sps, F, G, Sigma, Delta):
+    """PldaModel::em_iteration (PldaTools.cpp:2329-2343, 2359-2484, 2790-2815) with numpy, speaker by speaker."""
+    dim, n = X.shape; rf, rg = F.shape[1], G.shape[1]
+    X = X - Delta[:, None]
+    sigObs = X @ X.T
+    Si = np.linalg.inv(Sigma); Ftw = F.T @ Si; Gtw = G.T @ Si
+    iGG = np.linalg.inv(Gtw @ G + np.eye(rg)); FtwG = Ftw @ G
+    S = iGG @ FtwG.T; A = Ftw @ F - FtwG @ iGG @ FtwG.T
+    Ehh = np.zeros((rf + rg, rf + rg)); xh = np.zeros((dim, rf + rg)); U = np.zeros(rf + rg)
+    s0 = 0
+    for ns in sps:
+        Xs = X[:, s0:s0 + ns]; s0 += ns
+        M = np.linalg.inv(ns * A + np.eye(rf)); MsT = M @ S.T
+        fi = Ftw @ Xs; gi = Gtw @ Xs
+        h = M @ (fi.sum(1) - S.T @ gi.sum(1))
+        w = iGG @ gi - (S @ h)[:, None]
+        Eh = np.vstack([np.repeat(h[:, None], ns, 1), w])
+        tmpM = np.block([[M, -MsT], [-MsT.T, iGG + S @ MsT]])
+        Ehh += ns * tmpM + Eh @ Eh.T; xh += Xs @ Eh.T; U += Eh.sum(1)
+    FG = xh @ np.linalg.inv(Ehh)
+    Sig = (sigObs - FG @ xh.T) / n
+    U /= n
+    c = Ehh / n - np.outer(U, U)
+    Rh = np.linalg.cholesky(c[:rf, :rf]).T; Rw = np.linalg.cholesky(c[rf:, rf:]).T
+    return X, FG[:, :rf] @ Rh.T, FG[:, rf:] @ Rw.T, Sig, Delta + FG @ U
+
+
+def test_plda_em_iteration_against_numpy():
+    rng = np.random.default_rng(3)
+    dim, rf, rg = 8, 3, 2
+    sps = np.array([2, 2, 3, 3, 3, 1, 4, 2])
+    k, n = len(sps), int(sps.sum())
+    cls = np.repeat(np.arange(k), sps)
+    X = (rng.normal(size=(dim, k)))[:, cls] + 0.5 * rng.normal(size=(dim, n))
+    F = rng.normal(size=(dim, rf)); G = 0.5 * rng.normal(size=(dim, rg)); Sigma = np.cov(X) + 0.1 * np.eye(dim); Delta = np.zeros(dim)
+    state = (X, F, G, Sigma, Delta)
+    ref = state
+    for it in range(3):
+        state = orc.plda_em_iteration(state[0], sps, *state[1:])
+        ref = _plda_em_numpy(ref[0], sps, *ref[1:])
+        for a, b in zip(state, ref):
+            assert np.allclose(a, b, rtol=1e-8, atol=1e-10)
