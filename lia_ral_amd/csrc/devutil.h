@@ -111,6 +111,32 @@ __device__ __forceinline__ double gexp_scaled(double x, int E, const double *tab
     n = n < -2000 ? -2000 : n;
     return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
 }
+// gexp_scaled with the 64-entry table (gexp_table64_init): |r| <= ln2/128, degree-5 series (4e-17), two-step
+// argument reduction kept because x is a raw logit (|x| up to 1e4 and more).  The binary exponent is ki >> 6.
+__device__ __forceinline__ double gexp_scaled64(double x, int E, const double *tab)
+{
+    x = fmax(x, -2.0e7);
+    const double k = __builtin_rint(x * 92.33248261689366);
+    double r = __builtin_fma(k, -0.010830424609594047, x);   // ln2/64 high part (trailing bits zero)
+    r = __builtin_fma(k, -8.665509839009470e-11, r);         // ln2/64 low part
+    const int ki = (int)k;
+    const double tj = tab[ki & 63];
+    double p = 8.333333333333333e-03;
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    int n = (ki >> 6) - E;
+    n = n < -2000 ? -2000 : n;
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
+}
+// the binary exponent gexp_scaled64 assigns to exp(x): same clamp, same rounding
+__device__ __forceinline__ int gexp_exponent64(double x)
+{
+    x = fmax(x, -2.0e7);
+    return ((int)__builtin_rint(x * 92.33248261689366)) >> 6;
+}
 // floor(x log2 e) as used by gexp_scaled (the binary exponent of exp(x))
 __device__ __forceinline__ int gexp_exponent(double x)
 {
