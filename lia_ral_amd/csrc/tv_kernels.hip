@@ -15,19 +15,28 @@
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
-                                               long lda, long sA, const double *__restrict__ B, long ldb, long sB,
-                                               double beta, double *__restrict__ C, long ldc, long sC, int ksplit)
+// Two instantiations per transpose pair:
+//   EDGE = false  interior tiles (full 128 x 128, K range a multiple of 16, rows 16-byte aligned): no bounds
+//                 checks, 16-byte loads, one base pointer per operand advanced per k-tile.  The register
+//                 budget is 256 unified VGPRs (2 waves per SIMD): with 512 the compiler parks the
+//                 accumulators in AGPRs and pays 2 v_accvgpr moves per MFMA (measured: core loop 56 instead of
+//                 73 TFLOP/s, tools/gemm_probe.hip).
+//   EDGE = true   tiles cut by M, N or K: per-element loads with bounds checks (the original path).
+// bm0 / bn0: block offsets of the launched sub-grid (interior, right strip, bottom strip).
+template <bool TA, bool TB, bool EDGE>
+__global__ __launch_bounds__(256, (EDGE ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
+                                                  long lda, long sA, const double *__restrict__ B, long ldb, long sB,
+                                                  double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int bm0, int bn0)
 {
     constexpr int BM = 128, BN = 128, BK = 16;
     __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) double Bs[2][BK][BN];
+    typedef double d2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
-    const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+    const long m0 = (long)(blockIdx.y + bm0) * BM, n0 = (long)(blockIdx.x + bn0) * BN;
     // ksplit > 0: blockIdx.z selects a K range [kb, ke) and C is the z-th partial slab (stride sC);
     // otherwise blockIdx.z is the batch index.
     long kb = 0, ke = K;
@@ -40,8 +49,28 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
     }
     C += (size_t)blockIdx.z * sC;
 
+    // ---- staging: EDGE -> 8 + 8 checked scalar loads; interior -> 4 + 4 unchecked 16-byte loads -----------
     double ra[8], rb[8];
+    // interior path: operand with k fastest in memory: thread owns k pair kq = 2 (tid & 7), rows (tid >> 3) + 32 i;
+    //                operand with m (n) fastest:       thread owns column pair 2 (tid & 63), k rows (tid >> 6) + 4 i
+    const double *pa = nullptr, *pb = nullptr;
+    if (!EDGE) {
+        pa = TA ? A + (kb + (tid >> 6)) * lda + m0 + 2 * (tid & 63) : A + (m0 + (tid >> 3)) * lda + kb + 2 * (tid & 7);
+        pb = TB ? B + (n0 + (tid >> 3)) * ldb + kb + 2 * (tid & 7) : B + (kb + (tid >> 6)) * ldb + n0 + 2 * (tid & 63);
+    }
     auto gload = [&](int kt) {
+        if (!EDGE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const d2 va = *(const d2 *)(TA ? pa + (long)(4 * i) * lda : pa + (long)(32 * i) * lda);
+                const d2 vb = *(const d2 *)(TB ? pb + (long)(32 * i) * ldb : pb + (long)(4 * i) * ldb);
+                ra[2 * i] = va[0]; ra[2 * i + 1] = va[1];
+                rb[2 * i] = vb[0]; rb[2 * i + 1] = vb[1];
+            }
+            pa += TA ? (long)BK * lda : BK;
+            pb += TB ? BK : (long)BK * ldb;
+            return;
+        }
         const long k0 = kb + (long)kt * BK;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -65,6 +94,16 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
         }
     };
     auto swrite = [&](int buf) {
+        if (!EDGE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TA) { const int k = (tid >> 6) + 4 * i, m = 2 * (tid & 63); As[buf][k][m ^ kswz(k)] = ra[2 * i]; As[buf][k][(m + 1) ^ kswz(k)] = ra[2 * i + 1]; }
+                else { const int k = 2 * (tid & 7), m = (tid >> 3) + 32 * i; As[buf][k][m ^ kswz(k)] = ra[2 * i]; As[buf][k + 1][m ^ kswz(k + 1)] = ra[2 * i + 1]; }
+                if (TB) { const int k = 2 * (tid & 7), n = (tid >> 3) + 32 * i; Bs[buf][k][n ^ kswz(k)] = rb[2 * i]; Bs[buf][k + 1][n ^ kswz(k + 1)] = rb[2 * i + 1]; }
+                else { const int k = (tid >> 6) + 4 * i, n = 2 * (tid & 63); Bs[buf][k][n ^ kswz(k)] = rb[2 * i]; Bs[buf][k][(n + 1) ^ kswz(k)] = rb[2 * i + 1]; }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
@@ -116,11 +155,11 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long gm = m0 + wr * 64 + a * 16 + q + 4 * r;
-            if (gm >= M) continue;
+            if (EDGE && gm >= M) continue;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const long gn = n0 + wc * 64 + b * 16 + i16;
-                if (gn >= N) continue;
+                if (EDGE && gn >= N) continue;
                 double v = alpha * acc[a][b][r];
                 if (beta != 0.0) v += beta * C[gm * ldc + gn];
                 C[gm * ldc + gn] = v;
@@ -128,14 +167,54 @@ __global__ __launch_bounds__(256) void k_dgemm(int M, int N, int K, double alpha
         }
 }
 
+template <bool EDGE>
+static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
+                           long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
+                           int ksplit, int bm0, int bn0)
+{
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
+    if (!ta && !tb) k_dgemm<false, false, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    else if (!ta && tb) k_dgemm<false, true, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    else if (ta && !tb) k_dgemm<true, false, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    else k_dgemm<true, true, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+}
+
+// grid.z = batch (ksplit == 0) or K layers (ksplit > 0).  Interior tiles go to the unchecked kernel when every K range
+// is a multiple of 16 and the operands allow 16-byte loads; the right and bottom strips (and everything else) to EDGE.
 static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                          long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
                          int ksplit)
 {
-    if (!ta && !tb) k_dgemm<false, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
-    else if (!ta && tb) k_dgemm<false, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
-    else if (ta && !tb) k_dgemm<true, false><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
-    else k_dgemm<true, true><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit);
+    const bool kfull = K % 16 == 0 && (ksplit <= 0 || ksplit % 16 == 0);
+    const bool aligned = (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0 && sA % 2 == 0 && sB % 2 == 0;
+    const int fm = M / 128, fn = N / 128; // full tiles
+    if (!kfull || !aligned || K <= 0 || fm == 0 || fn == 0) {
+        launch_dgemm_e<true>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+        return;
+    }
+    // The strips are few workgroups that each walk the whole K range: on the caller's stream they would run AFTER the
+    // interior grid and add their full latency.  They go to a side stream (forked and joined with events) and run
+    // beside the interior tiles; the tiles are disjoint, so there is no ordering between the launches to keep.
+    const bool has_strips = (int)grid.x > fn || (int)grid.y > fm;
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false;
+    if (has_strips) {
+        if (!side) {
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+            else if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(side); side = nullptr; }
+        }
+        forked = side && hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
+    }
+    hipStream_t ss = forked ? side : st;
+    if ((int)grid.x > fn) launch_dgemm_e<true>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn);
+    if ((int)grid.y > fm) launch_dgemm_e<true>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0);
+    launch_dgemm_e<false>(st, ta, tb, dim3(fn, fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+    if (forked) {
+        (void)hipEventRecord(ev_join, side);
+        (void)hipStreamWaitEvent(st, ev_join, 0);
+    }
 }
 
 int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, long sA,

@@ -1,0 +1,43 @@
+// gemm_probe.hip -- times tvk_dgemm (lia_ral_amd/csrc/tv_kernels.hip) on the shapes the i-vector path uses.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/bin/gemm_probe
+#include "../lia_ral_amd/csrc/tv_kernels.hip"
+#include <cstdio>
+#include <vector>
+
+struct Shape { const char *name; bool ta, tb; int M, N, K; };
+
+int main()
+{
+    const Shape shapes[] = {
+        {"square 4096^3 NN", false, false, 4096, 4096, 4096},
+        {"square 4096^3 NT", false, true, 4096, 4096, 4096},
+        {"L = N TETt: 256 x 80200 x 2048 NN", false, false, 256, 80200, 2048},
+        {"A += N^T E: 2048 x 80200 x 256 TN", true, false, 2048, 80200, 256},
+        {"Cmx += W^T F: 400 x 122880 x 256 TN", true, false, 400, 122880, 256},
+        {"scores: 20000 x 20000 x 400 TN", true, false, 20000, 20000, 400},
+    };
+    hipStream_t st;
+    hipStreamCreate(&st);
+    for (const Shape &s : shapes) {
+        const size_t na = (size_t)s.M * s.K, nb = (size_t)s.K * s.N, nc = (size_t)s.M * s.N;
+        double *A, *B, *C;
+        hipMalloc(&A, na * 8); hipMalloc(&B, nb * 8); hipMalloc(&C, nc * 8);
+        hipMemset(A, 0, na * 8); hipMemset(B, 0, nb * 8);
+        const long lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        tvk_dgemm(st, s.ta, s.tb, s.M, s.N, s.K, 1.0, A, lda, 0, B, ldb, 0, 0.0, C, s.N, 0, 1);
+        hipStreamSynchronize(st);
+        hipEventRecord(e0, st);
+        const int reps = 3;
+        for (int r = 0; r < reps; ++r) tvk_dgemm(st, s.ta, s.tb, s.M, s.N, s.K, 1.0, A, lda, 0, B, ldb, 0, 0.0, C, s.N, 0, 1);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        ms /= reps;
+        printf("%-40s %8.3f ms  %6.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        hipFree(A); hipFree(B); hipFree(C);
+    }
+    return 0;
+}
