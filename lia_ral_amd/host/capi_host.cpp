@@ -105,6 +105,44 @@ int liagpu_compute_test(int device, const float *x, long T, int D, const long *s
     })
 }
 
+// ComputeTest with worldDecime and the WindowLLR mode (ComputeTest.cpp:154-207, UnsupervisedTools.cpp:70-145).
+// win_out receives up to max_win rows [idxBegin, idxEnd, llr(client 0..nClients-1)]; *n_win = rows produced.
+int liagpu_compute_test_ex(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg, int C,
+                           const double *w_world, const double *mean_world, const double *cov_world, int nClients, const double *w_cl,
+                           const double *mean_cl, const double *cov_cl, int topDistribsCount, int complete, double minLLK, double maxLLK,
+                           int segmentalMode, long worldDecime, long windowSize, long windowDec, double *llr_out, double *win_out,
+                           long max_win, long *n_win)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD world = make_mixture(C, D, w_world, mean_world, cov_world);
+        DeviceMixture dworld(srv, world);
+        std::vector<DeviceMixture *> cl;
+        const size_t CD = (size_t)C * D;
+        for (int i = 0; i < nClients; ++i)
+            cl.push_back(new DeviceMixture(srv, make_mixture(C, D, w_cl + (size_t)i * C, mean_cl + i * CD, cov_cl + i * CD)));
+        std::vector<double> out;
+        std::vector<WindowOut> wins;
+        try {
+            out = computeTestLLR(fs, segs, dworld, cl, topDistribsCount, complete != 0, minLLK, maxLLK, segmentalMode != 0,
+                                 (unsigned long)worldDecime, (unsigned long)windowSize, (unsigned long)windowDec, &wins);
+        } catch (...) { for (auto p : cl) delete p; throw; }
+        for (auto p : cl) delete p;
+        memcpy(llr_out, out.data(), out.size() * sizeof(double));
+        long nw = 0;
+        for (const WindowOut &o : wins) {
+            if (nw >= max_win) break;
+            double *row = win_out + (size_t)nw * (2 + nClients);
+            row[0] = (double)o.idxBegin; row[1] = (double)o.idxEnd;
+            for (int i = 0; i < nClients; ++i) row[2 + i] = o.llr[i];
+            ++nw;
+        }
+        if (n_win) *n_win = (long)wins.size();
+    })
+}
+
 // IvExtractor (IvExtractor.cpp:70-148): stats -> substractM -> estimateTETt -> estimateW
 int liagpu_iv_extract(int device, const float *x, long T, int D, const long *utt_begin, long U, int C, const double *w,
                       const double *mean, const double *cov, int R, const double *Tmat, double *W_out, double *N_out,

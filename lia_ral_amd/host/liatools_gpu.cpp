@@ -368,6 +368,106 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     return out;
 }
 
+WindowLLR::WindowLLR(unsigned long size, unsigned long dec, unsigned long nClient)
+    : _size(size), _dec(dec), _nClient(nClient), _bIdx(0), _count(0), _idx(size, 0), _acc(nClient, 0.0), _llr(size * nClient, 0.0) {}
+void WindowLLR::dec(unsigned long idxFrame)
+{
+    if (_count < _size) { // window is not full
+        _count++;
+        _idx[(_bIdx + _count - 1) % _size] = idxFrame;
+    } else {              // full: shift by _dec frames
+        for (unsigned long w = 0; w < _dec; ++w) {
+            for (unsigned long c = 0; c < _nClient; ++c) _acc[c] -= _llr[_bIdx * _nClient + c];
+            _bIdx = (_bIdx + 1) % _size;
+        }
+        _count -= (_dec - 1);
+        _idx[(_bIdx + _count - 1) % _size] = idxFrame;
+    }
+}
+void WindowLLR::accLLR(unsigned long clientIdx, double llr)
+{
+    _llr[((_bIdx + _count - 1) % _size) * _nClient + clientIdx] = llr;
+    _acc[clientIdx] += llr;
+}
+
+std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selectedSegments, DeviceMixture &world,
+                                   std::vector<DeviceMixture *> &clients, int topDistribsCount, bool complete, double minLLK,
+                                   double maxLLK, bool segmentalMode, unsigned long worldDecime, unsigned long windowSize,
+                                   unsigned long windowDec, std::vector<WindowOut> *windows)
+{
+    if (worldDecime == 0) throw Exception("computeTestLLR: worldDecime must be >= 1");
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
+    const int ctop = topDistribsCount;
+    std::vector<int32_t> idx((size_t)n * ctop);
+    std::vector<double> nllk(n), llkw(n), llkc(n);
+    // DETERMINE_TOP_DISTRIBS on every frame; frames that are not a multiple of worldDecime inside their segment then
+    // take the top set (and the non-top remainder) of the last frame that is, and the world is re-scored on it
+    srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), ctop, mode, minLLK, maxLLK,
+                                      idx.data(), nullptr, nullptr, nllk.data(), nullptr, llkw.data()));
+    std::vector<char> determined(n, 1);
+    std::vector<unsigned long> frameIdx(n); // absolute frame index (window bookkeeping)
+    {
+        size_t t = 0;
+        for (const Seg &sg : selectedSegments) {
+            const unsigned long first = sg.begin + fs.getFirstFeatureIndexOfASource(sg.source);
+            size_t last = t;
+            for (unsigned long f = 0; f < sg.length; ++f, ++t) {
+                frameIdx[t] = first + f;
+                if (f % worldDecime == 0) last = t;
+                else {
+                    determined[t] = 0;
+                    memcpy(&idx[t * ctop], &idx[last * ctop], ctop * sizeof(int32_t));
+                    nllk[t] = nllk[last];
+                }
+            }
+        }
+    }
+    if (worldDecime > 1) {
+        std::vector<double> w2(n);
+        srv.check(gmmiv_llk_use_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), ctop, idx.data(), nllk.data(),
+                                    mode, minLLK, maxLLK, w2.data()));
+        for (size_t t = 0; t < n; ++t) if (!determined[t]) llkw[t] = w2[t];
+    }
+    const size_t nseg = segmentalMode ? selectedSegments.size() : 1, nc = clients.size();
+    std::vector<double> out(nseg * nc, 0.0), llkcAll(windowSize ? n * nc : 0);
+    auto meanOver = [&](const std::vector<double> &v, size_t b, size_t e) {
+        double s = 0.0;
+        for (size_t i = b; i < e; ++i) s += v[i];
+        return e > b ? s / (double)(e - b) : 0.0;
+    };
+    for (size_t ci = 0; ci < nc; ++ci) {
+        srv.check(gmmiv_llk_use_top(srv.ctx(), clients[ci]->handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), ctop, idx.data(),
+                                    nllk.data(), mode, minLLK, maxLLK, llkc.data()));
+        size_t off = 0;
+        for (size_t s = 0; s < nseg; ++s) {
+            const size_t len = segmentalMode ? selectedSegments[s].length : n;
+            out[s * nc + ci] = meanOver(llkc, off, off + len) - meanOver(llkw, off, off + len);
+            off += len;
+        }
+        if (windowSize) for (size_t t = 0; t < n; ++t) llkcAll[t * nc + ci] = llkc[t];
+    }
+    if (windowSize && windows) {
+        // `double llkw = 0` is re-initialised for every frame in the reference loop (:160-161), so a frame whose
+        // world score was not recomputed contributes llkc - 0 to the window
+        windows->clear();
+        WindowLLR win(windowSize, windowDec ? windowDec : windowSize, nc);
+        for (size_t t = 0; t < n; ++t) {
+            win.dec(frameIdx[t]);
+            for (size_t ci = 0; ci < nc; ++ci) win.accLLR(ci, llkcAll[t * nc + ci] - (determined[t] ? llkw[t] : 0.0));
+            if (win.isEnd()) {
+                WindowOut o;
+                o.idxBegin = win.getIdxBegin(); o.idxEnd = win.getIdxEnd();
+                for (size_t ci = 0; ci < nc; ++ci) o.llr.push_back(win.getLLR(ci));
+                windows->push_back(o);
+            }
+        }
+    }
+    return out;
+}
+
 // ---- TVAcc -----------------------------------------------------------------------------------------
 TVAcc::TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned long nSpeakers)
     : _srv(srv), _ubm(ubm), _dubm(srv, ubm), _rankT(rankT), _n_speakers(nSpeakers), _n_distrib(ubm.getDistribCount()),

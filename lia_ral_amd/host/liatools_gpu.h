@@ -181,6 +181,28 @@ void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const Mix
 std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selectedSegments, DeviceMixture &world,
                                    std::vector<DeviceMixture *> &clients, int topDistribsCount, bool complete,
                                    double minLLK, double maxLLK, bool segmentalMode);
+// WindowLLR (LIA_SpkTools/src/UnsupervisedTools.cpp:70-145): sliding window over the per-frame LLRs of ComputeTest
+// (ComputeTest.cpp:165-178).  One WindowOut per position at which the window is full.
+struct WindowLLR {
+    WindowLLR(unsigned long size, unsigned long dec, unsigned long nClient);
+    void dec(unsigned long idxFrame);                        // :119-135
+    void accLLR(unsigned long clientIdx, double llr);        // :136-139
+    double getLLR(unsigned long clientIdx) const { return _acc[clientIdx] / (double)_size; }
+    bool isEnd() const { return _count == _size; }
+    unsigned long getIdxBegin() const { return _idx[_bIdx]; }
+    unsigned long getIdxEnd() const { return _idx[(_bIdx + _count - 1) % _size]; }
+    unsigned long _size, _dec, _nClient, _bIdx, _count;
+    std::vector<unsigned long> _idx;
+    std::vector<double> _acc, _llr; // _llr [size x nClient]
+};
+struct WindowOut { unsigned long idxBegin, idxEnd; std::vector<double> llr; /* one per client */ };
+// The full frame loop of ComputeTest.cpp:154-207: worldDecime (DETERMINE_TOP_DISTRIBS on every worldDecime-th frame
+// of a segment, USE_TOP_DISTRIBS with the last top set on the others) and the optional windowed LLRs
+// (windowSize == 0: off).  Returns the same file / segment LLRs as computeTestLLR.
+std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selectedSegments, DeviceMixture &world,
+                                   std::vector<DeviceMixture *> &clients, int topDistribsCount, bool complete,
+                                   double minLLK, double maxLLK, bool segmentalMode, unsigned long worldDecime,
+                                   unsigned long windowSize, unsigned long windowDec, std::vector<WindowOut> *windows);
 
 // ---- AccumulateTVStat.h ----------------------------------------------------------------------------
 class TVAcc {

@@ -89,6 +89,29 @@ def compute_test(x, seg_begin, seg_len, world, clients, top_c=10, complete=True,
     return out.reshape(-1, len(clients))
 
 
+def compute_test_ex(x, seg_begin, seg_len, world, clients, top_c=10, complete=True, min_llk=-200.0, max_llk=200.0, segmental=False,
+                    world_decime=1, window_size=0, window_dec=0, device=0):
+    """ComputeTest frame loop with worldDecime and the WindowLLR mode.  -> (llr [nseg or 1, nClients], windows [n, 2 + nClients])."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    sb = np.ascontiguousarray(seg_begin, np.int64); sl = np.ascontiguousarray(seg_len, np.int64)
+    ww, wm, wc = [np.ascontiguousarray(a, np.float64) for a in world]
+    C = len(ww)
+    cw = np.ascontiguousarray(np.stack([c[0] for c in clients]), np.float64)
+    cm = np.ascontiguousarray(np.stack([c[1] for c in clients]), np.float64)
+    cc = np.ascontiguousarray(np.stack([c[2] for c in clients]), np.float64)
+    nC = len(clients)
+    nseg = len(sb) if segmental else 1
+    out = np.empty((nseg, nC))
+    max_win = int(sl.sum()) + 1
+    win = np.zeros((max_win, 2 + nC)); nw = ct.c_long(0)
+    _chk(lib.liagpu_compute_test_ex(device, x.ctypes.data_as(_fp), ct.c_long(T), D, sb.ctypes.data_as(_lp), sl.ctypes.data_as(_lp),
+                                    ct.c_long(len(sb)), C, _d(ww), _d(wm), _d(wc), nC, _d(cw), _d(cm), _d(cc), top_c, int(complete),
+                                    ct.c_double(min_llk), ct.c_double(max_llk), int(segmental), ct.c_long(world_decime),
+                                    ct.c_long(window_size), ct.c_long(window_dec), _d(out), _d(win), ct.c_long(max_win), ct.byref(nw)))
+    return out, win[:nw.value]
+
+
 def iv_extract(x, utt_begin, ubm, Tmat, device=0, return_stats=False):
     x = np.ascontiguousarray(x, np.float32)
     T, D = x.shape

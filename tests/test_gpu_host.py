@@ -225,3 +225,69 @@ def test_plda_training_loop():
     assert relerr(res["F"], ref[1]) < 1e-7 and relerr(res["G"], ref[2]) < 1e-7 and relerr(res["Sigma"], ref[3]) < 1e-7
     assert relerr(res["Delta"], ref[4]) < 1e-7 and relerr(res["X"], ref[0]) < 1e-8
     assert relerr(res["original_mean"], X.mean(1)) < 1e-12
+
+
+def _window_llr_reference(size, dec, frame_idx, llr):
+    """UnsupervisedTools.cpp:119-145 in python: llr [n, nClient]; returns rows [idxBegin, idxEnd, llr...]."""
+    n, nc = llr.shape
+    idx = np.zeros(size, np.int64); acc = np.zeros(nc); buf = np.zeros((size, nc))
+    b = cnt = 0
+    rows = []
+    for t in range(n):
+        if cnt < size:
+            cnt += 1
+            idx[(b + cnt - 1) % size] = frame_idx[t]
+        else:
+            for _ in range(dec):
+                acc -= buf[b]
+                b = (b + 1) % size
+            cnt -= dec - 1
+            idx[(b + cnt - 1) % size] = frame_idx[t]
+        buf[(b + cnt - 1) % size] = llr[t]
+        acc += llr[t]
+        if cnt == size:
+            rows.append([idx[b], idx[(b + cnt - 1) % size]] + list(acc / size))
+    return np.array(rows).reshape(-1, 2 + nc)
+
+
+@pytest.mark.parametrize("decime,wsize,wdec", [(1, 0, 0), (3, 0, 0), (1, 30, 30), (4, 20, 5)])
+def test_compute_test_world_decime_and_window_llr(decime, wsize, wdec):
+    """ComputeTest.cpp:154-207: DETERMINE_TOP_DISTRIBS every worldDecime-th frame of a segment, USE_TOP_DISTRIBS with the
+    kept top set in between; WindowLLR over the per-frame LLRs.  Expected values from the oracle's per-frame functions."""
+    from lia_ral_amd import host_capi as host
+    C, D, topc = 64, 24, 6
+    w, mean, iv = make_gmm(C, D, seed=5)
+    rng = np.random.default_rng(1)
+    cl_means = [mean + 0.3 * rng.normal(size=mean.shape) for _ in range(2)]
+    x = make_frames(w, mean, iv, 400, seed=6)
+    seg_begin, seg_len = np.array([10, 150, 300]), np.array([70, 90, 41])
+    llr, wins = host.compute_test_ex(x, seg_begin, seg_len, (w, mean, 1.0 / iv), [(w, m, 1.0 / iv) for m in cl_means], top_c=topc,
+                                     complete=True, segmental=True, world_decime=decime, window_size=wsize, window_dec=wdec)
+    sel = np.concatenate([np.arange(b, b + n) for b, n in zip(seg_begin, seg_len)])
+    xs = x[sel].astype(np.float64)
+    gw = orc.Gmm(w, mean, iv)
+    det = orc.llk_determine_top(gw, xs, topc, True, -200.0, 200.0)
+    idx, nllk, llkw = det["idx"].copy(), det["nontop_lk"].copy(), det["llk"].copy()
+    determined = np.ones(len(sel), bool)
+    t = 0
+    for n in seg_len:
+        for f in range(n):
+            if f % decime:
+                last = t - (f % decime)
+                idx[t] = idx[last]; nllk[t] = nllk[last]; determined[t] = False
+            t += 1
+    w2 = orc.llk_use_top(gw, xs, idx, nllk, True, -200.0, 200.0)
+    llkw = np.where(determined, llkw, w2)
+    llkc = np.stack([orc.llk_use_top(orc.Gmm(w, m, iv), xs, idx, nllk, True, -200.0, 200.0) for m in cl_means], 1)
+    off = 0
+    for s, n in enumerate(seg_len):
+        ref = llkc[off:off + n].mean(0) - llkw[off:off + n].mean()
+        assert np.max(np.abs(llr[s] - ref)) < 1e-9
+        off += n
+    if wsize:
+        per_frame = llkc - np.where(determined, llkw, 0.0)[:, None]
+        ref = _window_llr_reference(wsize, wdec or wsize, sel, per_frame)
+        assert wins.shape == ref.shape and np.array_equal(wins[:, :2], ref[:, :2])
+        assert np.max(np.abs(wins[:, 2:] - ref[:, 2:])) < 1e-9
+    else:
+        assert wins.shape[0] == 0
