@@ -12,8 +12,8 @@
 //
 // Workgroup = 8 waves; wave w owns TWO Gaussian tiles (32 Gaussians = one tile pair of k_llk_mfma), so
 // every x operand read from LDS (and every x^2) feeds 4 MFMAs.  Frames stream through the same rotated
-// LDS tile as k_stats_mfma (64 rows [x_0..x_{D-1}, 0.., 1, scale / S_t, Efin, 0..], double buffered,
-// register staged).
+// LDS tile as k_stats_mfma (64 rows [x_0..x_{D-1}, 0.., 1, 0..], double buffered, register staged);
+// the per-frame posterior factors f = scale / S_t * 2^(E - Efin) of each wave ride along in LDS.
 //   mode 0 (EM):  out0[seg][c][2 RL] partial sums (cols: x | x^2 halves; col Dp = occupancy);
 //                 accum != 0 adds to what is there (frame chunks processed by successive launches)
 //   mode 1 (TV):  N = out0[seg][C], F = out1[seg][C*D] written directly
@@ -98,9 +98,11 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
         goff[i] = fr < FT ? (contig ? (unsigned)e : (unsigned)(fr * (int)ldx + d)) : 0u;
     }
-    int *etile = (int *)(buf1 + FT * RLp); // [2][NW][FT] running exponents of the wave's tile pair
+    // ftile[2][NW][FT]: per frame of the tile and per wave, the factor that turns a stored likelihood into a
+    // posterior, f = scale / S_t * 2^(E - Efin) with E the running exponent of the wave's tile pair (0 outside [f0, f1))
+    double *ftile = buf1 + FT * RLp;
     const int *epair = eit + (size_t)(active ? ct0 >> 1 : 0) * (nfb * 16) + fa;
-    const int srow = tid & (FT - 1);
+    const int srow = lane & (FT - 1);
     auto issue_stage = [&](int tl) { // exactly SL loads
         const long fb = fa + (long)tl * FT;
         const long rem = f1 - fb;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         const long t = fb + srow < f1 ? fb + srow : f1 - 1;
         stg_inv = inv[t];
         stg_ef = efin[t];
-        stg_e = epair[(long)tl * FT + (lane & (FT - 1))];
+        stg_e = epair[(long)tl * FT + srow];
     };
     auto finish_stage = [&](double *dst, int buf, int tl) {
         const long fb = fa + (long)tl * FT;
@@ -122,24 +124,21 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = pk[i] < lim ? (double)stg[i] : 0.0;
-        if (tid < FT) { // rows outside [f0, f1) get 1 / S_t = 0 -> posterior 0
-            const long t = fb + tid;
-            dst[tid * RLp + xrot(tid) + Dp + 1] = (t >= f0 && t < f1) ? stg_inv * scale : 0.0;
-            *(int *)(dst + tid * RLp + xrot(tid) + Dp + 2) = stg_ef; // RL >= Dp + 3 for every KS instantiated
+        if (lane < FT) { // rows outside [f0, f1) get f = 0 -> posterior 0
+            const long t = fb + lane;
+            ftile[(buf * NW + wave) * FT + lane] = (t >= f0 && t < f1) ? __builtin_ldexp(stg_inv * scale, stg_e - stg_ef) : 0.0;
         }
-        if (lane < FT) etile[(buf * NW + wave) * FT + lane] = stg_e;
     };
-    // pad columns (1.0 at Dp, zeros elsewhere; Dp + 1, Dp + 2 carry 1 / S_t and Efin) never change: written once
+    // pad columns (1.0 at Dp, zeros elsewhere) never change: written once
     for (int e = tid; e < 2 * npad; e += NT) {
         double *dst = e < npad ? buf0 : buf1;
         const int ee = e < npad ? e : e - npad;
         const int fr = ee / (RL - D), d = D + (ee - fr * (RL - D));
-        if (d != Dp + 1 && d != Dp + 2) dst[fr * RLp + xrot(fr) + d] = (d == Dp) ? 1.0 : 0.0;
+        dst[fr * RLp + xrot(fr) + d] = (d == Dp) ? 1.0 : 0.0;
     }
 
-    // per-lane LDS offsets (doubles): statistics B operand (row q, col i16) and the 1 / S_t column of row q
+    // per-lane LDS offset (doubles) of the statistics B operand (row q, col i16)
     const int offS = q * RLp + ((q & 1) << 4) + ((q >> 1) << 1) + i16;
-    const int offE = q * RLp + ((q & 1) << 4) + ((q >> 1) << 1) + Dp + 1;
 
     // likelihood stream: block n of tile t is 2 KB at zp[t] + n * 256 doubles, 32 bytes per lane.
     // Two register sets, alternating between even and odd blocks (the tile loop is unrolled).
@@ -178,17 +177,15 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         const bool staged = tl + 1 < ntiles;
         if (staged) issue_stage(tl + 1);
         if (active) {
-            const double *pS = cur + offS, *pE = cur + offE;
-            const int *pX = etile + ((tl & 1) * NW + wave) * FT + q;
+            const double *pS = cur + offS;
+            const double *pF = ftile + ((tl & 1) * NW + wave) * FT + q;
             auto block = [&](int fs, d2 (&zc)[TPW][2], d2 (&zn)[TPW][2], bool always) {
                 const int n = tl * BPT + fs;
                 if (always || n + 1 < nblk) issue_z(zn, n + 1);
                 // register r holds rows (frames) fs*16 + 4r + q of 16 Gaussians: already the A operand
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double iv_t = pE[(fs * 16 + 4 * r) * RLp + 4 * r];
-                    const int ef = *(const int *)(pE + (fs * 16 + 4 * r) * RLp + 4 * r + 1);
-                    const double f = __builtin_ldexp(iv_t, pX[fs * 16 + 4 * r] - ef); // 2^(E - Efin) / S_t (x EM weight)
+                    const double f = pF[fs * 16 + 4 * r]; // 2^(E - Efin) / S_t (x EM weight), 0 for a masked frame
                     double gm[TPW];
                     bool keep = false;
 #pragma unroll
@@ -274,8 +271,7 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
                     int mode, int accum, double prune_thr)
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
-    static_assert(RL >= 4 * KS + 3, "the frame tile needs columns Dp + 1 and Dp + 2");
-    const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * FT * sizeof(int); // two frame tiles + exponents
+    const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * FT * sizeof(double); // two frame tiles + posterior factors
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
