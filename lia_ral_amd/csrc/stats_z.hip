@@ -171,17 +171,19 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         PIN_Z(zA);
     }
     __syncthreads();
-    for (int tl = 0; tl < ntiles; ++tl) {
+    // one tile; `full` = not the last tile of the segment: all BPT blocks exist and so does every prefetch,
+    // the body is straight-line code (the compiler schedules LDS reads and waits across the blocks)
+    auto tile = [&](int tl, bool full) {
         const double *cur = (tl & 1) ? buf1 : buf0;
         double *nxt = (tl & 1) ? buf0 : buf1;
-        const bool staged = tl + 1 < ntiles;
+        const bool staged = full || tl + 1 < ntiles;
         if (staged) issue_stage(tl + 1);
         if (active) {
             const double *pS = cur + offS;
             const double *pF = ftile + ((tl & 1) * NW + wave) * FT + q;
-            auto block = [&](int fs, d2 (&zc)[TPW][2], d2 (&zn)[TPW][2], bool always) {
+            auto block = [&](int fs, d2 (&zc)[TPW][2], d2 (&zn)[TPW][2]) {
                 const int n = tl * BPT + fs;
-                if (always || n + 1 < nblk) issue_z(zn, n + 1);
+                if (full || n + 1 < nblk) issue_z(zn, n + 1);
                 // register r holds rows (frames) fs*16 + 4r + q of 16 Gaussians: already the A operand
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -205,17 +207,19 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
                 }
             };
             const int nb = nblk - tl * BPT; // blocks of this tile that exist (wave-uniform)
-            block(0, zA, zB, false);
-            if (nb > 1) block(1, zB, zA, false);
+            block(0, zA, zB);
+            if (full || nb > 1) block(1, zB, zA);
             if (BPT > 2) {
-                if (nb > 2) block(2, zA, zB, false);
-                if (nb > 3) block(3, zB, zA, false);
+                if (full || nb > 2) block(2, zA, zB);
+                if (full || nb > 3) block(3, zB, zA);
             }
             PIN_Z(zA); // the next tile's first block (issued by the last block above) has landed
         }
         if (staged) finish_stage(nxt, (tl + 1) & 1, tl + 1);
         __syncthreads();
-    }
+    };
+    for (int tl = 0; tl + 1 < ntiles; ++tl) tile(tl, true);
+    if (ntiles > 0) tile(ntiles - 1, false);
 #undef PIN_Z
     if (!active) return;
     // D layout: lane holds column j = 16 jt + i16, rows (Gaussians) q + 4 r
