@@ -135,10 +135,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     auto stage = [&](double *dst, int tile) {
         const char *src = (const char *)(Pt + (size_t)tile * TILE_D);
         if (use_glds) {
-            for (int p = wave; p < PIECES; p += NW)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
-                    (__attribute__((address_space(3))) void *)((char *)dst + p * 1024), 16, 0, 0);
+            if (PIECES % NW == 0) { // fixed trip count: straight-line code in the tile loop
+#pragma unroll
+                for (int j = 0; j < PIECES / NW; ++j) {
+                    const int p = wave + NW * j;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
+                        (__attribute__((address_space(3))) void *)((char *)dst + p * 1024), 16, 0, 0);
+                }
+            } else {
+                for (int p = wave; p < PIECES; p += NW)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
+                        (__attribute__((address_space(3))) void *)((char *)dst + p * 1024), 16, 0, 0);
+            }
         } else {
             for (int p = wave; p < PIECES; p += NW) {
                 uint4 v = *(const uint4 *)(src + p * 1024 + lane * 16);
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     // the fp64 MFMA pipe partially (tools/mfma_probe), work of the same wave never does.
     const bool late = NW == 8 && ((wave >> 1) & 1);
     d4 acc[GT][2];
-    auto mfma_phase = [&](const double *cur) {
+    auto mfma_phase = [&](const double *cur) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
         const double a = cur[(g * NR + 2 * KS) * 64 + lane];
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
     }
     };
-    auto epi_phase = [&](int te) {
+    auto epi_phase = [&](int te) __attribute__((always_inline)) {
         // Online log-sum-exp per (lane, frame row) with an INTEGER reference: the sum is kept as
         // sacc * 2^E.  exp(z) = t * 2^n (t in [1,2)) is added as ldexp(t, n - E); when a logit's n
         // exceeds E by 64 or more the reference moves with one ldexp (no exp, no fp64 compare
@@ -286,15 +296,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     };
     stage(buf0, 0);
     __syncthreads();
-    for (int tl = 0; tl < ntiles; ++tl) {
+    // One tile step; the loops below call it with compile-time-known flags so that the hot body carries no
+    // wave-uniform conditionals (hipcc ends a basic block -- and its instruction scheduling -- at each of them).
+    auto step = [&](int tl, bool staged, bool is_late, bool first) __attribute__((always_inline)) {
         double *cur = (tl & 1) ? buf1 : buf0;
         double *nxt = (tl & 1) ? buf0 : buf1;
-        if (tl + 1 < ntiles && dbg < 2) stage(nxt, tl + 1);
-        if (!late) {
+        if (staged && dbg < 2) stage(nxt, tl + 1);
+        if (!is_late) {
             mfma_phase(cur);
             epi_phase(tl);
         } else {
-            if (tl > 0) epi_phase(tl - 1);
+            if (!first) epi_phase(tl - 1);
             mfma_phase(cur);
         }
         if (WZ) {
@@ -303,11 +315,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             // round trip per tile).  Early waves wait inside their epilogue, BEFORE they issue the
             // stores (the DMA was issued a whole MFMA phase earlier); late waves issued their stores a
             // whole MFMA phase ago, so draining everything here costs them nothing.
-            if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (is_late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             __syncthreads();
         }
+    };
+    if (!late) {
+        for (int tl = 0; tl + 1 < ntiles; ++tl) step(tl, true, false, false);
+        if (ntiles > 0) step(ntiles - 1, false, false, false);
+    } else {
+        if (ntiles > 1) step(0, true, true, true);
+        for (int tl = 1; tl + 1 < ntiles; ++tl) step(tl, true, true, false);
+        if (ntiles > 0) step(ntiles - 1, false, true, ntiles == 1);
     }
     if (late && ntiles > 0) epi_phase(ntiles - 1);
     // combine the 16 lanes (Gaussian columns) that share a frame row: common exponent, then sum
