@@ -131,6 +131,29 @@ __device__ __forceinline__ double gexp_scaled64(double x, int E, const double *t
     n = n < -2000 ? -2000 : n;
     return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
 }
+// gexp_scaled64 in two halves, so that a caller that also needs the binary exponent of exp(x) (ki >> 6)
+// gets it from the argument reduction it has to do anyway: phase 1 -> (ki, r), phase 2 -> exp(x) 2^-E
+__device__ __forceinline__ void gexp64_reduce(double x, int &ki, double &r)
+{
+    x = fmax(x, -2.0e7);
+    const double k = __builtin_rint(x * 92.33248261689366);
+    r = __builtin_fma(k, -0.010830424609594047, x);
+    r = __builtin_fma(k, -8.665509839009470e-11, r);
+    ki = (int)k;
+}
+__device__ __forceinline__ double gexp64_finish(int ki, double r, int E, const double *tab)
+{
+    const double tj = tab[ki & 63];
+    double p = 8.333333333333333e-03;
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    int n = (ki >> 6) - E;
+    n = n < -2000 ? -2000 : n;
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
+}
 // the binary exponent gexp_scaled64 assigns to exp(x): same clamp, same rounding
 __device__ __forceinline__ int gexp_exponent64(double x)
 {

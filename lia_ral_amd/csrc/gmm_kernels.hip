@@ -200,13 +200,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         if (WZ) {
             // stored-likelihood variant: E is shared by the 16 lanes of a frame row (DPP row maximum
             // of the exponents), every pair's exponential is evaluated and kept
-            int nm[2][4];
+            // The argument reduction of the 16 exponentials comes first: its integer part is the binary
+            // exponent of exp(z), so the row maximum needs no separate evaluation; the reduced arguments
+            // replace the logits in the accumulator registers.
+            int nm[2][4], k0[2][4], k1[2][4];
             bool grow = false;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    nm[h][r] = row_max_i32(gexp_exponent64(fmax(acc[0][h][r], acc[1][h][r])));
+                    double r0, r1;
+                    gexp64_reduce(acc[0][h][r], k0[h][r], r0);
+                    gexp64_reduce(acc[1][h][r], k1[h][r], r1);
+                    acc[0][h][r] = r0;
+                    acc[1][h][r] = r1;
+                    const int km = k0[h][r] > k1[h][r] ? k0[h][r] : k1[h][r];
+                    nm[h][r] = row_max_i32(km >> 6);
                     grow |= nm[h][r] - E[h][r] >= 64;
                 }
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double e0 = gexp_scaled64(acc[0][h][r], E[h][r], etab), e1 = gexp_scaled64(acc[1][h][r], E[h][r], etab);
+                    const double e0 = gexp64_finish(k0[h][r], acc[0][h][r], E[h][r], etab);
+                    const double e1 = gexp64_finish(k1[h][r], acc[1][h][r], E[h][r], etab);
                     sacc[h][r] += e0 + e1;
                     acc[0][h][r] = e0;
                     acc[1][h][r] = e1;
