@@ -283,6 +283,12 @@ def main():
                                "unit": "TFLOP/s", "frac": kd["tflops"] / PEAK_F64_TFLOPS, "traffic": traffic,
                                "kernel_ms": kd["ms_per_launch"], "launches_per_step": kd["launches_per_step"],
                                "algorithmic_flop_per_launch": KERNEL_FLOP[dom] * T * C / kd["launches_per_step"]}
+        # the whole EM step against SURVEY 8(d)'s per-pair figure (240 logit + 242 statistics flop; this design
+        # executes exactly that: every logit once, every statistic once), over all ranks
+        step_tf = (FLOP_PER_PAIR_LLK + FLOP_PER_PAIR_ACC) * pairs_per_step / (dt / args.steps) / 1e12
+        out["step_roofline"] = {"bound": "mfma", "algorithmic_flop_per_pair": FLOP_PER_PAIR_LLK + FLOP_PER_PAIR_ACC,
+                                "achieved": step_tf, "peak": PEAK_F64_TFLOPS * world, "unit": "TFLOP/s",
+                                "frac": step_tf / (PEAK_F64_TFLOPS * world)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, mean, iv, seed=99)
         print(json.dumps(out), flush=True)
