@@ -442,20 +442,35 @@ __global__ __launch_bounds__(256) void k_potf2_inv(int n, int kk, int w, double 
 // except inside diagonal blocks (zeroed).
 int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, double *panel, int *status)
 {
+    // Two-level right-looking factorisation: 32-wide steps (diagonal block factored and inverted in LDS, panel
+    // by GEMM) inside 128-wide outer blocks.  A step only updates the columns of its own outer block; the rest of
+    // the trailing matrix is updated once per outer block with K = 128 -- a quarter of the read-modify-write
+    // traffic of updating the whole trailing matrix at every step (the batch is memory-bound there).
+    constexpr int WB = 128;
     const int nblk = (n + 31) / 32;
     const long sinv = (long)nblk * 1024, sa = (long)n * n, spn = (long)n * 32;
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int kk = kb * 32, w = (n - kk) < 32 ? (n - kk) : 32, m = n - kk - w;
-        k_potf2_inv<<<nb, 256, 0, st>>>(n, kk, w, Afull, invd, sinv, kb, status);
-        if (m > 0) {
-            // L21 = A21 * inv(L11)^T
-            TVCHK(tvk_dgemm(st, false, true, m, w, w, 1.0, Afull + (size_t)(kk + w) * n + kk, n, sa, invd + (size_t)kb * 1024,
-                            32, sinv, 0.0, panel, 32, spn, nb));
-            dim3 g((m * w + 255) / 256, nb);
-            k_copy2d<<<g, 256, 0, st>>>(m, w, panel, 32, spn, Afull + (size_t)(kk + w) * n + kk, n, sa);
-            // A22 -= L21 * L21^T
-            TVCHK(tvk_dgemm(st, false, true, m, m, w, -1.0, panel, 32, spn, panel, 32, spn, 1.0,
-                            Afull + (size_t)(kk + w) * n + (kk + w), n, sa, nb));
+    for (int j0 = 0; j0 < n; j0 += WB) {
+        const int jend = j0 + WB < n ? j0 + WB : n;
+        for (int kk = j0; kk < jend; kk += 32) {
+            const int kb = kk / 32, w = (n - kk) < 32 ? (n - kk) : 32, m = n - kk - w;
+            k_potf2_inv<<<nb, 256, 0, st>>>(n, kk, w, Afull, invd, sinv, kb, status);
+            if (m > 0) {
+                // L21 = A21 * inv(L11)^T
+                TVCHK(tvk_dgemm(st, false, true, m, w, w, 1.0, Afull + (size_t)(kk + w) * n + kk, n, sa, invd + (size_t)kb * 1024,
+                                32, sinv, 0.0, panel, 32, spn, nb));
+                dim3 g((m * w + 255) / 256, nb);
+                k_copy2d<<<g, 256, 0, st>>>(m, w, panel, 32, spn, Afull + (size_t)(kk + w) * n + kk, n, sa);
+                // columns kk+w .. jend of the rows below: A22[:, :cin] -= L21 * L21[0:cin]^T
+                const int cin = jend - (kk + w);
+                if (cin > 0)
+                    TVCHK(tvk_dgemm(st, false, true, m, cin, w, -1.0, panel, 32, spn, panel, 32, spn, 1.0,
+                                    Afull + (size_t)(kk + w) * n + (kk + w), n, sa, nb));
+            }
+        }
+        const int m2 = n - jend;
+        if (m2 > 0) { // trailing matrix beyond the outer block: -= L[jend:, j0:jend] * L[jend:, j0:jend]^T
+            const double *Lp = Afull + (size_t)jend * n + j0;
+            TVCHK(tvk_dgemm(st, false, true, m2, m2, jend - j0, -1.0, Lp, n, sa, Lp, n, sa, 1.0, Afull + (size_t)jend * n + jend, n, sa, nb));
         }
     }
     return (int)hipGetLastError();
