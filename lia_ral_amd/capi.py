@@ -55,7 +55,7 @@ def _ptr(a):
     if a is None:
         return ct.c_void_p(0)
     if _is_torch(a):
-        assert a.is_contiguous()
+        assert a.is_contiguous() or (a.dim() == 2 and a.stride(1) == 1)  # feature matrices may be row-strided (ldx)
         return ct.c_void_p(a.data_ptr())
     assert a.flags["C_CONTIGUOUS"]
     return ct.c_void_p(a.ctypes.data)

@@ -333,6 +333,56 @@ def test_posterior_vectors_match_oracle(ctx, C, D, T):
     assert g.occ(np.zeros((0, D), np.float32)).shape == (0, C)
 
 
+@pytest.mark.parametrize("C,D", [(128, 60), (2048, 60), (37, 13)])
+def test_row_strided_device_features(ctx, C, D):
+    """Frames as rows of a wider device matrix (ldx > D): every entry point that takes features, on the default
+    (stored-likelihood) path and on the recomputing one."""
+    import torch
+    w, mean, iv = make_gmm(C, D, seed=C + 41)
+    T = 1500
+    x = make_frames(w, mean, iv, T, seed=3)
+    wide = torch.zeros((T, D + 5), dtype=torch.float32, device="cuda")
+    wide[:, :D] = torch.from_numpy(x).cuda()
+    wide[:, D:] = 1e30                      # must never be read as a feature
+    xv = wide[:, :D]
+    assert xv.stride(0) == D + 5
+    g = ctx.gmm(w, mean, iv)
+    og = orc.Gmm(w, mean, iv)
+    assert np.max(np.abs(g.llk(xv, -1e9, 1e9) - orc.llk(og, x.astype(np.float64), -1e9, 1e9))) < 1e-9
+    ref = g.em_accumulate(x)
+    for sz in (1, 0):
+        ctx.set_option("stats_z", sz)
+        try:
+            assert relerr(g.em_accumulate(xv), ref) < 1e-12
+            ub = np.array([0, 700, 700, 1500])
+            N, F = g.tv_stats(xv, ub)
+            N0, F0 = g.tv_stats(x, ub)
+            assert relerr(N, N0) < 1e-12 and relerr(F, F0) < 1e-12
+        finally:
+            ctx.set_option("stats_z", 1)
+    assert np.array_equal(ctx.frame_moments(xv), ctx.frame_moments(x))
+
+
+def test_tv_stats_utterance_longer_than_the_scratch_falls_back(ctx):
+    """An utterance that does not fit the likelihood scratch sends tv_stats to the recomputing kernel."""
+    C, D = 128, 60
+    w, mean, iv = make_gmm(C, D, seed=77)
+    lens = [300, 9000, 120]
+    ub = np.concatenate([[0], np.cumsum(lens)])
+    x = make_frames(w, mean, iv, int(ub[-1]), seed=5)
+    g = ctx.gmm(w, mean, iv)
+    N0, F0 = g.tv_stats(x, ub)
+    prev = ctx.set_option("z_scratch_mb", 8)      # 6784 frames per chunk < 9000
+    try:
+        ctx.set_option("timing", 1)
+        N1, F1 = g.tv_stats(x, ub)
+        assert ctx.kernel_launches("k_stats_mfma") >= 1
+        ctx.set_option("timing", 0)
+    finally:
+        ctx.set_option("z_scratch_mb", prev)
+    assert relerr(N1, N0) < 1e-12 and relerr(F1, F0) < 1e-12
+
+
 def test_frame_moments(ctx):
     rng = np.random.default_rng(0)
     for T, D in [(1, 60), (1000, 60), (4097, 34), (50, 130)]:
