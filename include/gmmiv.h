@@ -253,6 +253,9 @@ int gmmiv_plda_em_iteration(gmmiv_ctx *ctx, int dim, int64_t n, double *X, int64
  * rotateLeft(FTJ) is gmmiv_iv_normalize with FTJ as the matrix; FTJF feeds gmmiv_score_plda. */
 int gmmiv_plda_precompute(gmmiv_ctx *ctx, int dim, int rf, int rg, const double *F, const double *G,
                           const double *Sigma, double *FTJ, double *FTJF);
+/* The two-covariance model of PldaTest::twoCovScoring (PldaTools.cpp:4089-4125):
+ *   G = W^-1 (B^-1 + 2 W^-1)^-1 W^-1,   H = W^-1 (B^-1 + W^-1)^-1 W^-1     (W, B symmetric positive definite) */
+int gmmiv_twocov_model(gmmiv_ctx *ctx, int dim, const double *W, const double *B, double *G, double *H);
 /* ---- PldaTest scoring (LIA_SpkTools/src/PldaTools.cpp) ------------------------------------------
  * models[dim x M], segs[dim x S]: one vector per COLUMN like PldaTest::_models/_segments;
  * scores[M x S].

@@ -257,6 +257,12 @@ class Context:
         _chk(lib.gmmiv_plda_em_iteration(self._h, dim, n, xp, k, sp, F.shape[1], G.shape[1], _ptr(F), _ptr(G), _ptr(Sigma), _ptr(Delta)))
         return X, F, G, Sigma, Delta
 
+    def twocov_model(self, W, B):
+        dim = W.shape[0]
+        G = np.empty((dim, dim)); H = np.empty((dim, dim))
+        _chk(lib.gmmiv_twocov_model(self._h, dim, _ptr(_f64(W)), _ptr(_f64(B)), _ptr(G), _ptr(H)))
+        return G, H
+
     def plda_precompute(self, F, G, Sigma):
         """-> (FTJ [rf x dim], FTJF [rf x rf]); G may be None."""
         dim, rf = F.shape

@@ -1096,6 +1096,38 @@ int gmmiv_plda_precompute(gmmiv_ctx *c, int dim, int rf, int rg, const double *F
     return o_jf.finish();
 }
 
+int gmmiv_twocov_model(gmmiv_ctx *c, int dim, const double *W, const double *B, double *G, double *H)
+{
+    if (!c || dim <= 0 || !W || !B || !G || !H) { gmmiv_set_error("twocov_model: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t dd = (size_t)dim * dim;
+    DevIn<double> i_w, i_b;
+    DevOut<double> o_g, o_h;
+    int rc;
+    if ((rc = i_w.init(c, WS_T0, W, dd)) || (rc = i_b.init(c, WS_T1, B, dd)) || (rc = o_g.init(c, WS_T2, G, dd, false)) || (rc = o_h.init(c, WS_T3, H, dd, false))) return rc;
+    InvWs ws;
+    if ((rc = ws.init(c, dim, 1))) return rc;
+    void *p;
+    if ((rc = c->scratch(WS_AUX, 5 * dd * 8, &p))) return rc;
+    double *iW = (double *)p, *iB = iW + dd, *sm = iB + dd, *ti = sm + dd, *t2 = ti + dd;
+    hipStream_t st = c->stream;
+    auto inv = [&](const double *src, double *dst, const char *what) -> int {
+        GCHK(hipMemcpyAsync(ws.full, src, dd * 8, hipMemcpyDeviceToDevice, st));
+        GCHK(hipMemsetAsync(ws.status, 0, sizeof(int), st));
+        GCHK(tvk_spd_inverse_batched(st, dim, 1, ws.full, dst, ws.X, ws.invd, ws.panel, ws.status));
+        return check_status(c, ws.status, 1, what);
+    };
+    if ((rc = inv(i_w.d, iW, "twocov_model: W")) || (rc = inv(i_b.d, iB, "twocov_model: B"))) return rc;
+    for (int pass = 0; pass < 2; ++pass) { // G: B^-1 + 2 W^-1 ; H: B^-1 + W^-1
+        GCHK(tvk_axpby(st, (long)dd, 1.0, iB, pass == 0 ? 2.0 : 1.0, iW, sm));
+        if ((rc = inv(sm, ti, "twocov_model: B^-1 + a W^-1"))) return rc;
+        GCHK(tvk_dgemm(st, false, false, dim, dim, dim, 1.0, iW, dim, 0, ti, dim, 0, 0.0, t2, dim, 0, 1));
+        GCHK(tvk_dgemm(st, false, false, dim, dim, dim, 1.0, t2, dim, 0, iW, dim, 0, 0.0, pass == 0 ? o_g.d : o_h.d, dim, 0, 1));
+    }
+    if ((rc = o_g.finish())) return rc;
+    return o_h.finish();
+}
+
 int gmmiv_score_plda(gmmiv_ctx *c, int rf, int64_t M, int64_t S, const double *models_sum, const int64_t *nsess,
                      const double *segs, const double *FTJF, double *scores)
 {

@@ -249,6 +249,37 @@ int liagpu_plda_train(int device, int dim, long n, double *X, long nspk, const l
     })
 }
 
+// IvTest (IvTest.cpp:73-471).  scoring: 0 cosine, 1 mahalanobis, 2 2cov, 3 plda.  dev [dim x nDev] with sessions grouped by
+// speaker; enrol [dim x nEnrol] grouped by model; test [dim x nTest]; scores [nModels x nTest].
+int liagpu_iv_test(int device, int dim, long nDev, const double *dev, long nspk, const long *sps, long nModels, const long *enrolPerModel,
+                   const double *enrol, long nTest, const double *test, int ivNorm, int ivNormIt, int sphNorm, int lda, int ldaRank,
+                   int wccn, int scoring, int rf, int rg, int pldaIt, const double *F, const double *G, const double *Sigma, double *scores)
+{
+    GUARD({
+        static const char *names[] = {"cosine", "mahalanobis", "2cov", "plda"};
+        if (scoring < 0 || scoring > 3) throw Exception("Scoring option is invalid, must be: cosine OR mahalanobis OR 2cov OR plda");
+        GpuServer srv(device);
+        PldaDev pd(srv, (unsigned long)dim, std::vector<double>(dev, dev + (size_t)dim * nDev), std::vector<unsigned long>(sps, sps + nspk));
+        IvTestCfg cfg;
+        cfg.ivNorm = ivNorm != 0; cfg.ivNormIterationNb = (unsigned long)ivNormIt; cfg.sphNorm = sphNorm != 0;
+        cfg.LDA = lda != 0; cfg.ldaRank = (unsigned long)ldaRank; cfg.WCCN = wccn != 0; cfg.scoring = names[scoring];
+        cfg.pldaRankF = (unsigned long)rf; cfg.pldaRankG = (unsigned long)rg; cfg.pldaNbIt = (unsigned long)pldaIt;
+        std::vector<unsigned long> epm(enrolPerModel, enrolPerModel + nModels);
+        unsigned long nEnrol = 0;
+        for (unsigned long e : epm) nEnrol += e;
+        const unsigned long d2 = cfg.ivNorm && cfg.LDA ? 0 : 0; (void)d2;
+        std::vector<double> f, g, s;
+        if (scoring == 3) {
+            // the PLDA matrices live in the space AFTER normalisation / LDA: their leading dimension is that space's
+            const unsigned long pd_dim = cfg.ivNorm && cfg.LDA ? cfg.ldaRank : (unsigned long)dim;
+            f.assign(F, F + pd_dim * rf); g.assign(G, G + pd_dim * rg); s.assign(Sigma, Sigma + pd_dim * pd_dim);
+        }
+        std::vector<double> out = ivTest(srv, cfg, pd, std::vector<double>(enrol, enrol + (size_t)dim * nEnrol), epm,
+                                         std::vector<double>(test, test + (size_t)dim * nTest), (unsigned long)nTest, f, g, s);
+        memcpy(scores, out.data(), out.size() * sizeof(double));
+    })
+}
+
 // TotalVariability (TotalVariability.cpp:118-169): nbIt iterations on precomputed N, F
 int liagpu_tv_train(int device, long U, int C, int D, const double *w, const double *mean, const double *cov, int R,
                     const double *N, const double *F, double *Tmat, int nbIt, int minDiv, double *mean_out)

@@ -723,6 +723,112 @@ void PldaModel::em_iteration()
     _Dev.emIteration(_rankF, _rankG, _F, _G, _Sigma, _Delta, sp);
 }
 
+// ---- IvTest ----------------------------------------------------------------------------------------
+namespace {
+void twoCovModel(GpuServer &srv, unsigned long dim, const std::vector<double> &W, const std::vector<double> &B, std::vector<double> &G,
+                 std::vector<double> &H)
+{
+    srv.check(gmmiv_twocov_model(srv.ctx(), (int)dim, W.data(), B.data(), G.data(), H.data()));
+}
+// center (optional) + rotateLeft (optional) + lengthNorm (optional) of the columns of X [dim x n] -> [rows x n]
+void normaliseColumns(GpuServer &srv, std::vector<double> &X, unsigned long &dim, unsigned long n, const std::vector<double> *mean,
+                      const std::vector<double> *M, unsigned long rows, bool lengthNorm)
+{
+    const unsigned long dout = M ? rows : dim;
+    std::vector<double> out(dout * n);
+    srv.check(gmmiv_iv_normalize(srv.ctx(), (int)dim, (int)dout, (int64_t)n, X.data(), mean ? mean->data() : nullptr, M ? M->data() : nullptr,
+                                 lengthNorm ? 1 : 0, out.data()));
+    X.swap(out);
+    dim = dout;
+}
+} // namespace
+
+std::vector<double> ivTest(GpuServer &srv, const IvTestCfg &cfg, PldaDev &dev, std::vector<double> enrol,
+                           const std::vector<unsigned long> &enrolPerModel, std::vector<double> test, unsigned long nTest,
+                           const std::vector<double> &pldaF, const std::vector<double> &pldaG, const std::vector<double> &pldaSigma)
+{
+    unsigned long dimE = dev.getVectSize(), dimT = dev.getVectSize(), nEnrol = 0;
+    for (unsigned long v : enrolPerModel) nEnrol += v;
+    const unsigned long nModels = enrolPerModel.size();
+    if (enrol.size() != dimE * nEnrol || test.size() != dimT * nTest) throw Exception("ivTest: enrol / test must be vectSize x count");
+    // 1. normalisation parameters on the development set (IvTest.cpp:131-160, 262-290)
+    std::vector<std::vector<double> > mats, means;
+    std::vector<double> ldaMat;
+    if (cfg.ivNorm) {
+        if (cfg.ivNormIterationNb > 0) dev.sphericalNuisanceNormalization(cfg.ivNormIterationNb, cfg.sphNorm, mats, means);
+        if (cfg.LDA) {
+            dev.computeLDA(ldaMat, cfg.ldaRank);
+            dev.rotateLeft(ldaMat, cfg.ldaRank);
+        }
+    }
+    // 2. back-end matrices on the normalised development set (:200-258) or the PLDA model (:262-310)
+    std::vector<double> wccn, mah, W, B, Sigma, F, G, Sg;
+    if (cfg.scoring == "cosine") { if (cfg.WCCN) dev.computeWccnChol(wccn); }
+    else if (cfg.scoring == "mahalanobis") dev.computeMahalanobis(mah);
+    else if (cfg.scoring == "2cov") dev.computeCovMat(Sigma, W, B);
+    else if (cfg.scoring == "plda") {
+        // plda.updateModel + centerData (:292-294): the data is centred on its own mean before the EM
+        const std::vector<double> mu(dev.getMean());
+        dev.center(mu);
+        PldaModel plda(dev, cfg.pldaRankF, cfg.pldaRankG, pldaF, pldaG, pldaSigma);
+        for (unsigned long it = 0; it < cfg.pldaNbIt; ++it) plda.em_iteration();
+        F = plda.getF(); G = plda.getG(); Sg = plda.getSigma();
+    } else throw Exception("Scoring option is invalid, must be: cosine OR mahalanobis OR 2cov OR plda");
+    // 3. the same normalisation on the enrolment and test vectors (:312-328)
+    if (cfg.ivNorm) {
+        for (size_t it = 0; it < mats.size(); ++it) {
+            normaliseColumns(srv, enrol, dimE, nEnrol, &means[it], &mats[it], mats[it].size() / dimE, true);
+            normaliseColumns(srv, test, dimT, nTest, &means[it], &mats[it], mats[it].size() / dimT, true);
+        }
+        if (cfg.LDA) {
+            normaliseColumns(srv, enrol, dimE, nEnrol, nullptr, &ldaMat, cfg.ldaRank, false);
+            normaliseColumns(srv, test, dimT, nTest, nullptr, &ldaMat, cfg.ldaRank, false);
+        }
+    }
+    if (cfg.scoring == "cosine" && cfg.WCCN) {
+        normaliseColumns(srv, enrol, dimE, nEnrol, nullptr, &wccn, dimE, false);
+        normaliseColumns(srv, test, dimT, nTest, nullptr, &wccn, dimT, false);
+    }
+    std::vector<double> FTJ, FTJF;
+    if (cfg.scoring == "plda") { // pldaNativeScoring: rotateLeft(FTJ), PldaTools.cpp:4494-4504
+        const unsigned long rf = cfg.pldaRankF, rg = cfg.pldaRankG;
+        FTJ.assign(rf * dimE, 0.0); FTJF.assign(rf * rf, 0.0);
+        srv.check(gmmiv_plda_precompute(srv.ctx(), (int)dimE, (int)rf, (int)rg, F.data(), rg ? G.data() : nullptr, Sg.data(), FTJ.data(), FTJF.data()));
+        normaliseColumns(srv, enrol, dimE, nEnrol, nullptr, &FTJ, rf, false);
+        normaliseColumns(srv, test, dimT, nTest, nullptr, &FTJ, rf, false);
+    }
+    // 4. one vector per model: mean of its enrolment vectors (sum + count for plda)
+    std::vector<double> models(dimE * nModels, 0.0);
+    std::vector<int64_t> nsess(nModels);
+    unsigned long s0 = 0;
+    for (unsigned long m = 0; m < nModels; ++m) {
+        const unsigned long ns = enrolPerModel[m];
+        if (ns == 0) throw Exception("ivTest: a model without enrolment vector");
+        nsess[m] = (int64_t)ns;
+        for (unsigned long d = 0; d < dimE; ++d) {
+            double a = 0.0;
+            for (unsigned long e = 0; e < ns; ++e) a += enrol[d * nEnrol + s0 + e];
+            models[d * nModels + m] = cfg.scoring == "plda" ? a : a / (double)ns;
+        }
+        s0 += ns;
+    }
+    // 5. scoring (:330-395)
+    std::vector<double> scores(nModels * nTest);
+    if (cfg.scoring == "cosine")
+        srv.check(gmmiv_score_cosine(srv.ctx(), (int)dimE, (int64_t)nModels, (int64_t)nTest, models.data(), test.data(), scores.data()));
+    else if (cfg.scoring == "mahalanobis")
+        srv.check(gmmiv_score_mahalanobis(srv.ctx(), (int)dimE, (int64_t)nModels, (int64_t)nTest, models.data(), test.data(), mah.data(), scores.data()));
+    else if (cfg.scoring == "2cov") {
+        // G and H of twoCovScoring (:4089-4125) from W and B
+        const size_t dd = dimE * dimE;
+        std::vector<double> Gm(dd), Hm(dd);
+        twoCovModel(srv, dimE, W, B, Gm, Hm);
+        srv.check(gmmiv_score_twocov(srv.ctx(), (int)dimE, (int64_t)nModels, (int64_t)nTest, models.data(), test.data(), Gm.data(), Hm.data(), scores.data()));
+    } else
+        srv.check(gmmiv_score_plda(srv.ctx(), (int)cfg.pldaRankF, (int64_t)nModels, (int64_t)nTest, models.data(), nsess.data(), test.data(), FTJF.data(), scores.data()));
+    return scores;
+}
+
 void computeEigenProblem(const std::vector<double> &EP, unsigned long n, std::vector<double> &eigenVect, std::vector<double> &eigenVal,
                          unsigned long rank)
 {

@@ -305,6 +305,28 @@ class PldaModel {
     std::vector<double> _F, _G, _Sigma, _Delta, _originalMean;
 };
 
+// ---- IvTest (LIA_SpkDet/IvTest/src/IvTest.cpp:73-471): normalisation estimated on a development set, applied to the
+// enrolment and test vectors, then one of the four scoring rules.  Everything the reference exchanges through matrix
+// files between the steps is kept in memory.
+struct IvTestCfg {
+    bool ivNorm = false;                  // ivNorm
+    unsigned long ivNormIterationNb = 1;  // ivNormIterationNb
+    bool sphNorm = false;                 // ivNormEfrMode == "sphNorm" (else EFR)
+    bool LDA = false;                     // LDA
+    unsigned long ldaRank = 0;            // ldaRank
+    bool WCCN = false;                    // wccn (cosine scoring only)
+    std::string scoring = "cosine";       // cosine | mahalanobis | 2cov | plda
+    unsigned long pldaRankF = 0, pldaRankG = 0, pldaNbIt = 0; // pldaEigenVoiceNumber / pldaEigenChannelNumber / pldaNbIt
+};
+// dev: development set (modified: normalised in place like the reference's PldaDev).
+// enrol [dim x nEnrol] one enrolment vector per column, enrolPerModel[m] consecutive columns per model (cosine,
+// mahalanobis and 2cov score the MEAN of a model's vectors, plda their sum with the session count, PldaTools.cpp:4206-4221);
+// test [dim x nTest].  pldaF / pldaG / pldaSigma: initial matrices of the PLDA EM (ignored for the other rules).
+// Returns scores [nModels x nTest].
+std::vector<double> ivTest(GpuServer &srv, const IvTestCfg &cfg, PldaDev &dev, std::vector<double> enrol,
+                           const std::vector<unsigned long> &enrolPerModel, std::vector<double> test, unsigned long nTest,
+                           const std::vector<double> &pldaF, const std::vector<double> &pldaG, const std::vector<double> &pldaSigma);
+
 // TVAcc::computeEigenProblem (AccumulateTVStat.cpp:2997-3102) for the SYMMETRIC matrices it is used on (the weighted
 // covariance W): cyclic Jacobi on the host, eigenvalues sorted descending, eigenVect[k*rank + j] = component k of
 // the j-th eigenvector (the reference's Eigen / LAPACK solver returns its own column order and sign; any orthonormal

@@ -167,6 +167,25 @@ def plda_train(X, sps, F, G, Sigma, nb_it, device=0):
     return dict(X=X, F=F, G=G, Sigma=Sigma, Delta=Delta, original_mean=om)
 
 
+def iv_test(dev, sps, enrol, enrol_per_model, test, scoring="cosine", iv_norm=False, iv_norm_it=1, sph_norm=False, lda_rank=0,
+            wccn=False, plda=None, plda_it=0, device=0):
+    """IvTest end to end.  plda = (F, G, Sigma) initial matrices in the normalised space.  -> scores [nModels, nTest]."""
+    dev = np.ascontiguousarray(dev, np.float64); enrol = np.ascontiguousarray(enrol, np.float64); test = np.ascontiguousarray(test, np.float64)
+    dim, n_dev = dev.shape
+    sps = np.ascontiguousarray(sps, np.int64); epm = np.ascontiguousarray(enrol_per_model, np.int64)
+    code = {"cosine": 0, "mahalanobis": 1, "2cov": 2, "plda": 3}[scoring]
+    if plda is not None:
+        F, G, S = [np.ascontiguousarray(a, np.float64) for a in plda]
+        rf, rg = F.shape[1], G.shape[1]
+    else:
+        F = G = S = np.zeros(1); rf = rg = 0
+    out = np.empty((len(epm), test.shape[1]))
+    _chk(lib.liagpu_iv_test(device, dim, ct.c_long(n_dev), _d(dev), ct.c_long(len(sps)), sps.ctypes.data_as(_lp), ct.c_long(len(epm)),
+                            epm.ctypes.data_as(_lp), _d(enrol), ct.c_long(test.shape[1]), _d(test), int(iv_norm), int(iv_norm_it), int(sph_norm),
+                            int(lda_rank > 0), int(lda_rank), int(wccn), code, rf, rg, int(plda_it), _d(F), _d(G), _d(S), _d(out)))
+    return out
+
+
 def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
     C, D = mean.shape

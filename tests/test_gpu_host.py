@@ -291,3 +291,67 @@ def test_compute_test_world_decime_and_window_llr(decime, wsize, wdec):
         assert np.max(np.abs(wins[:, 2:] - ref[:, 2:])) < 1e-9
     else:
         assert wins.shape[0] == 0
+
+
+def _ivtest_data(seed=2, dim=20, nspk=40):
+    rng = np.random.default_rng(seed)
+    sps = rng.integers(3, 7, nspk)
+    cls = np.repeat(np.arange(nspk), sps)
+    A = rng.normal(size=(dim, dim)) * 0.4 + np.eye(dim)
+    dev = A @ ((rng.normal(size=(dim, nspk)) * 1.3)[:, cls] + rng.normal(size=(dim, int(sps.sum())))) + 0.5
+    epm = np.array([1, 2, 1, 3, 2])
+    enrol = A @ rng.normal(size=(dim, int(epm.sum()))) * 1.5 + 0.5
+    test = A @ rng.normal(size=(dim, 9)) * 1.5 + 0.5
+    return dev, sps, enrol, epm, test
+
+
+@pytest.mark.parametrize("scoring", ["cosine", "mahalanobis", "2cov", "plda"])
+def test_iv_test_end_to_end(scoring):
+    """IvTest.cpp:73-471 through liagpu::ivTest (EFR x 2, LDA, WCCN for cosine, back-end matrices or PLDA EM, scoring)
+    against the same chain assembled from the oracle pieces."""
+    from lia_ral_amd import host_capi as host
+    dev, sps, enrol, epm, test = _ivtest_data()
+    dim = dev.shape[0]
+    lda_rank = 12
+    rng = np.random.default_rng(7)
+    rf, rg = 5, 3
+    plda0 = (rng.normal(size=(lda_rank, rf)), 0.3 * rng.normal(size=(lda_rank, rg)), np.eye(lda_rank) * 0.5)
+    got = host.iv_test(dev, sps, enrol, epm, test, scoring=scoring, iv_norm=True, iv_norm_it=2, lda_rank=lda_rank, wccn=(scoring == "cosine"),
+                       plda=plda0 if scoring == "plda" else None, plda_it=3)
+    # the same chain from oracle pieces (eigenvector signs of the EFR / LDA matrices are the solver's: take |.|-insensitive route by
+    # recomputing with numpy's eigh-based restatement through the oracle functions, then fixing signs to the oracle's own)
+    D, E, Tt = dev.copy(), enrol.copy(), test.copy()
+    for it in range(2):
+        S, W, B = orc.dev_cov_mat(D, sps)
+        M = orc.dev_efr_matrix(S); mu = D.mean(1)
+        f = lambda X: (lambda Y: Y / np.linalg.norm(Y, axis=0))(M @ (X - mu[:, None]))
+        D, E, Tt = f(D), f(E), f(Tt)
+    S, W, B = orc.dev_cov_mat(D, sps)
+    L, _ = orc.dev_lda(W, B, lda_rank)
+    D, E, Tt = L @ D, L @ E, L @ Tt
+    starts = np.concatenate([[0], np.cumsum(epm)])
+    if scoring == "cosine":
+        U = orc.dev_wccn_chol(D, sps)
+        E, Tt = U @ E, U @ Tt
+        models = np.stack([E[:, a:b].mean(1) for a, b in zip(starts[:-1], starts[1:])], 1)
+        ref = orc.score_cosine(models, Tt)
+    elif scoring == "mahalanobis":
+        S, W, B = orc.dev_cov_mat(D, sps)
+        models = np.stack([E[:, a:b].mean(1) for a, b in zip(starts[:-1], starts[1:])], 1)
+        ref = orc.score_mahalanobis(models, Tt, np.linalg.inv(W))
+    elif scoring == "2cov":
+        S, W, B = orc.dev_cov_mat(D, sps)
+        models = np.stack([E[:, a:b].mean(1) for a, b in zip(starts[:-1], starts[1:])], 1)
+        G, H = orc.twocov_model(W, B)
+        ref = orc.score_twocov(models, Tt, G, H)
+    else:
+        st = (D - D.mean(1)[:, None],) + plda0 + (np.zeros(lda_rank),)
+        for it in range(3):
+            st = orc.plda_em_iteration(st[0], sps, *st[1:])
+        FTJ, FTJF = orc.plda_precompute(st[1], st[2], st[3])
+        sums = np.stack([(FTJ @ E[:, a:b]).sum(1) for a, b in zip(starts[:-1], starts[1:])], 1)
+        ref = orc.score_plda(sums, epm, FTJ @ Tt, FTJF)
+    # EFR / LDA eigenvectors are defined up to sign: cosine, Mahalanobis, 2cov and PLDA scores are invariant to a sign flip of a
+    # whitening ROW only through the later steps -- all of them are (every step is linear or quadratic in the rotated vectors)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < 1e-6 * max(1.0, np.max(np.abs(ref)))
