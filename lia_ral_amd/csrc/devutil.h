@@ -11,6 +11,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 #define GMMIV_NEG_BIG (-1.0e300)
+#define GMMIV_PAD_LOGIT (-1.0e9) // constant term of padded / zero-weight Gaussians in the packed MFMA model
 
 // exp(x) for x <= ~700, branch-free, no special cases: arguments below -750 give ~0.
 // n = rint(x log2 e); r = x - n ln2 (Cody-Waite, two steps); exp(r) by a degree-13 Taylor
@@ -113,9 +114,10 @@ __device__ __forceinline__ double gexp_scaled(double x, int E, const double *tab
 }
 // gexp_scaled with the 64-entry table (gexp_table64_init): |r| <= ln2/128, degree-5 series (4e-17), two-step
 // argument reduction kept because x is a raw logit (|x| up to 1e4 and more).  The binary exponent is ki >> 6.
+// NO clamp: the callers' logits are >= GMMIV_PAD_LOGIT - |quadratic terms| (the packed model pads with -1e9, not with
+// -1e300); below -2.3e7 the float-to-int conversion saturates, the exponent stays hugely negative and the result is 0.
 __device__ __forceinline__ double gexp_scaled64(double x, int E, const double *tab)
 {
-    x = fmax(x, -2.0e7);
     const double k = __builtin_rint(x * 92.33248261689366);
     double r = __builtin_fma(k, -0.010830424609594047, x);   // ln2/64 high part (trailing bits zero)
     r = __builtin_fma(k, -8.665509839009470e-11, r);         // ln2/64 low part
@@ -127,15 +129,12 @@ __device__ __forceinline__ double gexp_scaled64(double x, int E, const double *t
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = p * r;
-    int n = (ki >> 6) - E;
-    n = n < -2000 ? -2000 : n;
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), (ki >> 6) - E);
 }
 // gexp_scaled64 in two halves, so that a caller that also needs the binary exponent of exp(x) (ki >> 6)
 // gets it from the argument reduction it has to do anyway: phase 1 -> (ki, r), phase 2 -> exp(x) 2^-E
 __device__ __forceinline__ void gexp64_reduce(double x, int &ki, double &r)
 {
-    x = fmax(x, -2.0e7);
     const double k = __builtin_rint(x * 92.33248261689366);
     r = __builtin_fma(k, -0.010830424609594047, x);
     r = __builtin_fma(k, -8.665509839009470e-11, r);
@@ -150,14 +149,11 @@ __device__ __forceinline__ double gexp64_finish(int ki, double r, int E, const d
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = p * r;
-    int n = (ki >> 6) - E;
-    n = n < -2000 ? -2000 : n;
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), (ki >> 6) - E);
 }
 // the binary exponent gexp_scaled64 assigns to exp(x): same clamp, same rounding
 __device__ __forceinline__ int gexp_exponent64(double x)
 {
-    x = fmax(x, -2.0e7);
     return ((int)__builtin_rint(x * 92.33248261689366)) >> 6;
 }
 // floor(x log2 e) as used by gexp_scaled (the binary exponent of exp(x))

@@ -63,9 +63,9 @@ __global__ void k_gmm_pack(int C, int D, int KS, int nct, const double *__restri
             v = row < KS ? mean[(size_t)c * D + k] * ivv : -0.5 * ivv;
         }
     } else if (row == 2 * KS) {
-        v = c < C ? a[c] : GMMIV_NEG_BIG;
+        v = c < C ? fmax(a[c], GMMIV_PAD_LOGIT) : GMMIV_PAD_LOGIT;
     } else {
-        v = q == 0 ? (c < C ? a[c] : GMMIV_NEG_BIG) : (q == 1 ? -1.0 : 0.0);
+        v = q == 0 ? (c < C ? fmax(a[c], GMMIV_PAD_LOGIT) : GMMIV_PAD_LOGIT) : (q == 1 ? -1.0 : 0.0);
     }
     Pt[e] = v;
 }
