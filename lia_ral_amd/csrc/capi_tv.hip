@@ -322,7 +322,7 @@ int gmmiv_tv_update_t(gmmiv_ctx *c, int C, int D, int R, const double *A_packed,
     if ((rc = i_a.init(c, WS_T0, A_packed, (size_t)C * P))) return rc;
     if ((rc = i_c.init(c, WS_T1, Cmx, (size_t)R * SV))) return rc;
     if ((rc = o_t.init(c, WS_T2, Tm, (size_t)R * SV, false))) return rc;
-    int CH = 128;
+    int CH = c->n_cu > 128 ? c->n_cu : 128; // one workgroup per matrix in the batched inverse: a batch fills the chip
     if (C < CH) CH = C;
     InvWs ws;
     if ((rc = ws.init(c, R, CH))) return rc;

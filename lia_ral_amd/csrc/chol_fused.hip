@@ -1,0 +1,505 @@
+// chol_fused.hip -- batched Cholesky of nb SPD matrices of order n (a few hundred) on gfx950, ONE workgroup per
+// matrix, left-looking, v_mfma_f64_16x16x4_f64.  Replaces the GEMM-built right-looking factorisation for the
+// i-vector systems L_u = I + sum_c N_uc T_c^T S_c^-1 T_c (reference: TVAcc::estimateW / estimateAandC invert
+// them one at a time on the host, LIA_SpkTools/src/AccumulateTVStat.cpp:2114-2169, :1702-1795).
+//
+// Why left-looking: a matrix (1.28 MB at n = 400) does not fit LDS, and a right-looking batch re-reads AND
+// re-writes every trailing matrix once per block step.  Here a panel of 32 columns is produced from the
+// finished columns to its left in one go,  P = A[j0:, j0:j0+32] - L[j0:, :j0] L[j0:j0+32, :j0]^T,  so the
+// matrix is written exactly once and the re-reads (n^3/(6*32) doubles) come out of L2 / MALL.
+//
+// Workgroup = 8 waves.  The panel is cut in row tiles of 16; a wave owns up to 4 of them and computes each
+// tile TRANSPOSED:  D'[c][row] = sum_k L[j0 + c][k] L[row][k]  (MFMA A operand = the 32 panel rows, B operand =
+// the tile's own rows).  Both operands are rows of L with k contiguous: a lane loads 64 contiguous bytes per row
+// and 32 k values (the k order inside a chunk is permuted, identically for A and B).  With the A-operand rows
+// taken in the order perm(i) = 4 (i & 3) + (i >> 2), lane (i16, q) ends up holding P[row i16][cols 4q .. 4q+3]
+// in the 4 result registers: one 32-byte load / store per lane, and -- the point of the transposition -- exactly
+// the B-operand layout of the triangular solve  X^T = inv(L_jj) P^T  that follows, again one MFMA chain.
+// Wave 0 owns the diagonal block: updates it first, factors it in registers (row i in lane i, cross-lane
+// v_readlane broadcasts, fully unrolled), inverts the 32 x 32 factor (column c in lane c) and publishes
+// inv(L_jj) in LDS while the other waves are still busy with their tiles; it takes off-diagonal tiles last.
+#include "devutil.h"
+#include "tv_kernels.h"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#define PIN_V(x) asm volatile("" : "+v"(x)) // orders the VALU chain producing x against later loads / asm statements
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int TW = 3; // row tiles per wave and pass: 2 x (2 + TW) x 16 operand VGPRs in flight + TW x 16 accumulators
+
+// One 32-wide k chunk of operands: the 32 panel rows (a0 / a1: rows perm(i16), 16 + perm(i16)) and CNT row tiles,
+// 64 contiguous bytes per lane and row.
+template <int CNT> struct RowOps { d2 a0[4], a1[4], b[CNT][4]; };
+
+template <int CNT>
+__device__ __forceinline__ void rows_load(RowOps<CNT> &o, const double *pa0, const double *pa1, const double *(&pb)[TW], int k)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        o.a0[v] = *(const d2 *)(pa0 + k + 2 * v);
+        o.a1[v] = *(const d2 *)(pa1 + k + 2 * v);
+    }
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + 2 * v);
+}
+template <int CNT, bool NEG>
+__device__ __forceinline__ void rows_mfma(const RowOps<CNT> &o, d4 (&acc)[TW][2])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double x0 = NEG ? -o.a0[e >> 1][e & 1] : o.a0[e >> 1][e & 1];
+        const double x1 = NEG ? -o.a1[e >> 1][e & 1] : o.a1[e >> 1][e & 1];
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            acc[u][0] = MFMA_F64(x0, o.b[u][e >> 1][e & 1], acc[u][0]);
+            acc[u][1] = MFMA_F64(x1, o.b[u][e >> 1][e & 1], acc[u][1]);
+        }
+    }
+}
+// keeps the operand loads of the NEXT chunk ahead of the MFMAs of the current one: the memory clobber pins them in
+// the IR (hipcc otherwise sinks them to their first use), the scheduling barrier in the machine scheduler
+#define ROWS_FENCE()                         \
+    do {                                     \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+// acc[u][ct] (+/-)= sum over k in [kb, ke) of panel_row[k] * tile_row[k]   ((ke - kb) % 32 == 0), register
+// double-buffered one chunk ahead.  Every load is unconditional (the last prefetch is clamped to the final chunk and
+// thrown away): with a conditional prefetch the compiler merges "issued" and "not issued" at the join and waits
+// vmcnt(0), i.e. for the prefetch itself.
+template <int CNT, bool NEG>
+__device__ __forceinline__ void rowdot(const double *pa0, const double *pa1, const double *(&pb)[TW], int kb, int ke,
+                                       d4 (&acc)[TW][2])
+{
+    if (ke - kb < 32) return;
+    RowOps<CNT> A, B;
+    const int last = ke - 32;
+    rows_load<CNT>(A, pa0, pa1, pb, kb);
+    int k = kb;
+    for (; k + 64 <= ke; k += 64) {
+        rows_load<CNT>(B, pa0, pa1, pb, k + 32);
+        ROWS_FENCE();
+        rows_mfma<CNT, NEG>(A, acc);
+        ROWS_FENCE();
+        rows_load<CNT>(A, pa0, pa1, pb, k + 64 < last ? k + 64 : last);
+        ROWS_FENCE();
+        rows_mfma<CNT, NEG>(B, acc);
+        ROWS_FENCE();
+    }
+    if (k < ke) rows_mfma<CNT, NEG>(A, acc);
+}
+template <bool NEG>
+__device__ __forceinline__ void rowdot_n(int cnt, const double *pa0, const double *pa1, const double *(&pb)[TW], int kb,
+                                         int ke, d4 (&acc)[TW][2])
+{
+    switch (cnt) { // wave-uniform
+    case 1: rowdot<1, NEG>(pa0, pa1, pb, kb, ke, acc); break;
+    case 2: rowdot<2, NEG>(pa0, pa1, pb, kb, ke, acc); break;
+    case 3: rowdot<3, NEG>(pa0, pa1, pb, kb, ke, acc); break;
+    default: break;
+    }
+}
+
+// X^T = inv(L_jj) P^T for one row tile: P in acc[0..1] (lane (i16, q): P[row i16][16 ct + 4 q + r]), the 12 operand
+// values of inv(L_jj) in la0 / la1; result x0 (columns 4q..4q+3) and x1 (columns 16 + 4q ..) of the same rows
+struct LinvOps { double la0[4], la1[2][4]; };
+__device__ __forceinline__ void linv_ops_load(LinvOps &o, const double (*linv)[34], int perm, int q)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o.la0[r] = linv[perm][4 * q + r];
+        o.la1[0][r] = linv[16 + perm][4 * q + r];
+        o.la1[1][r] = linv[16 + perm][16 + 4 * q + r];
+    }
+}
+__device__ __forceinline__ void tile_trsm(const LinvOps &o, const d4 (&p)[2], d4 &x0, d4 &x1)
+{
+    x0 = d4{0.0, 0.0, 0.0, 0.0};
+    x1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x0 = MFMA_F64(o.la0[r], p[0][r], x0);
+        x1 = MFMA_F64(o.la1[0][r], p[0][r], x1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x1 = MFMA_F64(o.la1[1][r], p[1][r], x1);
+}
+
+} // namespace
+
+// Afull[b]: n x n row-major, lower triangle read, overwritten by the factor (diagonal blocks: upper part zeroed;
+// elsewhere the upper triangle is left as it was).  invd[b][kb][32][32]: inverse of the kb-th 32 x 32 diagonal
+// block of the factor (zero padded).  status[b] = 1 on a non-positive pivot.  n must be even (16-byte rows).
+__global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, double *invd, long sinv, int *status)
+{
+    __shared__ __attribute__((aligned(16))) double pj[32][34];
+    __shared__ __attribute__((aligned(16))) double linv[32][34];
+    __shared__ double dv[32];
+    __shared__ __attribute__((aligned(16))) double col[2][32];
+    const long n = n_;
+    double *Lm = Afull + (size_t)blockIdx.x * n * n;
+    double *iv = invd + (size_t)blockIdx.x * sinv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+    const int perm = 4 * (i16 & 3) + (i16 >> 2);
+    const int slot = (wave + 7) & 7; // wave 1 picks first, wave 0 (the diagonal's owner) last
+    int bad = 0;
+    d4 acc[TW][2];
+
+    for (int j0 = 0; j0 < n_; j0 += 32) {
+        const int w = (n_ - j0) < 32 ? (n_ - j0) : 32;
+        const int below = n_ - j0 - 32;                       // rows under the diagonal block
+        const int nt = below > 0 ? (below + 15) / 16 : 0;     // off-diagonal row tiles
+        const int mine = nt > slot ? (nt - slot + 7) / 8 : 0; // tiles of this wave: slot, slot + 8, ...
+        const int ngroups = (((nt + 7) / 8) + TW - 1) / TW; // uniform over the workgroup
+        long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
+        ra0 = ra0 < n ? ra0 : n - 1;
+        ra1 = ra1 < n ? ra1 : n - 1;
+        const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
+
+        // ---------------- diagonal block (wave 0) ----------------
+        if (wave == 0) {
+            const double *pb[TW];
+            long rr[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                long r = j0 + 16 * u + i16;
+                rr[u] = r < n ? r : n - 1;
+                pb[u] = Lm + rr[u] * n + 8 * q;
+            }
+            pb[2] = pb[0];
+            if (w == 32) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const double *p = Lm + rr[u] * n + j0 + 16 * ct + 4 * q;
+                        const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
+                        acc[u][ct] = d4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * u + i16, k = 16 * ct + 4 * q + r;
+                            acc[u][ct][r] = (i < w && k < w) ? Lm[(long)(j0 + i) * n + j0 + k] : 0.0;
+                        }
+            }
+            rowdot<2, true>(pa0, pa1, pb, 0, j0, acc);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * u + i16, k = 16 * ct + 4 * q + r;
+                        pj[i][k] = (i < w && k < w) ? acc[u][ct][r] : (i == k ? 1.0 : 0.0);
+                    }
+            wave_sync();
+            // row i = lane & 31 in registers
+            const int li = lane & 31;
+            double a[32];
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const d2 t = *(const d2 *)&pj[li][k];
+                a[k] = t[0];
+                a[k + 1] = t[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                // Column j goes through LDS (uniform-address reads = broadcasts).  Scheduling notes: v_readlane would do,
+                // but hipcc hoists all 31 broadcasts of a step and spills the SGPRs through v_writelane; and VALU
+                // instructions carry no ordering chain, so without the PIN after every update the FMAs of ALL steps
+                // sink below ALL the LDS reads (1500 spilled VGPRs).
+                double *cj = col[j & 1];
+                if (lane < 32) cj[li] = a[j];
+                wave_sync();
+                double c[32];
+#pragma unroll
+                for (int k = j; k < 32; ++k) c[k] = cj[k];
+                double dj = c[j];
+                if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
+                const double sq = __builtin_sqrt(dj), rs = 1.0 / sq;
+                if (lane == 0) dv[j] = rs;
+                const double t = -a[j] * (rs * rs); // a[k] -= L[i][j] L[k][j] = a[j] c[k] / d
+                a[j] = (li == j) ? sq : a[j] * rs;
+#pragma unroll
+                for (int k = j + 1; k < 32; ++k) {
+                    a[k] = __builtin_fma(t, c[k], a[k]);
+                    PIN_V(a[k]);
+                }
+            }
+            wave_sync(); // every lane has read its pj row before it is overwritten
+            if (lane < 32) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) pj[li][k] = (k <= li) ? a[k] : 0.0;
+            }
+            wave_sync();
+            // inverse of the factor: lane c owns column c (forward substitution, L read as LDS broadcasts)
+            {
+                double x[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    double r[32];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) r[k] = pj[i][k];
+                    const double di = dv[i];
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) s = __builtin_fma(r[k], x[k], s);
+                    x[i] = (i == li) ? di : (i > li ? -s * di : 0.0);
+                    PIN_V(x[i]); // one row of L in flight, not all 496 broadcast reads
+                }
+                if (lane < 32) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) linv[i][li] = x[i];
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int e = lane + 64 * t, i = e >> 5, k = e & 31;
+                const bool in = i < w && k < w;
+                if (in) Lm[(long)(j0 + i) * n + j0 + k] = pj[i][k];
+                iv[(size_t)(j0 >> 5) * 1024 + e] = in ? linv[i][k] : 0.0;
+            }
+        }
+
+        // ---------------- off-diagonal tiles, TW per wave and group ----------------
+        for (int g = 0; g < ngroups; ++g) {
+            int cnt = mine - TW * g;
+            cnt = cnt < 0 ? 0 : (cnt > TW ? TW : cnt);
+            const double *pb[TW];
+            long rows[TW];
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                long r = j0 + 32 + 16L * (slot + 8 * (TW * g + u)) + i16;
+                rows[u] = r;
+                r = r < n ? r : n - 1;
+                pb[u] = Lm + r * n + 8 * q;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    if (u < cnt) {
+                        const double *p = Lm + r * n + j0 + 16 * ct + 4 * q;
+                        const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
+                        acc[u][ct] = d4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+            }
+            rowdot_n<true>(cnt, pa0, pa1, pb, 0, j0, acc);
+            if (g == 0) __syncthreads(); // inv(L_jj) is in LDS
+            if (cnt > 0) {
+                LinvOps lo;
+                linv_ops_load(lo, linv, perm, q);
+#pragma unroll
+                for (int u = 0; u < TW; ++u) {
+                    if (u < cnt) {
+                        d4 x0, x1;
+                        tile_trsm(lo, acc[u], x0, x1);
+                        if (rows[u] < n) {
+                            double *p = Lm + rows[u] * n + j0 + 4 * q;
+                            *(d2 *)p = d2{x0[0], x0[1]};
+                            *(d2 *)(p + 2) = d2{x0[2], x0[3]};
+                            *(d2 *)(p + 16) = d2{x1[0], x1[1]};
+                            *(d2 *)(p + 18) = d2{x1[2], x1[3]};
+                        }
+                    }
+                }
+            }
+        }
+        if (ngroups == 0) __syncthreads();
+        __syncthreads(); // the panel is in memory (and pj / linv are free) before the next one reads it
+    }
+    if (wave == 0 && lane == 0 && bad) status[blockIdx.x] = 1;
+}
+
+// U = L^-T (upper triangular, row-major; U[c][i] = (L^-1)[i][c]) from the factor and the inverses of its diagonal
+// blocks -- the same panel step as the factorisation with the roles shifted: for the 32 columns i0.. of U,
+//   T[c][i] = sum_{k < i0} U[c][k] L[i0 + i][k]   (rows of U x rows of L, k contiguous in both),   U[c][i0..] = -T inv(L_ii)^T
+// for the row tiles c < i0.  U[c][k] = 0 for k < c: a tile's k range starts at its own 32-block (whose diagonal
+// block is stored with its zeros), and tiles of one wave (128 rows apart) join the k loop one after the other.
+// Only the upper triangle (plus the diagonal blocks) of U is written; nothing else of U is ever read.
+__global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__restrict__ Lfull, const double *__restrict__ invd,
+                                                       long sinv, double *Ufull)
+{
+    __shared__ __attribute__((aligned(16))) double linv[32][34];
+    const long n = n_;
+    const double *Lm = Lfull + (size_t)blockIdx.x * n * n;
+    double *Um = Ufull + (size_t)blockIdx.x * n * n;
+    const double *iv = invd + (size_t)blockIdx.x * sinv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+    const int perm = 4 * (i16 & 3) + (i16 >> 2);
+    d4 acc[TW][2];
+    for (int i0 = 0; i0 < n_; i0 += 32) {
+        const int w = (n_ - i0) < 32 ? (n_ - i0) : 32;
+        for (int e = tid; e < 1024; e += 512) {
+            const int i = e >> 5, k = e & 31;
+            const double v = iv[(size_t)(i0 >> 5) * 1024 + e];
+            linv[i][k] = v;
+            if (i < w && k < w) Um[(long)(i0 + k) * n + i0 + i] = v; // diagonal block of U = inv(L_ii)^T
+        }
+        __syncthreads();
+        const int nt = i0 >> 4; // full row tiles above the diagonal block
+        const int mine = nt > wave ? (nt - wave + 7) / 8 : 0;
+        long ra0 = i0 + perm, ra1 = i0 + 16 + perm;
+        ra0 = ra0 < n ? ra0 : n - 1;
+        ra1 = ra1 < n ? ra1 : n - 1;
+        const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
+        for (int g = 0; TW * g < mine; ++g) {
+            int cnt = mine - TW * g;
+            cnt = cnt > TW ? TW : cnt;
+            const double *pb[TW];
+            long rows[TW];
+            int ks[TW + 1];
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                long r0 = 16L * (wave + 8 * (TW * g + u));
+                r0 = u < cnt ? r0 : 16L * wave; // unused slots alias a valid tile
+                rows[u] = r0 + i16;
+                pb[u] = Um + rows[u] * n + 8 * q;
+                ks[u] = (int)(r0 >> 5) << 5;
+                acc[u][0] = acc[u][1] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+            ks[TW] = i0;
+#pragma unroll
+            for (int s = 0; s < TW; ++s)
+                if (s < cnt) rowdot_n<true>(s + 1, pa0, pa1, pb, ks[s], (s + 1 < cnt) ? ks[s + 1] : i0, acc);
+            LinvOps lo;
+            linv_ops_load(lo, linv, perm, q);
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u < cnt) {
+                    d4 x0, x1;
+                    tile_trsm(lo, acc[u], x0, x1);
+                    double *p = Um + rows[u] * n + i0 + 4 * q;
+                    if (i0 + 4 * q < n) *(d2 *)p = d2{x0[0], x0[1]};
+                    if (i0 + 4 * q + 2 < n) *(d2 *)(p + 2) = d2{x0[2], x0[3]};
+                    if (i0 + 16 + 4 * q < n) *(d2 *)(p + 16) = d2{x1[0], x1[1]};
+                    if (i0 + 18 + 4 * q < n) *(d2 *)(p + 18) = d2{x1[2], x1[3]};
+                }
+            }
+        }
+        __syncthreads(); // the 32 columns are in memory (and linv is free) before the next panel
+    }
+}
+
+// inv = U U^T = A^-1:  inv[i][j] = sum_{k >= max(i, j)} U[i][k] U[j][k]  -- rows x rows again.  Panels of 32 columns
+// j0.., row tiles i >= j0, k from the tile's own 32-block to n (a last partial chunk is masked).  Each tile is
+// written to both triangles.  No synchronisation at all: U is only read.
+template <int CNT>
+__device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1, const double *(&pb)[TW], int kt, int n, int q,
+                                            d4 (&acc)[TW][2])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool ok = kt + 8 * q + e < n;
+        const double x0 = ok ? pa0[kt + e] : 0.0, x1 = ok ? pa1[kt + e] : 0.0;
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            const double y = ok ? pb[u][kt + e] : 0.0;
+            acc[u][0] = MFMA_F64(x0, y, acc[u][0]);
+            acc[u][1] = MFMA_F64(x1, y, acc[u][1]);
+        }
+    }
+}
+__global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv)
+{
+    const long n = n_;
+    const double *Um = Ufull + (size_t)blockIdx.x * n * n;
+    double *Om = inv + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+    const int perm = 4 * (i16 & 3) + (i16 >> 2);
+    const int nfl = n_ & ~31;
+    d4 acc[TW][2];
+    for (int j0 = 0; j0 < n_; j0 += 32) {
+        const int nt = (n_ - j0 + 15) >> 4; // row tiles from the diagonal block down
+        const int mine = nt > wave ? (nt - wave + 7) / 8 : 0;
+        long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
+        ra0 = ra0 < n ? ra0 : n - 1;
+        ra1 = ra1 < n ? ra1 : n - 1;
+        const double *pa0 = Um + ra0 * n + 8 * q, *pa1 = Um + ra1 * n + 8 * q;
+        for (int g = 0; TW * g < mine; ++g) {
+            int cnt = mine - TW * g;
+            cnt = cnt > TW ? TW : cnt;
+            const double *pb[TW];
+            long rows[TW];
+            int ks[TW + 1];
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                long r0 = j0 + 16L * (wave + 8 * (TW * g + u));
+                r0 = u < cnt ? r0 : j0 + 16L * wave;
+                rows[u] = r0 + i16;
+                const long rc = rows[u] < n ? rows[u] : n - 1;
+                pb[u] = Um + rc * n + 8 * q;
+                const int k0 = (int)(r0 >> 5) << 5;
+                ks[u] = k0 < nfl ? k0 : nfl;
+                acc[u][0] = acc[u][1] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+            ks[TW] = nfl;
+#pragma unroll
+            for (int s = 0; s < TW; ++s)
+                if (s < cnt) rowdot_n<false>(s + 1, pa0, pa1, pb, ks[s], (s + 1 < cnt) ? ks[s + 1] : nfl, acc);
+            if (nfl < n_) {
+                switch (cnt) {
+                case 1: rowdot_tail<1>(pa0, pa1, pb, nfl, n_, q, acc); break;
+                case 2: rowdot_tail<2>(pa0, pa1, pb, nfl, n_, q, acc); break;
+                case 3: rowdot_tail<3>(pa0, pa1, pb, nfl, n_, q, acc); break;
+                default: break;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u < cnt && rows[u] < n) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const long c0 = j0 + 16 * ct + 4 * q;
+                        double *p = Om + rows[u] * n + c0;
+                        if (c0 < n) *(d2 *)p = d2{acc[u][ct][0], acc[u][ct][1]};
+                        if (c0 + 2 < n) *(d2 *)(p + 2) = d2{acc[u][ct][2], acc[u][ct][3]};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c0 + r < n) Om[(c0 + r) * n + rows[u]] = acc[u][ct][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    const int nblk = (n + 31) / 32;
+    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status);
+    return (int)hipGetLastError();
+}
+
+// inv[b] = A[b]^-1 through the three one-workgroup-per-matrix kernels; U: scratch nb*n*n (only its upper triangle is used)
+int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    const int nblk = (n + 31) / 32;
+    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status);
+    k_trinv_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, U);
+    k_uut<<<nb, 512, 0, st>>>(n, U, inv);
+    return (int)hipGetLastError();
+}

@@ -437,6 +437,9 @@ __global__ __launch_bounds__(256) void k_potf2_inv(int n, int kk, int w, double 
         if (_r) return _r;           \
     } while (0)
 
+static int g_chol_gemm_path = 0; // A/B knob: 1 = the GEMM-built right-looking factorisation for every n
+void tvk_set_chol_gemm_path(int on) { g_chol_gemm_path = on; }
+
 // In-place batched Cholesky (lower) of nb SPD matrices [n x n]; invd receives the inverses of the
 // 32 x 32 diagonal blocks; panel: scratch nb*n*32 doubles. Upper triangles end up unspecified
 // except inside diagonal blocks (zeroed).
@@ -446,6 +449,7 @@ int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd,
     // by GEMM) inside 128-wide outer blocks.  A step only updates the columns of its own outer block; the rest of
     // the trailing matrix is updated once per outer block with K = 128 -- a quarter of the read-modify-write
     // traffic of updating the whole trailing matrix at every step (the batch is memory-bound there).
+    if (n % 2 == 0 && !g_chol_gemm_path) return tvk_chol_left_batched(st, n, nb, Afull, invd, status);
     constexpr int WB = 128;
     const int nblk = (n + 31) / 32;
     const long sinv = (long)nblk * 1024, sa = (long)n * n, spn = (long)n * 32;
@@ -481,6 +485,7 @@ int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd,
 int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,
                             double *panel, int *status)
 {
+    if (n % 2 == 0 && !g_chol_gemm_path) return tvk_spd_inverse_left_batched(st, n, nb, Afull, inv, X, invd, status);
     TVCHK(tvk_chol_batched(st, n, nb, Afull, invd, panel, status));
     const int nblk = (n + 31) / 32;
     const long sinv = (long)nblk * 1024, sa = (long)n * n, spn = (long)n * 32;

@@ -21,7 +21,7 @@ def sync_time(f, reps=2):
     for _ in range(reps):
         f()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t) / reps
+    return (time.perf_counter() - t) / max(reps, 1)
 
 # ---- T-matrix EM iteration on U utterances (statistics given)
 U = int(os.environ.get("TV_U", "1024"))
@@ -36,13 +36,16 @@ acc = dict(A=torch.zeros((C, P), dtype=torch.float64, device=dev), Cmx=torch.zer
            Rm=torch.zeros((R, R), dtype=torch.float64, device=dev), r=torch.zeros(R, dtype=torch.float64, device=dev),
            meanW=torch.zeros(R, dtype=torch.float64, device=dev), W=torch.empty((U, R), dtype=torch.float64, device=dev))
 Tn = torch.empty_like(Tm)
-t_tett = sync_time(lambda: ctx.tv_tett(Tm, invvar, C, D, out=tett))
+PH = os.environ.get("TV_PHASES", "tett,estep,mstep,scoring").split(",")
+t_tett = sync_time(lambda: ctx.tv_tett(Tm, invvar, C, D, out=tett), 2 if "tett" in PH else 0)
 def estep():
     for k in ("A", "Cmx", "Rm", "r", "meanW"):
         acc[k].zero_()
     ctx.tv_estimate_a_and_c(N, F, Tm, invvar, tett, C, D, acc=acc)
-t_e = sync_time(estep, 1)
-t_m = sync_time(lambda: ctx.tv_update_t(acc["A"], acc["Cmx"], C, D, out=Tn), 1)
+t_e = sync_time(estep, 1) if "estep" in PH else float("nan")
+if "estep" not in PH:
+    estep()          # the M-step needs a valid A
+t_m = sync_time(lambda: ctx.tv_update_t(acc["A"], acc["Cmx"], C, D, out=Tn), 1) if "mstep" in PH else float("nan")
 flop_e = U * (2.0 * C * P + 2.0 * C * D * R + 2.0 * C * P + 2.0 * R * C * D)      # L, aux, A (packed), Cmx
 out["tv_em"] = {"utterances": U, "tett_ms": t_tett * 1e3, "estep_ms": t_e * 1e3, "mstep_ms": t_m * 1e3,
                 "estep_ms_per_utterance": t_e * 1e3 / U, "estep_gemm_tflops": flop_e / t_e / 1e12,
@@ -50,6 +53,8 @@ out["tv_em"] = {"utterances": U, "tett_ms": t_tett * 1e3, "estep_ms": t_e * 1e3,
 del N, F, acc, tett, Tn
 torch.cuda.empty_cache()
 
+if "scoring" not in PH:
+    print(json.dumps(out)); sys.exit(0)
 # ---- scoring M x S
 M = S = int(os.environ.get("SC_N", "20000"))
 models = torch.randn((R, M), dtype=torch.float64, device=dev, generator=g)
