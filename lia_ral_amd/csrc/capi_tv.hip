@@ -237,7 +237,8 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
     double *Tiv = (double *)p;
     GCHK(tvk_scale_cols(c->stream, R, (long)SV, i_t.d, i_iv.d, Tiv));
 
-    int BC = 256;
+    int BC = (int)c->tv_batch;
+    if (BC < 1) BC = 256;
     if (U < BC) BC = (int)U;
     if ((rc = c->scratch(WS_LP, (size_t)BC * P * 8, &p))) { free_owned(); return rc; }
     double *Lp = (double *)p;

@@ -144,6 +144,20 @@ __device__ __forceinline__ void tile_trsm(const LinvOps &o, const d4 (&p)[2], d4
 
 } // namespace
 
+// the factored diagonal block and its inverse leave LDS: all 512 threads, two elements each
+__device__ __forceinline__ void chol_block_out(const double (*pj)[34], const double (*linv)[34], double *Lm, double *iv, long n,
+                                               int j0, int w, int tid)
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = tid + 512 * t, i = e >> 5, k = e & 31;
+        const bool in = i < w && k < w;
+        const double vl = pj[i][k], vi = linv[i][k];
+        if (in) Lm[(long)(j0 + i) * n + j0 + k] = vl;
+        iv[(size_t)(j0 >> 5) * 1024 + e] = in ? vi : 0.0;
+    }
+}
+
 // Afull[b]: n x n row-major, lower triangle read, overwritten by the factor (diagonal blocks: upper part zeroed;
 // elsewhere the upper triangle is left as it was).  invd[b][kb][32][32]: inverse of the kb-th 32 x 32 diagonal
 // block of the factor (zero padded).  status[b] = 1 on a non-positive pivot.  n must be even (16-byte rows).
@@ -151,18 +165,23 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
 {
     __shared__ __attribute__((aligned(16))) double pj[32][34];
     __shared__ __attribute__((aligned(16))) double linv[32][34];
-    __shared__ double dv[32];
     __shared__ __attribute__((aligned(16))) double col[2][32];
+    __shared__ double slab[8][32][33]; // partial updates of the diagonal block, one per wave
     const long n = n_;
     double *Lm = Afull + (size_t)blockIdx.x * n * n;
     double *iv = invd + (size_t)blockIdx.x * sinv;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
-    const int perm = 4 * (i16 & 3) + (i16 >> 2);
-    const int slot = (wave + 7) & 7; // wave 1 picks first, wave 0 (the diagonal's owner) last
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    // tiles go to waves 1 2 3 5 6 7 4 0 in turn: wave 0 owns the serial diagonal work, wave 4 shares its SIMD
+    const int slot = wave == 0 ? 7 : (wave == 4 ? 6 : (wave < 4 ? wave - 1 : wave - 2));
     int bad = 0;
     d4 acc[TW][2];
 
     for (int j0 = 0; j0 < n_; j0 += 32) {
+        // lane-derived indices are recomputed per panel: laundered, so that the compiler does not hoist every address
+        // expression of the panel body out of the loop and keep (spill) it for the whole kernel
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int i16 = lane & 15, q = lane >> 4, perm = 4 * (i16 & 3) + (i16 >> 2);
         const int w = (n_ - j0) < 32 ? (n_ - j0) : 32;
         const int below = n_ - j0 - 32;                       // rows under the diagonal block
         const int nt = below > 0 ? (below + 15) / 16 : 0;     // off-diagonal row tiles
@@ -173,8 +192,11 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
         ra1 = ra1 < n ? ra1 : n - 1;
         const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
 
-        // ---------------- diagonal block (wave 0) ----------------
-        if (wave == 0) {
+        // ---------------- diagonal block ----------------
+        // step 1, all waves: the update sum_{k < j0} L[j0 + i][k] L[j0 + c][k] of the 32 x 32 block is cut in 8 k ranges
+        // (one wave alone would walk the whole range at one memory latency per 32 columns and hold up everybody at the
+        // barrier below); the partial blocks meet in LDS.  Wave 0's partial starts from the block of A itself.
+        {
             const double *pb[TW];
             long rr[2];
 #pragma unroll
@@ -182,29 +204,34 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 long r = j0 + 16 * u + i16;
                 rr[u] = r < n ? r : n - 1;
                 pb[u] = Lm + rr[u] * n + 8 * q;
+                acc[u][0] = acc[u][1] = d4{0.0, 0.0, 0.0, 0.0};
             }
             pb[2] = pb[0];
-            if (w == 32) {
+            if (wave == 0) {
+                if (w == 32) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        const double *p = Lm + rr[u] * n + j0 + 16 * ct + 4 * q;
-                        const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
-                        acc[u][ct] = d4{lo[0], lo[1], hi[0], hi[1]};
-                    }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = 16 * u + i16, k = 16 * ct + 4 * q + r;
-                            acc[u][ct][r] = (i < w && k < w) ? Lm[(long)(j0 + i) * n + j0 + k] : 0.0;
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const double *p = Lm + rr[u] * n + j0 + 16 * ct + 4 * q;
+                            const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
+                            acc[u][ct] = d4{lo[0], lo[1], hi[0], hi[1]};
                         }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * u + i16, k = 16 * ct + 4 * q + r;
+                                acc[u][ct][r] = (i < w && k < w) ? Lm[(long)(j0 + i) * n + j0 + k] : 0.0;
+                            }
+                }
             }
-            rowdot<2, true>(pa0, pa1, pb, 0, j0, acc);
+            const int p32 = j0 >> 5;
+            rowdot<2, true>(pa0, pa1, pb, 32 * ((wave * p32) >> 3), 32 * (((wave + 1) * p32) >> 3), acc);
+            const double unit = wave == 0 ? 1.0 : 0.0; // rows / columns beyond n: identity
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -212,76 +239,80 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 16 * u + i16, k = 16 * ct + 4 * q + r;
-                        pj[i][k] = (i < w && k < w) ? acc[u][ct][r] : (i == k ? 1.0 : 0.0);
+                        slab[wave][i][k] = (i < w && k < w) ? acc[u][ct][r] : (i == k ? unit : 0.0);
                     }
-            wave_sync();
-            // row i = lane & 31 in registers
+        }
+        __syncthreads(); // the 8 partial updates are in LDS
+        // step 2, wave 0: row i = lane & 31 of the block in registers, factor, invert
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3); // the serial part: do not queue behind the MFMA stream of the wave sharing this SIMD
             const int li = lane & 31;
             double a[32];
 #pragma unroll
-            for (int k = 0; k < 32; k += 2) {
-                const d2 t = *(const d2 *)&pj[li][k];
-                a[k] = t[0];
-                a[k + 1] = t[1];
+            for (int k = 0; k < 32; ++k) a[k] = slab[0][li][k];
+#pragma unroll
+            for (int sl = 1; sl < 8; ++sl) {
+                double t[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) t[k] = slab[sl][li][k];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    a[k] += t[k];
+                    PIN_V(a[k]);
+                }
             }
+            // Factorisation and inversion of the 32 x 32 block in ONE sweep over its columns, ONE FMA stream for both:
+            // lanes 0..31 hold row i = lane of the block, lanes 32..63 the running sums of column i = lane - 32 of
+            // X = L^-1 (v[] either way).  Column j goes through LDS (uniform-address reads = broadcasts):
+            // c[k] = unscaled L[k][j].  With y = v[j] / sqrt(d):
+            //   lanes < 32 :  L[i][j] = y,                       v[k] -= y L[k][j]        = fma(-y rs, c[k], v[k])
+            //   lanes >= 32:  X[j][i] = delta_ij rs - [j > i] y, v[k] += L[k][j] X[j][i]  = fma(X[j][i] rs, c[k], v[k])
+            // The next column's entry is updated FIRST and written out before the rest of the step, so that its LDS
+            // round trip overlaps the remaining FMAs.
+            // Scheduling notes: v_readlane would do for the broadcasts, but hipcc hoists all 31 of a step and spills the
+            // SGPRs through v_writelane; and VALU instructions carry no ordering chain, so without the PIN after every
+            // update the FMAs of ALL steps sink below ALL the LDS reads (1500 spilled VGPRs).
+            const bool lo = lane < 32;
+            double v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = lo ? a[k] : 0.0;
+            if (lo) col[0][li] = v[0];
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                // Column j goes through LDS (uniform-address reads = broadcasts).  Scheduling notes: v_readlane would do,
-                // but hipcc hoists all 31 broadcasts of a step and spills the SGPRs through v_writelane; and VALU
-                // instructions carry no ordering chain, so without the PIN after every update the FMAs of ALL steps
-                // sink below ALL the LDS reads (1500 spilled VGPRs).
-                double *cj = col[j & 1];
-                if (lane < 32) cj[li] = a[j];
+                const double *cj = col[j & 1];
                 wave_sync();
                 double c[32];
 #pragma unroll
                 for (int k = j; k < 32; ++k) c[k] = cj[k];
                 double dj = c[j];
                 if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
-                const double sq = __builtin_sqrt(dj), rs = 1.0 / sq;
-                if (lane == 0) dv[j] = rs;
-                const double t = -a[j] * (rs * rs); // a[k] -= L[i][j] L[k][j] = a[j] c[k] / d
-                a[j] = (li == j) ? sq : a[j] * rs;
-#pragma unroll
-                for (int k = j + 1; k < 32; ++k) {
-                    a[k] = __builtin_fma(t, c[k], a[k]);
-                    PIN_V(a[k]);
+                // 1/sqrt(d) and sqrt(d) from v_rsq_f64 + Newton / Goldschmidt steps (a dozen dependent FMAs instead of the
+                // ~60 instructions of an IEEE sqrt followed by an IEEE divide): this chain is the serial part of the kernel
+                double rs = __builtin_amdgcn_rsq(dj);
+                const double hd = 0.5 * dj;
+                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
+                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
+                double sq = dj * rs;
+                sq = __builtin_fma(__builtin_fma(-sq, sq, dj), 0.5 * rs, sq);
+                rs = __builtin_fma(__builtin_fma(-sq, rs, 1.0), rs, rs);
+                const double y = v[j] * rs;
+                const double xj = (j == li) ? rs : (j > li ? -y : 0.0);
+                const double coef = (lo ? -y : xj) * rs;
+                if (j + 1 < 32) {
+                    v[j + 1] = __builtin_fma(coef, c[j + 1], v[j + 1]);
+                    PIN_V(v[j + 1]);
+                    if (lo) col[(j + 1) & 1][li] = v[j + 1];
                 }
-            }
-            wave_sync(); // every lane has read its pj row before it is overwritten
-            if (lane < 32) {
+                if (lo) pj[li][j] = (li == j) ? sq : (li > j ? y : 0.0);
+                else linv[j][li] = xj;
 #pragma unroll
-                for (int k = 0; k < 32; ++k) pj[li][k] = (k <= li) ? a[k] : 0.0;
-            }
-            wave_sync();
-            // inverse of the factor: lane c owns column c (forward substitution, L read as LDS broadcasts)
-            {
-                double x[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    double r[32];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) r[k] = pj[i][k];
-                    const double di = dv[i];
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; ++k) s = __builtin_fma(r[k], x[k], s);
-                    x[i] = (i == li) ? di : (i > li ? -s * di : 0.0);
-                    PIN_V(x[i]); // one row of L in flight, not all 496 broadcast reads
-                }
-                if (lane < 32) {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) linv[i][li] = x[i];
+                for (int k = j + 2; k < 32; ++k) {
+                    v[k] = __builtin_fma(coef, c[k], v[k]);
+                    PIN_V(v[k]);
                 }
             }
             wave_sync();
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int e = lane + 64 * t, i = e >> 5, k = e & 31;
-                const bool in = i < w && k < w;
-                if (in) Lm[(long)(j0 + i) * n + j0 + k] = pj[i][k];
-                iv[(size_t)(j0 >> 5) * 1024 + e] = in ? linv[i][k] : 0.0;
-            }
+            __builtin_amdgcn_s_setprio(0);
         }
 
         // ---------------- off-diagonal tiles, TW per wave and group ----------------
@@ -306,7 +337,10 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 }
             }
             rowdot_n<true>(cnt, pa0, pa1, pb, 0, j0, acc);
-            if (g == 0) __syncthreads(); // inv(L_jj) is in LDS
+            if (g == 0) {
+                __syncthreads(); // inv(L_jj) and L_jj are in LDS
+                chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
+            }
             if (cnt > 0) {
                 LinvOps lo;
                 linv_ops_load(lo, linv, perm, q);
@@ -326,10 +360,13 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 }
             }
         }
-        if (ngroups == 0) __syncthreads();
+        if (ngroups == 0) {
+            __syncthreads();
+            chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
+        }
         __syncthreads(); // the panel is in memory (and pj / linv are free) before the next one reads it
     }
-    if (wave == 0 && lane == 0 && bad) status[blockIdx.x] = 1;
+    if (wave == 0 && lane0 == 0 && bad) status[blockIdx.x] = 1;
 }
 
 // U = L^-T (upper triangular, row-major; U[c][i] = (L^-1)[i][c]) from the factor and the inverses of its diagonal

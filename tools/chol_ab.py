@@ -34,7 +34,8 @@ def t(f, reps=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 
-out = {"R": R, "U": U}
+ctx.set_option("tv_batch", int(os.environ.get("TV_BATCH", "256")))
+out = {"R": R, "U": U, "tv_batch": int(os.environ.get("TV_BATCH", "256"))}
 res = {}
 for mode in (1, 0, 1, 0):
     ctx.set_option("chol_gemm", mode)
