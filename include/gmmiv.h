@@ -57,6 +57,10 @@ const char *gmmiv_version(void);
  *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
+ *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one
+ *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
+ *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
+ *                      used for odd orders); process-wide A/B switch
  *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)
  *   "glds", "wg_waves", "em_chunks", "dbg": A/B switches of the measurement tools */
 long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);

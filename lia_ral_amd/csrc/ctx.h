@@ -48,7 +48,7 @@ struct gmmiv_ctx {
     // 1 (default): the log-likelihood kernel leaves the logits in HBM and the statistics kernel reads
     // them back (stats_z.hip) instead of recomputing them; 0: the recomputing k_stats_mfma
     long stats_z = 1;
-    long tv_batch = 256; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)
+    long tv_batch = 1024; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)
     long z_waves = 8; // waves per workgroup of k_stats_z: 8 (one workgroup per CU) or 4 (two per CU)
     // logit scratch budget (MiB): frames are processed in chunks that fit.  Sized for a 288 GB part --
     // fewer, larger launches (64 GiB = 3.4 M frames of a 2048-Gaussian model per chunk); never more
