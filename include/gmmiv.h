@@ -276,6 +276,31 @@ int gmmiv_score_twocov(gmmiv_ctx *ctx, int dim, int64_t M, int64_t S, const doub
 int gmmiv_score_plda(gmmiv_ctx *ctx, int rf, int64_t M, int64_t S, const double *models_sum,
                      const int64_t *nsess, const double *segs, const double *FTJF, double *scores);
 
+/* ---- JFA (LIA_SpkTools/src/AccumulateJFAStat.cpp): model M_{s,h} = m + V y_s + U x_h + D z_s ---------------------------
+ * The factor steps are the total-variability entry points under the JFA names:
+ *   JFAAcc::estimateVEVT / estimateUEUT (:1266-1352, :1425-1508)                         -> gmmiv_tv_tett
+ *   JFAAcc::estimateAndInverseL_EV + estimateYandV (:1970-1996, :2467-2511), _EC + estimateXandU (:2137-2163, :3040-3083)
+ *                                                                                          -> gmmiv_tv_estimate_a_and_c
+ *   JFAAcc::estimateY / estimateX (:2867-2957, :3262-3351)                                -> gmmiv_tv_estimate_w
+ *   JFAAcc::updateVestimate / updateUestimate (:3597-3644)                                -> gmmiv_tv_update_t
+ * What is specific to JFA is below.  All arrays host or device. */
+/* F[r,c,:] -= N[r,c] (means[c,:] + (W[o] T)[c,:] + Dm[c,:] Z[o][c,:]),  o = owner ? owner[r] : r.  Every term is optional
+ * (means, T/W, Dm/Z may be NULL).  N [rows x C], F [rows x C*D], T [R x C*D], W [nfact x R], Dm [C*D], Z [nfact x C*D].
+ * Replaces JFAAcc::substractMplusDZ (:3805-3822), substractMplusVY (:3988-4005), substractMplusVYplusDZ (:4400-4422, owner =
+ * the speaker of each session), substractMplusUX (:4336-4364), getMplusVYplusDZ / getUX (:1803-1957). */
+int gmmiv_jfa_subtract(gmmiv_ctx *ctx, int64_t rows, int C, int D, const double *N, double *F, const int64_t *owner, int64_t nfact,
+                       const double *means, int R, const double *T, const double *W, const double *Dm, const double *Z);
+/* F_X[s,c,:] -= sum over the sessions h in [sess_begin[s], sess_begin[s+1]) of N_h[h,c] (x_h U)[c,:]   (sessions grouped by
+ * speaker, sess_begin a HOST array of nspk + 1 offsets).  Replaces JFAAcc::substractUX (:4152-4172). */
+int gmmiv_jfa_subtract_sessions(gmmiv_ctx *ctx, int64_t nspk, const int64_t *sess_begin, int C, int D, const double *N_h, double *F_X,
+                                int R, const double *U, const double *X);
+/* tau < 0: Z = F iv D / (1 + N iv D^2) (JFAAcc::estimateZ, :3550-3573); tau >= 0: Z = tau / (tau + N) D iv F (estimateZMAP, :3576-3594). */
+int gmmiv_jfa_estimate_z(gmmiv_ctx *ctx, int64_t nspk, int C, int D, const double *N, const double *F, const double *invvar, const double *Dm,
+                         double tau, double *Z);
+/* JFAAcc::estimateZandD (:3480-3516): Z as above (tau < 0) and D <- sum_s z F / sum_s (1 / L + z^2) N, in place. */
+int gmmiv_jfa_estimate_z_and_d(gmmiv_ctx *ctx, int64_t nspk, int C, int D, const double *N, const double *F, const double *invvar, double *Dm,
+                               double *Z);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,34 @@ class Context:
                                              _ptr(Tm), _ptr(W)))
         return F
 
+    # ---- JFA (gmmiv_jfa_*; the factor steps are tv_tett / tv_estimate_a_and_c / tv_estimate_w / tv_update_t) ----
+    def jfa_subtract(self, N, F, C, D, owner=None, nfact=None, means=None, T=None, W=None, Dm=None, Z=None):
+        rows = N.shape[0]
+        if nfact is None:
+            nfact = W.shape[0] if W is not None else (Z.shape[0] if Z is not None else rows)
+        o = None if owner is None else (owner if _is_torch(owner) else np.ascontiguousarray(owner, np.int64))
+        _chk(lib.gmmiv_jfa_subtract(self._h, ct.c_int64(rows), C, D, _ptr(N), _ptr(F), _ptr(o), ct.c_int64(nfact), _ptr(means),
+                                    0 if T is None else T.shape[0], _ptr(T), _ptr(W), _ptr(Dm), _ptr(Z)))
+        return F
+
+    def jfa_subtract_sessions(self, sess_begin, N_h, F_X, U, X, C, D):
+        sb = np.ascontiguousarray(sess_begin, np.int64)
+        _chk(lib.gmmiv_jfa_subtract_sessions(self._h, ct.c_int64(len(sb) - 1), _ptr(sb), C, D, _ptr(N_h), _ptr(F_X), U.shape[0], _ptr(U), _ptr(X)))
+        return F_X
+
+    def jfa_estimate_z(self, N, F, invvar, Dm, C, D, tau=-1.0, out=None):
+        if out is None:
+            out = np.empty((N.shape[0], C * D))
+        _chk(lib.gmmiv_jfa_estimate_z(self._h, ct.c_int64(N.shape[0]), C, D, _ptr(N), _ptr(F), _ptr(invvar), _ptr(Dm), ct.c_double(tau), _ptr(out)))
+        return out
+
+    def jfa_estimate_z_and_d(self, N, F, invvar, Dm, C, D, out=None):
+        """Dm is updated in place; returns Z."""
+        if out is None:
+            out = np.empty((N.shape[0], C * D))
+        _chk(lib.gmmiv_jfa_estimate_z_and_d(self._h, ct.c_int64(N.shape[0]), C, D, _ptr(N), _ptr(F), _ptr(invvar), _ptr(Dm), _ptr(out)))
+        return out
+
     def tv_norm_t(self, Tm, invvar, C, D):
         _chk(lib.gmmiv_tv_norm_t(self._h, C, D, Tm.shape[0], _ptr(Tm), _ptr(invvar)))
         return Tm

@@ -419,6 +419,114 @@ int gmmiv_tv_subtract_m_plus_tw(gmmiv_ctx *c, int64_t U, int C, int D, int R, co
     return o_f.finish();
 }
 
+// ---- JFA (LIA_SpkTools/src/AccumulateJFAStat.cpp).  The factor steps themselves are the TV functions above under other
+// names: estimateVEVT / estimateUEUT = gmmiv_tv_tett, estimateAndInverseL_E{V,C} + estimate{YandV,XandU} =
+// gmmiv_tv_estimate_a_and_c, estimateY / estimateX = gmmiv_tv_estimate_w, update{V,U}estimate = gmmiv_tv_update_t. ----
+int gmmiv_jfa_subtract(gmmiv_ctx *c, int64_t rows, int C, int D, const double *N, double *F, const int64_t *owner, int64_t nfact,
+                       const double *means, int R, const double *Tm, const double *W, const double *Dm, const double *Z)
+{
+    if (!c || rows < 0 || C <= 0 || D <= 0 || !N || !F || nfact < 0 || (Tm && (R <= 0 || !W)) || (Dm && !Z)) { gmmiv_set_error("jfa_subtract: bad argument"); return GMMIV_ERR_ARG; }
+    if (rows == 0) return GMMIV_OK;
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    if (!owner && nfact < rows && (Tm || Dm)) { gmmiv_set_error("jfa_subtract: %lld factor rows for %lld statistics rows and no owner map", (long long)nfact, (long long)rows); return GMMIV_ERR_ARG; }
+    if (owner && !gmmiv_is_device_ptr(owner))
+        for (int64_t r = 0; r < rows; ++r)
+            if (owner[r] < 0 || owner[r] >= nfact) { gmmiv_set_error("jfa_subtract: owner[%lld] = %lld out of range", (long long)r, (long long)owner[r]); return GMMIV_ERR_ARG; }
+    DevIn<double> i_n, i_m, i_t, i_w, i_d, i_z;
+    DevIn<int64_t> i_o;
+    DevOut<double> o_f;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)rows * C)) || (rc = i_m.init(c, WS_T2, means, SV)) || (rc = i_t.init(c, WS_T3, Tm, Tm ? (size_t)R * SV : 0)) ||
+        (rc = i_w.init(c, WS_LSE, Tm ? W : nullptr, Tm ? (size_t)nfact * R : 0)) || (rc = i_d.init(c, WS_T4, Dm, SV)) ||
+        (rc = i_z.init(c, WS_T5, Dm ? Z : nullptr, Dm ? (size_t)nfact * SV : 0)) || (rc = i_o.init(c, WS_SEG, owner, (size_t)rows)) ||
+        (rc = o_f.init(c, WS_T1, F, (size_t)rows * SV, true))) return rc;
+    const int BC = rows < 256 ? (int)rows : 256;
+    double *TW = nullptr, *Wg = nullptr;
+    void *p;
+    if (Tm) {
+        if ((rc = c->scratch(WS_TIV, (size_t)BC * SV * 8, &p))) return rc;
+        TW = (double *)p;
+        if ((rc = c->scratch(WS_AUX, (size_t)BC * R * 8, &p))) return rc;
+        Wg = (double *)p;
+    }
+    for (int64_t r0 = 0; r0 < rows; r0 += BC) {
+        const int nb = (int)((rows - r0) < BC ? (rows - r0) : BC);
+        if (Tm) {
+            GCHK(tvk_gather_rows(c->stream, nb, R, (long)r0, (const long *)i_o.d, i_w.d, Wg));
+            GCHK(tvk_dgemm(c->stream, false, false, nb, (int)SV, R, 1.0, Wg, R, 0, i_t.d, (long)SV, 0, 0.0, TW, (long)SV, 0, 1));
+        }
+        GCHK(tvk_jfa_sub(c->stream, nb, C, D, (long)r0, (const long *)i_o.d, i_n.d, o_f.d, i_m.d, TW, i_d.d, i_z.d));
+    }
+    return o_f.finish();
+}
+
+int gmmiv_jfa_subtract_sessions(gmmiv_ctx *c, int64_t nspk, const int64_t *sess_begin, int C, int D, const double *N_h, double *F_X,
+                                int R, const double *Um, const double *X)
+{
+    if (!c || nspk < 0 || !sess_begin || C <= 0 || D <= 0 || R <= 0 || !N_h || !F_X || !Um || !X) { gmmiv_set_error("jfa_subtract_sessions: bad argument"); return GMMIV_ERR_ARG; }
+    if (gmmiv_is_device_ptr(sess_begin)) { gmmiv_set_error("jfa_subtract_sessions: sess_begin must be a host array"); return GMMIV_ERR_ARG; }
+    if (nspk == 0) return GMMIV_OK;
+    for (int64_t s = 0; s < nspk; ++s)
+        if (sess_begin[s + 1] < sess_begin[s] || sess_begin[0] != 0) { gmmiv_set_error("jfa_subtract_sessions: sess_begin must start at 0 and be non-decreasing"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    const int64_t nsess = sess_begin[nspk];
+    if (nsess == 0) return GMMIV_OK;
+    DevIn<double> i_n, i_u, i_x;
+    DevIn<int64_t> i_b;
+    DevOut<double> o_f;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N_h, (size_t)nsess * C)) || (rc = i_u.init(c, WS_T3, Um, (size_t)R * SV)) || (rc = i_x.init(c, WS_LSE, X, (size_t)nsess * R)) ||
+        (rc = i_b.init(c, WS_SEG, sess_begin, (size_t)nspk + 1)) || (rc = o_f.init(c, WS_T1, F_X, (size_t)nspk * SV, true))) return rc;
+    const int BC = nsess < 256 ? (int)nsess : 256;
+    void *p;
+    if ((rc = c->scratch(WS_TIV, (size_t)BC * SV * 8, &p))) return rc;
+    double *G = (double *)p;
+    int64_t s_lo = 0;
+    for (int64_t h0 = 0; h0 < nsess; h0 += BC) {
+        const int64_t h1 = (h0 + BC) < nsess ? (h0 + BC) : nsess;
+        GCHK(tvk_dgemm(c->stream, false, false, (int)(h1 - h0), (int)SV, R, 1.0, i_x.d + (size_t)h0 * R, R, 0, i_u.d, (long)SV, 0, 0.0, G, (long)SV, 0, 1));
+        while (s_lo < nspk && sess_begin[s_lo + 1] <= h0) ++s_lo;      // first speaker with a session in [h0, h1)
+        int64_t s_hi = s_lo;
+        while (s_hi < nspk && sess_begin[s_hi] < h1) ++s_hi;           // one past the last
+        GCHK(tvk_jfa_sub_sessions(c->stream, (long)s_lo, (long)(s_hi - s_lo), (long)h0, (long)h1, C, D, (const long *)i_b.d, i_n.d, G, o_f.d));
+    }
+    return o_f.finish();
+}
+
+int gmmiv_jfa_estimate_z(gmmiv_ctx *c, int64_t nspk, int C, int D, const double *N, const double *F, const double *invvar, const double *Dm,
+                         double tau, double *Z)
+{
+    if (!c || nspk < 0 || C <= 0 || D <= 0 || !N || !F || !invvar || !Dm || !Z) { gmmiv_set_error("jfa_estimate_z: bad argument"); return GMMIV_ERR_ARG; }
+    if (nspk == 0) return GMMIV_OK;
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_f, i_v, i_d;
+    DevOut<double> o_z;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)nspk * C)) || (rc = i_f.init(c, WS_T1, F, (size_t)nspk * SV)) || (rc = i_v.init(c, WS_T2, invvar, SV)) ||
+        (rc = i_d.init(c, WS_T4, Dm, SV)) || (rc = o_z.init(c, WS_T5, Z, (size_t)nspk * SV, false))) return rc;
+    GCHK(tvk_jfa_z(c->stream, (long)nspk, C, D, i_n.d, i_f.d, i_v.d, i_d.d, tau, o_z.d));
+    return o_z.finish();
+}
+
+int gmmiv_jfa_estimate_z_and_d(gmmiv_ctx *c, int64_t nspk, int C, int D, const double *N, const double *F, const double *invvar, double *Dm,
+                               double *Z)
+{
+    if (!c || nspk <= 0 || C <= 0 || D <= 0 || !N || !F || !invvar || !Dm || !Z) { gmmiv_set_error("jfa_estimate_z_and_d: bad argument"); return GMMIV_ERR_ARG; }
+    GCHK(hipSetDevice(c->device));
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_f, i_v;
+    DevOut<double> o_d, o_z;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)nspk * C)) || (rc = i_f.init(c, WS_T1, F, (size_t)nspk * SV)) || (rc = i_v.init(c, WS_T2, invvar, SV)) ||
+        (rc = o_d.init(c, WS_T4, Dm, SV, true)) || (rc = o_z.init(c, WS_T5, Z, (size_t)nspk * SV, false))) return rc;
+    GCHK(tvk_jfa_z_and_d(c->stream, (long)nspk, C, D, i_n.d, i_f.d, i_v.d, o_d.d, o_z.d));
+    if ((rc = o_d.finish())) return rc;
+    return o_z.finish();
+}
+
 int gmmiv_tv_norm_t(gmmiv_ctx *c, int C, int D, int R, double *Tm, const double *invvar)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !invvar) { gmmiv_set_error("tv_norm_t: bad argument"); return GMMIV_ERR_ARG; }

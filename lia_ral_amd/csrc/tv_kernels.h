@@ -43,3 +43,10 @@ int tvk_dev_center(hipStream_t st, int dim, long n, int mode, const double *X, c
                    const long *off, const int *cls, double *out);
 int tvk_dev_between(hipStream_t st, int dim, long nspk, int weighted, const double *mean, const double *smean, const long *off, double *out);
 int tvk_dev_expand(hipStream_t st, int rows, long n, long nspk, const double *H, const int *cls, double *out);
+int tvk_gather_rows(hipStream_t st, int nb, int R, long r0, const long *owner, const double *W, double *Wg);
+int tvk_jfa_sub(hipStream_t st, long nb, int C, int D, long r0, const long *owner, const double *N, double *F, const double *means,
+                const double *TW, const double *Dm, const double *Z);
+int tvk_jfa_sub_sessions(hipStream_t st, long s0, long ns, long h0, long h1, int C, int D, const long *sess_begin, const double *Nh,
+                         const double *G, double *FX);
+int tvk_jfa_z(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, const double *Dm, double tau, double *Z);
+int tvk_jfa_z_and_d(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, double *Dm, double *Z);

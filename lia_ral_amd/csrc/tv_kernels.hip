@@ -759,6 +759,109 @@ int tvk_add_identity(hipStream_t st, int n, double *A)
     return (int)hipGetLastError();
 }
 
+// ---- JFA (AccumulateJFAStat.cpp): statistics minus the model terms, diagonal factor z / D ---------------------------
+// Wg[r][:] = W[owner ? owner[r0 + r] : r0 + r][:]
+__global__ void k_gather_rows(int nb, int R, long r0, const long *__restrict__ owner, const double *__restrict__ W, double *__restrict__ Wg)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)nb * R; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / R, j = e - r * R;
+        const long o = owner ? owner[r0 + r] : r0 + r;
+        Wg[e] = W[o * R + j];
+    }
+}
+// F[r,c,:] -= N[r,c] (means[c,:] + TW[r - r0][c,:] + Dm[c,:] Z[owner(r)][c,:])   (every term optional)
+__global__ void k_jfa_sub(long nb, int C, int D, long r0, const long *__restrict__ owner, const double *__restrict__ N,
+                          double *__restrict__ F, const double *__restrict__ means, const double *__restrict__ TW,
+                          const double *__restrict__ Dm, const double *__restrict__ Z)
+{
+    const size_t SV = (size_t)C * D, tot = (size_t)nb * SV;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t rl = e / SV, k = e - rl * SV, r = r0 + rl;
+        double v = means ? means[k] : 0.0;
+        if (TW) v += TW[e];
+        if (Dm) v = __builtin_fma(Dm[k], Z[(size_t)(owner ? owner[r] : (long)r) * SV + k], v);
+        F[r * SV + k] -= N[r * C + k / D] * v;
+    }
+}
+// F_X[s,c,:] -= sum over the sessions h of speaker s inside [h0, h1) of N_h[h,c] G[h - h0][c,:]     (G = X U)
+__global__ void k_jfa_sub_sessions(long s0, long ns, long h0, long h1, int C, int D, const long *__restrict__ sess_begin,
+                                   const double *__restrict__ Nh, const double *__restrict__ G, double *__restrict__ FX)
+{
+    const size_t SV = (size_t)C * D, tot = (size_t)ns * SV;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t sl = e / SV, k = e - sl * SV, s = s0 + sl;
+        long a = sess_begin[s], b = sess_begin[s + 1];
+        a = a > h0 ? a : h0;
+        b = b < h1 ? b : h1;
+        double acc = 0.0;
+        for (long h = a; h < b; ++h) acc = __builtin_fma(Nh[h * C + k / D], G[(size_t)(h - h0) * SV + k], acc);
+        if (b > a) FX[s * SV + k] -= acc;
+    }
+}
+// tau < 0: z = F iv D / (1 + N iv D^2) (estimateZ, :3550-3573);  tau >= 0: z = tau / (tau + N) D iv F (estimateZMAP, :3576-3594)
+__global__ void k_jfa_z(long nspk, int C, int D, const double *__restrict__ N, const double *__restrict__ F,
+                        const double *__restrict__ iv, const double *__restrict__ Dm, double tau, double *__restrict__ Z)
+{
+    const size_t SV = (size_t)C * D, tot = (size_t)nspk * SV;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = e / SV, k = e - s * SV;
+        const double n = N[s * C + k / D], d = Dm[k], v = iv[k];
+        Z[e] = tau < 0.0 ? F[e] * v * d / (1.0 + n * v * d * d) : (tau / (tau + n)) * d * v * F[e];
+    }
+}
+// estimateZandD (:3480-3516): z as above, D[k] = sum_s z F / sum_s (1 / L + z^2) N; one thread per supervector entry,
+// speakers in order (deterministic)
+__global__ void k_jfa_z_and_d(long nspk, int C, int D, const double *__restrict__ N, const double *__restrict__ F,
+                              const double *__restrict__ iv, double *__restrict__ Dm, double *__restrict__ Z)
+{
+    const size_t SV = (size_t)C * D;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= SV) return;
+    const double d = Dm[k], v = iv[k];
+    double a1 = 0.0, a2 = 0.0;
+    for (long s = 0; s < nspk; ++s) {
+        const double n = N[s * C + k / D], f = F[s * SV + k];
+        const double L = 1.0 + n * v * d * d;
+        const double z = f * v * d / L;
+        Z[s * SV + k] = z;
+        a1 += (1.0 / L + z * z) * n;
+        a2 += z * f;
+    }
+    Dm[k] = a2 / a1;
+}
+int tvk_gather_rows(hipStream_t st, int nb, int R, long r0, const long *owner, const double *W, double *Wg)
+{
+    if (nb <= 0) return 0;
+    k_gather_rows<<<ew_blocks((long)nb * R), 256, 0, st>>>(nb, R, r0, owner, W, Wg);
+    return (int)hipGetLastError();
+}
+int tvk_jfa_sub(hipStream_t st, long nb, int C, int D, long r0, const long *owner, const double *N, double *F, const double *means,
+                const double *TW, const double *Dm, const double *Z)
+{
+    if (nb <= 0) return 0;
+    k_jfa_sub<<<ew_blocks(nb * C * D), 256, 0, st>>>(nb, C, D, r0, owner, N, F, means, TW, Dm, Z);
+    return (int)hipGetLastError();
+}
+int tvk_jfa_sub_sessions(hipStream_t st, long s0, long ns, long h0, long h1, int C, int D, const long *sess_begin, const double *Nh,
+                         const double *G, double *FX)
+{
+    if (ns <= 0) return 0;
+    k_jfa_sub_sessions<<<ew_blocks(ns * C * D), 256, 0, st>>>(s0, ns, h0, h1, C, D, sess_begin, Nh, G, FX);
+    return (int)hipGetLastError();
+}
+int tvk_jfa_z(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, const double *Dm, double tau, double *Z)
+{
+    if (nspk <= 0) return 0;
+    k_jfa_z<<<ew_blocks(nspk * C * D), 256, 0, st>>>(nspk, C, D, N, F, iv, Dm, tau, Z);
+    return (int)hipGetLastError();
+}
+int tvk_jfa_z_and_d(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, double *Dm, double *Z)
+{
+    const long SV = (long)C * D;
+    k_jfa_z_and_d<<<(unsigned)((SV + 255) / 256), 256, 0, st>>>(nspk, C, D, N, F, iv, Dm, Z);
+    return (int)hipGetLastError();
+}
+
 int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means)
 {
     if (U <= 0) return 0;

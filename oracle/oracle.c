@@ -1247,3 +1247,125 @@ int orc_score_plda(int rf, long M, long S, const double *models, const long *nse
     free(K1); free(KL); free(KL1); free(tmp); free(v); free(s1);
     return rc;
 }
+
+/* ---- JFA: LIA_SpkTools/src/AccumulateJFAStat.cpp -------------------------------------------------------------------------
+ * M_{s,h} = m + V y_s + U x_h + D z_s.  N [nspk x C] / F_X [nspk x SV] per speaker, N_h / F_X_h per session. */
+
+/* estimateAndInverseLUnThreaded_EV (:1970-1996) + estimateYandVUnThreaded (:2467-2511) -- the same two loops serve the
+ * eigenchannel side (_EC :2137-2163, estimateXandU :3040-3083) with per-session statistics.  A is FULL [C x R x R]. */
+int orc_jfa_estimate_y_and_v(long nspk, int C, int D, int R, const double *N, const double *F, const double *V, const double *invvar,
+                             const double *VEVT /* C x R x R */, double *Y, double *A, double *Cmx)
+{
+    const size_t SV = (size_t)C * D;
+    double *L = (double *)malloc(sizeof(double) * R * R), *invl = (double *)malloc(sizeof(double) * R * R);
+    double *aux = (double *)calloc(R, sizeof(double));
+    int rc = 0;
+    for (long spk = 0; spk < nspk && !rc; ++spk) {
+        for (int i = 0; i < R * R; ++i) L[i] = 0.0;                                     /* :1974-1975 */
+        for (int i = 0; i < R; ++i) L[i * R + i] = 1.0;
+        for (int dis = 0; dis < C; ++dis)                                             /* :1979-1986 */
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j <= i; ++j) L[i * R + j] += VEVT[(size_t)dis * R * R + i * R + j] * N[spk * C + dis];
+        for (int i = 0; i < R; ++i)                                                   /* :1988-1992 */
+            for (int j = i + 1; j < R; ++j) L[i * R + j] = L[j * R + i];
+        if (orc_invert(R, L, invl)) { rc = 1; break; }                                /* :1995 */
+        for (int i = 0; i < R; ++i) {                                                 /* :2478-2482 */
+            aux[i] = 0.0;
+            for (size_t k = 0; k < SV; ++k) aux[i] += F[spk * SV + k] * invvar[k] * V[i * SV + k];
+        }
+        for (int i = 0; i < R; ++i) {                                                 /* :2484-2488 */
+            Y[spk * R + i] = 0.0;
+            for (int k = 0; k < R; ++k) Y[spk * R + i] += aux[k] * invl[i * R + k];
+        }
+        for (int i = 0; i < R; ++i)                                                   /* :2489-2493 */
+            for (int j = 0; j < R; ++j) invl[i * R + j] += Y[spk * R + i] * Y[spk * R + j];
+        for (int dis = 0; dis < C; ++dis)                                             /* :2494-2500 */
+            for (int i = 0; i < R * R; ++i) A[(size_t)dis * R * R + i] += invl[i] * N[spk * C + dis];
+        for (int i = 0; i < R; ++i)                                                   /* :2501-2505 */
+            for (size_t j = 0; j < SV; ++j) Cmx[i * SV + j] += Y[spk * R + i] * F[spk * SV + j];
+    }
+    free(L); free(invl); free(aux);
+    return rc;
+}
+
+/* F[r] -= N[r] (.) (means + W[o] T + Dm (.) Z[o]), o = owner ? owner[r] : r -- one loop for substractMplusDZ (:3805-3822,
+ * getMplusDZ :1860-1867), substractMplusVY (:3988-4005, getMplusVY :1880-1889), substractMplusVYplusDZ (:4400-4422: rows are
+ * sessions, owner = their speaker), substractMplusUX (:4336-4364).  NULL terms are absent. */
+void orc_jfa_subtract(long rows, int C, int D, const double *N, double *F, const long *owner, const double *means, int R,
+                      const double *Tm, const double *W, const double *Dm, const double *Z)
+{
+    const size_t SV = (size_t)C * D;
+    double *v = (double *)malloc(sizeof(double) * SV);
+    for (long r = 0; r < rows; ++r) {
+        const long o = owner ? owner[r] : r;
+        for (size_t k = 0; k < SV; ++k) v[k] = 0.0;
+        if (Tm)
+            for (size_t k = 0; k < SV; ++k)
+                for (int j = 0; j < R; ++j) v[k] += Tm[j * SV + k] * W[o * R + j];     /* :4046-4048 */
+        if (means)
+            for (size_t k = 0; k < SV; ++k) v[k] += means[k];                          /* :4050 */
+        if (Dm)
+            for (size_t k = 0; k < SV; ++k) v[k] += Dm[k] * Z[o * SV + k];             /* :3866 */
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < D; ++j) F[r * SV + i * D + j] -= v[i * D + j] * N[r * C + i]; /* :3817-3821 */
+    }
+    free(v);
+}
+
+/* substractUXUnThreaded (:4152-4172): every session's channel term leaves the statistics of its speaker */
+void orc_jfa_subtract_sessions(long nspk, const long *sess_begin, int C, int D, const double *N_h, double *F_X, int R, const double *Um,
+                               const double *X)
+{
+    const size_t SV = (size_t)C * D;
+    double *ux = (double *)malloc(sizeof(double) * SV);
+    for (long spk = 0; spk < nspk; ++spk)
+        for (long h = sess_begin[spk]; h < sess_begin[spk + 1]; ++h) {
+            for (size_t i = 0; i < SV; ++i) {                                          /* getUX :1803-1817 */
+                ux[i] = 0.0;
+                for (int j = 0; j < R; ++j) ux[i] += Um[j * SV + i] * X[h * R + j];
+            }
+            for (int k = 0; k < C; ++k)
+                for (int i = 0; i < D; ++i) F_X[spk * SV + k * D + i] -= N_h[h * C + k] * ux[i + k * D]; /* :4166-4168 */
+        }
+    free(ux);
+}
+
+/* estimateZ (:3550-3573, tau < 0) / estimateZMAP (:3576-3594, tau >= 0) */
+void orc_jfa_estimate_z(long nspk, int C, int D, const double *N, const double *F, const double *invvar, const double *Dm, double tau,
+                        double *Z)
+{
+    const size_t SV = (size_t)C * D;
+    for (long spk = 0; spk < nspk; ++spk)
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < D; ++j) {
+                const size_t k = (size_t)i * D + j;
+                if (tau < 0.0) {
+                    const double L = 1 + N[spk * C + i] * invvar[k] * Dm[k] * Dm[k];
+                    Z[spk * SV + k] = F[spk * SV + k] * invvar[k] * Dm[k] / L;
+                } else Z[spk * SV + k] = (tau / (tau + N[spk * C + i])) * Dm[k] * invvar[k] * F[spk * SV + k];
+            }
+}
+
+/* estimateZandD (:3480-3516) */
+void orc_jfa_estimate_z_and_d(long nspk, int C, int D, const double *N, const double *F, const double *invvar, double *Dm, double *Z)
+{
+    const size_t SV = (size_t)C * D;
+    double *aux1 = (double *)calloc(SV, sizeof(double)), *aux2 = (double *)calloc(SV, sizeof(double));
+    double *L = (double *)malloc(sizeof(double) * SV);
+    for (long spk = 0; spk < nspk; ++spk) {
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < D; ++j) {
+                const size_t k = (size_t)i * D + j;
+                L[k] = 1 + N[spk * C + i] * invvar[k] * Dm[k] * Dm[k];
+                Z[spk * SV + k] = F[spk * SV + k] * invvar[k] * Dm[k] / L[k];
+            }
+        for (int i = 0; i < C; ++i)
+            for (int j = 0; j < D; ++j) {
+                const size_t k = (size_t)i * D + j;
+                aux1[k] += (1 / L[k] + Z[spk * SV + k] * Z[spk * SV + k]) * N[spk * C + i];
+                aux2[k] += Z[spk * SV + k] * F[spk * SV + k];
+            }
+    }
+    for (size_t i = 0; i < SV; ++i) Dm[i] = aux2[i] / aux1[i];
+    free(aux1); free(aux2); free(L);
+}

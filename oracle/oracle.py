@@ -493,3 +493,58 @@ def plda_em_iteration(X, sps, F, G, Sigma, Delta):
                                       Delta.ctypes.data_as(c_dp))
     assert rc == 0
     return X, F, G, Sigma, Delta
+
+
+# ---- JFA (AccumulateJFAStat.cpp) -----------------------------------------------------------------
+def _opt(a):
+    if a is None:
+        return None, None
+    return _d(a)
+
+
+def jfa_estimate_y_and_v(N, F, V, invvar, VEVT):
+    """estimateAndInverseL_E{V,C} + estimate{YandV,XandU}; VEVT [C, R, R] full. Returns Y, A [C, R, R], Cmx [R, SV]."""
+    N, Np = _d(N); F, Fp = _d(F); V, Vp = _d(V); iv, ivp = _d(invvar); VEVT, vp = _d(VEVT)
+    U, C = N.shape; R, SV = V.shape; D = SV // C
+    Y = np.zeros((U, R)); A = np.zeros((C, R, R)); Cm = np.zeros((R, SV))
+    f = _lib().orc_jfa_estimate_y_and_v; f.restype = ct.c_int
+    rc = f(ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(R), Np, Fp, Vp, ivp, vp, Y.ctypes.data_as(c_dp), A.ctypes.data_as(c_dp),
+           Cm.ctypes.data_as(c_dp))
+    if rc:
+        raise RuntimeError("orc_jfa_estimate_y_and_v: singular L")
+    return Y, A, Cm
+
+
+def jfa_subtract(N, F, owner=None, means=None, T=None, W=None, Dm=None, Z=None):
+    N, Np = _d(N); F = np.array(F, np.float64, order="C", copy=True)
+    rows, C = N.shape; D = F.shape[1] // C
+    m, mp = _opt(means); T_, tp = _opt(T); W_, wp = _opt(W); D_, dp = _opt(Dm); Z_, zp = _opt(Z)
+    o = None if owner is None else np.ascontiguousarray(owner, np.int64)
+    _lib().orc_jfa_subtract(ct.c_long(rows), ct.c_int(C), ct.c_int(D), Np, F.ctypes.data_as(c_dp),
+                            None if o is None else o.ctypes.data_as(c_lp), mp, ct.c_int(0 if T_ is None else T_.shape[0]), tp, wp, dp, zp)
+    return F
+
+
+def jfa_subtract_sessions(sess_begin, N_h, F_X, U, X):
+    N_h, np_ = _d(N_h); F_X = np.array(F_X, np.float64, order="C", copy=True); U, up = _d(U); X, xp = _d(X)
+    sb = np.ascontiguousarray(sess_begin, np.int64)
+    C = N_h.shape[1]; D = F_X.shape[1] // C
+    _lib().orc_jfa_subtract_sessions(ct.c_long(len(sb) - 1), sb.ctypes.data_as(c_lp), ct.c_int(C), ct.c_int(D), np_,
+                                     F_X.ctypes.data_as(c_dp), ct.c_int(U.shape[0]), up, xp)
+    return F_X
+
+
+def jfa_estimate_z(N, F, invvar, Dm, tau=-1.0):
+    N, Np = _d(N); F, Fp = _d(F); iv, ivp = _d(invvar); Dm, dp = _d(Dm)
+    U, C = N.shape; D = F.shape[1] // C
+    Z = np.zeros_like(F)
+    _lib().orc_jfa_estimate_z(ct.c_long(U), ct.c_int(C), ct.c_int(D), Np, Fp, ivp, dp, ct.c_double(tau), Z.ctypes.data_as(c_dp))
+    return Z
+
+
+def jfa_estimate_z_and_d(N, F, invvar, Dm):
+    N, Np = _d(N); F, Fp = _d(F); iv, ivp = _d(invvar); Dn = np.array(Dm, np.float64, order="C", copy=True)
+    U, C = N.shape; D = F.shape[1] // C
+    Z = np.zeros_like(F)
+    _lib().orc_jfa_estimate_z_and_d(ct.c_long(U), ct.c_int(C), ct.c_int(D), Np, Fp, ivp, Dn.ctypes.data_as(c_dp), Z.ctypes.data_as(c_dp))
+    return Z, Dn

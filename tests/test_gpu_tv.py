@@ -261,3 +261,40 @@ def test_plda_em_iterations_match_oracle(ctx, dim, rf, rg, nspk):
         for got, want in zip((Xg, F, G, Sigma, Delta), ref):
             assert relerr(got, want) < 1e-8, it
         assert relerr(Xd.cpu().numpy(), ref[0]) < 1e-8 and relerr(Fd, ref[1]) < 1e-8 and relerr(Sd, ref[3]) < 1e-8
+
+
+@pytest.mark.parametrize("C,D,R,nspk", [(6, 5, 3, 7), (64, 60, 40, 30), (16, 12, 10, 400)])
+def test_jfa_steps_match_oracle(ctx, C, D, R, nspk):
+    """JFAAcc steps (AccumulateJFAStat.cpp): the subtract family, substractUX over the sessions of each speaker, estimateZ /
+    estimateZMAP / estimateZandD, and estimateAndInverseL_EV + estimateYandV through the TV E-step entry point."""
+    rng = np.random.default_rng(C + R)
+    SV = C * D
+    nses = rng.integers(1, 4, nspk); sb = np.concatenate([[0], np.cumsum(nses)]); nsess = int(sb[-1])
+    owner = np.repeat(np.arange(nspk), nses)
+    N = rng.uniform(0.5, 20, (nspk, C)); F = rng.normal(size=(nspk, SV))
+    Nh = rng.uniform(0.2, 8, (nsess, C)); Fh = rng.normal(size=(nsess, SV))
+    m = rng.normal(size=SV); V = rng.normal(size=(R, SV)) * 0.3; U = rng.normal(size=(R, SV)) * 0.2
+    Y = rng.normal(size=(nspk, R)); X = rng.normal(size=(nsess, R)); Dm = rng.uniform(0.1, 1, SV); Z = rng.normal(size=(nspk, SV))
+    iv = rng.uniform(0.5, 2, SV)
+    assert relerr(ctx.jfa_subtract(N, F.copy(), C, D, means=m, Dm=Dm, Z=Z), orc.jfa_subtract(N, F, None, m, None, None, Dm, Z)) < 1e-13
+    assert relerr(ctx.jfa_subtract(N, F.copy(), C, D, means=m, T=V, W=Y), orc.jfa_subtract(N, F, None, m, V, Y)) < 1e-12
+    assert relerr(ctx.jfa_subtract(Nh, Fh.copy(), C, D, owner=owner, means=m, T=V, W=Y, Dm=Dm, Z=Z),
+                  orc.jfa_subtract(Nh, Fh, owner, m, V, Y, Dm, Z)) < 1e-12
+    assert relerr(ctx.jfa_subtract(Nh, Fh.copy(), C, D, T=U, W=X), orc.jfa_subtract(Nh, Fh, None, None, U, X)) < 1e-12   # UX alone
+    assert relerr(ctx.jfa_subtract_sessions(sb, Nh, F.copy(), U, X, C, D), orc.jfa_subtract_sessions(sb, Nh, F, U, X)) < 1e-12
+    assert relerr(ctx.jfa_estimate_z(N, F, iv, Dm, C, D), orc.jfa_estimate_z(N, F, iv, Dm)) < 1e-13
+    assert relerr(ctx.jfa_estimate_z(N, F, iv, Dm, C, D, tau=14.0), orc.jfa_estimate_z(N, F, iv, Dm, 14.0)) < 1e-13
+    Dg = Dm.copy()
+    Zg = ctx.jfa_estimate_z_and_d(N, F, iv, Dg, C, D)
+    Zo, Do = orc.jfa_estimate_z_and_d(N, F, iv, Dm)
+    assert relerr(Zg, Zo) < 1e-13 and relerr(Dg, Do) < 1e-12
+    from lia_ral_amd import capi
+    with pytest.raises(capi.GmmivError):
+        ctx.jfa_subtract(Nh, Fh.copy(), C, D, owner=owner + 1, means=m, T=V, W=Y)          # owner out of range
+    # eigenvoice E-step: packed A of the TV entry point against the full matrices of the JFA loops
+    te_o = orc.tv_tett(V, iv, C, D)
+    Yo, Ao, Co = orc.jfa_estimate_y_and_v(N, F, V, iv, te_o)
+    te_g = ctx.tv_tett(V, iv, C, D)
+    g = ctx.tv_estimate_a_and_c(N, F, V, iv, te_g, C, D)
+    il = np.tril_indices(R)
+    assert relerr(g["W"], Yo) < 1e-9 and relerr(g["A"], Ao[:, il[0], il[1]]) < 1e-9 and relerr(g["Cmx"], Co) < 1e-9

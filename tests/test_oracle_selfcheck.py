@@ -205,3 +205,39 @@ def test_plda_em_iteration_against_numpy():
         ref = _plda_em_numpy(ref[0], sps, *ref[1:])
         for a, b in zip(state, ref):
             assert np.allclose(a, b, rtol=1e-8, atol=1e-10)
+
+
+def test_jfa_pieces_against_numpy():
+    """JFA restatements (AccumulateJFAStat.cpp) against plain numpy; estimateYandV is the TV E-step under another name."""
+    rng = np.random.default_rng(11)
+    C, D, R, nspk = 5, 4, 3, 6
+    SV = C * D
+    sb = np.array([0, 2, 3, 6, 7, 9, 12]); nsess = sb[-1]
+    owner = np.repeat(np.arange(nspk), np.diff(sb))
+    N = rng.uniform(0.5, 20, (nspk, C)); F = rng.normal(size=(nspk, SV))
+    Nh = rng.uniform(0.2, 8, (nsess, C)); Fh = rng.normal(size=(nsess, SV))
+    m = rng.normal(size=SV); V = rng.normal(size=(R, SV)) * 0.3; U = rng.normal(size=(R, SV)) * 0.2
+    Y = rng.normal(size=(nspk, R)); X = rng.normal(size=(nsess, R)); Dm = rng.uniform(0.1, 1, SV); Z = rng.normal(size=(nspk, SV))
+    iv = rng.uniform(0.5, 2, SV)
+    rep = lambda n: np.repeat(n, D, axis=1)
+    assert np.abs(orc.jfa_subtract(N, F, None, m, None, None, Dm, Z) - (F - rep(N) * (m + Dm * Z))).max() < 1e-12        # M + DZ
+    assert np.abs(orc.jfa_subtract(N, F, None, m, V, Y) - (F - rep(N) * (m + Y @ V))).max() < 1e-12                    # M + VY
+    ref = Fh - rep(Nh) * (m + Y[owner] @ V + Dm * Z[owner])
+    assert np.abs(orc.jfa_subtract(Nh, Fh, owner, m, V, Y, Dm, Z) - ref).max() < 1e-12                                 # M + VY + DZ per session
+    ref = F.copy()
+    for s in range(nspk):
+        for h in range(sb[s], sb[s + 1]):
+            ref[s] -= np.repeat(Nh[h], D) * (X[h] @ U)
+    assert np.abs(orc.jfa_subtract_sessions(sb, Nh, F, U, X) - ref).max() < 1e-12                                      # UX
+    L = 1 + rep(N) * iv * Dm * Dm; z = F * iv * Dm / L
+    Zo, Dn = orc.jfa_estimate_z_and_d(N, F, iv, Dm)
+    assert np.abs(Zo - z).max() < 1e-13 and np.abs(Dn - (z * F).sum(0) / ((1 / L + z * z) * rep(N)).sum(0)).max() < 1e-12
+    assert np.abs(orc.jfa_estimate_z(N, F, iv, Dm) - z).max() < 1e-13
+    assert np.abs(orc.jfa_estimate_z(N, F, iv, Dm, 3.0) - (3.0 / (3.0 + rep(N))) * Dm * iv * F).max() < 1e-13
+    # estimateAndInverseL_EV + estimateYandV == TVAcc::estimateAandC
+    te = orc.tv_tett(V, iv, C, D)
+    Yj, Aj, Cj = orc.jfa_estimate_y_and_v(N, F, V, iv, te)
+    o = orc.tv_estimate_a_and_c(N, F, V, iv, te)
+    assert np.abs(Yj - o["W"]).max() < 1e-10 * np.abs(Yj).max()
+    assert np.abs(Aj.reshape(C, R * R) - o["A"]).max() < 1e-10 * np.abs(Aj).max()
+    assert np.abs(Cj - o["Cmx"]).max() < 1e-10 * np.abs(Cj).max()
