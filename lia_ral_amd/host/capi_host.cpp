@@ -303,6 +303,61 @@ int liagpu_tv_train(int device, long U, int C, int D, const double *w, const dou
     })
 }
 
+// EigenVoice / EigenChannel / EstimateDMatrix on given statistics (task 0 / 1 / 2; EigenVoice.cpp:71-160,
+// EigenChannel.cpp:71-165, EstimateDMatrix.cpp:103-210 minus the file I/O).  V, U, Dm: initial matrices in, trained out
+// (only the task's own matrix changes); Y, X, Z: the factors of the last estimate (outputs, may be NULL).
+int liagpu_jfa_train(int device, int task, long nspk, const long *sessPerSpk, int C, int D, const double *w, const double *mean,
+                     const double *cov, int rankEV, int rankEC, const double *N, const double *N_h, const double *F_X, const double *F_X_h,
+                     double *V, double *U, double *Dm, const double *Z0, int nbIt, int orthoV, double *Y, double *X, double *Z)
+{
+    GUARD({
+        GpuServer srv(device);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        std::vector<unsigned long> sps(sessPerSpk, sessPerSpk + nspk);
+        JFAAcc jfa(srv, ubm, (unsigned long)rankEV, (unsigned long)rankEC, sps);
+        const size_t SV = (size_t)C * D, nsess = jfa.getNSessions();
+        jfa.setStats(std::vector<double>(N, N + (size_t)nspk * C), std::vector<double>(N_h, N_h + nsess * C),
+                     std::vector<double>(F_X, F_X + (size_t)nspk * SV), std::vector<double>(F_X_h, F_X_h + nsess * SV));
+        jfa.loadEV(std::vector<double>(V, V + (size_t)rankEV * SV));
+        jfa.loadEC(std::vector<double>(U, U + (size_t)rankEC * SV));
+        jfa.loadD(std::vector<double>(Dm, Dm + SV));
+        if (Z0) jfa.getZ().assign(Z0, Z0 + (size_t)nspk * SV);
+        if (task == 0) eigenVoice(jfa, (unsigned long)nbIt, orthoV != 0);
+        else if (task == 1) eigenChannel(jfa, (unsigned long)nbIt);
+        else if (task == 2) estimateDMatrix(jfa, (unsigned long)nbIt);
+        else throw Exception("liagpu_jfa_train: task must be 0 (EigenVoice), 1 (EigenChannel) or 2 (EstimateDMatrix)");
+        memcpy(V, jfa.getV().data(), jfa.getV().size() * sizeof(double));
+        memcpy(U, jfa.getU().data(), jfa.getU().size() * sizeof(double));
+        memcpy(Dm, jfa.getD().data(), SV * sizeof(double));
+        if (Y) memcpy(Y, jfa.getY().data(), jfa.getY().size() * sizeof(double));
+        if (X) memcpy(X, jfa.getX().data(), jfa.getX().size() * sizeof(double));
+        if (Z) memcpy(Z, jfa.getZ().data(), jfa.getZ().size() * sizeof(double));
+    })
+}
+
+// JFA statistics from frames (JFAAcc::computeAndAccumulateJFAStat, :515-577): sessions = utterance ranges, grouped by speaker
+int liagpu_jfa_stats(int device, const float *x, long T, int D, const long *sess_begin, long nspk, const long *sessPerSpk, int C,
+                     const double *w, const double *mean, const double *cov, double *N, double *N_h, double *F_X, double *F_X_h)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        std::vector<unsigned long> sps(sessPerSpk, sessPerSpk + nspk);
+        JFAAcc jfa(srv, ubm, 1, 1, sps);
+        std::vector<SegCluster> segs(jfa.getNSessions());
+        for (unsigned long h = 0; h < jfa.getNSessions(); ++h) {
+            Seg s; s.begin = (unsigned long)sess_begin[h]; s.length = (unsigned long)(sess_begin[h + 1] - sess_begin[h]); s.source = 0;
+            segs[h].push_back(s);
+        }
+        jfa.computeAndAccumulateJFAStat(fs, segs);
+        memcpy(N, jfa.getN().data(), jfa.getN().size() * sizeof(double));
+        memcpy(N_h, jfa.getN_h().data(), jfa.getN_h().size() * sizeof(double));
+        memcpy(F_X, jfa.getF_X().data(), jfa.getF_X().size() * sizeof(double));
+        memcpy(F_X_h, jfa.getF_X_h().data(), jfa.getF_X_h().size() * sizeof(double));
+    })
+}
+
 // ComputeTest from FILES for one ndx line (test file + client list): RAW models, .prm features with
 // featureServerMask, .lbl selection.  Writes the NIST-style result lines (segmental mode) into out_text
 // and the LLRs into llr_out[nseg x nClients].  ComputeTest.cpp:129-215 + the format readers of io.h.

@@ -585,6 +585,250 @@ void TVAcc::estimateWEigenDecomposition(const std::vector<double> &D, const std:
                                          _statF.data(), _T.data(), D.data(), Q.data(), _W.data()));
 }
 
+
+// ---- JFAAcc ----------------------------------------------------------------------------------------
+JFAAcc::JFAAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankEV, unsigned long rankEC,
+               const std::vector<unsigned long> &sessionsPerSpeaker)
+    : _srv(srv), _ubm(ubm), _dubm(srv, ubm), _rankEV(rankEV), _rankEC(rankEC), _n_speakers(sessionsPerSpeaker.size()), _n_sessions(0),
+      _n_distrib(ubm.getDistribCount()), _vectSize(ubm.getVectSize()), _svSize(ubm.getDistribCount() * ubm.getVectSize())
+{
+    if (!rankEV || !rankEC) throw Exception("JFAAcc: eigenVoiceNumber and eigenChannelNumber must be positive");
+    _sess_begin.assign(_n_speakers + 1, 0);
+    for (unsigned long s = 0; s < _n_speakers; ++s) {
+        if (!sessionsPerSpeaker[s]) throw Exception("JFAAcc: a speaker without session");
+        _sess_begin[s + 1] = _sess_begin[s] + (int64_t)sessionsPerSpeaker[s];
+        for (unsigned long k = 0; k < sessionsPerSpeaker[s]; ++k) _owner.push_back((int64_t)s);
+    }
+    _n_sessions = (unsigned long)_sess_begin[_n_speakers];
+    _ubm_means = _ubm.means();
+    _ubm_invvar = _ubm.covInvs();
+    _matN.assign(_n_speakers * _n_distrib, 0.0);
+    _N_h.assign(_n_sessions * _n_distrib, 0.0);
+    _F_X.assign(_n_speakers * _svSize, 0.0);
+    _F_X_h.assign(_n_sessions * _svSize, 0.0);
+    _V.assign(_rankEV * _svSize, 0.0);
+    _matU.assign(_rankEC * _svSize, 0.0);
+    _D.assign(_svSize, 0.0);
+    _Y.assign(_n_speakers * _rankEV, 0.0);
+    _matX.assign(_n_sessions * _rankEC, 0.0);
+    _Z.assign(_n_speakers * _svSize, 0.0);
+    _vEvT.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankEV), 0.0);
+    _uEuT.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankEC), 0.0);
+    resetTmpAcc();
+}
+void JFAAcc::resetTmpAcc()
+{
+    _Aev.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankEV), 0.0);
+    _Cev.assign(_rankEV * _svSize, 0.0);
+    _Aec.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankEC), 0.0);
+    _Cec.assign(_rankEC * _svSize, 0.0);
+}
+void JFAAcc::computeAndAccumulateJFAStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerSession)
+{
+    if (segsPerSession.size() != _n_sessions) throw Exception("computeAndAccumulateJFAStat: one SegCluster per session expected");
+    SegCluster all;
+    std::vector<int64_t> begin(_n_sessions + 1, 0);
+    for (unsigned long h = 0; h < _n_sessions; ++h) {
+        for (const Seg &s : segsPerSession[h]) all.push_back(s);
+        begin[h + 1] = begin[h] + (int64_t)totalFrame(segsPerSession[h]);
+    }
+    unsigned long n = 0;
+    const float *x = fs.select(all, n);
+    // the frame loop (:544-575) runs once, per session, on the device; a speaker's rows are the sums of its sessions' rows
+    _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), begin.data(),
+                              (int64_t)_n_sessions, _N_h.data(), _F_X_h.data()));
+    std::fill(_matN.begin(), _matN.end(), 0.0);
+    std::fill(_F_X.begin(), _F_X.end(), 0.0);
+    for (unsigned long h = 0; h < _n_sessions; ++h) {
+        const unsigned long s = (unsigned long)_owner[h];
+        for (unsigned long k = 0; k < _n_distrib; ++k) _matN[s * _n_distrib + k] += _N_h[h * _n_distrib + k];
+        for (unsigned long k = 0; k < _svSize; ++k) _F_X[s * _svSize + k] += _F_X_h[h * _svSize + k];
+    }
+}
+void JFAAcc::setStats(const std::vector<double> &N, const std::vector<double> &N_h, const std::vector<double> &F_X,
+                      const std::vector<double> &F_X_h)
+{
+    if (N.size() != _matN.size() || N_h.size() != _N_h.size() || F_X.size() != _F_X.size() || F_X_h.size() != _F_X_h.size())
+        throw Exception("JFAAcc::setStats: dimension mismatch");
+    _matN = N; _N_h = N_h; _F_X = F_X; _F_X_h = F_X_h;
+}
+void JFAAcc::storeAccs() { _cF_X = _F_X; _cF_X_h = _F_X_h; _cN_h = _N_h; _cN = _matN; }
+void JFAAcc::restoreAccs() { _matN = _cN; _N_h = _cN_h; _F_X = _cF_X; _F_X_h = _cF_X_h; }
+void JFAAcc::loadEV(const std::vector<double> &V)
+{
+    if (V.size() != _V.size()) throw Exception("Incorrect dimension of EigenVoice Matrix");
+    _V = V;
+}
+void JFAAcc::loadEC(const std::vector<double> &U)
+{
+    if (U.size() != _matU.size()) throw Exception("Incorrect dimension of EigenChannel Matrix");
+    _matU = U;
+}
+void JFAAcc::loadD(const std::vector<double> &D)
+{
+    if (D.size() != _D.size()) throw Exception("Incorrect dimension of D Matrix");
+    _D = D;
+}
+void JFAAcc::initD(double regulationFactor)
+{
+    for (unsigned long i = 0; i < _svSize; ++i) _D[i] = sqrt(1.0 / (_ubm_invvar[i] * regulationFactor));
+}
+void JFAAcc::estimateVEVT()
+{
+    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEV, _V.data(), _ubm_invvar.data(), _vEvT.data()));
+}
+void JFAAcc::estimateUEUT()
+{
+    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEC, _matU.data(), _ubm_invvar.data(), _uEuT.data()));
+}
+void JFAAcc::estimateYandV()
+{
+    std::vector<double> Rm(_rankEV * _rankEV, 0.0), r(_rankEV, 0.0), mw(_rankEV, 0.0); // minimum-divergence sums: unused by JFA
+    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankEV, _matN.data(),
+                                         _F_X.data(), _V.data(), _ubm_invvar.data(), _vEvT.data(), _Y.data(), _Aev.data(), _Cev.data(),
+                                         Rm.data(), r.data(), mw.data()));
+}
+void JFAAcc::estimateY()
+{
+    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankEV, _matN.data(), _F_X.data(),
+                                   _V.data(), _ubm_invvar.data(), _vEvT.data(), _Y.data()));
+}
+void JFAAcc::estimateXandU()
+{
+    std::vector<double> Rm(_rankEC * _rankEC, 0.0), r(_rankEC, 0.0), mw(_rankEC, 0.0);
+    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, (int)_rankEC, _N_h.data(),
+                                         _F_X_h.data(), _matU.data(), _ubm_invvar.data(), _uEuT.data(), _matX.data(), _Aec.data(),
+                                         _Cec.data(), Rm.data(), r.data(), mw.data()));
+}
+void JFAAcc::estimateX()
+{
+    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, (int)_rankEC, _N_h.data(), _F_X_h.data(),
+                                   _matU.data(), _ubm_invvar.data(), _uEuT.data(), _matX.data()));
+}
+void JFAAcc::estimateZandD()
+{
+    _srv.check(gmmiv_jfa_estimate_z_and_d(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(),
+                                          _ubm_invvar.data(), _D.data(), _Z.data()));
+}
+void JFAAcc::estimateZ()
+{
+    _srv.check(gmmiv_jfa_estimate_z(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(),
+                                    _ubm_invvar.data(), _D.data(), -1.0, _Z.data()));
+}
+void JFAAcc::estimateZMAP(double tau)
+{
+    if (tau < 0.0) throw Exception("estimateZMAP: negative relevance factor");
+    _srv.check(gmmiv_jfa_estimate_z(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(),
+                                    _ubm_invvar.data(), _D.data(), tau, _Z.data()));
+}
+void JFAAcc::updateVestimate()
+{
+    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEV, _Aev.data(), _Cev.data(), _V.data()));
+    _Cev = _V; // the reference leaves the new matrix in _Cev too (:3617-3618)
+}
+void JFAAcc::updateUestimate()
+{
+    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEC, _Aec.data(), _Cec.data(), _matU.data()));
+    _Cec = _matU;
+}
+void JFAAcc::substractMplusDZ()
+{
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(), nullptr,
+                                  (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, _D.data(), _Z.data()));
+}
+void JFAAcc::substractMplusVY()
+{
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(), nullptr,
+                                  (int64_t)_n_speakers, _ubm_means.data(), (int)_rankEV, _V.data(), _Y.data(), nullptr, nullptr));
+}
+void JFAAcc::substractUX()
+{
+    _srv.check(gmmiv_jfa_subtract_sessions(_srv.ctx(), (int64_t)_n_speakers, _sess_begin.data(), (int)_n_distrib, (int)_vectSize, _N_h.data(),
+                                           _F_X.data(), (int)_rankEC, _matU.data(), _matX.data()));
+}
+void JFAAcc::substractMplusVYplusDZ()
+{
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.data(), _F_X_h.data(), _owner.data(),
+                                  (int64_t)_n_speakers, _ubm_means.data(), (int)_rankEV, _V.data(), _Y.data(), _D.data(), _Z.data()));
+}
+void JFAAcc::substractMplusUX()
+{
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.data(), _F_X_h.data(), nullptr,
+                                  (int64_t)_n_sessions, _ubm_means.data(), (int)_rankEC, _matU.data(), _matX.data(), nullptr, nullptr));
+}
+void JFAAcc::orthonormalizeV()
+{
+    _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankEV, (int64_t)_svSize, _V.data()));
+}
+void JFAAcc::getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk)
+{
+    if (spk >= _n_speakers) throw Exception("getMplusVYplusDZ: speaker index out of range");
+    // Sp = 0 - (-1) (m + V y + D z): the subtraction with unit negative occupations builds the supervector
+    std::vector<double> n1(_n_distrib, -1.0);
+    Sp.assign(_svSize, 0.0);
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), 1, (int)_n_distrib, (int)_vectSize, n1.data(), Sp.data(), nullptr, 1, _ubm_means.data(), (int)_rankEV,
+                                  _V.data(), _Y.data() + spk * _rankEV, _D.data(), _Z.data() + spk * _svSize));
+}
+
+void eigenVoice(JFAAcc &jfaAcc, unsigned long nbIt, bool orthonormalizeV)
+{
+    jfaAcc.storeAccs();
+    for (unsigned long it = 0; it < nbIt; ++it) {
+        jfaAcc.estimateVEVT();
+        jfaAcc.estimateAndInverseL_EV();
+        jfaAcc.substractMplusDZ();
+        jfaAcc.substractUX();
+        jfaAcc.estimateYandV();
+        jfaAcc.updateVestimate();
+        if (orthonormalizeV) jfaAcc.orthonormalizeV();
+        jfaAcc.resetTmpAcc();
+        jfaAcc.restoreAccs();
+    }
+}
+void eigenChannel(JFAAcc &jfaAcc, unsigned long nbIt)
+{
+    jfaAcc.storeAccs();                 // speaker factors first (EigenChannel.cpp:120-128)
+    jfaAcc.estimateVEVT();
+    jfaAcc.estimateAndInverseL_EV();
+    jfaAcc.substractMplusDZ();
+    jfaAcc.substractUX();
+    jfaAcc.estimateY();
+    jfaAcc.restoreAccs();
+    jfaAcc.storeAccs();
+    for (unsigned long it = 0; it < nbIt; ++it) {
+        jfaAcc.estimateUEUT();
+        jfaAcc.estimateAndInverseL_EC();
+        jfaAcc.substractMplusVYplusDZ();
+        jfaAcc.estimateXandU();
+        jfaAcc.updateUestimate();
+        jfaAcc.resetTmpAcc();
+        jfaAcc.restoreAccs();
+    }
+}
+void estimateDMatrix(JFAAcc &jfaAcc, unsigned long nbIt)
+{
+    jfaAcc.storeAccs();                 // y for every speaker (EstimateDMatrix.cpp:143-151)
+    jfaAcc.estimateVEVT();
+    jfaAcc.estimateAndInverseL_EV();
+    jfaAcc.substractMplusDZ();
+    jfaAcc.substractUX();
+    jfaAcc.estimateY();
+    jfaAcc.restoreAccs();
+    jfaAcc.storeAccs();                 // x for every session (:163-170)
+    jfaAcc.estimateUEUT();
+    jfaAcc.estimateAndInverseL_EC();
+    jfaAcc.substractMplusVYplusDZ();
+    jfaAcc.estimateX();
+    jfaAcc.restoreAccs();
+    jfaAcc.storeAccs();
+    for (unsigned long it = 0; it < nbIt; ++it) {   // :178-190
+        jfaAcc.substractMplusVY();
+        jfaAcc.substractUX();
+        jfaAcc.estimateZandD();
+        jfaAcc.resetTmpAcc();
+        jfaAcc.restoreAccs();
+    }
+}
 // ---- PldaDev ---------------------------------------------------------------------------------------
 PldaDev::PldaDev(GpuServer &srv, unsigned long vectSize, const std::vector<double> &data, const std::vector<unsigned long> &sessionPerSpeaker)
     : _srv(srv), _vectSize(vectSize), _n_sessions(0), _data(data), _session_per_speaker(sessionPerSpeaker)

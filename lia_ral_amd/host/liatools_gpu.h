@@ -243,6 +243,71 @@ class TVAcc {
     std::vector<double> _ubm_means, _ubm_invvar, _statN, _statF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
 };
 
+// ---- AccumulateJFAStat.h: JFAAcc, M_{s,h} = m + V y_s + U x_h + D z_s (AccumulateJFAStat.cpp) ---------------------------
+// Statistics rows: _matN / _F_X per speaker (ndx line), _N_h / _F_X_h per session (ndx element); sessions are grouped by
+// speaker in ndx order.  L matrices are never stored: estimateAndInverseL_E{V,C} only mark the step, the build + inverse
+// happens inside the estimate* call that consumes it, on the device (one workgroup per system).
+class JFAAcc {
+  public:
+    JFAAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankEV, unsigned long rankEC,
+           const std::vector<unsigned long> &sessionsPerSpeaker);                          // _init, :168-300
+    void computeAndAccumulateJFAStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerSession); // :515-577
+    void setStats(const std::vector<double> &N, const std::vector<double> &N_h, const std::vector<double> &F_X,
+                  const std::vector<double> &F_X_h);                                       // loadN / loadN_h / loadF_X / loadF_X_h, :1025-1068
+    void storeAccs();                  // :3777-3784
+    void restoreAccs();                // :3786-3793
+    void resetTmpAcc();                // :863-897
+    void loadEV(const std::vector<double> &V);      // :949-968
+    void loadEC(const std::vector<double> &U);      // :983-995
+    void loadD(const std::vector<double> &D);       // :1016-1023
+    void initD(double regulationFactor);            // initDType "MAP", :1214-1218
+    void estimateVEVT();               // :1266-1352
+    void estimateUEUT();               // :1425-1508
+    void estimateAndInverseL_EV() {}   // :1970-1996 (fused into estimateYandV / estimateY)
+    void estimateAndInverseL_EC() {}   // :2137-2163 (fused into estimateXandU / estimateX)
+    void estimateYandV();              // :2467-2511
+    void estimateY();                  // :2867-2957
+    void estimateXandU();              // :3040-3083
+    void estimateX();                  // :3262-3351
+    void estimateZandD();              // :3480-3516
+    void estimateZ();                  // :3550-3573
+    void estimateZMAP(double tau);     // :3576-3594
+    void updateVestimate();            // :3597-3619
+    void updateUestimate();            // :3622-3644
+    void substractMplusDZ();           // :3805-3822   _F_X   -= N   (m + D z)
+    void substractMplusVY();           // :3988-4005   _F_X   -= N   (m + V y)
+    void substractUX();                // :4152-4172   _F_X   -= sum_h N_h (U x_h)
+    void substractMplusVYplusDZ();     // :4400-4422   _F_X_h -= N_h (m + V y + D z) of the session's speaker
+    void substractMplusUX();           // :4336-4364   _F_X_h -= N_h (m + U x_h)
+    void orthonormalizeV();            // :4700-4777
+    void getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk); // :1926-1935
+    std::vector<double> &getV() { return _V; }
+    std::vector<double> &getU() { return _matU; }
+    std::vector<double> &getD() { return _D; }
+    std::vector<double> &getY() { return _Y; }
+    std::vector<double> &getX() { return _matX; }
+    std::vector<double> &getZ() { return _Z; }
+    std::vector<double> &getN() { return _matN; }
+    std::vector<double> &getN_h() { return _N_h; }
+    std::vector<double> &getF_X() { return _F_X; }
+    std::vector<double> &getF_X_h() { return _F_X_h; }
+    unsigned long getNSpeakers() const { return _n_speakers; }
+    unsigned long getNSessions() const { return _n_sessions; }
+
+  private:
+    GpuServer &_srv;
+    MixtureGD _ubm;
+    DeviceMixture _dubm;
+    unsigned long _rankEV, _rankEC, _n_speakers, _n_sessions, _n_distrib, _vectSize, _svSize;
+    std::vector<int64_t> _sess_begin, _owner;
+    std::vector<double> _ubm_means, _ubm_invvar, _matN, _N_h, _F_X, _F_X_h, _cN, _cN_h, _cF_X, _cF_X_h;
+    std::vector<double> _V, _matU, _D, _Y, _matX, _Z, _vEvT, _uEuT, _Aev, _Cev, _Aec, _Cec;
+};
+// the three training tools around it (statistics and initial matrices already in the accumulator)
+void eigenVoice(JFAAcc &jfaAcc, unsigned long nbIt, bool orthonormalizeV);   // EigenVoice.cpp:114-147
+void eigenChannel(JFAAcc &jfaAcc, unsigned long nbIt);                        // EigenChannel.cpp:118-160
+void estimateDMatrix(JFAAcc &jfaAcc, unsigned long nbIt);                     // EstimateDMatrix.cpp:143-206
+
 // ---- PldaTools.h: PldaDev, the development set of the i-vector back-end (PldaTools.cpp:274-2005) -------------
 // _data [vectSize x n_sessions] (one i-vector per column), sessions grouped by speaker.
 class PldaDev {

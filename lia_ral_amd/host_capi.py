@@ -198,6 +198,34 @@ def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     return Tm, means
 
 
+def jfa_train(task, sess_per_spk, ubm, N, N_h, F_X, F_X_h, V, U, Dm, nb_it, Z0=None, ortho_v=False, device=0):
+    """EigenVoice (task 0) / EigenChannel (1) / EstimateDMatrix (2) on given statistics; returns dict(V, U, D, Y, X, Z)."""
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    sps = np.ascontiguousarray(sess_per_spk, np.int64)
+    nspk, nsess = len(sps), int(sps.sum())
+    N, N_h, F_X, F_X_h = [np.ascontiguousarray(a, np.float64) for a in (N, N_h, F_X, F_X_h)]
+    V = np.array(V, np.float64); U = np.array(U, np.float64); Dm = np.array(Dm, np.float64)
+    Y = np.zeros((nspk, V.shape[0])); X = np.zeros((nsess, U.shape[0])); Z = np.zeros((nspk, C * D))
+    z0 = None if Z0 is None else np.ascontiguousarray(Z0, np.float64)
+    _chk(lib.liagpu_jfa_train(device, task, ct.c_long(nspk), sps.ctypes.data_as(_lp), C, D, _d(w), _d(mean), _d(cov), V.shape[0], U.shape[0],
+                              _d(N), _d(N_h), _d(F_X), _d(F_X_h), _d(V), _d(U), _d(Dm), None if z0 is None else _d(z0), nb_it, int(ortho_v),
+                              _d(Y), _d(X), _d(Z)))
+    return dict(V=V, U=U, D=Dm, Y=Y, X=X, Z=Z)
+
+
+def jfa_stats(x, sess_begin, sess_per_spk, ubm, device=0):
+    """JFAAcc::computeAndAccumulateJFAStat on float32 frames: returns N, N_h, F_X, F_X_h."""
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    x = np.ascontiguousarray(x, np.float32)
+    sb = np.ascontiguousarray(sess_begin, np.int64); sps = np.ascontiguousarray(sess_per_spk, np.int64)
+    nspk, nsess = len(sps), len(sb) - 1
+    N = np.empty((nspk, C)); Nh = np.empty((nsess, C)); FX = np.empty((nspk, C * D)); FXh = np.empty((nsess, C * D))
+    _chk(lib.liagpu_jfa_stats(device, x.ctypes.data_as(ct.POINTER(ct.c_float)), ct.c_long(x.shape[0]), D, sb.ctypes.data_as(_lp), ct.c_long(nspk),
+                              sps.ctypes.data_as(_lp), C, _d(w), _d(mean), _d(cov), _d(N), _d(Nh), _d(FX), _d(FXh)))
+    return N, Nh, FX, FXh
+
 def compute_test_files(world_path, client_paths, client_names, prm_path, lbl_path, mask="", label="male", frame_length=0.01,
                        top_c=10, complete=True, min_llk=-200.0, max_llk=200.0, gender="M", test_name="test", threshold=0.0,
                        device=0):

@@ -355,3 +355,101 @@ def test_iv_test_end_to_end(scoring):
     # whitening ROW only through the later steps -- all of them are (every step is linear or quadratic in the rotated vectors)
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) < 1e-6 * max(1.0, np.max(np.abs(ref)))
+
+
+def _jfa_problem(seed=5, C=8, D=6, rv=4, ru=3, nspk=12):
+    rng = np.random.default_rng(seed)
+    w, mean, iv = make_gmm(C, D, seed=seed)
+    SV = C * D
+    sps = rng.integers(1, 4, nspk); sb = np.concatenate([[0], np.cumsum(sps)]); nsess = int(sb[-1])
+    owner = np.repeat(np.arange(nspk), sps)
+    # statistics of a generative JFA model so that the EM steps have something to find
+    V0 = rng.normal(size=(rv, SV)) * 0.5; U0 = rng.normal(size=(ru, SV)) * 0.3; D0 = rng.uniform(0.05, 0.3, SV)
+    y = rng.normal(size=(nspk, rv)); xh = rng.normal(size=(nsess, ru)); z = rng.normal(size=(nspk, SV))
+    Nh = rng.uniform(5, 60, (nsess, C))
+    Ms = mean.ravel() + y[owner] @ V0 + xh @ U0 + D0 * z[owner]
+    Fh = np.repeat(Nh, D, axis=1) * (Ms + rng.normal(size=(nsess, SV)) * 0.05)
+    N = np.zeros((nspk, C)); F = np.zeros((nspk, SV))
+    np.add.at(N, owner, Nh); np.add.at(F, owner, Fh)
+    return dict(w=w, mean=mean, iv=iv, sps=sps, sb=sb, owner=owner, N=N, Nh=Nh, F=F, Fh=Fh,
+                V=rng.normal(size=(rv, SV)) * 0.1, U=rng.normal(size=(ru, SV)) * 0.1, D=np.sqrt(1.0 / (iv.ravel() * 14.0)), C=C, Dm=D)
+
+
+def _orc_y(p, V, U, Dv, X, Z):
+    """the 'speaker factors first' block shared by EigenChannel.cpp:120-128 and EstimateDMatrix.cpp:143-151"""
+    m, iv = p["mean"].ravel(), p["iv"].ravel()
+    F = orc.jfa_subtract(p["N"], p["F"], None, m, None, None, Dv, Z)
+    F = orc.jfa_subtract_sessions(p["sb"], p["Nh"], F, U, X)
+    return orc.tv_estimate_w(p["N"], F, V, iv, orc.tv_tett(V, iv, p["C"], p["Dm"]))
+
+
+def test_jfa_training_tools_match_the_oracle_loops():
+    """EigenVoice / EigenChannel / EstimateDMatrix driver loops through liagpu::JFAAcc against the same loops assembled from
+    the oracle's restatement of the JFAAcc methods (tests the orchestration: store / restore, which statistics feed which step)."""
+    from lia_ral_amd import host_capi as hc
+    p = _jfa_problem()
+    C, D = p["C"], p["Dm"]; SV = C * D
+    m, iv = p["mean"].ravel(), p["iv"].ravel()
+    ubm = (p["w"], p["mean"], 1.0 / p["iv"])
+    nspk, nsess = len(p["sps"]), len(p["owner"])
+    rv, ru = p["V"].shape[0], p["U"].shape[0]
+    il_v = np.tril_indices(rv); il_u = np.tril_indices(ru)
+    full = lambda A, R: A.reshape(C, R * R)
+
+    # ---- EigenVoice, 3 iterations (X = 0, Z = 0 like a first pass of the recipe)
+    V = p["V"].copy(); X0 = np.zeros((nsess, ru)); Z0 = np.zeros((nspk, SV))
+    for _ in range(3):
+        te = orc.tv_tett(V, iv, C, D)
+        F = orc.jfa_subtract(p["N"], p["F"], None, m, None, None, p["D"], Z0)
+        F = orc.jfa_subtract_sessions(p["sb"], p["Nh"], F, p["U"], X0)
+        Yo, Ao, Co = orc.jfa_estimate_y_and_v(p["N"], F, V, iv, te)
+        V = orc.tv_update_t(full(Ao, rv), Co, C, D)
+    g = hc.jfa_train(0, p["sps"], ubm, p["N"], p["Nh"], p["F"], p["Fh"], p["V"], p["U"], p["D"], 3)
+    assert relerr(g["V"], V) < 1e-8 and relerr(g["Y"], Yo) < 1e-8
+    assert np.array_equal(g["U"], p["U"]) and np.array_equal(g["D"], p["D"])
+    V_tr = g["V"]
+
+    # ---- EigenChannel, 3 iterations on top of the trained V
+    Yo = _orc_y(p, V_tr, p["U"], p["D"], X0, Z0)
+    U = p["U"].copy()
+    for _ in range(3):
+        te = orc.tv_tett(U, iv, C, D)
+        Fh = orc.jfa_subtract(p["Nh"], p["Fh"], p["owner"], m, V_tr, Yo, p["D"], Z0)
+        Xo, Ao, Co = orc.jfa_estimate_y_and_v(p["Nh"], Fh, U, iv, te)
+        U = orc.tv_update_t(full(Ao, ru), Co, C, D)
+    g = hc.jfa_train(1, p["sps"], ubm, p["N"], p["Nh"], p["F"], p["Fh"], V_tr, p["U"], p["D"], 3)
+    assert relerr(g["U"], U) < 1e-8 and relerr(g["X"], Xo) < 1e-8 and relerr(g["Y"], Yo) < 1e-8
+    U_tr = g["U"]
+
+    # ---- EstimateDMatrix, 2 iterations on top of V and U
+    Yo = _orc_y(p, V_tr, U_tr, p["D"], X0, Z0)
+    Fh = orc.jfa_subtract(p["Nh"], p["Fh"], p["owner"], m, V_tr, Yo, p["D"], Z0)
+    Xo = orc.tv_estimate_w(p["Nh"], Fh, U_tr, iv, orc.tv_tett(U_tr, iv, C, D))
+    Dv = p["D"].copy()
+    for _ in range(2):
+        F = orc.jfa_subtract(p["N"], p["F"], None, m, V_tr, Yo)
+        F = orc.jfa_subtract_sessions(p["sb"], p["Nh"], F, U_tr, Xo)
+        Zo, Dv = orc.jfa_estimate_z_and_d(p["N"], F, iv, Dv)
+    g = hc.jfa_train(2, p["sps"], ubm, p["N"], p["Nh"], p["F"], p["Fh"], V_tr, U_tr, p["D"], 2)
+    assert relerr(g["D"], Dv) < 1e-8 and relerr(g["Z"], Zo) < 1e-8 and relerr(g["X"], Xo) < 1e-8
+    # the estimated D moved towards the generating one (sanity of the recipe, not of the arithmetic)
+    assert np.all(np.isfinite(g["D"])) and g["D"].min() > 0
+
+
+def test_jfa_statistics_from_frames():
+    """computeAndAccumulateJFAStat (AccumulateJFAStat.cpp:515-577): per-session Baum-Welch statistics on the device, speaker rows
+    = sums over the speaker's sessions."""
+    from lia_ral_amd import host_capi as hc
+    C, D = 16, 12
+    w, mean, iv = make_gmm(C, D, seed=4)
+    x = make_frames(w, mean, iv, 900, seed=8).astype(np.float32)
+    sps = np.array([2, 1, 3]); sb = np.array([0, 100, 250, 400, 520, 700, 900])
+    N, Nh, FX, FXh = hc.jfa_stats(x, sb, sps, (w, mean, 1.0 / iv))
+    g = orc.Gmm(w, mean, iv)
+    utt = np.repeat(np.arange(len(sb) - 1), np.diff(sb))
+    No, Fo = orc.tv_stats(g, x.astype(np.float64), utt, len(sb) - 1)
+    assert relerr(Nh, No) < 1e-9 and relerr(FXh, Fo) < 1e-9
+    own = np.repeat(np.arange(3), sps)
+    Ns = np.zeros((3, C)); Fs = np.zeros((3, C * D))
+    np.add.at(Ns, own, No); np.add.at(Fs, own, Fo)
+    assert relerr(N, Ns) < 1e-9 and relerr(FX, Fs) < 1e-9
