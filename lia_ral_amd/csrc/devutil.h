@@ -66,30 +66,6 @@ __device__ __forceinline__ double gexp_t(double x, const double *tab)
     return __builtin_ldexp(__builtin_fma(tj, p, tj), ki >> 5);
 }
 
-// exp(x) for x <= ~0 with a 64-entry table of 2^(j/64) (tab64[j], j < 64): |r| <= ln2/128, so the
-// degree-5 series is exact to 4e-17; ONE fma reduces the argument -- the representation error of
-// ln2/64 (<= 2^-60) times |k| = 92 |x| is below 3e-15 |x|/36 relative to exp(x), i.e. invisible in a
-// posterior that small.  15 VALU instructions.
-__device__ __forceinline__ void gexp_table64_init(double *tab, int tid)
-{
-    if (tid < 64) tab[tid] = exp2((double)tid * 0.015625);
-}
-__device__ __forceinline__ double gexp_t64(double x, const double *tab)
-{
-    x = fmax(x, -750.0);
-    const double k = __builtin_rint(x * 92.33248261689366);
-    const double r = __builtin_fma(k, -0.010830424696249145, x);
-    const int ki = (int)k;
-    const double tj = tab[ki & 63];
-    double p = 8.333333333333333e-03;               // 1/120
-    p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/24
-    p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/6
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = p * r;
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), ki >> 6);
-}
-
 // exp(x) * 2^-E with the binary exponent applied in ONE ldexp, so x may be far outside exp()'s range
 // (logits of -5000 against a running exponent E of -7200 are fine).  x >= -4e7 (int32 range of k).
 __device__ __forceinline__ double gexp_scaled(double x, int E, const double *tab)
@@ -112,49 +88,81 @@ __device__ __forceinline__ double gexp_scaled(double x, int E, const double *tab
     n = n < -2000 ? -2000 : n;
     return __builtin_ldexp(__builtin_fma(tj, p, tj), n);
 }
-// gexp_scaled with the 64-entry table (gexp_table64_init): |r| <= ln2/128, degree-5 series (4e-17), two-step
-// argument reduction kept because x is a raw logit (|x| up to 1e4 and more).  The binary exponent is ki >> 6.
+// Table-driven exp for the MFMA log-likelihood kernel: N = 2^GEXP_TAB_BITS entries 2^(j/N) in LDS (gexp_tab_init),
+// x = (k/N) ln2 + r, |r| <= ln2/(2N).  With 2048 entries (16 KB) the degree-3 series is exact to r^4/24 = 3.5e-17, two
+// fp64 operations fewer per exponential than 64 entries + degree 5 -- fp64 VALU work is what this kernel pays for next to
+// its MFMAs (it does not overlap with them, not even from the other wave of the SIMD).  The argument reduction is a
+// single fma (see gexp_tab_reduce; -DGEXP_TAB_TWO_STEP restores the Cody-Waite pair, high part with 26 trailing zeros).
 // NO clamp: the callers' logits are >= GMMIV_PAD_LOGIT - |quadratic terms| (the packed model pads with -1e9, not with
-// -1e300); below -2.3e7 the float-to-int conversion saturates, the exponent stays hugely negative and the result is 0.
-__device__ __forceinline__ double gexp_scaled64(double x, int E, const double *tab)
+// -1e300); below -2^31/(N/ln2) the float-to-int conversion saturates, the exponent stays hugely negative, the result is 0.
+#ifndef GEXP_TAB_BITS
+#define GEXP_TAB_BITS 11
+#endif
+#define GEXP_TAB_N (1 << GEXP_TAB_BITS)
+#if GEXP_TAB_BITS == 11
+#define GEXP_TAB_SCALE 2954.639443740597       /* N / ln2 */
+#define GEXP_TAB_HI 0.00033845076904981397     /* ln2 / N, high part */
+#define GEXP_TAB_LO 2.7079718246904592e-12
+#define GEXP_TAB_LN2N 0.00033845077175778578    /* ln2 / N rounded to nearest */
+#elif GEXP_TAB_BITS == 6
+#define GEXP_TAB_SCALE 92.33248261689366
+#define GEXP_TAB_HI 0.010830424609594047
+#define GEXP_TAB_LO 8.66550983900947e-11
+#define GEXP_TAB_LN2N 0.010830424696249145
+#else
+#error "GEXP_TAB_BITS must be 6 or 11"
+#endif
+__device__ __forceinline__ void gexp_tab_init(double *tab, int tid, int nthreads)
 {
-    const double k = __builtin_rint(x * 92.33248261689366);
-    double r = __builtin_fma(k, -0.010830424609594047, x);   // ln2/64 high part (trailing bits zero)
-    r = __builtin_fma(k, -8.665509839009470e-11, r);         // ln2/64 low part
-    const int ki = (int)k;
-    const double tj = tab[ki & 63];
+    for (int j = tid; j < GEXP_TAB_N; j += nthreads) tab[j] = exp2((double)j * (1.0 / GEXP_TAB_N));
+}
+// exp(r) - 1 for the reduced argument
+__device__ __forceinline__ double gexp_tab_poly(double r)
+{
+#if GEXP_TAB_BITS == 11
+    double p = 1.6666666666666666e-01;
+#else
     double p = 8.333333333333333e-03;
     p = __builtin_fma(p, r, 4.1666666666666664e-02);
     p = __builtin_fma(p, r, 1.6666666666666666e-01);
+#endif
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
-    p = p * r;
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), (ki >> 6) - E);
+    return p * r;
 }
-// gexp_scaled64 in two halves, so that a caller that also needs the binary exponent of exp(x) (ki >> 6)
-// gets it from the argument reduction it has to do anyway: phase 1 -> (ki, r), phase 2 -> exp(x) 2^-E
-__device__ __forceinline__ void gexp64_reduce(double x, int &ki, double &r)
+// phase 1 -> (ki, r); a caller that also needs the binary exponent of exp(x) takes ki >> GEXP_TAB_BITS
+__device__ __forceinline__ void gexp_tab_reduce(double x, int &ki, double &r)
 {
-    const double k = __builtin_rint(x * 92.33248261689366);
-    r = __builtin_fma(k, -0.010830424609594047, x);
-    r = __builtin_fma(k, -8.665509839009470e-11, r);
+    const double k = __builtin_rint(x * GEXP_TAB_SCALE);
+#ifdef GEXP_TAB_TWO_STEP
+    r = __builtin_fma(k, -GEXP_TAB_HI, x);
+    r = __builtin_fma(k, -GEXP_TAB_LO, r);
+#else
+    // ONE fma: the representation error of ln2/N (<= 2^-53 ln2/N = 3.8e-20) times |k| = 2955 |x| puts <= 1.1e-16 |x|
+    // (absolute) on r, i.e. 1e-12 on exp(x) at |x| = 1e4 -- the size of the rounding error the expanded logit itself
+    // carries, and one fp64 instruction less per exponential
+    r = __builtin_fma(k, -GEXP_TAB_LN2N, x);
+#endif
     ki = (int)k;
 }
-__device__ __forceinline__ double gexp64_finish(int ki, double r, int E, const double *tab)
+// phase 2 -> exp(x) 2^-E
+__device__ __forceinline__ double gexp_tab_finish(int ki, double r, int E, const double *tab)
 {
-    const double tj = tab[ki & 63];
-    double p = 8.333333333333333e-03;
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = p * r;
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), (ki >> 6) - E);
+    const double tj = tab[ki & (GEXP_TAB_N - 1)];
+    // (v_ldexp_f64 beats inserting 2^n into the exponent field with integer instructions: measured +0.4 % kernel time)
+    return __builtin_ldexp(__builtin_fma(tj, gexp_tab_poly(r), tj), (ki >> GEXP_TAB_BITS) - E);
 }
-// the binary exponent gexp_scaled64 assigns to exp(x): same clamp, same rounding
-__device__ __forceinline__ int gexp_exponent64(double x)
+__device__ __forceinline__ double gexp_tab_scaled(double x, int E, const double *tab)
 {
-    return ((int)__builtin_rint(x * 92.33248261689366)) >> 6;
+    int ki;
+    double r;
+    gexp_tab_reduce(x, ki, r);
+    return gexp_tab_finish(ki, r, E, tab);
+}
+// the binary exponent gexp_tab_scaled assigns to exp(x): same rounding
+__device__ __forceinline__ int gexp_tab_exponent(double x)
+{
+    return ((int)__builtin_rint(x * GEXP_TAB_SCALE)) >> GEXP_TAB_BITS;
 }
 // floor(x log2 e) as used by gexp_scaled (the binary exponent of exp(x))
 __device__ __forceinline__ int gexp_exponent(double x)

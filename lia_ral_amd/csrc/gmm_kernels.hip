@@ -110,12 +110,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *buf0 = (double *)smem;
     double *buf1 = buf0 + TILE_D;
-    double *etab = buf1 + TILE_D; // 64-entry exp table
+    double *etab = buf1 + TILE_D; // exp table, GEXP_TAB_N entries
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
     const long tb = (long)blockIdx.x * (NW * 32) + wave * 32;
-    gexp_table64_init(etab, tid);
+    gexp_tab_init(etab, tid, NW * 64);
 
     double A[2][2 * KS];
 #pragma unroll
@@ -210,12 +210,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double r0, r1;
-                    gexp64_reduce(acc[0][h][r], k0[h][r], r0);
-                    gexp64_reduce(acc[1][h][r], k1[h][r], r1);
+                    gexp_tab_reduce(acc[0][h][r], k0[h][r], r0);
+                    gexp_tab_reduce(acc[1][h][r], k1[h][r], r1);
                     acc[0][h][r] = r0;
                     acc[1][h][r] = r1;
                     const int km = k0[h][r] > k1[h][r] ? k0[h][r] : k1[h][r];
-                    nm[h][r] = row_max_i32(km >> 6);
+                    nm[h][r] = row_max_i32(km >> GEXP_TAB_BITS);
                     grow |= nm[h][r] - E[h][r] >= 64;
                 }
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double e0 = gexp64_finish(k0[h][r], acc[0][h][r], E[h][r], etab);
-                    const double e1 = gexp64_finish(k1[h][r], acc[1][h][r], E[h][r], etab);
+                    const double e0 = gexp_tab_finish(k0[h][r], acc[0][h][r], E[h][r], etab);
+                    const double e1 = gexp_tab_finish(k1[h][r], acc[1][h][r], E[h][r], etab);
                     sacc[h][r] += e0 + e1;
                     acc[0][h][r] = e0;
                     acc[1][h][r] = e1;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                nm[h][r] = gexp_exponent64(fmax(acc[0][h][r], acc[1][h][r]));
+                nm[h][r] = gexp_tab_exponent(fmax(acc[0][h][r], acc[1][h][r]));
                 grow |= nm[h][r] - E[h][r] >= 64;
             }
         if (__builtin_amdgcn_ballot_w64(grow) != 0) {
@@ -294,14 +294,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    sacc[h][r] += gexp_scaled64(acc[0][h][r], E[h][r], etab) + gexp_scaled64(acc[1][h][r], E[h][r], etab);
+                    sacc[h][r] += gexp_tab_scaled(acc[0][h][r], E[h][r], etab) + gexp_tab_scaled(acc[1][h][r], E[h][r], etab);
         } else if (need) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (need & (1u << (h * 4 + r)))
-                        sacc[h][r] += gexp_scaled64(acc[0][h][r], E[h][r], etab) + gexp_scaled64(acc[1][h][r], E[h][r], etab);
+                        sacc[h][r] += gexp_tab_scaled(acc[0][h][r], E[h][r], etab) + gexp_tab_scaled(acc[1][h][r], E[h][r], etab);
         }
     };
     stage(buf0, 0);
@@ -880,7 +880,7 @@ static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, co
                       int *efin = nullptr)
 {
     constexpr int NR = 2 * KS + 2;
-    const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + 64 * sizeof(double); // two model stages + the exp table
+    const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + GEXP_TAB_N * sizeof(double); // two model stages + the exp table
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, WZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
