@@ -881,7 +881,10 @@ static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, co
 {
     constexpr int NR = 2 * KS + 2;
     const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + GEXP_TAB_N * sizeof(double); // two model stages + the exp table
-    static bool attr_set = false;
+    static bool attr_done[16] = {};      // the attribute is per device
+    int attr_dev = 0;
+    if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
+    bool &attr_set = attr_done[attr_dev];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, WZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -954,7 +957,10 @@ static int launch_stats_p(hipStream_t st, const void *x, long ldx, int D, int C,
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     const size_t lds = (2 * 64 * (RL + 32) + 32) * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_done[16] = {};      // the attribute is per device
+    int attr_dev = 0;
+    if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
+    bool &attr_set = attr_done[attr_dev];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *)k_stats_mfma<KS, SQ, XT, NW, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;

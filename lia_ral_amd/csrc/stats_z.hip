@@ -276,7 +276,10 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * FT * sizeof(double); // two frame tiles + posterior factors
-    static bool attr_set = false;
+    static bool attr_done[16] = {};      // the attribute is per device
+    int attr_dev = 0;
+    if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
+    bool &attr_set = attr_done[attr_dev];
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;

@@ -196,15 +196,22 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
     // interior grid and add their full latency.  They go to a side stream (forked and joined with events) and run
     // beside the interior tiles; the tiles are disjoint, so there is no ordering between the launches to keep.
     const bool has_strips = (int)grid.x > fn || (int)grid.y > fm;
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // one side stream + event pair per device (a process may hold contexts on several devices)
+    struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    static Side sides[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool forked = false;
-    if (has_strips) {
-        if (!side) {
-            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
-            else if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(side); side = nullptr; }
+    if (has_strips && dev >= 0) {
+        Side &sd = sides[dev];
+        if (!sd.s) {
+            if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) sd.s = nullptr;
+            else if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(sd.s); sd.s = nullptr; }
         }
+        side = sd.s; ev_fork = sd.fork; ev_join = sd.join;
         forked = side && hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
     }
     hipStream_t ss = forked ? side : st;
