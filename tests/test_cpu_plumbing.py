@@ -158,3 +158,52 @@ def test_two_rank_em_statistics_allreduce_gloo():
     ref = np.concatenate([a["occ"], a["sx"].ravel(), a["sxx"].ravel(), [a["llk"], a["count"]]])
     assert np.array_equal(res[0], res[1])                    # every rank holds the same global statistics
     assert np.allclose(res[0], ref, rtol=1e-12, atol=1e-12)  # == single-process accumulation
+
+
+def _tv_mstep_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lia_ral_amd.dist import shard_range, tv_mstep_sharded
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rng = np.random.default_rng(1)
+    C, D, R, U = 7, 4, 5, 13            # 7 Gaussians over 2 ranks: blocks of 4 and 3
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D)
+    te = orc.tv_tett(T, iv, C, D)
+    b, e = shard_range(U, rank, world)
+    o = orc.tv_estimate_a_and_c(N[b:e], F[b:e], T, iv, te)          # this rank's utterances
+    acc = dict(A=o["A"], Cmx=o["Cmx"], Rm=o["Rm"], r=o["r"], meanW=o["meanW"] * (e - b))
+
+    def update_t(A_blk, C_blk, Cb):     # CPU stand-in for gmmiv_tv_update_t on the rank's own Gaussians
+        return orc.tv_update_t(A_blk, C_blk, Cb, D)
+
+    Tn = tv_mstep_sharded(acc, update_t, C, D, rank, world)
+    q.put((rank, dict(T=Tn, Rm=acc["Rm"], r=acc["r"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tv_mstep_reduce_scatter_gloo():
+    """rank g owns a block of Gaussians -- reduce-scatter of A / Cmx, local T_c = A_c^-1 Cmx_c, all-gather of T."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tv_mstep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(1)
+    C, D, R, U = 7, 4, 5, 13
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D)
+    o = orc.tv_estimate_a_and_c(N, F, T, iv, orc.tv_tett(T, iv, C, D))
+    Tref = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+    assert np.array_equal(res[0]["T"], res[1]["T"])                      # every rank ends with the same T
+    assert np.allclose(res[0]["T"], Tref, rtol=1e-9, atol=1e-12)         # == the single-process M-step
+    assert np.allclose(res[0]["Rm"], o["Rm"], rtol=1e-12, atol=1e-12) and np.array_equal(res[0]["Rm"], res[1]["Rm"])
