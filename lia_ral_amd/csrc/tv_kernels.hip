@@ -23,8 +23,8 @@ __device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
 //                 73 TFLOP/s, tools/gemm_probe.hip).
 //   EDGE = true   tiles cut by M, N or K: per-element loads with bounds checks (the original path).
 // bm0 / bn0: block offsets of the launched sub-grid (interior, right strip, bottom strip).
-template <bool TA, bool TB, bool EDGE>
-__global__ __launch_bounds__(256, (EDGE ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
+template <bool TA, bool TB, int MODE>
+__global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                   long lda, long sA, const double *__restrict__ B, long ldb, long sB,
                                                   double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int bm0, int bn0)
 {
@@ -50,20 +50,38 @@ __global__ __launch_bounds__(256, (EDGE ? 1 : 2)) void k_dgemm(int M, int N, int
     C += (size_t)blockIdx.z * sC;
 
     // ---- staging: EDGE -> 8 + 8 checked scalar loads; interior -> 4 + 4 unchecked 16-byte loads -----------
+    constexpr bool EDGE = MODE == 1; // per-element checked loads
+    constexpr bool CHECK_OUT = MODE != 0;
     double ra[8], rb[8];
     // interior path: operand with k fastest in memory: thread owns k pair kq = 2 (tid & 7), rows (tid >> 3) + 32 i;
     //                operand with m (n) fastest:       thread owns column pair 2 (tid & 63), k rows (tid >> 6) + 4 i
+    // MODE 2 (tiles cut by M or N, K range still a multiple of 16): the same loads with the row / column-pair index CLAMPED
+    // into the matrix -- an output element depends only on its own row of op(A) and column of op(B), so the clamped
+    // duplicates only feed outputs that are not stored.  No check inside the k loop.
     const double *pa = nullptr, *pb = nullptr;
+    long oa[4] = {0, 0, 0, 0}, ob[4] = {0, 0, 0, 0}; // element offsets of the 4 loads of a k-tile
     if (!EDGE) {
-        pa = TA ? A + (kb + (tid >> 6)) * lda + m0 + 2 * (tid & 63) : A + (m0 + (tid >> 3)) * lda + kb + 2 * (tid & 7);
-        pb = TB ? B + (n0 + (tid >> 3)) * ldb + kb + 2 * (tid & 7) : B + (kb + (tid >> 6)) * ldb + n0 + 2 * (tid & 63);
+        long ma = m0 + (TA ? 2 * (tid & 63) : (tid >> 3)), nb_ = n0 + (TB ? (tid >> 3) : 2 * (tid & 63));
+        if (MODE == 2) {
+            if (TA) ma = ma < M - 2 ? ma : M - 2;
+            if (!TB) nb_ = nb_ < N - 2 ? nb_ : N - 2;
+        }
+        pa = TA ? A + (kb + (tid >> 6)) * lda + ma : A + kb + 2 * (tid & 7);
+        pb = TB ? B + kb + 2 * (tid & 7) : B + (kb + (tid >> 6)) * ldb + nb_;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long ri = ma + 32 * i, ci = nb_ + 32 * i;
+            if (MODE == 2) { ri = ri < M - 1 ? ri : M - 1; ci = ci < N - 1 ? ci : N - 1; }
+            oa[i] = TA ? (long)(4 * i) * lda : ri * lda;
+            ob[i] = TB ? ci * ldb : (long)(4 * i) * ldb;
+        }
     }
     auto gload = [&](int kt) {
         if (!EDGE) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const d2 va = *(const d2 *)(TA ? pa + (long)(4 * i) * lda : pa + (long)(32 * i) * lda);
-                const d2 vb = *(const d2 *)(TB ? pb + (long)(32 * i) * ldb : pb + (long)(4 * i) * ldb);
+                const d2 va = *(const d2 *)(pa + oa[i]);
+                const d2 vb = *(const d2 *)(pb + ob[i]);
                 ra[2 * i] = va[0]; ra[2 * i + 1] = va[1];
                 rb[2 * i] = vb[0]; rb[2 * i + 1] = vb[1];
             }
@@ -155,11 +173,11 @@ __global__ __launch_bounds__(256, (EDGE ? 1 : 2)) void k_dgemm(int M, int N, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long gm = m0 + wr * 64 + a * 16 + q + 4 * r;
-            if (EDGE && gm >= M) continue;
+            if (CHECK_OUT && gm >= M) continue;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const long gn = n0 + wc * 64 + b * 16 + i16;
-                if (EDGE && gn >= N) continue;
+                if (CHECK_OUT && gn >= N) continue;
                 double v = alpha * acc[a][b][r];
                 if (beta != 0.0) v += beta * C[gm * ldc + gn];
                 C[gm * ldc + gn] = v;
@@ -167,29 +185,40 @@ __global__ __launch_bounds__(256, (EDGE ? 1 : 2)) void k_dgemm(int M, int N, int
         }
 }
 
-template <bool EDGE>
+template <int MODE>
 static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                            long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
                            int ksplit, int bm0, int bn0)
 {
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
-    if (!ta && !tb) k_dgemm<false, false, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
-    else if (!ta && tb) k_dgemm<false, true, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
-    else if (ta && !tb) k_dgemm<true, false, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
-    else k_dgemm<true, true, EDGE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    if (!ta && !tb) k_dgemm<false, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    else if (!ta && tb) k_dgemm<false, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    else if (ta && !tb) k_dgemm<true, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    else k_dgemm<true, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
 }
 
-// grid.z = batch (ksplit == 0) or K layers (ksplit > 0).  Interior tiles go to the unchecked kernel when every K range
-// is a multiple of 16 and the operands allow 16-byte loads; the right and bottom strips (and everything else) to EDGE.
+static int g_gemm_clamp = 1; // A/B knob: 0 = cut tiles always on the per-element checked instantiation
+void tvk_set_gemm_clamp(int on) { g_gemm_clamp = on; }
+
+// grid.z = batch (ksplit == 0) or K layers (ksplit > 0).  Three instantiations: full tiles run MODE 0 (no checks at all) when
+// every K range is a multiple of 16 and the operands allow 16-byte loads; tiles cut by M or N run MODE 2 (the same loads,
+// indices clamped, checked stores) when the m- / n-fastest operands have an even extent; everything else MODE 1 (per-element
+// checks).
 static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                          long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
                          int ksplit)
 {
     const bool kfull = K % 16 == 0 && (ksplit <= 0 || ksplit % 16 == 0);
     const bool aligned = (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0 && sA % 2 == 0 && sB % 2 == 0;
+    const bool clamp_ok = g_gemm_clamp && (!ta || (M % 2 == 0 && M >= 2)) && (tb || (N % 2 == 0 && N >= 2));
     const int fm = M / 128, fn = N / 128; // full tiles
-    if (!kfull || !aligned || K <= 0 || fm == 0 || fn == 0) {
-        launch_dgemm_e<true>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+    if (!kfull || !aligned || K <= 0) {
+        launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+        return;
+    }
+    if (fm == 0 || fn == 0) { // no full tile at all
+        if (clamp_ok) launch_dgemm_e<2>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+        else launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
         return;
     }
     // The strips are few workgroups that each walk the whole K range: on the caller's stream they would run AFTER the
@@ -215,9 +244,14 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
         forked = side && hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
     }
     hipStream_t ss = forked ? side : st;
-    if ((int)grid.x > fn) launch_dgemm_e<true>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn);
-    if ((int)grid.y > fm) launch_dgemm_e<true>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0);
-    launch_dgemm_e<false>(st, ta, tb, dim3(fn, fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+    if (clamp_ok) {
+        if ((int)grid.x > fn) launch_dgemm_e<2>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn);
+        if ((int)grid.y > fm) launch_dgemm_e<2>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0);
+    } else {
+        if ((int)grid.x > fn) launch_dgemm_e<1>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn);
+        if ((int)grid.y > fm) launch_dgemm_e<1>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0);
+    }
+    launch_dgemm_e<0>(st, ta, tb, dim3(fn, fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
     if (forked) {
         (void)hipEventRecord(ev_join, side);
         (void)hipStreamWaitEvent(st, ev_join, 0);
