@@ -739,9 +739,10 @@ int gmmiv_score_cosine(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double
     GCHK(tvk_coldot(c->stream, dim, M, a.m.d, a.m.d, a.qm));
     GCHK(tvk_coldot(c->stream, dim, S, a.s.d, a.s.d, a.qs));
     c->t_begin("k_dgemm(score)");
-    GCHK(tvk_dgemm(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, M, 0, a.s.d, S, 0, 0.0, a.sc.d, S, 0, 1));
+    GCHK(tvk_rsqrt_vec(c->stream, M, a.qm));   // the normalisation rides in the GEMM epilogue: x 1/|m| x 1/|s|
+    GCHK(tvk_rsqrt_vec(c->stream, S, a.qs));
+    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, M, a.s.d, S, a.sc.d, S, 1, a.qm, a.qs, 0.0, 0.0, 0.0));
     c->t_end();
-    GCHK(tvk_score_cosnorm(c->stream, M, S, a.sc.d, a.qm, a.qs));
     return a.sc.finish();
 }
 
@@ -764,9 +765,9 @@ static int quad_score(gmmiv_ctx *c, ScoreArgs &a, int dim, int64_t M, int64_t S,
     GCHK(tvk_add_transpose(c->stream, dim, Qcross, Qcross, Qsym));
     GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qsym, dim, 0, a.s.d, S, 0, 0.0, Y, S, 0, 1));
     c->t_begin("k_dgemm(score)");
-    GCHK(tvk_dgemm(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, M, 0, Y, S, 0, 0.0, a.sc.d, S, 0, 1));
+    // ccross m^T Y s + bm q_m + bs q_s + cst in ONE pass over the M x S matrix (GEMM epilogue)
+    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, ccross, a.m.d, M, Y, S, a.sc.d, S, 2, a.qm, a.qs, bm, bs, cst));
     c->t_end();
-    GCHK(tvk_score_combine(c->stream, M, S, a.sc.d, ccross, a.qm, bm, a.qs, bs, cst));
     return GMMIV_OK;
 }
 

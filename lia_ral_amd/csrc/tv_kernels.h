@@ -20,9 +20,6 @@ int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full);
 int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y);
 int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const double *Mx, double *y);
 int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv);
-int tvk_score_combine(hipStream_t st, long M, long S, double *scores, double a, const double *qm, double bm,
-                      const double *qs, double bs, double cst);
-int tvk_score_cosnorm(hipStream_t st, long M, long S, double *scores, const double *qm, const double *qs);
 int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out);
 int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const double *y, double *out);
 int tvk_splitk_count(int M, int N, int K, int n_cu);
@@ -51,3 +48,6 @@ int tvk_jfa_sub_sessions(hipStream_t st, long s0, long ns, long h0, long h1, int
                          const double *G, double *FX);
 int tvk_jfa_z(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, const double *Dm, double tau, double *Z);
 int tvk_jfa_z_and_d(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, double *Dm, double *Z);
+int tvk_dgemm_epi(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, const double *B,
+                  long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst);
+int tvk_rsqrt_vec(hipStream_t st, long n, double *v);

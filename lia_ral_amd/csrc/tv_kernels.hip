@@ -23,10 +23,17 @@ __device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
 //                 73 TFLOP/s, tools/gemm_probe.hip).
 //   EDGE = true   tiles cut by M, N or K: per-element loads with bounds checks (the original path).
 // bm0 / bn0: block offsets of the launched sub-grid (interior, right strip, bottom strip).
+// Fused epilogue on the accumulator v = alpha * acc (before the beta term):
+//   mode 1: v * rv[m] * cv[n]                         (cosine scoring: the two reciprocal norms)
+//   mode 2: v + br * rv[m] + bc * cv[n] + cst         (quadratic-form scoring rules: the per-model / per-segment terms)
+// One pass over the M x N result instead of GEMM + a read-modify-write kernel (3.2 GB each way at 20 k x 20 k).
+struct DgemmEpi { const double *rv, *cv; double br, bc, cst; int mode; };
+
 template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                   long lda, long sA, const double *__restrict__ B, long ldb, long sB,
-                                                  double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int bm0, int bn0)
+                                                  double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int bm0, int bn0,
+                                                  DgemmEpi epi)
 {
     constexpr int BM = 128, BN = 128, BK = 16;
     __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
@@ -168,17 +175,28 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         __syncthreads();
     }
     // D layout: lane holds rows q + 4r, column i16 of every 16x16 tile
+    double cvv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (epi.mode != 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const long gn = n0 + wc * 64 + b * 16 + i16;
+            cvv[b] = (!CHECK_OUT || gn < N) ? epi.cv[gn] : 0.0;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long gm = m0 + wr * 64 + a * 16 + q + 4 * r;
             if (CHECK_OUT && gm >= M) continue;
+            const double rvv = epi.mode != 0 ? epi.rv[gm] : 0.0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const long gn = n0 + wc * 64 + b * 16 + i16;
                 if (CHECK_OUT && gn >= N) continue;
                 double v = alpha * acc[a][b][r];
+                if (epi.mode == 1) v = v * rvv * cvv[b];
+                else if (epi.mode == 2) v = v + epi.br * rvv + epi.bc * cvv[b] + epi.cst;
                 if (beta != 0.0) v += beta * C[gm * ldc + gn];
                 C[gm * ldc + gn] = v;
             }
@@ -188,13 +206,13 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
 template <int MODE>
 static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                            long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
-                           int ksplit, int bm0, int bn0)
+                           int ksplit, int bm0, int bn0, const DgemmEpi &epi)
 {
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
-    if (!ta && !tb) k_dgemm<false, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
-    else if (!ta && tb) k_dgemm<false, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
-    else if (ta && !tb) k_dgemm<true, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
-    else k_dgemm<true, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0);
+    if (!ta && !tb) k_dgemm<false, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
+    else if (!ta && tb) k_dgemm<false, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
+    else if (ta && !tb) k_dgemm<true, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
+    else k_dgemm<true, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
 }
 
 static int g_gemm_clamp = 1; // A/B knob: 0 = cut tiles always on the per-element checked instantiation
@@ -206,19 +224,19 @@ void tvk_set_gemm_clamp(int on) { g_gemm_clamp = on; }
 // checks).
 static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                          long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
-                         int ksplit)
+                         int ksplit, const DgemmEpi &epi = DgemmEpi{nullptr, nullptr, 0.0, 0.0, 0.0, 0})
 {
     const bool kfull = K % 16 == 0 && (ksplit <= 0 || ksplit % 16 == 0);
     const bool aligned = (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0 && sA % 2 == 0 && sB % 2 == 0;
     const bool clamp_ok = g_gemm_clamp && (!ta || (M % 2 == 0 && M >= 2)) && (tb || (N % 2 == 0 && N >= 2));
     const int fm = M / 128, fn = N / 128; // full tiles
     if (!kfull || !aligned || K <= 0) {
-        launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+        launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
         return;
     }
     if (fm == 0 || fn == 0) { // no full tile at all
-        if (clamp_ok) launch_dgemm_e<2>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
-        else launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+        if (clamp_ok) launch_dgemm_e<2>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
+        else launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
         return;
     }
     // The strips are few workgroups that each walk the whole K range: on the caller's stream they would run AFTER the
@@ -245,13 +263,13 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
     }
     hipStream_t ss = forked ? side : st;
     if (clamp_ok) {
-        if ((int)grid.x > fn) launch_dgemm_e<2>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn);
-        if ((int)grid.y > fm) launch_dgemm_e<2>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0);
+        if ((int)grid.x > fn) launch_dgemm_e<2>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn, epi);
+        if ((int)grid.y > fm) launch_dgemm_e<2>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0, epi);
     } else {
-        if ((int)grid.x > fn) launch_dgemm_e<1>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn);
-        if ((int)grid.y > fm) launch_dgemm_e<1>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0);
+        if ((int)grid.x > fn) launch_dgemm_e<1>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn, epi);
+        if ((int)grid.y > fm) launch_dgemm_e<1>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0, epi);
     }
-    launch_dgemm_e<0>(st, ta, tb, dim3(fn, fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0);
+    launch_dgemm_e<0>(st, ta, tb, dim3(fn, fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
     if (forked) {
         (void)hipEventRecord(ev_join, side);
         (void)hipStreamWaitEvent(st, ev_join, 0);
@@ -264,6 +282,15 @@ int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alph
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
     launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, 0);
+    return (int)hipGetLastError();
+}
+// C = epilogue(alpha op(A) op(B)): mode 1 -> x rv[m] cv[n]; mode 2 -> + br rv[m] + bc cv[n] + cst   (single matrix)
+int tvk_dgemm_epi(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, const double *B,
+                  long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst)
+{
+    if (M <= 0 || N <= 0) return 0;
+    dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, C, ldc, 0, 0, DgemmEpi{rv, cv, br, bc, cst, mode});
     return (int)hipGetLastError();
 }
 
@@ -966,25 +993,16 @@ __global__ void k_coldot(int dim, long n, const double *__restrict__ X, const do
         qv[j] = s;
     }
 }
-// scores[m][s] = a * scores[m][s] + bm * qm[m] + bs * qs[s] + cst
-__global__ void k_score_combine(long M, long S, double *__restrict__ scores, double a, const double *__restrict__ qm,
-                                double bm, const double *__restrict__ qs, double bs, double cst)
+// v[i] = 1 / sqrt(v[i])
+__global__ void k_rsqrt_vec(long n, double *__restrict__ v)
 {
-    const size_t tot = (size_t)M * S;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t m = e / S, s = e - m * S;
-        scores[e] = a * scores[e] + bm * qm[m] + bs * qs[s] + cst;
-    }
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) v[e] = 1.0 / sqrt(v[e]);
 }
-// scores[m][s] /= (sqrt(qm[m]) * sqrt(qs[s]))
-__global__ void k_score_cosnorm(long M, long S, double *__restrict__ scores, const double *__restrict__ qm,
-                                const double *__restrict__ qs)
+int tvk_rsqrt_vec(hipStream_t st, long n, double *v)
 {
-    const size_t tot = (size_t)M * S;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t m = e / S, s = e - m * S;
-        scores[e] = scores[e] / (sqrt(qm[m]) * sqrt(qs[s]));
-    }
+    if (n <= 0) return 0;
+    k_rsqrt_vec<<<ew_blocks(n), 256, 0, st>>>(n, v);
+    return (int)hipGetLastError();
 }
 // out[i][j] = a[i][j] + b[j][i]   (square n x n)
 __global__ void k_add_transpose(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
@@ -1022,19 +1040,6 @@ int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y
     if (n <= 0) return 0;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     k_coldot<<<blocks, 256, 0, st>>>(dim, n, X, Y, qv);
-    return (int)hipGetLastError();
-}
-int tvk_score_combine(hipStream_t st, long M, long S, double *scores, double a, const double *qm, double bm,
-                      const double *qs, double bs, double cst)
-{
-    if (M <= 0 || S <= 0) return 0;
-    k_score_combine<<<4096, 256, 0, st>>>(M, S, scores, a, qm, bm, qs, bs, cst);
-    return (int)hipGetLastError();
-}
-int tvk_score_cosnorm(hipStream_t st, long M, long S, double *scores, const double *qm, const double *qs)
-{
-    if (M <= 0 || S <= 0) return 0;
-    k_score_cosnorm<<<4096, 256, 0, st>>>(M, S, scores, qm, qs);
     return (int)hipGetLastError();
 }
 int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out)
