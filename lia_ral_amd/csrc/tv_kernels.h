@@ -8,6 +8,7 @@ int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd,
 int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status);
 void tvk_set_chol_gemm_path(int on);
 void tvk_set_gemm_clamp(int on);
+void tvk_set_gemm_remap(int on);
 int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status);
 int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,
                             double *panel, int *status);

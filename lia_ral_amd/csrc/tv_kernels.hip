@@ -27,7 +27,7 @@ __device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
 //   mode 1: v * rv[m] * cv[n]                         (cosine scoring: the two reciprocal norms)
 //   mode 2: v + br * rv[m] + bc * cv[n] + cst         (quadratic-form scoring rules: the per-model / per-segment terms)
 // One pass over the M x N result instead of GEMM + a read-modify-write kernel (3.2 GB each way at 20 k x 20 k).
-struct DgemmEpi { const double *rv, *cv; double br, bc, cst; int mode; };
+struct DgemmEpi { const double *rv, *cv; double br, bc, cst; int mode; int remap; };
 
 template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
@@ -43,7 +43,25 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
-    const long m0 = (long)(blockIdx.y + bm0) * BM, n0 = (long)(blockIdx.x + bn0) * BN;
+    // Tile order.  Hardware order is blockIdx.x (N tiles) fastest and workgroup i lands on XCD i % 8: the ~512 resident tiles
+    // of a wide GEMM then share one row panel of op(A) and stream 512 different column panels of op(B) -- every B panel comes
+    // from HBM once per M tile row.  remap: XCD x takes the N tiles n = 8 g + x and walks the M tiles fastest, so a B panel is
+    // fetched once (by one XCD's L2) and reused for the whole column of tiles; the A panels cycle through L2 / MALL.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (epi.remap) {
+        const int Nt = gridDim.x, Mt = gridDim.y, G = Nt >> 3;
+        const int id = by * Nt + bx;
+        if (id < G * 8 * Mt) {
+            const int xcd = id & 7, loc = id >> 3;
+            by = loc % Mt;
+            bx = (loc / Mt) * 8 + xcd;
+        } else {
+            const int r = id - G * 8 * Mt;
+            by = r % Mt;
+            bx = G * 8 + r / Mt;
+        }
+    }
+    const long m0 = (long)(by + bm0) * BM, n0 = (long)(bx + bn0) * BN;
     // ksplit > 0: blockIdx.z selects a K range [kb, ke) and C is the z-th partial slab (stride sC);
     // otherwise blockIdx.z is the batch index.
     long kb = 0, ke = K;
@@ -215,6 +233,8 @@ static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, i
     else k_dgemm<true, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
 }
 
+static int g_gemm_remap = 1; // A/B knob: XCD-aware tile order
+void tvk_set_gemm_remap(int on) { g_gemm_remap = on; }
 static int g_gemm_clamp = 1; // A/B knob: 0 = cut tiles always on the per-element checked instantiation
 void tvk_set_gemm_clamp(int on) { g_gemm_clamp = on; }
 
@@ -224,8 +244,9 @@ void tvk_set_gemm_clamp(int on) { g_gemm_clamp = on; }
 // checks).
 static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                          long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
-                         int ksplit, const DgemmEpi &epi = DgemmEpi{nullptr, nullptr, 0.0, 0.0, 0.0, 0})
+                         int ksplit, DgemmEpi epi = DgemmEpi{nullptr, nullptr, 0.0, 0.0, 0.0, 0, 0})
 {
+    epi.remap = g_gemm_remap && grid.x >= 16; // wide enough for the per-XCD column order to mean something
     const bool kfull = K % 16 == 0 && (ksplit <= 0 || ksplit % 16 == 0);
     const bool aligned = (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0 && sA % 2 == 0 && sB % 2 == 0;
     const bool clamp_ok = g_gemm_clamp && (!ta || (M % 2 == 0 && M >= 2)) && (tb || (N % 2 == 0 && N >= 2));
@@ -290,7 +311,7 @@ int tvk_dgemm_epi(hipStream_t st, bool ta, bool tb, int M, int N, int K, double 
 {
     if (M <= 0 || N <= 0) return 0;
     dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
-    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, C, ldc, 0, 0, DgemmEpi{rv, cv, br, bc, cst, mode});
+    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, C, ldc, 0, 0, DgemmEpi{rv, cv, br, bc, cst, mode, 0});
     return (int)hipGetLastError();
 }
 

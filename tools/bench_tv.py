@@ -12,6 +12,7 @@ from lia_ral_amd import capi
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
 ctx.set_option("gemm_clamp", int(os.environ.get("GEMM_CLAMP", "1")))
+ctx.set_option("gemm_remap", int(os.environ.get("GEMM_REMAP", "1")))
 C, D, R = 2048, 60, 400
 P = R * (R + 1) // 2
 out = {}
