@@ -92,6 +92,10 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
     else if (!strcmp(key, "z_waves")) slot = &c->z_waves;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
+    if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
+        gmmk_stats_z_set_tv4((int)value);
+        return 0;
+    }
     if (!strcmp(key, "gemm_remap")) { // A/B knob: 0 = hardware tile order in k_dgemm
         tvk_set_gemm_remap((int)value);
         return 0;

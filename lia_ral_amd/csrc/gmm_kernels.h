@@ -45,6 +45,7 @@ int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, 
                     const double *ivT, const double *lwc, const double *lse, double *gamma);
 int gmmk_stats_z_groups(int nct);
 void gmmk_stats_z_set_waves(int w);
+void gmmk_stats_z_set_tv4(int on);
 int gmmk_stats_z_wg_per_cu(void);
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
                  long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,

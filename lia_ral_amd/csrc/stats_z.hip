@@ -26,7 +26,8 @@
 // NW = 8: one 8-wave workgroup per CU, 64-frame tiles; NW = 4: two independent 4-wave workgroups per
 // CU with 32-frame tiles (their barriers and staging phases drift apart).
 // Shapes (NW waves, TPW Gaussian tiles per wave, FT frames per LDS tile):
-//   <8, 2, 64>   one workgroup per CU, 2 waves per SIMD, 256 VGPRs (default)
+//   <8, 2, 64>   one workgroup per CU, 2 waves per SIMD, 256 VGPRs (default for the EM statistics)
+//   <8, 4, 64>   the same with 4 tiles per wave: default for N / F statistics (SQ = false: no x^2 accumulators)
 //   <4, 2, 32>   two independent workgroups per CU
 //   <16, 1, 64>  one workgroup per CU, 4 waves per SIMD at 128 VGPRs: more waves to cover a stalled one,
 //                half the operand reuse (every x operand feeds 2 MFMAs)
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     constexpr int BPT = FT / 16; // logit blocks per frame tile
     constexpr int NLD = (FT * Dp + NT - 1) / NT;
     constexpr int RLp = RL + 32; // padded row: additive rotation xrot(t) < 32
+    constexpr int PF = TPW > 2 ? TPW / 2 : 1; // tile pairs of a wave (a running exponent belongs to a PAIR of tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *buf0 = (double *)smem;
     double *buf1 = buf0 + FT * RLp;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     typedef double d2 __attribute__((ext_vector_type(2)));
     XT stg[NLD];
     double stg_inv = 0.0;
-    int stg_ef = 0, stg_e = 0;
+    int stg_ef = 0, stg_e[PF];
     const int npad = FT * (RL - D);
     unsigned pk[NLD], goff[NLD];
     const bool contig = (ldx == D);
@@ -98,10 +100,12 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
         goff[i] = fr < FT ? (contig ? (unsigned)e : (unsigned)(fr * (int)ldx + d)) : 0u;
     }
-    // ftile[2][NW][FT]: per frame of the tile and per wave, the factor that turns a stored likelihood into a
+    // ftile[2][NW][PF][FT]: per frame of the tile, per wave and per tile pair of the wave, the factor that turns a stored likelihood into a
     // posterior, f = scale / S_t * 2^(E - Efin) with E the running exponent of the wave's tile pair (0 outside [f0, f1))
     double *ftile = buf1 + FT * RLp;
-    const int *epair = eit + (size_t)(active ? ct0 >> 1 : 0) * (nfb * 16) + fa;
+    const int *epair[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) epair[p] = eit + (size_t)(active ? (ct0 >> 1) + p : 0) * (nfb * 16) + fa;
     const int srow = lane & (FT - 1);
     auto issue_stage = [&](int tl) { // exactly SL loads
         const long fb = fa + (long)tl * FT;
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         const long t = fb + srow < f1 ? fb + srow : f1 - 1;
         stg_inv = inv[t];
         stg_ef = efin[t];
-        stg_e = epair[(long)tl * FT + srow];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) stg_e[p] = epair[p][(long)tl * FT + srow];
     };
     auto finish_stage = [&](double *dst, int buf, int tl) {
         const long fb = fa + (long)tl * FT;
@@ -126,7 +131,9 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
             if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = pk[i] < lim ? (double)stg[i] : 0.0;
         if (lane < FT) { // rows outside [f0, f1) get f = 0 -> posterior 0
             const long t = fb + lane;
-            ftile[(buf * NW + wave) * FT + lane] = (t >= f0 && t < f1) ? __builtin_ldexp(stg_inv * scale, stg_e - stg_ef) : 0.0;
+#pragma unroll
+            for (int p = 0; p < PF; ++p)
+                ftile[((buf * NW + wave) * PF + p) * FT + lane] = (t >= f0 && t < f1) ? __builtin_ldexp(stg_inv * scale, stg_e[p] - stg_ef) : 0.0;
         }
     };
     // pad columns (1.0 at Dp, zeros elsewhere) never change: written once
@@ -157,11 +164,13 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         }
     };
     // "this value is needed now": the compiler places the (exactly counted) wait for its load here
-    static_assert(TPW <= 2, "operand list of PIN_Z");
+    static_assert(TPW == 1 || TPW == 2 || TPW == 4, "operand list of PIN_Z");
 #define PIN_Z(z)                                                                                              \
     do {                                                                                                      \
         if constexpr (TPW == 1) asm volatile("" : "+v"(z[0][0]), "+v"(z[0][1]));                             \
-        else asm volatile("" : "+v"(z[0][0]), "+v"(z[0][1]), "+v"(z[TPW - 1][0]), "+v"(z[TPW - 1][1]));     \
+        else if constexpr (TPW == 2) asm volatile("" : "+v"(z[0][0]), "+v"(z[0][1]), "+v"(z[1][0]), "+v"(z[1][1])); \
+        else asm volatile("" : "+v"(z[0][0]), "+v"(z[0][1]), "+v"(z[1][0]), "+v"(z[1][1]), "+v"(z[TPW / 2][0]),     \
+                          "+v"(z[TPW / 2][1]), "+v"(z[TPW - 1][0]), "+v"(z[TPW - 1][1]));                      \
     } while (0)
 
     if (ntiles > 0) {
@@ -180,18 +189,20 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         if (staged) issue_stage(tl + 1);
         if (active) {
             const double *pS = cur + offS;
-            const double *pF = ftile + ((tl & 1) * NW + wave) * FT + q;
+            const double *pF = ftile + ((tl & 1) * NW + wave) * PF * FT + q;
             auto block = [&](int fs, d2 (&zc)[TPW][2], d2 (&zn)[TPW][2]) {
                 const int n = tl * BPT + fs;
                 if (full || n + 1 < nblk) issue_z(zn, n + 1);
                 // register r holds rows (frames) fs*16 + 4r + q of 16 Gaussians: already the A operand
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double f = pF[fs * 16 + 4 * r]; // 2^(E - Efin) / S_t (x EM weight), 0 for a masked frame
+                    double f[PF]; // 2^(E - Efin) / S_t (x EM weight), 0 for a masked frame
+#pragma unroll
+                    for (int p = 0; p < PF; ++p) f[p] = pF[p * FT + fs * 16 + 4 * r];
                     double gm[TPW];
                     bool keep = false;
 #pragma unroll
-                    for (int t = 0; t < TPW; ++t) { gm[t] = zc[t][r >> 1][r & 1] * f; keep |= gm[t] > prune_arg; }
+                    for (int t = 0; t < TPW; ++t) { gm[t] = zc[t][r >> 1][r & 1] * f[PF > 1 ? t >> 1 : 0]; keep |= gm[t] > prune_arg; }
                     if (PRUNE && __builtin_amdgcn_ballot_w64(keep) == 0) continue;
 #pragma unroll
                     for (int j = 0; j < JT; ++j) {
@@ -264,6 +275,8 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     } while (0)
 
 static int g_stats_z_waves = 8;
+static int g_stats_z_tv4 = 1; // A/B knob: 0 = two tiles per wave in the N / F mode too
+void gmmk_stats_z_set_tv4(int on) { g_stats_z_tv4 = on; }
 void gmmk_stats_z_set_waves(int w) { g_stats_z_waves = (w == 4 || w == 16) ? w : 8; }
 // Gaussian tiles per workgroup: 16 for <8,2> and <16,1>, 8 for <4,2>
 int gmmk_stats_z_groups(int nct) { const int tpg = g_stats_z_waves == 4 ? 8 : 16; return (nct + tpg - 1) / tpg; }
@@ -275,7 +288,8 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
                     int mode, int accum, double prune_thr)
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
-    const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * FT * sizeof(double); // two frame tiles + posterior factors
+    constexpr int PF = TPW > 2 ? TPW / 2 : 1;
+    const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * PF * FT * sizeof(double); // two frame tiles + posterior factors
     static bool attr_done[16] = {};      // the attribute is per device
     int attr_dev = 0;
     if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
@@ -301,6 +315,9 @@ static int launch_z_p(hipStream_t st, const void *x, long ldx, int D, int C, int
     if (prune_thr > 0.0) return launch_z<KS, SQ, XT, true, 8, 2, 64>(ZARGS);
     if (g_stats_z_waves == 4) return launch_z<KS, SQ, XT, false, 4, 2, 32>(ZARGS);
     if (g_stats_z_waves == 16) return launch_z<KS, SQ, XT, false, 16, 1, 64>(ZARGS);
+    // N / F statistics only (no x^2 accumulators): FOUR tiles per wave in the same 128 accumulator registers, so that
+    // every x operand read from LDS feeds 4 MFMAs here too
+    if constexpr (!SQ) { if (g_stats_z_tv4) return launch_z<KS, SQ, XT, false, 8, 4, 64>(ZARGS); }
     return launch_z<KS, SQ, XT, false, 8, 2, 64>(ZARGS);
 }
 
