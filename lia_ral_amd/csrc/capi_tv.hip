@@ -260,14 +260,17 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         c->t_begin("k_dgemm(L)");
         GCHK(tvk_dgemm(c->stream, false, false, nb, (int)P, C, 1.0, Nc, C, 0, i_te.d, (long)P, 0, 0.0, Lp, (long)P, 0, 1));
         c->t_end();
-        GCHK(tvk_unpack_sym(c->stream, R, nb, Lp, (long)P, ws.full, 1.0));
+        const bool packed_in = tvk_chol_accepts_packed(R); // the factorisation reads the packed GEMM result (+ I) itself
+        if (!packed_in) GCHK(tvk_unpack_sym(c->stream, R, nb, Lp, (long)P, ws.full, 1.0));
         // aux = F Sigma^-1 T^T
         GCHK(tvk_dgemm_splitk(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, Tiv, (long)SV, 0.0, aux, R, nz, slabs));
         if (accumulate) { // the T-matrix EM needs L^-1 itself (E = L^-1 + w w^T): explicit inverse like the reference
-            GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+            if (packed_in) GCHK(tvk_spd_inverse_left_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.status, Lp, (long)P, 1.0));
+            else GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
             GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
         } else {          // extraction only needs w = L^-1 aux: Cholesky + two triangular solves
-            GCHK(tvk_chol_batched(c->stream, R, nb, ws.full, ws.invd, ws.panel, ws.status));
+            if (packed_in) GCHK(tvk_chol_left_batched(c->stream, R, nb, ws.full, ws.invd, ws.status, Lp, (long)P, 1.0));
+            else GCHK(tvk_chol_batched(c->stream, R, nb, ws.full, ws.invd, ws.panel, ws.status));
             GCHK(tvk_chol_solve_batched(c->stream, R, nb, ws.full, ws.invd, aux, Wc));
         }
         if ((rc = check_status(c, ws.status, nb, "tv: L"))) { free_owned(); return rc; }
@@ -330,8 +333,12 @@ int gmmiv_tv_update_t(gmmiv_ctx *c, int C, int D, int R, const double *A_packed,
     for (int c0 = 0; c0 < C; c0 += CH) {
         const int nb = (C - c0) < CH ? (C - c0) : CH;
         GCHK(hipMemsetAsync(ws.status, 0, nb * sizeof(int), c->stream));
-        GCHK(tvk_unpack_sym(c->stream, R, nb, i_a.d + (size_t)c0 * P, (long)P, ws.full, 0.0));
-        GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+        if (tvk_chol_accepts_packed(R)) {
+            GCHK(tvk_spd_inverse_left_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.status, i_a.d + (size_t)c0 * P, (long)P, 0.0));
+        } else {
+            GCHK(tvk_unpack_sym(c->stream, R, nb, i_a.d + (size_t)c0 * P, (long)P, ws.full, 0.0));
+            GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+        }
         // T_c = A_c^-1 Cmx_c
         GCHK(tvk_dgemm(c->stream, false, false, R, D, R, 1.0, ws.inv, R, (long)RR, i_c.d + (size_t)c0 * D, (long)SV, D, 0.0,
                        o_t.d + (size_t)c0 * D, (long)SV, D, nb));

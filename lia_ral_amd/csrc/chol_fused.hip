@@ -158,10 +158,30 @@ __device__ __forceinline__ void chol_block_out(const double (*pj)[34], const dou
     }
 }
 
+// A[r][c0 .. c0 + 3] of the matrix being factored: from the row-major array itself (factorisation in place) or from
+// PACKED lower rows (r (r + 1) / 2 + c, the layout the L = N TETt GEMM produces) with diag_add on the diagonal -- the
+// unpack kernel (a 2 x 1.3 GB round trip per 1024 systems of order 400) disappears.  Entries above the diagonal come out
+// as whatever follows in the packed array; the factorisation never uses them.
+__device__ __forceinline__ d4 chol_src4(const double *Lm, const double *Apk, long n, long r, long c0, double diag_add)
+{
+    if (!Apk) {
+        const double *p = Lm + r * n + c0;
+        const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
+        return d4{lo[0], lo[1], hi[0], hi[1]};
+    }
+    const double *p = Apk + r * (r + 1) / 2 + c0;
+    d4 v = {p[0], p[1], p[2], p[3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (c0 + k == r) v[k] += diag_add;
+    return v;
+}
+
 // Afull[b]: n x n row-major, lower triangle read, overwritten by the factor (diagonal blocks: upper part zeroed;
 // elsewhere the upper triangle is left as it was).  invd[b][kb][32][32]: inverse of the kb-th 32 x 32 diagonal
 // block of the factor (zero padded).  status[b] = 1 on a non-positive pivot.  n must be even (16-byte rows).
-__global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, double *invd, long sinv, int *status)
+__global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
+                                                      long spk, double diag_add)
 {
     __shared__ __attribute__((aligned(16))) double pj[32][34];
     __shared__ __attribute__((aligned(16))) double linv[32][34];
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
     __shared__ double slab[8][32][33]; // partial updates of the diagonal block, one per wave
     const long n = n_;
     double *Lm = Afull + (size_t)blockIdx.x * n * n;
+    const double *Apk = Apacked ? Apacked + (size_t)blockIdx.x * spk : nullptr; // input, when it is not Afull itself
     double *iv = invd + (size_t)blockIdx.x * sinv;
     const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
     // tiles go to waves 1 2 3 5 6 7 4 0 in turn: wave 0 owns the serial diagonal work, wave 4 shares its SIMD
@@ -212,11 +233,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const double *p = Lm + rr[u] * n + j0 + 16 * ct + 4 * q;
-                            const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
-                            acc[u][ct] = d4{lo[0], lo[1], hi[0], hi[1]};
-                        }
+                        for (int ct = 0; ct < 2; ++ct) acc[u][ct] = chol_src4(Lm, Apk, n, rr[u], j0 + 16 * ct + 4 * q, diag_add);
                 } else {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
@@ -225,7 +242,12 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int i = 16 * u + i16, k = 16 * ct + 4 * q + r;
-                                acc[u][ct][r] = (i < w && k < w) ? Lm[(long)(j0 + i) * n + j0 + k] : 0.0;
+                                double v = 0.0;
+                                if (i < w && k < w) {
+                                    if (!Apk) v = Lm[(long)(j0 + i) * n + j0 + k];
+                                    else if (k <= i) v = Apk[(long)(j0 + i) * (j0 + i + 1) / 2 + j0 + k] + (k == i ? diag_add : 0.0);
+                                }
+                                acc[u][ct][r] = v;
                             }
                 }
             }
@@ -329,11 +351,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 pb[u] = Lm + r * n + 8 * q;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    if (u < cnt) {
-                        const double *p = Lm + r * n + j0 + 16 * ct + 4 * q;
-                        const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
-                        acc[u][ct] = d4{lo[0], lo[1], hi[0], hi[1]};
-                    }
+                    if (u < cnt) acc[u][ct] = chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
                 }
             }
             rowdot_n<true>(cnt, pa0, pa1, pb, 0, j0, acc);
@@ -522,20 +540,23 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
     }
 }
 
-int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status)
+int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked, long spk,
+                          double diag_add)
 {
     if (nb <= 0 || n <= 0) return 0;
     const int nblk = (n + 31) / 32;
-    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status);
+    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status, Apacked, spk, diag_add);
     return (int)hipGetLastError();
 }
 
-// inv[b] = A[b]^-1 through the three one-workgroup-per-matrix kernels; U: scratch nb*n*n (only its upper triangle is used)
-int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status)
+// inv[b] = A[b]^-1 through the three one-workgroup-per-matrix kernels; U: scratch nb*n*n (only its upper triangle is used).
+// Apacked != NULL: A comes as packed lower rows (stride spk) + diag_add I, Afull only receives the factor.
+int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status,
+                                 const double *Apacked, long spk, double diag_add)
 {
     if (nb <= 0 || n <= 0) return 0;
     const int nblk = (n + 31) / 32;
-    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status);
+    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status, Apacked, spk, diag_add);
     k_trinv_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, U);
     k_uut<<<nb, 512, 0, st>>>(n, U, inv);
     return (int)hipGetLastError();

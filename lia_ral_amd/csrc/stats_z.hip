@@ -317,7 +317,8 @@ static int launch_z_p(hipStream_t st, const void *x, long ldx, int D, int C, int
     if (g_stats_z_waves == 16) return launch_z<KS, SQ, XT, false, 16, 1, 64>(ZARGS);
     // N / F statistics only (no x^2 accumulators): FOUR tiles per wave in the same 128 accumulator registers, so that
     // every x operand read from LDS feeds 4 MFMAs here too
-    if constexpr (!SQ) { if (g_stats_z_tv4) return launch_z<KS, SQ, XT, false, 8, 4, 64>(ZARGS); }
+    // (a wave's four tiles must all exist: the host pads the packed model to PAIRS of tiles only)
+    if constexpr (!SQ) { if (g_stats_z_tv4 && nct % 4 == 0) return launch_z<KS, SQ, XT, false, 8, 4, 64>(ZARGS); }
     return launch_z<KS, SQ, XT, false, 8, 2, 64>(ZARGS);
 }
 

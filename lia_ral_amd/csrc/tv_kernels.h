@@ -5,11 +5,14 @@
 int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, long sA,
               const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC, int batch);
 int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, double *panel, int *status);
-int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status);
+int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked = nullptr,
+                          long spk = 0, double diag_add = 0.0);
+int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read packed lower rows directly
 void tvk_set_chol_gemm_path(int on);
 void tvk_set_gemm_clamp(int on);
 void tvk_set_gemm_remap(int on);
-int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status);
+int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status,
+                                 const double *Apacked = nullptr, long spk = 0, double diag_add = 0.0);
 int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,
                             double *panel, int *status);
 int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means);

@@ -528,6 +528,7 @@ __global__ __launch_bounds__(256) void k_potf2_inv(int n, int kk, int w, double 
 
 static int g_chol_gemm_path = 0; // A/B knob: 1 = the GEMM-built right-looking factorisation for every n
 void tvk_set_chol_gemm_path(int on) { g_chol_gemm_path = on; }
+int tvk_chol_accepts_packed(int n) { return n % 2 == 0 && !g_chol_gemm_path; }
 
 // In-place batched Cholesky (lower) of nb SPD matrices [n x n]; invd receives the inverses of the
 // 32 x 32 diagonal blocks; panel: scratch nb*n*32 doubles. Upper triangles end up unspecified

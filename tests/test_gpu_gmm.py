@@ -222,7 +222,7 @@ def test_em_zero_frames_and_ragged_edges(ctx):
         assert relerr(a["sxx"], ref["sxx"]) < 1e-9, T
 
 
-@pytest.mark.parametrize("C,D", [(128, 60), (2048, 60), (37, 13)])
+@pytest.mark.parametrize("C,D", [(128, 60), (2048, 60), (37, 13), (32, 20), (96, 60)])   # 8, 128, 4 (padded), 2 and 6 Gaussian tiles: both wave shapes
 def test_tv_stats_match_oracle(ctx, C, D):
     w, mean, iv = make_gmm(C, D, seed=C + 7)
     lens = [70, 0, 131, 64, 1]
