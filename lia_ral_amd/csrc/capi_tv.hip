@@ -265,9 +265,12 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         // aux = F Sigma^-1 T^T
         GCHK(tvk_dgemm_splitk(c->stream, false, true, nb, R, (int)SV, 1.0, Fc, (long)SV, Tiv, (long)SV, 0.0, aux, R, nz, slabs));
         if (accumulate) { // the T-matrix EM needs L^-1 itself (E = L^-1 + w w^T): explicit inverse like the reference
-            if (packed_in) GCHK(tvk_spd_inverse_left_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.status, Lp, (long)P, 1.0));
-            else GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
-            GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
+            if (packed_in) { // w by substitution, E = L^-1 + w w^T straight into the packed buffer
+                GCHK(tvk_inverse_e_packed_batched(c->stream, R, nb, ws.full, ws.X, ws.invd, ws.status, Lp, (long)P, 1.0, aux, Wc));
+            } else {
+                GCHK(tvk_spd_inverse_batched(c->stream, R, nb, ws.full, ws.inv, ws.X, ws.invd, ws.panel, ws.status));
+                GCHK(tvk_batched_matvec(c->stream, R, nb, ws.inv, aux, Wc));
+            }
         } else {          // extraction only needs w = L^-1 aux: Cholesky + two triangular solves
             if (packed_in) GCHK(tvk_chol_left_batched(c->stream, R, nb, ws.full, ws.invd, ws.status, Lp, (long)P, 1.0));
             else GCHK(tvk_chol_batched(c->stream, R, nb, ws.full, ws.invd, ws.panel, ws.status));
@@ -276,7 +279,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         if ((rc = check_status(c, ws.status, nb, "tv: L"))) { free_owned(); return rc; }
         if (accumulate) {
             // E = L^-1 + w w^T (packed, reusing Lp) ; A += N^T E ; Cmx += W^T F ; R += sum E ; r, meanW += sum w
-            GCHK(tvk_pack_sym(c->stream, R, nb, ws.inv, (long)RR, Wc, Lp, (long)P));
+            if (!packed_in) GCHK(tvk_pack_sym(c->stream, R, nb, ws.inv, (long)RR, Wc, Lp, (long)P));
             GCHK(tvk_dgemm(c->stream, true, false, C, (int)P, nb, 1.0, Nc, C, 0, Lp, (long)P, 0, 1.0, d_a, (long)P, 0, 1));
             GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, nb, 1.0, Wc, R, 0, Fc, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
             GCHK(tvk_batch_sum(c->stream, (long)P, nb, Lp, (long)P, d_rp));

@@ -476,11 +476,16 @@ __device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1
         }
     }
 }
-__global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv)
+// packed != NULL: instead of the full matrix, E = inv + w w^T goes out as PACKED lower rows (stride sp) -- what the T-matrix
+// E-step accumulates (A_c += N_uc E_u): no full inverse in memory, no matrix-vector pass, no pack pass.
+__global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv,
+                                                const double *__restrict__ wv, double *__restrict__ packed, long sp)
 {
     const long n = n_;
     const double *Um = Ufull + (size_t)blockIdx.x * n * n;
-    double *Om = inv + (size_t)blockIdx.x * n * n;
+    double *Om = inv ? inv + (size_t)blockIdx.x * n * n : nullptr;
+    double *Pk = packed ? packed + (size_t)blockIdx.x * sp : nullptr;
+    const double *wm = wv ? wv + (size_t)blockIdx.x * n : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
     const int perm = 4 * (i16 & 3) + (i16 >> 2);
     const int nfl = n_ & ~31;
@@ -523,7 +528,17 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
             }
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                if (u < cnt && rows[u] < n) {
+                if (u < cnt && rows[u] < n && Pk) {
+                    const long row = rows[u];
+                    const double wr = wm ? wm[row] : 0.0;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const long c0 = j0 + 16 * ct + 4 * q;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c0 + r <= row) Pk[row * (row + 1) / 2 + c0 + r] = acc[u][ct][r] + (wm ? wr * wm[c0 + r] : 0.0);
+                    }
+                } else if (u < cnt && rows[u] < n) {
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const long c0 = j0 + 16 * ct + 4 * q;
@@ -558,6 +573,21 @@ int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, d
     const int nblk = (n + 31) / 32;
     k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status, Apacked, spk, diag_add);
     k_trinv_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, U);
-    k_uut<<<nb, 512, 0, st>>>(n, U, inv);
+    k_uut<<<nb, 512, 0, st>>>(n, U, inv, nullptr, nullptr, 0);
+    return (int)hipGetLastError();
+}
+
+// T-matrix E-step form: A[b] arrives as packed lower rows + diag_add I in P[b] (stride sp); on return W[b] = A^-1 aux[b] and
+// P[b] holds E[b] = A^-1 + w w^T, packed.  Lf / U: scratch nb*n*n each (factor, triangular inverse).
+int tvk_inverse_e_packed_batched(hipStream_t st, int n, int nb, double *Lf, double *U, double *invd, int *status, double *P, long sp,
+                                 double diag_add, const double *aux, double *W)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    const int nblk = (n + 31) / 32;
+    k_chol_left<<<nb, 512, 0, st>>>(n, Lf, invd, (long)nblk * 1024, status, P, sp, diag_add);
+    int rc = tvk_chol_solve_batched(st, n, nb, Lf, invd, aux, W);
+    if (rc) return rc;
+    k_trinv_left<<<nb, 512, 0, st>>>(n, Lf, invd, (long)nblk * 1024, U);
+    k_uut<<<nb, 512, 0, st>>>(n, U, nullptr, W, P, sp);
     return (int)hipGetLastError();
 }

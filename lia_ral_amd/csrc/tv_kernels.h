@@ -55,3 +55,5 @@ int tvk_jfa_z_and_d(hipStream_t st, long nspk, int C, int D, const double *N, co
 int tvk_dgemm_epi(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, const double *B,
                   long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst);
 int tvk_rsqrt_vec(hipStream_t st, long n, double *v);
+int tvk_inverse_e_packed_batched(hipStream_t st, int n, int nb, double *Lf, double *U, double *invd, int *status, double *P, long sp,
+                                 double diag_add, const double *aux, double *W);
