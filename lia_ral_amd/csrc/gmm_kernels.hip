@@ -834,13 +834,23 @@ __global__ __launch_bounds__(256) void k_frame_moments(const void *__restrict__ 
         __syncthreads();
     }
 }
-__global__ void k_moments_reduce(const double *__restrict__ partial, int nb, int n, double *__restrict__ acc)
+// acc[e] += sum over the nb block partials, fixed order (deterministic): one workgroup per 4 columns, 64 lanes x 4 column
+// slots walk the blocks (a single workgroup looping over 2048 partial rows took longer than the streaming pass itself)
+__global__ __launch_bounds__(256) void k_moments_reduce(const double *__restrict__ partial, int nb, int n, double *__restrict__ acc)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + slot;
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * n + e];
-    acc[e] += s;
+    if (e < n)
+        for (int b = lane; b < nb; b += 64) s += partial[(size_t)b * n + e];
+    red[slot][lane] = s;
+    __syncthreads();
+    if (lane == 0 && e < n) {
+        double t = 0.0;
+        for (int l = 0; l < 64; ++l) t += red[slot][l];
+        acc[e] += t;
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1110,14 +1120,69 @@ int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, 
     return (int)hipGetLastError();
 }
 
+// Streaming variant for dense rows (ldx == D) whose length is a multiple of the 16-byte vector (4 floats / 2 doubles): the
+// matrix is one flat stream, lane i loads vector i of its block's slice and -- the block size being a multiple of the
+// D / V vectors of a row -- always sees the same V columns, so it keeps V sums and V sums of squares in registers.
+// 4 independent 16-byte loads in flight per lane (the scalar kernel has one 4-byte load per lane and iteration).
+template <typename XT>
+__global__ __launch_bounds__(256) void k_frame_moments_vec(const XT *__restrict__ x, long nvec, int D, int nthr, double *__restrict__ partial)
+{
+    constexpr int V = 16 / sizeof(XT);
+    typedef XT vec_t __attribute__((ext_vector_type(V)));
+    __shared__ double red[256][2 * V];
+    const int tid = threadIdx.x;
+    double s[V], ss[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { s[k] = 0.0; ss[k] = 0.0; }
+    if (tid < nthr) {
+        const vec_t *xv = (const vec_t *)x;
+        const long stride = (long)gridDim.x * nthr;
+        long j = (long)blockIdx.x * nthr + tid;
+        for (; j + 3 * stride < nvec; j += 4 * stride) {
+            const vec_t a = __builtin_nontemporal_load(xv + j), b = __builtin_nontemporal_load(xv + j + stride),
+                        c = __builtin_nontemporal_load(xv + j + 2 * stride), d = __builtin_nontemporal_load(xv + j + 3 * stride);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const double va = (double)a[k], vb = (double)b[k], vc = (double)c[k], vd = (double)d[k];
+                s[k] += (va + vb) + (vc + vd);
+                ss[k] = __builtin_fma(va, va, __builtin_fma(vb, vb, __builtin_fma(vc, vc, __builtin_fma(vd, vd, ss[k]))));
+            }
+        }
+        for (; j < nvec; j += stride) {
+            const vec_t a = xv[j];
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const double va = (double)a[k]; s[k] += va; ss[k] = __builtin_fma(va, va, ss[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) { red[tid][k] = s[k]; red[tid][V + k] = ss[k]; }
+    __syncthreads();
+    // column c = V g + k lives in the threads t = g, g + G, g + 2 G, ... (G = D / V vectors per row)
+    const int G = D / V;
+    for (int e = tid; e < 2 * D; e += 256) {
+        const int sq = e >= D, c = sq ? e - D : e, g = c / V, k = c - g * V;
+        double acc = 0.0;
+        for (int t = g; t < nthr; t += G) acc += red[t][sq * V + k];
+        partial[(size_t)blockIdx.x * 2 * D + e] = acc;
+    }
+}
+
 int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, double *partial,
                        int max_blocks, double *acc)
 {
     if (T <= 0) return 0;
     int nb = (int)((T + 3) / 4);
     if (nb > max_blocks) nb = max_blocks;
-    if (x_f64) k_frame_moments<double><<<nb, 256, 0, st>>>(x, T, ldx, D, partial);
+    const int V = x_f64 ? 2 : 4;
+    if (ldx == D && D % V == 0 && D / V <= 256 && ((size_t)x % 16) == 0) { // dense rows: the flat-stream kernel
+        const int G = D / V, nthr = G * (256 / G);
+        const long nvec = T * G;
+        long want = (nvec + (long)nthr * 8 - 1) / ((long)nthr * 8); // >= 8 vectors per lane
+        if (want < nb) nb = (int)(want < 1 ? 1 : want);
+        if (x_f64) k_frame_moments_vec<double><<<nb, 256, 0, st>>>((const double *)x, nvec, D, nthr, partial);
+        else k_frame_moments_vec<float><<<nb, 256, 0, st>>>((const float *)x, nvec, D, nthr, partial);
+    } else if (x_f64) k_frame_moments<double><<<nb, 256, 0, st>>>(x, T, ldx, D, partial);
     else k_frame_moments<float><<<nb, 256, 0, st>>>(x, T, ldx, D, partial);
-    k_moments_reduce<<<(2 * D + 255) / 256, 256, 0, st>>>(partial, nb, 2 * D, acc);
+    k_moments_reduce<<<(2 * D + 3) / 4, 256, 0, st>>>(partial, nb, 2 * D, acc);
     return (int)hipGetLastError();
 }
