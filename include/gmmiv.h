@@ -61,6 +61,8 @@ const char *gmmiv_version(void);
  *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
  *                      used for odd orders); process-wide A/B switch
+ *   "topc_z" 1         DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (k_llk_mfma<WZ> + k_topc_from_z, direct form only
+ *                      for the candidates); 0: the direct-form VALU kernel for every Gaussian
  *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)
  *   "glds", "wg_waves", "em_chunks", "dbg": A/B switches of the measurement tools */
 long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);

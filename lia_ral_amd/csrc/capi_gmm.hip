@@ -92,6 +92,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
     else if (!strcmp(key, "z_waves")) slot = &c->z_waves;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
+    else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
         gmmk_stats_z_set_tv4((int)value);
         return 0;
@@ -315,6 +316,11 @@ int gmmiv_llk(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
     return o_sum.finish();
 }
 
+// stored-likelihood helpers (defined with the EM path below)
+static long z_tile_blocks(int64_t n);
+static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g);
+static const void *x_at(const XView &xv, int dt, int64_t frame);
+
 int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, int ctop,
                             int mode, double min_llk, double max_llk, int32_t *idx, double *lk, double *nontop_lk,
                             double *nontop_llk, double *nontop_w, double *llk_out)
@@ -335,11 +341,48 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     if ((rc = o_nllk.init(c, WS_T3, nontop_llk, (size_t)T, false))) return rc;
     if ((rc = o_nw.init(c, WS_T4, nontop_w, (size_t)T, false))) return rc;
     if ((rc = o_llk.init(c, WS_T5, llk_out, (size_t)T, false))) return rc;
-    c->t_begin("k_topc_determine");
-    GCHK(gmmk_topc_determine(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc,
-                             g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_idx.d, o_lk.d, o_nlk.d,
-                             o_nllk.d, o_nw.d, o_llk.d));
-    c->t_end();
+    // Fast path: all logits on the matrix cores (k_llk_mfma<WZ>, the EM path's kernel), selection on the stored likelihoods, the
+    // direct form only for the candidates (topc_z.hip).  Redone with the direct-form kernel in the (never observed) case that a
+    // non-candidate comes within 1e-6 of the selected set.
+    bool done = false;
+    const int64_t Tc = c->topc_z ? z_chunk_frames(c, g) : 0;
+    if (Tc > 0 && T > 0 && ctop + 4 <= 64 && gmmk_topc_z_lds(g->nct, g->D)) {
+        const int64_t first = T < Tc ? T : Tc;
+        const long nfb = z_tile_blocks(first);
+        void *zb, *eit, *inv, *lse, *flg;
+        if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
+        if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
+        if ((rc = c->scratch(WS_INV, (size_t)first * (sizeof(double) + sizeof(int)), &inv))) return rc;
+        if ((rc = c->scratch(WS_LSE, (size_t)first * sizeof(double), &lse))) return rc;
+        if ((rc = c->scratch(WS_FLAGS, 64, &flg))) return rc;
+        int *efin = (int *)((double *)inv + first);
+        GCHK(hipMemsetAsync(flg, 0, sizeof(int), c->stream));
+        for (int64_t c0 = 0; c0 < T; c0 += Tc) {
+            const int64_t n = (T - c0) < Tc ? (T - c0) : Tc;
+            c->t_begin("k_llk_mfma", c0 == 0);
+            GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lse,
+                            (int)c->use_glds, (double *)zb, nfb, (int *)eit, (double *)inv, efin));
+            c->t_end();
+            c->t_begin("k_topc_from_z", c0 == 0);
+            GCHK(gmmk_topc_from_z(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->C, g->nct, (const double *)zb, nfb,
+                                  (const int *)eit, efin, g->mean, g->iv, g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk,
+                                  max_llk, o_idx.d + (size_t)c0 * ctop, o_lk.d ? o_lk.d + (size_t)c0 * ctop : nullptr,
+                                  o_nlk.d ? o_nlk.d + c0 : nullptr, o_nllk.d ? o_nllk.d + c0 : nullptr, o_nw.d ? o_nw.d + c0 : nullptr,
+                                  o_llk.d ? o_llk.d + c0 : nullptr, (int *)flg));
+            c->t_end();
+        }
+        int hflag = 0;
+        GCHK(hipMemcpyAsync(&hflag, flg, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        done = hflag == 0;
+    }
+    if (!done) {
+        c->t_begin("k_topc_determine");
+        GCHK(gmmk_topc_determine(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc,
+                                 g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_idx.d, o_lk.d, o_nlk.d,
+                                 o_nllk.d, o_nw.d, o_llk.d));
+        c->t_end();
+    }
     if ((rc = o_idx.finish())) return rc;
     if ((rc = o_lk.finish())) return rc;
     if ((rc = o_nlk.finish())) return rc;

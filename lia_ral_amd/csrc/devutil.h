@@ -183,6 +183,63 @@ __device__ __forceinline__ int row_max_i32(int v)
     return v;
 }
 
+// Wave-wide arg-max of (value, index) pairs, larger value first, smaller index on ties; every lane gets the winner.
+// DPP row rotations inside the 16-lane rows (plain VALU instructions), then the 4 row results through v_readlane and scalar
+// compares -- a ds_bpermute butterfly is 6 dependent LDS-pipe round trips of 3 permutes each (~2000 cycles per arg-max).
+__device__ __forceinline__ void wave_argmax_f64(double &v, int &c)
+{
+#define GMMIV_ARGMAX_STEP(CTRL)                                                                    \
+    {                                                                                              \
+        const int ohi = dpp_i32<CTRL>(__double2hiint(v)), olo = dpp_i32<CTRL>(__double2loint(v)); \
+        const int oc = dpp_i32<CTRL>(c);                                                           \
+        const double ov = __hiloint2double(ohi, olo);                                              \
+        if (ov > v || (ov == v && oc < c)) { v = ov; c = oc; }                                     \
+    }
+    GMMIV_ARGMAX_STEP(0x128)
+    GMMIV_ARGMAX_STEP(0x124)
+    GMMIV_ARGMAX_STEP(0x122)
+    GMMIV_ARGMAX_STEP(0x121)
+#undef GMMIV_ARGMAX_STEP
+    // row 0's own result takes part through lane 0
+    const double v0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const int c0 = __builtin_amdgcn_readlane(c, 0);
+    double wv = v0;
+    int wc = c0;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const double ov = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * r), __builtin_amdgcn_readlane(__double2loint(v), 16 * r));
+        const int oc = __builtin_amdgcn_readlane(c, 16 * r);
+        if (ov > wv || (ov == wv && oc < wc)) { wv = ov; wc = oc; }
+    }
+    v = wv;
+    c = wc;
+}
+
+// DPP versions of the wave reductions (row rotations + 4 v_readlane): no LDS-pipe round trips.  Every lane gets the result.
+__device__ __forceinline__ double dpp_f64_0x128(double v) { return __hiloint2double(dpp_i32<0x128>(__double2hiint(v)), dpp_i32<0x128>(__double2loint(v))); }
+__device__ __forceinline__ double dpp_f64_0x124(double v) { return __hiloint2double(dpp_i32<0x124>(__double2hiint(v)), dpp_i32<0x124>(__double2loint(v))); }
+__device__ __forceinline__ double dpp_f64_0x122(double v) { return __hiloint2double(dpp_i32<0x122>(__double2hiint(v)), dpp_i32<0x122>(__double2loint(v))); }
+__device__ __forceinline__ double dpp_f64_0x121(double v) { return __hiloint2double(dpp_i32<0x121>(__double2hiint(v)), dpp_i32<0x121>(__double2loint(v))); }
+__device__ __forceinline__ double readlane_f64u(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v)
+{
+    v += dpp_f64_0x128(v); v += dpp_f64_0x124(v); v += dpp_f64_0x122(v); v += dpp_f64_0x121(v);
+    return (readlane_f64u(v, 0) + readlane_f64u(v, 16)) + (readlane_f64u(v, 32) + readlane_f64u(v, 48));
+}
+__device__ __forceinline__ double wave_max_f64_dpp(double v)
+{
+    v = fmax(v, dpp_f64_0x128(v)); v = fmax(v, dpp_f64_0x124(v)); v = fmax(v, dpp_f64_0x122(v)); v = fmax(v, dpp_f64_0x121(v));
+    return fmax(fmax(readlane_f64u(v, 0), readlane_f64u(v, 16)), fmax(readlane_f64u(v, 32), readlane_f64u(v, 48)));
+}
+__device__ __forceinline__ double wave_min_f64_dpp(double v)
+{
+    v = fmin(v, dpp_f64_0x128(v)); v = fmin(v, dpp_f64_0x124(v)); v = fmin(v, dpp_f64_0x122(v)); v = fmin(v, dpp_f64_0x121(v));
+    return fmin(fmin(readlane_f64u(v, 0), readlane_f64u(v, 16)), fmin(readlane_f64u(v, 32), readlane_f64u(v, 48)));
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);

@@ -50,3 +50,8 @@ int gmmk_stats_z_wg_per_cu(void);
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
                  long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,
                  double *out0, double *out1, int mode, int accum, double prune_thr);
+size_t gmmk_topc_z_lds(int nct, int D);
+int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx, int D, int C, int nct, const double *zbuf, long nfb,
+                     const int *eit, const int *efin, const double *mean, const double *iv, const double *lwc,
+                     const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                     double *nw, double *llk, int *flag);

@@ -1,0 +1,225 @@
+// topc_z.hip -- DETERMINE_TOP_DISTRIBS (ComputeTest's world-model pass: LIA_SpkDet/ComputeTest/src/ComputeTest.cpp:163-167,
+// LIA_SpkTools/src/TopGauss.cpp:167-193) from the STORED scaled likelihoods of k_llk_mfma<WZ>.
+//
+// The first version evaluated every logit in the reference's own form a_c - 1/2 sum (x - mu)^2 iv on the VALU (180 fp64
+// instructions per frame-Gaussian pair) because the selection needs an exact ordering: 37 G pairs/s, six times slower than
+// the MFMA log-likelihood kernel next to it.  Only the handful of Gaussians that end up selected need that care:
+//   1. k_llk_mfma<WZ> evaluates all logits on the matrix cores and leaves e = exp(z) 2^-E in HBM (the EM path's kernel,
+//      unchanged; |z_mfma - z_exact| ~ 1e-12);
+//   2. this kernel, one workgroup per 8 frames: the frame's C values v = e 2^(E - Efin) go to REGISTERS (32 per lane); ctop + 4
+//      rounds of wave-wide arg-max pick the candidates by v; the candidates' logits are recomputed in the direct form and ranked on
+//      those (ties: lowest index, like the reference's stable order); the best NON-candidate must lie 1e-6 below the weakest
+//      selected logit -- a million times the MFMA error -- or the call is redone with the direct-form kernel (flag);
+//   3. the non-selected remainder is the plain sum of the other v (no total - top cancellation) plus the rejected candidates.
+#include "devutil.h"
+#include "gmm_kernels.h"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <typename XT>
+__global__ __launch_bounds__(256, 2) void k_topc_from_z(const void *__restrict__ x, long n, long ldx, int D, int C, int nct,
+                                                        const double *__restrict__ zbuf, long nfb, const int *__restrict__ eit,
+                                                        const int *__restrict__ efin, const double *__restrict__ mean,
+                                                        const double *__restrict__ iv, const double *__restrict__ lwc,
+                                                        const double *__restrict__ w, int ctop, int complete, double lo, double hi,
+                                                        int *__restrict__ idx_out, double *__restrict__ lk_out,
+                                                        double *__restrict__ nontop_lk, double *__restrict__ nontop_llk,
+                                                        double *__restrict__ nontop_w, double *__restrict__ llk_out, int *__restrict__ flag)
+{
+    // Workgroup = 8 frames of one 16-frame likelihood block: wave w takes the frames of lane group q0 = w, registers
+    // r = 2 half + j (j = 0, 1).  A frame's 2048 values sit in the 16 lanes (i16) of that group of each tile's block; here lane
+    // (i16, qq) of the wave loads them for the tiles 4 m + qq: 32 values per lane and frame, IN REGISTERS -- the selection rounds
+    // are register compares + one wave arg-max, nothing is re-read (the first version kept the values in LDS and re-scanned
+    // them every round: one LDS latency per element and round, 56 ms per 10^6 frames, all of it in the selection).
+    __shared__ double xs[8][64 + 1];
+    __shared__ int ord[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qq = lane >> 4;
+    const long fb = blockIdx.x >> 1;
+    const int half = blockIdx.x & 1, q0 = wave;
+    for (int e = tid; e < 8 * D; e += 256) { // frame rows for the exact logits: local frame 2 w + j
+        const int lf = e / D, d = e - lf * D;
+        const long t = fb * 16 + (lf >> 1) + 4 * (2 * half + (lf & 1));
+        xs[lf][d] = t < n ? feat_load<XT>::get(x, t * ldx + d) : 0.0;
+    }
+    long tj[2];
+    int ef[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        tj[j] = fb * 16 + q0 + 4 * (2 * half + j);
+        ef[j] = tj[j] < n ? efin[tj[j]] : 0;
+    }
+    double val[2][32];
+    // Loads first (tile index clamped), in two batches of 16 tiles, each closed by a compiler barrier: without it hipcc moves
+    // every load into the `ct < nct` arm that consumes it -- 32 basic blocks, each waiting for its own load.
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        d2 e2[16];
+        int e0[16], e1[16];
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) {
+            const int ct = 4 * (16 * h + mm) + qq, cc = ct < nct ? ct : nct - 1;
+            e2[mm] = *(const d2 *)(zbuf + (((size_t)cc * nfb + fb) * 64 + 16 * q0 + i16) * 4 + 2 * half);
+            const int *ep = eit + (size_t)(cc >> 1) * (nfb * 16) + fb * 16 + q0 + 8 * half;
+            e0[mm] = ep[0];
+            e1[mm] = ep[4];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) {
+            const int m = 16 * h + mm, ct = 4 * m + qq;
+            const double a0 = __builtin_ldexp(e2[mm][0], e0[mm] - ef[0]), a1 = __builtin_ldexp(e2[mm][1], e1[mm] - ef[1]);
+            val[0][m] = ct < nct ? a0 : -1.0;
+            val[1][m] = ct < nct ? a1 : -1.0;
+        }
+    }
+    __syncthreads();
+
+    const double NINF = -__builtin_inf();
+    const int K = ctop + 4 < C ? ctop + 4 : C; // candidates (host: K <= 64)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long t = tj[j];
+        if (t >= n) continue;
+        const int lf = 2 * wave + j;
+        // Candidates without rescanning: theta = the K-th largest of the 64 per-lane maxima (K arg-max rounds over ONE value
+        // per lane).  At least K values are >= theta, so the K largest of the frame all are: every value >= theta is a
+        // candidate (typically K .. 2K of them), compacted into LDS with ballots.
+        double lm;
+        {
+            double t16[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t16[i] = fmax(val[j][i], val[j][i + 16]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t16[i] = fmax(t16[i], t16[i + 8]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t16[i] = fmax(t16[i], t16[i + 4]);
+            lm = fmax(fmax(t16[0], t16[2]), fmax(t16[1], t16[3]));
+        }
+        double theta = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double gv = lm;
+            int gl = lane;
+            wave_argmax_f64(gv, gl);
+            theta = gv;
+            if (lane == gl) lm = -1.0;
+        }
+        if (!(theta > 0.0)) theta = 4.9e-324; // fewer than K lanes carry mass: every positive value is a candidate
+        int nc = 0;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const bool hit = val[j][m] >= theta;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+            if (mask) {
+                if (hit) {
+                    const int pos = nc + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    if (pos < 64) ord[wave][pos] = 16 * (4 * m + qq) + i16;
+                }
+                nc += __builtin_popcountll(mask);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (nc > 64) { if (lane == 0) atomicExch(flag, 1); continue; } // a pile-up of equal values: the direct-form kernel redoes the call
+        const int ci = lane < nc ? ord[wave][lane] : 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+        const double vnext = theta; // every non-candidate is below theta
+        // exact logits of the candidates
+        const bool cand = lane < nc && ci < C;
+        double zc = NINF;
+        if (cand) {
+            // the candidate's own rows of the row-major model: contiguous, all loads of a pass in flight together (the transposed
+            // copy would be D dependent strided gathers per candidate)
+            const double *mu = mean + (size_t)ci * D, *vi = iv + (size_t)ci * D;
+            double acc = 0.0;
+            int d = 0;
+            for (; d + 8 <= D; d += 8) {
+                double m8[8], v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { m8[u] = mu[d + u]; v8[u] = vi[d + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double dx = xs[lf][d + u] - m8[u];
+                    acc = __builtin_fma(dx * dx, v8[u], acc);
+                }
+            }
+            for (; d < D; ++d) {
+                const double dx = xs[lf][d] - mu[d];
+                acc = __builtin_fma(dx * dx, vi[d], acc);
+            }
+            zc = __builtin_fma(-0.5, acc, lwc[ci]);
+        }
+        int rank = 0;
+        for (int jj = 0; jj < nc; ++jj) {
+            const double zj = readlane_f64u(zc, jj); // jj is wave-uniform: v_readlane, not a permute through LDS
+            const int cj = __builtin_amdgcn_readlane(ci, jj);
+            if (jj != lane && (zj > zc || (zj == zc && cj < ci))) ++rank;
+        }
+        const bool sel = cand && rank < ctop;
+        const double M = wave_max_f64_dpp(zc);
+        // weakest selected logit vs the best non-candidate (from the stored likelihoods: exp(z) = v 2^Efin)
+        const double zmin = wave_min_f64_dpp(sel ? zc : __builtin_inf());
+        const double lnE = (double)ef[j] * 0.6931471805599453;
+        if (nc > ctop && log(vnext) + lnE > zmin - 1e-6) { if (lane == 0) atomicExch(flag, 1); }
+        // remainder: non-candidates straight from the stored values, rejected candidates from their exact logits
+        double sr = 0.0;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) sr += (val[j][m] > 0.0 && val[j][m] < theta) ? val[j][m] : 0.0;
+        sr = wave_sum_f64_dpp(sr);
+        double srel = sr > 0.0 ? exp(log(sr) + lnE - M) : 0.0;
+        srel += wave_sum_f64_dpp((cand && !sel) ? gexp(zc - M) : 0.0);
+        const double st = wave_sum_f64_dpp(sel ? gexp(zc - M) : 0.0);
+        if (sel) {
+            idx_out[t * ctop + rank] = ci;
+            if (lk_out) lk_out[t * ctop + rank] = exp(zc);
+            ord[wave][rank] = ci;
+        }
+        if (lane == 0) {
+            const double rest_llk = srel > 0.0 ? M + log(srel) : NINF;
+            if (nontop_llk) nontop_llk[t] = rest_llk;
+            if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+            if (llk_out) {
+                const double tot = complete ? st + srel : st;
+                llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+            }
+        }
+        if (nontop_w) { // 1 - sum of selected weights, subtracted in selection order (TopGauss.cpp:183-186)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                double snsw = 1.0;
+                for (int k = 0; k < ctop; ++k) snsw -= w[ord[wave][k]];
+                nontop_w[t] = snsw;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+#define HIPCHK(e)                                                         \
+    do {                                                                  \
+        hipError_t _e = (e);                                              \
+        if (_e != hipSuccess) return (int)_e;                             \
+    } while (0)
+
+// 1 when the kernel applies (a lane holds 32 values per frame: at most 128 Gaussian tiles; frame rows of at most 64 dims)
+size_t gmmk_topc_z_lds(int nct, int D) { return (nct <= 128 && D <= 64) ? 1 : 0; }
+
+int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx, int D, int C, int nct, const double *zbuf, long nfb,
+                     const int *eit, const int *efin, const double *mean, const double *iv, const double *lwc,
+                     const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                     double *nw, double *llk, int *flag)
+{
+    if (n <= 0) return 0;
+    if (!gmmk_topc_z_lds(nct, D)) return -1;
+    const size_t lds = 0;
+    const unsigned grid = (unsigned)(2 * ((n + 15) / 16));
+    if (x_f64)
+        k_topc_from_z<double><<<grid, 256, lds, st>>>(x, n, ldx, D, C, nct, zbuf, nfb, eit, efin, mean, iv, lwc, w, ctop, complete,
+                                                      lo, hi, idx, lk, nlk, nllk, nw, llk, flag);
+    else
+        k_topc_from_z<float><<<grid, 256, lds, st>>>(x, n, ldx, D, C, nct, zbuf, nfb, eit, efin, mean, iv, lwc, w, ctop, complete, lo,
+                                                     hi, idx, lk, nlk, nllk, nw, llk, flag);
+    return (int)hipGetLastError();
+}
