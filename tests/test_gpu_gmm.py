@@ -411,3 +411,24 @@ def test_linearity_property_full_size(ctx):
     f, p = full.cpu().numpy(), parts.cpu().numpy()
     assert relerr(p, f) < 1e-11
     assert abs(f[:2048].sum() - 200_000) < 1e-6
+
+
+@pytest.mark.parametrize("spread", [2.0, 0.3])
+def test_top_c_paths_agree(ctx, spread):
+    """DETERMINE_TOP_DISTRIBS: the stored-likelihood path (k_llk_mfma<WZ> + k_topc_from_z) against the direct-form kernel on the
+    same frames -- identical indices, values to 1e-9 -- on well separated and on heavily overlapping mixtures."""
+    C, D, T = 2048, 60, 3000
+    w, mean, iv = make_gmm(C, D, seed=5, spread=spread)
+    x = make_frames(w, mean, iv, T, seed=6).astype(np.float32)
+    g = ctx.gmm(w, mean, iv)
+    res = {}
+    for z in (1, 0):
+        ctx.set_option("topc_z", z)
+        res[z] = g.llk_determine_top(x, 10, complete=True)
+    ctx.set_option("topc_z", 1)
+    assert np.array_equal(res[1]["idx"], res[0]["idx"])
+    for k in ("lk", "nontop_lk", "llk", "nontop_w"):
+        assert relerr(res[1][k], res[0][k]) < 1e-9, k
+    fin = np.isfinite(res[0]["nontop_llk"])
+    assert np.array_equal(fin, np.isfinite(res[1]["nontop_llk"]))
+    assert np.max(np.abs(res[1]["nontop_llk"][fin] - res[0]["nontop_llk"][fin])) < 1e-8
