@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256, 2) void k_topc_from_z(const void *__restrict__
     // them every round: one LDS latency per element and round, 56 ms per 10^6 frames, all of it in the selection).
     __shared__ double xs[8][64 + 1];
     __shared__ int ord[4][64];
+    __shared__ __attribute__((aligned(16))) double lmx[4][64];
+    __shared__ double thx[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qq = lane >> 4;
     const long fb = blockIdx.x >> 1;
     const int half = blockIdx.x & 1, q0 = wave;
@@ -95,14 +97,24 @@ __global__ __launch_bounds__(256, 2) void k_topc_from_z(const void *__restrict__
             for (int i = 0; i < 4; ++i) t16[i] = fmax(t16[i], t16[i + 4]);
             lm = fmax(fmax(t16[0], t16[2]), fmax(t16[1], t16[3]));
         }
-        double theta = 0.0;
-        for (int k = 0; k < K; ++k) {
-            double gv = lm;
-            int gl = lane;
-            wave_argmax_f64(gv, gl);
-            theta = gv;
-            if (lane == gl) lm = -1.0;
+        // K-th largest of the 64 lane maxima: every lane ranks its own value against all 64 (LDS broadcast reads, ~200
+        // instructions; K rounds of wave arg-max were 1400)
+        lmx[wave][lane] = lm;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int lrank = 0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const double o = lmx[wave][i];
+            lrank += (o > lm || (o == lm && i < lane)) ? 1 : 0;
         }
+        if (lrank == K - 1) thx[wave] = lm;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double theta = thx[wave];
+        __builtin_amdgcn_wave_barrier();
         if (!(theta > 0.0)) theta = 4.9e-324; // fewer than K lanes carry mass: every positive value is a candidate
         int nc = 0;
 #pragma unroll
