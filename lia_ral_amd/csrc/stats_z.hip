@@ -91,15 +91,28 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     double stg_inv = 0.0;
     int stg_ef = 0, stg_e[PF];
     const int npad = FT * (RL - D);
-    unsigned pk[NLD], goff[NLD];
+    // staging plan of element i of this thread: pk = (tile row << 16 | LDS byte offset), goff = offset in the frame block.
+    // Kept in registers (2 x NLD) except in the 4-tile shape, whose 128 accumulator + 64 stream registers leave no room:
+    // there it is recomputed at every stage (a dozen integer instructions per element and 64-frame tile).
+    constexpr bool PLAN_IN_REGS = TPW < 4;
     const bool contig = (ldx == D);
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
+    auto plan_pk = [&](int i) -> unsigned {
         const int e = tid + NT * i;
         const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
-        pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
-        goff[i] = fr < FT ? (contig ? (unsigned)e : (unsigned)(fr * (int)ldx + d)) : 0u;
+        return fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
+    };
+    auto plan_goff = [&](int i) -> unsigned {
+        const int e = tid + NT * i;
+        const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
+        return fr < FT ? (contig ? (unsigned)e : (unsigned)(fr * (int)ldx + d)) : 0u;
+    };
+    unsigned pk_r[PLAN_IN_REGS ? NLD : 1], goff_r[PLAN_IN_REGS ? NLD : 1];
+    if constexpr (PLAN_IN_REGS) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) { pk_r[i] = plan_pk(i); goff_r[i] = plan_goff(i); }
     }
+#define PK(i) (PLAN_IN_REGS ? pk_r[PLAN_IN_REGS ? (i) : 0] : plan_pk(i))
+#define GOFF(i) (PLAN_IN_REGS ? goff_r[PLAN_IN_REGS ? (i) : 0] : plan_goff(i))
     // ftile[2][NW][PF][FT]: per frame of the tile, per wave and per tile pair of the wave, the factor that turns a stored likelihood into a
     // posterior, f = scale / S_t * 2^(E - Efin) with E the running exponent of the wave's tile pair (0 outside [f0, f1))
     double *ftile = buf1 + FT * RLp;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         const XT *xt = (const XT *)x + fb * ldx;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            stg[i] = xt[pk[i] < lim ? goff[i] : 0u]; // unconditional (clamped, masked at use): no branch per element
+            stg[i] = xt[PK(i) < lim ? GOFF(i) : 0u]; // unconditional (clamped, masked at use): no branch per element
         }
         const long t = fb + srow < f1 ? fb + srow : f1 - 1;
         stg_inv = inv[t];
@@ -128,7 +141,10 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         const unsigned lim = rem >= FT ? (unsigned)FT << 16 : (unsigned)rem << 16;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = pk[i] < lim ? (double)stg[i] : 0.0;
+        {
+            const unsigned pki = PK(i);
+            if (pki < ((unsigned)FT << 16)) *(double *)((char *)dst + (pki & 0xffffu)) = pki < lim ? (double)stg[i] : 0.0;
+        }
         if (lane < FT) { // rows outside [f0, f1) get f = 0 -> posterior 0
             const long t = fb + lane;
 #pragma unroll
@@ -149,16 +165,15 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
 
     // likelihood stream: block n of tile t is 2 KB at zp[t] + n * 256 doubles, 32 bytes per lane.
     // Two register sets, alternating between even and odd blocks (the tile loop is unrolled).
-    const double *zp[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) zp[t] = zbuf + ((((size_t)(active ? ct0 + t : 0)) * nfb + (fa >> 4)) * 64 + lane) * 4;
+    const double *zp0 = zbuf + ((((size_t)(active ? ct0 : 0)) * nfb + (fa >> 4)) * 64 + lane) * 4;
+    const size_t ztile = (size_t)nfb * 256; // doubles between consecutive tiles (uniform)
     d2 zA[TPW][2], zB[TPW][2];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) { zA[t][0] = (d2){0, 0}; zA[t][1] = zA[t][0]; zB[t][0] = zA[t][0]; zB[t][1] = zA[t][0]; }
     auto issue_z = [&](d2 (&z)[TPW][2], int n) { // streamed once, kept out of the caches (nt)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const d2 *pz = (const d2 *)(zp[t] + (size_t)n * 256);
+            const d2 *pz = (const d2 *)(zp0 + (size_t)t * ztile + (size_t)n * 256);
             z[t][0] = __builtin_nontemporal_load(pz);
             z[t][1] = __builtin_nontemporal_load(pz + 1);
         }
@@ -232,6 +247,8 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     for (int tl = 0; tl + 1 < ntiles; ++tl) tile(tl, true);
     if (ntiles > 0) tile(ntiles - 1, false);
 #undef PIN_Z
+#undef PK
+#undef GOFF
     if (!active) return;
     // D layout: lane holds column j = 16 jt + i16, rows (Gaussians) q + 4 r
 #pragma unroll
