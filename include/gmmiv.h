@@ -289,7 +289,8 @@ int gmmiv_score_plda(gmmiv_ctx *ctx, int rf, int64_t M, int64_t S, const double 
 /* F[r,c,:] -= N[r,c] (means[c,:] + (W[o] T)[c,:] + Dm[c,:] Z[o][c,:]),  o = owner ? owner[r] : r.  Every term is optional
  * (means, T/W, Dm/Z may be NULL).  N [rows x C], F [rows x C*D], T [R x C*D], W [nfact x R], Dm [C*D], Z [nfact x C*D].
  * Replaces JFAAcc::substractMplusDZ (:3805-3822), substractMplusVY (:3988-4005), substractMplusVYplusDZ (:4400-4422, owner =
- * the speaker of each session), substractMplusUX (:4336-4364), getMplusVYplusDZ / getUX (:1803-1957). */
+ * the speaker of each session), the mean part of substractMplusUX (:4336-4364; its channel part is gmmiv_jfa_subtract_sessions),
+ * getMplusVYplusDZ / getUX (:1803-1957). */
 int gmmiv_jfa_subtract(gmmiv_ctx *ctx, int64_t rows, int C, int D, const double *N, double *F, const int64_t *owner, int64_t nfact,
                        const double *means, int R, const double *T, const double *W, const double *Dm, const double *Z);
 /* F_X[s,c,:] -= sum over the sessions h in [sess_begin[s], sess_begin[s+1]) of N_h[h,c] (x_h U)[c,:]   (sessions grouped by

@@ -335,6 +335,28 @@ int liagpu_jfa_train(int device, int task, long nspk, const long *sessPerSpk, in
     })
 }
 
+// ComputeTest, JFA dot-product scoring (ComputeTest.cpp:303-358) for nTest segments given their statistics (N == N_h, F == F_h:
+// one session each) and the client supervectors [nClients x SV]; scores [nTest x nClients]
+int liagpu_jfa_dot_product(int device, long nTest, int C, int D, const double *w, const double *mean, const double *cov, int rankEV,
+                           int rankEC, const double *N, const double *F, const double *V, const double *U, const double *Dm,
+                           long nClients, const double *clientSV, double *scores)
+{
+    GUARD({
+        GpuServer srv(device);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        std::vector<unsigned long> sps((size_t)nTest, 1ul);
+        JFAAcc jfa(srv, ubm, (unsigned long)rankEV, (unsigned long)rankEC, sps);
+        const size_t SV = (size_t)C * D;
+        const std::vector<double> Nv(N, N + (size_t)nTest * C), Fv(F, F + (size_t)nTest * SV);
+        jfa.setStats(Nv, Nv, Fv, Fv);
+        jfa.loadEV(std::vector<double>(V, V + (size_t)rankEV * SV));
+        jfa.loadEC(std::vector<double>(U, U + (size_t)rankEC * SV));
+        jfa.loadD(std::vector<double>(Dm, Dm + SV));
+        std::vector<double> sc = computeTestDotProduct(srv, jfa, std::vector<double>(clientSV, clientSV + (size_t)nClients * SV), (unsigned long)nClients);
+        memcpy(scores, sc.data(), sc.size() * sizeof(double));
+    })
+}
+
 // JFA statistics from frames (JFAAcc::computeAndAccumulateJFAStat, :515-577): sessions = utterance ranges, grouped by speaker
 int liagpu_jfa_stats(int device, const float *x, long T, int D, const long *sess_begin, long nspk, const long *sessPerSpk, int C,
                      const double *w, const double *mean, const double *cov, double *N, double *N_h, double *F_X, double *F_X_h)

@@ -753,8 +753,11 @@ void JFAAcc::substractMplusVYplusDZ()
 }
 void JFAAcc::substractMplusUX()
 {
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.data(), _F_X_h.data(), nullptr,
-                                  (int64_t)_n_sessions, _ubm_means.data(), (int)_rankEC, _matU.data(), _matX.data(), nullptr, nullptr));
+    // The reference takes N_h (m + U x_h) of every session out of the SPEAKER statistics (:4344-4356).  sum_h N_h m = N m
+    // (the speaker occupancies are the sums of their sessions'), the channel parts are substractUX.
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(), nullptr,
+                                  (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, nullptr, nullptr));
+    substractUX();
 }
 void JFAAcc::orthonormalizeV()
 {
@@ -768,6 +771,32 @@ void JFAAcc::getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk)
     Sp.assign(_svSize, 0.0);
     _srv.check(gmmiv_jfa_subtract(_srv.ctx(), 1, (int)_n_distrib, (int)_vectSize, n1.data(), Sp.data(), nullptr, 1, _ubm_means.data(), (int)_rankEV,
                                   _V.data(), _Y.data() + spk * _rankEV, _D.data(), _Z.data() + spk * _svSize));
+}
+
+std::vector<double> computeTestDotProduct(GpuServer &srv, JFAAcc &jfaAcc, const std::vector<double> &clientSV, unsigned long nClients)
+{
+    const unsigned long nTest = jfaAcc.getNSpeakers();
+    if (jfaAcc.getNSessions() != nTest) throw Exception("computeTestDotProduct: one session per test segment expected");
+    const unsigned long C = jfaAcc.getN().size() / nTest, SV = jfaAcc.getF_X().size() / nTest;
+    if (clientSV.size() != nClients * SV) throw Exception("computeTestDotProduct: client supervector dimension mismatch");
+    jfaAcc.estimateUEUT();                 // ComputeTest.cpp:319-331
+    jfaAcc.estimateAndInverseL_EC();
+    jfaAcc.substractMplusVYplusDZ();
+    jfaAcc.estimateX();
+    jfaAcc.substractMplusUX();
+    // f_x /= sum_c N_c (:333-342), laid out [SV x nTest] for the product
+    std::vector<double> ft(SV * nTest);
+    for (unsigned long t = 0; t < nTest; ++t) {
+        double sumN = 0.0;
+        for (unsigned long i = 0; i < C; ++i) sumN += jfaAcc.getN()[t * C + i];
+        for (unsigned long k = 0; k < SV; ++k) ft[k * nTest + t] = jfaAcc.getF_X()[t * SV + k] / sumN;
+    }
+    // scores = M F' (:352-357): clients x tests on the device, returned test-major
+    std::vector<double> sc(nClients * nTest), out(nTest * nClients);
+    srv.check(gmmiv_iv_normalize(srv.ctx(), (int)SV, (int)nClients, (int64_t)nTest, ft.data(), nullptr, clientSV.data(), 0, sc.data()));
+    for (unsigned long c = 0; c < nClients; ++c)
+        for (unsigned long t = 0; t < nTest; ++t) out[t * nClients + c] = sc[c * nTest + t];
+    return out;
 }
 
 void eigenVoice(JFAAcc &jfaAcc, unsigned long nbIt, bool orthonormalizeV)

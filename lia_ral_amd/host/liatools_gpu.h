@@ -278,7 +278,7 @@ class JFAAcc {
     void substractMplusVY();           // :3988-4005   _F_X   -= N   (m + V y)
     void substractUX();                // :4152-4172   _F_X   -= sum_h N_h (U x_h)
     void substractMplusVYplusDZ();     // :4400-4422   _F_X_h -= N_h (m + V y + D z) of the session's speaker
-    void substractMplusUX();           // :4336-4364   _F_X_h -= N_h (m + U x_h)
+    void substractMplusUX();           // :4336-4364   _F_X   -= sum_h N_h (m + U x_h)
     void orthonormalizeV();            // :4700-4777
     void getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk); // :1926-1935
     std::vector<double> &getV() { return _V; }
@@ -307,6 +307,9 @@ class JFAAcc {
 void eigenVoice(JFAAcc &jfaAcc, unsigned long nbIt, bool orthonormalizeV);   // EigenVoice.cpp:114-147
 void eigenChannel(JFAAcc &jfaAcc, unsigned long nbIt);                        // EigenChannel.cpp:118-160
 void estimateDMatrix(JFAAcc &jfaAcc, unsigned long nbIt);                     // EstimateDMatrix.cpp:143-206
+// ComputeTest in the JFA framework, dot-product scoring (ComputeTest.cpp:303-358): every statistics row of jfaAcc is one test
+// segment (one session, y = z = 0); returns scores[nTest x nClients] = <client supervector, channel-compensated mean statistics>
+std::vector<double> computeTestDotProduct(GpuServer &srv, JFAAcc &jfaAcc, const std::vector<double> &clientSV, unsigned long nClients);
 
 // ---- PldaTools.h: PldaDev, the development set of the i-vector back-end (PldaTools.cpp:274-2005) -------------
 // _data [vectSize x n_sessions] (one i-vector per column), sessions grouped by speaker.

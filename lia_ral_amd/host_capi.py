@@ -214,6 +214,16 @@ def jfa_train(task, sess_per_spk, ubm, N, N_h, F_X, F_X_h, V, U, Dm, nb_it, Z0=N
     return dict(V=V, U=U, D=Dm, Y=Y, X=X, Z=Z)
 
 
+def jfa_dot_product(ubm, N, F, V, U, Dm, client_sv, device=0):
+    """ComputeTest dot-product scoring in the JFA framework: scores[nTest, nClients]."""
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    N, F, V, U, Dm, client_sv = [np.ascontiguousarray(a, np.float64) for a in (N, F, V, U, Dm, client_sv)]
+    sc = np.empty((N.shape[0], client_sv.shape[0]))
+    _chk(lib.liagpu_jfa_dot_product(device, ct.c_long(N.shape[0]), C, D, _d(w), _d(mean), _d(cov), V.shape[0], U.shape[0], _d(N), _d(F), _d(V),
+                                    _d(U), _d(Dm), ct.c_long(client_sv.shape[0]), _d(client_sv), _d(sc)))
+    return sc
+
 def jfa_stats(x, sess_begin, sess_per_spk, ubm, device=0):
     """JFAAcc::computeAndAccumulateJFAStat on float32 frames: returns N, N_h, F_X, F_X_h."""
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]

@@ -1290,7 +1290,7 @@ int orc_jfa_estimate_y_and_v(long nspk, int C, int D, int R, const double *N, co
 
 /* F[r] -= N[r] (.) (means + W[o] T + Dm (.) Z[o]), o = owner ? owner[r] : r -- one loop for substractMplusDZ (:3805-3822,
  * getMplusDZ :1860-1867), substractMplusVY (:3988-4005, getMplusVY :1880-1889), substractMplusVYplusDZ (:4400-4422: rows are
- * sessions, owner = their speaker), substractMplusUX (:4336-4364).  NULL terms are absent. */
+ * sessions, owner = their speaker).  NULL terms are absent. */
 void orc_jfa_subtract(long rows, int C, int D, const double *N, double *F, const long *owner, const double *means, int R,
                       const double *Tm, const double *W, const double *Dm, const double *Z)
 {
@@ -1369,3 +1369,23 @@ void orc_jfa_estimate_z_and_d(long nspk, int C, int D, const double *N, const do
     for (size_t i = 0; i < SV; ++i) Dm[i] = aux2[i] / aux1[i];
     free(aux1); free(aux2); free(L);
 }
+
+/* substractMplusUX (:4336-4364): the SPEAKER statistics lose, for every session of the speaker, N_h (.) (m + U x_h) */
+void orc_jfa_subtract_m_plus_ux(long nspk, const long *sess_begin, int C, int D, const double *N_h, double *F_X, const double *means,
+                                int R, const double *Um, const double *X)
+{
+    const size_t SV = (size_t)C * D;
+    double *mux = (double *)malloc(sizeof(double) * SV);
+    for (long spk = 0; spk < nspk; ++spk)
+        for (long h = sess_begin[spk]; h < sess_begin[spk + 1]; ++h) {
+            for (size_t i = 0; i < SV; ++i) {                                          /* getMplusUX :1902-1911 */
+                mux[i] = 0.0;
+                for (int j = 0; j < R; ++j) mux[i] += Um[j * SV + i] * X[h * R + j];
+                mux[i] += means[i];
+            }
+            for (int k = 0; k < C; ++k)
+                for (int i = 0; i < D; ++i) F_X[spk * SV + k * D + i] -= N_h[h * C + k] * mux[i + k * D]; /* :4350-4354 */
+        }
+    free(mux);
+}
+

@@ -548,3 +548,13 @@ def jfa_estimate_z_and_d(N, F, invvar, Dm):
     Z = np.zeros_like(F)
     _lib().orc_jfa_estimate_z_and_d(ct.c_long(U), ct.c_int(C), ct.c_int(D), Np, Fp, ivp, Dn.ctypes.data_as(c_dp), Z.ctypes.data_as(c_dp))
     return Z, Dn
+
+
+def jfa_subtract_m_plus_ux(sess_begin, N_h, F_X, means, U, X):
+    N_h, np_ = _d(N_h); F_X = np.array(F_X, np.float64, order="C", copy=True); m, mp = _d(means); U, up = _d(U); X, xp = _d(X)
+    sb = np.ascontiguousarray(sess_begin, np.int64)
+    C = N_h.shape[1]; D = F_X.shape[1] // C
+    _lib().orc_jfa_subtract_m_plus_ux(ct.c_long(len(sb) - 1), sb.ctypes.data_as(c_lp), ct.c_int(C), ct.c_int(D), np_,
+                                      F_X.ctypes.data_as(c_dp), mp, ct.c_int(U.shape[0]), up, xp)
+    return F_X
+

@@ -453,3 +453,25 @@ def test_jfa_statistics_from_frames():
     Ns = np.zeros((3, C)); Fs = np.zeros((3, C * D))
     np.add.at(Ns, own, No); np.add.at(Fs, own, Fo)
     assert relerr(N, Ns) < 1e-9 and relerr(FX, Fs) < 1e-9
+
+
+def test_jfa_dot_product_scoring():
+    """ComputeTest.cpp:303-358: x of every test segment (y = z = 0), SPEAKER statistics minus N_h (m + U x), normalised by the
+    occupancy, dotted with the client supervectors -- against the same steps assembled from the oracle's JFAAcc restatement
+    (pins substractMplusUX to the reference's semantics: it modifies _F_X, not _F_X_h)."""
+    from lia_ral_amd import host_capi as hc
+    p = _jfa_problem(seed=9, nspk=7)
+    C, D = p["C"], p["Dm"]; SV = C * D
+    m, iv = p["mean"].ravel(), p["iv"].ravel()
+    N, F = p["Nh"][:9], p["Fh"][:9]                       # 9 test segments
+    nT = N.shape[0]
+    rng = np.random.default_rng(2)
+    clients = rng.normal(size=(5, SV))
+    sb = np.arange(nT + 1)
+    Fh = orc.jfa_subtract(N, F, None, m, None, None, None, None)                      # substractMplusVYplusDZ with y = z = 0
+    X = orc.tv_estimate_w(N, Fh, p["U"], iv, orc.tv_tett(p["U"], iv, C, D))           # estimateX
+    Fx = orc.jfa_subtract_m_plus_ux(sb, N, F, m, p["U"], X)                           # substractMplusUX on the speaker statistics
+    ref = (Fx / N.sum(1, keepdims=True)) @ clients.T
+    got = hc.jfa_dot_product((p["w"], p["mean"], 1.0 / p["iv"]), N, F, p["V"], p["U"], p["D"], clients)
+    assert relerr(got, ref) < 1e-9
+

@@ -229,6 +229,11 @@ def test_jfa_pieces_against_numpy():
         for h in range(sb[s], sb[s + 1]):
             ref[s] -= np.repeat(Nh[h], D) * (X[h] @ U)
     assert np.abs(orc.jfa_subtract_sessions(sb, Nh, F, U, X) - ref).max() < 1e-12                                      # UX
+    ref2 = F.copy()
+    for s in range(nspk):
+        for h in range(sb[s], sb[s + 1]):
+            ref2[s] -= np.repeat(Nh[h], D) * (m + X[h] @ U)
+    assert np.abs(orc.jfa_subtract_m_plus_ux(sb, Nh, F, m, U, X) - ref2).max() < 1e-12                                  # M + UX, speaker rows
     L = 1 + rep(N) * iv * Dm * Dm; z = F * iv * Dm / L
     Zo, Dn = orc.jfa_estimate_z_and_d(N, F, iv, Dm)
     assert np.abs(Zo - z).max() < 1e-13 and np.abs(Dn - (z * F).sum(0) / ((1 / L + z * z) * rep(N)).sum(0)).max() < 1e-12
