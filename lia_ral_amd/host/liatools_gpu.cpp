@@ -759,6 +759,11 @@ void JFAAcc::substractMplusUX()
                                   (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, nullptr, nullptr));
     substractUX();
 }
+void JFAAcc::substractMplusDZByChannel()
+{
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.data(), _F_X_h.data(), _owner.data(),
+                                  (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, _D.data(), _Z.data()));
+}
 void JFAAcc::orthonormalizeV()
 {
     _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankEV, (int64_t)_svSize, _V.data()));

@@ -279,6 +279,7 @@ class JFAAcc {
     void substractUX();                // :4152-4172   _F_X   -= sum_h N_h (U x_h)
     void substractMplusVYplusDZ();     // :4400-4422   _F_X_h -= N_h (m + V y + D z) of the session's speaker
     void substractMplusUX();           // :4336-4364   _F_X   -= sum_h N_h (m + U x_h)
+    void substractMplusDZByChannel();  // :3948-3976   _F_X_h -= N_h (m + D z) of the session's speaker
     void orthonormalizeV();            // :4700-4777
     void getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk); // :1926-1935
     std::vector<double> &getV() { return _V; }
