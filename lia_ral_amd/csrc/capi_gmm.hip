@@ -408,8 +408,14 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     if ((rc = i_n.init(c, WS_T1, nontop_llk, (size_t)T))) return rc;
     if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T, false))) return rc;
     c->t_begin("k_topc_use");
-    GCHK(gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, ctop, i_idx.d, i_n.d,
-                       mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d));
+    // 16 lanes per frame when the selection fits a DPP row (topc_z.hip); else one wave per frame
+    int krc = c->topc_z ? gmmk_topc_use16(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, ctop, i_idx.d, i_n.d,
+                                          mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d)
+                        : -1;
+    if (krc == -1)
+        krc = gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, ctop, i_idx.d, i_n.d,
+                            mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d);
+    GCHK(krc);
     c->t_end();
     return o_llk.finish();
 }

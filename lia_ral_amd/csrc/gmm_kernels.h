@@ -55,3 +55,5 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
                      const int *eit, const int *efin, const double *mean, const double *iv, const double *lwc,
                      const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
                      double *nw, double *llk, int *flag);
+int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
+                    const double *lwc, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk);

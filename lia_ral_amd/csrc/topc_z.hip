@@ -235,3 +235,71 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
                                                      hi, idx, lk, nlk, nllk, nw, llk, flag);
     return (int)hipGetLastError();
 }
+
+// USE_TOP_DISTRIBS (client models on the world's top-C' indices, TopGauss.cpp:224-316 / ComputeTest.cpp:170-207), 16 lanes per
+// frame: lane k of a frame's DPP row evaluates candidate k from the row-major model (16-byte loads, 8 dimensions in flight at
+// a time), the frame's log-sum is two DPP row reductions.  The first kernel gave a whole wave to one frame (10 busy lanes, one
+// 8-byte load per dimension and lane, permute-based reductions): 190 M frames/s per client model -- and ComputeTest runs this
+// once per CLIENT of every test segment.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_use16(const void *__restrict__ x, long T, long ldx, int D, const double *__restrict__ mean,
+                                                    const double *__restrict__ iv, const double *__restrict__ lwc, int ctop,
+                                                    const int *__restrict__ idx, const double *__restrict__ nontop_llk, int complete,
+                                                    double lo, double hi, double *__restrict__ llk_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem; // [16][D + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane & 15, f = wave * 4 + (lane >> 4);
+    const long tb = (long)blockIdx.x * 16, t = tb + f;
+    const int Dp = D + 1;
+    for (int e = tid; e < 16 * D; e += 256) {
+        const int ff = e / D, d = e - ff * D;
+        xs[ff * Dp + d] = tb + ff < T ? feat_load<XT>::get(x, (tb + ff) * ldx + d) : 0.0;
+    }
+    __syncthreads();
+    const double NINF = -__builtin_inf();
+    double z = NINF;
+    if (t < T && k < ctop) {
+        const int c = idx[t * ctop + k];
+        const double *mu = mean + (size_t)c * D, *vi = iv + (size_t)c * D, *xr = xs + f * Dp;
+        double acc = 0.0;
+        int d = 0;
+        for (; d + 8 <= D; d += 8) {
+            d2 m4[4], v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { m4[u] = *(const d2 *)(mu + d + 2 * u); v4[u] = *(const d2 *)(vi + d + 2 * u); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double dx0 = xr[d + 2 * u] - m4[u][0], dx1 = xr[d + 2 * u + 1] - m4[u][1];
+                acc = __builtin_fma(dx0 * dx0, v4[u][0], acc);
+                acc = __builtin_fma(dx1 * dx1, v4[u][1], acc);
+            }
+        }
+        for (; d < D; ++d) {
+            const double dx = xr[d] - mu[d];
+            acc = __builtin_fma(dx * dx, vi[d], acc);
+        }
+        z = __builtin_fma(-0.5, acc, lwc[c]);
+    }
+    const double r = (complete && nontop_llk && t < T) ? nontop_llk[t] : NINF;
+    double M = fmax(z, r);
+    M = fmax(M, dpp_f64_0x128(M)); M = fmax(M, dpp_f64_0x124(M)); M = fmax(M, dpp_f64_0x122(M)); M = fmax(M, dpp_f64_0x121(M));
+    double s = (t < T && k < ctop) ? gexp(z - M) : 0.0;
+    s += dpp_f64_0x128(s); s += dpp_f64_0x124(s); s += dpp_f64_0x122(s); s += dpp_f64_0x121(s);
+    if (k == 0 && t < T) {
+        if (r > NINF) s += gexp(r - M);
+        llk_out[t] = fmin(fmax(M + log(s), lo), hi);
+    }
+}
+
+int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
+                    const double *lwc, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk)
+{
+    if (T <= 0) return 0;
+    if (ctop > 16 || D % 2 != 0) return -1; // the caller keeps the one-wave-per-frame kernel
+    const unsigned grid = (unsigned)((T + 15) / 16);
+    const size_t lds = (size_t)16 * (D + 1) * sizeof(double);
+    if (x_f64) k_topc_use16<double><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+    else k_topc_use16<float><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+    return (int)hipGetLastError();
+}
