@@ -428,10 +428,34 @@ int gmmiv_occ(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
     if (T > 0x7fffffff) { gmmiv_set_error("occ: too many frames in one call"); return GMMIV_ERR_UNSUPPORTED; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    double *lse;
-    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     DevOut<double> o;
     if ((rc = o.init(c, WS_T0, gamma, (size_t)T * g->C, false))) return rc;
+    // Fast path: logits on the matrix cores (k_llk_mfma<WZ>), posteriors = the stored scaled likelihoods rescaled and transposed
+    const int64_t Tcz = c->topc_z ? z_chunk_frames(c, g) : 0;
+    if (Tcz > 0 && T > 0) {
+        const int64_t first = T < Tcz ? T : Tcz;
+        const long nfb = z_tile_blocks(first);
+        void *zb, *eit, *inv, *lz;
+        if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
+        if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
+        if ((rc = c->scratch(WS_INV, (size_t)first * (sizeof(double) + sizeof(int)), &inv))) return rc;
+        if ((rc = c->scratch(WS_LSE, (size_t)first * sizeof(double), &lz))) return rc;
+        int *efin = (int *)((double *)inv + first);
+        for (int64_t c0 = 0; c0 < T; c0 += Tcz) {
+            const int64_t n = (T - c0) < Tcz ? (T - c0) : Tcz;
+            c->t_begin("k_llk_mfma", c0 == 0);
+            GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lz,
+                            (int)c->use_glds, (double *)zb, nfb, (int *)eit, (double *)inv, efin));
+            c->t_end();
+            c->t_begin("k_post_from_z", c0 == 0);
+            GCHK(gmmk_post_from_z(c->stream, n, g->C, g->nct, (const double *)zb, nfb, (const int *)eit, (const double *)inv, efin,
+                                  o.d + (size_t)c0 * g->C));
+            c->t_end();
+        }
+        return o.finish();
+    }
+    double *lse;
+    if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     c->t_begin("k_posteriors");
     GCHK(gmmk_posteriors(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc, lse, o.d));
     c->t_end();

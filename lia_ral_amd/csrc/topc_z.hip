@@ -303,3 +303,44 @@ int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, 
     else k_topc_use16<float><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
     return (int)hipGetLastError();
 }
+
+// Posterior vectors gamma[t][c] (MixtureGDStat::computeAndAccumulateOcc / getOccVect) from the stored scaled likelihoods:
+// gamma = e 2^(E - Efin) / S_t.  One wave per 16-frame block and group of 8 tiles; register r of a lane is frame q + 4 r,
+// Gaussian 16 ct + i16: for every r the 16 lanes of a row write 128 contiguous bytes.  Memory-bound (16 KB per frame each way);
+// the direct-form kernel it replaces evaluated every logit on the VALU (16 G pairs/s).
+__global__ __launch_bounds__(256) void k_post_from_z(long n, int C, int nct, const double *__restrict__ zbuf, long nfb,
+                                                     const int *__restrict__ eit, const double *__restrict__ inv,
+                                                     const int *__restrict__ efin, double *__restrict__ gamma)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, q = lane >> 4;
+    const long fb = blockIdx.x;
+    double fs[4];
+    int ef[4];
+    long tr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        tr[r] = fb * 16 + q + 4 * r;
+        const long tc = tr[r] < n ? tr[r] : n - 1;
+        fs[r] = inv[tc];
+        ef[r] = efin[tc];
+    }
+    for (int ct = blockIdx.y * 4 + wave; ct < nct; ct += gridDim.y * 4) {
+        const d2 *pz = (const d2 *)(zbuf + (((size_t)ct * nfb + fb) * 64 + lane) * 4);
+        const d2 a = __builtin_nontemporal_load(pz), b = __builtin_nontemporal_load(pz + 1);
+        const double e[4] = {a[0], a[1], b[0], b[1]};
+        const int *ep = eit + (size_t)(ct >> 1) * (nfb * 16) + fb * 16 + q;
+        const int c = 16 * ct + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tr[r] < n && c < C) gamma[(size_t)tr[r] * C + c] = __builtin_ldexp(e[r] * fs[r], ep[4 * r] - ef[r]);
+    }
+}
+
+int gmmk_post_from_z(hipStream_t st, long n, int C, int nct, const double *zbuf, long nfb, const int *eit, const double *inv,
+                     const int *efin, double *gamma)
+{
+    if (n <= 0) return 0;
+    const unsigned gy = nct >= 32 ? 8 : 1; // 8 tile groups per frame block: enough workgroups for short inputs
+    k_post_from_z<<<dim3((unsigned)((n + 15) / 16), gy), 256, 0, st>>>(n, C, nct, zbuf, nfb, eit, inv, efin, gamma);
+    return (int)hipGetLastError();
+}
