@@ -248,8 +248,9 @@ int gmmiv_dev_lda(gmmiv_ctx *ctx, int dim, const double *W, const double *B, int
  *   x = mu + F h_spk + G w_session + eps,  eps ~ N(0, Sigma)
  * on the development set X [dim x n] (sessions grouped by speaker; X is centred IN PLACE by the incoming Delta, like
  * _Dev.center(_Delta)).  F [dim x rf], G [dim x rg], Sigma [dim x dim], Delta [dim] are updated in place (M-step with
- * the minimum-divergence re-scaling of F and G).  The O(dim n r) products run on the device, the per-speaker
- * r x r algebra on the host like the reference's Eigen code. */
+ * the minimum-divergence re-scaling of F and G).  rg may be 0 (pldaEigenChannelNumber 0, the simplified model: G is then
+ * ignored and may be NULL).  The O(dim n r) products run on the device, the per-speaker r x r algebra on the host like the
+ * reference's Eigen code. */
 int gmmiv_plda_em_iteration(gmmiv_ctx *ctx, int dim, int64_t n, double *X, int64_t nspk, const int64_t *sessions_per_speaker,
                             int rf, int rg, double *F, double *G, double *Sigma, double *Delta);
 

@@ -98,6 +98,7 @@ void host_sym_eigen(int n, const std::vector<double> &A, int rank, std::vector<d
 int fetch_host(gmmiv_ctx *c, const double *p, size_t n, std::vector<double> &out)
 {
     out.resize(n);
+    if (n == 0 || !p) return GMMIV_OK;
     if (gmmiv_is_device_ptr(p)) {
         GCHK(hipMemcpyAsync(out.data(), p, n * 8, hipMemcpyDeviceToHost, c->stream));
         GCHK(hipStreamSynchronize(c->stream));
@@ -1059,7 +1060,8 @@ void hmm(int M, int N, int K, const double *A, bool ta, const double *B, bool tb
 int gmmiv_plda_em_iteration(gmmiv_ctx *c, int dim, int64_t n, double *X, int64_t nspk, const int64_t *sps, int rf, int rg, double *Fm,
                             double *Gm, double *Sigma, double *Delta)
 {
-    if (rf <= 0 || rg <= 0 || !Fm || !Gm || !Sigma || !Delta) { gmmiv_set_error("plda_em_iteration: bad argument"); return GMMIV_ERR_ARG; }
+    // rg == 0 (pldaEigenChannelNumber 0, the common "simplified PLDA" configuration): every G-sized object is empty
+    if (rf <= 0 || rg < 0 || !Fm || (rg > 0 && !Gm) || !Sigma || !Delta) { gmmiv_set_error("plda_em_iteration: bad argument"); return GMMIV_ERR_ARG; }
     DevSet ds; // validates the arguments, uploads X (when it is a host array), builds cls / off
     int rc = ds.init(c, dim, n, X, nspk, sps, "plda_em_iteration");
     if (rc) return rc;
@@ -1099,7 +1101,7 @@ int gmmiv_plda_em_iteration(gmmiv_ctx *c, int dim, int64_t n, double *X, int64_t
     for (size_t i = 0; i < A.size(); ++i) A[i] = FtwF[i] - A[i];
     // 3. (Ftw; Gtw) X on the device, per-speaker sums back to the host
     GCHK(hipMemcpyAsync(dFG, FGtw.data(), FGtw.size() * 8, hipMemcpyHostToDevice, st));
-    GCHK(hipMemcpyAsync(dIGG, iGG.data(), iGG.size() * 8, hipMemcpyHostToDevice, st));
+    if (rg > 0) GCHK(hipMemcpyAsync(dIGG, iGG.data(), iGG.size() * 8, hipMemcpyHostToDevice, st));
     GCHK(tvk_dgemm(st, false, false, rh, (int)n, dim, 1.0, dFG, dim, 0, Xd, (long)n, 0, 0.0, FGX, (long)n, 0, 1));
     void *q;
     if ((rc = c->scratch(WS_T3, ((size_t)2 * rh * nspk + rh) * 8, &q))) return rc;
@@ -1135,8 +1137,10 @@ int gmmiv_plda_em_iteration(gmmiv_ctx *c, int dim, int64_t n, double *X, int64_t
     // 5. Eh = [h_spk ; iGG g_i - S h_spk] per session, its Gram matrix and X Eh^T on the device
     GCHK(hipMemcpyAsync(dH, Hs.data(), Hs.size() * 8, hipMemcpyHostToDevice, st));
     GCHK(tvk_dev_expand(st, rf, (long)n, (long)nspk, dH, ds.cls, Eh));
-    GCHK(tvk_dgemm(st, false, false, rg, (int)n, rg, 1.0, dIGG, rg, 0, FGX + (size_t)rf * n, (long)n, 0, 0.0, Eh + (size_t)rf * n, (long)n, 0, 1));
-    GCHK(tvk_dev_center(st, rg, (long)n, 1, Eh + (size_t)rf * n, nullptr, dH + (size_t)rf * nspk, (long)nspk, ds.off, ds.cls, Eh + (size_t)rf * n));
+    if (rg > 0) {
+        GCHK(tvk_dgemm(st, false, false, rg, (int)n, rg, 1.0, dIGG, rg, 0, FGX + (size_t)rf * n, (long)n, 0, 0.0, Eh + (size_t)rf * n, (long)n, 0, 1));
+        GCHK(tvk_dev_center(st, rg, (long)n, 1, Eh + (size_t)rf * n, nullptr, dH + (size_t)rf * nspk, (long)nspk, ds.off, ds.cls, Eh + (size_t)rf * n));
+    }
     double *dGram = dOut + dd, *dXh = dGram + (size_t)rh * rh;
     if ((rc = dev_gram(c, rh, (long)n, Eh, 1.0, dGram))) return rc;
     {

@@ -209,11 +209,12 @@ def test_backend_training_chain(sph_norm):
     assert relerr(np.abs(res["lda"]), np.abs(oL)) < 1e-6
 
 
-def test_plda_training_loop():
+@pytest.mark.parametrize("rg", [4, 0])        # 0: pldaEigenChannelNumber 0, the simplified model
+def test_plda_training_loop(rg):
     """PLDA.cpp:80-95 through liagpu::PldaModel: 4 EM iterations against the oracle loop."""
     from lia_ral_amd import host_capi as host
     rng = np.random.default_rng(8)
-    dim, rf, rg, nspk = 24, 6, 4, 60
+    dim, rf, nspk = 24, 6, 60
     sps = rng.integers(2, 6, nspk)
     cls = np.repeat(np.arange(nspk), sps); n = int(sps.sum())
     X = rng.normal(size=(dim, rf)) @ rng.normal(size=(rf, nspk))[:, cls] + 0.5 * rng.normal(size=(dim, n)) + 1.0
@@ -222,7 +223,7 @@ def test_plda_training_loop():
     ref = (X, F, G, Sigma, np.zeros(dim))
     for it in range(4):
         ref = orc.plda_em_iteration(ref[0], sps, *ref[1:])
-    assert relerr(res["F"], ref[1]) < 1e-7 and relerr(res["G"], ref[2]) < 1e-7 and relerr(res["Sigma"], ref[3]) < 1e-7
+    assert relerr(res["F"], ref[1]) < 1e-7 and (rg == 0 or relerr(res["G"], ref[2]) < 1e-7) and relerr(res["Sigma"], ref[3]) < 1e-7
     assert relerr(res["Delta"], ref[4]) < 1e-7 and relerr(res["X"], ref[0]) < 1e-8
     assert relerr(res["original_mean"], X.mean(1)) < 1e-12
 

@@ -239,7 +239,7 @@ def test_efr_lda_and_eigen(ctx, dim):
     assert relerr(Y, Yo) < 1e-10
 
 
-@pytest.mark.parametrize("dim,rf,rg,nspk", [(8, 3, 2, 8), (60, 20, 10, 120), (200, 60, 40, 400)])
+@pytest.mark.parametrize("dim,rf,rg,nspk", [(8, 3, 2, 8), (60, 20, 10, 120), (200, 60, 40, 400), (40, 12, 0, 60)])   # rankG 0: simplified PLDA
 def test_plda_em_iterations_match_oracle(ctx, dim, rf, rg, nspk):
     """PldaModel::em_iteration (PldaTools.cpp:2329-2343, 2359-2484, 2790-2815): three iterations, every quantity
     (centred data, F, G, Sigma, Delta) against the oracle; numpy arrays in place and a device-resident X."""
@@ -259,7 +259,8 @@ def test_plda_em_iterations_match_oracle(ctx, dim, rf, rg, nspk):
         ctx.plda_em_iteration(Xg, sps, F, G, Sigma, Delta)
         ctx.plda_em_iteration(Xd, sps, Fd, Gd, Sd, Dd)
         for got, want in zip((Xg, F, G, Sigma, Delta), ref):
-            assert relerr(got, want) < 1e-8, it
+            if want.size:
+                assert relerr(got, want) < 1e-8, it
         assert relerr(Xd.cpu().numpy(), ref[0]) < 1e-8 and relerr(Fd, ref[1]) < 1e-8 and relerr(Sd, ref[3]) < 1e-8
 
 
