@@ -342,11 +342,20 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
     const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
-    std::vector<int32_t> idx((size_t)n * topDistribsCount);
-    std::vector<double> nllk(n), llkw(n), llkc(n);
+    // the world's top-C' indices and non-top remainder STAY on the device for the client passes (40 bytes per frame that every
+    // client would otherwise upload again); only the per-frame log-likelihoods come back for the segment means
+    struct DevBuf {
+        void *p = nullptr;
+        explicit DevBuf(size_t bytes) { hipcheck(hipMalloc(&p, bytes ? bytes : 8), "computeTestLLR: hipMalloc"); }
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    };
+    DevBuf dIdx((size_t)n * topDistribsCount * sizeof(int32_t)), dNllk((size_t)n * sizeof(double));
+    int32_t *idx = (int32_t *)dIdx.p;
+    double *nllk = (double *)dNllk.p;
+    std::vector<double> llkw(n), llkc(n);
     // world: DETERMINE_TOP_DISTRIBS on every frame (worldDecime = 1)
     srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount, mode,
-                                      minLLK, maxLLK, idx.data(), nullptr, nullptr, nllk.data(), nullptr, llkw.data()));
+                                      minLLK, maxLLK, idx, nullptr, nullptr, nllk, nullptr, llkw.data()));
     const size_t nseg = segmentalMode ? selectedSegments.size() : 1;
     std::vector<double> out(nseg * clients.size(), 0.0);
     auto meanOver = [&](const std::vector<double> &v, size_t b, size_t e) {
@@ -357,7 +366,7 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     for (size_t ci = 0; ci < clients.size(); ++ci) {
         // clients: USE_TOP_DISTRIBS with the world's indices (+ the world's non-top remainder if COMPLETE)
         srv.check(gmmiv_llk_use_top(srv.ctx(), clients[ci]->handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount,
-                                    idx.data(), nllk.data(), mode, minLLK, maxLLK, llkc.data()));
+                                    idx, nllk, mode, minLLK, maxLLK, llkc.data()));
         size_t off = 0;
         for (size_t s = 0; s < nseg; ++s) {
             const size_t len = segmentalMode ? selectedSegments[s].length : n;
