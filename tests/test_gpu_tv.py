@@ -127,6 +127,12 @@ def test_iv_normalisation_and_orthonormalize(ctx):
     assert relerr(Q, Qo) < 1e-10
     keep = [i for i in range(24) if i != 5]
     assert np.allclose(Q[keep] @ Q[keep].T, np.eye(23), atol=1e-10) and not Q[5].any()
+    # full-rank T: the Gram-matrix Cholesky route (Q = L^-1 T), same Q as the step-by-step scheme
+    for R, SV in [(24, 1000), (100, 7680)]:
+        T = rng.normal(size=(R, SV)) * 0.05 + 0.01
+        Q = ctx.tv_orthonormalize_t(T.copy())
+        assert relerr(Q, orc.tv_orthonormalize_t(T)) < 1e-10
+        assert np.allclose(Q @ Q.T, np.eye(R), atol=1e-10)
 
 
 @pytest.mark.parametrize("U,C,D,R", [(7, 16, 12, 20), (300, 64, 60, 40), (3, 128, 60, 100)])
