@@ -26,3 +26,17 @@ print("norm_statistics %.2f ms" % tm(lambda: ctx.tv_norm_statistics(N, F, means,
 Z = torch.randn((U, SV), dtype=torch.float64, device=dev, generator=g); Dm = torch.rand(SV, dtype=torch.float64, device=dev, generator=g)
 print("jfa_estimate_z_and_d %.2f ms" % tm(lambda: ctx.jfa_estimate_z_and_d(N, F, invvar, Dm.clone(), C, D, out=Z)))
 print("jfa_subtract(M+VY+DZ) %.2f ms" % tm(lambda: ctx.jfa_subtract(N, F, C, D, means=means, T=T, W=Wv, Dm=Dm, Z=Z)))
+# approximate extractors (IvExtractor modes ubmWeight / eigenDecomposition)
+wgt = torch.rand(C, dtype=torch.float64, device=dev, generator=g); wgt /= wgt.sum()
+Wm = torch.empty((R, R), dtype=torch.float64, device=dev)
+print("weighted_cov %.2f ms" % tm(lambda: ctx.tv_weighted_cov(T, wgt, C, D, out=Wm)))
+Wm2 = (Wm + Wm.T) / 2 + torch.eye(R, dtype=torch.float64, device=dev)
+Wout = torch.zeros((U, R), dtype=torch.float64, device=dev)
+print("estimate_w_ubm_weight %.2f ms" % tm(lambda: ctx.tv_estimate_w_ubm_weight(N, F, T, Wm2, C, D, out=Wout)))
+Q = torch.linalg.qr(torch.randn((R, R), dtype=torch.float64, device=dev, generator=g))[0].contiguous()
+Dq = torch.empty((C, R), dtype=torch.float64, device=dev)
+print("approximate_tctc %.2f ms" % tm(lambda: ctx.tv_approximate_tctc(T, Q, C, D, out=Dq)))
+print("estimate_w_eigen %.2f ms" % tm(lambda: ctx.tv_estimate_w_eigen(N, F, T, Dq, Q, C, D, out=Wout)))
+tett = torch.empty((C, R * (R + 1) // 2), dtype=torch.float64, device=dev)
+print("tett %.2f ms" % tm(lambda: ctx.tv_tett(T, invvar, C, D, out=tett)))
+print("estimate_w (exact) %.2f ms" % tm(lambda: ctx.tv_estimate_w(N, F, T, invvar, tett, C, D, out=Wout)))
