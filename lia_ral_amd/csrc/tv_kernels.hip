@@ -136,6 +136,22 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
             rb[i] = v;
         }
     };
+    // the last k-tile when the K range is not a multiple of 16 (K even): pairs / rows beyond the range are fetched from a
+    // valid element of the tile and count as zero -- estimateTETt (K = D = 60) and every other odd-sized product stay on
+    // the 16-byte-load instantiations instead of the per-element checked one
+    const int krem = EDGE ? 0 : (int)((ke - kb) & 15);
+    auto gload_tail = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ka = TA ? (tid >> 6) + 4 * i : 2 * (tid & 7), kb_ = TB ? 2 * (tid & 7) : (tid >> 6) + 4 * i;
+            const bool oka = ka < krem, okb = kb_ < krem;
+            const double *qa = pa + oa[i] - (oka ? 0L : (TA ? (long)ka * lda : (long)ka));
+            const double *qb = pb + ob[i] - (okb ? 0L : (TB ? (long)kb_ : (long)kb_ * ldb));
+            const d2 va = *(const d2 *)qa, vb = *(const d2 *)qb;
+            ra[2 * i] = oka ? va[0] : 0.0; ra[2 * i + 1] = oka ? va[1] : 0.0;
+            rb[2 * i] = okb ? vb[0] : 0.0; rb[2 * i + 1] = okb ? vb[1] : 0.0;
+        }
+    };
     auto swrite = [&](int buf) {
         if (!EDGE) {
 #pragma unroll
@@ -170,11 +186,18 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         for (int b = 0; b < 4; ++b) acc[a][b] = (d4){0, 0, 0, 0};
 
     const int nkt = (int)((ke - kb + BK - 1) / BK);
-    if (nkt > 0) { gload(0); swrite(0); }
+    if (nkt > 0) {
+        if (krem && nkt == 1) gload_tail();
+        else gload(0);
+        swrite(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+        if (kt + 1 < nkt) {
+            if (krem && kt + 2 == nkt) gload_tail();
+            else gload(kt + 1);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int k = 4 * ks + q;
@@ -247,7 +270,7 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
                          int ksplit, DgemmEpi epi = DgemmEpi{nullptr, nullptr, 0.0, 0.0, 0.0, 0, 0})
 {
     epi.remap = g_gemm_remap && grid.x >= 16; // wide enough for the per-XCD column order to mean something
-    const bool kfull = K % 16 == 0 && (ksplit <= 0 || ksplit % 16 == 0);
+    const bool kfull = K % 2 == 0 && (ksplit <= 0 || ksplit % 16 == 0); // a partial last k-tile is handled in the kernel (even K)
     const bool aligned = (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0 && sA % 2 == 0 && sB % 2 == 0;
     const bool clamp_ok = g_gemm_clamp && (!ta || (M % 2 == 0 && M >= 2)) && (tb || (N % 2 == 0 && N >= 2));
     const int fm = M / 128, fn = N / 128; // full tiles
