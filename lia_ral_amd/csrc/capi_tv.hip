@@ -605,7 +605,8 @@ int gmmiv_tv_estimate_w_ubm_weight(gmmiv_ctx *c, int64_t U, int C, int D, int R,
     int rc;
     if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_f.init(c, WS_T1, F, (size_t)U * SV)) || (rc = i_t.init(c, WS_T2, Tm, (size_t)R * SV)) ||
         (rc = i_w.init(c, WS_T3, Wm, (size_t)R * R)) || (rc = o.init(c, WS_LSE, W, (size_t)U * R, true))) return rc;
-    const int BC = U < 256 ? (int)(U > 0 ? U : 1) : 256;
+    const int tvb = c->tv_batch > 0 ? (int)c->tv_batch : 256;
+    const int BC = U < tvb ? (int)(U > 0 ? U : 1) : tvb;
     void *p;
     if ((rc = c->scratch(WS_AUX, (size_t)2 * BC * R * 8, &p))) return rc;
     double *aux = (double *)p, *wc = aux + (size_t)BC * R;
@@ -638,7 +639,8 @@ int gmmiv_tv_estimate_w_eigen(gmmiv_ctx *c, int64_t U, int C, int D, int R, cons
     int rc;
     if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_f.init(c, WS_T1, F, (size_t)U * SV)) || (rc = i_t.init(c, WS_T2, Tm, (size_t)R * SV)) ||
         (rc = i_d.init(c, WS_T3, Dm, (size_t)C * R)) || (rc = i_q.init(c, WS_T4, Q, (size_t)R * R)) || (rc = o.init(c, WS_LSE, W, (size_t)U * R, true))) return rc;
-    const int BC = U < 256 ? (int)(U > 0 ? U : 1) : 256;
+    const int tvb = c->tv_batch > 0 ? (int)c->tv_batch : 256;
+    const int BC = U < tvb ? (int)(U > 0 ? U : 1) : tvb;
     void *p;
     if ((rc = c->scratch(WS_AUX, (size_t)3 * BC * R * 8, &p))) return rc;
     double *aux = (double *)p, *nd = aux + (size_t)BC * R, *b = nd + (size_t)BC * R;
