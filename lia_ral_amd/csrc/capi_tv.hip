@@ -418,7 +418,8 @@ int gmmiv_tv_subtract_m_plus_tw(gmmiv_ctx *c, int64_t U, int C, int D, int R, co
     int rc;
     if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C)) || (rc = i_m.init(c, WS_T2, means, SV)) || (rc = i_t.init(c, WS_T3, Tm, (size_t)R * SV)) ||
         (rc = i_w.init(c, WS_LSE, W, (size_t)U * R)) || (rc = o_f.init(c, WS_T1, F, (size_t)U * SV, true))) return rc;
-    const int BC = U < 256 ? (int)(U > 0 ? U : 1) : 256;
+    const int tvb = c->tv_batch > 0 ? (int)c->tv_batch : 256;
+    const int BC = U < tvb ? (int)(U > 0 ? U : 1) : tvb;
     void *p;
     if ((rc = c->scratch(WS_TIV, (size_t)BC * SV * 8, &p))) return rc;
     double *TW = (double *)p;
@@ -452,7 +453,8 @@ int gmmiv_jfa_subtract(gmmiv_ctx *c, int64_t rows, int C, int D, const double *N
         (rc = i_w.init(c, WS_LSE, Tm ? W : nullptr, Tm ? (size_t)nfact * R : 0)) || (rc = i_d.init(c, WS_T4, Dm, SV)) ||
         (rc = i_z.init(c, WS_T5, Dm ? Z : nullptr, Dm ? (size_t)nfact * SV : 0)) || (rc = i_o.init(c, WS_SEG, owner, (size_t)rows)) ||
         (rc = o_f.init(c, WS_T1, F, (size_t)rows * SV, true))) return rc;
-    const int BC = rows < 256 ? (int)rows : 256;
+    const int tvb = c->tv_batch > 0 ? (int)c->tv_batch : 256;
+    const int BC = rows < tvb ? (int)rows : tvb;
     double *TW = nullptr, *Wg = nullptr;
     void *p;
     if (Tm) {
@@ -490,7 +492,8 @@ int gmmiv_jfa_subtract_sessions(gmmiv_ctx *c, int64_t nspk, const int64_t *sess_
     int rc;
     if ((rc = i_n.init(c, WS_T0, N_h, (size_t)nsess * C)) || (rc = i_u.init(c, WS_T3, Um, (size_t)R * SV)) || (rc = i_x.init(c, WS_LSE, X, (size_t)nsess * R)) ||
         (rc = i_b.init(c, WS_SEG, sess_begin, (size_t)nspk + 1)) || (rc = o_f.init(c, WS_T1, F_X, (size_t)nspk * SV, true))) return rc;
-    const int BC = nsess < 256 ? (int)nsess : 256;
+    const int tvb = c->tv_batch > 0 ? (int)c->tv_batch : 256;
+    const int BC = nsess < tvb ? (int)nsess : tvb;
     void *p;
     if ((rc = c->scratch(WS_TIV, (size_t)BC * SV * 8, &p))) return rc;
     double *G = (double *)p;
