@@ -51,8 +51,11 @@ const char *gmmiv_version(void);
 /* Runtime knobs; returns the previous value (-1: unknown key).
  *   "stats_z" 1        EM / Baum-Welch statistics from stored scaled likelihoods (k_llk_mfma<WZ> + k_stats_z);
  *                      0: the recomputing k_stats_mfma (also used for D > 60 or when the scratch does not fit)
- *   "z_scratch_mb"     likelihood scratch budget in MiB (default 65536, at most half of the free memory):
- *                      frames are processed in chunks that fit
+ *   "z_scratch_mb"     likelihood scratch budget in MiB (default 65536, at most a quarter of the device's TOTAL memory):
+ *                      frames are processed in chunks that fit.  The chunk length -- and with it the fp64 summation
+ *                      order -- depends only on this option, the model shape and the device model, not on the memory
+ *                      free at call time: results are bitwise reproducible across runs and ranks.  (The order differs
+ *                      from the reference's frame-by-frame accumulation: parity is to a tolerance, see DESIGN.md.)
  *   "z_waves" 8        workgroup shape of k_stats_z (8, 16 or 4 waves)
  *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
@@ -60,7 +63,7 @@ const char *gmmiv_version(void);
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one
  *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
- *                      used for odd orders); process-wide A/B switch
+ *                      used for odd orders); A/B switch of the calling host thread (like "gemm_remap", "gemm_clamp", "z_tv4")
  *   "topc_z" 1         DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (k_llk_mfma<WZ> + k_topc_from_z, direct form only
  *                      for the candidates); 0: the direct-form VALU kernel for every Gaussian
  *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)
@@ -108,7 +111,8 @@ int gmmiv_llk(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x_dtype, in
  * Per frame: idx[t*ctop+j] / lk[t*ctop+j] = the ctop largest w_c lk_c, descending (ties: lower
  * index first); nontop_lk = sum of the others (linear, may underflow), nontop_llk = its log
  * (-inf when empty), nontop_w = 1 - sum of the selected weights; llk = clamp(log(top [+ rest])).
- * lk, nontop_lk, nontop_w, llk_out may be NULL. ctop <= 64. */
+ * lk, nontop_lk, nontop_w, llk_out may be NULL.  1 <= ctop <= min(64, C): a request for more Gaussians than the
+ * model has is GMMIV_ERR_ARG, not clamped -- the row stride of idx / lk is the caller's ctop, so the caller clamps. */
 int gmmiv_llk_determine_top(gmmiv_ctx *ctx, const gmmiv_gmm *world, const void *x, int x_dtype,
                             int64_t T, int64_t ldx, int ctop, int mode, double min_llk, double max_llk,
                             int32_t *idx, double *lk, double *nontop_lk, double *nontop_llk,
@@ -116,7 +120,8 @@ int gmmiv_llk_determine_top(gmmiv_ctx *ctx, const gmmiv_gmm *world, const void *
 
 /* ---- computeAndAccumulateLLK(f,1.0,USE_TOP_DISTRIBS) on a client model ------------------------
  * (ComputeTest.cpp:166-167; StatServer::setTopDistribIndexVector, TopGauss.cpp:297-308)
- * llk_out[t] = clamp(log(sum_j w_c lk_c(client) over c = idx[t][j]  [+ exp(nontop_llk[t])])). */
+ * llk_out[t] = clamp(log(sum_j w_c lk_c(client) over c = idx[t][j]  [+ exp(nontop_llk[t])])).
+ * ctop as above; an entry of idx outside [0, C) contributes nothing (it is never dereferenced). */
 int gmmiv_llk_use_top(gmmiv_ctx *ctx, const gmmiv_gmm *client, const void *x, int x_dtype, int64_t T,
                       int64_t ldx, int ctop, const int32_t *idx, const double *nontop_llk, int mode,
                       double min_llk, double max_llk, double *llk_out);

@@ -50,7 +50,7 @@ int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out)
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { GCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->n_cu = prop.multiProcessorCount; c->total_mem = prop.totalGlobalMem; }
     *out = c;
     return GMMIV_OK;
 }
@@ -94,20 +94,16 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
-        gmmk_stats_z_set_tv4((int)value);
-        return 0;
+        return gmmk_stats_z_set_tv4((int)value);
     }
     if (!strcmp(key, "gemm_remap")) { // A/B knob: 0 = hardware tile order in k_dgemm
-        tvk_set_gemm_remap((int)value);
-        return 0;
+        return tvk_set_gemm_remap((int)value);
     }
     if (!strcmp(key, "gemm_clamp")) { // A/B knob: 0 = cut GEMM tiles on the per-element checked instantiation
-        tvk_set_gemm_clamp((int)value);
-        return 0;
+        return tvk_set_gemm_clamp((int)value);
     }
     if (!strcmp(key, "chol_gemm")) { // A/B knob: the GEMM-built batched Cholesky instead of k_chol_left
-        tvk_set_chol_gemm_path((int)value);
-        return 0;
+        return tvk_set_chol_gemm_path((int)value);
     }
     if (!slot) return -1;
     long prev = *slot;
@@ -167,14 +163,17 @@ int gmmiv_gmm_create(gmmiv_ctx *c, int C, int D, const double *w, const double *
     g->Cp64 = (C + 63) / 64 * 64;
     const size_t CD = (size_t)C * D;
     const int Cpa = g->Cp64 > g->nct * 16 ? g->Cp64 : g->nct * 16;
-    GCHK(hipMalloc(&g->w, C * sizeof(double)));
-    GCHK(hipMalloc(&g->mean, CD * sizeof(double)));
-    GCHK(hipMalloc(&g->iv, CD * sizeof(double)));
-    GCHK(hipMalloc(&g->a, Cpa * sizeof(double)));
-    GCHK(hipMalloc(&g->lwc, Cpa * sizeof(double)));
-    GCHK(hipMalloc(&g->Pt, (size_t)g->nct * (2 * KS + 2) * 64 * sizeof(double)));
-    GCHK(hipMalloc(&g->meanT, (size_t)D * g->Cp64 * sizeof(double)));
-    GCHK(hipMalloc(&g->ivT, (size_t)D * g->Cp64 * sizeof(double)));
+    struct { void **p; size_t n; } need[] = {{(void **)&g->w, (size_t)C}, {(void **)&g->mean, CD}, {(void **)&g->iv, CD}, {(void **)&g->a, (size_t)Cpa},
+                                           {(void **)&g->lwc, (size_t)Cpa}, {(void **)&g->Pt, (size_t)g->nct * (2 * KS + 2) * 64},
+                                           {(void **)&g->meanT, (size_t)D * g->Cp64}, {(void **)&g->ivT, (size_t)D * g->Cp64}};
+    for (auto &a : need) {
+        const hipError_t e = hipMalloc(a.p, a.n * sizeof(double));
+        if (e != hipSuccess) { // nothing allocated so far may leak
+            gmmiv_set_error("gmm_create: hipMalloc of %zu bytes -> %s", a.n * sizeof(double), hipGetErrorString(e));
+            gmmiv_gmm_destroy(g);
+            return GMMIV_ERR_HIP;
+        }
+    }
     int rc = gmm_upload(g, w, mean, covinv);
     if (rc) { gmmiv_gmm_destroy(g); return rc; }
     *out = g;
@@ -328,7 +327,9 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     int rc = check_model(c, g);
     if (rc) return rc;
     if (T < 0 || !idx || ctop <= 0) { gmmiv_set_error("determine_top: bad argument"); return GMMIV_ERR_ARG; }
-    if (ctop > g->C) ctop = g->C;
+    // no silent clamp: the stride of idx / lk is the caller's ctop, so a caller that asks for more than the model has must
+    // clamp on its side (liagpu::computeTestLLR and the Python binding do) -- otherwise its buffers and use_top disagree
+    if (ctop > g->C) { gmmiv_set_error("determine_top: topDistribsCount %d exceeds mixtureDistribCount %d (clamp it at the call site)", ctop, g->C); return GMMIV_ERR_ARG; }
     if (ctop > 64) { gmmiv_set_error("determine_top: topDistribsCount %d > 64 not supported", ctop); return GMMIV_ERR_UNSUPPORTED; }
     if (!gmmk_topc_frames_per_block(g->Cp64, g->D)) { gmmiv_set_error("determine_top: mixtureDistribCount %d too large for the LDS selection kernel", g->C); return GMMIV_ERR_UNSUPPORTED; }
     XView xv;
@@ -398,6 +399,7 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     int rc = check_model(c, g);
     if (rc) return rc;
     if (T < 0 || !idx || !llk_out || ctop <= 0 || ctop > 64) { gmmiv_set_error("use_top: bad argument"); return GMMIV_ERR_ARG; }
+    if (ctop > g->C) { gmmiv_set_error("use_top: topDistribsCount %d exceeds mixtureDistribCount %d", ctop, g->C); return GMMIV_ERR_ARG; }
     if (mode == GMMIV_TOP_COMPLETE && !nontop_llk) { gmmiv_set_error("use_top: COMPLETE mode needs nontop_llk"); return GMMIV_ERR_ARG; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
@@ -409,11 +411,11 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T, false))) return rc;
     c->t_begin("k_topc_use");
     // 16 lanes per frame when the selection fits a DPP row (topc_z.hip); else one wave per frame
-    int krc = c->topc_z ? gmmk_topc_use16(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, ctop, i_idx.d, i_n.d,
+    int krc = c->topc_z ? gmmk_topc_use16(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
                                           mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d)
                         : -1;
     if (krc == -1)
-        krc = gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, ctop, i_idx.d, i_n.d,
+        krc = gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
                             mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d);
     GCHK(krc);
     c->t_end();
@@ -497,12 +499,11 @@ static long z_tile_blocks(int64_t n)
 static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g)
 {
     if (!c->stats_z || g->KS > 15 || c->wg_waves != 8) return 0;
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-    size_t have = c->ws_size[WS_Z];
+    // The chunk length fixes the segment bounds and with them the fp64 summation order of every reduction of this path, so
+    // it depends ONLY on the option and the device's TOTAL memory (the same on every rank of a node), never on what happens
+    // to be free: replicated M-steps stay bit-identical.  If the scratch then does not fit, scratch() fails loudly.
     size_t budget = (size_t)(c->z_scratch_mb > 0 ? c->z_scratch_mb : 0) << 20;
-    const size_t avail = have + fr / 2; // never take more than half of what is free now
-    if (budget > avail) budget = avail;
+    if (c->total_mem && budget > c->total_mem / 4) budget = c->total_mem / 4;
     const size_t per_frame = (size_t)g->nct * 16 * sizeof(double) + (size_t)g->nct * 2 + 16; // likelihoods + exponents
     int64_t tc = (int64_t)(budget / per_frame / 1.2); // scratch() over-allocates by 1/8
     // whole rounds of the log-likelihood kernel: 2 resident workgroups per CU x 256 frames

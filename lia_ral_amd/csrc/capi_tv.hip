@@ -216,21 +216,27 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
     // accumulators: keep device-side copies when the caller passed host arrays
     void *p;
     double *d_a = nullptr, *d_c = nullptr, *d_rm = nullptr, *d_r = nullptr, *d_mw = nullptr, *d_rp = nullptr;
-    std::vector<void *> owned;
+    // device copies of HOST accumulators live for this call only; the guard frees them on EVERY return path
+    struct Owned {
+        gmmiv_ctx *c;
+        std::vector<void *> v;
+        ~Owned() { release(); }
+        void release() { if (v.empty()) return; (void)hipStreamSynchronize(c->stream); for (void *q : v) (void)hipFree(q); v.clear(); }
+    } owned{c, {}};
     auto dev_acc = [&](double *user, size_t n, double **dev) -> int {
         if (gmmiv_is_device_ptr(user)) { *dev = user; return GMMIV_OK; }
         GCHK(hipMalloc(&p, n * 8));
-        owned.push_back(p);
+        owned.v.push_back(p);
         GCHK(hipMemcpyAsync(p, user, n * 8, hipMemcpyHostToDevice, c->stream));
         *dev = (double *)p;
         return GMMIV_OK;
     };
-    auto free_owned = [&]() { (void)hipStreamSynchronize(c->stream); for (void *q : owned) (void)hipFree(q); owned.clear(); };
+    auto free_owned = [&]() { owned.release(); };
     if (accumulate) {
         if ((rc = dev_acc(A_packed, (size_t)C * P, &d_a)) || (rc = dev_acc(Cmx, (size_t)R * SV, &d_c)) ||
             (rc = dev_acc(Rm, RR, &d_rm)) || (rc = dev_acc(r, R, &d_r)) || (rc = dev_acc(meanW, R, &d_mw))) { free_owned(); return rc; }
         GCHK(hipMalloc(&p, P * 8));
-        owned.push_back(p);
+        owned.v.push_back(p);
         d_rp = (double *)p;
         GCHK(hipMemsetAsync(d_rp, 0, P * 8, c->stream));
     }

@@ -56,6 +56,7 @@ struct gmmiv_ctx {
     // than half of the memory that is free when the scratch is first needed.
     long z_scratch_mb = 65536;
     int n_cu = 256;
+    size_t total_mem = 0; // device memory size (bounds the likelihood scratch deterministically)
     // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name,
     // one event pair per launch of that kernel inside the call
     enum { NSLOT = 6 };
@@ -76,7 +77,14 @@ struct gmmiv_ctx {
                 ws_size[slot] = 0;
             }
             size_t want = bytes + bytes / 8;
-            GCHK(hipMalloc(&ws[slot], want));
+            hipError_t me = hipMalloc(&ws[slot], want);
+            if (me != hipSuccess) {
+                (void)hipGetLastError();
+                ws[slot] = nullptr;
+                gmmiv_set_error("device workspace %d: hipMalloc of %zu MiB failed (%s); lower the \"z_scratch_mb\" / \"tv_batch\" options or free device memory",
+                                slot, want >> 20, hipGetErrorString(me));
+                return GMMIV_ERR_HIP;
+            }
             ws_size[slot] = want;
         }
         *out = ws[slot];

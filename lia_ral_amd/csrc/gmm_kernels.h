@@ -24,7 +24,7 @@ int gmmk_topc_determine(hipStream_t st, int x_f64, const void *x, long T, long l
                         int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
                         double *nw, double *llk);
 int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
-                  const double *iv, const double *lwc, int ctop, const int *idx, const double *nllk, int complete,
+                  const double *iv, const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete,
                   double lo, double hi, double *llk);
 int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, double *partial,
                        int max_blocks, double *acc);
@@ -45,7 +45,7 @@ int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, 
                     const double *ivT, const double *lwc, const double *lse, double *gamma);
 int gmmk_stats_z_groups(int nct);
 void gmmk_stats_z_set_waves(int w);
-void gmmk_stats_z_set_tv4(int on);
+int gmmk_stats_z_set_tv4(int on);   // thread-local A/B switch, returns the previous value
 int gmmk_stats_z_wg_per_cu(void);
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
                  long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,
@@ -56,6 +56,6 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
                      const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
                      double *nw, double *llk, int *flag);
 int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
-                    const double *lwc, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk);
+                    const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk);
 int gmmk_post_from_z(hipStream_t st, long n, int C, int nct, const double *zbuf, long nfb, const int *eit, const double *inv,
                      const int *efin, double *gamma);

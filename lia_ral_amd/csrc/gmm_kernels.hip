@@ -9,6 +9,7 @@
 // (lane = Gaussian column, registers = frame rows) is exactly the A-operand layout of the second,
 // so posteriors never leave registers and the T x C matrix is never materialised.
 // The top-C kernels evaluate the direct form (x-mu)^2 iv on the VALU like the reference does.
+#include <atomic>
 #include "devutil.h"
 #include "gmm_kernels.h"
 
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(256) void k_topc_determine(
 template <typename XT>
 __global__ __launch_bounds__(256) void k_topc_use(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ mean, const double *__restrict__ iv,
-                                                  const double *__restrict__ lwc, int ctop,
+                                                  const double *__restrict__ lwc, int C, int ctop,
                                                   const int *__restrict__ idx, const double *__restrict__ nontop_llk,
                                                   int complete, double lo, double hi, double *__restrict__ llk_out)
 {
@@ -761,8 +762,9 @@ __global__ __launch_bounds__(256) void k_topc_use(const void *__restrict__ x, lo
     const long t = (long)blockIdx.x * 4 + wave;
     if (t >= T) return;
     double z = -__builtin_inf();
-    if (lane < ctop) {
-        const int c = idx[t * ctop + lane];
+    const int c = lane < ctop ? idx[t * ctop + lane] : -1;
+    const bool live = (unsigned)c < (unsigned)C; // indices outside the model are skipped, never dereferenced
+    if (live) {
         double acc = 0.0;
         for (int d = 0; d < D; ++d) {
             const double dx = feat_load<XT>::get(x, t * ldx + d) - mean[(size_t)c * D + d];
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(256) void k_topc_use(const void *__restrict__ x, lo
     }
     double r = (complete && nontop_llk) ? nontop_llk[t] : -__builtin_inf();
     double M = wave_max_f64(fmax(z, r));
-    double s = (lane < ctop) ? gexp(z - M) : 0.0;
+    double s = live ? gexp(z - M) : 0.0;
     s = wave_sum_f64(s);
     if (lane == 0) {
         if (r > -__builtin_inf()) s += gexp(r - M);
@@ -891,13 +893,13 @@ static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, co
 {
     constexpr int NR = 2 * KS + 2;
     const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + GEXP_TAB_N * sizeof(double); // two model stages + the exp table
-    static bool attr_done[16] = {};      // the attribute is per device
+    static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
     int attr_dev = 0;
     if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
-    bool &attr_set = attr_done[attr_dev];
-    if (!attr_set) {
+    std::atomic<bool> &attr_set = attr_done[attr_dev];
+    if (!attr_set.load(std::memory_order_acquire)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, WZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const unsigned grid = (unsigned)((T + NW * 32 - 1) / (NW * 32));
     k_llk_mfma<KS, XT, NW, WZ><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb, eit, inv, efin);
@@ -967,13 +969,13 @@ static int launch_stats_p(hipStream_t st, const void *x, long ldx, int D, int C,
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     const size_t lds = (2 * 64 * (RL + 32) + 32) * sizeof(double);
-    static bool attr_done[16] = {};      // the attribute is per device
+    static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
     int attr_dev = 0;
     if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
-    bool &attr_set = attr_done[attr_dev];
-    if (!attr_set) {
+    std::atomic<bool> &attr_set = attr_done[attr_dev];
+    if (!attr_set.load(std::memory_order_acquire)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_stats_mfma<KS, SQ, XT, NW, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const int ngrp = (nct + NW - 1) / NW;
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
@@ -1099,15 +1101,15 @@ int gmmk_topc_determine(hipStream_t st, int x_f64, const void *x, long T, long l
 }
 
 int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
-                  const double *iv, const double *lwc, int ctop, const int *idx, const double *nllk, int complete,
+                  const double *iv, const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete,
                   double lo, double hi, double *llk)
 {
     if (T <= 0) return 0;
     const unsigned grid = (unsigned)((T + 3) / 4);
     if (x_f64)
-        k_topc_use<double><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+        k_topc_use<double><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
     else
-        k_topc_use<float><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+        k_topc_use<float><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
     return (int)hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 // Segment bounds are frame indices relative to x / inv / efin / zbuf block 0; a segment may start
 // anywhere: its first tile starts at the 16-frame block holding f0 and rows before f0 are masked
 // (1 / S_t = 0).
+#include <atomic>
 #include "devutil.h"
 #include "gmm_kernels.h"
 
@@ -291,9 +292,11 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         if (_e != hipSuccess) return (int)_e;                             \
     } while (0)
 
-static int g_stats_z_waves = 8;
-static int g_stats_z_tv4 = 1; // A/B knob: 0 = two tiles per wave in the N / F mode too
-void gmmk_stats_z_set_tv4(int on) { g_stats_z_tv4 = on; }
+// per host thread: a context belongs to one thread at a time and pushes its own option right before the launch,
+// so contexts driven from different threads (one per GPU) cannot see each other's value
+static thread_local int g_stats_z_waves = 8;
+static thread_local int g_stats_z_tv4 = 1; // A/B knob: 0 = two tiles per wave in the N / F mode too
+int gmmk_stats_z_set_tv4(int on) { const int prev = g_stats_z_tv4; g_stats_z_tv4 = on; return prev; }
 void gmmk_stats_z_set_waves(int w) { g_stats_z_waves = (w == 4 || w == 16) ? w : 8; }
 // Gaussian tiles per workgroup: 16 for <8,2> and <16,1>, 8 for <4,2>
 int gmmk_stats_z_groups(int nct) { const int tpg = g_stats_z_waves == 4 ? 8 : 16; return (nct + tpg - 1) / tpg; }
@@ -307,13 +310,13 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     constexpr int PF = TPW > 2 ? TPW / 2 : 1;
     const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * PF * FT * sizeof(double); // two frame tiles + posterior factors
-    static bool attr_done[16] = {};      // the attribute is per device
+    static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
     int attr_dev = 0;
     if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
-    bool &attr_set = attr_done[attr_dev];
-    if (!attr_set) {
+    std::atomic<bool> &attr_set = attr_done[attr_dev];
+    if (!attr_set.load(std::memory_order_acquire)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const int ngrp = (nct + TPW * NW - 1) / (TPW * NW);
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));

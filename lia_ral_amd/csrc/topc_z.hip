@@ -243,7 +243,7 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
 // once per CLIENT of every test segment.
 template <typename XT>
 __global__ __launch_bounds__(256) void k_topc_use16(const void *__restrict__ x, long T, long ldx, int D, const double *__restrict__ mean,
-                                                    const double *__restrict__ iv, const double *__restrict__ lwc, int ctop,
+                                                    const double *__restrict__ iv, const double *__restrict__ lwc, int C, int ctop,
                                                     const int *__restrict__ idx, const double *__restrict__ nontop_llk, int complete,
                                                     double lo, double hi, double *__restrict__ llk_out)
 {
@@ -259,8 +259,9 @@ __global__ __launch_bounds__(256) void k_topc_use16(const void *__restrict__ x, 
     __syncthreads();
     const double NINF = -__builtin_inf();
     double z = NINF;
-    if (t < T && k < ctop) {
-        const int c = idx[t * ctop + k];
+    const int c = (t < T && k < ctop) ? idx[t * ctop + k] : -1;
+    const bool live = (unsigned)c < (unsigned)C; // an index outside the model (a caller's stale / mis-strided vector) is skipped, never dereferenced
+    if (live) {
         const double *mu = mean + (size_t)c * D, *vi = iv + (size_t)c * D, *xr = xs + f * Dp;
         double acc = 0.0;
         int d = 0;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void k_topc_use16(const void *__restrict__ x, 
     const double r = (complete && nontop_llk && t < T) ? nontop_llk[t] : NINF;
     double M = fmax(z, r);
     M = fmax(M, dpp_f64_0x128(M)); M = fmax(M, dpp_f64_0x124(M)); M = fmax(M, dpp_f64_0x122(M)); M = fmax(M, dpp_f64_0x121(M));
-    double s = (t < T && k < ctop) ? gexp(z - M) : 0.0;
+    double s = live ? gexp(z - M) : 0.0;
     s += dpp_f64_0x128(s); s += dpp_f64_0x124(s); s += dpp_f64_0x122(s); s += dpp_f64_0x121(s);
     if (k == 0 && t < T) {
         if (r > NINF) s += gexp(r - M);
@@ -293,14 +294,14 @@ __global__ __launch_bounds__(256) void k_topc_use16(const void *__restrict__ x, 
 }
 
 int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
-                    const double *lwc, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk)
+                    const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk)
 {
     if (T <= 0) return 0;
     if (ctop > 16 || D % 2 != 0) return -1; // the caller keeps the one-wave-per-frame kernel
     const unsigned grid = (unsigned)((T + 15) / 16);
     const size_t lds = (size_t)16 * (D + 1) * sizeof(double);
-    if (x_f64) k_topc_use16<double><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
-    else k_topc_use16<float><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, ctop, idx, nllk, complete, lo, hi, llk);
+    if (x_f64) k_topc_use16<double><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
+    else k_topc_use16<float><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
     return (int)hipGetLastError();
 }
 

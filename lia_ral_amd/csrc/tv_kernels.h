@@ -8,9 +8,10 @@ int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd,
 int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked = nullptr,
                           long spk = 0, double diag_add = 0.0);
 int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read packed lower rows directly
-void tvk_set_chol_gemm_path(int on);
-void tvk_set_gemm_clamp(int on);
-void tvk_set_gemm_remap(int on);
+// A/B switches: thread-local (they act on the launches of the calling host thread); return the previous value
+int tvk_set_chol_gemm_path(int on);
+int tvk_set_gemm_clamp(int on);
+int tvk_set_gemm_remap(int on);
 int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status,
                                  const double *Apacked = nullptr, long spk = 0, double diag_add = 0.0);
 int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,

@@ -410,7 +410,7 @@ int liagpu_compute_test_files(int device, const char *world_path, int nClients, 
         for (size_t s = 0; s < segs.size(); ++s)
             for (int i = 0; i < nClients; ++i)   // frameIdxToTime(begin), frameIdxToTime(begin + length) (ComputeTest.cpp:186)
                 text += resultLine(out[s * nClients + i], client_names[i], testName, gender, threshold, true,
-                                   segs[s].begin * frameLength, (segs[s].begin + segs[s].length) * frameLength) + "\n";
+                                   frameIdxToTime(segs[s].begin, frameLength), frameIdxToTime(segs[s].begin + segs[s].length, frameLength)) + "\n";
         if ((long)text.size() + 1 > out_cap) throw Exception("out_text too small");
         memcpy(out_text, text.c_str(), text.size() + 1);
     })

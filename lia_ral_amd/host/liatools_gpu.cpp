@@ -23,11 +23,24 @@ unsigned long totalFrame(const SegCluster &c)
     return n;
 }
 
+unsigned long timeToFrameIdx(double time, double frameLength)
+{
+    // SegTools.cpp:135-142: the quotient is TRUNCATED; only a fractional part above 0.99999 (a time that is a whole
+    // number of frames up to rounding, e.g. 0.07 / 0.01 = 6.999999...) moves to the next frame
+    const double q = time / frameLength, whole = floor(q);
+    return (unsigned long)whole + ((q - whole) > 0.99999 ? 1ul : 0ul);
+}
+double frameIdxToTime(unsigned long idx, double frameLength)
+{
+    // SegTools.cpp:143-148: the time in whole milliseconds, truncated
+    return (double)(unsigned long)((double)idx * 1000.0 * frameLength) / 1000.0;
+}
+
 Seg segFromLabel(double begin_s, double end_s, double frameLength, unsigned long source)
 {
-    // SegTools.cpp:265-271: frame index = time / frameLength (rounded), end frame INCLUSIVE
+    // SegTools.cpp:265-271: both times go through timeToFrameIdx, end frame INCLUSIVE
     Seg s;
-    const unsigned long b = (unsigned long)(begin_s / frameLength + 0.5), e = (unsigned long)(end_s / frameLength + 0.5);
+    const unsigned long b = timeToFrameIdx(begin_s, frameLength), e = timeToFrameIdx(end_s, frameLength);
     s.begin = b;
     s.length = e - b + 1;
     s.source = source;
@@ -95,7 +108,7 @@ void MixtureGD::computeAll()
     for (size_t i = 0; i < _cov.size(); ++i) _covInv[i] = 1.0 / _cov[i];
 }
 
-DeviceMixture::DeviceMixture(GpuServer &srv, const MixtureGD &m) : _srv(srv)
+DeviceMixture::DeviceMixture(GpuServer &srv, const MixtureGD &m) : _srv(srv), _c(m.getDistribCount()), _d(m.getVectSize())
 {
     MixtureGD &mm = const_cast<MixtureGD &>(m);
     srv.check(gmmiv_gmm_create(srv.ctx(), (int)m.getDistribCount(), (int)m.getVectSize(), mm.weights().data(), mm.means().data(),
@@ -342,6 +355,8 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
     const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
+    // a model with fewer Gaussians than topDistribsCount selects all of them (the row stride of idx follows the clamped count)
+    topDistribsCount = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), world.getDistribCount());
     // the world's top-C' indices and non-top remainder STAY on the device for the client passes (40 bytes per frame that every
     // client would otherwise upload again); only the per-frame log-likelihoods come back for the segment means
     struct DevBuf {
@@ -409,7 +424,7 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
     const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
-    const int ctop = topDistribsCount;
+    const int ctop = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), world.getDistribCount());
     std::vector<int32_t> idx((size_t)n * ctop);
     std::vector<double> nllk(n), llkw(n), llkc(n);
     // DETERMINE_TOP_DISTRIBS on every frame; frames that are not a multiple of worldDecime inside their segment then

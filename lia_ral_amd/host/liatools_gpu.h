@@ -31,6 +31,8 @@ struct Seg {
 };
 typedef std::vector<Seg> SegCluster;
 unsigned long totalFrame(const SegCluster &c);
+unsigned long timeToFrameIdx(double time, double frameLength);   // SegTools.cpp:135-142
+double frameIdxToTime(unsigned long idx, double frameLength);    // SegTools.cpp:143-148
 Seg segFromLabel(double begin_s, double end_s, double frameLength, unsigned long source = 0);
 
 class GpuServer; // context owner (the StatServer/MixtureServer pair of the reference)
@@ -100,10 +102,13 @@ class DeviceMixture {
     void update(const MixtureGD &m);
     gmmiv_gmm *handle() const { return _g; }
     GpuServer &server() { return _srv; }
+    unsigned long getDistribCount() const { return _c; }
+    unsigned long getVectSize() const { return _d; }
 
   private:
     GpuServer &_srv;
     gmmiv_gmm *_g = nullptr;
+    unsigned long _c = 0, _d = 0;
 };
 
 // MixtureStat in EM mode: resetEM / computeAndAccumulateEM (batched) / getEM / getEMFeatureCount / addAccEM

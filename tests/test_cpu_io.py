@@ -44,6 +44,18 @@ def test_label_selection_inclusive_end():
     assert len(b) == 0
 
 
+def test_label_times_off_the_frame_grid(tmp_path):
+    """timeToFrameIdx (SegTools.cpp:135-142) truncates time / frameLength and only moves to the next frame when the
+    fractional part exceeds 0.99999 -- it does NOT round to nearest: 0.125 s -> frame 12, 5.928 s -> 592, while
+    0.29 / 0.01 = 28.999999999999996 -> 29 (a whole number of frames up to rounding)."""
+    from lia_ral_amd import host_capi as h
+    lbl = tmp_path / "off.lbl"
+    lbl.write_text("0.125 0.138 sp\n5.928 5.9399 sp\n0.07 0.29 sp\n0.0199 0.02999995 sp\n0.0199 0.0299999 sp\n")
+    b, l = h.label_segments(str(lbl), "sp")
+    assert list(b) == [12, 592, 7, 1, 1]
+    assert list(l) == [13 - 12 + 1, 593 - 592 + 1, 29 - 7 + 1, 3 - 1 + 1, 2 - 1 + 1]   # 2.999995 -> 3, 2.99999 -> 2     # end frame inclusive (:269-270)
+
+
 def test_damaged_file_is_reported(tmp_path):
     from lia_ral_amd import host_capi as h
     bad = tmp_path / "short.gmm"
