@@ -7,6 +7,12 @@ log-likelihood pass + full-posterior sufficient statistics over every frame (HIP
 the RCCL all-reduce of the 1.98 MB statistics when N > 1, the M-step and the model re-pack.
 Metric: Gframe-Gaussian evaluations/s, whole job (all ranks).  Scaling is weak (10 M frames/GPU).
 
+`--workload tv` runs BASELINE.json configs[3] instead: one TotalVariability T-matrix EM iteration per step on
+utterance-sharded statistics (6250 utterances x 3000 frames per GPU = 50 k over 8 GPUs, 2048-g UBM, rank 400): estimateTETt,
+estimateAandC, reduce-scatter of A / Cmx by Gaussian blocks, sharded updateTestimate, all-gather of T, minDivergence.  With
+N > 1 the default (EM) run also reports that iteration as `tv_em`.  The collectives are the C ABI's own (gmmiv_comm_*: RCCL
+called by libgmmiv on the device buffers); torch.distributed only launches the ranks and carries the 128-byte RCCL id.
+
 Launch: python bench.py --gpus 1   |   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
 """
 import argparse
@@ -47,24 +53,49 @@ def synth_frames(w, mean, iv, T, device, seed):
     return x
 
 
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; falls back to the logical count."""
+    try:
+        seen, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":")[1].strip()))
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(w, mean, iv, seed):
-    """Oracle port (-O3 -ffast-math, pthreads with the reference's frame partitioning) on the host cores."""
+    """Oracle port (-O3 -ffast-math, pthreads with the reference's frame partitioning and one private accumulator per thread,
+    AccumulateStat.cpp:170-299) on the host cores: 1 thread, then a sweep up to the logical core count.  The private
+    accumulators are 2 MB per thread (C (1 + 2 D) doubles, like the reference's per-thread MixtureStat), so past the point
+    where they stop fitting the last-level cache the loop is DRAM-bound: the best thread count is reported as `value`, the
+    single-thread figure and the whole sweep beside it."""
     from conftest import make_frames
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
-    frames = min(30000 * cores, 2_000_000)
-    x = make_frames(w, mean, iv, frames, seed=seed).astype(np.float64)
+    logical, phys = os.cpu_count() or 1, physical_cores()
+    counts = sorted({1, max(1, phys // 4), max(1, phys // 2), phys, logical})
     g = orc.Gmm(w, mean, iv)
-    orc.em_accumulate(g, x[:2000], fast=True, threads=cores)       # warm-up / page-in
-    t = time.time()
-    orc.em_accumulate(g, x, fast=True, threads=cores)
-    dt = time.time() - t
-    return {"value": frames * C / dt / 1e9, "unit": "Gframe-Gaussian/s", "cores": cores, "kind": "port",
-            "sample": "%d frames x %d Gaussians, one EM statistics pass, %d pthreads (oracle/oracle_mt.c, "
-                      "gcc -O3 -ffast-math like the reference), %.1f s" % (frames, C, cores, dt)}
+    x = make_frames(w, mean, iv, 4000 * max(counts), seed=seed).astype(np.float64)
+    orc.em_accumulate(g, x[:2000], fast=True, threads=min(8, logical))       # warm-up / page-in
+    sweep = []
+    for th in counts:
+        frames = 4000 * th
+        t = time.time()
+        orc.em_accumulate(g, x[:frames], fast=True, threads=th)
+        dt = time.time() - t
+        sweep.append({"threads": th, "frames": frames, "seconds": dt, "gpairs_per_s": frames * C / dt / 1e9})
+    best = max(sweep, key=lambda r: r["gpairs_per_s"])
+    return {"value": best["gpairs_per_s"], "unit": "Gframe-Gaussian/s", "cores": best["threads"], "kind": "port",
+            "single_thread": sweep[0]["gpairs_per_s"], "logical_cores": logical, "physical_cores": phys, "sweep": sweep,
+            "sample": "4000 frames per thread x %d Gaussians, one EM statistics pass per thread count (oracle/oracle_mt.c, gcc -O3 "
+                      "-ffast-math like the reference; a restatement of the reference loops, not the original binary), %.1f s in all"
+                      % (C, sum(r["seconds"] for r in sweep))}
 
 
-def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000, R=400):
+def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000, R=400, check=True):
     """BASELINE.json configs[2] on a bounded slice: IvExtractor end-to-end (Baum-Welch N/F statistics,
     substractM, L = I + sum N TETt, SPD inverse, w = L^-1 T Sigma^-1 F) for U utterances x 3000 frames
     per GPU; TETt is precomputed once (T is fixed during extraction, IvExtractor.cpp:136)."""
@@ -114,9 +145,172 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    parity = ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None
     return {"metric": "i-vectors/s (IvExtractor end-to-end, 2048-g UBM, rank 400, 3000-frame utterances)",
             "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "stats_ms": times["stats_ms"],
-            "solve_ms": times["solve_ms"], "finite": bool(torch.isfinite(W).all().item()), "fused_stats": fused}
+            "solve_ms": times["solve_ms"], "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "fused_stats": fused}
+
+
+def ivector_parity(x, frames, w, mean, iv, Tm, W, rows):
+    """The CHECKER leg of the secondary (untimed): the i-vectors of a few utterances recomputed end to end by the CPU oracle
+    (Baum-Welch statistics, substractM, estimateTETt, estimateW) from the same frames; north_star tolerance 1e-6 relative."""
+    from oracle import oracle as orc
+    og = orc.Gmm(w, mean, iv)
+    Tm_h = Tm.cpu().numpy()
+    te = orc.tv_tett(Tm_h, iv.ravel(), C, D)
+    worst = 0.0
+    for u in rows:
+        xu = x[u * frames:(u + 1) * frames].cpu().numpy().astype(np.float64)
+        No, Fo = orc.tv_stats(og, xu, np.zeros(frames, np.int64), 1)
+        Wo = orc.tv_estimate_w(No, orc.tv_subtract_m(No, Fo, mean.ravel()), Tm_h, iv.ravel(), te)[0]
+        worst = max(worst, float(np.max(np.abs(W[u].cpu().numpy() - Wo)) / np.max(np.abs(Wo))))
+    return {"utterances_checked": rows, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "ok": worst < 1e-6}
+
+
+def make_collectives(ctx, dev, world, rank, want):
+    """The product's collectives (gmmiv_comm_* = RCCL inside libgmmiv).  Every rank must end up with the SAME back end, so
+    the outcome of the communicator set-up is agreed through the launcher's process group; if it failed anywhere, all ranks
+    use torch.distributed's RCCL binding instead and the JSON line says so (`collectives`)."""
+    from lia_ral_amd import capi
+    from lia_ral_amd import dist as gd
+    if world == 1:
+        return gd.GmmivCollectives(capi.Comm(ctx, 1, 0)), None
+    import threading
+    import torch.distributed as dist
+    if want == "torch":
+        return gd.TorchCollectives(), "requested with --collectives torch"
+    box = {}
+
+    def create():
+        try:
+            box["coll"] = gd.gmmiv_collectives_from_torch(ctx, dev)
+        except Exception as e:      # noqa: BLE001 - reported, never silent
+            box["err"] = repr(e)
+    th = threading.Thread(target=create, daemon=True)
+    th.start()
+    th.join(timeout=180.0)
+    ok = torch.tensor([1 if "coll" in box else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        coll = box["coll"]
+        probe = torch.full((4096,), float(rank + 1), dtype=torch.float64, device=dev)
+        coll.allreduce(probe)
+        torch.cuda.synchronize()
+        if bool((probe == world * (world + 1) / 2.0).all().item()):
+            coll.take_bytes()
+            return coll, None
+        box["err"] = "probe all-reduce returned a wrong sum"
+    return gd.TorchCollectives(), "gmmiv_comm unavailable on some rank (%s): torch.distributed collectives used" % box.get("err", "timeout")
+
+
+class GpuTvOps:
+    """The per-rank compute of one TotalVariability iteration on device-resident statistics (lia_ral_amd.dist.tv_em_iteration)."""
+
+    def __init__(self, ctx, N, F, Tm, invvar, means, R):
+        self.ctx, self.N, self.F, self.T, self.invvar, self.means, self.R = ctx, N, F, Tm, invvar, means, R
+        dev = N.device
+        P = R * (R + 1) // 2
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+        self.tett_buf = torch.empty((C, P), dtype=torch.float64, device=dev)
+        self.acc = dict(A=z(C, P), Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=torch.empty((N.shape[0], R), dtype=torch.float64, device=dev))
+
+    def tett(self):
+        self.ctx.tv_tett(self.T, self.invvar, C, D, out=self.tett_buf)
+
+    def estep(self):
+        for k in ("A", "Cmx", "Rm", "r", "meanW"):      # TVAcc::resetTmpAcc
+            self.acc[k].zero_()
+        self.ctx.tv_estimate_a_and_c(self.N, self.F, self.T, self.invvar, self.tett_buf, C, D, acc=self.acc)
+        return self.acc
+
+    def update_t(self, A_blk, C_blk, cb):
+        return self.ctx.tv_update_t(A_blk, C_blk, cb, D, out=torch.empty((self.R, cb * D), dtype=torch.float64, device=A_blk.device))
+
+    def min_divergence(self, acc, Tn, n):
+        self.ctx.tv_min_divergence(acc["Rm"], acc["r"], acc["meanW"] / n, self.means, Tn, n, C, D)
+        self.T = Tn
+        return Tn
+
+
+TV_FLOP_PER_UTT = 2.0 * C * (400 * 401 // 2) * 2 + 2.0 * C * D * 400 * 2 + 21.7e6    # SURVEY 8(d): L + A (packed), aux + Cmx, solve: 875 M
+
+
+def tv_cpu_baseline(R):
+    """The oracle's scalar estimateAandC loop (AccumulateTVStat.cpp:1702-1795 restated) on 6 utterances at full shape, 1 thread."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    U = 6
+    N = rng.gamma(0.6, 2.5, (U, C)); F = rng.normal(size=(U, C * D)); Tm = rng.normal(0, 0.02, (R, C * D)); iv = rng.uniform(0.5, 2, C * D)
+    te = orc.tv_tett(Tm, iv, C, D)
+    t = time.time()
+    orc.tv_estimate_a_and_c(N, F, Tm, iv, te)
+    dt = time.time() - t
+    return {"value": U / dt, "unit": "utterances/s", "cores": 1, "kind": "port",
+            "sample": "estimateAandC on %d utterances at C=2048, R=%d, scalar fp64 oracle (-O2), %.1f s; TETt precomputed" % (U, R, dt)}
+
+
+def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup):
+    """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
+    then `steps` EM iterations timed.  Returns the JSON fields of the workload."""
+    from lia_ral_amd import dist as gd
+    import torch.distributed as dist
+    invvar = torch.from_numpy(iv.ravel().copy()).to(dev)
+    means = torch.from_numpy(mean.ravel().copy()).to(dev)
+    N = torch.empty((U, C), dtype=torch.float64, device=dev)
+    F = torch.empty((U, C * D), dtype=torch.float64, device=dev)
+    t_stats = time.perf_counter()
+    CH = 1250
+    for u0 in range(0, U, CH):
+        n = min(CH, U - u0)
+        x = synth_frames(w, mean, iv, n * frames, dev, seed=9000 + 131 * rank + u0)
+        g.tv_stats(x, np.arange(n + 1, dtype=np.int64) * frames, N[u0:u0 + n], F[u0:u0 + n])
+        del x
+    ctx.tv_subtract_m(N, F, means, C, D)                # TVAcc::substractM once (the centred statistics are kept)
+    torch.cuda.synchronize()
+    t_stats = time.perf_counter() - t_stats
+    gen = torch.Generator(device=dev); gen.manual_seed(5)     # the same initial T on every rank
+    Tm = 0.01 * torch.randn((R, C * D), dtype=torch.float64, device=dev, generator=gen)
+    ops = GpuTvOps(ctx, N, F, Tm, invvar, means, R)
+    n_total = U * world
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll)
+    coll.take_bytes()
+    phases = {"sync": torch.cuda.synchronize}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    nbytes = coll.take_bytes() / max(steps, 1)
+    ph = {k: v / steps * 1e3 for k, v in phases.items() if k != "sync"}
+    estep_tf = TV_FLOP_PER_UTT * U / (ph["estep"] * 1e-3) / 1e12
+    finite = bool(torch.isfinite(ops.T).all().item())
+    return {
+        "metric": "utterances/s (TotalVariability: one T-matrix EM iteration, 2048-g UBM, rank %d)" % R,
+        "value": n_total * steps / dt, "unit": "utterances/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "TotalVariability T-matrix EM: 2048-g UBM, rank %d, %d utterances x %d frames per GPU (50 k over 8 GPUs), "
+                               "N/F resident in HBM, 1 EM iteration per step" % (R, U, frames),
+                   "gaussians": C, "dim": D, "rank": R, "utterances_per_gpu": U,
+                   "partitioning": "utterances sharded per rank; reduce-scatter of A_packed / Cmx by Gaussian blocks, sharded "
+                                   "updateTestimate, all-gather of T, all-reduce of R / r / meanW"},
+        "phases_ms": ph, "collective_bytes_per_step_per_rank": nbytes, "collectives": coll.name,
+        "statistics_once_s": t_stats, "finite": finite,
+        "roofline": {"bound": "mfma", "kernel": "E-step (k_dgemm: L, aux, A, Cmx + chol_fused)", "achieved": estep_tf, "peak": PEAK_F64_TFLOPS,
+                     "unit": "TFLOP/s", "frac": estep_tf / PEAK_F64_TFLOPS, "traffic": None,
+                     "algorithmic_flop_per_utterance": TV_FLOP_PER_UTT, "kernel_ms": ph["estep"]},
+    }
 
 
 def main():
@@ -125,6 +319,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
+    ap.add_argument("--workload", choices=["em", "tv"], default="em", help="em: TrainWorld EM pass (headline); tv: TotalVariability T-matrix EM iteration (configs[3])")
+    ap.add_argument("--tv-utterances", type=int, default=6250, help="utterances per GPU of the T-matrix EM workload")
+    ap.add_argument("--tv-rank", type=int, default=400)
+    ap.add_argument("--collectives", choices=["gmmiv", "torch"], default="gmmiv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--mean-spread", type=float, default=2.0,
@@ -149,7 +347,6 @@ def main():
 
     w, mean, iv = make_gmm(C, D, seed=0, spread=args.mean_spread)
     T = args.frames
-    x = synth_frames(w, mean, iv, T, dev, seed=1234 + rank)
     ctx = capi.Context(local, torch.cuda.current_stream().cuda_stream)
     ctx.set_option("timing", 1)
     if args.wg_waves:
@@ -157,6 +354,22 @@ def main():
     if args.em_fused >= 0:
         ctx.set_option("em_fused", args.em_fused)
     g = ctx.gmm(w, mean, iv)
+    coll, coll_note = make_collectives(ctx, dev, world, rank, args.collectives)
+    if args.workload == "tv":
+        res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup)
+        if rank == 0:
+            if coll_note:
+                res["collectives_note"] = coll_note
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = tv_cpu_baseline(args.tv_rank)
+            print(json.dumps(res), flush=True)
+        g.close()
+        ctx.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    x = synth_frames(w, mean, iv, T, dev, seed=1234 + rank)
     nacc = g.em_acc_len()
     acc = torch.zeros(nacc, dtype=torch.float64, device=dev)
     mean_d = torch.from_numpy(mean).to(dev)
@@ -177,7 +390,7 @@ def main():
                 if ctx.kernel_launches(name) > 0:
                     kern_ms.setdefault(name, []).append((ctx.kernel_ms(name), ctx.kernel_launches(name)))
         if world > 1:
-            dist.all_reduce(acc)                            # EM sufficient statistics, 1.98 MB fp64
+            coll.allreduce(acc)                             # EM sufficient statistics, 1.98 MB fp64 (gmmiv_allreduce_f64)
         # M-step (MixtureStat::getEM) + variance flooring + re-pack of the device model
         capi._chk(capi.lib.gmmiv_em_get(ctx._h, C, D, capi._ptr(acc), capi._ptr(mean_d), capi._ptr(cov_d),
                                         capi._ptr(w_d), capi._ptr(nm_d), capi._ptr(nc_d)))
@@ -215,7 +428,10 @@ def main():
                                "resident in HBM, 1 EM iteration per step" % T,
                    "gaussians": C, "dim": D, "frames_per_gpu": T, "partitioning": "frames sharded per rank, "
                    "one RCCL all-reduce of %d doubles per step" % nacc},
+        "collectives": coll.name,
     }
+    if coll_note:
+        out["collectives_note"] = coll_note
     # the same E-step on a heavily overlapping mixture (means ~ N(0, 0.3^2)): hundreds of Gaussians carry
     # posterior mass per frame, none of the data-dependent skips of K1/K2 can fire -- the dense floor.
     dense = None
@@ -255,12 +471,19 @@ def main():
                  "k_stats_tflops": KERNEL_FLOP[sname] * Td * C / (dense_k[1] * 1e-3) / 1e12}
         del xd, accd
     secondary = None
+    tv_em = None
     if not args.no_secondary:
         g.set(w, mean, iv)     # back to the seed model for the i-vector slice
-        secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world)
+        secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, check=not args.no_cpu_baseline)
+        if world > 1:          # configs[3] is natively multi-GPU: one T-matrix EM iteration on utterance-sharded statistics
+            x = xs = None          # release the 2.4 GB frame block of the EM workload
+            torch.cuda.empty_cache()
+            tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1)
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
+        if tv_em:
+            out["tv_em"] = tv_em
         if dense:
             out["dense_data"] = dense
         # per kernel: total ms per step, launches per step (frame chunks), algorithmic TFLOP/s

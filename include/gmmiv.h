@@ -46,6 +46,9 @@ enum { GMMIV_TOP_PARTIAL = 0, GMMIV_TOP_COMPLETE = 1 }; /* computeLLKWithTopDist
 int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out);
 void gmmiv_ctx_destroy(gmmiv_ctx *ctx);
 int gmmiv_ctx_sync(gmmiv_ctx *ctx);
+/* The hipStream_t every call of this context is enqueued on (the one given to gmmiv_ctx_create, or the private one): a host
+ * layer that keeps its own device buffers orders its copies / memsets on it instead of synchronising around every call. */
+void *gmmiv_ctx_stream(gmmiv_ctx *ctx);
 const char *gmmiv_last_error(void);
 const char *gmmiv_version(void);
 /* Runtime knobs; returns the previous value (-1: unknown key).
@@ -309,6 +312,43 @@ int gmmiv_jfa_estimate_z(gmmiv_ctx *ctx, int64_t nspk, int C, int D, const doubl
 /* JFAAcc::estimateZandD (:3480-3516): Z as above (tau < 0) and D <- sum_s z F / sum_s (1 / L + z^2) N, in place. */
 int gmmiv_jfa_estimate_z_and_d(gmmiv_ctx *ctx, int64_t nspk, int C, int D, const double *N, const double *F, const double *invvar, double *Dm,
                                double *Z);
+
+/* ---- collectives of the paths that shard: RCCL over xGMI ---------------------------------------------
+ * The reference merges the private accumulators of its worker threads under a mutex: MixtureStat::addAccEM
+ * (LIA_SpkTools/src/AccumulateStat.cpp:286-292) for the EM statistics, `+=` of A / Cmx / R / r in the threaded
+ * estimateAandC (AccumulateTVStat.cpp:1920-1937, 2036-2044).  With one rank per GPU the merge is a collective on the
+ * accumulators where they lie (device memory):
+ *   EM statistics (TrainWorld)        gmmiv_allreduce_f64 of the flat accumulator, gmmiv_em_acc_len() doubles (1.98 MB)
+ *   T-matrix EM (TotalVariability)    gmmiv_reduce_scatter_f64 of A_packed and Cmx by blocks of Gaussians -> each rank
+ *                                     solves T_c = A_c^-1 Cmx_c for its own Gaussians (updateTestimate is independent per
+ *                                     Gaussian, :981-1000) -> gmmiv_allgather_f64 of the T blocks; R, r, meanW: allreduce
+ * One communicator per context.  Rank 0 obtains an id (gmmiv_comm_get_unique_id) and ships its 128 bytes to the other ranks
+ * over any host channel (gmmiv_comm_exchange_id_file: a file in a directory all ranks see; MPI / a TCP store work as well),
+ * then EVERY rank calls gmmiv_comm_create (collective).  world == 1 needs no id and no RCCL.  The calls are enqueued on the
+ * context's stream; device buffers are used in place, host buffers (allreduce / broadcast only) are staged and the call
+ * returns after the result is back.  RCCL is loaded at run time (dlopen of the copy already mapped in the process, else
+ * librccl.so.1; override with the environment variable GMMIV_RCCL_LIB): GMMIV_ERR_UNSUPPORTED when it cannot be found. */
+typedef struct gmmiv_comm gmmiv_comm;
+#define GMMIV_COMM_ID_BYTES 128
+int gmmiv_comm_get_unique_id(void *id128);
+/* rank 0: creates the id and publishes it at `path` (atomically); other ranks: wait up to timeout_s for it and read it. */
+int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double timeout_s);
+int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gmmiv_comm **out);
+void gmmiv_comm_destroy(gmmiv_comm *comm);
+int gmmiv_comm_world(const gmmiv_comm *comm);
+int gmmiv_comm_rank(const gmmiv_comm *comm);
+const char *gmmiv_comm_backend(const gmmiv_comm *comm); /* path of the RCCL library in use */
+/* payload bytes this rank passed to collectives since the last call of this function (then reset to 0) */
+double gmmiv_comm_take_bytes(gmmiv_comm *comm);
+/* buf[n] <- sum over ranks (in place; host or device) */
+int gmmiv_allreduce_f64(gmmiv_comm *comm, double *buf, size_t n);
+/* recv[recvcount] <- block `rank` of the sum over ranks of send[world * recvcount] (device; in place when
+ * recv == send + rank * recvcount) */
+int gmmiv_reduce_scatter_f64(gmmiv_comm *comm, const double *send, double *recv, size_t recvcount);
+/* recv[world * sendcount] <- the ranks' send[sendcount], in rank order (device; in place when send == recv + rank * sendcount) */
+int gmmiv_allgather_f64(gmmiv_comm *comm, const double *send, double *recv, size_t sendcount);
+/* buf[n] on every rank <- buf of rank `root` (host or device) */
+int gmmiv_broadcast_f64(gmmiv_comm *comm, double *buf, size_t n, int root);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,8 @@ def _load():
     lib.gmmiv_ctx_kernel_ms.restype = ct.c_double
     lib.gmmiv_ctx_kernel_launches.restype = ct.c_long
     lib.gmmiv_ctx_set_option.restype = ct.c_long
+    lib.gmmiv_comm_backend.restype = ct.c_char_p
+    lib.gmmiv_comm_take_bytes.restype = ct.c_double
     return lib
 
 
@@ -372,6 +374,75 @@ class Context:
         _chk(lib.gmmiv_score_plda(self._h, models_sum.shape[0], ct.c_int64(M), ct.c_int64(S), _ptr(models_sum),
                                   ns.ctypes.data_as(ct.c_void_p), _ptr(segs), _ptr(FTJF), _ptr(out)))
         return out
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """gmmiv_comm: the RCCL communicator of one context (one rank per GPU).  world == 1 needs no id and no RCCL.
+    Buffers: torch CUDA tensors (float64, contiguous) are used in place; numpy arrays are accepted by allreduce / broadcast."""
+
+    def __init__(self, ctx, world=1, rank=0, uid=None):
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        self._h = ct.c_void_p()
+        if world > 1 and (uid is None or len(uid) != COMM_ID_BYTES):
+            raise GmmivError("Comm: world > 1 needs the %d-byte id of rank 0 (Comm.unique_id())" % COMM_ID_BYTES)
+        buf = ct.create_string_buffer(bytes(uid), COMM_ID_BYTES) if uid is not None else None
+        _chk(lib.gmmiv_comm_create(ctx._h, self.world, self.rank, buf, ct.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        buf = ct.create_string_buffer(COMM_ID_BYTES)
+        _chk(lib.gmmiv_comm_get_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def exchange_id_file(path, rank, timeout_s=120.0):
+        buf = ct.create_string_buffer(COMM_ID_BYTES)
+        _chk(lib.gmmiv_comm_exchange_id_file(path.encode(), int(rank), buf, ct.c_double(timeout_s)))
+        return buf.raw
+
+    def close(self):
+        if self._h:
+            lib.gmmiv_comm_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            if sys is None or sys.is_finalizing():
+                return
+            self.close()
+        except Exception:
+            pass
+
+    def backend(self):
+        return lib.gmmiv_comm_backend(self._h).decode()
+
+    def take_bytes(self):
+        return lib.gmmiv_comm_take_bytes(self._h)
+
+    @staticmethod
+    def _n(a):
+        return a.numel() if _is_torch(a) else a.size
+
+    def allreduce(self, a):
+        _chk(lib.gmmiv_allreduce_f64(self._h, _ptr(a), ct.c_size_t(self._n(a))))
+        return a
+
+    def broadcast(self, a, root=0):
+        _chk(lib.gmmiv_broadcast_f64(self._h, _ptr(a), ct.c_size_t(self._n(a)), int(root)))
+        return a
+
+    def reduce_scatter(self, send, recv):
+        assert self._n(send) == self.world * self._n(recv)
+        _chk(lib.gmmiv_reduce_scatter_f64(self._h, _ptr(send), _ptr(recv), ct.c_size_t(self._n(recv))))
+        return recv
+
+    def allgather(self, send, recv):
+        assert self._n(recv) == self.world * self._n(send)
+        _chk(lib.gmmiv_allgather_f64(self._h, _ptr(send), _ptr(recv), ct.c_size_t(self._n(send))))
+        return recv
 
 
 class Gmm:

@@ -99,6 +99,21 @@ struct gmmiv_comm {
     }
 };
 
+// Release everything that needs the context (called by gmmiv_comm_destroy, and by gmmiv_ctx_destroy for communicators the
+// caller still holds: afterwards the handle is an empty shell that gmmiv_comm_destroy can still delete safely).
+void gmmiv_comm_orphan(gmmiv_comm *c)
+{
+    if (!c || !c->ctx) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->nc) { (void)c->api->CommDestroy(c->nc); c->nc = nullptr; }
+    if (c->stage) { (void)hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
+    auto &v = c->ctx->comms;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == c) { v.erase(v.begin() + i); break; }
+    c->ctx = nullptr;
+}
+
 #define NCHK(c, expr)                                                                                                  \
     do {                                                                                                               \
         ncclResult_t _r = (expr);                                                                                      \
@@ -168,6 +183,7 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
             return GMMIV_ERR_HIP;
         }
     }
+    ctx->comms.push_back(c);
     *out = c;
     return GMMIV_OK;
 }
@@ -175,10 +191,7 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
 void gmmiv_comm_destroy(gmmiv_comm *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->nc) (void)c->api->CommDestroy(c->nc);
-    if (c->stage) (void)hipFree(c->stage);
+    gmmiv_comm_orphan(c); // releases RCCL and the staging buffer (no-op when the context already went away)
     delete c;
 }
 
@@ -187,7 +200,7 @@ int gmmiv_comm_rank(const gmmiv_comm *c) { return c ? c->rank : -1; }
 const char *gmmiv_comm_backend(const gmmiv_comm *c)
 {
     if (!c) return "";
-    return c->world == 1 ? "single rank (no collective library)" : c->api->where.c_str();
+    return c->world == 1 || !c->api ? "single rank (no collective library)" : c->api->where.c_str();
 }
 double gmmiv_comm_take_bytes(gmmiv_comm *c)
 {
@@ -200,7 +213,7 @@ double gmmiv_comm_take_bytes(gmmiv_comm *c)
 // buf[n] <- sum over ranks, in place; buf: host or device
 int gmmiv_allreduce_f64(gmmiv_comm *c, double *buf, size_t n)
 {
-    if (!c || (!buf && n)) { gmmiv_set_error("allreduce_f64: bad argument"); return GMMIV_ERR_ARG; }
+    if (!c || !c->ctx || (!buf && n)) { gmmiv_set_error("allreduce_f64: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)n * 8;
     if (c->world == 1 || n == 0) return GMMIV_OK;
     GCHK(hipSetDevice(c->ctx->device));
@@ -223,7 +236,7 @@ int gmmiv_allreduce_f64(gmmiv_comm *c, double *buf, size_t n)
 // In place when recv == send + rank * recvcount.
 int gmmiv_reduce_scatter_f64(gmmiv_comm *c, const double *send, double *recv, size_t recvcount)
 {
-    if (!c || ((!send || !recv) && recvcount)) { gmmiv_set_error("reduce_scatter_f64: bad argument"); return GMMIV_ERR_ARG; }
+    if (!c || !c->ctx || ((!send || !recv) && recvcount)) { gmmiv_set_error("reduce_scatter_f64: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)recvcount * 8 * c->world;
     if (recvcount == 0) return GMMIV_OK;
     if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("reduce_scatter_f64: device buffers only"); return GMMIV_ERR_ARG; }
@@ -239,7 +252,7 @@ int gmmiv_reduce_scatter_f64(gmmiv_comm *c, const double *send, double *recv, si
 // recv[world * sendcount] <- the ranks' send[sendcount] in rank order; DEVICE buffers.  In place when send == recv + rank * sendcount.
 int gmmiv_allgather_f64(gmmiv_comm *c, const double *send, double *recv, size_t sendcount)
 {
-    if (!c || ((!send || !recv) && sendcount)) { gmmiv_set_error("allgather_f64: bad argument"); return GMMIV_ERR_ARG; }
+    if (!c || !c->ctx || ((!send || !recv) && sendcount)) { gmmiv_set_error("allgather_f64: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)sendcount * 8 * c->world;
     if (sendcount == 0) return GMMIV_OK;
     if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("allgather_f64: device buffers only"); return GMMIV_ERR_ARG; }
@@ -255,7 +268,7 @@ int gmmiv_allgather_f64(gmmiv_comm *c, const double *send, double *recv, size_t 
 // buf[n] on every rank <- buf of `root`; host or device
 int gmmiv_broadcast_f64(gmmiv_comm *c, double *buf, size_t n, int root)
 {
-    if (!c || (!buf && n) || root < 0 || root >= c->world) { gmmiv_set_error("broadcast_f64: bad argument"); return GMMIV_ERR_ARG; }
+    if (!c || !c->ctx || (!buf && n) || root < 0 || root >= c->world) { gmmiv_set_error("broadcast_f64: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)n * 8;
     if (c->world == 1 || n == 0) return GMMIV_OK;
     GCHK(hipSetDevice(c->ctx->device));

@@ -60,6 +60,7 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (gmmiv_comm *cm : std::vector<gmmiv_comm *>(c->comms)) gmmiv_comm_orphan(cm); // their handles stay valid for gmmiv_comm_destroy
     for (int i = 0; i < WS_COUNT; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     for (int i = 0; i < gmmiv_ctx::NSLOT; ++i) {
@@ -76,6 +77,8 @@ int gmmiv_ctx_sync(gmmiv_ctx *c)
     GCHK(hipStreamSynchronize(c->stream));
     return GMMIV_OK;
 }
+
+void *gmmiv_ctx_stream(gmmiv_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
 {

@@ -56,6 +56,8 @@ struct gmmiv_ctx {
     // than half of the memory that is free when the scratch is first needed.
     long z_scratch_mb = 65536;
     int n_cu = 256;
+    // communicators created on this context (capi_comm.hip): released with the context if the caller has not done so
+    std::vector<struct gmmiv_comm *> comms;
     size_t total_mem = 0; // device memory size (bounds the likelihood scratch deterministically)
     // HIP-event timing of the kernels of the last call (option "timing"): one slot per kernel name,
     // one event pair per launch of that kernel inside the call
@@ -135,6 +137,7 @@ struct gmmiv_ctx {
 };
 
 bool gmmiv_is_device_ptr(const void *p);
+void gmmiv_comm_orphan(struct gmmiv_comm *comm); // capi_comm.hip: the context of `comm` is going away
 
 // Read-only argument: device view of a host-or-device array (copies host data into a scratch slot).
 template <typename T> struct DevIn {

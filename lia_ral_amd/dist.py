@@ -1,8 +1,17 @@
-"""Multi-GPU plumbing for the paths that shard: one process per GPU, frames or
-utterances split into contiguous per-rank ranges exactly like the reference splits work across
-pthreads (LIA_SpkTools/src/AccumulateStat.cpp:234-299, AccumulateTVStat.cpp:498-507), and ONE
-all-reduce (RCCL over xGMI with the "nccl" backend; gloo in the CPU tests) of the flat
-sufficient-statistics array per EM iteration -- the collective twin of MixtureStat::addAccEM."""
+"""Multi-GPU plumbing for the paths that shard: one process per GPU, frames or utterances split into
+contiguous per-rank ranges exactly like the reference splits work across pthreads (LIA_SpkTools/src/AccumulateStat.cpp:234-299,
+AccumulateTVStat.cpp:498-507), and the ranks' private accumulators merged by a collective where the reference merges its
+threads' accumulators under a mutex (MixtureStat::addAccEM, AccumulateStat.cpp:286-292; the `+=` of A / Cmx / R / r in the
+threaded estimateAandC, AccumulateTVStat.cpp:1920-1937, 2036-2044).
+
+Collectives come in three interchangeable back ends with the same four operations:
+  * GmmivCollectives -- the product's own C ABI (gmmiv_comm_*: RCCL over xGMI on the device buffers), what bench.py uses;
+  * TorchCollectives -- torch.distributed: "nccl" (= RCCL) with reduce_scatter_tensor / all_gather_into_tensor, or "gloo" in
+    the CPU tests (gloo has no reduce-scatter: it is emulated with one reduce per destination, same bytes on the wire);
+  * LocalCollectives -- a single rank.
+Everything here is orchestration; the arithmetic is done by the callbacks (libgmmiv on a GPU rank)."""
+import time
+
 import numpy as np
 
 
@@ -13,102 +22,270 @@ def shard_range(n, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def all_reduce_sum(acc):
-    """In-place sum over ranks of a torch tensor or numpy array; no-op without a process group."""
-    try:
-        import torch
+def _as_tensor(a):
+    """torch view of a numpy array (shared memory) or the tensor itself."""
+    import torch
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return torch.from_numpy(a)
+    return a
+
+
+# ---------------------------------------------------------------------------------------- collectives
+class LocalCollectives:
+    world, rank, name = 1, 0, "single rank"
+
+    def allreduce(self, a):
+        return a
+
+    def reduce_scatter(self, send, recv):
+        _as_tensor(recv).copy_(_as_tensor(send).reshape(-1)[: _as_tensor(recv).numel()].view_as(_as_tensor(recv)))
+        return recv
+
+    def allgather(self, send, recv):
+        _as_tensor(recv).reshape(-1).copy_(_as_tensor(send).reshape(-1))
+        return recv
+
+    def take_bytes(self):
+        return 0.0
+
+
+class TorchCollectives:
+    """torch.distributed process group (must be initialised).  Tensors or numpy arrays, float64, contiguous."""
+
+    def __init__(self):
         import torch.distributed as dist
+        assert dist.is_available() and dist.is_initialized()
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.backend = dist.get_backend()
+        self.name = "torch.distributed(%s)" % self.backend
+        self._bytes = 0.0
+
+    def allreduce(self, a):
+        t = _as_tensor(a)
+        self._bytes += t.numel() * 8
+        self.dist.all_reduce(t)
+        return a
+
+    def reduce_scatter(self, send, recv):
+        s, r = _as_tensor(send).reshape(-1), _as_tensor(recv)
+        n = r.numel()
+        assert s.numel() == self.world * n
+        self._bytes += s.numel() * 8
+        if self.backend == "nccl":
+            self.dist.reduce_scatter_tensor(r.view(-1), s)
+        else:  # gloo: one reduce per destination
+            for g in range(self.world):
+                chunk = s[g * n:(g + 1) * n].clone()
+                self.dist.reduce(chunk, dst=g)
+                if g == self.rank:
+                    r.view(-1).copy_(chunk)
+        return recv
+
+    def allgather(self, send, recv):
+        s, r = _as_tensor(send).reshape(-1), _as_tensor(recv).view(-1)
+        n = s.numel()
+        assert r.numel() == self.world * n
+        self._bytes += r.numel() * 8
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(r, s.contiguous())
+        else:
+            parts = [s.new_empty(n) for _ in range(self.world)]
+            self.dist.all_gather(parts, s.contiguous())
+            for g in range(self.world):
+                r[g * n:(g + 1) * n].copy_(parts[g])
+        return recv
+
+    def take_bytes(self):
+        b, self._bytes = self._bytes, 0.0
+        return b
+
+
+class GmmivCollectives:
+    """The C ABI's communicator (include/gmmiv.h, gmmiv_comm_*): RCCL called by libgmmiv on the context's stream."""
+
+    def __init__(self, comm):
+        self.comm = comm
+        self.world, self.rank = comm.world, comm.rank
+        self.name = "gmmiv_comm (%s)" % comm.backend()
+
+    def allreduce(self, a):
+        return self.comm.allreduce(a)
+
+    def reduce_scatter(self, send, recv):
+        return self.comm.reduce_scatter(send, recv)
+
+    def allgather(self, send, recv):
+        return self.comm.allgather(send, recv)
+
+    def take_bytes(self):
+        return self.comm.take_bytes()
+
+
+def default_collectives():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return TorchCollectives()
     except Exception:  # pragma: no cover
-        return acc
+        pass
+    return LocalCollectives()
+
+
+def gmmiv_collectives_from_torch(ctx, device=None):
+    """Bootstrap a gmmiv communicator inside an initialised torch.distributed job: rank 0 draws the RCCL id, the id travels
+    through the existing process group, every rank joins.  Returns GmmivCollectives, or LocalCollectives for one rank."""
+    import torch
+    import torch.distributed as dist
+    from . import capi
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return acc
-    if isinstance(acc, np.ndarray):
-        t = torch.from_numpy(acc)
-        dist.all_reduce(t)
-        return acc
-    dist.all_reduce(acc)
-    return acc
+        return GmmivCollectives(capi.Comm(ctx, 1, 0))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    uid = capi.Comm.unique_id() if rank == 0 else bytes(capi.COMM_ID_BYTES)
+    t = torch.tensor(list(uid), dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.broadcast(t, src=0)
+    uid = bytes(t.cpu().tolist())
+    return GmmivCollectives(capi.Comm(ctx, world, rank, uid))
 
 
-def em_iteration(accumulate, n_frames, acc, rank=0, world=1):
-    """One distributed E-step: `accumulate(begin, end, acc)` adds the statistics of frames
-    [begin, end) into the flat accumulator (gmmiv_em_accumulate on a GPU rank), then the ranks'
-    accumulators are summed.  Every rank returns the same global statistics."""
+def all_reduce_sum(acc, coll=None):
+    """In-place sum over ranks of a torch tensor or numpy array; no-op without a process group."""
+    coll = coll or default_collectives()
+    if coll.world == 1:
+        return acc
+    return coll.allreduce(acc)
+
+
+# ---------------------------------------------------------------------------------------- UBM EM
+def em_iteration(accumulate, n_frames, acc, rank=0, world=1, coll=None):
+    """One distributed E-step: `accumulate(begin, end, acc)` adds the statistics of frames [begin, end) into the flat
+    accumulator (gmmiv_em_accumulate on a GPU rank), then the ranks' accumulators are summed -- ONE all-reduce of
+    C (1 + 2 D) + 2 doubles.  Every rank returns the same global statistics."""
     b, e = shard_range(n_frames, rank, world)
     accumulate(b, e, acc)
-    return all_reduce_sum(acc)
+    return all_reduce_sum(acc, coll)
 
 
-def tv_estep(estimate, n_utt, acc, rank=0, world=1):
-    """One distributed E-step of the T-matrix EM (TVAcc::estimateAandC, AccumulateTVStat.cpp:1702-1795):
-    `estimate(begin, end, acc)` adds the utterances [begin, end) of this rank into the accumulators
-    acc = {"A", "Cmx", "Rm", "r", "meanW"} (gmmiv_tv_estimate_a_and_c on a GPU rank; meanW is the SUM
-    of the i-vectors), then every accumulator is summed over ranks -- the collective twin of the
-    mutex-guarded `+=` of the reference's threads (:1920-1937, :2036-2044).  A (packed, 1.31 GB at
-    C=2048, R=400) and Cmx (393 MB) dominate the payload; the M-step is replicated on every rank."""
+# ---------------------------------------------------------------------------------------- T-matrix EM
+def tv_estep(estimate, n_utt, acc, rank=0, world=1, coll=None):
+    """One distributed E-step of the T-matrix EM (TVAcc::estimateAandC, AccumulateTVStat.cpp:1702-1795), all-reduce form:
+    `estimate(begin, end, acc)` adds the utterances [begin, end) of this rank into acc = {"A", "Cmx", "Rm", "r", "meanW"}
+    (gmmiv_tv_estimate_a_and_c; meanW is the SUM of the i-vectors), then every accumulator is summed over ranks and the
+    M-step is replicated.  The sharded form below moves half the bytes and splits the M-step; this one is kept for
+    callers that want the global A on every rank."""
     b, e = shard_range(n_utt, rank, world)
     estimate(b, e, acc)
     for k in ("A", "Cmx", "Rm", "r", "meanW"):
-        all_reduce_sum(acc[k])
+        all_reduce_sum(acc[k], coll)
     return acc
 
 
-def _reduce_to_owner(chunks, rank, world):
-    """chunks[g]: this rank's contribution to the block owned by rank g (numpy arrays or torch tensors).  Returns the SUM over
-    ranks of chunks[rank] -- a reduce-scatter written as one reduce per destination (RCCL has reduce_scatter, gloo does not;
-    the traffic is the same: every rank ships (world - 1) / world of its data once)."""
-    import torch
-    import torch.distributed as dist
-    mine = None
-    for g in range(world):
-        c = chunks[g]
-        t = torch.from_numpy(np.ascontiguousarray(c)) if isinstance(c, np.ndarray) else c.contiguous()
-        dist.reduce(t, dst=g)
-        if g == rank:
-            mine = t
-    return mine.numpy() if isinstance(chunks[rank], np.ndarray) else mine
+def block_size(C, world):
+    """Gaussians per rank of the sharded M-step: equal blocks (a reduce-scatter needs them), the last may be padded."""
+    return (int(C) + int(world) - 1) // int(world)
 
 
-def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1):
-    """Distributed M-step of the T-matrix EM, the layout SURVEY.md 8(e) prefers: T_c = A_c^-1 Cmx_c is independent per Gaussian
-    (TVAcc::updateTestimate, AccumulateTVStat.cpp:981-1000), so rank g OWNS the Gaussians [c0_g, c1_g) = shard_range(C, g, world):
-      * reduce-scatter of A (packed, 1.31 GB at C = 2048, R = 400) and of the matching column blocks of Cmx (393 MB): every rank
-        receives only the sum of its own blocks -- (world - 1) / world of the payload crosses each link once, where the all-reduce of
-        tv_estep moves it twice, and no rank ever holds the global A;
-      * `update_t(A_block [Cb x P], Cmx_block [R x Cb*D], Cb) -> T_block [R x Cb*D]` solves the rank's own Gaussians
-        (gmmiv_tv_update_t on a GPU rank): the 2048 factorisations are split over the ranks too;
-      * all-gather of the T blocks (393 MB / world each); TETt is recomputed locally by the caller.
-    R, r, meanW (a few KB, for the minimum-divergence step) are all-reduced in place.  acc: the per-rank accumulators of
-    gmmiv_tv_estimate_a_and_c (A [C, P], Cmx [R, C*D], Rm, r, meanW).  Returns the full T [R, C*D], identical on every rank."""
-    A, Cmx = acc["A"], acc["Cmx"]
-    R = Cmx.shape[0]
-    if world == 1:
-        return update_t(A, Cmx, C)
+def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=None):
+    """Distributed M-step of the T-matrix EM, the layout SURVEY.md 8(e) prefers.  T_c = A_c^-1 Cmx_c is independent per
+    Gaussian (TVAcc::updateTestimate, AccumulateTVStat.cpp:981-1000), so rank g OWNS the Gaussians [g Cb, (g+1) Cb),
+    Cb = ceil(C / world):
+      * ONE reduce-scatter of A (packed [C x P], 1.31 GB at C = 2048, R = 400; row blocks are contiguous) and ONE of Cmx
+        (393 MB, re-laid out as [world][R][Cb D] so that a rank's column block is contiguous): every rank receives only the
+        sum of its own block -- (world - 1) / world of the payload crosses each link once where an all-reduce moves it twice,
+        and no rank ever holds the global A;
+      * `update_t(A_block [cb x P], Cmx_block [R x cb*D], cb) -> T_block [R x cb*D]` on the rank's own cb <= Cb real
+        Gaussians (gmmiv_tv_update_t on a GPU rank): the C factorisations are split over the ranks too;
+      * ONE all-gather of the T blocks; TETt is recomputed locally by the caller;
+      * R, r, meanW (a few KB, for the minimum-divergence step) travel in one small all-reduce.
+    acc: the per-rank accumulators of gmmiv_tv_estimate_a_and_c (A [C, P], Cmx [R, C*D], Rm, r, meanW), numpy arrays or torch
+    tensors; Rm / r / meanW are summed in place.  Returns the full T [R, C*D], identical on every rank.
+    phases (dict, optional): receives wall-clock seconds of "reduce_scatter", "update_t", "allgather" (the caller's `sync`
+    entry, if present, is called before each stamp)."""
     import torch
-    import torch.distributed as dist
-    is_np = isinstance(A, np.ndarray)
-    ranges = [shard_range(C, g, world) for g in range(world)]
-    a_mine = _reduce_to_owner([A[c0:c1] for c0, c1 in ranges], rank, world)
-    c_mine = _reduce_to_owner([Cmx[:, c0 * D:c1 * D] for c0, c1 in ranges], rank, world)
+    coll = coll or default_collectives()
+    is_np = isinstance(acc["A"], np.ndarray)
+    A, Cmx = _as_tensor(acc["A"]), _as_tensor(acc["Cmx"])
+    R, P = Cmx.shape[0], A.shape[1]
+    sync = (phases or {}).get("sync") or (lambda: None)
+
+    def stamp(key, t0):
+        if phases is not None:
+            sync()
+            phases[key] = phases.get(key, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    t0 = time.perf_counter()
+    # the small accumulators in one buffer
+    small = torch.cat([_as_tensor(acc[k]).reshape(-1) for k in ("Rm", "r", "meanW")])
+    coll.allreduce(small)
+    o = 0
     for k in ("Rm", "r", "meanW"):
-        all_reduce_sum(acc[k])
-    c0, c1 = ranges[rank]
-    t_mine = update_t(a_mine, c_mine, c1 - c0) if c1 > c0 else (np.zeros((R, 0)) if is_np else Cmx.new_zeros((R, 0)))
-    # all-gather of unequal blocks: broadcast from each owner
-    if is_np:
-        T = np.empty((R, C * D))
+        t = _as_tensor(acc[k])
+        t.copy_(small[o:o + t.numel()].view_as(t)); o += t.numel()
+    if world == 1:
+        t0 = stamp("reduce_scatter", t0)
+        Tn = update_t(acc["A"], acc["Cmx"], C)
+        stamp("update_t", t0)
+        return Tn
+    Cb = block_size(C, world)
+    Cpad = Cb * world
+    if Cpad != C:   # pad with empty Gaussians so that the blocks are equal
+        A_send = A.new_zeros((Cpad, P)); A_send[:C] = A
+        Cp = Cmx.new_zeros((R, Cpad * D)); Cp[:, :C * D] = Cmx
     else:
-        T = Cmx.new_empty((R, C * D))
-    for g, (g0, g1) in enumerate(ranges):
-        if g1 == g0:
-            continue
-        if is_np:
-            blk = torch.from_numpy(np.ascontiguousarray(t_mine)) if g == rank else torch.empty((R, (g1 - g0) * D), dtype=torch.float64)
+        A_send, Cp = A, Cmx
+    C_send = Cp.view(R, world, Cb * D).permute(1, 0, 2).contiguous()          # [world][R][Cb D]
+    a_mine = A.new_empty((Cb, P)); c_mine = Cmx.new_empty((R, Cb * D))
+    coll.reduce_scatter(A_send, a_mine)
+    coll.reduce_scatter(C_send, c_mine)
+    t0 = stamp("reduce_scatter", t0)
+    cb = max(0, min(Cb, C - rank * Cb))                                       # real Gaussians of this rank's block
+    t_mine = Cmx.new_zeros((R, Cb * D))
+    if cb > 0:
+        a_in = a_mine[:cb]
+        c_in = c_mine if cb == Cb else c_mine[:, :cb * D].contiguous()
+        tb = update_t(a_in.numpy() if is_np else a_in, c_in.numpy() if is_np else c_in, cb)
+        tb = _as_tensor(tb)
+        if cb == Cb:
+            t_mine = tb.contiguous()
         else:
-            blk = t_mine.contiguous() if g == rank else Cmx.new_empty((R, (g1 - g0) * D))
-        dist.broadcast(blk, src=g)
-        if is_np:
-            T[:, g0 * D:g1 * D] = blk.numpy()
-        else:
-            T[:, g0 * D:g1 * D] = blk
-    return T
+            t_mine[:, :cb * D] = tb
+    t0 = stamp("update_t", t0)
+    gathered = Cmx.new_empty((world, R, Cb * D))
+    coll.allgather(t_mine, gathered)
+    Tn = gathered.permute(1, 0, 2).reshape(R, Cpad * D)[:, :C * D].contiguous()
+    stamp("allgather", t0)
+    return Tn.numpy() if is_np else Tn
+
+
+def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, phases=None):
+    """One full iteration of TotalVariability's EM on utterance-sharded statistics (TotalVariability.cpp:118-169 around
+    TVAcc, AccumulateTVStat.cpp): every rank holds the statistics N / F of its own utterances and the full T.
+      ops.tett()                          estimateTETt from the current T (replicated: 3 ms at 2048 x 400)
+      ops.estep() -> acc                  resetTmpAcc + estimateAandC over the rank's utterances
+      [reduce-scatter / update_t / all-gather: tv_mstep_sharded]
+      ops.update_t(A_blk, Cmx_blk, cb)    updateTestimate on the rank's own Gaussians
+      ops.min_divergence(acc, T, n)       minDivergence with the all-reduced R, r, meanW (replicated; T and the UBM
+                                          means are updated in place on every rank identically)
+    Returns the new T.  phases collects per-phase seconds ("tett", "estep", "reduce_scatter", "update_t", "allgather",
+    "min_divergence")."""
+    coll = coll or default_collectives()
+    sync = (phases or {}).get("sync") or (lambda: None)
+
+    def lap(key, t0):
+        if phases is not None:
+            sync()
+            phases[key] = phases.get(key, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    t0 = time.perf_counter()
+    ops.tett()
+    t0 = lap("tett", t0)
+    acc = ops.estep()
+    t0 = lap("estep", t0)
+    Tn = tv_mstep_sharded(acc, ops.update_t, C, D, rank, world, coll, phases)
+    t0 = time.perf_counter()
+    Tn = ops.min_divergence(acc, Tn, n_sessions_total)
+    lap("min_divergence", t0)
+    return Tn

@@ -3,6 +3,8 @@
 // mirroring the reference tools' "catch, print, carry on" drivers.
 #include <string.h>
 
+#include <chrono>
+
 #include "liatools_gpu.h"
 #include "io.h"
 
@@ -58,6 +60,18 @@ int liagpu_train_world(int device, const float *x, long T, int D, const long *se
         memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
         memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
         if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
+    })
+}
+
+// accumulateStatLLK over a cluster (AccumulateStat.cpp:69-94): getMeanLLK of the selected frames, clamped per frame
+int liagpu_mean_llk(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg, int C,
+                    const double *w, const double *mean, const double *cov, double minLLK, double maxLLK, double *out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        DeviceMixture dm(srv, make_mixture(C, D, w, mean, cov));
+        *out = accumulateStatLLK(fs, dm, make_cluster(seg_begin, seg_len, nseg), minLLK, maxLLK);
     })
 }
 
@@ -289,9 +303,10 @@ int liagpu_tv_train(int device, long U, int C, int D, const double *w, const dou
         MixtureGD ubm = make_mixture(C, D, w, mean, cov);
         TVAcc tv(srv, ubm, (unsigned long)R, (unsigned long)U);
         tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
-        const std::vector<double> N0(N, N + (size_t)U * C), F0(F, F + (size_t)U * C * D);
+        tv.setStats(N, F);         // one upload; everything below stays on the device until getT()
+        tv.storeStats();
         for (int it = 0; it < nbIt; ++it) {
-            tv.setStats(N0, F0);   // the reference reloads N and F every iteration (:152-153)
+            if (it) tv.restoreStats();   // the reference reloads N and F from disk every iteration (:152-153): device-to-device here
             tv.substractM();
             tv.estimateTETt();
             tv.estimateAandC();
@@ -300,6 +315,80 @@ int liagpu_tv_train(int device, long U, int C, int D, const double *w, const dou
         }
         memcpy(Tmat, tv.getT().data(), tv.getT().size() * sizeof(double));
         if (mean_out) memcpy(mean_out, tv.getUbmMeans().data(), tv.getUbmMeans().size() * sizeof(double));
+    })
+}
+
+// One rank of a multi-GPU TotalVariability run (configs[3]: utterances sharded over the GPUs of a node, one process -- or host
+// thread -- per GPU).  N, F: the statistics of THIS rank's U utterances; Tmat: the same initial matrix on every rank.  The
+// ranks meet through `id_file` (rank 0 publishes the RCCL id there, gmmiv_comm_exchange_id_file); per iteration the only
+// exchange is reduce-scatter(A, Cmx) / all-gather(T) / all-reduce(R, r, meanW) on device buffers (TVAcc::updateTestimate(comm)).
+// U_total = utterances over all ranks (the session count of minDivergence).  times_ms (nullable, 4 x nbIt): wall-clock of
+// estimateTETt / estimateAandC / updateTestimate (with its collectives) / minDivergence per iteration.
+int liagpu_tv_train_dist(int device, int world, int rank, const char *id_file, long U, long U_total, int C, int D, const double *w,
+                         const double *mean, const double *cov, int R, const double *N, const double *F, double *Tmat, int nbIt,
+                         int minDiv, double *mean_out, double *times_ms)
+{
+    GUARD({
+        GpuServer srv(device);
+        gmmiv_comm *comm = nullptr;
+        if (world > 1) {
+            unsigned char id[GMMIV_COMM_ID_BYTES];
+            srv.check(gmmiv_comm_exchange_id_file(id_file, rank, id, 300.0));
+            srv.check(gmmiv_comm_create(srv.ctx(), world, rank, id, &comm));
+        }
+        struct CommGuard { gmmiv_comm *c; ~CommGuard() { gmmiv_comm_destroy(c); } } guard{comm};
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        TVAcc tv(srv, ubm, (unsigned long)R, (unsigned long)U);
+        tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
+        tv.setStats(N, F);
+        tv.storeStats();
+        auto now = [&]() { srv.check(gmmiv_ctx_sync(srv.ctx())); return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        for (int it = 0; it < nbIt; ++it) {
+            if (it) tv.restoreStats();
+            tv.substractM();
+            auto t0 = now();
+            tv.estimateTETt();
+            auto t1 = now();
+            tv.estimateAandC();
+            auto t2 = now();
+            tv.updateTestimate(comm, (unsigned long)U_total);
+            auto t3 = now();
+            if (minDiv) tv.minDivergence();
+            auto t4 = now();
+            if (times_ms) { times_ms[4 * it] = ms(t0, t1); times_ms[4 * it + 1] = ms(t1, t2); times_ms[4 * it + 2] = ms(t2, t3); times_ms[4 * it + 3] = ms(t3, t4); }
+        }
+        memcpy(Tmat, tv.getT().data(), tv.getT().size() * sizeof(double));
+        if (mean_out) memcpy(mean_out, tv.getUbmMeans().data(), tv.getUbmMeans().size() * sizeof(double));
+    })
+}
+
+// One rank of a multi-GPU TrainWorld run: x = this rank's frames, global_cov = the variance-control reference (replicated);
+// per iteration ONE gmmiv_allreduce_f64 of the flat EM accumulator on the device (trainModelStream(..., comm)).
+int liagpu_train_world_dist(int device, int world, int rank, const char *id_file, const float *x, long T, int D, const long *seg_begin,
+                            const long *seg_len, long nseg, int C, double *w, double *mean, double *cov, int nbTrainIt,
+                            double initVarFloor, double finalVarFloor, double initVarCeil, double finalVarCeil, const double *global_cov,
+                            double *llk_it_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        gmmiv_comm *comm = nullptr;
+        unsigned char id[GMMIV_COMM_ID_BYTES] = {0};
+        if (world > 1) srv.check(gmmiv_comm_exchange_id_file(id_file, rank, id, 300.0));
+        srv.check(gmmiv_comm_create(srv.ctx(), world, rank, id, &comm));
+        struct CommGuard { gmmiv_comm *c; ~CommGuard() { gmmiv_comm_destroy(c); } } guard{comm};
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD model = make_mixture(C, D, w, mean, cov);
+        TrainCfg cfg;
+        cfg.nbTrainIt = nbTrainIt;
+        cfg.initVarianceFlooring = initVarFloor; cfg.finalVarianceFlooring = finalVarFloor;
+        cfg.initVarianceCeiling = initVarCeil; cfg.finalVarianceCeiling = finalVarCeil;
+        std::vector<double> llk = trainModelStream(cfg, fs, segs, std::vector<double>(global_cov, global_cov + D), model, comm);
+        memcpy(w, model.weights().data(), C * sizeof(double));
+        memcpy(mean, model.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov, model.covs().data(), (size_t)C * D * sizeof(double));
+        if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
     })
 }
 

@@ -58,6 +58,105 @@ void GpuServer::check(int rc) const
     if (rc != 0) throw Exception(gmmiv_last_error());
 }
 
+// ---- DVec --------------------------------------------------------------------------------------
+DVec::~DVec()
+{
+    if (_d) { if (_srv) (void)gmmiv_ctx_sync(_srv->ctx()); (void)hipFree(_d); }
+}
+void DVec::sync() const
+{
+    if (_srv) _srv->sync();
+    else hipcheck(hipDeviceSynchronize(), "DVec: sync");
+}
+void *DVec::st() const { return _srv ? _srv->stream() : nullptr; }
+void DVec::reserve(size_t n)
+{
+    if (n <= _cap) return;
+    sync(); // kernels in flight may still use the old buffer
+    if (_d) hipcheck(hipFree(_d), "DVec: hipFree");
+    _d = nullptr; _cap = 0;
+    hipcheck(hipMalloc((void **)&_d, (n ? n : 1) * sizeof(double)), "DVec: hipMalloc");
+    _cap = n;
+}
+void DVec::assign(size_t n, double v)
+{
+    reserve(n);
+    _n = n;
+    _hostValid = _hostDirty = false;
+    _h.clear();
+    if (n == 0) return;
+    if (v == 0.0) hipcheck(hipMemsetAsync(_d, 0, n * sizeof(double), (hipStream_t)st()), "DVec: hipMemsetAsync");
+    else {
+        const std::vector<double> tmp(n, v);
+        hipcheck(hipMemcpyAsync(_d, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)st()), "DVec: upload");
+        sync(); // tmp goes out of scope
+    }
+}
+void DVec::set(const double *h, size_t n)
+{
+    reserve(n);
+    _n = n;
+    _hostValid = _hostDirty = false;
+    _h.clear();
+    if (n == 0) return;
+    hipcheck(hipMemcpyAsync(_d, h, n * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)st()), "DVec: upload");
+    sync(); // the caller may free h on return
+}
+void DVec::copyFrom(const DVec &o)
+{
+    const double *src = o.cdev();
+    reserve(o._n);
+    _n = o._n;
+    _hostValid = _hostDirty = false;
+    _h.clear();
+    if (_n == 0) return;
+    hipcheck(hipMemcpyAsync(_d, src, _n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)st()), "DVec: copy"); // in stream order
+}
+void DVec::swap(DVec &o)
+{
+    std::swap(_srv, o._srv); std::swap(_d, o._d); std::swap(_n, o._n); std::swap(_cap, o._cap);
+    _h.swap(o._h); std::swap(_hostValid, o._hostValid); std::swap(_hostDirty, o._hostDirty);
+}
+const double *DVec::cdev() const
+{
+    if (_hostDirty) {
+        if (_h.size() != _n) throw Exception("DVec: the host view was resized");
+        if (_n) hipcheck(hipMemcpyAsync(_d, _h.data(), _n * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)st()), "DVec: upload");
+        sync();
+        _hostDirty = false; // _h still mirrors the device copy
+    }
+    return _d;
+}
+double *DVec::dev()
+{
+    (void)cdev();
+    _hostValid = false; // a kernel is about to write
+    return _d;
+}
+const std::vector<double> &DVec::chost() const
+{
+    if (!_hostValid && !_hostDirty) {
+        _h.resize(_n);
+        if (_n) hipcheck(hipMemcpyAsync(_h.data(), _d, _n * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)st()), "DVec: download");
+        sync();
+        _hostValid = true;
+    }
+    return _h;
+}
+std::vector<double> &DVec::host()
+{
+    (void)chost();
+    _hostDirty = true;
+    return _h;
+}
+void DVec::get(double *h, size_t n, size_t offset) const
+{
+    if (offset + n > _n) throw Exception("DVec::get: range out of bounds");
+    const double *src = cdev();
+    if (n) hipcheck(hipMemcpyAsync(h, src + offset, n * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)st()), "DVec: download");
+    sync();
+}
+
 // ---- FeatureBuffer -----------------------------------------------------------------------------
 FeatureBuffer::FeatureBuffer(GpuServer &srv, const float *frames, unsigned long nFrames, unsigned long vectSize,
                              const std::vector<unsigned long> &sourceFirstFrame)
@@ -122,21 +221,36 @@ void DeviceMixture::update(const MixtureGD &m)
 }
 
 // ---- EMAcc -------------------------------------------------------------------------------------
-EMAcc::EMAcc(DeviceMixture &dm, const MixtureGD &model)
-    : _dm(dm), _model(model), _acc(gmmiv_em_acc_len((int)model.getDistribCount(), (int)model.getVectSize()), 0.0)
+EMAcc::EMAcc(DeviceMixture &dm, const MixtureGD &model) : _dm(dm), _model(model), _acc(dm.server())
 {
+    _acc.assign(gmmiv_em_acc_len((int)model.getDistribCount(), (int)model.getVectSize()), 0.0);
 }
-void EMAcc::resetEM() { std::fill(_acc.begin(), _acc.end(), 0.0); }
+void EMAcc::resetEM() { _acc.assign(_acc.size(), 0.0); }
+double EMAcc::getEMFeatureCount() const
+{
+    double v = 0.0;
+    _acc.get(&v, 1, _acc.size() - 1);
+    return v;
+}
+double EMAcc::getAccumulatedLLK() const
+{
+    double v = 0.0;
+    _acc.get(&v, 1, _acc.size() - 2);
+    return v;
+}
 void EMAcc::addAccEM(const EMAcc &o)
 {
-    for (size_t i = 0; i < _acc.size(); ++i) _acc[i] += o._acc[i];
+    // MixtureStat::addAccEM merges a worker thread's accumulator (AccumulateStat.cpp:286-292): small (2 MB), done on the host view
+    const std::vector<double> &b = o._acc.chost();
+    std::vector<double> &a = _acc.host();
+    for (size_t i = 0; i < a.size(); ++i) a[i] += b[i];
 }
 MixtureGD EMAcc::getEM() const
 {
     MixtureGD out = _model;
     MixtureGD &m = const_cast<MixtureGD &>(_model);
     GpuServer &srv = const_cast<DeviceMixture &>(_dm).server();
-    srv.check(gmmiv_em_get(srv.ctx(), (int)m.getDistribCount(), (int)m.getVectSize(), _acc.data(), m.means().data(), m.covs().data(),
+    srv.check(gmmiv_em_get(srv.ctx(), (int)m.getDistribCount(), (int)m.getVectSize(), _acc.cdev(), m.means().data(), m.covs().data(),
                            out.weights().data(), out.means().data(), out.covs().data()));
     out.computeAll();
     return out;
@@ -165,10 +279,9 @@ double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selec
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
-    std::vector<double> &a = emAcc.flat();
-    const double before = a[a.size() - 2];
-    srv.check(gmmiv_em_accumulate(srv.ctx(), emAcc.mixture().handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), weight, a.data()));
-    return a[a.size() - 2] - before; // weight * sum log lk of this call (AccumulateStat.cpp:143-152)
+    const double before = emAcc.getAccumulatedLLK();
+    srv.check(gmmiv_em_accumulate(srv.ctx(), emAcc.mixture().handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), weight, emAcc.acc().dev()));
+    return emAcc.getAccumulatedLLK() - before; // weight * sum log lk of this call (AccumulateStat.cpp:143-152)
 }
 double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments)
 {
@@ -261,7 +374,14 @@ void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedFrameS
 }
 
 std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
-                                     const std::vector<double> &globalCov, MixtureGD &world, AllReduceFn allReduce, void *user)
+                                     const std::vector<double> &globalCov, MixtureGD &world, gmmiv_comm *comm)
+{
+    return trainModelStream(cfg, fs, selectedSegments, globalCov, world, nullptr, nullptr, comm);
+}
+
+std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
+                                     const std::vector<double> &globalCov, MixtureGD &world, AllReduceFn allReduce, void *user,
+                                     gmmiv_comm *comm)
 {
     std::vector<double> llkIt;
     DeviceMixture dworld(fs.server(), world);
@@ -286,7 +406,8 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, con
             baggedSegments(selectedSegments, baggedFramesCluster, baggedProba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
             llkPreviousIt += accumulateStatEM(fs, emAcc, baggedFramesCluster);
         }
-        if (allReduce) allReduce(emAcc.flat().data(), emAcc.flat().size(), user); // sum over ranks == addAccEM over threads
+        if (comm) fs.server().check(gmmiv_allreduce_f64(comm, emAcc.acc().dev(), emAcc.acc().size())); // RCCL on the device accumulator
+        else if (allReduce) allReduce(emAcc.flat().data(), emAcc.flat().size(), user);               // sum over ranks == addAccEM over threads
         llkPreviousIt = emAcc.getAccumulatedLLK() / emAcc.getEMFeatureCount();
         world = emAcc.getEM();
         varianceControl(world, varianceFlooring, varianceCeiling, globalCov);
@@ -497,8 +618,10 @@ TVAcc::TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned
     : _srv(srv), _ubm(ubm), _dubm(srv, ubm), _rankT(rankT), _n_speakers(nSpeakers), _n_distrib(ubm.getDistribCount()),
       _vectSize(ubm.getVectSize()), _svSize(ubm.getDistribCount() * ubm.getVectSize())
 {
-    _ubm_means = _ubm.means();          // supervector of means / inverse variances (AccumulateTVStat.cpp:154-162)
-    _ubm_invvar = _ubm.covInvs();
+    for (DVec *v : {&_ubm_means, &_ubm_invvar, &_statN, &_statF, &_cN, &_cF, &_T, &_W, &_TETt, &_A, &_Cmx, &_R, &_r, &_meanW}) v->bind(srv);
+    _n_sessions_global = _n_speakers;
+    _ubm_means.set(_ubm.means());       // supervector of means / inverse variances (AccumulateTVStat.cpp:154-162)
+    _ubm_invvar.set(_ubm.covInvs());
     _statN.assign(_n_speakers * _n_distrib, 0.0);
     _statF.assign(_n_speakers * _svSize, 0.0);
     _T.assign(_rankT * _svSize, 0.0);
@@ -516,6 +639,84 @@ void TVAcc::resetTmpAcc()
     _meanW.assign(_rankT, 0.0);
 }
 
+void TVAcc::loadT(const std::vector<double> &T)
+{
+    if (T.size() != _rankT * _svSize) throw Exception("loadT: T must be rankT x (distribCount * vectSize)");
+    _T.set(T);
+}
+void TVAcc::setStats(const std::vector<double> &N, const std::vector<double> &F)
+{
+    if (N.size() != _n_speakers * _n_distrib || F.size() != _n_speakers * _svSize) throw Exception("TVAcc::setStats: dimension mismatch");
+    setStats(N.data(), F.data());
+}
+void TVAcc::setStats(const double *N, const double *F)
+{
+    _statN.set(N, _n_speakers * _n_distrib);
+    _statF.set(F, _n_speakers * _svSize);
+}
+void TVAcc::storeStats() { _cN.copyFrom(_statN); _cF.copyFrom(_statF); }
+void TVAcc::restoreStats()
+{
+    if (_cN.size() != _statN.size() || _cF.size() != _statF.size()) throw Exception("TVAcc::restoreStats: nothing stored");
+    _statN.copyFrom(_cN); _statF.copyFrom(_cF);
+}
+
+// updateTestimate on utterance-sharded statistics: rank g owns the Gaussians [g Cb, (g + 1) Cb), Cb = ceil(C / world).
+void TVAcc::updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks)
+{
+    _n_sessions_global = nSessionsAllRanks;
+    const int world = comm ? gmmiv_comm_world(comm) : 1, rank = comm ? gmmiv_comm_rank(comm) : 0;
+    if (world <= 1) { updateTestimate(); return; }
+    const size_t P = gmmiv_tv_packed_len((int)_rankT), C = _n_distrib, D = _vectSize, R = _rankT;
+    const size_t Cb = (C + world - 1) / world, Cpad = Cb * world;
+    // the small sums in one all-reduce: [R x R | R | R]
+    DVec small(_srv);
+    small.assign(R * R + 2 * R, 0.0);
+    hipStream_t st = (hipStream_t)_srv.stream();
+    hipcheck(hipMemcpyAsync(small.dev(), _R.cdev(), R * R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pack");
+    hipcheck(hipMemcpyAsync(small.dev() + R * R, _r.cdev(), R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pack");
+    hipcheck(hipMemcpyAsync(small.dev() + R * R + R, _meanW.cdev(), R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pack");
+    _srv.check(gmmiv_allreduce_f64(comm, small.dev(), small.size()));
+    hipcheck(hipMemcpyAsync(_R.dev(), small.cdev(), R * R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
+    hipcheck(hipMemcpyAsync(_r.dev(), small.cdev() + R * R, R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
+    hipcheck(hipMemcpyAsync(_meanW.dev(), small.cdev() + R * R + R, R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
+    // A: row blocks are contiguous (padded with empty Gaussians when C does not divide); Cmx: [world][R][Cb D]
+    DVec aSend(_srv), cSend(_srv), aMine(_srv), cMine(_srv), tMine(_srv), tAll(_srv);
+    const double *aSrc = _A.cdev();
+    if (Cpad != C) {
+        aSend.assign(Cpad * P, 0.0);
+        hipcheck(hipMemcpyAsync(aSend.dev(), _A.cdev(), C * P * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pad A");
+        aSrc = aSend.cdev();
+    }
+    cSend.assign((size_t)world * R * Cb * D, 0.0);
+    for (int g = 0; g < world; ++g) {
+        const size_t c0 = g * Cb, cb = c0 >= C ? 0 : std::min(Cb, C - c0);
+        if (cb) hipcheck(hipMemcpy2DAsync(cSend.dev() + (size_t)g * R * Cb * D, Cb * D * 8, _Cmx.cdev() + c0 * D, C * D * 8, cb * D * 8, R, hipMemcpyDeviceToDevice, st),
+                         "updateTestimate: block Cmx");
+    }
+    aMine.assign(Cb * P, 0.0); cMine.assign(R * Cb * D, 0.0);
+    _srv.check(gmmiv_reduce_scatter_f64(comm, aSrc, aMine.dev(), Cb * P));
+    _srv.check(gmmiv_reduce_scatter_f64(comm, cSend.cdev(), cMine.dev(), R * Cb * D));
+    // the rank's own Gaussians
+    const size_t c0 = (size_t)rank * Cb, cb = c0 >= C ? 0 : std::min(Cb, C - c0);
+    tMine.assign(R * Cb * D, 0.0);
+    if (cb == Cb) _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)cb, (int)D, (int)R, aMine.cdev(), cMine.cdev(), tMine.dev()));
+    else if (cb) { // a cut block: repack its Cmx columns to the width the ABI expects, solve, spread back
+        DVec cc(_srv), tt(_srv);
+        cc.assign(R * cb * D, 0.0); tt.assign(R * cb * D, 0.0);
+            hipcheck(hipMemcpy2DAsync(cc.dev(), cb * D * 8, cMine.cdev(), Cb * D * 8, cb * D * 8, R, hipMemcpyDeviceToDevice, st), "updateTestimate: cut block");
+        _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)cb, (int)D, (int)R, aMine.cdev(), cc.cdev(), tt.dev()));
+            hipcheck(hipMemcpy2DAsync(tMine.dev(), Cb * D * 8, tt.cdev(), cb * D * 8, cb * D * 8, R, hipMemcpyDeviceToDevice, st), "updateTestimate: cut block");
+    }
+    tAll.assign((size_t)world * R * Cb * D, 0.0);
+    _srv.check(gmmiv_allgather_f64(comm, tMine.cdev(), tAll.dev(), R * Cb * D));
+    for (int g = 0; g < world; ++g) {
+        const size_t g0 = g * Cb, gb = g0 >= C ? 0 : std::min(Cb, C - g0);
+        if (gb) hipcheck(hipMemcpy2DAsync(_T.dev() + g0 * D, C * D * 8, tAll.cdev() + (size_t)g * R * Cb * D, Cb * D * 8, gb * D * 8, R, hipMemcpyDeviceToDevice, st),
+                         "updateTestimate: gather T");
+    }
+}
+
 void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerLine)
 {
     if (segsPerLine.size() != _n_speakers) throw Exception("computeAndAccumulateTVStat: one SegCluster per ndx line expected");
@@ -529,84 +730,86 @@ void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegC
     unsigned long n = 0;
     const float *x = fs.select(all, n);
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), uttBegin.data(),
-                              (int64_t)_n_speakers, _statN.data(), _statF.data()));
+                              (int64_t)_n_speakers, _statN.dev(), _statF.dev()));
 }
 
 void TVAcc::substractM()
 {
-    _srv.check(gmmiv_tv_subtract_m(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.data(), _statF.data(), _ubm_means.data()));
+    _srv.check(gmmiv_tv_subtract_m(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.cdev(), _statF.dev(), _ubm_means.cdev()));
 }
 void TVAcc::estimateTETt()
 {
-    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), _ubm_invvar.data(), _TETt.data()));
+    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.cdev(), _ubm_invvar.cdev(), _TETt.dev()));
 }
 void TVAcc::estimateW()
 {
-    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(), _statF.data(),
-                                   _T.data(), _ubm_invvar.data(), _TETt.data(), _W.data()));
+    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(), _statF.cdev(),
+                                   _T.cdev(), _ubm_invvar.cdev(), _TETt.cdev(), _W.dev()));
 }
 void TVAcc::estimateAandC()
 {
     resetTmpAcc(); // the reference zeroes A, C, R, r, meanW at entry (:1712-1722)
-    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
-                                         _statF.data(), _T.data(), _ubm_invvar.data(), _TETt.data(), _W.data(), _A.data(), _Cmx.data(),
-                                         _R.data(), _r.data(), _meanW.data()));
-    for (double &v : _meanW) v /= (double)_n_speakers; // :1791-1794
+    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
+                                         _statF.cdev(), _T.cdev(), _ubm_invvar.cdev(), _TETt.cdev(), _W.dev(), _A.dev(), _Cmx.dev(),
+                                         _R.dev(), _r.dev(), _meanW.dev()));
+    // _meanW stays the SUM of the i-vectors on the device (the all-reduce payload of the sharded form); minDivergence divides (:1791-1794)
 }
 void TVAcc::updateTestimate()
 {
-    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _A.data(), _Cmx.data(), _T.data()));
+    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _A.cdev(), _Cmx.cdev(), _T.dev()));
 }
 void TVAcc::minDivergence()
 {
     // _n_sessions == number of statistics rows in TotalVariability (one session per line)
-    _srv.check(gmmiv_tv_min_divergence(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, (double)_n_speakers, _R.data(), _r.data(),
-                                       _meanW.data(), _ubm_means.data(), _T.data()));
+    std::vector<double> mw = _meanW.chost();                      // meanW /= n (:1791-1794), R floats
+    for (double &v : mw) v /= (double)_n_sessions_global;
+    _srv.check(gmmiv_tv_min_divergence(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, (double)_n_sessions_global, _R.dev(), _r.dev(),
+                                       mw.data(), _ubm_means.dev(), _T.dev()));
 }
 
 void TVAcc::orthonormalizeT()
 {
-    _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankT, (int64_t)_svSize, _T.data()));
+    _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankT, (int64_t)_svSize, _T.dev()));
 }
 
 void TVAcc::normStatistics()
 {
-    _srv.check(gmmiv_tv_norm_statistics(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.data(), _statF.data(),
-                                        _ubm_means.data(), _ubm_invvar.data()));
+    _srv.check(gmmiv_tv_norm_statistics(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.cdev(), _statF.dev(),
+                                        _ubm_means.cdev(), _ubm_invvar.cdev()));
 }
 void TVAcc::substractMplusTW()
 {
-    _srv.check(gmmiv_tv_subtract_m_plus_tw(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
-                                           _statF.data(), _ubm_means.data(), _T.data(), _W.data()));
+    _srv.check(gmmiv_tv_subtract_m_plus_tw(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
+                                           _statF.dev(), _ubm_means.cdev(), _T.cdev(), _W.cdev()));
 }
 void TVAcc::normTMatrix()
 {
-    _srv.check(gmmiv_tv_norm_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), _ubm_invvar.data()));
+    _srv.check(gmmiv_tv_norm_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.dev(), _ubm_invvar.cdev()));
 }
 void TVAcc::getWeightedCov(std::vector<double> &W, const std::vector<double> &weight)
 {
     if (weight.size() != _n_distrib) throw Exception("getWeightedCov: one weight per distribution expected");
     W.assign(_rankT * _rankT, 0.0);
-    _srv.check(gmmiv_tv_weighted_cov(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), weight.data(), W.data()));
+    _srv.check(gmmiv_tv_weighted_cov(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.cdev(), weight.data(), W.data()));
 }
 void TVAcc::approximateTcTc(std::vector<double> &D, const std::vector<double> &Q)
 {
     if (Q.size() != _rankT * _rankT) throw Exception("approximateTcTc: Q must be rankT x rankT");
     if (D.size() != _n_distrib * _rankT) D.assign(_n_distrib * _rankT, 0.0);
-    _srv.check(gmmiv_tv_approximate_tctc(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.data(), Q.data(), D.data()));
+    _srv.check(gmmiv_tv_approximate_tctc(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, _T.cdev(), Q.data(), D.data()));
 }
 void TVAcc::estimateWUbmWeight(const std::vector<double> &W)
 {
     if (W.size() != _rankT * _rankT) throw Exception("estimateWUbmWeight: W must be rankT x rankT");
-    std::fill(_W.begin(), _W.end(), 0.0); // _W.setAllValues(0.0), :2353
-    _srv.check(gmmiv_tv_estimate_w_ubm_weight(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
-                                              _statF.data(), _T.data(), W.data(), _W.data()));
+    _W.assign(_W.size(), 0.0); // _W.setAllValues(0.0), :2353
+    _srv.check(gmmiv_tv_estimate_w_ubm_weight(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
+                                              _statF.cdev(), _T.cdev(), W.data(), _W.dev()));
 }
 void TVAcc::estimateWEigenDecomposition(const std::vector<double> &D, const std::vector<double> &Q)
 {
     if (D.size() != _n_distrib * _rankT || Q.size() != _rankT * _rankT) throw Exception("estimateWEigenDecomposition: D is C x rankT, Q rankT x rankT");
-    _srv.check(gmmiv_tv_estimate_w_eigen(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.data(),
-                                         _statF.data(), _T.data(), D.data(), Q.data(), _W.data()));
+    _srv.check(gmmiv_tv_estimate_w_eigen(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
+                                         _statF.cdev(), _T.cdev(), D.data(), Q.data(), _W.dev()));
 }
 
 
@@ -624,8 +827,10 @@ JFAAcc::JFAAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankEV, unsig
         for (unsigned long k = 0; k < sessionsPerSpeaker[s]; ++k) _owner.push_back((int64_t)s);
     }
     _n_sessions = (unsigned long)_sess_begin[_n_speakers];
-    _ubm_means = _ubm.means();
-    _ubm_invvar = _ubm.covInvs();
+    for (DVec *v : {&_ubm_means, &_ubm_invvar, &_matN, &_N_h, &_F_X, &_F_X_h, &_cN, &_cN_h, &_cF_X, &_cF_X_h, &_V, &_matU, &_D, &_Y, &_matX, &_Z,
+                    &_vEvT, &_uEuT, &_Aev, &_Cev, &_Aec, &_Cec, &_mdR, &_mdr, &_mdmw}) v->bind(srv);
+    _ubm_means.set(_ubm.means());
+    _ubm_invvar.set(_ubm.covInvs());
     _matN.assign(_n_speakers * _n_distrib, 0.0);
     _N_h.assign(_n_sessions * _n_distrib, 0.0);
     _F_X.assign(_n_speakers * _svSize, 0.0);
@@ -660,137 +865,142 @@ void JFAAcc::computeAndAccumulateJFAStat(FeatureBuffer &fs, const std::vector<Se
     const float *x = fs.select(all, n);
     // the frame loop (:544-575) runs once, per session, on the device; a speaker's rows are the sums of its sessions' rows
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), begin.data(),
-                              (int64_t)_n_sessions, _N_h.data(), _F_X_h.data()));
-    std::fill(_matN.begin(), _matN.end(), 0.0);
-    std::fill(_F_X.begin(), _F_X.end(), 0.0);
+                              (int64_t)_n_sessions, _N_h.dev(), _F_X_h.dev()));
+    // speaker rows = sums of the speaker's session rows (once per statistics pass; on the host views)
+    const std::vector<double> &nh = _N_h.chost(), &fh = _F_X_h.chost();
+    std::vector<double> nS(_n_speakers * _n_distrib, 0.0), fS(_n_speakers * _svSize, 0.0);
     for (unsigned long h = 0; h < _n_sessions; ++h) {
         const unsigned long s = (unsigned long)_owner[h];
-        for (unsigned long k = 0; k < _n_distrib; ++k) _matN[s * _n_distrib + k] += _N_h[h * _n_distrib + k];
-        for (unsigned long k = 0; k < _svSize; ++k) _F_X[s * _svSize + k] += _F_X_h[h * _svSize + k];
+        for (unsigned long k = 0; k < _n_distrib; ++k) nS[s * _n_distrib + k] += nh[h * _n_distrib + k];
+        for (unsigned long k = 0; k < _svSize; ++k) fS[s * _svSize + k] += fh[h * _svSize + k];
     }
+    _matN.set(nS); _F_X.set(fS);
 }
 void JFAAcc::setStats(const std::vector<double> &N, const std::vector<double> &N_h, const std::vector<double> &F_X,
                       const std::vector<double> &F_X_h)
 {
     if (N.size() != _matN.size() || N_h.size() != _N_h.size() || F_X.size() != _F_X.size() || F_X_h.size() != _F_X_h.size())
         throw Exception("JFAAcc::setStats: dimension mismatch");
-    _matN = N; _N_h = N_h; _F_X = F_X; _F_X_h = F_X_h;
+    _matN.set(N); _N_h.set(N_h); _F_X.set(F_X); _F_X_h.set(F_X_h);
 }
-void JFAAcc::storeAccs() { _cF_X = _F_X; _cF_X_h = _F_X_h; _cN_h = _N_h; _cN = _matN; }
-void JFAAcc::restoreAccs() { _matN = _cN; _N_h = _cN_h; _F_X = _cF_X; _F_X_h = _cF_X_h; }
+void JFAAcc::storeAccs() { _cF_X.copyFrom(_F_X); _cF_X_h.copyFrom(_F_X_h); _cN_h.copyFrom(_N_h); _cN.copyFrom(_matN); }   // device-to-device
+void JFAAcc::restoreAccs() { _matN.copyFrom(_cN); _N_h.copyFrom(_cN_h); _F_X.copyFrom(_cF_X); _F_X_h.copyFrom(_cF_X_h); }
 void JFAAcc::loadEV(const std::vector<double> &V)
 {
     if (V.size() != _V.size()) throw Exception("Incorrect dimension of EigenVoice Matrix");
-    _V = V;
+    _V.set(V);
 }
 void JFAAcc::loadEC(const std::vector<double> &U)
 {
     if (U.size() != _matU.size()) throw Exception("Incorrect dimension of EigenChannel Matrix");
-    _matU = U;
+    _matU.set(U);
 }
 void JFAAcc::loadD(const std::vector<double> &D)
 {
     if (D.size() != _D.size()) throw Exception("Incorrect dimension of D Matrix");
-    _D = D;
+    _D.set(D);
 }
 void JFAAcc::initD(double regulationFactor)
 {
-    for (unsigned long i = 0; i < _svSize; ++i) _D[i] = sqrt(1.0 / (_ubm_invvar[i] * regulationFactor));
+    const std::vector<double> &iv = _ubm_invvar.chost();
+    std::vector<double> d(_svSize);
+    for (unsigned long i = 0; i < _svSize; ++i) d[i] = sqrt(1.0 / (iv[i] * regulationFactor));
+    _D.set(d);
 }
 void JFAAcc::estimateVEVT()
 {
-    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEV, _V.data(), _ubm_invvar.data(), _vEvT.data()));
+    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEV, _V.cdev(), _ubm_invvar.cdev(), _vEvT.dev()));
 }
 void JFAAcc::estimateUEUT()
 {
-    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEC, _matU.data(), _ubm_invvar.data(), _uEuT.data()));
+    _srv.check(gmmiv_tv_tett(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEC, _matU.cdev(), _ubm_invvar.cdev(), _uEuT.dev()));
 }
 void JFAAcc::estimateYandV()
 {
-    std::vector<double> Rm(_rankEV * _rankEV, 0.0), r(_rankEV, 0.0), mw(_rankEV, 0.0); // minimum-divergence sums: unused by JFA
-    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankEV, _matN.data(),
-                                         _F_X.data(), _V.data(), _ubm_invvar.data(), _vEvT.data(), _Y.data(), _Aev.data(), _Cev.data(),
-                                         Rm.data(), r.data(), mw.data()));
+    _mdR.assign(_rankEV * _rankEV, 0.0); _mdr.assign(_rankEV, 0.0); _mdmw.assign(_rankEV, 0.0); // minimum-divergence sums: unused by JFA
+    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankEV, _matN.cdev(),
+                                         _F_X.cdev(), _V.cdev(), _ubm_invvar.cdev(), _vEvT.cdev(), _Y.dev(), _Aev.dev(), _Cev.dev(),
+                                         _mdR.dev(), _mdr.dev(), _mdmw.dev()));
 }
 void JFAAcc::estimateY()
 {
-    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankEV, _matN.data(), _F_X.data(),
-                                   _V.data(), _ubm_invvar.data(), _vEvT.data(), _Y.data()));
+    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankEV, _matN.cdev(), _F_X.cdev(),
+                                   _V.cdev(), _ubm_invvar.cdev(), _vEvT.cdev(), _Y.dev()));
 }
 void JFAAcc::estimateXandU()
 {
-    std::vector<double> Rm(_rankEC * _rankEC, 0.0), r(_rankEC, 0.0), mw(_rankEC, 0.0);
-    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, (int)_rankEC, _N_h.data(),
-                                         _F_X_h.data(), _matU.data(), _ubm_invvar.data(), _uEuT.data(), _matX.data(), _Aec.data(),
-                                         _Cec.data(), Rm.data(), r.data(), mw.data()));
+    _mdR.assign(_rankEC * _rankEC, 0.0); _mdr.assign(_rankEC, 0.0); _mdmw.assign(_rankEC, 0.0);
+    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, (int)_rankEC, _N_h.cdev(),
+                                         _F_X_h.cdev(), _matU.cdev(), _ubm_invvar.cdev(), _uEuT.cdev(), _matX.dev(), _Aec.dev(),
+                                         _Cec.dev(), _mdR.dev(), _mdr.dev(), _mdmw.dev()));
 }
 void JFAAcc::estimateX()
 {
-    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, (int)_rankEC, _N_h.data(), _F_X_h.data(),
-                                   _matU.data(), _ubm_invvar.data(), _uEuT.data(), _matX.data()));
+    _srv.check(gmmiv_tv_estimate_w(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, (int)_rankEC, _N_h.cdev(), _F_X_h.cdev(),
+                                   _matU.cdev(), _ubm_invvar.cdev(), _uEuT.cdev(), _matX.dev()));
 }
 void JFAAcc::estimateZandD()
 {
-    _srv.check(gmmiv_jfa_estimate_z_and_d(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(),
-                                          _ubm_invvar.data(), _D.data(), _Z.data()));
+    _srv.check(gmmiv_jfa_estimate_z_and_d(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.cdev(), _F_X.cdev(),
+                                          _ubm_invvar.cdev(), _D.dev(), _Z.dev()));
 }
 void JFAAcc::estimateZ()
 {
-    _srv.check(gmmiv_jfa_estimate_z(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(),
-                                    _ubm_invvar.data(), _D.data(), -1.0, _Z.data()));
+    _srv.check(gmmiv_jfa_estimate_z(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.cdev(), _F_X.cdev(),
+                                    _ubm_invvar.cdev(), _D.cdev(), -1.0, _Z.dev()));
 }
 void JFAAcc::estimateZMAP(double tau)
 {
     if (tau < 0.0) throw Exception("estimateZMAP: negative relevance factor");
-    _srv.check(gmmiv_jfa_estimate_z(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(),
-                                    _ubm_invvar.data(), _D.data(), tau, _Z.data()));
+    _srv.check(gmmiv_jfa_estimate_z(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.cdev(), _F_X.cdev(),
+                                    _ubm_invvar.cdev(), _D.cdev(), tau, _Z.dev()));
 }
 void JFAAcc::updateVestimate()
 {
-    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEV, _Aev.data(), _Cev.data(), _V.data()));
-    _Cev = _V; // the reference leaves the new matrix in _Cev too (:3617-3618)
+    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEV, _Aev.cdev(), _Cev.cdev(), _V.dev()));
+    _Cev.copyFrom(_V); // the reference leaves the new matrix in _Cev too (:3617-3618)
 }
 void JFAAcc::updateUestimate()
 {
-    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEC, _Aec.data(), _Cec.data(), _matU.data()));
-    _Cec = _matU;
+    _srv.check(gmmiv_tv_update_t(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankEC, _Aec.cdev(), _Cec.cdev(), _matU.dev()));
+    _Cec.copyFrom(_matU);
 }
 void JFAAcc::substractMplusDZ()
 {
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(), nullptr,
-                                  (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, _D.data(), _Z.data()));
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.cdev(), _F_X.dev(), nullptr,
+                                  (int64_t)_n_speakers, _ubm_means.cdev(), 0, nullptr, nullptr, _D.cdev(), _Z.cdev()));
 }
 void JFAAcc::substractMplusVY()
 {
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(), nullptr,
-                                  (int64_t)_n_speakers, _ubm_means.data(), (int)_rankEV, _V.data(), _Y.data(), nullptr, nullptr));
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.cdev(), _F_X.dev(), nullptr,
+                                  (int64_t)_n_speakers, _ubm_means.cdev(), (int)_rankEV, _V.cdev(), _Y.cdev(), nullptr, nullptr));
 }
 void JFAAcc::substractUX()
 {
-    _srv.check(gmmiv_jfa_subtract_sessions(_srv.ctx(), (int64_t)_n_speakers, _sess_begin.data(), (int)_n_distrib, (int)_vectSize, _N_h.data(),
-                                           _F_X.data(), (int)_rankEC, _matU.data(), _matX.data()));
+    _srv.check(gmmiv_jfa_subtract_sessions(_srv.ctx(), (int64_t)_n_speakers, _sess_begin.data(), (int)_n_distrib, (int)_vectSize, _N_h.cdev(),
+                                           _F_X.dev(), (int)_rankEC, _matU.cdev(), _matX.cdev()));
 }
 void JFAAcc::substractMplusVYplusDZ()
 {
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.data(), _F_X_h.data(), _owner.data(),
-                                  (int64_t)_n_speakers, _ubm_means.data(), (int)_rankEV, _V.data(), _Y.data(), _D.data(), _Z.data()));
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.cdev(), _F_X_h.dev(), _owner.data(),
+                                  (int64_t)_n_speakers, _ubm_means.cdev(), (int)_rankEV, _V.cdev(), _Y.cdev(), _D.cdev(), _Z.cdev()));
 }
 void JFAAcc::substractMplusUX()
 {
     // The reference takes N_h (m + U x_h) of every session out of the SPEAKER statistics (:4344-4356).  sum_h N_h m = N m
     // (the speaker occupancies are the sums of their sessions'), the channel parts are substractUX.
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.data(), _F_X.data(), nullptr,
-                                  (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, nullptr, nullptr));
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _matN.cdev(), _F_X.dev(), nullptr,
+                                  (int64_t)_n_speakers, _ubm_means.cdev(), 0, nullptr, nullptr, nullptr, nullptr));
     substractUX();
 }
 void JFAAcc::substractMplusDZByChannel()
 {
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.data(), _F_X_h.data(), _owner.data(),
-                                  (int64_t)_n_speakers, _ubm_means.data(), 0, nullptr, nullptr, _D.data(), _Z.data()));
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)_n_sessions, (int)_n_distrib, (int)_vectSize, _N_h.cdev(), _F_X_h.dev(), _owner.data(),
+                                  (int64_t)_n_speakers, _ubm_means.cdev(), 0, nullptr, nullptr, _D.cdev(), _Z.cdev()));
 }
 void JFAAcc::orthonormalizeV()
 {
-    _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankEV, (int64_t)_svSize, _V.data()));
+    _srv.check(gmmiv_tv_orthonormalize_t(_srv.ctx(), (int)_rankEV, (int64_t)_svSize, _V.dev()));
 }
 void JFAAcc::getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk)
 {
@@ -798,8 +1008,8 @@ void JFAAcc::getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk)
     // Sp = 0 - (-1) (m + V y + D z): the subtraction with unit negative occupations builds the supervector
     std::vector<double> n1(_n_distrib, -1.0);
     Sp.assign(_svSize, 0.0);
-    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), 1, (int)_n_distrib, (int)_vectSize, n1.data(), Sp.data(), nullptr, 1, _ubm_means.data(), (int)_rankEV,
-                                  _V.data(), _Y.data() + spk * _rankEV, _D.data(), _Z.data() + spk * _svSize));
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), 1, (int)_n_distrib, (int)_vectSize, n1.data(), Sp.data(), nullptr, 1, _ubm_means.cdev(), (int)_rankEV,
+                                  _V.cdev(), _Y.cdev() + spk * _rankEV, _D.cdev(), _Z.cdev() + spk * _svSize));
 }
 
 std::vector<double> computeTestDotProduct(GpuServer &srv, JFAAcc &jfaAcc, const std::vector<double> &clientSV, unsigned long nClients)
@@ -889,13 +1099,14 @@ void estimateDMatrix(JFAAcc &jfaAcc, unsigned long nbIt)
 }
 // ---- PldaDev ---------------------------------------------------------------------------------------
 PldaDev::PldaDev(GpuServer &srv, unsigned long vectSize, const std::vector<double> &data, const std::vector<unsigned long> &sessionPerSpeaker)
-    : _srv(srv), _vectSize(vectSize), _n_sessions(0), _data(data), _session_per_speaker(sessionPerSpeaker)
+    : _srv(srv), _vectSize(vectSize), _n_sessions(0), _data(srv), _session_per_speaker(sessionPerSpeaker)
 {
     for (unsigned long v : sessionPerSpeaker) {
         if (v == 0) throw Exception("PldaDev: a speaker without session");
         _n_sessions += v;
     }
-    if (_vectSize == 0 || _data.size() != _vectSize * _n_sessions) throw Exception("PldaDev: data must be vectSize x n_sessions");
+    if (_vectSize == 0 || data.size() != _vectSize * _n_sessions) throw Exception("PldaDev: data must be vectSize x n_sessions");
+    _data.set(data);   // the development set lives on the device from here on
     computeAll();
 }
 std::vector<int64_t> PldaDev::sps64() const { return std::vector<int64_t>(_session_per_speaker.begin(), _session_per_speaker.end()); }
@@ -904,21 +1115,23 @@ void PldaDev::computeAll()
     const std::vector<int64_t> sp = sps64();
     _mean.assign(_vectSize, 0.0);
     _speaker_means.assign(_vectSize * sp.size(), 0.0);
-    _srv.check(gmmiv_dev_means(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), _mean.data(),
+    _srv.check(gmmiv_dev_means(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), (int64_t)sp.size(), sp.data(), _mean.data(),
                                _speaker_means.data()));
 }
 void PldaDev::lengthNorm()
 {
-    std::vector<double> out(_data.size());
-    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)_vectSize, (int64_t)_n_sessions, _data.data(), nullptr, nullptr, 1, out.data()));
+    DVec out(_srv);
+    out.assign(_data.size(), 0.0);
+    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), nullptr, nullptr, 1, out.dev()));
     _data.swap(out);
     computeAll();
 }
 void PldaDev::center(const std::vector<double> &mu)
 {
     if (mu.size() != _vectSize) throw Exception("PldaDev::center: mean of the wrong size");
-    std::vector<double> out(_data.size());
-    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)_vectSize, (int64_t)_n_sessions, _data.data(), mu.data(), nullptr, 0, out.data()));
+    DVec out(_srv);
+    out.assign(_data.size(), 0.0);
+    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), mu.data(), nullptr, 0, out.dev()));
     _data.swap(out);
     computeAll();
 }
@@ -926,15 +1139,17 @@ void PldaDev::centerPerSpeaker()
 {
     const unsigned long k = _session_per_speaker.size();
     unsigned long s = 0;
+    std::vector<double> &x = _data.host();
     for (unsigned long c = 0; c < k; ++c)
         for (unsigned long e = 0; e < _session_per_speaker[c]; ++e, ++s)
-            for (unsigned long d = 0; d < _vectSize; ++d) _data[d * _n_sessions + s] -= _speaker_means[d * k + c];
+            for (unsigned long d = 0; d < _vectSize; ++d) x[d * _n_sessions + s] -= _speaker_means[d * k + c];
 }
 void PldaDev::rotateLeft(const std::vector<double> &M, unsigned long rows)
 {
     if (M.size() != rows * _vectSize) throw Exception("Rotation dimension mismatch !");
-    std::vector<double> out(rows * _n_sessions);
-    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)rows, (int64_t)_n_sessions, _data.data(), nullptr, M.data(), 0, out.data()));
+    DVec out(_srv);
+    out.assign(rows * _n_sessions, 0.0);
+    _srv.check(gmmiv_iv_normalize(_srv.ctx(), (int)_vectSize, (int)rows, (int64_t)_n_sessions, _data.cdev(), nullptr, M.data(), 0, out.dev()));
     _data.swap(out);
     _vectSize = rows;
     computeAll();
@@ -944,26 +1159,26 @@ void PldaDev::computeCovMat(std::vector<double> &Sigma, std::vector<double> &W, 
     const std::vector<int64_t> sp = sps64();
     const size_t dd = _vectSize * _vectSize;
     Sigma.assign(dd, 0.0); W.assign(dd, 0.0); B.assign(dd, 0.0);
-    _srv.check(gmmiv_dev_cov_mat(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), Sigma.data(),
+    _srv.check(gmmiv_dev_cov_mat(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), (int64_t)sp.size(), sp.data(), Sigma.data(),
                                  W.data(), B.data()));
 }
 void PldaDev::computeWccnChol(std::vector<double> &WCCN)
 {
     const std::vector<int64_t> sp = sps64();
     WCCN.assign(_vectSize * _vectSize, 0.0);
-    _srv.check(gmmiv_dev_wccn_chol(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), WCCN.data()));
+    _srv.check(gmmiv_dev_wccn_chol(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), (int64_t)sp.size(), sp.data(), WCCN.data()));
 }
 void PldaDev::computeMahalanobis(std::vector<double> &M)
 {
     const std::vector<int64_t> sp = sps64();
     M.assign(_vectSize * _vectSize, 0.0);
-    _srv.check(gmmiv_dev_mahalanobis(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), M.data()));
+    _srv.check(gmmiv_dev_mahalanobis(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), (int64_t)sp.size(), sp.data(), M.data()));
 }
 void PldaDev::computeScatterMat(std::vector<double> &SB, std::vector<double> &SW)
 {
     const std::vector<int64_t> sp = sps64();
     SB.assign(_vectSize * _vectSize, 0.0); SW.assign(_vectSize * _vectSize, 0.0);
-    _srv.check(gmmiv_dev_scatter_mat(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), SB.data(),
+    _srv.check(gmmiv_dev_scatter_mat(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.cdev(), (int64_t)sp.size(), sp.data(), SB.data(),
                                      SW.data()));
 }
 void PldaDev::computeLDA(std::vector<double> &ldaMat, unsigned long ldaRank, bool scatterMatrices)
@@ -993,7 +1208,7 @@ void PldaDev::sphericalNuisanceNormalization(unsigned long nbIt, bool sphNorm, s
 void PldaDev::emIteration(unsigned long rankF, unsigned long rankG, std::vector<double> &F, std::vector<double> &G, std::vector<double> &Sigma,
                           std::vector<double> &Delta, const std::vector<int64_t> &sp)
 {
-    _srv.check(gmmiv_plda_em_iteration(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.data(), (int64_t)sp.size(), sp.data(), (int)rankF,
+    _srv.check(gmmiv_plda_em_iteration(_srv.ctx(), (int)_vectSize, (int64_t)_n_sessions, _data.dev(), (int64_t)sp.size(), sp.data(), (int)rankF,
                                        (int)rankG, F.data(), G.data(), Sigma.data(), Delta.data()));
     computeAll(); // _Dev.center(_Delta) ends with computeAll(), :466-474
 }

@@ -37,6 +37,46 @@ Seg segFromLabel(double begin_s, double end_s, double frameLength, unsigned long
 
 class GpuServer; // context owner (the StatServer/MixtureServer pair of the reference)
 
+// A Matrix<double> / DoubleVector of the reference that LIVES ON THE DEVICE.  The accumulator classes below (EMAcc, TVAcc,
+// JFAAcc, PldaDev) keep their statistics, matrices and accumulators in these: the C ABI is called with device pointers, so
+// nothing crosses PCIe between the steps of a training loop -- at BASELINE's T-matrix configuration one rank holds F (6.1 GB),
+// TETt and A (1.3 GB each); staging them per call would cost more than the compute.  A host copy exists only while somebody
+// looks at it: host() downloads when the device copy is newer and assumes the caller may write (the next dev() uploads it
+// again), chost() is the read-only view.  All copies / memsets are enqueued on the context's stream, i.e. in order with the
+// kernels of the C ABI calls; only transfers that involve host memory wait for the stream.
+class DVec {
+  public:
+    DVec() = default;
+    explicit DVec(GpuServer &srv) : _srv(&srv) {}
+    ~DVec();
+    DVec(const DVec &) = delete;
+    DVec &operator=(const DVec &) = delete;
+    void bind(GpuServer &srv) { _srv = &srv; }
+    size_t size() const { return _n; }
+    bool empty() const { return _n == 0; }
+    void assign(size_t n, double v = 0.0);            // vector::assign: n elements equal to v (device-side for v == 0)
+    void set(const double *h, size_t n);              // upload
+    void set(const std::vector<double> &h) { set(h.data(), h.size()); }
+    void copyFrom(const DVec &o);                     // device-to-device (storeAccs / restoreAccs)
+    void swap(DVec &o);
+    double *dev();                                    // read-write device view (uploads a modified host copy first)
+    const double *cdev() const;                       // read-only device view
+    std::vector<double> &host();                      // read-write host view (downloads if the device copy is newer)
+    const std::vector<double> &chost() const;         // read-only host view
+    void get(double *h, size_t n, size_t offset = 0) const; // download a range without keeping a host copy
+
+  private:
+    void sync() const;
+    void *st() const;
+    void reserve(size_t n);
+    GpuServer *_srv = nullptr;
+    mutable double *_d = nullptr;
+    size_t _n = 0, _cap = 0;
+    mutable std::vector<double> _h;
+    mutable bool _hostValid = false;  // _h mirrors the device copy
+    mutable bool _hostDirty = false;  // _h may have been written through host(): the device copy is stale
+};
+
 // FeatureServer(ALL_FEATURES): all frames of all sources, float32 like SPro files, device resident.
 class FeatureBuffer {
   public:
@@ -88,6 +128,8 @@ class GpuServer {
     explicit GpuServer(int device = 0);
     ~GpuServer();
     gmmiv_ctx *ctx() { return _ctx; }
+    void *stream() { return gmmiv_ctx_stream(_ctx); } // hipStream_t of the context: the host layer's own copies are ordered on it
+    void sync() { check(gmmiv_ctx_sync(_ctx)); }
     void check(int rc) const; // throws Exception(gmmiv_last_error()) on rc != 0
 
   private:
@@ -116,17 +158,18 @@ class EMAcc {
   public:
     EMAcc(DeviceMixture &dm, const MixtureGD &model);
     void resetEM();
-    double getEMFeatureCount() const { return _acc.back(); }
-    double getAccumulatedLLK() const { return _acc[_acc.size() - 2]; }
+    double getEMFeatureCount() const;   // sum of the frame weights (2 doubles come back from the device)
+    double getAccumulatedLLK() const;
     MixtureGD getEM() const; // ML weights / means / covariances; occ == 0 keeps the model's values
     void addAccEM(const EMAcc &o);
-    std::vector<double> &flat() { return _acc; } // the all-reduce payload
+    std::vector<double> &flat() { return _acc.host(); } // host view of the flat accumulator (downloaded on demand)
+    DVec &acc() { return _acc; }                         // the device-resident accumulator = the all-reduce payload
     DeviceMixture &mixture() { return _dm; }
 
   private:
     DeviceMixture &_dm;
     MixtureGD _model;
-    std::vector<double> _acc;
+    DVec _acc;
 };
 
 // FrameAccGD
@@ -163,10 +206,15 @@ void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedFrameS
                     unsigned long minimumLength, unsigned long maximumLength);
 // trainModelStream (TrainTools.cpp:1030-1110), single stream; returns the per-iteration mean llk
 // ("llkPreviousIt").  allReduce, when given, sums the flat accumulator over ranks (RCCL/xGMI).
+// Multi-GPU: frames sharded per rank, ONE all-reduce of the flat EM accumulator per iteration, the collective twin of
+// MixtureStat::addAccEM (AccumulateStat.cpp:286-292).  The default is the C ABI's own RCCL communicator (comm, on the device
+// accumulator); AllReduceFn is the hook for another transport (it gets the HOST view of the accumulator).
 typedef void (*AllReduceFn)(double *buf, size_t n, void *user);
 std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
+                                     const std::vector<double> &globalCov, MixtureGD &world, gmmiv_comm *comm);
+std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
                                      const std::vector<double> &globalCov, MixtureGD &world,
-                                     AllReduceFn allReduce = nullptr, void *user = nullptr);
+                                     AllReduceFn allReduce = nullptr, void *user = nullptr, gmmiv_comm *comm = nullptr);
 
 // ---- TrainTarget: MAP adaptation (TrainTools.cpp:445-489 computeMAPOccDep, :871-904 adaptModel) ----
 struct MAPCfg { // MAPCfg::MAPCfg, TrainTools.cpp:95-140 (subset: method MAPOccDep)
@@ -231,21 +279,33 @@ class TVAcc {
     void estimateWUbmWeight(const std::vector<double> &W);                                 // :2348-2396 (zeroes _W first)
     void estimateWEigenDecomposition(const std::vector<double> &D, const std::vector<double> &Q); // :2566-2609 (accumulates into _W)
     void resetTmpAcc();                // :620-629
-    void loadT(const std::vector<double> &T) { _T = T; }
-    void setStats(const std::vector<double> &N, const std::vector<double> &F) { _statN = N; _statF = F; }
-    std::vector<double> &getT() { return _T; }
-    std::vector<double> &getW() { return _W; }
-    std::vector<double> &getN() { return _statN; }
-    std::vector<double> &getF() { return _statF; }
-    std::vector<double> &getUbmMeans() { return _ubm_means; }
+    void loadT(const std::vector<double> &T);
+    void setStats(const std::vector<double> &N, const std::vector<double> &F);   // loadN / loadF (upload, no host copy kept)
+    void setStats(const double *N, const double *F);
+    // TotalVariability reloads N and F from disk at every iteration because substractM works in place
+    // (TotalVariability.cpp:152-153); here the pristine statistics are kept on the device instead
+    void storeStats();
+    void restoreStats();
+    // Multi-GPU form of updateTestimate for utterance-sharded statistics: reduce-scatter of A / Cmx by blocks
+    // of Gaussians, T_c = A_c^-1 Cmx_c on the rank's own Gaussians, all-gather of T; R, r and meanW (sums) are all-reduced
+    // for minDivergence, whose session count becomes the global one.  comm == NULL or one rank: plain updateTestimate.
+    void updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks);
+    // all host views below download on demand (and re-upload before the next device step, they may be written through)
+    std::vector<double> &getT() { return _T.host(); }
+    std::vector<double> &getW() { return _W.host(); }
+    std::vector<double> &getN() { return _statN.host(); }
+    std::vector<double> &getF() { return _statF.host(); }
+    std::vector<double> &getUbmMeans() { return _ubm_means.host(); }
+    DVec &deviceT() { return _T; }
+    DVec &deviceW() { return _W; }
     unsigned long getRankT() const { return _rankT; }
 
   private:
     GpuServer &_srv;
     MixtureGD _ubm;
     DeviceMixture _dubm;
-    unsigned long _rankT, _n_speakers, _n_distrib, _vectSize, _svSize;
-    std::vector<double> _ubm_means, _ubm_invvar, _statN, _statF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
+    unsigned long _rankT, _n_speakers, _n_distrib, _vectSize, _svSize, _n_sessions_global;
+    DVec _ubm_means, _ubm_invvar, _statN, _statF, _cN, _cF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
 };
 
 // ---- AccumulateJFAStat.h: JFAAcc, M_{s,h} = m + V y_s + U x_h + D z_s (AccumulateJFAStat.cpp) ---------------------------
@@ -287,16 +347,16 @@ class JFAAcc {
     void substractMplusDZByChannel();  // :3948-3976   _F_X_h -= N_h (m + D z) of the session's speaker
     void orthonormalizeV();            // :4700-4777
     void getMplusVYplusDZ(std::vector<double> &Sp, unsigned long spk); // :1926-1935
-    std::vector<double> &getV() { return _V; }
-    std::vector<double> &getU() { return _matU; }
-    std::vector<double> &getD() { return _D; }
-    std::vector<double> &getY() { return _Y; }
-    std::vector<double> &getX() { return _matX; }
-    std::vector<double> &getZ() { return _Z; }
-    std::vector<double> &getN() { return _matN; }
-    std::vector<double> &getN_h() { return _N_h; }
-    std::vector<double> &getF_X() { return _F_X; }
-    std::vector<double> &getF_X_h() { return _F_X_h; }
+    std::vector<double> &getV() { return _V.host(); }
+    std::vector<double> &getU() { return _matU.host(); }
+    std::vector<double> &getD() { return _D.host(); }
+    std::vector<double> &getY() { return _Y.host(); }
+    std::vector<double> &getX() { return _matX.host(); }
+    std::vector<double> &getZ() { return _Z.host(); }
+    std::vector<double> &getN() { return _matN.host(); }
+    std::vector<double> &getN_h() { return _N_h.host(); }
+    std::vector<double> &getF_X() { return _F_X.host(); }
+    std::vector<double> &getF_X_h() { return _F_X_h.host(); }
     unsigned long getNSpeakers() const { return _n_speakers; }
     unsigned long getNSessions() const { return _n_sessions; }
 
@@ -306,8 +366,8 @@ class JFAAcc {
     DeviceMixture _dubm;
     unsigned long _rankEV, _rankEC, _n_speakers, _n_sessions, _n_distrib, _vectSize, _svSize;
     std::vector<int64_t> _sess_begin, _owner;
-    std::vector<double> _ubm_means, _ubm_invvar, _matN, _N_h, _F_X, _F_X_h, _cN, _cN_h, _cF_X, _cF_X_h;
-    std::vector<double> _V, _matU, _D, _Y, _matX, _Z, _vEvT, _uEuT, _Aev, _Cev, _Aec, _Cec;
+    DVec _ubm_means, _ubm_invvar, _matN, _N_h, _F_X, _F_X_h, _cN, _cN_h, _cF_X, _cF_X_h;
+    DVec _V, _matU, _D, _Y, _matX, _Z, _vEvT, _uEuT, _Aev, _Cev, _Aec, _Cec, _mdR, _mdr, _mdmw; // _md*: minimum-divergence sums, unused by JFA
 };
 // the three training tools around it (statistics and initial matrices already in the accumulator)
 void eigenVoice(JFAAcc &jfaAcc, unsigned long nbIt, bool orthonormalizeV);   // EigenVoice.cpp:114-147
@@ -326,7 +386,8 @@ class PldaDev {
     unsigned long getSpeakerNumber() const { return _session_per_speaker.size(); }
     unsigned long getSessionNumber() const { return _n_sessions; }
     unsigned long getSpeakerSessionNumber(unsigned long spk) const { return _session_per_speaker.at(spk); }
-    std::vector<double> &getData() { return _data; }
+    std::vector<double> &getData() { return _data.host(); }   // host view, downloaded on demand
+    DVec &deviceData() { return _data; }
     const std::vector<double> &getMean() const { return _mean; }
     const std::vector<double> &getSpeakerMeans() const { return _speaker_means; } // [vectSize x n_speakers]
     void computeAll();                                   // :353-387
@@ -353,7 +414,8 @@ class PldaDev {
     std::vector<int64_t> sps64() const;
     GpuServer &_srv;
     unsigned long _vectSize, _n_sessions;
-    std::vector<double> _data, _mean, _speaker_means;
+    DVec _data;                                   // [vectSize x n_sessions], device resident
+    std::vector<double> _mean, _speaker_means;
     std::vector<unsigned long> _session_per_speaker;
 };
 

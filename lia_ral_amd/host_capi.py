@@ -57,6 +57,18 @@ def train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, bagged_p=1.0, init_f
     return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk)
 
 
+def mean_llk(x, seg_begin, seg_len, model, min_llk=-200.0, max_llk=200.0, device=0):
+    """accumulateStatLLK: mean clamped log-likelihood of the selected frames."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in model]
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    out = ct.c_double(0.0)
+    _chk(lib.liagpu_mean_llk(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), len(w), _d(w), _d(mean), _d(cov),
+                             ct.c_double(min_llk), ct.c_double(max_llk), ct.byref(out)))
+    return out.value
+
+
 def train_target(x, seg_begin, seg_len, world, nb_it=1, mean_reg=16.0, device=0):
     """TrainTarget: mean-only MAPOccDep adaptation of the world model; returns (w, mean, cov)."""
     x = np.ascontiguousarray(x, np.float32)
@@ -196,6 +208,33 @@ def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     _chk(lib.liagpu_tv_train(device, ct.c_long(N.shape[0]), C, D, _d(w), _d(mean), _d(cov), R, _d(N), _d(F), _d(Tm), nb_it,
                              int(min_div), _d(means)))
     return Tm, means
+
+
+def tv_train_dist(N, F, ubm, Tmat, nb_it, world=1, rank=0, id_file="", n_total=None, min_div=True, device=0):
+    """One rank of a multi-GPU TotalVariability run (liagpu_tv_train_dist); returns (T, means, times_ms [nb_it x 4])."""
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    N = np.ascontiguousarray(N, np.float64); F = np.ascontiguousarray(F, np.float64)
+    Tm = np.array(Tmat, np.float64)
+    R = Tm.shape[0]
+    means = np.empty(C * D); times = np.zeros((nb_it, 4))
+    _chk(lib.liagpu_tv_train_dist(device, world, rank, id_file.encode(), ct.c_long(N.shape[0]), ct.c_long(n_total or N.shape[0]), C, D, _d(w),
+                                  _d(mean), _d(cov), R, _d(N), _d(F), _d(Tm), nb_it, int(min_div), _d(means), _d(times)))
+    return Tm, means, times
+
+
+def train_world_dist(x, seg_begin, seg_len, w, mean, cov, nb_it, global_cov, world=1, rank=0, id_file="", init_floor=0.0, final_floor=0.0,
+                     init_ceil=10.0, final_ceil=10.0, device=0):
+    """One rank of a multi-GPU TrainWorld run (liagpu_train_world_dist)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w = np.array(w, np.float64); mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    llk = np.empty(nb_it); gc = np.ascontiguousarray(global_cov, np.float64)
+    _chk(lib.liagpu_train_world_dist(device, world, rank, id_file.encode(), x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)),
+                                     len(w), _d(w), _d(mean), _d(cov), nb_it, ct.c_double(init_floor), ct.c_double(final_floor),
+                                     ct.c_double(init_ceil), ct.c_double(final_ceil), _d(gc), _d(llk)))
+    return dict(w=w, mean=mean, cov=cov, llk=llk)
 
 
 def jfa_train(task, sess_per_spk, ubm, N, N_h, F_X, F_X_h, V, U, Dm, nb_it, Z0=None, ortho_v=False, device=0):

@@ -207,3 +207,68 @@ def test_two_rank_tv_mstep_reduce_scatter_gloo():
     assert np.array_equal(res[0]["T"], res[1]["T"])                      # every rank ends with the same T
     assert np.allclose(res[0]["T"], Tref, rtol=1e-9, atol=1e-12)         # == the single-process M-step
     assert np.allclose(res[0]["Rm"], o["Rm"], rtol=1e-12, atol=1e-12) and np.array_equal(res[0]["Rm"], res[1]["Rm"])
+
+
+def _tv_iter_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lia_ral_amd.dist import shard_range, tv_em_iteration
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    C, D, R, U = 7, 4, 5, 13            # 7 Gaussians over 3 ranks: blocks of 3, 3 and 1 (+ 2 of padding)
+    rng = np.random.default_rng(1)
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D); means = rng.normal(size=C * D)
+    b, e = shard_range(U, rank, world)
+
+    class Ops:                           # CPU stand-ins for the gmmiv_tv_* calls of a GPU rank
+        def tett(self):
+            self.te = orc.tv_tett(T, iv, C, D)
+
+        def estep(self):
+            o = orc.tv_estimate_a_and_c(N[b:e], F[b:e], T, iv, self.te)
+            return dict(A=o["A"], Cmx=o["Cmx"], Rm=o["Rm"], r=o["r"], meanW=o["meanW"] * (e - b))
+
+        def update_t(self, A_blk, C_blk, cb):
+            return orc.tv_update_t(A_blk, C_blk, cb, D)
+
+        def min_divergence(self, acc, Tn, n):
+            self.means, Tm = orc.tv_min_divergence(acc["Rm"], acc["r"], acc["meanW"] / n, means, Tn, n, C, D)
+            return Tm
+
+    ops = Ops()
+    phases = {}
+    Tn = tv_em_iteration(ops, U, C, D, rank, world, phases=phases)
+    q.put((rank, dict(T=Tn, means=ops.means, phases=sorted(phases))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_tv_em_iteration_padded_blocks_gloo():
+    """A whole TotalVariability iteration (estimateTETt, estimateAandC, reduce-scatter, sharded updateTestimate, all-gather,
+    minDivergence) on 3 ranks with a Gaussian count that does not divide: same T and means as one process."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_tv_iter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    C, D, R, U = 7, 4, 5, 13
+    rng = np.random.default_rng(1)
+    N = rng.uniform(0.5, 20, (U, C)); F = rng.normal(size=(U, C * D)); T = rng.normal(size=(R, C * D)) * 0.3
+    iv = rng.uniform(0.5, 2, C * D); means = rng.normal(size=C * D)
+    o = orc.tv_estimate_a_and_c(N, F, T, iv, orc.tv_tett(T, iv, C, D))
+    Tref = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+    mref, Tref = orc.tv_min_divergence(o["Rm"], o["r"], o["meanW"], means, Tref, U, C, D)
+    for r in range(1, world):
+        assert np.array_equal(res[0]["T"], res[r]["T"]) and np.array_equal(res[0]["means"], res[r]["means"])
+    assert np.allclose(res[0]["T"], Tref, rtol=1e-9, atol=1e-12)
+    assert np.allclose(res[0]["means"], mref, rtol=1e-9, atol=1e-12)
+    assert res[0]["phases"] == ["allgather", "estep", "min_divergence", "reduce_scatter", "tett", "update_t"]

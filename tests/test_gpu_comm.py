@@ -1,0 +1,145 @@
+"""The C ABI's collectives (gmmiv_comm_*, RCCL inside libgmmiv) and the sharded TotalVariability iteration on HIP.
+
+One MI355X per gpurun box: the single-rank forms are checked here (every entry point, device and host buffers, the whole
+iteration against the oracle's loop); the 2-rank RCCL test runs when the box shows two devices, the N-rank orchestration
+itself is covered on CPU with gloo (tests/test_cpu_plumbing.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def test_single_rank_collectives_are_identities():
+    import torch
+    from lia_ral_amd import capi
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    comm = capi.Comm(ctx, 1, 0)
+    assert comm.world == 1 and comm.rank == 0 and "single rank" in comm.backend()
+    a = torch.arange(1000, dtype=torch.float64, device="cuda")
+    b = a.clone()
+    comm.allreduce(b); comm.broadcast(b, 0)
+    out = torch.empty_like(a)
+    comm.reduce_scatter(a, out)
+    assert torch.equal(out, a) and torch.equal(b, a)
+    out.zero_()
+    comm.allgather(a, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, a)
+    h = np.arange(10.0)
+    comm.allreduce(h)
+    assert np.array_equal(h, np.arange(10.0))
+    assert comm.take_bytes() == (1000 * 4 + 10) * 8 and comm.take_bytes() == 0
+    with pytest.raises(capi.GmmivError):
+        capi.Comm(ctx, 2, 0)                      # world > 1 needs the id of rank 0
+    assert len(capi.Comm.unique_id()) == capi.COMM_ID_BYTES     # RCCL resolves at run time (dlopen)
+    comm.close(); ctx.close()
+
+
+def test_tv_em_iterations_on_device_match_oracle_loop():
+    """lia_ral_amd.dist.tv_em_iteration with libgmmiv as the compute (device-resident N, F, T, accumulators) == the same
+    TotalVariability loop assembled from oracle pieces (TotalVariability.cpp:118-169), two iterations."""
+    import torch
+    from lia_ral_amd import capi
+    from lia_ral_amd import dist as gd
+    C, D, R, U = 32, 20, 40, 200
+    rng = np.random.default_rng(3)
+    N = rng.gamma(0.8, 3.0, (U, C)); F = rng.normal(size=(U, C * D)) * np.sqrt(np.repeat(N, D, 1) + 0.1)
+    T0 = rng.normal(0, 0.05, (R, C * D)); iv = rng.uniform(0.5, 2, C * D); means = rng.normal(size=C * D)
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    coll = gd.GmmivCollectives(capi.Comm(ctx, 1, 0))
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    P = R * (R + 1) // 2
+
+    class Ops:
+        def __init__(self):
+            self.N, self.F, self.T, self.iv, self.means = dv(N), dv(F), dv(T0), dv(iv), dv(means)
+            z = lambda *s: torch.zeros(s, dtype=torch.float64, device="cuda")
+            self.te = z(C, P)
+            self.acc = dict(A=z(C, P), Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=z(U, R))
+
+        def tett(self):
+            ctx.tv_tett(self.T, self.iv, C, D, out=self.te)
+
+        def estep(self):
+            for k in ("A", "Cmx", "Rm", "r", "meanW"):
+                self.acc[k].zero_()
+            return ctx.tv_estimate_a_and_c(self.N, self.F, self.T, self.iv, self.te, C, D, acc=self.acc)
+
+        def update_t(self, A_blk, C_blk, cb):
+            return ctx.tv_update_t(A_blk, C_blk, cb, D, out=torch.empty((R, cb * D), dtype=torch.float64, device="cuda"))
+
+        def min_divergence(self, acc, Tn, n):
+            ctx.tv_min_divergence(acc["Rm"], acc["r"], acc["meanW"] / n, self.means, Tn, n, C, D)
+            self.T = Tn
+            return Tn
+
+    ops = Ops()
+    To, mo = T0.copy(), means.copy()
+    for it in range(2):
+        phases = {"sync": torch.cuda.synchronize}
+        Tg = gd.tv_em_iteration(ops, U, C, D, 0, 1, coll, phases)
+        o = orc.tv_estimate_a_and_c(N, F, To, iv, orc.tv_tett(To, iv, C, D))
+        To = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+        mo, To = orc.tv_min_divergence(o["Rm"], o["r"], o["meanW"], mo, To, U, C, D)
+        assert relerr(Tg.cpu().numpy(), To) < 1e-7, it
+        assert relerr(ops.means.cpu().numpy(), mo) < 1e-9
+        assert set(phases) >= {"tett", "estep", "reduce_scatter", "update_t", "min_divergence"}
+    ctx.close()
+
+
+def _rank_main(rank, world, idfile, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    from lia_ral_amd import capi
+    torch.cuda.set_device(rank)
+    ctx = capi.Context(rank, torch.cuda.current_stream().cuda_stream)
+    uid = capi.Comm.exchange_id_file(idfile, rank, 60.0)
+    comm = capi.Comm(ctx, world, rank, uid)
+    dev = torch.device("cuda", rank)
+    a = torch.full((1 << 16,), float(rank + 1), dtype=torch.float64, device=dev)
+    comm.allreduce(a)
+    send = torch.arange(world * 1000, dtype=torch.float64, device=dev) * (rank + 1)
+    mine = torch.empty(1000, dtype=torch.float64, device=dev)
+    comm.reduce_scatter(send, mine)
+    gathered = torch.empty(world * 1000, dtype=torch.float64, device=dev)
+    comm.allgather(mine, gathered)
+    h = np.full(7, rank + 1.0)
+    comm.allreduce(h)
+    torch.cuda.synchronize()
+    q.put((rank, float(a[0].item()), mine.cpu().numpy(), gathered.cpu().numpy(), h, comm.backend()))
+    comm.close(); ctx.close()
+
+
+def test_two_rank_rccl_through_the_c_abi(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the multi-rank RCCL path needs two devices")
+    import torch.multiprocessing as mp
+    world = 2
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_main, args=(r, world, str(tmp_path / "rccl.id"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tot = sum(range(1, world + 1))
+    full = np.arange(world * 1000, dtype=np.float64) * tot
+    for r in range(world):
+        assert res[r][1] == tot
+        assert np.array_equal(res[r][2], full[r * 1000:(r + 1) * 1000])
+        assert np.array_equal(res[r][3], full)
+        assert np.array_equal(res[r][4], np.full(7, float(tot)))
+        assert "rccl" in res[r][5]

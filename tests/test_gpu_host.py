@@ -476,3 +476,108 @@ def test_jfa_dot_product_scoring():
     got = hc.jfa_dot_product((p["w"], p["mean"], 1.0 / p["iv"]), N, F, p["V"], p["U"], p["D"], clients)
     assert relerr(got, ref) < 1e-9
 
+
+
+def _tv_case(seed=3):
+    C, D, R, U = 7, 12, 10, 60                       # 7 Gaussians: blocks of 4 + 3 on two ranks
+    rng = np.random.default_rng(seed)
+    w, mean, iv = make_gmm(C, D, seed=seed)
+    N = rng.gamma(0.8, 3.0, (U, C)); F = rng.normal(size=(U, C * D)) * 3 + np.repeat(N, D, 1) * mean.ravel()
+    Tm = rng.normal(0, 0.05, (R, C * D))
+    return C, D, R, U, w, mean, iv, N, F, Tm
+
+
+def _oracle_tv_loop(C, D, U, mean, iv, N, F, Tm, nb_it):
+    To, mo = Tm.copy(), mean.ravel().copy()
+    for _ in range(nb_it):
+        F0 = orc.tv_subtract_m(N, F, mo)
+        o = orc.tv_estimate_a_and_c(N, F0, To, iv.ravel(), orc.tv_tett(To, iv.ravel(), C, D))
+        To = orc.tv_update_t(o["A"], o["Cmx"], C, D)
+        mo, To = orc.tv_min_divergence(o["Rm"], o["r"], o["meanW"], mo, To, U, C, D)
+    return To, mo
+
+
+def test_tv_train_dist_single_rank_is_the_plain_loop():
+    """liagpu_tv_train_dist with one rank (device-resident TVAcc, no RCCL) == TotalVariability's loop from oracle pieces."""
+    from lia_ral_amd import host_capi as h
+    C, D, R, U, w, mean, iv, N, F, Tm = _tv_case()
+    Tg, mg, times = h.tv_train_dist(N, F, (w, mean, 1.0 / iv), Tm, 2)
+    To, mo = _oracle_tv_loop(C, D, U, mean, iv, N, F, Tm, 2)
+    assert relerr(Tg, To) < 1e-6 and relerr(mg, mo) < 1e-8
+    assert times.shape == (2, 4) and np.all(times > 0)
+
+
+def _tv_rank(rank, world, idfile, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from lia_ral_amd import host_capi as h
+    from lia_ral_amd.dist import shard_range
+    C, D, R, U, w, mean, iv, N, F, Tm = _tv_case()
+    b, e = shard_range(U, rank, world)
+    Tg, mg, _ = h.tv_train_dist(N[b:e], F[b:e], (w, mean, 1.0 / iv), Tm, 2, world=world, rank=rank, id_file=idfile, n_total=U, device=rank)
+    q.put((rank, Tg, mg))
+
+
+def test_tv_train_dist_two_ranks_rccl(tmp_path):
+    """Utterances sharded over two GPUs, reduce-scatter / all-gather through gmmiv_comm inside the C++ host layer: same T and
+    means on both ranks, equal to the single-process loop."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_tv_rank, args=(r, 2, str(tmp_path / "id"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    C, D, R, U, w, mean, iv, N, F, Tm = _tv_case()
+    To, mo = _oracle_tv_loop(C, D, U, mean, iv, N, F, Tm, 2)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert relerr(res[0][1], To) < 1e-6 and relerr(res[0][2], mo) < 1e-8
+
+
+def test_train_world_dist_single_rank_matches_train_world():
+    from lia_ral_amd import host_capi as h
+    C, D, T = 16, 12, 3000
+    w, mean, iv = make_gmm(C, D, seed=5)
+    x = make_frames(w, mean, iv, T, seed=6)
+    w0 = np.full(C, 1.0 / C); mean0 = mean + 0.3; cov0 = np.ones((C, D)) * 2.0
+    a = h.train_world(x, [0], [T], w0, mean0, cov0, nb_it=2, init_floor=0.1, final_floor=0.1)
+    b = h.train_world_dist(x, [0], [T], w0, mean0, cov0, 2, a["global_cov"], init_floor=0.1, final_floor=0.1)
+    assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["cov"], b["cov"]) and np.array_equal(a["llk"], b["llk"])
+
+
+def test_accumulate_stat_llk_wrapper_and_kat4_through_frame_moments(golden_dir):
+    """KAT-4 (LIA_SpkDet/NormFeat/test/test1.validate.prm: FrameAccGD mean / biased std, AccumulateStat.cpp:387-396) through
+    gmmiv_frame_moments on the device, and liagpu::accumulateStatLLK (AccumulateStat.cpp:69-94) through the host layer."""
+    from lia_ral_amd import capi, host_capi as h
+    k = np.load(os.path.join(golden_dir, "kat4_normfeat.npz"))
+    rows = np.concatenate([np.arange(b, b + n) for b, n in zip(k["seg_begin"], k["seg_len"])])
+    x = np.ascontiguousarray(k["x"][rows], np.float32)
+    D = x.shape[1]
+    ctx = capi.Context(0)
+    acc = ctx.frame_moments(x)
+    ctx.close()
+    n = acc[2 * D]
+    mean = acc[:D] / n
+    cov = acc[D:2 * D] / n - mean * mean                    # biased (ddof = 0), FrameAccGD::getCovVect
+    diff = np.abs((x.astype(np.float64) - mean) / np.sqrt(cov) - k["x_norm"][rows].astype(np.float64))
+    assert n == len(rows) and np.median(diff) < float(k["median_tol"]) and diff.max() < float(k["max_tol"])
+    s_, ss_, cnt = orc.frame_acc(x.astype(np.float64))
+    assert relerr(acc[:D], s_) < 1e-13 and relerr(acc[D:2 * D], ss_) < 1e-13 and n == cnt
+    # accumulateStatLLK: mean clamped log-likelihood over label segments
+    C, T = 16, 900
+    w, m, iv = make_gmm(C, D, seed=2)
+    xx = make_frames(w, m, iv, T, seed=3)
+    segs_b, segs_l = [10, 400], [200, 333]
+    got = h.mean_llk(xx, segs_b, segs_l, (w, m, 1.0 / iv), -200.0, 200.0)
+    sel = np.concatenate([np.arange(b, b + n_) for b, n_ in zip(segs_b, segs_l)])
+    ref = orc.llk(orc.Gmm(w, m, iv), xx[sel].astype(np.float64)).mean()
+    assert abs(got - ref) < 1e-10
+    floor = h.mean_llk(xx, segs_b, segs_l, (w, m, 1.0 / iv), ref + 50.0, 400.0)      # every frame clamped to minLLK
+    assert abs(floor - (ref + 50.0)) < 1.0 and floor >= ref + 50.0 - 1e-12
