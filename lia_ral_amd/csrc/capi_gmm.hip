@@ -1,6 +1,7 @@
 // capi_gmm.hip -- C ABI (include/gmmiv.h): context, model, GMM likelihood / statistics entry points.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "ctx.h"
 #include "gmm_kernels.h"
@@ -96,6 +97,8 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "z_waves")) slot = &c->z_waves;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
+    else if (!strcmp(key, "topc_fused")) slot = &c->topc_fused;
+    else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
     if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
         return gmmk_stats_z_set_tv4((int)value);
     }
@@ -349,7 +352,76 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     // direct form only for the candidates (topc_z.hip).  Redone with the direct-form kernel in the (never observed) case that a
     // non-candidate comes within 1e-6 of the selected set.
     bool done = false;
-    const int64_t Tc = c->topc_z ? z_chunk_frames(c, g) : 0;
+    // Fused path (default): the candidates are collected in the epilogue of the MFMA log-likelihood kernel itself
+    // (k_llk_mfma<TC>: 4 KB of candidate records per frame instead of the 16 KB likelihood round trip) and ranked by
+    // k_topc_rank.  Redone by the paths below if a frame overflows its list or fails the margin check (flag).
+    if (c->topc_fused && T > 0 && ctop <= 16 && g->C <= 2048 && g->D <= 64 && g->KS <= 15 && c->wg_waves == 8) {
+        const size_t per_frame = (size_t)gmmk_topc_cap() * 16;
+        size_t budget = (size_t)(c->z_scratch_mb > 0 ? c->z_scratch_mb : 0) << 20;
+        if (c->total_mem && budget > c->total_mem / 4) budget = c->total_mem / 4;
+        int64_t Tf = (int64_t)(budget / per_frame / 1.2) / 256 * 256;
+        if (Tf >= 256) {
+            const int64_t first = T < Tf ? (T + 255) / 256 * 256 : Tf;
+            void *cand, *cnt, *th, *sl, *flg;
+            if ((rc = c->scratch(WS_Z, (size_t)first * per_frame, &cand))) return rc;
+            if ((rc = c->scratch(WS_EIT, (size_t)first * sizeof(int), &cnt))) return rc;
+            if ((rc = c->scratch(WS_INV, (size_t)first * (sizeof(double) + sizeof(int)), &sl))) return rc;
+            if ((rc = c->scratch(WS_LSE, (size_t)first * sizeof(double), &th))) return rc;
+            if ((rc = c->scratch(WS_FLAGS, 64, &flg))) return rc;
+            int *efin = (int *)((double *)sl + first);
+            void *redo;
+            if ((rc = c->scratch(WS_SEG, (size_t)first * sizeof(long), &redo))) return rc;
+            const int stats = getenv("GMMIV_TOPC_STATS") != nullptr;
+            int krc = 0;
+            bool whole = false; // too many frames failed the fused path: the paths below redo the call
+            for (int64_t c0 = 0; c0 < T && krc == 0 && !whole; c0 += Tf) {
+                const int64_t n = (T - c0) < Tf ? (T - c0) : Tf;
+                GCHK(hipMemsetAsync(flg, 0, 64, c->stream));
+                c->t_begin("k_llk_mfma", c0 == 0);
+                krc = gmmk_llk_topc(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (int)c->use_glds,
+                                    ctop, (double *)cand, (int *)cnt, (double *)th, (double *)sl, efin);
+                c->t_end();
+                if (krc) break;
+                int *oi = o_idx.d + (size_t)c0 * ctop;
+                double *olk = o_lk.d ? o_lk.d + (size_t)c0 * ctop : nullptr, *onlk = o_nlk.d ? o_nlk.d + c0 : nullptr;
+                double *onllk = o_nllk.d ? o_nllk.d + c0 : nullptr, *onw = o_nw.d ? o_nw.d + c0 : nullptr, *ollk = o_llk.d ? o_llk.d + c0 : nullptr;
+                c->t_begin("k_topc_rank", c0 == 0);
+                krc = gmmk_topc_rank(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->C, (const double *)cand, (const int *)cnt,
+                                     (const double *)th, (const double *)sl, efin, g->mean, g->iv, g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE,
+                                     min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, (int *)flg, (long *)redo, stats);
+                c->t_end();
+                if (krc) break;
+                int hf[16] = {0};
+                GCHK(hipMemcpyAsync(hf, flg, 64, hipMemcpyDeviceToHost, c->stream));
+                GCHK(hipStreamSynchronize(c->stream));
+                if (stats)
+                    fprintf(stderr, "topc fused: %ld frames, redone %d | overflow %d, survivors > 64: %d, < ctop: %d, margin %d | list max %d mean %.1f | survivors max %d mean %.1f\n",
+                            (long)n, hf[0], hf[1], hf[2], hf[3], hf[4], hf[5], (double)*(unsigned long long *)&hf[6] / (double)n, hf[8],
+                            (double)*(unsigned long long *)&hf[10] / (double)n);
+                const int64_t nr = hf[0];
+                c->topc_fallbacks += nr;
+                if (nr == 0) continue;
+                if (nr > n / 8 + 64) { whole = true; break; }
+                // the few frames whose list overflowed / piled up / failed the margin: direct form for every Gaussian
+                // (k_topc_determine) on a gathered copy, results scattered back
+                void *gx, *t_idx, *t_d;
+                if ((rc = c->scratch(WS_PART, (size_t)nr * g->D * esize(dt), &gx))) return rc;
+                if ((rc = c->scratch(WS_T6, (size_t)nr * ctop * sizeof(int), &t_idx))) return rc;
+                if ((rc = c->scratch(WS_T7, (size_t)nr * (ctop + 4) * sizeof(double), &t_d))) return rc;
+                double *t_lk = (double *)t_d, *t_nlk = t_lk + (size_t)nr * ctop, *t_nllk = t_nlk + nr, *t_nw = t_nllk + nr, *t_llk = t_nw + nr;
+                GCHK(gmmk_gather_frames(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, (const long *)redo, nr, gx));
+                c->t_begin("k_topc_determine", c0 == 0);
+                GCHK(gmmk_topc_determine(c->stream, dt == GMMIV_F64, gx, nr, g->D, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc, g->w, ctop,
+                                         mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, (int *)t_idx, t_lk, t_nlk, t_nllk, t_nw, t_llk));
+                c->t_end();
+                GCHK(gmmk_topc_scatter(c->stream, nr, ctop, (const long *)redo, (const int *)t_idx, t_lk, t_nlk, t_nllk, t_nw, t_llk, oi, olk, onlk,
+                                       onllk, onw, ollk));
+            }
+            if (krc > 0) GCHK(krc);
+            done = krc == 0 && !whole;
+        }
+    }
+    const int64_t Tc = (!done && c->topc_z) ? z_chunk_frames(c, g) : 0;
     if (Tc > 0 && T > 0 && ctop + 4 <= 64 && gmmk_topc_z_lds(g->nct, g->D)) {
         const int64_t first = T < Tc ? T : Tc;
         const long nfb = z_tile_blocks(first);

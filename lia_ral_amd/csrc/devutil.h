@@ -183,6 +183,16 @@ __device__ __forceinline__ int row_max_i32(int v)
     return v;
 }
 
+__device__ __forceinline__ int row_min_i32(int v)
+{
+    int o;
+    o = dpp_i32<0x128>(v); v = o < v ? o : v;
+    o = dpp_i32<0x124>(v); v = o < v ? o : v;
+    o = dpp_i32<0x122>(v); v = o < v ? o : v;
+    o = dpp_i32<0x121>(v); v = o < v ? o : v;
+    return v;
+}
+
 // Wave-wide arg-max of (value, index) pairs, larger value first, smaller index on ties; every lane gets the winner.
 // DPP row rotations inside the 16-lane rows (plain VALU instructions), then the 4 row results through v_readlane and scalar
 // compares -- a ds_bpermute butterfly is 6 dependent LDS-pipe round trips of 3 permutes each (~2000 cycles per arg-max).

@@ -41,6 +41,18 @@ int gmmk_em_fused(hipStream_t st, int KS, int sq, int x_f64, const void *x, long
 // stats_z.hip / k_llk_mfma<WZ>: scaled likelihoods written once by the log-likelihood kernel, statistics from them
 int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
                double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin);
+// k_llk_mfma<TC>: candidates of the top-C' selection collected in the log-likelihood kernel (see gmm_kernels.hip), ranked by
+// gmmk_topc_rank (topc_z.hip)
+int gmmk_topc_cap(void);
+int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct, int use_glds,
+                  int ctop, double *cand, int *cnt, double *theta, double *slow, int *efin);
+int gmmk_topc_rank(hipStream_t st, int x_f64, const void *x, long n, long ldx, int D, int C, const double *cand, const int *cnt,
+                   const double *theta, const double *slow, const int *efin, const double *mean, const double *iv, const double *lwc,
+                   const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                   double *nw, double *llk, int *flag, long *redo, int stats);
+int gmmk_topc_scatter(hipStream_t st, long n, int ctop, const long *redo, const int *sidx, const double *slk, const double *snlk,
+                      const double *snllk, const double *snw, const double *sllk, int *idx, double *lk, double *nlk, double *nllk, double *nw,
+                      double *llk);
 int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp, const double *meanT,
                     const double *ivT, const double *lwc, const double *lse, double *gamma);
 int gmmk_stats_z_groups(int nct);

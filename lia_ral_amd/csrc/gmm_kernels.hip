@@ -13,6 +13,8 @@
 #include "devutil.h"
 #include "gmm_kernels.h"
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+
 // -------------------------------------------------------------------------------------------
 // Model packing
 // -------------------------------------------------------------------------------------------
@@ -95,13 +97,24 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // 1 / S_t (the sum is S_t 2^Efin) are written per frame at the end.  zbuf keeps the register layout
 // of the MFMA result = A-operand layout of the statistics MFMA: 2 KB blocks
 // [Gaussian tile ct][16-frame block fb][lane][4 rows], so both sides move 32 contiguous bytes per lane.
-template <int KS, typename XT, int NW, bool WZ>
+// MODE 2 (TC), the world pass of ComputeTest with the top-C' candidates collected IN the epilogue (no likelihood round trip
+// through HBM): every logit that reaches the frame's running threshold th is appended, as a 16-byte record (logit, Gaussian),
+// to the frame's candidate list cand[t][0..TOPC_CAP) through a per-frame LDS counter; th = the smallest of the 16 per-lane
+// running maxima of the frame's row (16 distinct Gaussians reach it, so the C' <= 16 largest logits of the frame all do), as a
+// float rounded DOWN, refreshed after every stage with four v_min_f32 DPP steps per row; it only ever rises, so every logit
+// >= the FINAL threshold is in the list.  The sum of the likelihoods that were NOT appended is kept like the log-sum-exp of the
+// other modes (sacc 2^E, all exponentials evaluated); k_topc_rank (topc_z.hip) finishes: filter by the final threshold,
+// direct-form logits of the survivors, ranking, remainder.  zbuf = the record array, eit = the per-frame candidate counts,
+// inv_out = the non-appended sums (2^-Efin), lse_out = the final thresholds.
+#define TOPC_CAP 256
+template <int KS, typename XT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ Pt, int nct,
                                                   double *__restrict__ lse_out, int use_glds, int dbg,
                                                   double *__restrict__ zbuf, long nfb, int *__restrict__ eit,
                                                   double *__restrict__ inv_out, int *__restrict__ efin_out)
 {
+    constexpr bool WZ = MODE == 1, TC = MODE == 2;
     // dbg (timing experiments only, results are wrong when != 0): 1 = no log-sum-exp epilogue,
     // 2 = additionally no per-tile staging / barrier, 3 = additionally B operands not re-read from LDS
     constexpr int NR = 2 * KS + 2;
@@ -112,13 +125,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     double *buf0 = (double *)smem;
     double *buf1 = buf0 + TILE_D;
     double *etab = buf1 + TILE_D; // exp table, GEXP_TAB_N entries
+    int *ccnt = (int *)(etab + GEXP_TAB_N); // TC: candidates appended per frame of the workgroup
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
     const long tb = (long)blockIdx.x * (NW * 32) + wave * 32;
     gexp_tab_init(etab, tid, NW * 64);
+    if (TC) ccnt[tid >> 1] = 0; // NW * 32 counters
 
-    double A[2][2 * KS];
+    // TC keeps only x in registers and squares it inside the MFMA phase (60 extra v_mul_f64 per stage, ~4 % of the MFMA time):
+    // its epilogue state (thresholds, lane maxima) does not fit next to 120 operand registers -- with them the compiler spilled
+    // 140 VGPRs and reloaded operands from scratch inside the MFMA loop (2x slower)
+    constexpr int NA = TC ? KS : 2 * KS;
+    double A[2][NA];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const long t = tb + h * 16 + i16;
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             double v = 0.0;
             if (t < T && k < D) v = feat_load<XT>::get(x, t * ldx + k);
             A[h][s] = v;
-            A[h][KS + s] = v * v;
+            if (!TC) A[h][NA - KS + s] = v * v;
         }
     }
 
@@ -173,8 +192,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     // in its MFMA phase while the other is in its VALU phase: VALU work of a different wave overlaps
     // the fp64 MFMA pipe partially (tools/mfma_probe), work of the same wave never does.
     const bool late = NW == 8 && ((wave >> 1) & 1);
+    // TC: threshold (row-uniform) and running maximum (per lane) of every frame row
+    float thf[2][4], lmaxf[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { thf[h][r] = -__builtin_inff(); lmaxf[h][r] = -__builtin_inff(); }
     d4 acc[GT][2];
     auto mfma_phase = [&](const double *cur) __attribute__((always_inline)) {
+    // TC: x^2 = fma(x, x, zv) with zv an OPAQUE zero redefined in every stage -- a plain x * x is loop invariant and gets hoisted
+    // out of the tile loop (60 more live registers: spills); an inline-asm multiply stays put but hides its VALU -> MFMA
+    // operand hazard from the compiler (wrong logits in the second half of the wave: the parity tests caught it)
+    double zv = 0.0;
+    if (TC) asm volatile("" : "+v"(zv));
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
         const double a = cur[(g * NR + 2 * KS) * 64 + lane];
@@ -185,10 +215,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     for (int s = 0; s < 2 * KS; ++s) {
         const double b0 = cur[(0 * NR + s) * 64 + lane];
         const double b1 = cur[(1 * NR + s) * 64 + lane];
-        acc[0][0] = MFMA_F64(A[0][s], b0, acc[0][0]);
-        acc[1][0] = MFMA_F64(A[0][s], b1, acc[1][0]);
-        acc[0][1] = MFMA_F64(A[1][s], b0, acc[0][1]);
-        acc[1][1] = MFMA_F64(A[1][s], b1, acc[1][1]);
+        double a0, a1;
+        if (TC && s >= KS) { a0 = __builtin_fma(A[0][s - KS], A[0][s - KS], zv); a1 = __builtin_fma(A[1][s - KS], A[1][s - KS], zv); }
+        else { a0 = A[0][s < NA ? s : 0]; a1 = A[1][s < NA ? s : 0]; }
+        acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
+        acc[1][0] = MFMA_F64(a0, b1, acc[1][0]);
+        acc[0][1] = MFMA_F64(a1, b0, acc[0][1]);
+        acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
     }
     };
     auto epi_phase = [&](int te) __attribute__((always_inline)) {
@@ -198,6 +231,106 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         // chain).  A pair whose n is 57 or more below the largest n seen in its row is skipped:
         // sacc * 2^E >= 2^nref already, so such a term (both of its terms together) is < 2^-54 of the sum -- skipping is bit-exact.
         // All branches are wave-uniform (ballots): every VALU instruction here is MFMA time.
+        if (TC) {
+            // refresh schedule (wave-uniform): every stage up to 8, every 2nd up to 16, every 4th up to 32, then every 8th, and the last
+            const bool refresh = te < 8 || (te < 16 && (te & 1) == 1) || (te < 32 && (te & 3) == 3) || (te & 7) == 7 || te == ntiles - 1;
+            const int kth = dbg > 0 ? dbg : 16;          // TC: the launcher passes ctop here
+            // one half (16 frames) at a time: the temporaries of 4 rows, not 8, are live
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int nm[4], k0[4], k1[4];
+                bool hit0[4], hit1[4];
+                bool grow = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lmaxf[h][r] = fmaxf(lmaxf[h][r], (float)fmax(acc[0][h][r], acc[1][h][r])); // rounding to nearest: the push-down covers it
+                // Threshold refresh (wave-uniform schedule above), BEFORE
+                // this stage's logits are tested: th = the ctop-th largest of the row's 16 lane maxima -- ctop distinct Gaussians
+                // reach it, so the ctop largest logits of the frame do -- pushed down by 2^-17 (relative): that covers the float
+                // roundings and leaves a gap of about 4e-6 |z| to the weakest of them, which k_topc_rank's margin check needs.
+                // Between refreshes the stale (lower) threshold only lets more candidates in.
+                if (refresh) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // Order-preserving integer keys (negative floats: magnitude bits flipped), made unique inside the row (low 4
+                        // bits <- lane, at most 15 ulps either way): selection by knock-out is exact and runs on v_min/max_i32 DPP.
+                        const int fb = __float_as_int(lmaxf[h][r]);
+                        int key = ((fb ^ ((fb >> 31) & 0x7fffffff)) & ~15) | i16;
+                        if (kth <= 8) { // the kth largest: knock out the maximum kth - 1 times
+                            for (int i = 1; i < kth; ++i) {
+                                const int mx = row_max_i32(key);
+                                key = key == mx ? (int)0x80000000 : key;
+                            }
+                            key = row_max_i32(key);
+                        } else {        // = the (17 - kth)-th smallest of the 16: knock out the minimum 16 - kth times
+                            for (int i = kth; i < 16; ++i) {
+                                const int mn = row_min_i32(key);
+                                key = key == mn ? 0x7fffffff : key;
+                            }
+                            key = row_min_i32(key);
+                        }
+                        const float f = __int_as_float(key ^ ((key >> 31) & 0x7fffffff));
+                        thf[h][r] = __builtin_fmaf(-__builtin_fabsf(f), 0x1p-17f, f); // 15 ulps of key + rounding, then the margin
+                    }
+                }
+                // hits of the four rows, ONE counter update per row (both tiles), all four in flight before the first is used
+                int slot[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double thd = (double)thf[h][r];
+                    hit0[r] = acc[0][h][r] >= thd;
+                    hit1[r] = acc[1][h][r] >= thd;
+                    slot[r] = 0;
+                    if (hit0[r] || hit1[r])
+                        slot[r] = __hip_atomic_fetch_add(ccnt + (wave * 32 + q) + (h * 16 + 4 * r), (hit0[r] ? 1 : 0) + (hit1[r] ? 1 : 0), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (hit0[r] || hit1[r]) { // append (logit, Gaussian) records to the frame's list
+                        double *rp = zbuf + 2 * ((size_t)(tb + q + h * 16 + 4 * r) * TOPC_CAP + slot[r]);
+                        if (hit0[r] && slot[r] < TOPC_CAP) {
+                            d2v rec; rec[0] = acc[0][h][r]; rec[1] = __longlong_as_double((long long)(32 * te + i16));
+                            *(d2v *)rp = rec;
+                        }
+                        const int s1 = slot[r] + (hit0[r] ? 1 : 0);
+                        if (hit1[r] && s1 < TOPC_CAP) {
+                            d2v rec; rec[0] = acc[1][h][r]; rec[1] = __longlong_as_double((long long)(32 * te + 16 + i16));
+                            *(d2v *)(rp + (hit0[r] ? 2 : 0)) = rec;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double r0, r1;
+                    gexp_tab_reduce(acc[0][h][r], k0[r], r0);
+                    gexp_tab_reduce(acc[1][h][r], k1[r], r1);
+                    acc[0][h][r] = r0;
+                    acc[1][h][r] = r1;
+                    const int km = k0[r] > k1[r] ? k0[r] : k1[r];
+                    nm[r] = row_max_i32(km >> GEXP_TAB_BITS);
+                    grow |= nm[r] - E[h][r] >= 64;
+                }
+                if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nm[r] - E[h][r] >= 64) {
+                            int sh = E[h][r] - nm[r];
+                            sh = sh < -2000 ? -2000 : sh;
+                            sacc[h][r] = __builtin_ldexp(sacc[h][r], sh);
+                            E[h][r] = nm[r];
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double e0 = gexp_tab_finish(k0[r], acc[0][h][r], E[h][r], etab);
+                    const double e1 = gexp_tab_finish(k1[r], acc[1][h][r], E[h][r], etab);
+                    sacc[h][r] += (hit0[r] ? 0.0 : e0) + (hit1[r] ? 0.0 : e1); // appended values leave the remainder
+                }
+            }
+            return;
+        }
         if (WZ) {
             // stored-likelihood variant: E is shared by the 16 lanes of a frame row (DPP row maximum
             // of the exponents), every pair's exponential is evaluated and kept
@@ -312,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     auto step = [&](int tl, bool staged, bool is_late, bool first) __attribute__((always_inline)) {
         double *cur = (tl & 1) ? buf1 : buf0;
         double *nxt = (tl & 1) ? buf0 : buf1;
-        if (staged && dbg < 2) stage(nxt, tl + 1);
+        if (staged && (TC || dbg < 2)) stage(nxt, tl + 1);
         if (!is_late) {
             mfma_phase(cur);
             epi_phase(tl);
@@ -355,11 +488,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) sv += shfl_xor_f64(sv, o);
             const long t = tb + h * 16 + q + 4 * r;
+            if (TC) {
+                if (i16 == 0 && t < T) { lse_out[t] = (double)thf[h][r]; inv_out[t] = sv; efin_out[t] = Em; }
+                continue;
+            }
             if (i16 == 0 && t < T) {
                 lse_out[t] = log(sv) + (double)Em * 0.693147180559945309417;
                 if (WZ) { inv_out[t] = 1.0 / sv; efin_out[t] = Em; }
             }
         }
+    if (TC) { // candidate counts of the workgroup's frames (each wave appended to its own 32 rows only)
+        __syncthreads();
+        const long t = (long)blockIdx.x * (NW * 32) + tid;
+        if (tid < NW * 32 && t < T) eit[t] = ccnt[tid];
+    }
 }
 
 // clamp + sums: out[t] = clamp(lse[t]); partial[b] = {sum clamped, sum raw}
@@ -886,23 +1028,23 @@ int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, con
     return (int)hipGetLastError();
 }
 
-template <int KS, typename XT, int NW, bool WZ>
+template <int KS, typename XT, int NW, int MODE>
 static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, const double *Pt, int nct,
                       double *lse, int use_glds, double *zbuf = nullptr, long nfb = 0, int *eit = nullptr, double *inv = nullptr,
                       int *efin = nullptr)
 {
     constexpr int NR = 2 * KS + 2;
-    const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + GEXP_TAB_N * sizeof(double); // two model stages + the exp table
+    const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + GEXP_TAB_N * sizeof(double) + (MODE == 2 ? NW * 32 * sizeof(int) : 0); // two model stages + the exp table (+ TC: candidate counters)
     static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
     int attr_dev = 0;
     if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
     std::atomic<bool> &attr_set = attr_done[attr_dev];
     if (!attr_set.load(std::memory_order_acquire)) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, WZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.store(true, std::memory_order_release);
     }
     const unsigned grid = (unsigned)((T + NW * 32 - 1) / (NW * 32));
-    k_llk_mfma<KS, XT, NW, WZ><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb, eit, inv, efin);
+    k_llk_mfma<KS, XT, NW, MODE><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb, eit, inv, efin);
     return (int)hipGetLastError();
 }
 
@@ -915,10 +1057,10 @@ int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx,
 #define CASE(K)                                                                                      \
     case K:                                                                                          \
         if (wg_waves == 8)                                                                           \
-            return x_f64 ? launch_llk<K, double, 8, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds) \
-                         : launch_llk<K, float, 8, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds); \
-        return x_f64 ? launch_llk<K, double, 4, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds)     \
-                     : launch_llk<K, float, 4, false>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
+            return x_f64 ? launch_llk<K, double, 8, 0>(st, x, T, ldx, D, Pt, nct, lse, use_glds) \
+                         : launch_llk<K, float, 8, 0>(st, x, T, ldx, D, Pt, nct, lse, use_glds); \
+        return x_f64 ? launch_llk<K, double, 4, 0>(st, x, T, ldx, D, Pt, nct, lse, use_glds)     \
+                     : launch_llk<K, float, 4, 0>(st, x, T, ldx, D, Pt, nct, lse, use_glds);
     switch (KS) {
         CASE(4) CASE(8) CASE(15) CASE(20)
     }
@@ -935,8 +1077,28 @@ int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ld
     if (T <= 0) return 0;
 #define CASE(K)                                                                                                              \
     case K:                                                                                                                  \
-        return x_f64 ? launch_llk<K, double, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin)   \
-                     : launch_llk<K, float, 8, true>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin);
+        return x_f64 ? launch_llk<K, double, 8, 1>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin)   \
+                     : launch_llk<K, float, 8, 1>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin);
+    switch (KS) {
+        CASE(4) CASE(8) CASE(15)
+    }
+#undef CASE
+    return -1;
+}
+
+// TC: the world pass of ComputeTest; cand = 2 * TOPC_CAP doubles per frame for ceil(T / 256) * 256 frames, cnt / theta / slow /
+// efin per frame (see k_llk_mfma, MODE 2).  Returns -1 when no instantiation serves KS.
+int gmmk_topc_cap(void) { return TOPC_CAP; }
+int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct, int use_glds,
+                  int ctop, double *cand, int *cnt, double *theta, double *slow, int *efin)
+{
+    if (T <= 0) return 0;
+    if (ctop < 1 || ctop > 16) return -1;
+    use_glds = (use_glds & 1) | (ctop << 8); // the kernel's dbg argument carries ctop in this mode
+#define CASE(K)                                                                                                                    \
+    case K:                                                                                                                        \
+        return x_f64 ? launch_llk<K, double, 8, 2>(st, x, T, ldx, D, Pt, nct, theta, use_glds, cand, 0, cnt, slow, efin)            \
+                     : launch_llk<K, float, 8, 2>(st, x, T, ldx, D, Pt, nct, theta, use_glds, cand, 0, cnt, slow, efin);
     switch (KS) {
         CASE(4) CASE(8) CASE(15)
     }

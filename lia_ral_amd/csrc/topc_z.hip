@@ -236,6 +236,240 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
     return (int)hipGetLastError();
 }
 
+// ---- ranking of the candidates collected by k_llk_mfma<TC> (gmm_kernels.hip, MODE 2) -----------------------------------------
+// One wave per frame.  The frame's list holds every Gaussian whose MFMA logit reached the running threshold of its time, in the
+// order the appends happened to win their LDS counter -- first of all it is put into a CANONICAL order (ascending Gaussian index,
+// through a bitmap of the indices in LDS), so that everything below, sums included, is bitwise reproducible.  Then, like
+// k_topc_from_z: the survivors of the FINAL threshold theta (a superset of the C' largest: at least 16 logits reach theta) get
+// their logit in the reference's direct form and are ranked on it (ties: lowest index); theta must lie 1e-6 below the weakest
+// selected logit or the call is redone by the direct-form kernel (flag).  Remainder = the likelihoods k_llk_mfma never appended
+// (slow 2^Efin) + the appended ones below theta (from their MFMA logits) + the rejected survivors (direct form).
+#define TOPC_CAP 256
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, long n, long ldx, int D, int C, const double *__restrict__ cand,
+                                                   const int *__restrict__ cnt, const double *__restrict__ theta,
+                                                   const double *__restrict__ slow, const int *__restrict__ efin,
+                                                   const double *__restrict__ mean, const double *__restrict__ iv,
+                                                   const double *__restrict__ lwc, const double *__restrict__ w, int ctop, int complete,
+                                                   double lo, double hi, int *__restrict__ idx_out, double *__restrict__ lk_out,
+                                                   double *__restrict__ nontop_lk, double *__restrict__ nontop_llk,
+                                                   double *__restrict__ nontop_w, double *__restrict__ llk_out, int *__restrict__ flag, long *__restrict__ redo,
+                                                   int stats)
+{
+    // flag[0] = number of frames handed to the direct-form kernel (their indices in redo[]); flag[1..4] = reasons (list overflow,
+    // more than 64 survivors, fewer than ctop, margin); with `stats` also flag[5] / [6,7] = max / sum of the list lengths and
+    // flag[8] / [10,11] of the survivor counts (global atomics from every wave: measurement runs only)
+    __shared__ double xs[4][64 + 1];
+    __shared__ unsigned bmap[4][64];      // Gaussians 32 l .. 32 l + 31 of the frame's list (C <= 2048)
+    __shared__ double sz[4][TOPC_CAP];    // logits in canonical order
+    __shared__ int si[4][TOPC_CAP];
+    __shared__ int ord[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long t = (long)blockIdx.x * 4 + wave;
+    const bool live = t < n;
+    for (int d = lane; d < D; d += 64) xs[wave][d] = live ? feat_load<XT>::get(x, t * ldx + d) : 0.0;
+    bmap[wave][lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!live) return;
+    const double NINF = -__builtin_inf();
+    const int ncr = cnt[t];
+    if (stats && lane == 0) { atomicMax(&flag[5], ncr); atomicAdd((unsigned long long *)&flag[6], (unsigned long long)ncr); }
+    if (ncr > TOPC_CAP) { if (lane == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[1], 1); } return; } // list overflow: the direct-form kernel redoes the frame
+    const int nc = ncr;
+    double zl[4];
+    int cl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        zl[j] = NINF; cl[j] = -1;
+        if (k < nc) {
+            const d2 rec = *(const d2 *)(cand + 2 * ((size_t)t * TOPC_CAP + k));
+            zl[j] = rec[0];
+            cl[j] = (int)__double_as_longlong(rec[1]);
+            atomicOr(&bmap[wave][(cl[j] >> 5) & 63], 1u << (cl[j] & 31));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // exclusive prefix of the word populations -> canonical position of every record
+    const unsigned myw = bmap[wave][lane];
+    int pre = __builtin_popcount(myw);
+    {
+        int inc = pre;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        pre = inc - pre;
+    }
+    ord[wave][lane] = pre; // reused as the prefix table until the survivors are compacted
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (cl[j] >= 0) {
+            const int wd = (cl[j] >> 5) & 63;
+            const int pos = ord[wave][wd] + __builtin_popcount(bmap[wave][wd] & ((1u << (cl[j] & 31)) - 1u));
+            sz[wave][pos] = zl[j];
+            si[wave][pos] = cl[j];
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double th = theta[t];
+    const int ef = efin[t];
+    const double lnE = (double)ef * 0.6931471805599453;
+    // canonical order from here on: lane l looks at records l, l + 64, ...; survivors (logit >= theta) are compacted in that order
+    int ns = 0;
+    double zrej[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        const double z = k < nc ? sz[wave][k] : NINF;
+        const bool hit = k < nc && z >= th;
+        zrej[j] = (k < nc && !hit) ? z : NINF;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) {
+            const int pos = ns + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (pos < 64) ord[wave][pos] = si[wave][k];
+        }
+        ns += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (stats && lane == 0) { atomicMax(&flag[8], ns); atomicAdd((unsigned long long *)&flag[10], (unsigned long long)ns); }
+    if (ns > 64 || ns < (ctop < C ? ctop : C)) { if (lane == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[ns > 64 ? 2 : 3], 1); } return; } // a pile-up of near-equal logits
+    const int ci = lane < ns ? ord[wave][lane] : 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    const bool cd = lane < ns && ci < C;
+    // The survivors' logits in the reference's direct form, FOUR lanes per survivor (16 survivors per pass): lane `sub` of a
+    // group takes the dimension pairs sub, sub + 4, ... of the survivor's own rows of the row-major model (16-byte loads), the
+    // group's partial sums meet through two quad exchanges.  (One lane per survivor left 3/4 of the wave idle behind 120 loads.)
+    for (int p0 = 0; p0 < ns; p0 += 16) {
+        const int cj = p0 + (lane >> 2), sub = lane & 3;
+        const int c = cj < ns ? ord[wave][cj] : 0x7fffffff;
+        double acc = 0.0;
+        if (c < C) {
+            const double *mu = mean + (size_t)c * D, *vi = iv + (size_t)c * D, *xr = xs[wave];
+            if ((D & 1) == 0) {
+                for (int pr = sub; pr < (D >> 1); pr += 4) {
+                    const d2 m2 = *(const d2 *)(mu + 2 * pr), v2 = *(const d2 *)(vi + 2 * pr);
+                    const double dx0 = xr[2 * pr] - m2[0], dx1 = xr[2 * pr + 1] - m2[1];
+                    acc = __builtin_fma(dx0 * dx0, v2[0], acc);
+                    acc = __builtin_fma(dx1 * dx1, v2[1], acc);
+                }
+            } else {
+                for (int d = sub; d < D; d += 4) {
+                    const double dx = xr[d] - mu[d];
+                    acc = __builtin_fma(dx * dx, vi[d], acc);
+                }
+            }
+        }
+        acc += shfl_xor_f64(acc, 1);
+        acc += shfl_xor_f64(acc, 2);
+        if (sub == 0 && cj < ns) sz[wave][cj] = c < C ? __builtin_fma(-0.5, acc, lwc[c]) : NINF; // sz is free again: reused for the exact logits
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double zc = cd ? sz[wave][lane] : NINF;
+    int rank = 0;
+    for (int jj = 0; jj < ns; ++jj) {
+        const double zj = readlane_f64u(zc, jj);
+        const int cj = __builtin_amdgcn_readlane(ci, jj);
+        if (jj != lane && (zj > zc || (zj == zc && cj < ci))) ++rank;
+    }
+    const bool sel = cd && rank < ctop;
+    const double M = wave_max_f64_dpp(zc);
+    const double zmin = wave_min_f64_dpp(sel ? zc : __builtin_inf());
+    // every Gaussian outside the survivors has an MFMA logit below theta: it must not be able to overtake the weakest selected
+    if (ns > ctop && th > zmin - 1e-6) { if (lane == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[4], 1); } return; } // uniform: th, zmin are wave-wide
+    // remainder relative to M: never-appended likelihoods + appended below theta + rejected survivors
+    double srel = 0.0;
+    {
+        const double sl = slow[t];
+        if (sl > 0.0) srel = exp(log(sl) + lnE - M);
+    }
+    double sr = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sr += zrej[j] > NINF ? gexp(zrej[j] - M) : 0.0;
+    srel += wave_sum_f64_dpp(sr);
+    srel += wave_sum_f64_dpp((cd && !sel) ? gexp(zc - M) : 0.0);
+    const double st = wave_sum_f64_dpp(sel ? gexp(zc - M) : 0.0);
+    if (sel) {
+        idx_out[t * ctop + rank] = ci;
+        if (lk_out) lk_out[t * ctop + rank] = exp(zc);
+        ord[wave][rank] = ci;
+    }
+    if (lane == 0) {
+        const double rest_llk = srel > 0.0 ? M + log(srel) : NINF;
+        if (nontop_llk) nontop_llk[t] = rest_llk;
+        if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+        if (llk_out) {
+            const double tot = complete ? st + srel : st;
+            llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+        }
+    }
+    if (nontop_w) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            double snsw = 1.0;
+            for (int k = 0; k < ctop; ++k) snsw -= w[ord[wave][k]];
+            nontop_w[t] = snsw;
+        }
+    }
+}
+
+// results of the frames redone by the direct-form kernel (rows i of the s* arrays) -> rows redo[i] of the caller's arrays
+__global__ void k_topc_scatter(long n, int ctop, const long *__restrict__ redo, const int *__restrict__ sidx, const double *__restrict__ slk,
+                               const double *__restrict__ snlk, const double *__restrict__ snllk, const double *__restrict__ snw,
+                               const double *__restrict__ sllk, int *__restrict__ idx, double *__restrict__ lk, double *__restrict__ nlk,
+                               double *__restrict__ nllk, double *__restrict__ nw, double *__restrict__ llk)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * ctop) return;
+    const long i = e / ctop, t = redo[i];
+    const int k = (int)(e - i * ctop);
+    idx[t * ctop + k] = sidx[e];
+    if (lk) lk[t * ctop + k] = slk[e];
+    if (k == 0) {
+        if (nlk) nlk[t] = snlk[i];
+        if (nllk) nllk[t] = snllk[i];
+        if (nw) nw[t] = snw[i];
+        if (llk) llk[t] = sllk[i];
+    }
+}
+int gmmk_topc_scatter(hipStream_t st, long n, int ctop, const long *redo, const int *sidx, const double *slk, const double *snlk,
+                      const double *snllk, const double *snw, const double *sllk, int *idx, double *lk, double *nlk, double *nllk, double *nw,
+                      double *llk)
+{
+    if (n <= 0) return 0;
+    k_topc_scatter<<<(unsigned)((n * ctop + 255) / 256), 256, 0, st>>>(n, ctop, redo, sidx, slk, snlk, snllk, snw, sllk, idx, lk, nlk, nllk, nw, llk);
+    return (int)hipGetLastError();
+}
+
+int gmmk_topc_rank(hipStream_t st, int x_f64, const void *x, long n, long ldx, int D, int C, const double *cand, const int *cnt,
+                   const double *theta, const double *slow, const int *efin, const double *mean, const double *iv, const double *lwc,
+                   const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                   double *nw, double *llk, int *flag, long *redo, int stats)
+{
+    if (n <= 0) return 0;
+    if (C > 2048 || D > 64 || ctop > 16) return -1; // the index bitmap / frame row / threshold rule of this path
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    if (x_f64)
+        k_topc_rank<double><<<grid, 256, 0, st>>>(x, n, ldx, D, C, cand, cnt, theta, slow, efin, mean, iv, lwc, w, ctop, complete, lo, hi, idx, lk,
+                                                  nlk, nllk, nw, llk, flag, redo, stats);
+    else
+        k_topc_rank<float><<<grid, 256, 0, st>>>(x, n, ldx, D, C, cand, cnt, theta, slow, efin, mean, iv, lwc, w, ctop, complete, lo, hi, idx, lk,
+                                                 nlk, nllk, nw, llk, flag, redo, stats);
+    return (int)hipGetLastError();
+}
+
 // USE_TOP_DISTRIBS (client models on the world's top-C' indices, TopGauss.cpp:224-316 / ComputeTest.cpp:170-207), 16 lanes per
 // frame: lane k of a frame's DPP row evaluates candidate k from the row-major model (16-byte loads, 8 dimensions in flight at
 // a time), the frame's log-sum is two DPP row reductions.  The first kernel gave a whole wave to one frame (10 busy lanes, one

@@ -432,3 +432,28 @@ def test_top_c_paths_agree(ctx, spread):
     fin = np.isfinite(res[0]["nontop_llk"])
     assert np.array_equal(fin, np.isfinite(res[1]["nontop_llk"]))
     assert np.max(np.abs(res[1]["nontop_llk"][fin] - res[0]["nontop_llk"][fin])) < 1e-8
+
+
+def test_fused_top_c_redoes_piled_up_frames_exactly(ctx):
+    """Fused selection (candidates collected in k_llk_mfma<TC>, ranked by k_topc_rank): a mixture with 100 identical Gaussians
+    makes more than 64 logits tie at the threshold -- those frames go through the direct-form kernel and still come back in the
+    reference's order (ties: lowest index first, TopGauss.cpp:167-193); separated frames stay on the fused path."""
+    C, D, T, ctop = 256, 60, 700, 10
+    w, mean, iv = make_gmm(C, D, seed=21)
+    mean[100:200] = mean[100]; iv[100:200] = iv[100]; w[100:200] = w[100]; w /= w.sum()
+    x = make_frames(w, mean, iv, T, seed=22)
+    g = ctx.gmm(w, mean, iv)
+    before = ctx.set_option("topc_fallbacks", 0)
+    d = g.llk_determine_top(x, ctop, True)
+    redone = ctx.set_option("topc_fallbacks", 0)
+    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x.astype(np.float64), ctop, True)
+    assert np.array_equal(d["idx"], do["idx"])
+    assert np.max(np.abs(d["llk"] - do["llk"])) < 1e-9 and relerr(d["lk"], do["lk"]) < 1e-10
+    assert 0 < redone < T            # the frames drawn from the duplicated Gaussians were redone, the others were not
+    # the three selection paths agree
+    for fused, z in ((0, 1), (0, 0)):
+        ctx.set_option("topc_fused", fused); ctx.set_option("topc_z", z)
+        e = g.llk_determine_top(x, ctop, True)
+        assert np.array_equal(e["idx"], d["idx"]) and np.max(np.abs(e["llk"] - d["llk"])) < 1e-9
+        assert np.max(np.abs(e["nontop_llk"] - d["nontop_llk"])) < 1e-9
+    ctx.set_option("topc_fused", 1); ctx.set_option("topc_z", 1)

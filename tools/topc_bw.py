@@ -12,6 +12,7 @@ dev = torch.device("cuda", 0)
 ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
 ctx.set_option("timing", 1)
 ctx.set_option("topc_z", int(os.environ.get("TOPC_Z", "1")))
+ctx.set_option("topc_fused", int(os.environ.get("TOPC_FUSED", "1")))
 C, D, T, ctop = 2048, 60, int(os.environ.get("T", "1000000")), 10
 w, mean, iv = make_gmm(C, D, seed=0, spread=2.0)
 x = synth_frames(w, mean, iv, T, dev, seed=5)
@@ -25,7 +26,8 @@ def tm(f, reps=3):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
 a = tm(lambda: g.llk(x, out=out))
 b = tm(lambda: _chk(lib.gmmiv_llk_determine_top(ctx._h, g._h, _ptr(x), capi.F32, ct.c_int64(T), ct.c_int64(D), ctop, capi.TOP_COMPLETE, ct.c_double(-200.0), ct.c_double(200.0), _ptr(idx), _ptr(lk), _ptr(nlk), _ptr(nllk), _ptr(nw), _ptr(out))))
-kk = {k: round(ctx.kernel_ms(k), 3) for k in ("k_llk_mfma", "k_topc_from_z", "k_topc_determine")}
+kk = {k: round(ctx.kernel_ms(k), 3) for k in ("k_llk_mfma", "k_topc_rank", "k_topc_from_z", "k_topc_determine")}
+kk["fallbacks"] = ctx.set_option("topc_fallbacks", 0)
 c = tm(lambda: _chk(lib.gmmiv_llk_use_top(ctx._h, g._h, _ptr(x), capi.F32, ct.c_int64(T), ct.c_int64(D), ctop, _ptr(idx), _ptr(nllk), capi.TOP_COMPLETE, ct.c_double(-200.0), ct.c_double(200.0), _ptr(out))))
 print(kk)
 print("T=%d: llk %.2f ms (%.1f Gpair/s) | determine_top %.2f ms (%.1f Gpair/s) | use_top %.3f ms (%.1f Mframe/s)" % (T, a, T * C / a / 1e6, b, T * C / b / 1e6, c, T / c / 1e3))
