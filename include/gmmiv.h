@@ -162,6 +162,13 @@ int gmmiv_variance_control(gmmiv_ctx *ctx, int C, int D, double *cov, double flo
  * N[u*C+c] = sum_t g_tc ; F[u*C*D + c*D + i] = sum_t g_tc x_ti   (rows are overwritten). */
 int gmmiv_tv_stats(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x_dtype, int64_t T,
                    int64_t ldx, const int64_t *utt_begin, int64_t U, double *N, double *F);
+/* The same with the reference's file -> ndx-line map (AccumulateTVStat.cpp:318-346, TVTranslate::locIndices): the frames of
+ * feature file f are x[file_begin[f] .. file_begin[f+1]); statistics row l (an ndx line) is the SUM over the files
+ * line_files[line_off[l] .. line_off[l+1]) -- a file listed on several lines is evaluated once and added to each of them
+ * (file_begin, line_off, line_files: HOST arrays; rows are overwritten). */
+int gmmiv_tv_stats_lines(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int x_dtype, int64_t T, int64_t ldx,
+                         const int64_t *file_begin, int64_t nfiles, int64_t nlines, const int64_t *line_off,
+                         const int64_t *line_files, double *N, double *F);
 
 /* ---- TVAcc i-vector maths (exact mode) -------------------------------------------------------
  * T: [R x C*D] row-major total-variability matrix; invvar: [C*D] UBM inverse variances.
@@ -289,6 +296,19 @@ int gmmiv_score_twocov(gmmiv_ctx *ctx, int dim, int64_t M, int64_t S, const doub
                        const double *segs, const double *G, const double *H, double *scores);
 int gmmiv_score_plda(gmmiv_ctx *ctx, int rf, int64_t M, int64_t S, const double *models_sum,
                      const int64_t *nsess, const double *segs, const double *FTJF, double *scores);
+/* PldaTest::twoCovScoringMixPart (:3923-3949, the L3 seam of twoCovScoring): scores[m][s] += (m + s)^T G (m + s) for every
+ * pair -- ACCUMULATES like the reference's `_scores(m,s) +=` (zero the array for the bare term). */
+int gmmiv_score_twocov_mix_part(gmmiv_ctx *ctx, int dim, int64_t M, int64_t S, const double *models, const double *segs,
+                                const double *G, double *scores);
+/* PldaTest::_trials (:3437, :3591-3620): cosineDistance / mahalanobisDistance score only the listed trials (:3871, :3889), the
+ * other cells keep _scores' initial 0.  All rules above fill the whole M x S block with one GEMM; this call then writes `fill`
+ * into every cell whose flag trials[m*S + s] is 0 (bytes, host or device). */
+int gmmiv_score_apply_trials(gmmiv_ctx *ctx, int64_t M, int64_t S, const unsigned char *trials, double fill, double *scores);
+/* Multi-GPU scoring: the M x S matrix tiles by blocks of MODELS, no collective -- rank g calls any rule above
+ * with the columns [m0, m1) of `models` (and the matching nsess / rows of scores); gmmiv_shard_range gives the contiguous range
+ * of rank `rank` out of `world` over n items (sizes differ by at most one), the same split as the reference's thread ranges
+ * (PldaTools.cpp:4175-4183 dispatch, AccumulateTVStat.cpp:498-507). */
+void gmmiv_shard_range(int64_t n, int rank, int world, int64_t *begin, int64_t *end);
 
 /* ---- JFA (LIA_SpkTools/src/AccumulateJFAStat.cpp): model M_{s,h} = m + V y_s + U x_h + D z_s ---------------------------
  * The factor steps are the total-variability entry points under the JFA names:

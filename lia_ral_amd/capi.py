@@ -368,6 +368,20 @@ class Context:
                                     _ptr(G), _ptr(H), _ptr(out)))
         return out
 
+    def score_twocov_mix_part(self, models, segs, G, scores):
+        """scores += (m + s)^T G (m + s) (PldaTest::twoCovScoringMixPart); scores is updated in place."""
+        M, S = models.shape[1], segs.shape[1]
+        _chk(lib.gmmiv_score_twocov_mix_part(self._h, models.shape[0], ct.c_int64(M), ct.c_int64(S), _ptr(models), _ptr(segs), _ptr(G),
+                                             _ptr(scores)))
+        return scores
+
+    def score_apply_trials(self, trials, scores, fill=0.0):
+        """scores[m, s] = fill where trials[m, s] == 0 (PldaTest::_trials); in place."""
+        M, S = scores.shape
+        t = trials if _is_torch(trials) else np.ascontiguousarray(trials, np.uint8)
+        _chk(lib.gmmiv_score_apply_trials(self._h, ct.c_int64(M), ct.c_int64(S), _ptr(t), ct.c_double(fill), _ptr(scores)))
+        return scores
+
     def score_plda(self, models_sum, nsess, segs, FTJF, out=None):
         M, S, out = self._score_out(models_sum, segs, out)
         ns = np.ascontiguousarray(nsess, dtype=np.int64)
@@ -443,6 +457,13 @@ class Comm:
         assert self._n(recv) == self.world * self._n(send)
         _chk(lib.gmmiv_allgather_f64(self._h, _ptr(send), _ptr(recv), ct.c_size_t(self._n(send))))
         return recv
+
+
+def shard_range(n, rank, world):
+    """gmmiv_shard_range: contiguous [begin, end) of rank's share of n items."""
+    b, e = ct.c_int64(), ct.c_int64()
+    lib.gmmiv_shard_range(ct.c_int64(n), int(rank), int(world), ct.byref(b), ct.byref(e))
+    return b.value, e.value
 
 
 class Gmm:
@@ -532,6 +553,20 @@ class Gmm:
         a = np.asarray(acc)
         return dict(occ=a[:C], sx=a[C:C + C * D].reshape(C, D), sxx=a[C + C * D:C + 2 * C * D].reshape(C, D),
                     llk=a[-2], count=a[-1])
+
+    def tv_stats_lines(self, x, file_begin, lines, N=None, F=None):
+        """Baum-Welch statistics per ndx LINE: lines = list of lists of file indices (a file may appear on several lines)."""
+        x, dt, T, ldx = _feat(x)
+        fb = np.ascontiguousarray(file_begin, dtype=np.int64)
+        off = np.zeros(len(lines) + 1, np.int64)
+        off[1:] = np.cumsum([len(l) for l in lines])
+        files = np.ascontiguousarray([f for l in lines for f in l], dtype=np.int64) if off[-1] else np.zeros(1, np.int64)
+        if N is None:
+            N = np.empty((len(lines), self.C)); F = np.empty((len(lines), self.C * self.D))
+        _chk(lib.gmmiv_tv_stats_lines(self.ctx._h, self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), fb.ctypes.data_as(ct.c_void_p),
+                                      ct.c_int64(len(fb) - 1), ct.c_int64(len(lines)), off.ctypes.data_as(ct.c_void_p),
+                                      files.ctypes.data_as(ct.c_void_p), _ptr(N), _ptr(F)))
+        return N, F
 
     def tv_stats(self, x, utt_begin, N=None, F=None):
         x, dt, T, ldx = _feat(x)

@@ -125,6 +125,16 @@ void gmmiv_comm_orphan(gmmiv_comm *c)
 
 extern "C" {
 
+void gmmiv_shard_range(int64_t n, int rank, int world, int64_t *begin, int64_t *end)
+{
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    const int64_t base = n / world, rem = n % world;
+    const int64_t b = rank * base + (rank < rem ? rank : rem);
+    if (begin) *begin = b;
+    if (end) *end = b + base + (rank < rem ? 1 : 0);
+}
+
 int gmmiv_comm_get_unique_id(void *id128)
 {
     if (!id128) { gmmiv_set_error("comm_get_unique_id: id == NULL"); return GMMIV_ERR_ARG; }

@@ -904,4 +904,43 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     return o_f.finish();
 }
 
+// TVAcc::computeAndAccumulateTVStat with the reference's file -> ndx-line map (AccumulateTVStat.cpp:318-346: the statistics of a
+// feature file are added to EVERY line `locidcs` that lists it, and a line sums all of its files): the Baum-Welch pass runs
+// ONCE per file, the line rows are sums of file rows.
+int gmmiv_tv_stats_lines(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, const int64_t *file_begin,
+                         int64_t nfiles, int64_t nlines, const int64_t *line_off, const int64_t *line_files, double *N, double *F)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (nfiles < 0 || nlines < 0 || !file_begin || !line_off || (!line_files && nlines && line_off[nlines]) || !N || !F) { gmmiv_set_error("tv_stats_lines: bad argument"); return GMMIV_ERR_ARG; }
+    if (gmmiv_is_device_ptr(line_off) || gmmiv_is_device_ptr(line_files)) { gmmiv_set_error("tv_stats_lines: the line map must be host arrays"); return GMMIV_ERR_ARG; }
+    if (nlines == 0) return GMMIV_OK;
+    if (line_off[0] != 0) { gmmiv_set_error("tv_stats_lines: line_off must start at 0"); return GMMIV_ERR_ARG; }
+    for (int64_t l = 0; l < nlines; ++l)
+        if (line_off[l + 1] < line_off[l]) { gmmiv_set_error("tv_stats_lines: line_off must be non-decreasing"); return GMMIV_ERR_ARG; }
+    const int64_t npairs = line_off[nlines];
+    for (int64_t p = 0; p < npairs; ++p)
+        if (line_files[p] < 0 || line_files[p] >= nfiles) { gmmiv_set_error("tv_stats_lines: file index %lld out of range", (long long)line_files[p]); return GMMIV_ERR_ARG; }
+    const size_t SV = (size_t)g->C * g->D;
+    void *pn, *pf, *pm;
+    if ((rc = c->scratch(WS_T6, (size_t)(nfiles ? nfiles : 1) * g->C * sizeof(double), &pn))) return rc;
+    if ((rc = c->scratch(WS_T7, (size_t)(nfiles ? nfiles : 1) * SV * sizeof(double), &pf))) return rc;
+    if ((rc = gmmiv_tv_stats(c, g, x, dt, T, ldx, file_begin, nfiles, (double *)pn, (double *)pf))) return rc;   // once per file, on the device
+    if ((rc = c->scratch(WS_T8, (size_t)(nlines + 1 + npairs + 1) * sizeof(long), &pm))) return rc;
+    std::vector<long> h((size_t)nlines + 1 + npairs);
+    for (int64_t l = 0; l <= nlines; ++l) h[l] = (long)line_off[l];
+    for (int64_t p = 0; p < npairs; ++p) h[nlines + 1 + p] = (long)line_files[p];
+    GCHK(hipMemcpyAsync(pm, h.data(), h.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    DevOut<double> o_n, o_f;
+    if ((rc = o_n.init(c, WS_T4, N, (size_t)nlines * g->C, false))) return rc;
+    if ((rc = o_f.init(c, WS_T5, F, (size_t)nlines * SV, false))) return rc;
+    const long *off = (const long *)pm, *rows = off + nlines + 1;
+    GCHK(tvk_merge_rows(c->stream, (long)nlines, g->C, off, rows, (const double *)pn, o_n.d));
+    GCHK(tvk_merge_rows(c->stream, (long)nlines, (long)SV, off, rows, (const double *)pf, o_f.d));
+    GCHK(hipStreamSynchronize(c->stream)); // h is a stack-lifetime vector
+    if ((rc = o_n.finish())) return rc;
+    return o_f.finish();
+}
+
+
 } // extern "C"

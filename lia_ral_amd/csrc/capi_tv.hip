@@ -777,12 +777,12 @@ struct ScoreArgs {
     DevIn<double> m, s;
     DevOut<double> sc;
     double *qm = nullptr, *qs = nullptr;
-    int init(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs, double *scores)
+    int init(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs, double *scores, bool load = false)
     {
         int rc;
         if ((rc = m.init(c, WS_T0, models, (size_t)dim * M))) return rc;
         if ((rc = s.init(c, WS_T1, segs, (size_t)dim * S))) return rc;
-        if ((rc = sc.init(c, WS_T2, scores, (size_t)M * S, false))) return rc;
+        if ((rc = sc.init(c, WS_T2, scores, (size_t)M * S, load))) return rc;
         void *p;
         if ((rc = c->scratch(WS_T3, (size_t)(M + S) * 8, &p))) return rc;
         qm = (double *)p;
@@ -818,7 +818,7 @@ int gmmiv_score_cosine(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double
 
 // scores = Mt (Q + Q^T) S * half_cross + bm * diag(Mt Qm M) + bs * diag(St Qs S)
 static int quad_score(gmmiv_ctx *c, ScoreArgs &a, int dim, int64_t M, int64_t S, const double *Qcross, double ccross,
-                      const double *Qm, double bm, const double *Qs, double bs, double cst)
+                      const double *Qm, double bm, const double *Qs, double bs, double cst, double beta = 0.0)
 {
     int rc;
     void *p;
@@ -836,7 +836,7 @@ static int quad_score(gmmiv_ctx *c, ScoreArgs &a, int dim, int64_t M, int64_t S,
     GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qsym, dim, 0, a.s.d, S, 0, 0.0, Y, S, 0, 1));
     c->t_begin("k_dgemm(score)");
     // ccross m^T Y s + bm q_m + bs q_s + cst in ONE pass over the M x S matrix (GEMM epilogue)
-    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, ccross, a.m.d, M, Y, S, a.sc.d, S, 2, a.qm, a.qs, bm, bs, cst));
+    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, ccross, a.m.d, M, Y, S, a.sc.d, S, 2, a.qm, a.qs, bm, bs, cst, beta));
     c->t_end();
     return GMMIV_OK;
 }
@@ -876,6 +876,39 @@ int gmmiv_score_twocov(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double
     GCHK(tvk_axpby(c->stream, (long)nn, 1.0, g.d, -1.0, h.d, GmH));
     if ((rc = quad_score(c, a, dim, M, S, g.d, 1.0, GmH, 1.0, GmH, 1.0, 0.0))) return rc;
     return a.sc.finish();
+}
+
+// PldaTest::twoCovScoringMixPart (PldaTools.cpp:3923-3949): scores[m][s] += (m + s)^T G (m + s) for every pair (ACCUMULATES,
+// like the reference's `_scores(m,s) +=`): m'Gm + s'Gs + m'(G + G')s with the model / segment terms in the GEMM epilogue.
+int gmmiv_score_twocov_mix_part(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs, const double *G,
+                                double *scores)
+{
+    int rc = score_check(c, dim, M, S, models, segs, scores, "score_twocov_mix_part");
+    if (rc) return rc;
+    if (!G) { gmmiv_set_error("score_twocov_mix_part: G == NULL"); return GMMIV_ERR_ARG; }
+    if (M == 0 || S == 0) return GMMIV_OK;
+    ScoreArgs a;
+    if ((rc = a.init(c, dim, M, S, models, segs, scores, true))) return rc;
+    DevIn<double> g;
+    if ((rc = g.init(c, WS_T6, G, (size_t)dim * dim))) return rc;
+    if ((rc = quad_score(c, a, dim, M, S, g.d, 1.0, g.d, 1.0, g.d, 1.0, 0.0, 1.0))) return rc;
+    return a.sc.finish();
+}
+
+// PldaTest::_trials (PldaTools.cpp:3437, 3591-3620): cosineDistance / mahalanobisDistance only score the listed trials
+// (:3871, :3889), the others keep the initial value of _scores (0).  The device computes the whole M x S block in one GEMM;
+// this entry point then writes `fill` into every cell whose trial flag is 0.  trials: [M x S] bytes, host or device.
+int gmmiv_score_apply_trials(gmmiv_ctx *c, int64_t M, int64_t S, const unsigned char *trials, double fill, double *scores)
+{
+    if (!c || M < 0 || S < 0 || !trials || !scores) { gmmiv_set_error("score_apply_trials: bad argument"); return GMMIV_ERR_ARG; }
+    if (M == 0 || S == 0) return GMMIV_OK;
+    GCHK(hipSetDevice(c->device));
+    DevIn<unsigned char> t;
+    DevOut<double> o;
+    int rc;
+    if ((rc = t.init(c, WS_T0, trials, (size_t)M * S)) || (rc = o.init(c, WS_T2, scores, (size_t)M * S, true))) return rc;
+    GCHK(tvk_mask_trials(c->stream, (long)(M * S), t.d, fill, o.d));
+    return o.finish();
 }
 
 // ---- PldaDev: development-set statistics ---------------------------------------------------------

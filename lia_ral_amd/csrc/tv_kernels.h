@@ -20,6 +20,7 @@ int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double
 int tvk_scale_cols(hipStream_t st, long rows, long cols, const double *in, const double *scale, double *out);
 int tvk_unpack_sym(hipStream_t st, int n, int nb, const double *packed, long sp, double *full, double diag_add);
 int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, const double *w, double *packed, long sp);
+int tvk_merge_rows(hipStream_t st, long ndst, long width, const long *off, const long *rows, const double *src, double *dst);
 int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst);
 int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full);
 int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y);
@@ -54,7 +55,8 @@ int tvk_jfa_sub_sessions(hipStream_t st, long s0, long ns, long h0, long h1, int
 int tvk_jfa_z(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, const double *Dm, double tau, double *Z);
 int tvk_jfa_z_and_d(hipStream_t st, long nspk, int C, int D, const double *N, const double *F, const double *iv, double *Dm, double *Z);
 int tvk_dgemm_epi(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, const double *B,
-                  long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst);
+                  long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst, double beta = 0.0);
+int tvk_mask_trials(hipStream_t st, long n, const unsigned char *trials, double fill, double *scores);
 int tvk_rsqrt_vec(hipStream_t st, long n, double *v);
 int tvk_inverse_e_packed_batched(hipStream_t st, int n, int nb, double *Lf, double *U, double *invd, int *status, double *P, long sp,
                                  double diag_add, const double *aux, double *W);

@@ -330,11 +330,25 @@ int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alph
 }
 // C = epilogue(alpha op(A) op(B)): mode 1 -> x rv[m] cv[n]; mode 2 -> + br rv[m] + bc cv[n] + cst   (single matrix)
 int tvk_dgemm_epi(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, const double *B,
-                  long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst)
+                  long ldb, double *C, long ldc, int mode, const double *rv, const double *cv, double br, double bc, double cst, double beta)
 {
     if (M <= 0 || N <= 0) return 0;
     dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
-    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, C, ldc, 0, 0, DgemmEpi{rv, cv, br, bc, cst, mode, 0});
+    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 0, DgemmEpi{rv, cv, br, bc, cst, mode, 0});
+    return (int)hipGetLastError();
+}
+
+// scores[m][s] = fill wherever trials[m][s] == 0 (PldaTest::_trials: only the listed trials are scored, PldaTools.cpp:3871, 3889)
+__global__ void k_mask_trials(long n, const unsigned char *__restrict__ trials, double fill, double *__restrict__ scores)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        if (!trials[e]) scores[e] = fill;
+}
+int tvk_mask_trials(hipStream_t st, long n, const unsigned char *trials, double fill, double *scores)
+{
+    if (n <= 0) return 0;
+    const long nb = (n + 255) / 256;
+    k_mask_trials<<<(unsigned)(nb > 65536 ? 65536 : nb), 256, 0, st>>>(n, trials, fill, scores);
     return (int)hipGetLastError();
 }
 
@@ -998,6 +1012,28 @@ int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, con
     if (nb <= 0) return 0;
     dim3 g((n * n + 255) / 256 > 512 ? 512 : (n * n + 255) / 256, nb);
     k_pack_sym<<<g, 256, 0, st>>>(n, full, sf, w, packed, sp);
+    return (int)hipGetLastError();
+}
+// dst[d][j] = sum over p in [off[d], off[d + 1]) of src[rows[p]][j]   (statistics rows of ndx lines = sums of their files' rows;
+// fixed order: deterministic)
+__global__ void k_merge_rows(long ndst, long width, const long *__restrict__ off, const long *__restrict__ rows,
+                             const double *__restrict__ src, double *__restrict__ dst)
+{
+    const long d = blockIdx.y;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < width; j += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (long p = off[d]; p < off[d + 1]; ++p) s += src[rows[p] * width + j];
+        dst[d * width + j] = s;
+    }
+}
+int tvk_merge_rows(hipStream_t st, long ndst, long width, const long *off, const long *rows, const double *src, double *dst)
+{
+    if (ndst <= 0 || width <= 0) return 0;
+    const long bx = (width + 255) / 256;
+    for (long d0 = 0; d0 < ndst; d0 += 65535) {
+        const long nd = ndst - d0 < 65535 ? ndst - d0 : 65535;
+        k_merge_rows<<<dim3((unsigned)(bx > 64 ? 64 : bx), (unsigned)nd), 256, 0, st>>>(nd, width, off + d0, rows, src, dst + d0 * width);
+    }
     return (int)hipGetLastError();
 }
 int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst)

@@ -167,6 +167,22 @@ def em_iteration(accumulate, n_frames, acc, rank=0, world=1, coll=None):
     return all_reduce_sum(acc, coll)
 
 
+# ---------------------------------------------------------------------------------------- i-vector scoring
+def score_model_block(score, models, segs, rank=0, world=1, nsess=None):
+    """IvTest scoring on several GPUs: the M x S score matrix tiles by blocks of MODELS, models / segments are
+    replicated (2 x 320 MB at 100 k x 400), there is no collective -- rank g scores the model columns [m0, m1) =
+    shard_range(M, g, world) against every segment and keeps / writes its own rows, like the reference's worker threads take
+    ranges of models (PldaTools.cpp:4175-4183 -> pldaScoringThreaded, :3912-3920).  `score(models_block, segs[, nsess_block])`
+    is any gmmiv_score_* rule bound to a context.  Returns (m0, m1, scores[m1 - m0, S])."""
+    M = models.shape[1]
+    m0, m1 = shard_range(M, rank, world)
+    blk = models[:, m0:m1]
+    blk = np.ascontiguousarray(blk) if isinstance(blk, np.ndarray) else blk.contiguous()
+    if nsess is not None:
+        return m0, m1, score(blk, segs, nsess[m0:m1])
+    return m0, m1, score(blk, segs)
+
+
 # ---------------------------------------------------------------------------------------- T-matrix EM
 def tv_estep(estimate, n_utt, acc, rank=0, world=1, coll=None):
     """One distributed E-step of the T-matrix EM (TVAcc::estimateAandC, AccumulateTVStat.cpp:1702-1795), all-reduce form:

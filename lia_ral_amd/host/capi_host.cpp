@@ -1,6 +1,7 @@
 // capi_host.cpp -- flat C entry points over liatools_gpu (used by the Python tests / tools; a C++
 // caller includes liatools_gpu.h directly).  Every function returns 0 or -1 (+ liagpu_last_error()),
 // mirroring the reference tools' "catch, print, carry on" drivers.
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -318,6 +319,39 @@ int liagpu_tv_train(int device, long U, int C, int D, const double *w, const dou
     })
 }
 
+// TVAcc::initT ("normal" law) for a UBM with the given inverse variances: seeds glibc with `seed` first (the reference never calls
+// srand, i.e. seed 1) and fills Tmat [R x C*D]
+int liagpu_tv_init_t(int device, int C, int D, const double *w, const double *mean, const double *cov, int R, unsigned seed, double *Tmat)
+{
+    GUARD({
+        GpuServer srv(device);
+        TVAcc tv(srv, make_mixture(C, D, w, mean, cov), (unsigned long)R, 1);
+        srand(seed);
+        tv.initT("normal");
+        memcpy(Tmat, tv.getT().data(), (size_t)R * C * D * sizeof(double));
+    })
+}
+
+// computeAndAccumulateTVStat with the file -> ndx-line map: file f = frames [file_begin[f], file_begin[f+1]) of x, line l lists the
+// files line_files[line_off[l] .. line_off[l+1]); N [nlines x C], F [nlines x C*D]
+int liagpu_tv_stats_lines(int device, const float *x, long T, int D, const long *file_begin, long nfiles, long nlines, const long *line_off,
+                          const long *line_files, int C, const double *w, const double *mean, const double *cov, double *N, double *F)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        TVAcc tv(srv, make_mixture(C, D, w, mean, cov), 1, (unsigned long)nlines);
+        std::vector<SegCluster> segs(nfiles);
+        for (long f = 0; f < nfiles; ++f) { Seg s; s.begin = (unsigned long)file_begin[f]; s.length = (unsigned long)(file_begin[f + 1] - file_begin[f]); segs[f].push_back(s); }
+        std::vector<std::vector<unsigned long> > lines(nlines);
+        for (long l = 0; l < nlines; ++l)
+            for (long p = line_off[l]; p < line_off[l + 1]; ++p) lines[l].push_back((unsigned long)line_files[p]);
+        tv.computeAndAccumulateTVStat(fs, segs, lines);
+        memcpy(N, tv.getN().data(), tv.getN().size() * sizeof(double));
+        memcpy(F, tv.getF().data(), tv.getF().size() * sizeof(double));
+    })
+}
+
 // One rank of a multi-GPU TotalVariability run (configs[3]: utterances sharded over the GPUs of a node, one process -- or host
 // thread -- per GPU).  N, F: the statistics of THIS rank's U utterances; Tmat: the same initial matrix on every rank.  The
 // ranks meet through `id_file` (rank 0 publishes the RCCL id there, gmmiv_comm_exchange_id_file); per iteration the only
@@ -502,6 +536,44 @@ int liagpu_compute_test_files(int device, const char *world_path, int nClients, 
                                    frameIdxToTime(segs[s].begin, frameLength), frameIdxToTime(segs[s].begin + segs[s].length, frameLength)) + "\n";
         if ((long)text.size() + 1 > out_cap) throw Exception("out_text too small");
         memcpy(out_text, text.c_str(), text.size() + 1);
+    })
+}
+
+// XML mixture round trip + DB / DT matrices + per-id vector files (CPU tests; no GPU involved).
+// xml_in -> xml_out (re-written) and raw_out (the same model as a RAW file); dims = {C, D}; first = {weight 0, covInv(0,0), mean(0,0)}
+int liagpu_io_xml(const char *xml_in, const char *xml_out, const char *raw_out, long *dims, double *first)
+{
+    GUARD({
+        MixtureGD m = readMixture(xml_in);
+        dims[0] = (long)m.getDistribCount(); dims[1] = (long)m.getVectSize();
+        first[0] = m.weight(0); first[1] = m.getCovInv(0, 0); first[2] = m.getMean(0, 0);
+        writeMixtureXML(xml_out, m);
+        if (raw_out && *raw_out) {
+            writeMixtureRAW(raw_out, m);
+            MixtureGD r = readMixture(raw_out);        // sniffed as RAW
+            if (r.getDistribCount() != m.getDistribCount() || r.getMean(0, 0) != m.getMean(0, 0)) throw Exception("RAW re-read differs");
+        }
+    })
+}
+// matrix file -> matrix file in another format; dims = {rows, cols}
+int liagpu_io_matrix_convert(const char *in, const char *fmt_in, const char *out, const char *fmt_out, long *dims)
+{
+    GUARD({
+        const MatrixD m = readMatrix(in, fmt_in);
+        dims[0] = (long)m.rows; dims[1] = (long)m.cols;
+        writeMatrix(out, m, fmt_out);
+    })
+}
+// W [n x rank] -> one vector file per id under dir (saveWbyFile), read back as columns (PldaTest::load): back [rank x n]
+int liagpu_io_vectors(const char *dir, int n, const char **ids, const char *ext, const char *fmt, int rank, const double *W, double *back)
+{
+    GUARD({
+        std::vector<std::string> v(ids, ids + n);
+        saveVectorsById(std::string(dir) + "/", v, ext, std::vector<double>(W, W + (size_t)n * rank), (unsigned long)rank, fmt);
+        unsigned long dim = 0;
+        const std::vector<double> cols = loadVectorsById(dir, v, ext, dim, fmt);
+        if (dim != (unsigned long)rank) throw Exception("vector files: dimension changed on the way");
+        memcpy(back, cols.data(), cols.size() * sizeof(double));
     })
 }
 

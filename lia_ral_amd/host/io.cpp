@@ -138,6 +138,154 @@ void writeMixtureRAW(const std::string &path, const MixtureGD &m)
     }
 }
 
+// ---- XML mixtures ---------------------------------------------------------------------------------------------------------
+namespace {
+// value of attribute `name` inside the tag text [b, e)
+std::string xmlAttr(const std::string &t, size_t b, size_t e, const char *name, const std::string &path)
+{
+    const std::string key = std::string(name) + "=\"";
+    const size_t p = t.find(key, b);
+    if (p == std::string::npos || p >= e) throw Exception("XML mixture [" + path + "]: attribute " + name + " missing");
+    const size_t q = t.find('"', p + key.size());
+    if (q == std::string::npos || q > e) throw Exception("XML mixture [" + path + "]: unterminated attribute " + name);
+    return t.substr(p + key.size(), q - p - key.size());
+}
+} // namespace
+
+MixtureGD readMixtureXML(const std::string &path)
+{
+    const std::vector<unsigned char> raw = slurp(path);
+    const std::string t(raw.begin(), raw.end());
+    size_t pos = t.find("<MixtureGD");
+    if (pos == std::string::npos) throw Exception("XML mixture [" + path + "]: no <MixtureGD> element");
+    size_t end = t.find('>', pos);
+    if (end == std::string::npos) throw Exception("XML mixture [" + path + "]: truncated header");
+    const unsigned long C = strtoul(xmlAttr(t, pos, end, "distribCount", path).c_str(), nullptr, 10);
+    const unsigned long D = strtoul(xmlAttr(t, pos, end, "vectSize", path).c_str(), nullptr, 10);
+    if (!C || !D) throw Exception("XML mixture [" + path + "]: distribCount / vectSize must be positive");
+    MixtureGD m(C, D);
+    pos = end;
+    for (unsigned long c = 0; c < C; ++c) {
+        pos = t.find("<DistribGD", pos);
+        if (pos == std::string::npos) throw Exception("XML mixture [" + path + "]: fewer <DistribGD> elements than distribCount");
+        end = t.find('>', pos);
+        if (strtoul(xmlAttr(t, pos, end, "i", path).c_str(), nullptr, 10) != c) throw Exception("XML mixture [" + path + "]: distributions out of order");
+        m.weight(c) = strtod(xmlAttr(t, pos, end, "weight", path).c_str(), nullptr);
+        const size_t close = t.find("</DistribGD>", end);
+        if (close == std::string::npos) throw Exception("XML mixture [" + path + "]: unterminated <DistribGD>");
+        for (int what = 0; what < 2; ++what) {
+            const std::string tag = what == 0 ? "<covInv i=\"" : "<mean i=\"";
+            size_t p = end;
+            for (unsigned long d = 0; d < D; ++d) {
+                p = t.find(tag, p);
+                if (p == std::string::npos || p > close) throw Exception("XML mixture [" + path + "]: a distribution has fewer than vectSize entries");
+                const unsigned long idx = strtoul(t.c_str() + p + tag.size(), nullptr, 10);
+                const size_t v = t.find('>', p);
+                if (idx >= D || v == std::string::npos) throw Exception("XML mixture [" + path + "]: bad entry index");
+                const double val = strtod(t.c_str() + v + 1, nullptr);
+                if (what == 0) m.setCovInv(c, val, idx); else m.setMean(c, val, idx);
+                p = v;
+            }
+        }
+        pos = close;
+    }
+    return m; // no computeAll(): the covInv bits of the file are kept
+}
+
+void writeMixtureXML(const std::string &path, const MixtureGD &m, const std::string &id)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) throw Exception("cannot write [" + path + "]");
+    const unsigned long C = m.getDistribCount(), D = m.getVectSize();
+    fprintf(f, "<MixtureGD version=\"1\" id=\"%s\" distribCount=\"%lu\" vectSize=\"%lu\">\n", id.c_str(), C, D);
+    for (unsigned long c = 0; c < C; ++c) {
+        double det = 1.0;
+        for (unsigned long d = 0; d < D; ++d) det *= m.getCov(c, d);
+        const double cst = pow(2.0 * M_PI, -0.5 * D) / sqrt(det); // DistribGD::computeAll
+        fprintf(f, "\t<DistribGD i=\"%lu\" weight=\"%.19g\" cst=\"%.19g\" det=\"%.19g\">\n", c, m.weight(c), cst, det);
+        for (unsigned long d = 0; d < D; ++d) fprintf(f, "\t\t<covInv i=\"%lu\">%.19g</covInv>\n", d, m.getCovInv(c, d));
+        for (unsigned long d = 0; d < D; ++d) fprintf(f, "\t\t<mean i=\"%lu\">%.19g</mean>\n", d, m.getMean(c, d));
+        fprintf(f, "\t</DistribGD>\n");
+    }
+    fprintf(f, "</MixtureGD>\n");
+    fclose(f);
+}
+
+MixtureGD readMixture(const std::string &path)
+{
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f) throw Exception("cannot open [" + path + "]");
+    char c = 0;
+    while (f.get(c) && (c == ' ' || c == '\n' || c == '\r' || c == '\t')) {}
+    return c == '<' ? readMixtureXML(path) : readMixtureRAW(path);
+}
+
+// ---- DB matrices and per-id vector files ------------------------------------------------------------------------------------
+MatrixD readMatrixDB(const std::string &path)
+{
+    const std::vector<unsigned char> b = slurp(path);
+    if (b.size() < 8) throw Exception("DB matrix too short [" + path + "]");
+    uint32_t r, c;
+    memcpy(&r, b.data(), 4);
+    memcpy(&c, b.data() + 4, 4);
+    if (b.size() != 8 + 8 * (size_t)r * c) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "DB matrix [%s]: %zu bytes, expected %zu for %u x %u", path.c_str(), b.size(), 8 + 8 * (size_t)r * c, r, c);
+        throw Exception(msg);
+    }
+    MatrixD m;
+    m.rows = r; m.cols = c;
+    m.v.resize((size_t)r * c);
+    if (!m.v.empty()) memcpy(m.v.data(), b.data() + 8, 8 * m.v.size());
+    return m;
+}
+void writeMatrixDB(const std::string &path, const MatrixD &m)
+{
+    std::ofstream o(path.c_str(), std::ios::binary);
+    if (!o) throw Exception("cannot write [" + path + "]");
+    const uint32_t r = (uint32_t)m.rows, c = (uint32_t)m.cols;
+    o.write((const char *)&r, 4);
+    o.write((const char *)&c, 4);
+    if (!m.v.empty()) o.write((const char *)m.v.data(), 8 * m.v.size());
+}
+MatrixD readMatrix(const std::string &path, const std::string &format)
+{
+    if (format == "DT") return readMatrixDT(path);
+    if (format == "DB") return readMatrixDB(path);
+    throw Exception("unknown matrix format [" + format + "]");
+}
+void writeMatrix(const std::string &path, const MatrixD &m, const std::string &format)
+{
+    if (format == "DT") writeMatrixDT(path, m);
+    else if (format == "DB") writeMatrixDB(path, m);
+    else throw Exception("unknown matrix format [" + format + "]");
+}
+
+void saveVectorsById(const std::string &dir, const std::vector<std::string> &ids, const std::string &ext, const std::vector<double> &W,
+                     unsigned long rank, const std::string &format)
+{
+    if (W.size() != ids.size() * rank) throw Exception("saveVectorsById: W must hold one row of `rank` values per id");
+    for (size_t s = 0; s < ids.size(); ++s) { // one 1 x rank matrix per id, in list order (saveWbyFile: session++)
+        MatrixD y;
+        y.rows = 1; y.cols = rank;
+        y.v.assign(W.begin() + s * rank, W.begin() + (s + 1) * rank);
+        writeMatrix(dir + ids[s] + ext, y, format);
+    }
+}
+std::vector<double> loadVectorsById(const std::string &dir, const std::vector<std::string> &ids, const std::string &ext, unsigned long &dim,
+                                    const std::string &format)
+{
+    dim = 0;
+    std::vector<double> out;
+    for (size_t k = 0; k < ids.size(); ++k) {
+        const MatrixD v = readMatrix(dir + "/" + ids[k] + ext, format);
+        if (k == 0) { dim = v.cols; out.assign((size_t)dim * ids.size(), 0.0); } // _vectSize = tmpVect.cols() of the first file
+        if (v.rows < 1 || v.cols != dim) throw Exception("vector file [" + ids[k] + ext + "]: expected 1 x " + std::to_string(dim));
+        for (unsigned long i = 0; i < dim; ++i) out[i * ids.size() + k] = v.v[i]; // _models(k, m) = tmpVect(0, k)
+    }
+    return out;
+}
+
 MatrixD readMatrixDT(const std::string &path)
 {
     std::ifstream f(path.c_str());

@@ -35,10 +35,32 @@ SegCluster selectSegments(const std::vector<LabelSeg> &lab, const std::string &l
 
 MixtureGD readMixtureRAW(const std::string &path);
 void writeMixtureRAW(const std::string &path, const MixtureGD &m);
+// XML mixture files (saveMixtureFileFormat XML; fixture LIA_SpkDet/TrainWorld/test/wld.validate):
+//   <MixtureGD version="1" id="#1" distribCount="C" vectSize="D"> / <DistribGD i weight cst det> / <covInv i>v</covInv> ... <mean i>v</mean>
+// numbers carry 19 significant digits (%.19g).  weight / covInv / mean round-trip bit for bit; cst / det are recomputed from the
+// covariances like DistribGD::computeAll does and agree with the file to rounding.
+MixtureGD readMixtureXML(const std::string &path);
+void writeMixtureXML(const std::string &path, const MixtureGD &m, const std::string &id = "#1");
+MixtureGD readMixture(const std::string &path); // XML when the file starts with '<', else RAW
 
 struct MatrixD { unsigned long rows = 0, cols = 0; std::vector<double> v; };
 MatrixD readMatrixDT(const std::string &path);
 void writeMatrixDT(const std::string &path, const MatrixD &m);
+// DB matrices (saveMatrixFormat DB, the binary twin of DT written by alize-core's Matrix<double>::save): u32 rows, u32 cols, then
+// rows * cols float64, little-endian.  alize-core is not part of the LIA_RAL tree and no DB file ships with it, so this layout is
+// the survey's reading of ALIZE and is NOT pinned by a reference file; DT is (ComputeTest/test/zero.mat).
+MatrixD readMatrixDB(const std::string &path);
+void writeMatrixDB(const std::string &path, const MatrixD &m);
+MatrixD readMatrix(const std::string &path, const std::string &format);   // "DT" | "DB" (loadMatrixFormat)
+void writeMatrix(const std::string &path, const MatrixD &m, const std::string &format);
+// Per-id vector files: TVAcc::saveWbyFile (AccumulateTVStat.cpp:2799-2822) writes row `session` of W as a 1 x rankT matrix to
+// <saveVectorFilesPath><id><vectorFilesExtension>; PldaTest::load (PldaTools.cpp:3552-3588) reads <testVectorFilesPath>/<id><ext>
+// back as column k of _models / _segments.
+void saveVectorsById(const std::string &dir, const std::vector<std::string> &ids, const std::string &ext, const std::vector<double> &W,
+                     unsigned long rank, const std::string &format = "DB");
+// -> [dim x ids.size()] one vector per COLUMN (the layout of PldaTest::_models / _segments); dim from the first file
+std::vector<double> loadVectorsById(const std::string &dir, const std::vector<std::string> &ids, const std::string &ext, unsigned long &dim,
+                                    const std::string &format = "DB");
 
 // gender, client id, decision ('1'/'0' by threshold), test file, [start end,] score
 std::string resultLine(double llr, const std::string &clientName, const std::string &testName, const std::string &gender,

@@ -3,6 +3,7 @@
 #include "liatools_gpu.h"
 
 #include <algorithm>
+#include <cmath>
 
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -731,6 +732,56 @@ void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegC
     const float *x = fs.select(all, n);
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), uttBegin.data(),
                               (int64_t)_n_speakers, _statN.dev(), _statF.dev()));
+}
+
+void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerFile,
+                                       const std::vector<std::vector<unsigned long> > &filesOfLine)
+{
+    if (filesOfLine.size() != _n_speakers) throw Exception("computeAndAccumulateTVStat: one file list per ndx line expected");
+    SegCluster all;
+    std::vector<int64_t> fileBegin(segsPerFile.size() + 1, 0), lineOff(_n_speakers + 1, 0), lineFiles;
+    for (size_t f = 0; f < segsPerFile.size(); ++f) {
+        for (const Seg &s : segsPerFile[f]) all.push_back(s);
+        fileBegin[f + 1] = fileBegin[f] + (int64_t)totalFrame(segsPerFile[f]);
+    }
+    for (unsigned long l = 0; l < _n_speakers; ++l) {
+        for (unsigned long f : filesOfLine[l]) {
+            if (f >= segsPerFile.size()) throw Exception("computeAndAccumulateTVStat: file index out of range");
+            lineFiles.push_back((int64_t)f);
+        }
+        lineOff[l + 1] = (int64_t)lineFiles.size();
+    }
+    if (lineFiles.empty()) lineFiles.push_back(0);
+    unsigned long n = 0;
+    const float *x = fs.select(all, n);
+    _srv.check(gmmiv_tv_stats_lines(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), fileBegin.data(),
+                                    (int64_t)segsPerFile.size(), (int64_t)_n_speakers, lineOff.data(), lineFiles.data(), _statN.dev(), _statF.dev()));
+}
+
+// ScoreWarp.cpp:68-81: the generator keeps the previous uniform draw as the phase of the next sample
+static double g_bm_x1 = 0.0, g_bm_x2 = 0.0;
+static void boxMullerGeneratorInit() { g_bm_x1 = (rand() / (float)RAND_MAX); }
+static double boxMullerGenerator(double mean, double cov)
+{
+    g_bm_x2 = g_bm_x1;
+    g_bm_x1 = (rand() / (float)RAND_MAX);
+    const double y = sqrt(-2.0 * log(g_bm_x1)) * cos(3.14159265358979323846 * 2 * g_bm_x2);
+    return y * cov + mean;
+}
+void TVAcc::initT(const std::string &randomInitLaw)
+{
+    if (randomInitLaw != "normal") throw Exception("Selected random initialization law does not exist"); // AccumulateTVStat.cpp:750
+    const std::vector<double> &iv = _ubm_invvar.chost();
+    double norm = 0.0;
+    for (unsigned long k = 0; k < _svSize; ++k) norm += iv[k];
+    std::vector<double> T(_rankT * _svSize);
+    boxMullerGeneratorInit();
+    for (size_t e = 0; e < T.size(); ++e) { // row-major (i, j) order like the reference's double loop
+        double val = boxMullerGenerator(0.0, 1.0);
+        while (std::isnan(val) || std::isinf(val)) val = boxMullerGenerator(0.0, 1.0);
+        T[e] = val * norm * 0.001;
+    }
+    _T.set(T);
 }
 
 void TVAcc::substractM()

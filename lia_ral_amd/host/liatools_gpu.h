@@ -111,6 +111,8 @@ class MixtureGD {
     double getCovInv(unsigned long c, unsigned long i) const { return _covInv[c * _d + i]; }
     void setMean(unsigned long c, double v, unsigned long i) { _mean[c * _d + i] = v; }
     void setCov(unsigned long c, double v, unsigned long i) { _cov[c * _d + i] = v; }
+    // a model file stores covInv: keep the file's bits (1 / (1 / v) need not round back to v)
+    void setCovInv(unsigned long c, double v, unsigned long i) { _covInv[c * _d + i] = v; _cov[c * _d + i] = 1.0 / v; }
     void computeAll(); // covInv = 1/cov (cst, det are derived on the device)
     std::vector<double> &weights() { return _w; }
     std::vector<double> &means() { return _mean; }
@@ -263,6 +265,15 @@ class TVAcc {
     // ndx lines = statistics rows; row u owns the frames of segs[u] (TVAcc::_init, :129-196)
     TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned long nSpeakers);
     void computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerLine); // :281-351
+    // the same with the reference's file -> line map (TVTranslate::locIndices, :318-346): segsPerFile[f] = selected segments of
+    // feature file f, filesOfLine[l] = the files listed on ndx line l (a file may be listed on several lines: it is evaluated
+    // once and its statistics are added to each)
+    void computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerFile,
+                                    const std::vector<std::vector<unsigned long> > &filesOfLine);
+    // initT, randomInitLaw "normal" (:729-748): T(i,j) = boxMuller(0,1) * (sum_k invvar_k) * 0.001 with the Box-Muller chain of
+    // ScoreWarp.cpp:68-81 on glibc rand() (no srand: the caller's seed state, 1 by default); NaN / Inf draws are redrawn.  The
+    // "uniform" law calls Matrix::randomInit of alize-core (not in the LIA_RAL tree): not reproduced, throws.
+    void initT(const std::string &randomInitLaw = "normal");
     void substractM();                 // :1088-1105
     void estimateTETt();               // :777-805
     void estimateW();                  // :2114-2169

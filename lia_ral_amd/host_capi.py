@@ -210,6 +210,52 @@ def tv_train(N, F, ubm, Tmat, nb_it, min_div=True, device=0):
     return Tm, means
 
 
+def io_xml(xml_in, xml_out, raw_out=""):
+    dims = np.zeros(2, np.int64); first = np.zeros(3)
+    _chk(lib.liagpu_io_xml(xml_in.encode(), xml_out.encode(), raw_out.encode(), dims.ctypes.data_as(_lp), _d(first)))
+    return dims, first
+
+
+def io_matrix_convert(path_in, fmt_in, path_out, fmt_out):
+    dims = np.zeros(2, np.int64)
+    _chk(lib.liagpu_io_matrix_convert(path_in.encode(), fmt_in.encode(), path_out.encode(), fmt_out.encode(), dims.ctypes.data_as(_lp)))
+    return tuple(int(v) for v in dims)
+
+
+def io_vectors(directory, ids, ext, fmt, W):
+    W = np.ascontiguousarray(W, np.float64)
+    n, rank = W.shape
+    arr = (ct.c_char_p * n)(*[i.encode() for i in ids])
+    back = np.empty((rank, n))
+    _chk(lib.liagpu_io_vectors(directory.encode(), n, arr, ext.encode(), fmt.encode(), rank, _d(W), _d(back)))
+    return back
+
+
+def tv_init_t(ubm, R, seed=1, device=0):
+    """TVAcc::initT, randomInitLaw normal (glibc rand() Box-Muller chain); seed 1 = a process that never called srand."""
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    Tm = np.empty((R, C * D))
+    _chk(lib.liagpu_tv_init_t(device, C, D, _d(w), _d(mean), _d(cov), R, ct.c_uint(seed), _d(Tm)))
+    return Tm
+
+
+def tv_stats_lines(x, file_begin, lines, ubm, device=0):
+    """Baum-Welch statistics per ndx line through liagpu::TVAcc (a file may be listed on several lines)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C = len(w)
+    fb = np.ascontiguousarray(file_begin, np.int64)
+    off = np.zeros(len(lines) + 1, np.int64); off[1:] = np.cumsum([len(l) for l in lines])
+    files = np.ascontiguousarray([f for l in lines for f in l] or [0], np.int64)
+    N = np.empty((len(lines), C)); F = np.empty((len(lines), C * D))
+    _chk(lib.liagpu_tv_stats_lines(device, x.ctypes.data_as(_fp), ct.c_long(T), D, fb.ctypes.data_as(_lp), ct.c_long(len(fb) - 1),
+                                   ct.c_long(len(lines)), off.ctypes.data_as(_lp), files.ctypes.data_as(_lp), C, _d(w), _d(mean), _d(cov),
+                                   _d(N), _d(F)))
+    return N, F
+
+
 def tv_train_dist(N, F, ubm, Tmat, nb_it, world=1, rank=0, id_file="", n_total=None, min_div=True, device=0):
     """One rank of a multi-GPU TotalVariability run (liagpu_tv_train_dist); returns (T, means, times_ms [nb_it x 4])."""
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]

@@ -1389,3 +1389,25 @@ void orc_jfa_subtract_m_plus_ux(long nspk, const long *sess_begin, int C, int D,
     free(mux);
 }
 
+/* TVAcc::initT, randomInitLaw "normal" (LIA_SpkTools/src/AccumulateTVStat.cpp:729-748) with boxMullerGenerator
+ * (LIA_SpkTools/src/ScoreWarp.cpp:68-81): x1 = rand()/(float)RAND_MAX is kept as the phase of the next draw,
+ * y = sqrt(-2 log x1) cos(2 pi x2), NaN / Inf values are redrawn, T(i,j) = y * (sum_k invvar_k) * 0.001.  glibc rand();
+ * the reference never seeds (default seed 1): `seed` is applied with srand() first. */
+void orc_tv_init_t(int R, long SV, const double *invvar, unsigned seed, double *Tm)
+{
+    const double PI2 = 3.14159265358979323846 * 2;
+    double norm = 0.0;
+    for (long k = 0; k < SV; ++k) norm += invvar[k];
+    srand(seed);
+    double x1 = (rand() / (float)RAND_MAX), x2;
+    for (long e = 0; e < (long)R * SV; ++e) {
+        double val;
+        do {
+            x2 = x1;
+            x1 = (rand() / (float)RAND_MAX);
+            val = sqrt(-2.0 * log(x1)) * cos(PI2 * x2);
+        } while (isnan(val) || isinf(val));
+        Tm[e] = val * norm * 0.001;
+    }
+}
+

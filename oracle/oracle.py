@@ -260,6 +260,13 @@ def tv_min_divergence(Rm, r, meanW, means, Tm, n_sessions, C, D):
     return means, Tm
 
 
+def tv_init_t(R, invvar, seed=1):
+    iv, ivp = _d(invvar)
+    Tm = np.empty((R, len(iv)))
+    _lib().orc_tv_init_t(ct.c_int(R), ct.c_long(len(iv)), ivp, ct.c_uint(seed), Tm.ctypes.data_as(c_dp))
+    return Tm
+
+
 def tv_orthonormalize_t(Tm):
     Tm = np.array(Tm, np.float64)
     R, SV = Tm.shape

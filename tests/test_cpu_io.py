@@ -62,3 +62,55 @@ def test_damaged_file_is_reported(tmp_path):
     bad.write_bytes(open(os.path.join(REF, "traintarget_wld.raw.gmm"), "rb").read()[:-3])
     with pytest.raises(h.HostError, match="text-mode damaged"):
         h.io_roundtrip(str(bad), str(tmp_path / "o.gmm"), os.path.join(REF, "test1.prm"), str(tmp_path / "o.prm"), "")
+
+
+def test_xml_mixture_reads_and_rewrites_the_reference_file(tmp_path):
+    """LIA_SpkDet/TrainWorld/test/wld.validate (XML, 10 x 32): weights / covInv / means come back bit for bit, and the re-written
+    file is the same text except for the last digits of the recomputed cst / det attributes (DistribGD::computeAll)."""
+    import re
+    from lia_ral_amd import host_capi as h
+    src = os.path.join(REF, "trainworld_wld.validate.xml")
+    out, raw = str(tmp_path / "w.xml"), str(tmp_path / "w.raw")
+    dims, first = h.io_xml(src, out, raw)
+    assert tuple(dims) == (10, 32)
+    a, b = open(src).read().splitlines(), open(out).read().splitlines()
+    assert len(a) == len(b) == 1 + 10 * (2 + 64) + 1
+    assert first[0] == 0.1457922064745452162 and first[1] == 0.2845698083139924783
+    num = re.compile(r'(cst|det)="([^"]+)"')
+    for la, lb in zip(a, b):
+        if "<DistribGD" in la:
+            assert num.sub("", la) == num.sub("", lb)                     # i and weight: identical text
+            for (ka, va), (kb, vb) in zip(num.findall(la), num.findall(lb)):
+                assert ka == kb and abs(float(va) - float(vb)) <= 1e-12 * abs(float(va))
+        else:
+            assert la == lb                                               # every covInv / mean line: identical text
+    # reading the re-written file gives the same text again (fixed point), and the RAW twin holds the same numbers
+    out2 = str(tmp_path / "w2.xml")
+    h.io_xml(out, out2)
+    assert open(out).read() == open(out2).read()
+    rawb = open(raw, "rb").read()
+    assert struct.unpack_from("<II", rawb) == (10, 32) and np.frombuffer(rawb, "<f8", 1, 8)[0] == first[0]
+
+
+def test_dt_db_matrices_and_vector_files(tmp_path):
+    """DT matrix: the reference's own LIA_SpkDet/ComputeTest/test/zero.mat (32768 x 5) re-written byte for byte; DB (binary, layout
+    unpinned: no DB file ships with LIA_RAL) round-trips through DT; per-id i-vector files (TVAcc::saveWbyFile -> PldaTest::load)."""
+    import gzip
+    from lia_ral_amd import host_capi as h
+    zero = tmp_path / "zero.mat"
+    zero.write_bytes(gzip.open(os.path.join(REF, "computetest_zero.mat.gz")).read())
+    assert h.io_matrix_convert(str(zero), "DT", str(tmp_path / "z.db"), "DB") == (32768, 5)
+    assert os.path.getsize(tmp_path / "z.db") == 8 + 8 * 32768 * 5
+    assert h.io_matrix_convert(str(tmp_path / "z.db"), "DB", str(tmp_path / "z.dt"), "DT") == (32768, 5)
+    assert filecmp.cmp(zero, tmp_path / "z.dt", shallow=False)
+    rng = np.random.default_rng(0)
+    W = rng.normal(size=(5, 40))
+    ids = ["spk%d_a" % i for i in range(5)]
+    for fmt in ("DB", "DT"):
+        d = tmp_path / fmt; d.mkdir()
+        back = h.io_vectors(str(d), ids, ".y", fmt, W)
+        assert np.array_equal(back, W.T)                                   # one vector per COLUMN like PldaTest::_models
+        assert sorted(os.listdir(d)) == sorted(i + ".y" for i in ids)
+    with pytest.raises(h.HostError, match="expected"):
+        (tmp_path / "bad.db").write_bytes(b"\x02\x00\x00\x00\x03\x00\x00\x00" + b"\x00" * 40)
+        h.io_matrix_convert(str(tmp_path / "bad.db"), "DB", str(tmp_path / "o"), "DT")

@@ -581,3 +581,31 @@ def test_accumulate_stat_llk_wrapper_and_kat4_through_frame_moments(golden_dir):
     assert abs(got - ref) < 1e-10
     floor = h.mean_llk(xx, segs_b, segs_l, (w, m, 1.0 / iv), ref + 50.0, 400.0)      # every frame clamped to minLLK
     assert abs(floor - (ref + 50.0)) < 1.0 and floor >= ref + 50.0 - 1e-12
+
+
+def test_init_t_and_statistics_with_a_file_on_several_lines():
+    """TVAcc::initT (AccumulateTVStat.cpp:701-757, Box-Muller chain on glibc rand(), ScoreWarp.cpp:68-81) and
+    computeAndAccumulateTVStat with the file -> ndx-line map (:318-346): a file listed on two lines counts for both, a line with
+    two files sums them, an empty line stays zero."""
+    from lia_ral_amd import capi, host_capi as h
+    C, D, R = 16, 12, 5
+    w, mean, iv = make_gmm(C, D, seed=4)
+    ubm = (w, mean, 1.0 / iv)
+    for seed in (1, 77):
+        Tg = h.tv_init_t(ubm, R, seed)
+        To = orc.tv_init_t(R, iv.ravel(), seed)
+        assert np.array_equal(Tg, To) and np.all(np.isfinite(Tg)) and abs(Tg.std() / (iv.sum() * 0.001) - 1.0) < 0.2
+    lens = [120, 75, 200, 33]
+    fb = np.concatenate([[0], np.cumsum(lens)])
+    x = make_frames(w, mean, iv, int(fb[-1]), seed=5)
+    lines = [[0], [1, 2], [], [2], [3, 0]]
+    og = orc.Gmm(w, mean, iv)
+    Nf, Ff = orc.tv_stats(og, x.astype(np.float64), np.repeat(np.arange(4), lens), 4)
+    Nref = np.array([Nf[l].sum(0) if l else np.zeros(C) for l in lines])
+    Fref = np.array([Ff[l].sum(0) if l else np.zeros(C * D) for l in lines])
+    N, F = h.tv_stats_lines(x, fb, lines, ubm)                        # C++ host layer
+    assert relerr(N, Nref) < 1e-10 and relerr(F, Fref) < 1e-10 and not N[2].any() and not F[2].any()
+    ctx = capi.Context(0)
+    N2, F2 = ctx.gmm(w, mean, iv).tv_stats_lines(x, fb, lines)        # C ABI directly
+    assert np.array_equal(N2, N) and np.array_equal(F2, F)
+    ctx.close()

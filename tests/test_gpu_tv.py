@@ -305,3 +305,43 @@ def test_jfa_steps_match_oracle(ctx, C, D, R, nspk):
     g = ctx.tv_estimate_a_and_c(N, F, V, iv, te_g, C, D)
     il = np.tril_indices(R)
     assert relerr(g["W"], Yo) < 1e-9 and relerr(g["A"], Ao[:, il[0], il[1]]) < 1e-9 and relerr(g["Cmx"], Co) < 1e-9
+
+
+def test_twocov_mix_part_trials_mask_and_model_blocks(ctx):
+    """PldaTest::twoCovScoringMixPart (PldaTools.cpp:3923-3949, accumulating), the _trials mask of cosineDistance /
+    mahalanobisDistance (:3871, :3889) and the model-block tiling of the score matrix over ranks."""
+    from lia_ral_amd import capi
+    from lia_ral_amd.dist import score_model_block
+    rng = np.random.default_rng(9)
+    dim, M, S = 60, 137, 211
+    m = rng.normal(size=(dim, M)); s = rng.normal(size=(dim, S))
+    G = rng.normal(size=(dim, dim)) / dim
+    base = rng.normal(size=(M, S))
+    got = ctx.score_twocov_mix_part(m, s, G, base.copy())
+    ref = base + orc.score_twocov(m, s, G, np.zeros((dim, dim)))          # H = 0 leaves (m+s)'G(m+s)
+    assert relerr(got, ref) < 1e-11
+    # twoCovScoring == mix part on zeros minus the model / segment terms (:4127-4171)
+    H = rng.normal(size=(dim, dim)) / dim
+    full = ctx.score_twocov(m, s, G, H)
+    mp = ctx.score_twocov_mix_part(m, s, G, np.zeros((M, S)))
+    md = np.einsum("im,ik,km->m", m, H, m); sd = np.einsum("is,ik,ks->s", s, H, s)
+    assert relerr(mp - md[:, None] - sd[None, :], full) < 1e-11
+    # trials mask
+    trials = rng.random((M, S)) < 0.3
+    Q = rng.normal(size=(dim, dim)); Mah = Q @ Q.T / dim + np.eye(dim)
+    gc = ctx.score_apply_trials(trials, ctx.score_cosine(m, s))
+    gm = ctx.score_apply_trials(trials, ctx.score_mahalanobis(m, s, Mah))
+    assert relerr(gc, orc.score_cosine(m, s, trials)) < 1e-12 and relerr(gm, orc.score_mahalanobis(m, s, Mah, trials)) < 1e-11
+    assert np.all(gc[~trials] == 0.0) and np.all(gm[~trials] == 0.0)
+    # model blocks: three "ranks" reproduce the rows of the one-call matrix bit for bit, PLDA with its per-model session counts too
+    whole = ctx.score_mahalanobis(m, s, Mah)
+    nsess = np.sort(rng.integers(1, 4, M)); FTJF = G @ G.T + np.eye(dim)
+    whole_p = ctx.score_plda(m * nsess, nsess, s, FTJF)
+    rows = 0
+    for r in range(3):
+        m0, m1, blk = score_model_block(lambda a, b: ctx.score_mahalanobis(a, b, Mah), m, s, r, 3)
+        assert (m0, m1) == capi.shard_range(M, r, 3) and np.array_equal(blk, whole[m0:m1])
+        _, _, bp = score_model_block(lambda a, b, n: ctx.score_plda(a, n, b, FTJF), m * nsess, s, r, 3, nsess=nsess)
+        assert relerr(bp, whole_p[m0:m1]) < 1e-13
+        rows += m1 - m0
+    assert rows == M

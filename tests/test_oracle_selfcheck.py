@@ -246,3 +246,26 @@ def test_jfa_pieces_against_numpy():
     assert np.abs(Yj - o["W"]).max() < 1e-10 * np.abs(Yj).max()
     assert np.abs(Aj.reshape(C, R * R) - o["A"]).max() < 1e-10 * np.abs(Aj).max()
     assert np.abs(Cj - o["Cmx"]).max() < 1e-10 * np.abs(Cj).max()
+
+
+def test_init_t_box_muller_chain_matches_numpy_restatement():
+    """orc_tv_init_t against an independent restatement of ScoreWarp.cpp:68-81 driven by the same glibc rand() stream."""
+    import ctypes as ct
+    libc = ct.CDLL("libc.so.6")
+    R, SV, seed = 3, 40, 5
+    iv = np.linspace(0.5, 2.0, SV)
+    got = orc.tv_init_t(R, iv, seed)
+    libc.srand(seed)
+    RAND_MAX = 2147483647
+    u = lambda: float(np.float32(libc.rand()) / np.float32(RAND_MAX))
+    x1 = u()
+    ref = np.empty(R * SV)
+    for e in range(R * SV):
+        while True:
+            x2, x1 = x1, u()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                y = np.sqrt(-2.0 * np.log(x1)) * np.cos(2 * np.pi * x2)
+            if np.isfinite(y):
+                break
+        ref[e] = y * iv.sum() * 0.001
+    assert np.allclose(got.ravel(), ref, rtol=1e-13, atol=0)
