@@ -1,6 +1,8 @@
 // tv_kernels.hip -- fp64 building blocks of the i-vector path on gfx950: a strided-batched MFMA
 // GEMM (v_mfma_f64_16x16x4_f64, LDS-tiled 128x128x16), a batched blocked Cholesky / SPD inverse
 // built from it, and the small element-wise / packing kernels around them.
+#include <type_traits>
+
 #include "devutil.h"
 #include "tv_kernels.h"
 
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
             rb[2 * i] = okb ? vb[0] : 0.0; rb[2 * i + 1] = okb ? vb[1] : 0.0;
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
         if (!EDGE) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -189,11 +192,14 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
     if (nkt > 0) {
         if (krem && nkt == 1) gload_tail();
         else gload(0);
-        swrite(0);
+        swrite(std::integral_constant<int, 0>{});
     }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
+    // The k-tile loop is unrolled by two so that the LDS buffer index is a compile-time constant: the 32 operand reads and 16
+    // staging writes of a k-tile then address "lane-dependent register + immediate" -- with a run-time buffer index every one
+    // of them paid a v_lshl_add to rebuild its address (48 VALU instructions next to 64 MFMAs).
+    auto ktile = [&](auto curc, int kt) __attribute__((always_inline)) {
+        constexpr int cur = decltype(curc)::value;
         if (kt + 1 < nkt) {
             if (krem && kt + 2 == nkt) gload_tail();
             else gload(kt + 1);
@@ -212,8 +218,12 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);
         }
-        if (kt + 1 < nkt) swrite(cur ^ 1);
+        if (kt + 1 < nkt) swrite(std::integral_constant<int, cur ^ 1>{});
         __syncthreads();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        ktile(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nkt) ktile(std::integral_constant<int, 1>{}, kt + 1);
     }
     // D layout: lane holds rows q + 4r, column i16 of every 16x16 tile
     double cvv[4] = {0.0, 0.0, 0.0, 0.0};
@@ -238,8 +248,9 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
                 double v = alpha * acc[a][b][r];
                 if (epi.mode == 1) v = v * rvv * cvv[b];
                 else if (epi.mode == 2) v = v + epi.br * rvv + epi.bc * cvv[b] + epi.cst;
-                if (beta != 0.0) v += beta * C[gm * ldc + gn];
-                C[gm * ldc + gn] = v;
+                if (beta != 0.0) { v += beta * C[gm * ldc + gn]; C[gm * ldc + gn] = v; }
+                else if (epi.mode != 0) __builtin_nontemporal_store(v, &C[gm * ldc + gn]); // score matrices (GBs, written once): streamed past L2
+                else C[gm * ldc + gn] = v;
             }
         }
 }

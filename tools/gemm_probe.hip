@@ -1,5 +1,5 @@
 // gemm_probe.hip -- times tvk_dgemm (lia_ral_amd/csrc/tv_kernels.hip) on the shapes the i-vector path uses.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip -o tools/bin/gemm_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip lia_ral_amd/csrc/chol_fused.hip -o tools/bin/gemm_probe
 #include "../lia_ral_amd/csrc/tv_kernels.hip"
 #include <cstdio>
 #include <vector>
@@ -15,6 +15,10 @@ int main()
         {"A += N^T E: 2048 x 80200 x 256 TN", true, false, 2048, 80200, 256},
         {"Cmx += W^T F: 400 x 122880 x 256 TN", true, false, 400, 122880, 256},
         {"scores: 20000 x 20000 x 400 TN", true, false, 20000, 20000, 400},
+        {"scores: 20000 x 20000 x 200 TN", true, false, 20000, 20000, 200},
+        {"scores: 20000 x 20000 x 16 TN (store-bound probe)", true, false, 20000, 20000, 16},
+        {"aux = F Tiv^T: 1024 x 400 x 122880 NT", false, true, 1024, 400, 122880},
+        {"T_c = A_c^-1 C_c: 400 x 60 x 400 NN", false, false, 400, 60, 400},
     };
     hipStream_t st;
     hipStreamCreate(&st);
