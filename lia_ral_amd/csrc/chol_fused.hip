@@ -18,10 +18,16 @@
 // Wave 0 owns the diagonal block: updates it first, factors it in registers (row i in lane i, cross-lane
 // v_readlane broadcasts, fully unrolled), inverts the 32 x 32 factor (column c in lane c) and publishes
 // inv(L_jj) in LDS while the other waves are still busy with their tiles; it takes off-diagonal tiles last.
+#include <atomic>
+
 #include "devutil.h"
 #include "tv_kernels.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// A/B switch of the calling host thread: 0 = every wave fetches the panel rows itself (the round-1 kernels)
+static thread_local int g_chol_lds = 1;
+int tvk_set_chol_lds(int on) { const int prev = g_chol_lds; g_chol_lds = on; return prev; }
 
 namespace {
 
@@ -117,6 +123,102 @@ __device__ __forceinline__ void rowdot_n(int cnt, const double *pa0, const doubl
     }
 }
 
+// ---- panel rows from LDS --------------------------------------------------------------------------------------------------
+// The 32 panel rows are the A operand of EVERY wave's MFMAs: fetched by each wave itself they were 40 % of the kernel's L2 / MALL
+// traffic (8 KB per wave and 32-column chunk next to 12 KB of its own tile rows) -- and these kernels are bound by exactly that
+// traffic (2.8 GB per launch of 256 matrices).  The panel block [32 rows x klen columns] (at most 32 x n doubles = 103 KB at
+// n = 400) is staged ONCE per panel by the whole workgroup; a wave then reads its A operands with 8 ds_read_b128 per chunk.
+// Row stride S (doubles) with S / 2 odd: the 16 lanes of a b128 read (16 different rows, same column) hit 16 distinct 4-bank groups.
+__device__ __forceinline__ int pan_stride(int n) { return (n & 2) ? n : n + 2; }   // n even: S / 2 odd
+// rows row0 .. row0 + 31 (clamped to n - 1), columns [kbase, kbase + klen) of the row-major matrix X -> pan[row][0 .. klen)
+__device__ __forceinline__ void stage_panel(double *pan, int S, const double *X, long n, long row0, int kbase, int klen, int tid)
+{
+    const int segs = klen >> 1; // 16-byte segments per row
+    for (int e = tid; e < 32 * segs; e += 512) {
+        const int row = e / segs, seg = e - row * segs;
+        long r = row0 + row;
+        r = r < n ? r : n - 1;
+        *(d2 *)(pan + row * S + 2 * seg) = *(const d2 *)(X + r * n + kbase + 2 * seg);
+    }
+}
+template <int CNT> struct TileOps { d2 b[CNT][4]; };
+struct PanOps { d2 a0[4], a1[4]; };
+template <int CNT>
+__device__ __forceinline__ void tiles_load(TileOps<CNT> &o, const double *(&pb)[TW], int k)
+{
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + 2 * v);
+}
+__device__ __forceinline__ void pan_load(PanOps &o, const double *la0, const double *la1, int kl)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        o.a0[v] = *(const d2 *)(la0 + kl + 2 * v);
+        o.a1[v] = *(const d2 *)(la1 + kl + 2 * v);
+    }
+}
+template <int CNT, bool NEG>
+__device__ __forceinline__ void pan_mfma(const PanOps &a, const TileOps<CNT> &o, d4 (&acc)[TW][2])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double x0 = NEG ? -a.a0[e >> 1][e & 1] : a.a0[e >> 1][e & 1];
+        const double x1 = NEG ? -a.a1[e >> 1][e & 1] : a.a1[e >> 1][e & 1];
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            acc[u][0] = MFMA_F64(x0, o.b[u][e >> 1][e & 1], acc[u][0]);
+            acc[u][1] = MFMA_F64(x1, o.b[u][e >> 1][e & 1], acc[u][1]);
+        }
+    }
+}
+// rowdot with the panel rows in LDS (la0 / la1: the lane's two panel rows + 8 q, LDS column = k - kbase); tile rows still come
+// from memory, register double-buffered one chunk ahead; the LDS operands of the next chunk are requested before the MFMAs of
+// the current one.
+template <int CNT, bool NEG>
+__device__ __forceinline__ void rowdot_lds(const double *la0, const double *la1, const double *(&pb)[TW], int kb, int ke, int kbase,
+                                           d4 (&acc)[TW][2])
+{
+    // (A third rotating operand buffer -- tile rows requested two chunks ahead -- was tried: 120-137 spilled VGPRs in all three
+    // kernels and the gain of the LDS panel gone.  Two buffers it is.)
+    if (ke - kb < 32) return;
+    TileOps<CNT> A, B;
+    PanOps xa, xb;
+    const int last = ke - 32;
+    tiles_load<CNT>(A, pb, kb);
+    pan_load(xa, la0, la1, kb - kbase);
+    int k = kb;
+    for (; k + 64 <= ke; k += 64) {
+        tiles_load<CNT>(B, pb, k + 32);
+        pan_load(xb, la0, la1, k + 32 - kbase);
+        ROWS_FENCE();
+        pan_mfma<CNT, NEG>(xa, A, acc);
+        ROWS_FENCE();
+        const int kn = k + 64 < last ? k + 64 : last;
+        tiles_load<CNT>(A, pb, kn);
+        pan_load(xa, la0, la1, kn - kbase);
+        ROWS_FENCE();
+        pan_mfma<CNT, NEG>(xb, B, acc);
+        ROWS_FENCE();
+    }
+    if (k < ke) pan_mfma<CNT, NEG>(xa, A, acc);
+}
+// dispatcher over the tile count; the operand source is a template parameter of the kernels (two code paths in one kernel cost
+// 150 spilled VGPRs)
+template <bool LDS, bool NEG>
+__device__ __forceinline__ void rowdot_sel(int cnt, const double *pa0, const double *pa1, const double *la0, const double *la1,
+                                           const double *(&pb)[TW], int kb, int ke, int kbase, d4 (&acc)[TW][2])
+{
+    if (!LDS) { rowdot_n<NEG>(cnt, pa0, pa1, pb, kb, ke, acc); return; }
+    switch (cnt) {
+    case 1: rowdot_lds<1, NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
+    case 2: rowdot_lds<2, NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
+    case 3: rowdot_lds<3, NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
+    default: break;
+    }
+}
+
 // X^T = inv(L_jj) P^T for one row tile: P in acc[0..1] (lane (i16, q): P[row i16][16 ct + 4 q + r]), the 12 operand
 // values of inv(L_jj) in la0 / la1; result x0 (columns 4q..4q+3) and x1 (columns 16 + 4q ..) of the same rows
 struct LinvOps { double la0[4], la1[2][4]; };
@@ -180,13 +282,19 @@ __device__ __forceinline__ d4 chol_src4(const double *Lm, const double *Apk, lon
 // Afull[b]: n x n row-major, lower triangle read, overwritten by the factor (diagonal blocks: upper part zeroed;
 // elsewhere the upper triangle is left as it was).  invd[b][kb][32][32]: inverse of the kb-th 32 x 32 diagonal
 // block of the factor (zero padded).  status[b] = 1 on a non-positive pivot.  n must be even (16-byte rows).
+template <bool use_lds>
 __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
                                                       long spk, double diag_add)
 {
     __shared__ __attribute__((aligned(16))) double pj[32][34];
     __shared__ __attribute__((aligned(16))) double linv[32][34];
     __shared__ __attribute__((aligned(16))) double col[2][32];
-    __shared__ double slab[8][32][33]; // partial updates of the diagonal block, one per wave
+    // dynamic: the partial updates of the diagonal block, one per wave (slab[8][32][33]) -- and, once wave 0 has taken them into its
+    // registers, the panel rows L[j0 .. j0 + 31][0 .. j0) for the off-diagonal tiles (use_lds; the two never live at the same time)
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    double (*slab)[32][33] = (double (*)[32][33])dyn_lds;
+    double *pan = dyn_lds;
+    const int S = pan_stride(n_);
     const long n = n_;
     double *Lm = Afull + (size_t)blockIdx.x * n * n;
     const double *Apk = Apacked ? Apacked + (size_t)blockIdx.x * spk : nullptr; // input, when it is not Afull itself
@@ -266,9 +374,8 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
         }
         __syncthreads(); // the 8 partial updates are in LDS
         // step 2, wave 0: row i = lane & 31 of the block in registers, factor, invert
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3); // the serial part: do not queue behind the MFMA stream of the wave sharing this SIMD
-            const int li = lane & 31;
+        const int li = lane & 31;
+        if (use_lds && wave == 0) { // the summed block moves to pj: the slab memory is about to become the panel buffer
             double a[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) a[k] = slab[0][li][k];
@@ -283,6 +390,39 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                     PIN_V(a[k]);
                 }
             }
+            if (lane < 32) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) pj[li][k] = a[k];
+            }
+        }
+        if (use_lds && j0 > 0) {
+            __syncthreads(); // wave 0 has taken the block: the slab memory is free
+            stage_panel(pan, S, Lm, n, j0, 0, j0, tid);
+            __syncthreads(); // the panel rows are in LDS for everybody (wave 0 included: it takes its tiles last)
+        }
+        if (wave == 0) {
+            double a[32];
+            if (use_lds) {
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 32; ++k) a[k] = pj[li][k];
+                wave_sync(); // every lane holds its row before the sweep starts overwriting pj
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) a[k] = slab[0][li][k];
+#pragma unroll
+                for (int sl = 1; sl < 8; ++sl) {
+                    double t[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) t[k] = slab[sl][li][k];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        a[k] += t[k];
+                        PIN_V(a[k]);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(3); // the serial part: do not queue behind the MFMA stream of the wave sharing this SIMD
             // Factorisation and inversion of the 32 x 32 block in ONE sweep over its columns, ONE FMA stream for both:
             // lanes 0..31 hold row i = lane of the block, lanes 32..63 the running sums of column i = lane - 32 of
             // X = L^-1 (v[] either way).  Column j goes through LDS (uniform-address reads = broadcasts):
@@ -354,7 +494,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                     if (u < cnt) acc[u][ct] = chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
                 }
             }
-            rowdot_n<true>(cnt, pa0, pa1, pb, 0, j0, acc);
+            rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
             if (g == 0) {
                 __syncthreads(); // inv(L_jj) and L_jj are in LDS
                 chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
@@ -393,10 +533,14 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
 // for the row tiles c < i0.  U[c][k] = 0 for k < c: a tile's k range starts at its own 32-block (whose diagonal
 // block is stored with its zeros), and tiles of one wave (128 rows apart) join the k loop one after the other.
 // Only the upper triangle (plus the diagonal blocks) of U is written; nothing else of U is ever read.
+template <bool use_lds>
 __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__restrict__ Lfull, const double *__restrict__ invd,
                                                        long sinv, double *Ufull)
 {
     __shared__ __attribute__((aligned(16))) double linv[32][34];
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[]; // use_lds: the panel rows L[i0 .. i0 + 31][0 .. i0)
+    double *pan = dyn_lds;
+    const int S = pan_stride(n_);
     const long n = n_;
     const double *Lm = Lfull + (size_t)blockIdx.x * n * n;
     double *Um = Ufull + (size_t)blockIdx.x * n * n;
@@ -412,6 +556,7 @@ __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__r
             linv[i][k] = v;
             if (i < w && k < w) Um[(long)(i0 + k) * n + i0 + i] = v; // diagonal block of U = inv(L_ii)^T
         }
+        if (use_lds && i0 > 0) stage_panel(pan, S, Lm, n, i0, 0, i0, tid);
         __syncthreads();
         const int nt = i0 >> 4; // full row tiles above the diagonal block
         const int mine = nt > wave ? (nt - wave + 7) / 8 : 0;
@@ -437,7 +582,9 @@ __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__r
             ks[TW] = i0;
 #pragma unroll
             for (int s = 0; s < TW; ++s)
-                if (s < cnt) rowdot_n<true>(s + 1, pa0, pa1, pb, ks[s], (s + 1 < cnt) ? ks[s + 1] : i0, acc);
+                if (s < cnt)
+                    rowdot_sel<use_lds, true>(s + 1, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, ks[s],
+                                              (s + 1 < cnt) ? ks[s + 1] : i0, 0, acc);
             LinvOps lo;
             linv_ops_load(lo, linv, perm, q);
 #pragma unroll
@@ -478,9 +625,13 @@ __device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1
 }
 // packed != NULL: instead of the full matrix, E = inv + w w^T goes out as PACKED lower rows (stride sp) -- what the T-matrix
 // E-step accumulates (A_c += N_uc E_u): no full inverse in memory, no matrix-vector pass, no pack pass.
+template <bool use_lds>
 __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv,
                                                 const double *__restrict__ wv, double *__restrict__ packed, long sp)
 {
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[]; // use_lds: the panel rows U[j0 .. j0 + 31][j0 .. nfl)
+    double *pan = dyn_lds;
+    const int S = pan_stride(n_);
     const long n = n_;
     const double *Um = Ufull + (size_t)blockIdx.x * n * n;
     double *Om = inv ? inv + (size_t)blockIdx.x * n * n : nullptr;
@@ -497,6 +648,11 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
         const double *pa0 = Um + ra0 * n + 8 * q, *pa1 = Um + ra1 * n + 8 * q;
+        if (use_lds) {
+            if (j0 > 0) __syncthreads(); // every wave is done with the previous panel's rows
+            if (nfl > j0) stage_panel(pan, S, Um, n, j0, j0, nfl - j0, tid);
+            __syncthreads();
+        }
         for (int g = 0; TW * g < mine; ++g) {
             int cnt = mine - TW * g;
             cnt = cnt > TW ? TW : cnt;
@@ -517,7 +673,9 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
             ks[TW] = nfl;
 #pragma unroll
             for (int s = 0; s < TW; ++s)
-                if (s < cnt) rowdot_n<false>(s + 1, pa0, pa1, pb, ks[s], (s + 1 < cnt) ? ks[s + 1] : nfl, acc);
+                if (s < cnt)
+                    rowdot_sel<use_lds, false>(s + 1, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, ks[s],
+                                               (s + 1 < cnt) ? ks[s + 1] : nfl, j0, acc);
             if (nfl < n_) {
                 switch (cnt) {
                 case 1: rowdot_tail<1>(pa0, pa1, pb, nfl, n_, q, acc); break;
@@ -555,13 +713,67 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
     }
 }
 
+// Dynamic LDS of the three kernels and whether the panel rows fit next to the static arrays (160 KB per workgroup on gfx950)
+namespace {
+struct CholLds { int use; size_t chol, trinv, uut; };
+CholLds chol_lds(int n)
+{
+    const size_t pan = (size_t)32 * ((n & 2) ? n : n + 2) * sizeof(double), slab = (size_t)8 * 32 * 33 * sizeof(double);
+    CholLds r;
+    r.use = g_chol_lds && pan + 20 * 1024 <= 160 * 1024 ? 1 : 0;
+    r.chol = r.use && pan > slab ? pan : slab;
+    r.trinv = r.use ? pan : 16;
+    r.uut = r.use ? pan : 16;
+    return r;
+}
+template <typename K> int chol_attr(K kernel, size_t lds, std::atomic<size_t> (&done)[16])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (done[dev].load(std::memory_order_acquire) < lds) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        done[dev].store(lds, std::memory_order_release);
+    }
+    return 0;
+}
+std::atomic<size_t> g_attr_chol[2][16], g_attr_trinv[2][16], g_attr_uut[2][16];
+int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked, long spk, double diag_add)
+{
+    const CholLds l = chol_lds(n);
+    const long sinv = (long)((n + 31) / 32) * 1024;
+    int rc = l.use ? chol_attr(k_chol_left<true>, l.chol, g_attr_chol[1]) : chol_attr(k_chol_left<false>, l.chol, g_attr_chol[0]);
+    if (rc) return rc;
+    if (l.use) k_chol_left<true><<<nb, 512, l.chol, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
+    else k_chol_left<false><<<nb, 512, l.chol, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
+    return (int)hipGetLastError();
+}
+int launch_trinv(hipStream_t st, int n, int nb, const double *Lf, const double *invd, double *U)
+{
+    const CholLds l = chol_lds(n);
+    const long sinv = (long)((n + 31) / 32) * 1024;
+    int rc = l.use ? chol_attr(k_trinv_left<true>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false>, l.trinv, g_attr_trinv[0]);
+    if (rc) return rc;
+    if (l.use) k_trinv_left<true><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
+    else k_trinv_left<false><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
+    return (int)hipGetLastError();
+}
+int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, const double *w, double *packed, long sp)
+{
+    const CholLds l = chol_lds(n);
+    int rc = l.use ? chol_attr(k_uut<true>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false>, l.uut, g_attr_uut[0]);
+    if (rc) return rc;
+    if (l.use) k_uut<true><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
+    else k_uut<false><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
+    return (int)hipGetLastError();
+}
+} // namespace
+
 int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked, long spk,
                           double diag_add)
 {
     if (nb <= 0 || n <= 0) return 0;
-    const int nblk = (n + 31) / 32;
-    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status, Apacked, spk, diag_add);
-    return (int)hipGetLastError();
+    return launch_chol(st, n, nb, Afull, invd, status, Apacked, spk, diag_add);
 }
 
 // inv[b] = A[b]^-1 through the three one-workgroup-per-matrix kernels; U: scratch nb*n*n (only its upper triangle is used).
@@ -570,11 +782,10 @@ int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, d
                                  const double *Apacked, long spk, double diag_add)
 {
     if (nb <= 0 || n <= 0) return 0;
-    const int nblk = (n + 31) / 32;
-    k_chol_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, status, Apacked, spk, diag_add);
-    k_trinv_left<<<nb, 512, 0, st>>>(n, Afull, invd, (long)nblk * 1024, U);
-    k_uut<<<nb, 512, 0, st>>>(n, U, inv, nullptr, nullptr, 0);
-    return (int)hipGetLastError();
+    int rc;
+    if ((rc = launch_chol(st, n, nb, Afull, invd, status, Apacked, spk, diag_add))) return rc;
+    if ((rc = launch_trinv(st, n, nb, Afull, invd, U))) return rc;
+    return launch_uut(st, n, nb, U, inv, nullptr, nullptr, 0);
 }
 
 // T-matrix E-step form: A[b] arrives as packed lower rows + diag_add I in P[b] (stride sp); on return W[b] = A^-1 aux[b] and
@@ -583,11 +794,9 @@ int tvk_inverse_e_packed_batched(hipStream_t st, int n, int nb, double *Lf, doub
                                  double diag_add, const double *aux, double *W)
 {
     if (nb <= 0 || n <= 0) return 0;
-    const int nblk = (n + 31) / 32;
-    k_chol_left<<<nb, 512, 0, st>>>(n, Lf, invd, (long)nblk * 1024, status, P, sp, diag_add);
-    int rc = tvk_chol_solve_batched(st, n, nb, Lf, invd, aux, W);
-    if (rc) return rc;
-    k_trinv_left<<<nb, 512, 0, st>>>(n, Lf, invd, (long)nblk * 1024, U);
-    k_uut<<<nb, 512, 0, st>>>(n, U, nullptr, W, P, sp);
-    return (int)hipGetLastError();
+    int rc;
+    if ((rc = launch_chol(st, n, nb, Lf, invd, status, P, sp, diag_add))) return rc;
+    if ((rc = tvk_chol_solve_batched(st, n, nb, Lf, invd, aux, W))) return rc;
+    if ((rc = launch_trinv(st, n, nb, Lf, invd, U))) return rc;
+    return launch_uut(st, n, nb, U, nullptr, W, P, sp);
 }

@@ -10,6 +10,7 @@ int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *
 int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read packed lower rows directly
 // A/B switches: thread-local (they act on the launches of the calling host thread); return the previous value
 int tvk_set_chol_gemm_path(int on);
+int tvk_set_chol_lds(int on);   // 0: the panel rows of chol_fused.hip from memory per wave (round 1) instead of LDS
 int tvk_set_gemm_clamp(int on);
 int tvk_set_gemm_remap(int on);
 int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status,
