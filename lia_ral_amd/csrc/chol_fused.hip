@@ -713,6 +713,116 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
     }
 }
 
+// X = A^-1 B for NR <= 64 right-hand sides per system through the Cholesky factor (k_chol_left) and the inverses of its 32 x 32
+// diagonal blocks: blocked forward (L Y = B) and backward (L^T X = Y) substitution on the matrix cores, one workgroup per system.
+// TVAcc::updateTestimate (AccumulateTVStat.cpp:981-1000) is T_c = A_c^-1 Cmx_c with 60 columns: the reference inverts A_c
+// explicitly; substituting needs 2 n^2 NR flops instead of the 4 n^3 / 3 of triangular inverse + U U^T and leaves out two of the
+// three kernels per batch.  8 waves = 2 row halves x 4 column tiles of a 32-row block; Y / X live in the output array itself
+// (element (k, d) at X[k ldx + d]) and are re-read from there (L2) as the B operand of later block rows -- visible to the other
+// waves of the workgroup after the barrier, like the panels of k_chol_left.
+__global__ __launch_bounds__(512, 1) void k_chol_solve_multi(int n_, int NR, const double *__restrict__ Lfull, const double *__restrict__ invd,
+                                                             long sinv, const double *__restrict__ Bsrc, long ldb, long sB,
+                                                             double *__restrict__ Xdst, long ldx, long sX)
+{
+    __shared__ __attribute__((aligned(16))) double rs[32][66];  // the block row's right-hand side after the update
+    __shared__ __attribute__((aligned(16))) double dinv[32][34]; // inv(L_ii)
+    const long n = n_;
+    const double *Lm = Lfull + (size_t)blockIdx.x * n * n;
+    const double *iv = invd + (size_t)blockIdx.x * sinv;
+    const double *Bm = Bsrc + (size_t)blockIdx.x * sB;
+    double *Xm = Xdst + (size_t)blockIdx.x * sX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+    const int rt = wave >> 2, ct = wave & 3;
+    const int col = 16 * ct + i16;          // right-hand side of this lane (B operand / result column)
+    const bool colok = col < NR;
+    const int colc = colok ? col : NR - 1;
+    const int nblk = (n_ + 31) >> 5;
+    // ---- forward: L Y = B, block rows top down ----
+    for (int ib = 0; ib < nblk; ++ib) {
+        const int r0 = ib << 5;
+        for (int e = tid; e < 1024; e += 512) dinv[e >> 5][e & 31] = iv[(size_t)ib * 1024 + e];
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = r0 + 16 * rt + q + 4 * r;
+            acc[r] = (row < n && colok) ? Bm[row * ldb + col] : 0.0;
+        }
+        long ar = r0 + 16 * rt + i16;        // row of L this lane feeds as the A operand
+        ar = ar < n ? ar : n - 1;
+        const double *pa = Lm + ar * n + 8 * q;
+        for (int k = 0; k < r0; k += 32) {
+            d2 a[4];
+            double b[8];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[v] = *(const d2 *)(pa + k + 2 * v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = Xm[(long)(k + 8 * q + e) * ldx + colc];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = MFMA_F64(-a[e >> 1][e & 1], b[e], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[16 * rt + q + 4 * r][col] = acc[r];
+        __syncthreads();
+        d4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < 8; ++sk) y = MFMA_F64(dinv[16 * rt + i16][4 * sk + q], rs[4 * sk + q][col], y);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = r0 + 16 * rt + q + 4 * r;
+            if (row < n && colok) Xm[row * ldx + col] = y[r];
+        }
+        __syncthreads(); // Y of this block row is in memory, rs / dinv are free
+    }
+    // ---- backward: L^T X = Y, block rows bottom up ----
+    for (int ib = nblk - 1; ib >= 0; --ib) {
+        const int c0 = ib << 5;
+        for (int e = tid; e < 1024; e += 512) dinv[e >> 5][e & 31] = iv[(size_t)ib * 1024 + e];
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = c0 + 16 * rt + q + 4 * r;
+            acc[r] = (row < n && colok) ? Xm[row * ldx + col] : 0.0;
+        }
+        long ac = c0 + 16 * rt + i16;        // column of L = row of L^T this lane feeds as the A operand
+        ac = ac < n ? ac : n - 1;
+        for (int k = c0 + 32; k < n_; k += 32) {
+            double a[8], b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long kk = k + 8 * q + e;
+                const bool ok = kk < n;
+                const long kc = ok ? kk : n - 1;
+                const double av = Lm[kc * n + ac], bv = Xm[kc * ldx + colc];
+                a[e] = ok ? av : 0.0;
+                b[e] = ok ? bv : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = MFMA_F64(-a[e], b[e], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[16 * rt + q + 4 * r][col] = acc[r];
+        __syncthreads();
+        d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < 8; ++sk) x = MFMA_F64(dinv[4 * sk + q][16 * rt + i16], rs[4 * sk + q][col], x); // inv(L_ii)^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = c0 + 16 * rt + q + 4 * r;
+            if (row < n && colok) Xm[row * ldx + col] = x[r];
+        }
+        __syncthreads();
+    }
+}
+
+int tvk_chol_solve_multi_batched(hipStream_t st, int n, int nb, int nrhs, const double *Lf, const double *invd, const double *B, long ldb,
+                                 long sB, double *X, long ldx, long sX)
+{
+    if (nb <= 0 || n <= 0 || nrhs <= 0) return 0;
+    if (nrhs > 64 || (n & 1)) return -1; // the caller keeps the explicit inverse
+    k_chol_solve_multi<<<nb, 512, 0, st>>>(n, nrhs, Lf, invd, (long)((n + 31) / 32) * 1024, B, ldb, sB, X, ldx, sX);
+    return (int)hipGetLastError();
+}
+
 // Dynamic LDS of the three kernels and whether the panel rows fit next to the static arrays (160 KB per workgroup on gfx950)
 namespace {
 struct CholLds { int use; size_t chol, trinv, uut; };

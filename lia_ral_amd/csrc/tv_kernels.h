@@ -7,6 +7,8 @@ int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alph
 int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, double *panel, int *status);
 int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked = nullptr,
                           long spk = 0, double diag_add = 0.0);
+int tvk_chol_solve_multi_batched(hipStream_t st, int n, int nb, int nrhs, const double *Lf, const double *invd, const double *B, long ldb,
+                                 long sB, double *X, long ldx, long sX); // -1: nrhs > 64 or odd n (use the explicit inverse)
 int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read packed lower rows directly
 // A/B switches: thread-local (they act on the launches of the calling host thread); return the previous value
 int tvk_set_chol_gemm_path(int on);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of chol_fused.hip's panel-row source (option "chol_lds": 1 = staged once per workgroup in LDS, 0 = fetched by every wave):
-T-matrix E-step, M-step and i-vector solve at C = 2048, R = 400; results must agree to rounding."""
+T-matrix E-step, M-step (by substitution, and with the explicit inverse: option "tv_mstep_solve") and i-vector solve at C = 2048,
+R = 400; results must agree to rounding."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,7 +37,11 @@ for mode in (0, 1, 0, 1):
     a = t(lambda: ctx.tv_estimate_w(N, F, Tm, invvar, tett, C, D, out=W)); keep[key + "W"] = W.clone()
     b = t(estep, 2); keep[key + "A"] = acc["A"].clone()
     c = t(lambda: ctx.tv_update_t(acc["A"], acc["Cmx"], C, D, out=Tn), 2); keep[key + "T"] = Tn.clone()
-    out.setdefault(key, []).append({"estimate_w_ms": a, "estep_ms": b, "mstep_ms": c})
+    ctx.set_option("tv_mstep_solve", 0)
+    c0 = t(lambda: ctx.tv_update_t(acc["A"], acc["Cmx"], C, D, out=Tn), 2); keep[key + "Tinv"] = Tn.clone()
+    ctx.set_option("tv_mstep_solve", 1)
+    out.setdefault(key, []).append({"estimate_w_ms": a, "estep_ms": b, "mstep_ms": c, "mstep_explicit_inverse_ms": c0})
 for k in "WAT":
     out["max_rel_diff_" + k] = float(((keep["lds" + k] - keep["mem" + k]).abs().max() / keep["mem" + k].abs().max()).item())
+out["max_rel_diff_T_solve_vs_inverse"] = float(((keep["ldsT"] - keep["ldsTinv"]).abs().max() / keep["ldsTinv"].abs().max()).item())
 print(json.dumps(out))
