@@ -252,7 +252,9 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
     if ((rc = c->scratch(WS_AUX, (size_t)BC * R * 8, &p))) { free_owned(); return rc; }
     double *aux = (double *)p;
     const int nz = tvk_splitk_count(BC, R, (int)SV, c->n_cu);
-    if ((rc = c->scratch(WS_SLAB, (size_t)nz * BC * R * 8, &p))) { free_owned(); return rc; }
+    size_t slab_doubles = (size_t)nz * BC * R;
+    if (accumulate && slab_doubles < (size_t)TVK_BATCH_SUM_SLABS * P) slab_doubles = (size_t)TVK_BATCH_SUM_SLABS * P; // also the partial sums of sum_u E_u
+    if ((rc = c->scratch(WS_SLAB, slab_doubles * 8, &p))) { free_owned(); return rc; }
     double *slabs = (double *)p;
     InvWs ws;
     if ((rc = ws.init(c, R, BC))) { free_owned(); return rc; }
@@ -289,7 +291,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
             if (!packed_in) GCHK(tvk_pack_sym(c->stream, R, nb, ws.inv, (long)RR, Wc, Lp, (long)P));
             GCHK(tvk_dgemm(c->stream, true, false, C, (int)P, nb, 1.0, Nc, C, 0, Lp, (long)P, 0, 1.0, d_a, (long)P, 0, 1));
             GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, nb, 1.0, Wc, R, 0, Fc, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
-            GCHK(tvk_batch_sum(c->stream, (long)P, nb, Lp, (long)P, d_rp));
+            GCHK(tvk_batch_sum(c->stream, (long)P, nb, Lp, (long)P, d_rp, slabs)); // slabs (split-K workspace of aux) is free again
             GCHK(tvk_batch_sum(c->stream, R, nb, Wc, R, d_r));
             GCHK(tvk_batch_sum(c->stream, R, nb, Wc, R, d_mw));
         }
@@ -1365,11 +1367,15 @@ int gmmiv_score_plda(gmmiv_ctx *c, int rf, int64_t M, int64_t S, const double *m
     const size_t nn = (size_t)rf * rf;
     std::vector<double> hF(nn);
     GCHK(hipMemcpy(hF.data(), FTJF, nn * 8, gmmiv_is_device_ptr(FTJF) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
-    // K_n = (n FTJF + I)^-1 and alpha_n = log det K_n on the host, cached per n
-    struct KN { std::vector<double> K; double alpha; };
-    std::map<int64_t, KN> cache;
+    // K_n = (n FTJF + I)^-1 and alpha_n = log det K_n on the host, cached per n in the context for as long as FTJF is unchanged
+    typedef gmmiv_ctx::PldaK KN;
+    if (c->plda_ftjf.size() != nn || memcmp(c->plda_ftjf.data(), hF.data(), nn * 8) != 0) {
+        c->plda_ftjf = hF;
+        c->plda_k.clear();
+    }
+    std::map<long, KN> &cache = c->plda_k;
     auto getK = [&](int64_t n) -> const KN * {
-        auto it = cache.find(n);
+        auto it = cache.find((long)n);
         if (it != cache.end()) return &it->second;
         std::vector<double> t(nn);
         for (size_t e = 0; e < nn; ++e) t[e] = (double)n * hF[e];
@@ -1378,7 +1384,7 @@ int gmmiv_score_plda(gmmiv_ctx *c, int rf, int64_t M, int64_t S, const double *m
         double ld;
         if (!host_spd_inverse(rf, t, kn.K, &ld)) return nullptr;
         kn.alpha = -ld; // log det K = -log det (nFTJF + I)
-        return &cache.emplace(n, std::move(kn)).first->second;
+        return &cache.emplace((long)n, std::move(kn)).first->second;
     };
     const KN *K1 = getK(1);
     if (!K1) { gmmiv_set_error("score_plda: FTJF + I is not positive definite"); return GMMIV_ERR_NUMERIC; }

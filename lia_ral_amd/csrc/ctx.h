@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,11 @@ struct gmmiv_ctx {
     // than half of the memory that is free when the scratch is first needed.
     long z_scratch_mb = 65536;
     int n_cu = 256;
+    // gmmiv_score_plda: K_n = (n FTJF + I)^-1 and log det K_n per session count n, kept while FTJF stays the same matrix
+    // (each costs an O(rankF^3) inverse on the host: 3 ms per call at rankF = 200 when recomputed every time)
+    std::vector<double> plda_ftjf;
+    struct PldaK { std::vector<double> K; double alpha; };
+    std::map<long, PldaK> plda_k;
     // communicators created on this context (capi_comm.hip): released with the context if the caller has not done so
     std::vector<struct gmmiv_comm *> comms;
     size_t total_mem = 0; // device memory size (bounds the likelihood scratch deterministically)

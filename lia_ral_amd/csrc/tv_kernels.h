@@ -24,7 +24,8 @@ int tvk_scale_cols(hipStream_t st, long rows, long cols, const double *in, const
 int tvk_unpack_sym(hipStream_t st, int n, int nb, const double *packed, long sp, double *full, double diag_add);
 int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, const double *w, double *packed, long sp);
 int tvk_merge_rows(hipStream_t st, long ndst, long width, const long *off, const long *rows, const double *src, double *dst);
-int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst);
+#define TVK_BATCH_SUM_SLABS 16
+int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst, double *tmp = nullptr); // tmp: SLABS * n doubles
 int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full);
 int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y);
 int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const double *Mx, double *y);
