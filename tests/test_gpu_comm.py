@@ -143,3 +143,26 @@ def test_two_rank_rccl_through_the_c_abi(tmp_path):
         assert np.array_equal(res[r][3], full)
         assert np.array_equal(res[r][4], np.full(7, float(tot)))
         assert "rccl" in res[r][5]
+
+
+@pytest.mark.parametrize("extra", [["--workload", "tv", "--tv-utterances", "300", "--steps", "2", "--warmup", "1"],
+                                   ["--frames", "300000", "--steps", "1", "--warmup", "1", "--no-secondary"]])
+def test_bench_cli_emits_the_contract_line(extra):
+    """bench.py as the driver launches it (one rank): one JSON line with the contract's keys, roofline and cpu_baseline objects;
+    the T-matrix workload stays finite over consecutive EM iterations."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "collectives"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f64" and "workload" in d["config"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert "gmmiv_comm" in d["collectives"]
+    if "tv" in extra:
+        assert d["finite"] and set(d["phases_ms"]) >= {"tett", "estep", "update_t", "min_divergence"}
