@@ -12,7 +12,8 @@ except Exception:  # pragma: no cover - torch is optional for the binding itself
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgmmiv.so")
+# GMMIV_LIB_PATH: development knob (tools/k1_ablate.sh times instrumented builds of the same library); still libgmmiv, never a fallback
+LIB_PATH = os.environ.get("GMMIV_LIB_PATH") or os.path.join(_HERE, "csrc", "libgmmiv.so")
 
 F32, F64 = 0, 1
 TOP_PARTIAL, TOP_COMPLETE = 0, 1

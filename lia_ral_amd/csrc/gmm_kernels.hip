@@ -107,6 +107,11 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // direct-form logits of the survivors, ranking, remainder.  zbuf = the record array, eit = the per-frame candidate counts,
 // inv_out = the non-appended sums (2^-Efin), lse_out = the final thresholds.
 #define TOPC_CAP 256
+// K1_ABL (compile-time, timing experiments only -- tools/k1_ablate.sh; results are wrong when != 0): 1 = no epilogue, 2 = exp table read
+// from one address, 4 = no likelihood stores, 8 = no DPP row maximum, 16 = no staging / barrier, 32 = no stores of the running exponents
+#ifndef K1_ABL
+#define K1_ABL 0
+#endif
 template <int KS, typename XT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ Pt, int nct,
@@ -225,6 +230,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     }
     };
     auto epi_phase = [&](int te) __attribute__((always_inline)) {
+        if (K1_ABL & 1) {
+#pragma unroll
+            for (int g = 0; g < GT; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(acc[g][h]));
+            return;
+        }
         // Online log-sum-exp per (lane, frame row) with an INTEGER reference: the sum is kept as
         // sacc * 2^E.  exp(z) = t * 2^n (t in [1,2)) is added as ldexp(t, n - E); when a logit's n
         // exceeds E by 64 or more the reference moves with one ldexp (no exp, no fp64 compare
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     acc[0][h][r] = r0;
                     acc[1][h][r] = r1;
                     const int km = k0[h][r] > k1[h][r] ? k0[h][r] : k1[h][r];
-                    nm[h][r] = row_max_i32(km >> GEXP_TAB_BITS);
+                    nm[h][r] = (K1_ABL & 8) ? km >> GEXP_TAB_BITS : row_max_i32(km >> GEXP_TAB_BITS);
                     grow |= nm[h][r] - E[h][r] >= 64;
                 }
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {
@@ -368,8 +380,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double e0 = gexp_tab_finish(k0[h][r], acc[0][h][r], E[h][r], etab);
-                    const double e1 = gexp_tab_finish(k1[h][r], acc[1][h][r], E[h][r], etab);
+                    const double e0 = gexp_tab_finish(k0[h][r], acc[0][h][r], E[h][r], (K1_ABL & 2) ? etab - (k0[h][r] & (GEXP_TAB_N - 1)) : etab);
+                    const double e1 = gexp_tab_finish(k1[h][r], acc[1][h][r], E[h][r], (K1_ABL & 2) ? etab - (k1[h][r] & (GEXP_TAB_N - 1)) : etab);
                     sacc[h][r] += e0 + e1;
                     acc[0][h][r] = e0;
                     acc[1][h][r] = e1;
@@ -381,11 +393,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // unconditional stores: zbuf / eit cover the whole grid (nfb = 16 blocks per workgroup)
             double *zw = zbuf + ((((size_t)(te * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
+            if (K1_ABL & 4) {
+#pragma unroll
+                for (int g = 0; g < GT; ++g)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(acc[g][h]));
+                return;
+            }
 #pragma unroll
             for (int g = 0; g < GT; ++g)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) __builtin_nontemporal_store(acc[g][h], (d4 *)(zw + ((size_t)g * nfb + h) * 256)); // streamed: keep the model tiles in L2
-            if (i16 == 0) {
+            if (i16 == 0 && !(K1_ABL & 32)) {
                 int *ew = eit + (size_t)te * (nfb * 16) + tb + q;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -445,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     auto step = [&](int tl, bool staged, bool is_late, bool first) __attribute__((always_inline)) {
         double *cur = (tl & 1) ? buf1 : buf0;
         double *nxt = (tl & 1) ? buf0 : buf1;
-        if (staged && (TC || dbg < 2)) stage(nxt, tl + 1);
+        if (staged && (TC || dbg < 2) && !(K1_ABL & 16)) stage(nxt, tl + 1);
         if (!is_late) {
             mfma_phase(cur);
             epi_phase(tl);
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             // stores (the DMA was issued a whole MFMA phase earlier); late waves issued their stores a
             // whole MFMA phase ago, so draining everything here costs them nothing.
             if (is_late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(K1_ABL & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             __syncthreads();
         }
