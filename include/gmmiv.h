@@ -66,7 +66,7 @@ const char *gmmiv_version(void);
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one
  *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
- *                      used for odd orders); A/B switch of the calling host thread (like "gemm_remap", "gemm_clamp", "z_tv4")
+ *                      used for odd orders); A/B switch of the calling host thread (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
  *   "topc_fused" 1     DETERMINE_TOP_DISTRIBS with the candidates collected in the epilogue of the MFMA log-likelihood kernel
  *                      (k_llk_mfma<TC> + k_topc_rank; C' <= 16, C <= 2048, D <= 64); 0 or not applicable: "topc_z".
  *                      "topc_fallbacks" counts the calls the fused path handed on (candidate list overflow / margin check)

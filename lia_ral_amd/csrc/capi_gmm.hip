@@ -109,6 +109,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     if (!strcmp(key, "gemm_clamp")) { // A/B knob: 0 = cut GEMM tiles on the per-element checked instantiation
         return tvk_set_gemm_clamp((int)value);
     }
+    if (!strcmp(key, "gemm_narrow")) return tvk_set_gemm_narrow((int)value); // A/B knob: 0 = 128 x 128 tiles on the strips cut by M / N too
     if (!strcmp(key, "chol_lds")) return tvk_set_chol_lds((int)value); // A/B knob: 0 = panel rows from memory per wave
     if (!strcmp(key, "chol_gemm")) { // A/B knob: the GEMM-built batched Cholesky instead of k_chol_left
         return tvk_set_chol_gemm_path((int)value);

@@ -14,6 +14,7 @@ int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read
 int tvk_set_chol_gemm_path(int on);
 int tvk_set_chol_lds(int on);   // 0: the panel rows of chol_fused.hip from memory per wave (round 1) instead of LDS
 int tvk_set_gemm_clamp(int on);
+int tvk_set_gemm_narrow(int on); // 0 = 128 x 128 tiles on the strips cut by M / N as well (default: 32-wide tiles on strips of <= 64)
 int tvk_set_gemm_remap(int on);
 int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status,
                                  const double *Apacked = nullptr, long spk = 0, double diag_add = 0.0);

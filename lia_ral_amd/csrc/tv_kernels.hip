@@ -24,20 +24,28 @@ __device__ __forceinline__ int kswz(int k) { return (k & 15) ^ ((k & 1) << 4); }
 //                 accumulators in AGPRs and pays 2 v_accvgpr moves per MFMA (measured: core loop 56 instead of
 //                 73 TFLOP/s, tools/gemm_probe.hip).
 //   EDGE = true   tiles cut by M, N or K: per-element loads with bounds checks (the original path).
-// bm0 / bn0: block offsets of the launched sub-grid (interior, right strip, bottom strip).
+// m_off / n_off: element offsets of the launched sub-grid (interior, right strip, bottom strip).
 // Fused epilogue on the accumulator v = alpha * acc (before the beta term):
 //   mode 1: v * rv[m] * cv[n]                         (cosine scoring: the two reciprocal norms)
 //   mode 2: v + br * rv[m] + bc * cv[n] + cst         (quadratic-form scoring rules: the per-model / per-segment terms)
 // One pass over the M x N result instead of GEMM + a read-modify-write kernel (3.2 GB each way at 20 k x 20 k).
 struct DgemmEpi { const double *rv, *cv; double br, bc, cst; int mode; int remap; };
 
-template <bool TA, bool TB, int MODE>
+// AM x AN: 16 x 16 MFMA tiles per wave (2 x 2 waves): the workgroup tile is 32 AM x 32 AN.  4 x 4 everywhere except on the strips that
+// M or N cut off a 128-multiple (MODE 2 only): 1 x 4 (32 x 128) below, 4 x 1 (128 x 32) to the right -- with R = 400 = 3 x 128 + 16
+// a 128-row strip tile spends 7/8 of its MFMAs on clamped duplicates (Cmx += W^T F at 400 x 122880 x 1024: 2.04 ms against 1.55 ms
+// for 384 rows).
+template <bool TA, bool TB, int MODE, int AM = 4, int AN = 4>
 __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                   long lda, long sA, const double *__restrict__ B, long ldb, long sB,
-                                                  double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int bm0, int bn0,
+                                                  double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int m_off, int n_off,
                                                   DgemmEpi epi)
 {
-    constexpr int BM = 128, BN = 128, BK = 16;
+    constexpr int BM = 32 * AM, BN = 32 * AN, BK = 16;
+    static_assert(MODE == 2 || (AM == 4 && AN == 4), "narrow tiles exist for the clamped strips only");
+    constexpr int NLA = BM / 32, NLB = BN / 32;           // 16-byte staging loads per thread and k-tile
+    constexpr int HA = BM / 2, HB = BN / 2;               // column pairs of an m- (n-) fastest operand tile
+    constexpr int KSA = 256 / HA, KSB = 256 / HB;         // k rows covered by one such load of the workgroup
     __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) double Bs[2][BK][BN];
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
             bx = G * 8 + r / Mt;
         }
     }
-    const long m0 = (long)(by + bm0) * BM, n0 = (long)(bx + bn0) * BN;
+    const long m0 = (long)by * BM + m_off, n0 = (long)bx * BN + n_off;
     // ksplit > 0: blockIdx.z selects a K range [kb, ke) and C is the z-th partial slab (stride sC);
     // otherwise blockIdx.z is the batch index.
     long kb = 0, ke = K;
@@ -79,37 +87,40 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
     // ---- staging: EDGE -> 8 + 8 checked scalar loads; interior -> 4 + 4 unchecked 16-byte loads -----------
     constexpr bool EDGE = MODE == 1; // per-element checked loads
     constexpr bool CHECK_OUT = MODE != 0;
-    double ra[8], rb[8];
+    double ra[EDGE ? 8 : 2 * NLA], rb[EDGE ? 8 : 2 * NLB];
     // interior path: operand with k fastest in memory: thread owns k pair kq = 2 (tid & 7), rows (tid >> 3) + 32 i;
-    //                operand with m (n) fastest:       thread owns column pair 2 (tid & 63), k rows (tid >> 6) + 4 i
+    //                operand with m (n) fastest:       thread owns column pair 2 (tid % HA), k rows tid / HA + KSA i  (128 wide: 2 (tid & 63), (tid >> 6) + 4 i)
     // MODE 2 (tiles cut by M or N, K range still a multiple of 16): the same loads with the row / column-pair index CLAMPED
     // into the matrix -- an output element depends only on its own row of op(A) and column of op(B), so the clamped
     // duplicates only feed outputs that are not stored.  No check inside the k loop.
     const double *pa = nullptr, *pb = nullptr;
-    long oa[4] = {0, 0, 0, 0}, ob[4] = {0, 0, 0, 0}; // element offsets of the 4 loads of a k-tile
+    long oa[4] = {0, 0, 0, 0}, ob[4] = {0, 0, 0, 0}; // element offsets of the (up to 4) loads of a k-tile
     if (!EDGE) {
-        long ma = m0 + (TA ? 2 * (tid & 63) : (tid >> 3)), nb_ = n0 + (TB ? (tid >> 3) : 2 * (tid & 63));
+        long ma = m0 + (TA ? 2 * (tid % HA) : (tid >> 3)), nb_ = n0 + (TB ? (tid >> 3) : 2 * (tid % HB));
         if (MODE == 2) {
             if (TA) ma = ma < M - 2 ? ma : M - 2;
             if (!TB) nb_ = nb_ < N - 2 ? nb_ : N - 2;
         }
-        pa = TA ? A + (kb + (tid >> 6)) * lda + ma : A + kb + 2 * (tid & 7);
-        pb = TB ? B + kb + 2 * (tid & 7) : B + (kb + (tid >> 6)) * ldb + nb_;
+        pa = TA ? A + (kb + tid / HA) * lda + ma : A + kb + 2 * (tid & 7);
+        pb = TB ? B + kb + 2 * (tid & 7) : B + (kb + tid / HB) * ldb + nb_;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long ri = ma + 32 * i, ci = nb_ + 32 * i;
             if (MODE == 2) { ri = ri < M - 1 ? ri : M - 1; ci = ci < N - 1 ? ci : N - 1; }
-            oa[i] = TA ? (long)(4 * i) * lda : ri * lda;
-            ob[i] = TB ? ci * ldb : (long)(4 * i) * ldb;
+            oa[i] = TA ? (long)(KSA * i) * lda : ri * lda;
+            ob[i] = TB ? ci * ldb : (long)(KSB * i) * ldb;
         }
     }
     auto gload = [&](int kt) {
         if (!EDGE) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NLA; ++i) {
                 const d2 va = *(const d2 *)(pa + oa[i]);
-                const d2 vb = *(const d2 *)(pb + ob[i]);
                 ra[2 * i] = va[0]; ra[2 * i + 1] = va[1];
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                const d2 vb = *(const d2 *)(pb + ob[i]);
                 rb[2 * i] = vb[0]; rb[2 * i + 1] = vb[1];
             }
             pa += TA ? (long)BK * lda : BK;
@@ -144,13 +155,19 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
     const int krem = EDGE ? 0 : (int)((ke - kb) & 15);
     auto gload_tail = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ka = TA ? (tid >> 6) + 4 * i : 2 * (tid & 7), kb_ = TB ? 2 * (tid & 7) : (tid >> 6) + 4 * i;
-            const bool oka = ka < krem, okb = kb_ < krem;
+        for (int i = 0; i < NLA; ++i) {
+            const int ka = TA ? tid / HA + KSA * i : 2 * (tid & 7);
+            const bool oka = ka < krem;
             const double *qa = pa + oa[i] - (oka ? 0L : (TA ? (long)ka * lda : (long)ka));
-            const double *qb = pb + ob[i] - (okb ? 0L : (TB ? (long)kb_ : (long)kb_ * ldb));
-            const d2 va = *(const d2 *)qa, vb = *(const d2 *)qb;
+            const d2 va = *(const d2 *)qa;
             ra[2 * i] = oka ? va[0] : 0.0; ra[2 * i + 1] = oka ? va[1] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int kb_ = TB ? 2 * (tid & 7) : tid / HB + KSB * i;
+            const bool okb = kb_ < krem;
+            const double *qb = pb + ob[i] - (okb ? 0L : (TB ? (long)kb_ : (long)kb_ * ldb));
+            const d2 vb = *(const d2 *)qb;
             rb[2 * i] = okb ? vb[0] : 0.0; rb[2 * i + 1] = okb ? vb[1] : 0.0;
         }
     };
@@ -158,11 +175,14 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         constexpr int buf = decltype(bufc)::value;
         if (!EDGE) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (TA) { const int k = (tid >> 6) + 4 * i, m = 2 * (tid & 63); As[buf][k][m ^ kswz(k)] = ra[2 * i]; As[buf][k][(m + 1) ^ kswz(k)] = ra[2 * i + 1]; }
+            for (int i = 0; i < NLA; ++i) {
+                if (TA) { const int k = tid / HA + KSA * i, m = 2 * (tid % HA); As[buf][k][m ^ kswz(k)] = ra[2 * i]; As[buf][k][(m + 1) ^ kswz(k)] = ra[2 * i + 1]; }
                 else { const int k = 2 * (tid & 7), m = (tid >> 3) + 32 * i; As[buf][k][m ^ kswz(k)] = ra[2 * i]; As[buf][k + 1][m ^ kswz(k + 1)] = ra[2 * i + 1]; }
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
                 if (TB) { const int k = 2 * (tid & 7), n = (tid >> 3) + 32 * i; Bs[buf][k][n ^ kswz(k)] = rb[2 * i]; Bs[buf][k + 1][n ^ kswz(k + 1)] = rb[2 * i + 1]; }
-                else { const int k = (tid >> 6) + 4 * i, n = 2 * (tid & 63); Bs[buf][k][n ^ kswz(k)] = rb[2 * i]; Bs[buf][k][(n + 1) ^ kswz(k)] = rb[2 * i + 1]; }
+                else { const int k = tid / HB + KSB * i, n = 2 * (tid % HB); Bs[buf][k][n ^ kswz(k)] = rb[2 * i]; Bs[buf][k][(n + 1) ^ kswz(k)] = rb[2 * i + 1]; }
             }
             return;
         }
@@ -182,11 +202,11 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         }
     };
 
-    d4 acc[4][4];
+    d4 acc[AM][AN];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (d4){0, 0, 0, 0};
+        for (int b = 0; b < AN; ++b) acc[a][b] = (d4){0, 0, 0, 0};
 
     const int nkt = (int)((ke - kb + BK - 1) / BK);
     if (nkt > 0) {
@@ -208,15 +228,15 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         for (int ks = 0; ks < 4; ++ks) {
             const int k = 4 * ks + q;
             const int sw = kswz(k);
-            double av[4], bv[4];
+            double av[AM], bv[AN];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = As[cur][k][(wr * 64 + a * 16 + i16) ^ sw];
+            for (int a = 0; a < AM; ++a) av[a] = As[cur][k][(wr * (16 * AM) + a * 16 + i16) ^ sw];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = Bs[cur][k][(wc * 64 + b * 16 + i16) ^ sw];
+            for (int b = 0; b < AN; ++b) bv[b] = Bs[cur][k][(wc * (16 * AN) + b * 16 + i16) ^ sw];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < AM; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < AN; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);
         }
         if (kt + 1 < nkt) swrite(std::integral_constant<int, cur ^ 1>{});
         __syncthreads();
@@ -226,51 +246,72 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         if (kt + 1 < nkt) ktile(std::integral_constant<int, 1>{}, kt + 1);
     }
     // D layout: lane holds rows q + 4r, column i16 of every 16x16 tile
-    double cvv[4] = {0.0, 0.0, 0.0, 0.0};
+    double cvv[AN];
+#pragma unroll
+    for (int b = 0; b < AN; ++b) cvv[b] = 0.0;
     if (epi.mode != 0) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const long gn = n0 + wc * 64 + b * 16 + i16;
+        for (int b = 0; b < AN; ++b) {
+            const long gn = n0 + wc * (16 * AN) + b * 16 + i16;
             cvv[b] = (!CHECK_OUT || gn < N) ? epi.cv[gn] : 0.0;
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < AM; ++a) {
+        // beta != 0: the 16 old values of this row block are requested TOGETHER, before the first store -- read one by one inside
+        // the store loop every load waits behind the previous store to the same array (may alias: the compiler keeps the order
+        // and each load pays its full latency; A += N^T E at K = 1024: 5.64 -> 5.13 ms)
+        double cin[4][AN];
+        if (beta != 0.0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long gm = m0 + wr * (16 * AM) + a * 16 + q + 4 * r;
+#pragma unroll
+                for (int b = 0; b < AN; ++b) {
+                    const long gn = n0 + wc * (16 * AN) + b * 16 + i16;
+                    cin[r][b] = (!CHECK_OUT || (gm < M && gn < N)) ? C[gm * ldc + gn] : 0.0;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long gm = m0 + wr * 64 + a * 16 + q + 4 * r;
+            const long gm = m0 + wr * (16 * AM) + a * 16 + q + 4 * r;
             if (CHECK_OUT && gm >= M) continue;
             const double rvv = epi.mode != 0 ? epi.rv[gm] : 0.0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const long gn = n0 + wc * 64 + b * 16 + i16;
+            for (int b = 0; b < AN; ++b) {
+                const long gn = n0 + wc * (16 * AN) + b * 16 + i16;
                 if (CHECK_OUT && gn >= N) continue;
                 double v = alpha * acc[a][b][r];
                 if (epi.mode == 1) v = v * rvv * cvv[b];
                 else if (epi.mode == 2) v = v + epi.br * rvv + epi.bc * cvv[b] + epi.cst;
-                if (beta != 0.0) { v += beta * C[gm * ldc + gn]; C[gm * ldc + gn] = v; }
+                if (beta != 0.0) C[gm * ldc + gn] = v + beta * cin[r][b];
                 else if (epi.mode != 0) __builtin_nontemporal_store(v, &C[gm * ldc + gn]); // score matrices (GBs, written once): streamed past L2
                 else C[gm * ldc + gn] = v;
             }
         }
+    }
 }
 
-template <int MODE>
+// m_off / n_off: element offsets of the launched sub-grid (interior, right strip, bottom strip)
+template <int MODE, int AM = 4, int AN = 4>
 static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int N, int K, double alpha, const double *A,
                            long lda, long sA, const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC,
-                           int ksplit, int bm0, int bn0, const DgemmEpi &epi)
+                           int ksplit, int m_off, int n_off, const DgemmEpi &epi)
 {
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
-    if (!ta && !tb) k_dgemm<false, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
-    else if (!ta && tb) k_dgemm<false, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
-    else if (ta && !tb) k_dgemm<true, false, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
-    else k_dgemm<true, true, MODE><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, bm0, bn0, epi);
+    if (!ta && !tb) k_dgemm<false, false, MODE, AM, AN><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, m_off, n_off, epi);
+    else if (!ta && tb) k_dgemm<false, true, MODE, AM, AN><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, m_off, n_off, epi);
+    else if (ta && !tb) k_dgemm<true, false, MODE, AM, AN><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, m_off, n_off, epi);
+    else k_dgemm<true, true, MODE, AM, AN><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, m_off, n_off, epi);
 }
 
 static thread_local int g_gemm_remap = 1; // A/B knob: XCD-aware tile order
 int tvk_set_gemm_remap(int on) { const int prev = g_gemm_remap; g_gemm_remap = on; return prev; }
 static thread_local int g_gemm_clamp = 1; // A/B knob: 0 = cut tiles always on the per-element checked instantiation
 int tvk_set_gemm_clamp(int on) { const int prev = g_gemm_clamp; g_gemm_clamp = on; return prev; }
+static thread_local int g_gemm_narrow = 1; // A/B knob: 0 = 128 x 128 tiles on the strips too
+int tvk_set_gemm_narrow(int on) { const int prev = g_gemm_narrow; g_gemm_narrow = on; return prev; }
 
 // grid.z = batch (ksplit == 0) or K layers (ksplit > 0).  Three instantiations: full tiles run MODE 0 (no checks at all) when
 // every K range is a multiple of 16 and the operands allow 16-byte loads; tiles cut by M or N run MODE 2 (the same loads,
@@ -318,11 +359,19 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
     }
     hipStream_t ss = forked ? side : st;
     if (clamp_ok) {
-        if ((int)grid.x > fn) launch_dgemm_e<2>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn, epi);
-        if ((int)grid.y > fm) launch_dgemm_e<2>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0, epi);
+        // strips of at most 64 rows / columns run 32-wide tiles (g_gemm_narrow: A/B knob)
+        const int rm = M - fm * 128, rn = N - fn * 128;
+        if ((int)grid.x > fn) {
+            if (g_gemm_narrow && rn <= 64) launch_dgemm_e<2, 4, 1>(ss, ta, tb, dim3((rn + 31) / 32, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn * 128, epi);
+            else launch_dgemm_e<2>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn * 128, epi);
+        }
+        if ((int)grid.y > fm) {
+            if (g_gemm_narrow && rm <= 64) launch_dgemm_e<2, 1, 4>(ss, ta, tb, dim3(fn, (rm + 31) / 32, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm * 128, 0, epi);
+            else launch_dgemm_e<2>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm * 128, 0, epi);
+        }
     } else {
-        if ((int)grid.x > fn) launch_dgemm_e<1>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn, epi);
-        if ((int)grid.y > fm) launch_dgemm_e<1>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm, 0, epi);
+        if ((int)grid.x > fn) launch_dgemm_e<1>(ss, ta, tb, dim3(grid.x - fn, grid.y, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, fn * 128, epi);
+        if ((int)grid.y > fm) launch_dgemm_e<1>(ss, ta, tb, dim3(fn, grid.y - fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, fm * 128, 0, epi);
     }
     launch_dgemm_e<0>(st, ta, tb, dim3(fn, fm, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
     if (forked) {

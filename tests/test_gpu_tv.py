@@ -84,7 +84,8 @@ def test_tv_em_iteration(ctx, C, D, R, U):
 def test_dgemm_shapes_through_scoring(ctx):
     """The MFMA GEMM behind every TV step: odd sizes, all transposes exercised via the score rules."""
     rng = np.random.default_rng(1)
-    for dim, M, S in [(5, 3, 7), (50, 130, 129), (400, 260, 17), (33, 1, 300)]:
+    # (64, 400, 432), (400, 190, 150), (30, 258, 322): even sizes a little over a multiple of 128 -> the 32-wide strip tiles, both sides
+    for dim, M, S in [(5, 3, 7), (50, 130, 129), (400, 260, 17), (33, 1, 300), (64, 400, 432), (400, 190, 150), (30, 258, 322)]:
         m = rng.normal(size=(dim, M)); s = rng.normal(size=(dim, S))
         assert relerr(ctx.score_cosine(m, s), orc.score_cosine(m, s)) < 1e-12
         Q = rng.normal(size=(dim, dim)); Mah = Q @ Q.T / dim + np.eye(dim)

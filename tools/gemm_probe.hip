@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 
-struct Shape { const char *name; bool ta, tb; int M, N, K; };
+struct Shape { const char *name; bool ta, tb; int M, N, K; double beta = 0.0; };
 
 int main()
 {
@@ -17,7 +17,17 @@ int main()
         {"scores: 20000 x 20000 x 400 TN", true, false, 20000, 20000, 400},
         {"scores: 20000 x 20000 x 200 TN", true, false, 20000, 20000, 200},
         {"scores: 20000 x 20000 x 16 TN (store-bound probe)", true, false, 20000, 20000, 16},
-        {"aux = F Tiv^T: 1024 x 400 x 122880 NT", false, true, 1024, 400, 122880},
+        {"aux = F Tiv^T: 1024 x 400 x 122880 NT (one K layer; the product splits K)", false, true, 1024, 400, 122880},
+        {"L = N TETt: 1024 x 80200 x 2048 NN", false, false, 1024, 80200, 2048},
+        {"L, N a multiple of 128: 1024 x 80128 x 2048 NN", false, false, 1024, 80128, 2048},
+        {"A += N^T E: 2048 x 80200 x 1024 TN beta 1", true, false, 2048, 80200, 1024, 1.0},
+        {"A  = N^T E: 2048 x 80200 x 1024 TN beta 0", true, false, 2048, 80200, 1024},
+        {"A  = N E (NN): 2048 x 80200 x 1024 NN beta 0", false, false, 2048, 80200, 1024},
+        {"Cmx += W^T F: 400 x 122880 x 1024 TN beta 1", true, false, 400, 122880, 1024, 1.0},
+        {"Cmx, 384 rows: 384 x 122880 x 1024 TN beta 1", true, false, 384, 122880, 1024, 1.0},
+        {"4096 x 4096 x 1024 NN", false, false, 4096, 4096, 1024},
+        {"4096 x 4096 x 2048 NN", false, false, 4096, 4096, 2048},
+        {"8192 x 8192 x 2048 NN", false, false, 8192, 8192, 2048},
         {"T_c = A_c^-1 C_c: 400 x 60 x 400 NN", false, false, 400, 60, 400},
     };
     hipStream_t st;
@@ -26,21 +36,21 @@ int main()
         const size_t na = (size_t)s.M * s.K, nb = (size_t)s.K * s.N, nc = (size_t)s.M * s.N;
         double *A, *B, *C;
         hipMalloc(&A, na * 8); hipMalloc(&B, nb * 8); hipMalloc(&C, nc * 8);
-        hipMemset(A, 0, na * 8); hipMemset(B, 0, nb * 8);
+        hipMemset(A, 0, na * 8); hipMemset(B, 0, nb * 8); hipMemset(C, 0, nc * 8);
         const long lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        tvk_dgemm(st, s.ta, s.tb, s.M, s.N, s.K, 1.0, A, lda, 0, B, ldb, 0, 0.0, C, s.N, 0, 1);
+        tvk_dgemm(st, s.ta, s.tb, s.M, s.N, s.K, 1.0, A, lda, 0, B, ldb, 0, s.beta, C, s.N, 0, 1);
         hipStreamSynchronize(st);
         hipEventRecord(e0, st);
         const int reps = 3;
-        for (int r = 0; r < reps; ++r) tvk_dgemm(st, s.ta, s.tb, s.M, s.N, s.K, 1.0, A, lda, 0, B, ldb, 0, 0.0, C, s.N, 0, 1);
+        for (int r = 0; r < reps; ++r) tvk_dgemm(st, s.ta, s.tb, s.M, s.N, s.K, 1.0, A, lda, 0, B, ldb, 0, s.beta, C, s.N, 0, 1);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         ms /= reps;
-        printf("%-40s %8.3f ms  %6.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        printf("%-75s %8.3f ms  %6.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
         hipFree(A); hipFree(B); hipFree(C);
     }
     return 0;
