@@ -142,11 +142,20 @@ def gmmiv_collectives_from_torch(ctx, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return GmmivCollectives(capi.Comm(ctx, 1, 0))
     world, rank = dist.get_world_size(), dist.get_rank()
-    uid = capi.Comm.unique_id() if rank == 0 else bytes(capi.COMM_ID_BYTES)
-    t = torch.tensor(list(uid), dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
+    # rank 0 ALWAYS broadcasts (id + a validity byte): if it cannot draw an id (no RCCL to load) the other ranks must not be left
+    # waiting in a broadcast that never comes while rank 0 moves on to the next collective of the launcher's process group
+    uid, err = bytes(capi.COMM_ID_BYTES), None
+    if rank == 0:
+        try:
+            uid = capi.Comm.unique_id()
+        except Exception as e:      # noqa: BLE001 - re-raised on every rank below
+            err = e
+    t = torch.tensor(list(uid) + [0 if err else 1], dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.broadcast(t, src=0)
-    uid = bytes(t.cpu().tolist())
-    return GmmivCollectives(capi.Comm(ctx, world, rank, uid))
+    got = t.cpu().tolist()
+    if got[-1] != 1:
+        raise capi.GmmivError("rank 0 could not draw an RCCL unique id%s" % (": %r" % err if err else ""))
+    return GmmivCollectives(capi.Comm(ctx, world, rank, bytes(got[:-1])))
 
 
 def all_reduce_sum(acc, coll=None):
