@@ -67,6 +67,10 @@ const char *gmmiv_version(void);
  *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
  *                      used for odd orders); A/B switch of the calling host thread (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
+ *   "chol_lds" 1       chol_fused.hip stages the 32 panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
+ *   "tv_mstep_solve" 1 updateTestimate by blocked substitution through the Cholesky factor of A_c (k_chol_solve_multi);
+ *                      0: explicit inverse + GEMM like the reference
+ *   "tv_md_device" 1   minDivergence: R normalised and factored on the device (even R); 0: on the host
  *   "topc_fused" 1     DETERMINE_TOP_DISTRIBS with the candidates collected in the epilogue of the MFMA log-likelihood kernel
  *                      (k_llk_mfma<TC> + k_topc_rank; C' <= 16, C <= 2048, D <= 64); 0 or not applicable: "topc_z".
  *                      "topc_fallbacks" counts the calls the fused path handed on (candidate list overflow / margin check)

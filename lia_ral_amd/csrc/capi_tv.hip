@@ -381,28 +381,45 @@ int gmmiv_tv_min_divergence(gmmiv_ctx *c, int C, int D, int R, double n_sessions
     if ((rc = i_mw.init(c, WS_T2, meanW, R))) return rc;
     if ((rc = o_mean.init(c, WS_T3, ubm_means, SV, true))) return rc;
     if ((rc = o_t.init(c, WS_T4, Tm, (size_t)R * SV, true))) return rc;
-    // R x R normalisation + Cholesky on the host (O(R^3) once per EM iteration)
-    std::vector<double> hR(RR), hr(R), ch;
-    GCHK(hipMemcpyAsync(hR.data(), o_rm.d, RR * 8, hipMemcpyDeviceToHost, c->stream));
-    GCHK(hipMemcpyAsync(hr.data(), o_r.d, R * 8, hipMemcpyDeviceToHost, c->stream));
-    GCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < R; ++i) hr[i] /= n_sessions;
-    for (int i = 0; i < R; ++i)
-        for (int j = 0; j < R; ++j) hR[(size_t)i * R + j] = hR[(size_t)i * R + j] / n_sessions - hr[i] * hr[j];
-    if (!host_cholesky_upper(R, hR, ch)) { gmmiv_set_error("tv_min_divergence: R is not positive definite"); return GMMIV_ERR_NUMERIC; }
-    GCHK(hipMemcpyAsync(o_rm.d, hR.data(), RR * 8, hipMemcpyHostToDevice, c->stream));
-    GCHK(hipMemcpyAsync(o_r.d, hr.data(), R * 8, hipMemcpyHostToDevice, c->stream));
     void *p;
     if ((rc = c->scratch(WS_T5, RR * 8, &p))) return rc;
     double *dCh = (double *)p;
-    GCHK(hipMemcpyAsync(dCh, ch.data(), RR * 8, hipMemcpyHostToDevice, c->stream));
+    if (tvk_chol_accepts_packed(R) && c->tv_md_device) {
+        // R <- R / n - r r^T and its factor on the device: one workgroup of k_chol_left (R = L L^T, Ch = L^T); the host only sees the
+        // status word.  (The host route below cost 4-5 ms of a 130 ms iteration at R = 400: two 1.28 MB copies each way and a scalar
+        // O(R^3) loop.)
+        if ((rc = c->scratch(WS_T8, RR * 8, &p))) return rc;
+        double *work = (double *)p;
+        if ((rc = c->scratch(WS_T7, (size_t)((R + 31) / 32) * 1024 * 8, &p))) return rc;
+        double *invd = (double *)p;
+        if ((rc = c->scratch(WS_SMALL, sizeof(int) + 64, &p))) return rc;
+        int *status = (int *)p;
+        GCHK(hipMemsetAsync(status, 0, sizeof(int), c->stream));
+        GCHK(tvk_md_normalize(c->stream, R, n_sessions, o_rm.d, o_r.d, work));
+        GCHK(tvk_chol_left_batched(c->stream, R, 1, work, invd, status));
+        GCHK(tvk_lower_to_upper(c->stream, R, work, dCh));
+        if (check_status(c, status, 1, "tv_min_divergence: R")) { gmmiv_set_error("tv_min_divergence: R is not positive definite"); return GMMIV_ERR_NUMERIC; }
+    } else {
+        // R x R normalisation + Cholesky on the host (odd R: the device factorisation wants 16-byte rows)
+        std::vector<double> hR(RR), hr(R), ch;
+        GCHK(hipMemcpyAsync(hR.data(), o_rm.d, RR * 8, hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipMemcpyAsync(hr.data(), o_r.d, R * 8, hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < R; ++i) hr[i] /= n_sessions;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < R; ++j) hR[(size_t)i * R + j] = hR[(size_t)i * R + j] / n_sessions - hr[i] * hr[j];
+        if (!host_cholesky_upper(R, hR, ch)) { gmmiv_set_error("tv_min_divergence: R is not positive definite"); return GMMIV_ERR_NUMERIC; }
+        GCHK(hipMemcpyAsync(o_rm.d, hR.data(), RR * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipMemcpyAsync(o_r.d, hr.data(), R * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipMemcpyAsync(dCh, ch.data(), RR * 8, hipMemcpyHostToDevice, c->stream));
+        GCHK(hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+    }
     // mean += T^T meanW (old T), then T <- Ch T
     GCHK(tvk_vecmat_add(c->stream, R, (long)SV, i_mw.d, o_t.d, o_mean.d));
     if ((rc = c->scratch(WS_T6, (size_t)R * SV * 8, &p))) return rc;
     double *Tn = (double *)p;
     GCHK(tvk_dgemm(c->stream, false, false, R, (int)SV, R, 1.0, dCh, R, 0, o_t.d, (long)SV, 0, 0.0, Tn, (long)SV, 0, 1));
     GCHK(hipMemcpyAsync(o_t.d, Tn, (size_t)R * SV * 8, hipMemcpyDeviceToDevice, c->stream));
-    GCHK(hipStreamSynchronize(c->stream)); // host vectors above go out of scope
     if ((rc = o_rm.finish()) || (rc = o_r.finish()) || (rc = o_mean.finish())) return rc;
     return o_t.finish();
 }

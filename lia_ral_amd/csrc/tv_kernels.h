@@ -28,6 +28,8 @@ int tvk_merge_rows(hipStream_t st, long ndst, long width, const long *off, const
 #define TVK_BATCH_SUM_SLABS 16
 int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst, double *tmp = nullptr); // tmp: SLABS * n doubles
 int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full);
+int tvk_md_normalize(hipStream_t st, int R, double n_sessions, double *Rm, double *r, double *work); // Rm, work <- Rm / n - (r / n)(r / n)^T ; r /= n
+int tvk_lower_to_upper(hipStream_t st, int n, const double *L, double *U);                       // U = L^T, zero below the diagonal
 int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y);
 int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const double *Mx, double *y);
 int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv);

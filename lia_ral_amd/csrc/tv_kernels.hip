@@ -1141,6 +1141,41 @@ int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full)
     k_add_unpacked<<<(n * n + 255) / 256, 256, 0, st>>>(n, packed, full);
     return (int)hipGetLastError();
 }
+// minDivergence on the device: Rn = Rm / n - (r / n)(r / n)^T into BOTH Rm (the caller's normalised R) and work (factored in place);
+// r /= n by a second launch (every element above reads the old r)
+__global__ void k_md_normalize(int R, double inv_n, double *__restrict__ Rm, const double *__restrict__ r, double *__restrict__ work)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * R) return;
+    const int i = e / R, j = e - i * R;
+    const double v = Rm[e] * inv_n - (r[i] * inv_n) * (r[j] * inv_n);
+    Rm[e] = v;
+    work[e] = v;
+}
+__global__ void k_scale_vec(int n, double f, double *__restrict__ v)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) v[e] *= f;
+}
+// U = L^T of a lower factor stored row-major (whatever sits above L's diagonal is ignored), zero below the diagonal
+__global__ void k_lower_to_upper(int n, const double *__restrict__ L, double *__restrict__ U)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    U[e] = j >= i ? L[(size_t)j * n + i] : 0.0;
+}
+int tvk_md_normalize(hipStream_t st, int R, double n_sessions, double *Rm, double *r, double *work)
+{
+    k_md_normalize<<<(R * R + 255) / 256, 256, 0, st>>>(R, 1.0 / n_sessions, Rm, r, work);
+    k_scale_vec<<<(R + 255) / 256, 256, 0, st>>>(R, 1.0 / n_sessions, r);
+    return (int)hipGetLastError();
+}
+int tvk_lower_to_upper(hipStream_t st, int n, const double *L, double *U)
+{
+    k_lower_to_upper<<<(n * n + 255) / 256, 256, 0, st>>>(n, L, U);
+    return (int)hipGetLastError();
+}
 int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y)
 {
     if (nb <= 0) return 0;

@@ -346,3 +346,33 @@ def test_twocov_mix_part_trials_mask_and_model_blocks(ctx):
         assert relerr(bp, whole_p[m0:m1]) < 1e-13
         rows += m1 - m0
     assert rows == M
+
+
+def test_min_divergence_device_factor_matches_host_and_oracle(ctx):
+    """gmmiv_tv_min_divergence: R normalised and factored by one workgroup of k_chol_left (default, even R) == the host route
+    (option tv_md_device 0, and odd R) == the oracle (TVAcc::minDivergence, AccumulateTVStat.cpp:1003-1047); a non-positive
+    definite R is an error on both routes, never a NaN matrix."""
+    from lia_ral_amd import capi
+    rng = np.random.default_rng(11)
+    C, D, U = 6, 10, 50
+    for R in (24, 66, 25):
+        W = rng.normal(size=(U, R)) + 0.3
+        Rm = W.T @ W + 0.1 * U * np.eye(R); r = W.sum(0); meanW = r / U
+        means = rng.normal(size=C * D); T = rng.normal(size=(R, C * D))
+        m_o, T_o = orc.tv_min_divergence(Rm.copy(), r.copy(), meanW, means.copy(), T.copy(), U, C, D)
+        outs = []
+        for dev_route in (1, 0):
+            prev = ctx.set_option("tv_md_device", dev_route)
+            Rg, rg, mg, Tg = Rm.copy(), r.copy(), means.copy(), T.copy()
+            ctx.tv_min_divergence(Rg, rg, meanW, mg, Tg, U, C, D)
+            ctx.set_option("tv_md_device", prev)
+            assert relerr(mg, m_o) < 1e-12 and relerr(Tg, T_o) < 1e-11
+            assert relerr(rg, r / U) < 1e-14 and relerr(Rg, Rm / U - np.outer(r / U, r / U)) < 1e-13
+            outs.append(Tg)
+        assert relerr(outs[0], outs[1]) < 1e-12
+    bad = -np.eye(24)
+    for dev_route in (1, 0):
+        prev = ctx.set_option("tv_md_device", dev_route)
+        with pytest.raises(capi.GmmivError):
+            ctx.tv_min_divergence(bad.copy(), np.zeros(24), np.zeros(24), np.zeros(C * D), np.ones((24, C * D)), U, C, D)
+        ctx.set_option("tv_md_device", prev)
