@@ -277,14 +277,17 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     const int ncr = cnt[t];
     if (stats && lane == 0) { atomicMax(&flag[5], ncr); atomicAdd((unsigned long long *)&flag[6], (unsigned long long)ncr); }
     if (ncr > TOPC_CAP) { if (lane == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[1], 1); } return; } // list overflow: the direct-form kernel redoes the frame
-    const int nc = ncr;
+    // the list length as a SCALAR: the four 64-record slices below are skipped wave-uniformly when the list ends before them (mean
+    // length 68 of 256: slices 2 and 3 almost never exist, and a skipped slice costs a branch instead of its predicated
+    // instructions -- the exponentials of the rejected records above all)
+    const int nc = __builtin_amdgcn_readfirstlane(ncr);
     double zl[4];
     int cl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = lane + 64 * j;
         zl[j] = NINF; cl[j] = -1;
-        if (k < nc) {
+        if (64 * j < nc && k < nc) {
             const d2 rec = *(const d2 *)(cand + 2 * ((size_t)t * TOPC_CAP + k));
             zl[j] = rec[0];
             cl[j] = (int)__double_as_longlong(rec[1]);
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (cl[j] >= 0) {
+        if (64 * j < nc && cl[j] >= 0) {
             const int wd = (cl[j] >> 5) & 63;
             const int pos = ord[wave][wd] + __builtin_popcount(bmap[wave][wd] & ((1u << (cl[j] & 31)) - 1u));
             sz[wave][pos] = zl[j];
@@ -326,6 +329,8 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     double zrej[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        zrej[j] = NINF;
+        if (64 * j >= nc) continue; // wave-uniform
         const int k = lane + 64 * j;
         const double z = k < nc ? sz[wave][k] : NINF;
         const bool hit = k < nc && z >= th;
@@ -395,7 +400,8 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     }
     double sr = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sr += zrej[j] > NINF ? gexp(zrej[j] - M) : 0.0;
+    for (int j = 0; j < 4; ++j)
+        if (64 * j < nc) sr += zrej[j] > NINF ? gexp(zrej[j] - M) : 0.0; // wave-uniform skip
     srel += wave_sum_f64_dpp(sr);
     srel += wave_sum_f64_dpp((cd && !sel) ? gexp(zc - M) : 0.0);
     const double st = wave_sum_f64_dpp(sel ? gexp(zc - M) : 0.0);

@@ -53,5 +53,25 @@ int main()
         printf("%-75s %8.3f ms  %6.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
         hipFree(A); hipFree(B); hipFree(C);
     }
+    { // split-K of aux = F Tiv^T (1024 x 400 x 122880 NT): which layer count fills 2 x 256 workgroup slots best?
+        const int M = 1024, N = 400, K = 122880;
+        double *A, *B, *C, *slabs;
+        hipMalloc(&A, (size_t)M * K * 8); hipMalloc(&B, (size_t)N * K * 8); hipMalloc(&C, (size_t)M * N * 8); hipMalloc(&slabs, (size_t)128 * M * N * 8);
+        hipMemset(A, 0, (size_t)M * K * 8); hipMemset(B, 0, (size_t)N * K * 8);
+        for (int nz : {8, 12, 16, 21, 24, 32, 42, 48, 64, 96}) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            tvk_dgemm_splitk(st, false, true, M, N, K, 1.0, A, K, B, K, 0.0, C, N, nz, slabs);
+            hipStreamSynchronize(st);
+            hipEventRecord(e0, st);
+            for (int r = 0; r < 3; ++r) tvk_dgemm_splitk(st, false, true, M, N, K, 1.0, A, K, B, K, 0.0, C, N, nz, slabs);
+            hipEventRecord(e1, st);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            ms /= 3;
+            printf("aux split-K, %3d layers (default %d)   %8.3f ms  %6.1f TFLOP/s\n", nz, tvk_splitk_count(M, N, K, 256), ms, 2.0 * M * N * K / ms / 1e9);
+        }
+    }
     return 0;
 }
