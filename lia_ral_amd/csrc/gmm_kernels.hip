@@ -108,7 +108,8 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // inv_out = the non-appended sums (2^-Efin), lse_out = the final thresholds.
 #define TOPC_CAP 256
 // K1_ABL (compile-time, timing experiments only -- tools/k1_ablate.sh; results are wrong when != 0): 1 = no epilogue, 2 = exp table read
-// from one address, 4 = no likelihood stores, 8 = no DPP row maximum, 16 = no staging / barrier, 32 = no stores of the running exponents
+// from one address, 4 = no likelihood stores, 8 = no DPP row maximum, 16 = no staging / barrier, 32 = no stores of the running exponents; TC mode: 64 = no hit test / append,
+// 128 = no lane maxima / threshold refresh, 256 = x^2 operands not recomputed (x fed twice)
 #ifndef K1_ABL
 #define K1_ABL 0
 #endif
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         const double b0 = cur[(0 * NR + s) * 64 + lane];
         const double b1 = cur[(1 * NR + s) * 64 + lane];
         double a0, a1;
-        if (TC && s >= KS) { a0 = __builtin_fma(A[0][s - KS], A[0][s - KS], zv); a1 = __builtin_fma(A[1][s - KS], A[1][s - KS], zv); }
+        if (TC && s >= KS && !(K1_ABL & 256)) { a0 = __builtin_fma(A[0][s - KS], A[0][s - KS], zv); a1 = __builtin_fma(A[1][s - KS], A[1][s - KS], zv); }
+        else if (TC && s >= KS) { a0 = A[0][s - KS]; a1 = A[1][s - KS]; }
         else { a0 = A[0][s < NA ? s : 0]; a1 = A[1][s < NA ? s : 0]; }
         acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
         acc[1][0] = MFMA_F64(a0, b1, acc[1][0]);
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                 int nm[4], k0[4], k1[4];
                 bool hit0[4], hit1[4];
                 bool grow = false;
+                if (!(K1_ABL & 128))
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     lmaxf[h][r] = fmaxf(lmaxf[h][r], (float)fmax(acc[0][h][r], acc[1][h][r])); // rounding to nearest: the push-down covers it
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                 // reach it, so the ctop largest logits of the frame do -- pushed down by 2^-17 (relative): that covers the float
                 // roundings and leaves a gap of about 4e-6 |z| to the weakest of them, which k_topc_rank's margin check needs.
                 // Between refreshes the stale (lower) threshold only lets more candidates in.
-                if (refresh) {
+                if (refresh && !(K1_ABL & 128)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // Order-preserving integer keys (negative floats: magnitude bits flipped), made unique inside the row (low 4
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double thd = (double)thf[h][r];
-                    hit0[r] = acc[0][h][r] >= thd;
-                    hit1[r] = acc[1][h][r] >= thd;
+                    hit0[r] = !(K1_ABL & 64) && acc[0][h][r] >= thd;
+                    hit1[r] = !(K1_ABL & 64) && acc[1][h][r] >= thd;
                     slot[r] = 0;
                     if (hit0[r] || hit1[r])
                         slot[r] = __hip_atomic_fetch_add(ccnt + (wave * 32 + q) + (h * 16 + 4 * r), (hit0[r] ? 1 : 0) + (hit1[r] ? 1 : 0), __ATOMIC_RELAXED,
