@@ -25,6 +25,14 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// CHOL_ABL (compile-time, timing experiments only -- tools/chol_ablate.sh; results are wrong when != 0), k_chol_left: 1 = no factorisation /
+// inversion sweep of the diagonal block, 2 = no triangular solve + stores of the tiles, 4 = no k-loops of the off-diagonal tiles,
+// 8 = no k-loop of the diagonal block's update, 16 = triangular solve kept but no stores of the tiles, 32 = the barrier that ends a panel does
+// not wait for the stores (s_barrier alone)
+#ifndef CHOL_ABL
+#define CHOL_ABL 0
+#endif
+
 // A/B switch of the calling host thread: 0 = every wave fetches the panel rows itself (the round-1 kernels)
 static thread_local int g_chol_lds = 1;
 int tvk_set_chol_lds(int on) { const int prev = g_chol_lds; g_chol_lds = on; return prev; }
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 }
             }
             const int p32 = j0 >> 5;
-            rowdot<2, true>(pa0, pa1, pb, 32 * ((wave * p32) >> 3), 32 * (((wave + 1) * p32) >> 3), acc);
+            if (!(CHOL_ABL & 8)) rowdot<2, true>(pa0, pa1, pb, 32 * ((wave * p32) >> 3), 32 * (((wave + 1) * p32) >> 3), acc);
             const double unit = wave == 0 ? 1.0 : 0.0; // rows / columns beyond n: identity
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
             for (int k = 0; k < 32; ++k) v[k] = lo ? a[k] : 0.0;
             if (lo) col[0][li] = v[0];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < ((CHOL_ABL & 1) ? 1 : 32); ++j) {
                 const double *cj = col[j & 1];
                 wave_sync();
                 double c[32];
@@ -494,12 +502,12 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                     if (u < cnt) acc[u][ct] = chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
                 }
             }
-            rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
+            if (!(CHOL_ABL & 4)) rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
             if (g == 0) {
                 __syncthreads(); // inv(L_jj) and L_jj are in LDS
                 chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
             }
-            if (cnt > 0) {
+            if (cnt > 0 && !(CHOL_ABL & 2)) {
                 LinvOps lo;
                 linv_ops_load(lo, linv, perm, q);
 #pragma unroll
@@ -507,6 +515,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                     if (u < cnt) {
                         d4 x0, x1;
                         tile_trsm(lo, acc[u], x0, x1);
+                        if (CHOL_ABL & 16) { asm volatile("" ::"v"(x0), "v"(x1)); continue; }
                         if (rows[u] < n) {
                             double *p = Lm + rows[u] * n + j0 + 4 * q;
                             *(d2 *)p = d2{x0[0], x0[1]};
@@ -522,7 +531,8 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
             __syncthreads();
             chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
         }
-        __syncthreads(); // the panel is in memory (and pj / linv are free) before the next one reads it
+        if (CHOL_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads(); // the panel is in memory (and pj / linv are free) before the next one reads it
     }
     if (wave == 0 && lane0 == 0 && bad) status[blockIdx.x] = 1;
 }

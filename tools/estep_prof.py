@@ -25,8 +25,11 @@ acc = dict(A=torch.zeros((C, P), dtype=torch.float64, device=dev), Cmx=torch.zer
            meanW=torch.zeros(R, dtype=torch.float64, device=dev), W=torch.empty((U, R), dtype=torch.float64, device=dev))
 what = os.environ.get("WHAT", "estep")
 for _ in range(3):
-    if what == "estep":
-        ctx.tv_estimate_a_and_c(N, F, Tm, invvar, tett, C, D, acc=acc)
-    else:
-        ctx.tv_estimate_w(N, F, Tm, invvar, tett, C, D, out=W)
+    try:
+        if what == "estep":
+            ctx.tv_estimate_a_and_c(N, F, Tm, invvar, tett, C, D, acc=acc)
+        else:
+            ctx.tv_estimate_w(N, F, Tm, invvar, tett, C, D, out=W)
+    except capi.GmmivError as e:       # instrumented builds (tools/chol_ablate.sh) produce non-SPD garbage on purpose
+        print("call failed:", e)
 torch.cuda.synchronize()
