@@ -321,6 +321,10 @@ def test_twocov_mix_part_trials_mask_and_model_blocks(ctx):
     got = ctx.score_twocov_mix_part(m, s, G, base.copy())
     ref = base + orc.score_twocov(m, s, G, np.zeros((dim, dim)))          # H = 0 leaves (m+s)'G(m+s)
     assert relerr(got, ref) < 1e-11
+    # the same accumulating epilogue on the 32-wide strip tiles of k_dgemm (M, S a little over multiples of 128, both even)
+    m2 = rng.normal(size=(dim, 400)); s2 = rng.normal(size=(dim, 278)); base2 = rng.normal(size=(400, 278))
+    got2 = ctx.score_twocov_mix_part(m2, s2, G, base2.copy())
+    assert relerr(got2, base2 + orc.score_twocov(m2, s2, G, np.zeros((dim, dim)))) < 1e-11
     # twoCovScoring == mix part on zeros minus the model / segment terms (:4127-4171)
     H = rng.normal(size=(dim, dim)) / dim
     full = ctx.score_twocov(m, s, G, H)
