@@ -104,6 +104,8 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
         return gmmk_stats_z_set_tv4((int)value);
     }
+    if (!strcmp(key, "z_depth_em")) return gmmk_stats_z_set_depth((int)value, 0) / 10; // A/B knobs: stream prefetch depth of k_stats_z (2 / 3 register sets)
+    if (!strcmp(key, "z_depth_tv")) return gmmk_stats_z_set_depth(0, (int)value) % 10;
     if (!strcmp(key, "gemm_remap")) { // A/B knob: 0 = hardware tile order in k_dgemm
         return tvk_set_gemm_remap((int)value);
     }

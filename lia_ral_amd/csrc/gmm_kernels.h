@@ -59,6 +59,7 @@ int gmmk_stats_z_groups(int nct);
 void gmmk_stats_z_set_waves(int w);
 int gmmk_stats_z_set_tv4(int on);   // thread-local A/B switch, returns the previous value
 int gmmk_stats_z_wg_per_cu(void);
+int gmmk_stats_z_set_depth(int em, int tv); // stream register sets of k_stats_z per mode (2 or 3; other values leave a mode as it is); returns 10 * em + tv before
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
                  long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,
                  double *out0, double *out1, int mode, int accum, double prune_thr);

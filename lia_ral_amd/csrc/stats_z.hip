@@ -32,7 +32,12 @@
 //   <4, 2, 32>   two independent workgroups per CU
 //   <16, 1, 64>  one workgroup per CU, 4 waves per SIMD at 128 VGPRs: more waves to cover a stalled one,
 //                half the operand reuse (every x operand feeds 2 MFMAs)
-template <int KS, bool SQ, typename XT, bool PRUNE, int NW = 8, int TPW = 2, int FT = 64>
+// ZD: register sets of the likelihood stream = prefetch distance + 1.  2: block n + 1 is requested when block n starts.  4: block n + 3
+// -- the N / F shape does 32 MFMAs per 16-frame block and wave (the EM shape 64): one block of cover is less than the HBM latency under
+// load, the kernel stalled on every block (0.70 of the MFMA peak at 3.4 TB/s of the 7 TB/s a plain stream reaches).  ZD divides the blocks
+// per tile, so the set of a block is a compile-time index without unrolling the tile loop; everything in flight is collected at the end of
+// a tile (the compiler's vmcnt bookkeeping does not survive the back-edge), i.e. the first block of a tile still has one block of cover.
+template <int KS, bool SQ, typename XT, bool PRUNE, int NW = 8, int TPW = 2, int FT = 64, int ZD = 2>
 __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const void *__restrict__ x, long ldx, int D, int C, int nct,
                                                     const double *__restrict__ zbuf, long nfb, const int *__restrict__ eit,
                                                     const double *__restrict__ inv, const int *__restrict__ efin, double scale,
@@ -168,9 +173,12 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     // Two register sets, alternating between even and odd blocks (the tile loop is unrolled).
     const double *zp0 = zbuf + ((((size_t)(active ? ct0 : 0)) * nfb + (fa >> 4)) * 64 + lane) * 4;
     const size_t ztile = (size_t)nfb * 256; // doubles between consecutive tiles (uniform)
-    d2 zA[TPW][2], zB[TPW][2];
+    static_assert((FT / 16) % ZD == 0, "the stream sets must divide the blocks of a tile");
+    d2 zs[ZD][TPW][2];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) { zA[t][0] = (d2){0, 0}; zA[t][1] = zA[t][0]; zB[t][0] = zA[t][0]; zB[t][1] = zA[t][0]; }
+    for (int b = 0; b < ZD; ++b)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) { zs[b][t][0] = (d2){0, 0}; zs[b][t][1] = zs[b][t][0]; }
     auto issue_z = [&](d2 (&z)[TPW][2], int n) { // streamed once, kept out of the caches (nt)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -191,9 +199,13 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
 
     if (ntiles > 0) {
         issue_stage(0);
-        if (active) issue_z(zA, 0);
+        if (active) {
+#pragma unroll
+            for (int b = 0; b + 1 < ZD; ++b) issue_z(zs[b], b < nblk ? b : nblk - 1);
+        }
         finish_stage(buf0, 0, 0);
-        PIN_Z(zA);
+#pragma unroll
+        for (int b = 0; b + 1 < ZD; ++b) PIN_Z(zs[b]);
     }
     __syncthreads();
     // one tile; `full` = not the last tile of the segment: all BPT blocks exist and so does every prefetch,
@@ -208,7 +220,9 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
             const double *pF = ftile + ((tl & 1) * NW + wave) * PF * FT + q;
             auto block = [&](int fs, d2 (&zc)[TPW][2], d2 (&zn)[TPW][2]) {
                 const int n = tl * BPT + fs;
-                if (full || n + 1 < nblk) issue_z(zn, n + 1);
+                // (full tile, more than two sets: the request may lie beyond the segment's last block -- clamped, never consumed)
+                if (full) issue_z(zn, (ZD == 2 || n + ZD - 1 < nblk) ? n + ZD - 1 : nblk - 1);
+                else if (n + ZD - 1 < nblk) issue_z(zn, n + ZD - 1);
                 // register r holds rows (frames) fs*16 + 4r + q of 16 Gaussians: already the A operand
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -234,13 +248,16 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
                 }
             };
             const int nb = nblk - tl * BPT; // blocks of this tile that exist (wave-uniform)
-            block(0, zA, zB);
-            if (full || nb > 1) block(1, zB, zA);
+            // block fs consumes set fs % ZD and requests block n + ZD - 1 into the set block n - 1 has just left
+            block(0, zs[0], zs[ZD - 1]);
+            if (full || nb > 1) block(1, zs[1 % ZD], zs[0]);
             if (BPT > 2) {
-                if (full || nb > 2) block(2, zA, zB);
-                if (full || nb > 3) block(3, zB, zA);
+                if (full || nb > 2) block(2, zs[2 % ZD], zs[1 % ZD]);
+                if (full || nb > 3) block(3, zs[3 % ZD], zs[2 % ZD]);
             }
-            PIN_Z(zA); // the next tile's first block (issued by the last block above) has landed
+            // the next tile's first blocks (issued by the last blocks above) have landed: nothing in flight at the back-edge
+#pragma unroll
+            for (int b = 0; b + 1 < ZD; ++b) PIN_Z(zs[b]);
         }
         if (staged) finish_stage(nxt, (tl + 1) & 1, tl + 1);
         __syncthreads();
@@ -296,13 +313,22 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
 // so contexts driven from different threads (one per GPU) cannot see each other's value
 static thread_local int g_stats_z_waves = 8;
 static thread_local int g_stats_z_tv4 = 1; // A/B knob: 0 = two tiles per wave in the N / F mode too
+// stream register sets (prefetch distance + 1) of the 8-wave / two-tile shape, per statistics mode: 2 or 4 (see k_stats_z, ZD)
+static thread_local int g_stats_z_depth_em = 2, g_stats_z_depth_tv = 4; // measured: EM 30.5 ms (2) / 31.1 (4) per 4 M frames, N / F 14.2 (four tiles, 2) / 13.7 (two tiles, 4) per 3 M
+int gmmk_stats_z_set_depth(int em, int tv)
+{
+    const int prev = g_stats_z_depth_em * 10 + g_stats_z_depth_tv;
+    if (em == 2 || em == 4) g_stats_z_depth_em = em;
+    if (tv == 2 || tv == 4) g_stats_z_depth_tv = tv;
+    return prev;
+}
 int gmmk_stats_z_set_tv4(int on) { const int prev = g_stats_z_tv4; g_stats_z_tv4 = on; return prev; }
 void gmmk_stats_z_set_waves(int w) { g_stats_z_waves = (w == 4 || w == 16) ? w : 8; }
 // Gaussian tiles per workgroup: 16 for <8,2> and <16,1>, 8 for <4,2>
 int gmmk_stats_z_groups(int nct) { const int tpg = g_stats_z_waves == 4 ? 8 : 16; return (nct + tpg - 1) / tpg; }
 int gmmk_stats_z_wg_per_cu(void) { return g_stats_z_waves == 4 ? 2 : 1; }
 
-template <int KS, bool SQ, typename XT, bool PRUNE, int NW, int TPW, int FT>
+template <int KS, bool SQ, typename XT, bool PRUNE, int NW, int TPW, int FT, int ZD = 2>
 static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int nct, const double *zbuf, long nfb, const int *eit,
                     const double *inv, const int *efin, double scale, const long *seg_begin, int nseg, double *out0, double *out1,
                     int mode, int accum, double prune_thr)
@@ -315,13 +341,13 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
     if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
     std::atomic<bool> &attr_set = attr_done[attr_dev];
     if (!attr_set.load(std::memory_order_acquire)) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT, ZD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.store(true, std::memory_order_release);
     }
     const int ngrp = (nct + TPW * NW - 1) / (TPW * NW);
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
     const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);
-    k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT><<<grid, NW * 64, lds, st>>>(x, ldx, D, C, nct, zbuf, nfb, eit, inv, efin, scale, seg_begin, nseg, ngrp,
+    k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT, ZD><<<grid, NW * 64, lds, st>>>(x, ldx, D, C, nct, zbuf, nfb, eit, inv, efin, scale, seg_begin, nseg, ngrp,
                                                               out0, out1, mode, accum, magicD, prune_thr);
     return (int)hipGetLastError();
 }
@@ -338,7 +364,10 @@ static int launch_z_p(hipStream_t st, const void *x, long ldx, int D, int C, int
     // N / F statistics only (no x^2 accumulators): FOUR tiles per wave in the same 128 accumulator registers, so that
     // every x operand read from LDS feeds 4 MFMAs here too
     // (a wave's four tiles must all exist: the host pads the packed model to PAIRS of tiles only)
-    if constexpr (!SQ) { if (g_stats_z_tv4 && nct % 4 == 0) return launch_z<KS, SQ, XT, false, 8, 4, 64>(ZARGS); }
+    if constexpr (!SQ) {
+        if (g_stats_z_depth_tv == 4) return launch_z<KS, SQ, XT, false, 8, 2, 64, 4>(ZARGS);
+        if (g_stats_z_tv4 && nct % 4 == 0) return launch_z<KS, SQ, XT, false, 8, 4, 64>(ZARGS);
+    } else if (g_stats_z_depth_em == 4) return launch_z<KS, SQ, XT, false, 8, 2, 64, 4>(ZARGS);
     return launch_z<KS, SQ, XT, false, 8, 2, 64>(ZARGS);
 }
 
