@@ -60,6 +60,8 @@ const char *gmmiv_version(void);
  *                      free at call time: results are bitwise reproducible across runs and ranks.  (The order differs
  *                      from the reference's frame-by-frame accumulation: parity is to a tolerance, see DESIGN.md.)
  *   "z_waves" 8        workgroup shape of k_stats_z (8, 16 or 4 waves)
+ *   "z_depth_tv" 4     register sets of k_stats_z's likelihood stream (prefetch distance + 1; 2 or 4) in the N / F mode,
+ *   "z_depth_em" 2     and in the EM mode; A/B switches of the calling host thread, bit-identical results
  *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
