@@ -67,6 +67,8 @@ const char *gmmiv_version(void);
  *                      for dead Gaussians; off by default)
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one
  *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
+ *   "tv_acc_mb" 8192   T-matrix E-step: MiB of packed E_u = L_u^-1 + w_u w_u^T kept in HBM before A += N^T E and Cmx += W^T F run
+ *                      (one GEMM per super-batch, K = its utterances, instead of one per tv_batch)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
  *                      used for odd orders); A/B switch of the calling host thread (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
  *   "chol_lds" 1       chol_fused.hip stages the 32 panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)

@@ -99,6 +99,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     else if (!strcmp(key, "tv_mstep_solve")) slot = &c->tv_mstep_solve;
     else if (!strcmp(key, "tv_md_device")) slot = &c->tv_md_device;
+    else if (!strcmp(key, "tv_acc_mb")) slot = &c->tv_acc_mb;
     else if (!strcmp(key, "topc_fused")) slot = &c->topc_fused;
     else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
     if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z

@@ -247,8 +247,18 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
     int BC = (int)c->tv_batch;
     if (BC < 1) BC = 256;
     if (U < BC) BC = (int)U;
-    if ((rc = c->scratch(WS_LP, (size_t)BC * P * 8, &p))) { free_owned(); return rc; }
-    double *Lp = (double *)p;
+    // T-matrix EM: the E_u of a SUPER-BATCH of utterances stay in HBM (tv_acc_mb, default 8 GiB = 13 k utterances at rank 400) and
+    // A += N^T E, Cmx += W^T F run ONCE per super-batch with K = its utterance count, instead of once per tv_batch with the 1.3 GB
+    // accumulator read and written back every time (config 4's 6250 utterances per rank: 7 x 5.1 ms -> 30 ms for A alone).
+    int64_t SB = BC;
+    if (accumulate) {
+        const int64_t fit = ((int64_t)(c->tv_acc_mb > 0 ? c->tv_acc_mb : 0) << 20) / (int64_t)(P * 8);
+        SB = fit / BC * BC;
+        if (SB < BC) SB = BC;
+        if (SB > U) SB = (U + BC - 1) / BC * BC;
+    }
+    if ((rc = c->scratch(WS_LP, (size_t)SB * P * 8, &p))) { free_owned(); return rc; }
+    double *Lp0 = (double *)p;
     if ((rc = c->scratch(WS_AUX, (size_t)BC * R * 8, &p))) { free_owned(); return rc; }
     double *aux = (double *)p;
     const int nz = tvk_splitk_count(BC, R, (int)SV, c->n_cu);
@@ -259,11 +269,14 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
     InvWs ws;
     if ((rc = ws.init(c, R, BC))) { free_owned(); return rc; }
 
-    for (int64_t u0 = 0; u0 < U; u0 += BC) {
-        const int nb = (int)((U - u0) < BC ? (U - u0) : BC);
+    for (int64_t s0 = 0; s0 < U; s0 += SB) {
+    const int64_t ns = (U - s0) < SB ? (U - s0) : SB; // utterances of this super-batch
+    for (int64_t u0 = s0; u0 < s0 + ns; u0 += BC) {
+        const int nb = (int)((s0 + ns - u0) < BC ? (s0 + ns - u0) : BC);
         const double *Nc = i_n.d + (size_t)u0 * C;
         const double *Fc = i_f.d + (size_t)u0 * SV;
         double *Wc = o_w.d + (size_t)u0 * R;
+        double *Lp = Lp0 + (size_t)(u0 - s0) * P;
         GCHK(hipMemsetAsync(ws.status, 0, nb * sizeof(int), c->stream));
         // L (packed) = N * TETt ; + I on unpack
         c->t_begin("k_dgemm(L)");
@@ -286,15 +299,18 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
             GCHK(tvk_chol_solve_batched(c->stream, R, nb, ws.full, ws.invd, aux, Wc));
         }
         if ((rc = check_status(c, ws.status, nb, "tv: L"))) { free_owned(); return rc; }
-        if (accumulate) {
-            // E = L^-1 + w w^T (packed, reusing Lp) ; A += N^T E ; Cmx += W^T F ; R += sum E ; r, meanW += sum w
-            if (!packed_in) GCHK(tvk_pack_sym(c->stream, R, nb, ws.inv, (long)RR, Wc, Lp, (long)P));
-            GCHK(tvk_dgemm(c->stream, true, false, C, (int)P, nb, 1.0, Nc, C, 0, Lp, (long)P, 0, 1.0, d_a, (long)P, 0, 1));
-            GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, nb, 1.0, Wc, R, 0, Fc, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
-            GCHK(tvk_batch_sum(c->stream, (long)P, nb, Lp, (long)P, d_rp, slabs)); // slabs (split-K workspace of aux) is free again
-            GCHK(tvk_batch_sum(c->stream, R, nb, Wc, R, d_r));
-            GCHK(tvk_batch_sum(c->stream, R, nb, Wc, R, d_mw));
-        }
+        // E = L^-1 + w w^T (packed, in the super-batch buffer)
+        if (accumulate && !packed_in) GCHK(tvk_pack_sym(c->stream, R, nb, ws.inv, (long)RR, Wc, Lp, (long)P));
+    }
+    if (accumulate) {
+        // A += N^T E ; Cmx += W^T F ; R += sum E ; r, meanW += sum w    over the ns utterances of the super-batch
+        const double *Ns = i_n.d + (size_t)s0 * C, *Fs = i_f.d + (size_t)s0 * SV, *Ws = o_w.d + (size_t)s0 * R;
+        GCHK(tvk_dgemm(c->stream, true, false, C, (int)P, (int)ns, 1.0, Ns, C, 0, Lp0, (long)P, 0, 1.0, d_a, (long)P, 0, 1));
+        GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, (int)ns, 1.0, Ws, R, 0, Fs, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
+        GCHK(tvk_batch_sum(c->stream, (long)P, (int)ns, Lp0, (long)P, d_rp, slabs)); // slabs (split-K workspace of aux) is free again
+        GCHK(tvk_batch_sum(c->stream, R, (int)ns, Ws, R, d_r));
+        GCHK(tvk_batch_sum(c->stream, R, (int)ns, Ws, R, d_mw));
+    }
     }
     if (accumulate) {
         GCHK(tvk_add_unpacked(c->stream, R, d_rp, d_rm));
