@@ -380,3 +380,28 @@ def test_min_divergence_device_factor_matches_host_and_oracle(ctx):
         with pytest.raises(capi.GmmivError):
             ctx.tv_min_divergence(bad.copy(), np.zeros(24), np.zeros(24), np.zeros(C * D), np.ones((24, C * D)), U, C, D)
         ctx.set_option("tv_md_device", prev)
+
+
+def test_tv_estep_batching_does_not_change_the_statistics(ctx):
+    """gmmiv_tv_estimate_a_and_c: utterances go through the solve in batches of tv_batch, their E_u are kept for a super-batch
+    (tv_acc_mb) and A / Cmx / R / r are updated once per super-batch.  Ragged batch and super-batch boundaries (U = 75 with
+    tv_batch 16: super-batches of 64 + 11 utterances when only one batch's worth of E fits, one of 80 by default) == the oracle."""
+    C, D, R, U = 16, 12, 40, 75
+    p = tv_problem(C, D, R, U, seed=21, frames=100)
+    invvar = p["iv"].ravel()
+    F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
+    o = orc.tv_estimate_a_and_c(p["N"], F0, p["Tm"], invvar, orc.tv_tett(p["Tm"], invvar, C, D))
+    te = ctx.tv_tett(p["Tm"], invvar, C, D)
+    il = np.tril_indices(R)
+    A_o = o["A"].reshape(C, R, R)[:, il[0], il[1]]
+    outs = []
+    prev_b = ctx.set_option("tv_batch", 16)
+    for acc_mb in (0, 8192):
+        prev_a = ctx.set_option("tv_acc_mb", acc_mb)
+        g = ctx.tv_estimate_a_and_c(p["N"], F0, p["Tm"], invvar, te, C, D)
+        ctx.set_option("tv_acc_mb", prev_a)
+        for k, ref in (("W", o["W"]), ("A", A_o), ("Cmx", o["Cmx"]), ("Rm", o["Rm"]), ("r", o["r"])):
+            assert relerr(g[k], ref) < 1e-9, (acc_mb, k)
+        outs.append(g)
+    ctx.set_option("tv_batch", prev_b)
+    assert relerr(outs[0]["A"], outs[1]["A"]) < 1e-12 and np.array_equal(outs[0]["W"], outs[1]["W"])

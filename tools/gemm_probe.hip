@@ -25,6 +25,9 @@ int main()
         {"A  = N E (NN): 2048 x 80200 x 1024 NN beta 0", false, false, 2048, 80200, 1024},
         {"Cmx += W^T F: 400 x 122880 x 1024 TN beta 1", true, false, 400, 122880, 1024, 1.0},
         {"Cmx, 384 rows: 384 x 122880 x 1024 TN beta 1", true, false, 384, 122880, 1024, 1.0},
+        {"Cmx += W^T F: 400 x 122880 x 6250 TN beta 1", true, false, 400, 122880, 6250, 1.0},
+        {"Cmx, 384 rows: 384 x 122880 x 6250 TN beta 1", true, false, 384, 122880, 6250, 1.0},
+        {"A += N^T E: 2048 x 80200 x 6250 TN beta 1", true, false, 2048, 80200, 6250, 1.0},
         {"4096 x 4096 x 1024 NN", false, false, 4096, 4096, 1024},
         {"4096 x 4096 x 2048 NN", false, false, 4096, 4096, 2048},
         {"8192 x 8192 x 2048 NN", false, false, 8192, 8192, 2048},
