@@ -1307,8 +1307,10 @@ int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, 
 }
 
 // Streaming variant for dense rows (ldx == D) whose length is a multiple of the 16-byte vector (4 floats / 2 doubles): the
-// matrix is one flat stream, lane i loads vector i of its block's slice and -- the block size being a multiple of the
-// D / V vectors of a row -- always sees the same V columns, so it keeps V sums and V sums of squares in registers.
+// matrix is one flat stream of 16-byte vectors, G = D / V per row.  Thread tid of block b starts at vector 256 b + tid and advances by
+// gridDim.x * 256 -- the launcher makes the grid a multiple of G, so a thread always sees the same V columns (phase (256 b + tid) % G)
+// and keeps V sums and V sums of squares in registers, while every wave-load is 1 KB on a 1 KB boundary (the first version used
+// G * (256 / G) = 255 threads per block at D = 60: every load straddled one more cache line than it needed).
 // 4 independent 16-byte loads in flight per lane (the scalar kernel has one 4-byte load per lane and iteration).
 template <typename XT>
 __global__ __launch_bounds__(256) void k_frame_moments_vec(const XT *__restrict__ x, long nvec, int D, int nthr, double *__restrict__ partial)
@@ -1320,18 +1322,22 @@ __global__ __launch_bounds__(256) void k_frame_moments_vec(const XT *__restrict_
     double s[V], ss[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { s[k] = 0.0; ss[k] = 0.0; }
-    if (tid < nthr) {
+    {
         const vec_t *xv = (const vec_t *)x;
-        const long stride = (long)gridDim.x * nthr;
-        long j = (long)blockIdx.x * nthr + tid;
-        for (; j + 3 * stride < nvec; j += 4 * stride) {
-            const vec_t a = __builtin_nontemporal_load(xv + j), b = __builtin_nontemporal_load(xv + j + stride),
-                        c = __builtin_nontemporal_load(xv + j + 2 * stride), d = __builtin_nontemporal_load(xv + j + 3 * stride);
+        const long stride = (long)gridDim.x * 256;
+        long j = (long)blockIdx.x * 256 + tid;
+        for (; j + 7 * stride < nvec; j += 8 * stride) { // 8 independent 16-byte loads in flight per lane
+            vec_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xv + j + u * stride);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                const double va = (double)a[k], vb = (double)b[k], vc = (double)c[k], vd = (double)d[k];
-                s[k] += (va + vb) + (vc + vd);
-                ss[k] = __builtin_fma(va, va, __builtin_fma(vb, vb, __builtin_fma(vc, vc, __builtin_fma(vd, vd, ss[k]))));
+                double d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d[u] = (double)v[u][k];
+                s[k] += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ss[k] = __builtin_fma(d[u], d[u], ss[k]);
             }
         }
         for (; j < nvec; j += stride) {
@@ -1343,12 +1349,14 @@ __global__ __launch_bounds__(256) void k_frame_moments_vec(const XT *__restrict_
 #pragma unroll
     for (int k = 0; k < V; ++k) { red[tid][k] = s[k]; red[tid][V + k] = ss[k]; }
     __syncthreads();
-    // column c = V g + k lives in the threads t = g, g + G, g + 2 G, ... (G = D / V vectors per row)
+    // column c = V g + k lives in the threads t with (256 b + t) % G == g   (G = D / V vectors per row)
     const int G = D / V;
+    (void)nthr;
+    const int base = (int)(((long)blockIdx.x * 256) % G);
     for (int e = tid; e < 2 * D; e += 256) {
         const int sq = e >= D, c = sq ? e - D : e, g = c / V, k = c - g * V;
         double acc = 0.0;
-        for (int t = g; t < nthr; t += G) acc += red[t][sq * V + k];
+        for (int t = (g - base + G) % G; t < 256; t += G) acc += red[t][sq * V + k];
         partial[(size_t)blockIdx.x * 2 * D + e] = acc;
     }
 }
@@ -1361,10 +1369,12 @@ int gmmk_frame_moments(hipStream_t st, int x_f64, const void *x, long T, long ld
     if (nb > max_blocks) nb = max_blocks;
     const int V = x_f64 ? 2 : 4;
     if (ldx == D && D % V == 0 && D / V <= 256 && ((size_t)x % 16) == 0) { // dense rows: the flat-stream kernel
-        const int G = D / V, nthr = G * (256 / G);
+        const int G = D / V, nthr = 256;
         const long nvec = T * G;
         long want = (nvec + (long)nthr * 8 - 1) / ((long)nthr * 8); // >= 8 vectors per lane
         if (want < nb) nb = (int)(want < 1 ? 1 : want);
+        nb = nb >= G ? nb / G * G : G;                              // the grid stride must be a multiple of the row length in vectors
+        if (nb > max_blocks) nb = max_blocks / G * G;
         if (x_f64) k_frame_moments_vec<double><<<nb, 256, 0, st>>>((const double *)x, nvec, D, nthr, partial);
         else k_frame_moments_vec<float><<<nb, 256, 0, st>>>((const float *)x, nvec, D, nthr, partial);
     } else if (x_f64) k_frame_moments<double><<<nb, 256, 0, st>>>(x, T, ldx, D, partial);
