@@ -13,7 +13,11 @@ estimateAandC, reduce-scatter of A / Cmx by Gaussian blocks, sharded updateTesti
 N > 1 the default (EM) run also reports that iteration as `tv_em`.  The collectives are the C ABI's own (gmmiv_comm_*: RCCL
 called by libgmmiv on the device buffers); torch.distributed only launches the ranks and carries the 128-byte RCCL id.
 
-Launch: python bench.py --gpus 1   |   python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+Launch: python bench.py --gpus N (N > 1 without a launcher's WORLD_SIZE: bench.py starts its N ranks itself, like the reference
+tools start their own worker threads, AccumulateStat.cpp:234-299) | python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N.  The number of ranks must equal --gpus and every rank needs its own GPU -- anything else exits non-zero, unless
+--share-gpu is given: a correctness mode in which the ranks share the visible device(s) over the C ABI's "shm" transport
+(gloo carries the launcher's small messages); its throughput says nothing about scaling and the JSON line says so.
 """
 import argparse
 import json
@@ -140,11 +144,7 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         fused["i-vectors/s"] = U * world / (fused["stats_ms"] * 1e-3 + times["solve_ms"] * 1e-3)
     finally:
         ctx.set_option("em_fused", 0)
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, world, dev)
     parity = ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None
     return {"metric": "i-vectors/s (IvExtractor end-to-end, 2048-g UBM, rank 400, 3000-frame utterances)",
             "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "stats_ms": times["stats_ms"],
@@ -167,7 +167,7 @@ def ivector_parity(x, frames, w, mean, iv, Tm, W, rows):
     return {"utterances_checked": rows, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "ok": worst < 1e-6}
 
 
-def make_collectives(ctx, dev, world, rank, want):
+def make_collectives(ctx, dev, world, rank, want, transport=None):
     """The product's collectives (gmmiv_comm_* = RCCL inside libgmmiv).  Every rank must end up with the SAME back end, so
     the outcome of the communicator set-up is agreed through the launcher's process group; if it failed anywhere, all ranks
     use torch.distributed's RCCL binding instead and the JSON line says so (`collectives`)."""
@@ -183,13 +183,13 @@ def make_collectives(ctx, dev, world, rank, want):
 
     def create():
         try:
-            box["coll"] = gd.gmmiv_collectives_from_torch(ctx, dev)
+            box["coll"] = gd.gmmiv_collectives_from_torch(ctx, dev, transport)
         except Exception as e:      # noqa: BLE001 - reported, never silent
             box["err"] = repr(e)
     th = threading.Thread(target=create, daemon=True)
     th.start()
     th.join(timeout=180.0)
-    ok = torch.tensor([1 if "coll" in box else 0], dtype=torch.int32, device=dev)
+    ok = torch.tensor([1 if "coll" in box else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 1:
         coll = box["coll"]
@@ -206,13 +206,24 @@ def make_collectives(ctx, dev, world, rank, want):
 class GpuTvOps:
     """The per-rank compute of one TotalVariability iteration on device-resident statistics (lia_ral_amd.dist.tv_em_iteration)."""
 
-    def __init__(self, ctx, N, F, Tm, invvar, means, R):
+    def __init__(self, ctx, N, F, Tm, invvar, means, R, F_raw=None):
         self.ctx, self.N, self.F, self.T, self.invvar, self.means, self.R = ctx, N, F, Tm, invvar, means, R
+        self.F_raw = F_raw          # the uncentred first-order statistics (TVAcc::storeStats), or None: F is centred once and kept
         dev = N.device
         P = R * (R + 1) // 2
         z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
         self.tett_buf = torch.empty((C, P), dtype=torch.float64, device=dev)
         self.acc = dict(A=z(C, P), Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=torch.empty((N.shape[0], R), dtype=torch.float64, device=dev))
+
+    def stream_context(self):
+        return torch.cuda.stream(self.ctx.torch_stream())
+
+    def recentre(self):
+        """TotalVariability.cpp:123-124: the statistics are reloaded and substractM runs at the top of EVERY iteration --
+        minDivergence has moved the UBM means since the last one."""
+        if self.F_raw is not None:
+            self.F.copy_(self.F_raw)                                    # TVAcc::restoreStats
+            self.ctx.tv_subtract_m(self.N, self.F, self.means, C, D)    # TVAcc::substractM with the current means
 
     def tett(self):
         self.ctx.tv_tett(self.T, self.invvar, C, D, out=self.tett_buf)
@@ -235,42 +246,97 @@ class GpuTvOps:
 TV_FLOP_PER_UTT = 2.0 * C * (400 * 401 // 2) * 2 + 2.0 * C * D * 400 * 2 + 21.7e6    # L + A (packed), aux + Cmx, solve: 875 M
 
 
-def tv_cpu_baseline(R):
-    """The oracle's scalar estimateAandC loop (AccumulateTVStat.cpp:1702-1795 restated) on 6 utterances at full shape, 1 thread."""
+def tv_parity_and_cpu_baseline(ops, R, U_chk=4, want_cpu=True):
+    """The CHECKER leg of the T-matrix workload (untimed, rank 0): estimateAandC of this rank's first U_chk utterances under the
+    CURRENT T at full shape, HIP (a fresh call on those rows) against the oracle's scalar loop (AccumulateTVStat.cpp:1702-1795
+    restated) on the same rows; every Gaussian of A, all of Cmx, W, R, r.  The oracle's run time on those utterances is the
+    cpu_baseline of this workload (1 thread, TETt precomputed)."""
     from oracle import oracle as orc
-    rng = np.random.default_rng(0)
-    U = 6
-    N = rng.gamma(0.6, 2.5, (U, C)); F = rng.normal(size=(U, C * D)); Tm = rng.normal(0, 0.02, (R, C * D)); iv = rng.uniform(0.5, 2, C * D)
-    te = orc.tv_tett(Tm, iv, C, D)
+    ctx = ops.ctx
+    Nd, Fd = ops.N[:U_chk].contiguous(), ops.F[:U_chk].contiguous()
+    got = ctx.tv_estimate_a_and_c(Nd, Fd, ops.T, ops.invvar, ops.tett_buf, C, D, acc=dict(
+        A=torch.zeros_like(ops.acc["A"]), Cmx=torch.zeros_like(ops.acc["Cmx"]), Rm=torch.zeros_like(ops.acc["Rm"]),
+        r=torch.zeros_like(ops.acc["r"]), meanW=torch.zeros_like(ops.acc["meanW"]),
+        W=torch.empty((U_chk, R), dtype=torch.float64, device=Nd.device)))
+    torch.cuda.synchronize()
+    Th, ivh = ops.T.cpu().numpy(), ops.invvar.cpu().numpy()
+    te = orc.tv_tett(Th, ivh, C, D)
+    te_err = float(np.max(np.abs(ops.tett_buf.cpu().numpy() - te)) / np.max(np.abs(te)))
     t = time.time()
-    orc.tv_estimate_a_and_c(N, F, Tm, iv, te)
+    ref = orc.tv_estimate_a_and_c(Nd.cpu().numpy(), Fd.cpu().numpy(), Th, ivh, te)
     dt = time.time() - t
-    return {"value": U / dt, "unit": "utterances/s", "cores": 1, "kind": "port",
-            "sample": "estimateAandC on %d utterances at C=2048, R=%d, scalar fp64 oracle (-O2), %.1f s; TETt precomputed" % (U, R, dt)}
+    rel = lambda a, b: float(np.max(np.abs(a.cpu().numpy() - b)) / max(np.max(np.abs(b)), 1e-300))
+    errs = {"TETt": te_err, "A": rel(got["A"], ref["A"]), "Cmx": rel(got["Cmx"], ref["Cmx"]), "W": rel(got["W"], ref["W"]),
+            "R": rel(got["Rm"], ref["Rm"]), "r": rel(got["r"], ref["r"])}
+    worst = max(errs.values())
+    parity = {"max_rel_err": worst, "tolerance": 1e-9, "ok": bool(worst < 1e-9), "per_output": errs,
+              "what": "estimateTETt + estimateAandC of %d utterances at C=%d, R=%d under the T of the last timed iteration: libgmmiv vs the "
+                      "oracle's scalar loops (restatement, parity unpinned: no reference vector exists for this path)" % (U_chk, C, R)}
+    cpu = {"value": U_chk / dt, "unit": "utterances/s", "cores": 1, "kind": "port",
+           "sample": "estimateAandC on %d utterances at C=2048, R=%d, scalar fp64 oracle (-O2), %.1f s; TETt precomputed" % (U_chk, R, dt)}
+    return parity, (cpu if want_cpu else None)
 
 
-def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup):
+def em_parity(ctx, g, w, mean, iv, x, acc_last, frames_per_rank, world, nframes=2000):
+    """The CHECKER leg of the headline (untimed): (1) the EM statistics of the first `nframes` frames of the timed block under
+    the seed model, libgmmiv against the oracle (MixtureStat::computeAndAccumulateEM restated, pinned by KAT-2); (2) a
+    size-independent property of the LAST TIMED step's all-reduced accumulator at full size: the posteriors of a frame sum to
+    one, so sum_c occ_c = the frame count over all ranks = acc[-1]."""
+    from oracle import oracle as orc
+    g.set(w, mean, iv)
+    xs = x[:nframes]
+    acc = torch.zeros(g.em_acc_len(), dtype=torch.float64, device=x.device)
+    g.em_accumulate(xs, acc=acc)
+    torch.cuda.synchronize()
+    a = g.split_acc(acc.cpu().numpy())
+    ref = orc.em_accumulate(orc.Gmm(w, mean, iv), xs.cpu().numpy().astype(np.float64))
+    rel = lambda p, q: float(np.max(np.abs(p - q)) / np.max(np.abs(q)))
+    errs = {"occ": rel(a["occ"], ref["occ"]), "sum_gamma_x": rel(a["sx"], ref["sx"]), "sum_gamma_x2": rel(a["sxx"], ref["sxx"]),
+            "sum_log_lk": float(abs(a["llk"] - ref["llk"]) / abs(ref["llk"]))}
+    last = acc_last.cpu().numpy()
+    total = float(frames_per_rank) * world
+    occ_sum_err = float(abs(last[:C].sum() - total) / total)
+    count_ok = bool(last[-1] == total)
+    worst = max(errs.values())
+    return {"max_rel_err": worst, "tolerance": 1e-9, "ok": bool(worst < 1e-9 and occ_sum_err < 1e-9 and count_ok), "per_output": errs,
+            "timed_step_invariant": {"sum_occ_vs_frames_rel_err": occ_sum_err, "frame_count_exact": count_ok, "frames_all_ranks": total},
+            "what": "EM statistics of the first %d frames of the timed block under the seed model: libgmmiv vs the oracle "
+                    "(computeAndAccumulateEM restated, pinned by KAT-2); plus sum_c occ_c == frames on the last timed step's accumulator" % nframes}
+
+
+def max_over_ranks(dt, world, dev):
+    """The slowest rank's time (the contract's MAX over ranks); on the gloo launcher group the value travels as a host tensor."""
+    if world == 1:
+        return dt
+    import torch.distributed as dist
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True):
     """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
-    then `steps` EM iterations timed.  Returns the JSON fields of the workload."""
+    then `steps` EM iterations timed, each the tool's full sequence: restore + substractM, estimateTETt, estimateAandC,
+    updateTestimate (sharded), minDivergence.  Returns the JSON fields of the workload."""
     from lia_ral_amd import dist as gd
     import torch.distributed as dist
     invvar = torch.from_numpy(iv.ravel().copy()).to(dev)
     means = torch.from_numpy(mean.ravel().copy()).to(dev)
     N = torch.empty((U, C), dtype=torch.float64, device=dev)
-    F = torch.empty((U, C * D), dtype=torch.float64, device=dev)
+    F_raw = torch.empty((U, C * D), dtype=torch.float64, device=dev)
     t_stats = time.perf_counter()
     CH = 1250
     for u0 in range(0, U, CH):
         n = min(CH, U - u0)
         x = synth_frames(w, mean, iv, n * frames, dev, seed=9000 + 131 * rank + u0)
-        g.tv_stats(x, np.arange(n + 1, dtype=np.int64) * frames, N[u0:u0 + n], F[u0:u0 + n])
+        g.tv_stats(x, np.arange(n + 1, dtype=np.int64) * frames, N[u0:u0 + n], F_raw[u0:u0 + n])
         del x
-    ctx.tv_subtract_m(N, F, means, C, D)                # TVAcc::substractM once (the centred statistics are kept)
     torch.cuda.synchronize()
     t_stats = time.perf_counter() - t_stats
+    F = torch.empty_like(F_raw)                               # the centred working copy, rebuilt by every iteration's recentre
     gen = torch.Generator(device=dev); gen.manual_seed(5)     # the same initial T on every rank
     Tm = 0.01 * torch.randn((R, C * D), dtype=torch.float64, device=dev, generator=gen)
-    ops = GpuTvOps(ctx, N, F, Tm, invvar, means, R)
+    ops = GpuTvOps(ctx, N, F, Tm, invvar, means, R, F_raw=F_raw)
     n_total = U * world
 
     def barrier():
@@ -286,22 +352,19 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
     for _ in range(steps):
         gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     nbytes = coll.take_bytes() / max(steps, 1)
     ph = {k: v / steps * 1e3 for k, v in phases.items() if k != "sync"}
     estep_tf = TV_FLOP_PER_UTT * U / (ph["estep"] * 1e-3) / 1e12
     finite = bool(torch.isfinite(ops.T).all().item())
-    return {
+    res = {
         "metric": "utterances/s (TotalVariability: one T-matrix EM iteration, 2048-g UBM, rank %d)" % R,
         "value": n_total * steps / dt, "unit": "utterances/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "TotalVariability T-matrix EM: 2048-g UBM, rank %d, %d utterances x %d frames per GPU (50 k over 8 GPUs), "
-                               "N/F resident in HBM, 1 EM iteration per step" % (R, U, frames),
+                               "N/F resident in HBM, 1 EM iteration per step (restore + substractM, estimateTETt, estimateAandC, "
+                               "updateTestimate, minDivergence)" % (R, U, frames),
                    "gaussians": C, "dim": D, "rank": R, "utterances_per_gpu": U,
                    "partitioning": "utterances sharded per rank; reduce-scatter of A_packed / Cmx by Gaussian blocks, sharded "
                                    "updateTestimate, all-gather of T, all-reduce of R / r / meanW"},
@@ -311,6 +374,28 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
                      "unit": "TFLOP/s", "frac": estep_tf / PEAK_F64_TFLOPS, "traffic": None,
                      "algorithmic_flop_per_utterance": TV_FLOP_PER_UTT, "kernel_ms": ph["estep"]},
     }
+    if rank == 0 and check:
+        res["parity"], cpub = tv_parity_and_cpu_baseline(ops, R, want_cpu=cpu)
+        if cpub:
+            res["cpu_baseline"] = cpub
+    return res
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node (the
+    same command line the driver uses) and hand its exit status back."""
+    import socket
+    import subprocess
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -329,39 +414,75 @@ def main():
                     help="std of the synthetic UBM means (SURVEY 8(d): 2.0; smaller = overlapping Gaussians)")
     ap.add_argument("--em-fused", type=int, default=-1, help="A/B knob: 1 = single-pass cooperative EM kernel, 0 = two-kernel path")
     ap.add_argument("--wg-waves", type=int, default=0, help="A/B knob: waves per workgroup of the MFMA kernels (4 or 8)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="correctness mode: let the ranks share the visible GPU(s) (rank r on device r %% count) over the C ABI's shm transport")
     args = ap.parse_args()
 
+    ndev = torch.cuda.device_count()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves (the reference tools fan their worker threads out the same way)
+        if ndev < args.gpus and not args.share_gpu:
+            print("bench.py: --gpus %d but %d GPU(s) visible: one rank per GPU is required (pass --share-gpu to run the ranks on "
+                  "shared devices for a correctness check only)" % (args.gpus, ndev), file=sys.stderr, flush=True)
+            sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a number for the wrong job size"
+              % (args.gpus, world), file=sys.stderr, flush=True)
+        sys.exit(2)
+    if ndev < 1 or (ndev < world and not args.share_gpu):
+        print("bench.py: %d rank(s) but %d GPU(s) visible (one rank per GPU; --share-gpu for a correctness-only run)" % (world, ndev),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    shared = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        if shared:       # RCCL refuses two ranks on one device: the launcher group runs on gloo, the data path on gmmiv's shm transport
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
 
     from conftest import make_gmm
     from lia_ral_amd import capi
 
     w, mean, iv = make_gmm(C, D, seed=0, spread=args.mean_spread)
     T = args.frames
-    ctx = capi.Context(local, torch.cuda.current_stream().cuda_stream)
+    # ONE stream for everything: torch's kernels (synthetic data, re-layouts of the sharded M-step) and libgmmiv's kernels and
+    # collectives are enqueued on it in program order -- no cross-stream hazards, and the HIP events of the library bracket
+    # exactly its own kernels
+    side = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(side)
+    ctx = capi.Context(local, side.cuda_stream)
     ctx.set_option("timing", 1)
     if args.wg_waves:
         ctx.set_option("wg_waves", args.wg_waves)
     if args.em_fused >= 0:
         ctx.set_option("em_fused", args.em_fused)
     g = ctx.gmm(w, mean, iv)
-    coll, coll_note = make_collectives(ctx, dev, world, rank, args.collectives)
+    coll, coll_note = make_collectives(ctx, dev, world, rank, args.collectives, "shm" if shared else None)
+    if coll.world != world:
+        print("bench.py: the communicator spans %d rank(s), the job %d" % (coll.world, world), file=sys.stderr, flush=True)
+        sys.exit(2)
+    comm_info = {"world": coll.world, "backend": getattr(coll, "backend", coll.name), "launcher_group": (dist.get_backend() if world > 1 else None),
+                 "physical_gpus": min(ndev, world), "gpu_sharing": shared}
+    if shared:
+        comm_info["note"] = "ranks SHARE the GPU(s): a correctness run of the multi-rank orchestration, not a scaling measurement"
+    check = not args.no_cpu_baseline
     if args.workload == "tv":
-        res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup)
+        res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup,
+                          check=check, cpu=(world == 1))
         if rank == 0:
+            res["comm"] = comm_info
             if coll_note:
                 res["collectives_note"] = coll_note
-            if world == 1 and not args.no_cpu_baseline:
-                res["cpu_baseline"] = tv_cpu_baseline(args.tv_rank)
             print(json.dumps(res), flush=True)
         g.close()
         ctx.close()
@@ -411,11 +532,8 @@ def main():
     for _ in range(args.steps):
         step(record=True)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    parity = em_parity(ctx, g, w, mean, iv, x, acc, T, world) if rank == 0 and check else None   # untimed checker leg
 
     pairs_per_step = float(T) * C * world
     value = pairs_per_step * args.steps / dt / 1e9
@@ -428,8 +546,10 @@ def main():
                                "resident in HBM, 1 EM iteration per step" % T,
                    "gaussians": C, "dim": D, "frames_per_gpu": T, "partitioning": "frames sharded per rank, "
                    "one RCCL all-reduce of %d doubles per step" % nacc},
-        "collectives": coll.name,
+        "collectives": coll.name, "comm": comm_info,
     }
+    if parity:
+        out["parity"] = parity
     if coll_note:
         out["collectives_note"] = coll_note
     # the same E-step on a heavily overlapping mixture (means ~ N(0, 0.3^2)): hundreds of Gaussians carry
@@ -474,11 +594,11 @@ def main():
     tv_em = None
     if not args.no_secondary:
         g.set(w, mean, iv)     # back to the seed model for the i-vector slice
-        secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, check=not args.no_cpu_baseline)
+        secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
         if world > 1:          # configs[3] is natively multi-GPU: one T-matrix EM iteration on utterance-sharded statistics
             x = xs = None          # release the 2.4 GB frame block of the EM workload
             torch.cuda.empty_cache()
-            tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1)
+            tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1, check=check, cpu=False)
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
@@ -514,7 +634,7 @@ def main():
         out["step_roofline"] = {"bound": "mfma", "algorithmic_flop_per_pair": FLOP_PER_PAIR_LLK + FLOP_PER_PAIR_ACC,
                                 "achieved": step_tf, "peak": PEAK_F64_TFLOPS * world, "unit": "TFLOP/s",
                                 "frac": step_tf / (PEAK_F64_TFLOPS * world)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and check:
             out["cpu_baseline"] = cpu_baseline(w, mean, iv, seed=99)
         print(json.dumps(out), flush=True)
     g.close()

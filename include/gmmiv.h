@@ -42,7 +42,9 @@ enum { GMMIV_TOP_PARTIAL = 0, GMMIV_TOP_COMPLETE = 1 }; /* computeLLKWithTopDist
 #define GMMIV_ERR_NUMERIC (-4)
 
 /* ---- context --------------------------------------------------------------------------- */
-/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a private one. */
+/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a private non-blocking one.  A caller whose
+ * other work runs on the NULL (legacy default) stream passes hipStreamLegacy ((hipStream_t)1) to have the context launch there:
+ * a private stream is NOT ordered with the NULL stream, so buffers written by NULL-stream work must be complete before a call. */
 int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out);
 void gmmiv_ctx_destroy(gmmiv_ctx *ctx);
 int gmmiv_ctx_sync(gmmiv_ctx *ctx);
@@ -358,17 +360,33 @@ int gmmiv_jfa_estimate_z_and_d(gmmiv_ctx *ctx, int64_t nspk, int C, int D, const
  * then EVERY rank calls gmmiv_comm_create (collective).  world == 1 needs no id and no RCCL.  The calls are enqueued on the
  * context's stream; device buffers are used in place, host buffers (allreduce / broadcast only) are staged and the call
  * returns after the result is back.  RCCL is loaded at run time (dlopen of the copy already mapped in the process, else
- * librccl.so.1; override with the environment variable GMMIV_RCCL_LIB): GMMIV_ERR_UNSUPPORTED when it cannot be found. */
+ * librccl.so.1; the environment variable GMMIV_RCCL_LIB, when set, names the ONLY library tried): GMMIV_ERR_UNSUPPORTED when
+ * it cannot be found.
+ *
+ * Transports.  The id rank 0 draws selects the transport of the communicator every rank then creates from it:
+ *   "rccl"  (default) RCCL over xGMI / PCIe, one rank per GPU -- the production path;
+ *   "shm"   ranks of ONE host that may SHARE a GPU (RCCL refuses two ranks on one device), or a host without RCCL: buffers
+ *           are staged through one mmap'ed file (GMMIV_COMM_SHM_DIR, default /dev/shm; GMMIV_COMM_SHM_SLOT_MB per rank,
+ *           default 16) and every rank sums the pieces on its own device in rank order -- bitwise the same result on every
+ *           rank.  It is how the multi-rank orchestration (reduce-scatter by Gaussian blocks, sharded updateTestimate,
+ *           all-gather) is exercised end to end on a one-GPU machine; calls block until the exchange is complete.
+ * gmmiv_comm_get_unique_id_for(transport, id): transport "rccl", "shm", or NULL = the environment variable
+ * GMMIV_COMM_TRANSPORT, else "rccl"; gmmiv_comm_get_unique_id(id) = gmmiv_comm_get_unique_id_for(NULL, id).
+ * A rank that waits longer than GMMIV_COMM_TIMEOUT_S (default 300) for its peers in the shm transport fails with GMMIV_ERR_HIP. */
 typedef struct gmmiv_comm gmmiv_comm;
 #define GMMIV_COMM_ID_BYTES 128
 int gmmiv_comm_get_unique_id(void *id128);
-/* rank 0: creates the id and publishes it at `path` (atomically); other ranks: wait up to timeout_s for it and read it. */
+int gmmiv_comm_get_unique_id_for(const char *transport, void *id128);
+/* rank 0: creates the id and publishes it at `path` (atomically; a file already there is removed first); other ranks: wait up
+ * to timeout_s for it and read it (a file last modified more than 30 s before the call is taken for a dead job's leftover and
+ * ignored).  Rank 0 removes the file again as soon as its gmmiv_comm_create on that id has succeeded -- every rank has read
+ * the id by then -- so a path can be reused by the next job. */
 int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double timeout_s);
 int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gmmiv_comm **out);
 void gmmiv_comm_destroy(gmmiv_comm *comm);
 int gmmiv_comm_world(const gmmiv_comm *comm);
 int gmmiv_comm_rank(const gmmiv_comm *comm);
-const char *gmmiv_comm_backend(const gmmiv_comm *comm); /* path of the RCCL library in use */
+const char *gmmiv_comm_backend(const gmmiv_comm *comm); /* "rccl: <path of the library in use>", "shm (...)", or "single rank ..." */
 /* payload bytes this rank passed to collectives since the last call of this function (then reset to 0) */
 double gmmiv_comm_take_bytes(gmmiv_comm *comm);
 /* buf[n] <- sum over ranks (in place; host or device) */

@@ -38,6 +38,7 @@ def _load():
     lib.gmmiv_ctx_set_option.restype = ct.c_long
     lib.gmmiv_comm_backend.restype = ct.c_char_p
     lib.gmmiv_comm_take_bytes.restype = ct.c_double
+    lib.gmmiv_ctx_stream.restype = ct.c_void_p
     return lib
 
 
@@ -85,10 +86,51 @@ def _feat(x):
     return x, (F64 if x.dtype == np.float64 else F32), x.shape[0], x.shape[1]
 
 
+HIP_STREAM_LEGACY = 1      # hipStreamLegacy: the NULL stream, as an explicit handle
+
+
 class Context:
+    """stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) or None for a private non-blocking stream.
+    The handle 0 -- what torch reports for its DEFAULT stream -- means "the stream torch is using", so it is passed on as
+    hipStreamLegacy: every call of the context is then ordered with the torch kernels around it (a private stream would not be).
+    torch_stream(): the same stream as a torch object, for `with torch.cuda.stream(ctx.torch_stream()):`."""
+
     def __init__(self, device=0, stream=None):
         self._h = ct.c_void_p()
+        self.device = int(device)
+        if stream is not None and int(stream) == 0:
+            stream = HIP_STREAM_LEGACY
         _chk(lib.gmmiv_ctx_create(ct.c_int(device), ct.c_void_p(stream or 0), ct.byref(self._h)))
+
+    def stream(self):
+        return int(lib.gmmiv_ctx_stream(self._h) or 0)
+
+    def ordered(self):
+        """Context manager: the context's stream waits for torch's current stream on entry, torch's current stream waits for
+        the context's on exit -- calls made inside see every tensor torch has written and torch sees their results.  A no-op
+        when both are the same stream."""
+        import contextlib
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        mine = self.torch_stream()
+        if cur.cuda_stream == mine.cuda_stream:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def bracket():
+            mine.wait_stream(cur)
+            try:
+                yield
+            finally:
+                cur.wait_stream(mine)
+        return bracket()
+
+    def torch_stream(self):
+        import torch
+        h = self.stream()
+        if h in (0, HIP_STREAM_LEGACY):
+            return torch.cuda.default_stream(self.device)
+        return torch.cuda.ExternalStream(h, device=self.device)
 
     def close(self):
         if self._h:
@@ -407,9 +449,10 @@ class Comm:
         _chk(lib.gmmiv_comm_create(ctx._h, self.world, self.rank, buf, ct.byref(self._h)))
 
     @staticmethod
-    def unique_id():
+    def unique_id(transport=None):
+        """transport: "rccl", "shm" (ranks sharing a GPU / no RCCL; see include/gmmiv.h) or None = $GMMIV_COMM_TRANSPORT, else rccl."""
         buf = ct.create_string_buffer(COMM_ID_BYTES)
-        _chk(lib.gmmiv_comm_get_unique_id(buf))
+        _chk(lib.gmmiv_comm_get_unique_id_for(transport.encode() if transport else None, buf))
         return buf.raw
 
     @staticmethod

@@ -6,11 +6,21 @@
 // RCCL is resolved at run time (dlopen) so that libgmmiv.so keeps a single hard dependency, the HIP runtime: a single-GPU
 // user never needs RCCL (world == 1 is handled without it), and inside a PyTorch process the copy of RCCL that torch already
 // mapped is reused instead of loading a second one next to it.
+//
+// Second transport, "shm" (opt-in, chosen by the id rank 0 draws): the ranks stage their buffers through ONE mmap'ed file and
+// every rank sums the pieces ON ITS DEVICE in rank order (bitwise the same result on every rank).  It exists for ranks that
+// SHARE a GPU (RCCL refuses two ranks on one device) and for boxes without RCCL: it is how the multi-rank orchestration of
+// the T-matrix EM / UBM EM runs on a one-GPU machine.  A production node uses RCCL over xGMI.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <link.h>
 #include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <mutex>
 
 #include <rccl/rccl.h>
@@ -50,13 +60,23 @@ void load_rccl()
     std::string loaded;
     dl_iterate_phdr(find_loaded_rccl, &loaded); // e.g. torch/lib/librccl.so inside a PyTorch process
     const char *env = getenv("GMMIV_RCCL_LIB");
-    const char *cand[] = {env, loaded.empty() ? nullptr : loaded.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *name : cand) {
+    // GMMIV_RCCL_LIB, when set, is the ONLY candidate (an override that silently fell through to another copy would hide a typo)
+    const char *cand_env[] = {env};
+    const char *cand_def[] = {loaded.empty() ? nullptr : loaded.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const bool forced = env && *env;
+    const char *const *cand = forced ? cand_env : cand_def;
+    const int ncand = forced ? 1 : 4;
+    for (int ci = 0; ci < ncand; ++ci) {
+        const char *name = cand[ci];
         if (!name || !*name) continue;
         g_rccl.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.h) { g_rccl.where = name; break; }
     }
-    if (!g_rccl.h) { g_rccl_err = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?"); return; }
+    if (!g_rccl.h) {
+        const char *e = dlerror(); // ONE call: dlerror() clears the message it returns
+        g_rccl_err = std::string("RCCL not found (dlopen librccl.so.1): ") + (e ? e : "?");
+        return;
+    }
     bool ok = true;
     auto sym = [&](const char *n) { void *p = dlsym(g_rccl.h, n); if (!p) { ok = false; g_rccl_err = std::string("RCCL symbol missing: ") + n; } return p; };
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
@@ -79,6 +99,33 @@ const Rccl *rccl()
 
 } // namespace
 
+// ---- "shm" transport: one mmap'ed file, a slot per rank, a sense-reversing barrier in its header ----------------------------
+static const char SHM_MAGIC[8] = {'G', 'M', 'M', 'I', 'V', 'S', 'H', 'M'};
+
+struct ShmHdr {
+    char magic[8];
+    uint32_t world;
+    std::atomic<uint32_t> ready;   // rank 0 sets it once the header is initialised
+    std::atomic<uint32_t> count;   // barrier arrivals of the current generation
+    std::atomic<uint32_t> gen;     // barrier generation
+    std::atomic<uint32_t> failed;  // a rank gave up (timeout / HIP error): the others stop waiting
+    uint64_t slot_bytes;
+};
+static const size_t SHM_HDR_BYTES = 4096;
+static_assert(sizeof(ShmHdr) <= SHM_HDR_BYTES, "header page");
+
+static double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+__global__ void k_comm_add_f64(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
 struct gmmiv_comm {
     gmmiv_ctx *ctx = nullptr;
     int world = 1, rank = 0;
@@ -87,6 +134,12 @@ struct gmmiv_comm {
     void *stage = nullptr; // device staging for HOST buffers (grow-only)
     size_t stage_bytes = 0;
     double bytes_moved = 0.0; // payload bytes this rank handed to collectives since the last query
+    // shm transport
+    ShmHdr *shm = nullptr;
+    size_t shm_bytes = 0;
+    std::string shm_path, backend;
+    void *addbuf = nullptr; // device staging of one slot (the summand of a peer)
+    double timeout_s = 300.0;
     int staged(size_t bytes, void **out)
     {
         if (stage_bytes < bytes) {
@@ -97,7 +150,200 @@ struct gmmiv_comm {
         *out = stage;
         return GMMIV_OK;
     }
+    bool is_shm() const { return shm != nullptr; }
+    double *slot(int r) const { return (double *)((char *)shm + SHM_HDR_BYTES + (size_t)r * shm->slot_bytes); }
+    size_t slot_elems() const { return (size_t)(shm->slot_bytes / 8); }
+    int fail(const char *what)
+    {
+        if (shm) shm->failed.store(1, std::memory_order_release);
+        gmmiv_set_error("gmmiv_comm (shm, rank %d of %d): %s", rank, world, what);
+        return GMMIV_ERR_HIP;
+    }
+    int barrier()
+    {
+        const uint32_t g = shm->gen.load(std::memory_order_acquire);
+        if (shm->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+            shm->count.store(0, std::memory_order_relaxed);
+            shm->gen.store(g + 1, std::memory_order_release);
+            return GMMIV_OK;
+        }
+        const double t0 = now_s();
+        for (unsigned spin = 0; shm->gen.load(std::memory_order_acquire) == g; ++spin) {
+            if (shm->failed.load(std::memory_order_acquire)) return fail("a peer rank failed");
+            if (spin > 2000) usleep(50);
+            if ((spin & 1023) == 1023 && now_s() - t0 > timeout_s) return fail("barrier timed out (a peer rank is gone?)");
+        }
+        return GMMIV_OK;
+    }
+    // dst[m] (device) <- sum over ranks r = 0 .. world-1, in that order, of the m doubles at element offset `eoff` of slot r
+    int sum_slots(double *dst, size_t eoff, size_t m)
+    {
+        hipStream_t st = ctx->stream;
+        GCHK(hipMemcpyAsync(dst, slot(0) + eoff, m * 8, hipMemcpyHostToDevice, st));
+        for (int r = 1; r < world; ++r) {
+            GCHK(hipMemcpyAsync(addbuf, slot(r) + eoff, m * 8, hipMemcpyHostToDevice, st));
+            const unsigned blocks = (unsigned)((m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048);
+            hipLaunchKernelGGL(k_comm_add_f64, dim3(blocks), dim3(256), 0, st, dst, (const double *)addbuf, m);
+            GCHK(hipGetLastError());
+        }
+        GCHK(hipStreamSynchronize(st));
+        return GMMIV_OK;
+    }
 };
+
+#define SCHK(c, expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t _e = (hipError_t)(expr);                                                                            \
+        if (_e != hipSuccess) {                                                                                        \
+            (c)->shm->failed.store(1, std::memory_order_release);                                                      \
+            gmmiv_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));                      \
+            return GMMIV_ERR_HIP;                                                                                      \
+        }                                                                                                              \
+    } while (0)
+#define SRC(c, expr)                                                                                                   \
+    do {                                                                                                               \
+        int _rc = (expr);                                                                                              \
+        if (_rc) { (c)->shm->failed.store(1, std::memory_order_release); return _rc; }                                 \
+    } while (0)
+
+namespace {
+
+int shm_allreduce(gmmiv_comm *c, double *buf, size_t n)
+{
+    hipStream_t st = c->ctx->stream;
+    const size_t ch = c->slot_elems();
+    for (size_t off = 0; off < n; off += ch) {
+        const size_t m = n - off < ch ? n - off : ch;
+        SCHK(c, hipMemcpyAsync(c->slot(c->rank), buf + off, m * 8, hipMemcpyDeviceToHost, st));
+        SCHK(c, hipStreamSynchronize(st));
+        SRC(c, c->barrier());
+        SRC(c, c->sum_slots(buf + off, 0, m));
+        SRC(c, c->barrier()); // nobody overwrites its slot before everybody has read it
+    }
+    return GMMIV_OK;
+}
+
+int shm_reduce_scatter(gmmiv_comm *c, const double *send, double *recv, size_t recvcount)
+{
+    hipStream_t st = c->ctx->stream;
+    const size_t ch = c->slot_elems() / (size_t)c->world; // a slot holds one piece per destination
+    if (ch == 0) return c->fail("slot smaller than the world size");
+    for (size_t off = 0; off < recvcount; off += ch) {
+        const size_t m = recvcount - off < ch ? recvcount - off : ch;
+        for (int d = 0; d < c->world; ++d)
+            SCHK(c, hipMemcpyAsync(c->slot(c->rank) + (size_t)d * ch, send + (size_t)d * recvcount + off, m * 8, hipMemcpyDeviceToHost, st));
+        SCHK(c, hipStreamSynchronize(st));
+        SRC(c, c->barrier());
+        SRC(c, c->sum_slots(recv + off, (size_t)c->rank * ch, m));
+        SRC(c, c->barrier());
+    }
+    return GMMIV_OK;
+}
+
+int shm_allgather(gmmiv_comm *c, const double *send, double *recv, size_t sendcount)
+{
+    hipStream_t st = c->ctx->stream;
+    const size_t ch = c->slot_elems();
+    for (size_t off = 0; off < sendcount; off += ch) {
+        const size_t m = sendcount - off < ch ? sendcount - off : ch;
+        SCHK(c, hipMemcpyAsync(c->slot(c->rank), send + off, m * 8, hipMemcpyDeviceToHost, st));
+        SCHK(c, hipStreamSynchronize(st));
+        SRC(c, c->barrier());
+        for (int r = 0; r < c->world; ++r)
+            SCHK(c, hipMemcpyAsync(recv + (size_t)r * sendcount + off, c->slot(r), m * 8, hipMemcpyHostToDevice, st));
+        SCHK(c, hipStreamSynchronize(st));
+        SRC(c, c->barrier());
+    }
+    return GMMIV_OK;
+}
+
+int shm_broadcast(gmmiv_comm *c, double *buf, size_t n, int root)
+{
+    hipStream_t st = c->ctx->stream;
+    const size_t ch = c->slot_elems();
+    for (size_t off = 0; off < n; off += ch) {
+        const size_t m = n - off < ch ? n - off : ch;
+        if (c->rank == root) {
+            SCHK(c, hipMemcpyAsync(c->slot(root), buf + off, m * 8, hipMemcpyDeviceToHost, st));
+            SCHK(c, hipStreamSynchronize(st));
+        }
+        SRC(c, c->barrier());
+        if (c->rank != root) {
+            SCHK(c, hipMemcpyAsync(buf + off, c->slot(root), m * 8, hipMemcpyHostToDevice, st));
+            SCHK(c, hipStreamSynchronize(st));
+        }
+        SRC(c, c->barrier());
+    }
+    return GMMIV_OK;
+}
+
+// rank 0 creates and initialises the file named in the id, the others wait for it; a first barrier, then rank 0 unlinks the
+// name (the mappings keep the memory alive, nothing is left behind when the ranks exit or crash later)
+int shm_attach(gmmiv_comm *c, const char *path)
+{
+    const char *mb = getenv("GMMIV_COMM_SHM_SLOT_MB");
+    size_t slot_bytes = (size_t)(mb && atol(mb) > 0 ? atol(mb) : 16) << 20;
+    const size_t total = SHM_HDR_BYTES + slot_bytes * (size_t)c->world;
+    int fd = -1;
+    if (c->rank == 0) {
+        fd = open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { if (fd >= 0) { close(fd); unlink(path); } gmmiv_set_error("gmmiv_comm (shm): cannot create %s (%zu MiB)", path, total >> 20); return GMMIV_ERR_HIP; }
+    } else {
+        const double t0 = now_s();
+        for (;;) {
+            fd = open(path, O_RDWR);
+            struct stat sb;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= SHM_HDR_BYTES) break;
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (now_s() - t0 > c->timeout_s) { gmmiv_set_error("gmmiv_comm (shm): rank %d waited %.0f s for %s", c->rank, c->timeout_s, path); return GMMIV_ERR_HIP; }
+            usleep(2000);
+        }
+    }
+    size_t map_bytes = total;
+    if (c->rank != 0) { // the slot size is rank 0's: read it from the header page first
+        void *h = mmap(nullptr, SHM_HDR_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (h == MAP_FAILED) { close(fd); gmmiv_set_error("gmmiv_comm (shm): mmap of %s failed", path); return GMMIV_ERR_HIP; }
+        ShmHdr *hh = (ShmHdr *)h;
+        const double t0 = now_s();
+        while (hh->ready.load(std::memory_order_acquire) != 1) {
+            if (now_s() - t0 > c->timeout_s) { munmap(h, SHM_HDR_BYTES); close(fd); gmmiv_set_error("gmmiv_comm (shm): rank %d: %s never became ready", c->rank, path); return GMMIV_ERR_HIP; }
+            usleep(1000);
+        }
+        const bool ok = memcmp(hh->magic, SHM_MAGIC, 8) == 0 && hh->world == (uint32_t)c->world;
+        map_bytes = SHM_HDR_BYTES + (size_t)hh->slot_bytes * (size_t)c->world;
+        munmap(h, SHM_HDR_BYTES);
+        if (!ok) { close(fd); gmmiv_set_error("gmmiv_comm (shm): %s belongs to another job (world mismatch)", path); return GMMIV_ERR_ARG; }
+    }
+    void *m = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { if (c->rank == 0) unlink(path); gmmiv_set_error("gmmiv_comm (shm): mmap of %zu MiB failed", map_bytes >> 20); return GMMIV_ERR_HIP; }
+    c->shm = (ShmHdr *)m;
+    c->shm_bytes = map_bytes;
+    c->shm_path = path;
+    if (c->rank == 0) {
+        memcpy(c->shm->magic, SHM_MAGIC, 8);
+        c->shm->world = (uint32_t)c->world;
+        c->shm->slot_bytes = slot_bytes;
+        c->shm->count.store(0); c->shm->gen.store(0); c->shm->failed.store(0);
+        c->shm->ready.store(1, std::memory_order_release);
+    }
+    hipError_t e = hipMalloc(&c->addbuf, (size_t)c->shm->slot_bytes);
+    if (e != hipSuccess) { c->shm->failed.store(1); gmmiv_set_error("gmmiv_comm (shm): hipMalloc of the slot staging failed (%s)", hipGetErrorString(e)); return GMMIV_ERR_HIP; }
+    int rc = c->barrier();
+    if (c->rank == 0) unlink(path);
+    if (rc) return rc;
+    char b[256];
+    snprintf(b, sizeof(b), "shm (host shared-memory staging, device-side sums; %d ranks, %zu MiB slots)", c->world, (size_t)c->shm->slot_bytes >> 20);
+    c->backend = b;
+    return GMMIV_OK;
+}
+
+// the id files rank 0 published (gmmiv_comm_exchange_id_file): removed once the communicator exists, so that a later job that
+// reuses the path cannot pick up this job's id
+std::mutex g_idfile_mu;
+std::vector<std::pair<std::string, std::string> > g_idfiles; // (id bytes, path)
+
+} // namespace
 
 // Release everything that needs the context (called by gmmiv_comm_destroy, and by gmmiv_ctx_destroy for communicators the
 // caller still holds: afterwards the handle is an empty shell that gmmiv_comm_destroy can still delete safely).
@@ -108,6 +354,8 @@ void gmmiv_comm_orphan(gmmiv_comm *c)
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->nc) { (void)c->api->CommDestroy(c->nc); c->nc = nullptr; }
     if (c->stage) { (void)hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
+    if (c->addbuf) { (void)hipFree(c->addbuf); c->addbuf = nullptr; }
+    if (c->shm) { munmap((void *)c->shm, c->shm_bytes); c->shm = nullptr; }
     auto &v = c->ctx->comms;
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i] == c) { v.erase(v.begin() + i); break; }
@@ -135,9 +383,25 @@ void gmmiv_shard_range(int64_t n, int rank, int world, int64_t *begin, int64_t *
     if (end) *end = b + base + (rank < rem ? 1 : 0);
 }
 
-int gmmiv_comm_get_unique_id(void *id128)
+int gmmiv_comm_get_unique_id_for(const char *transport, void *id128)
 {
     if (!id128) { gmmiv_set_error("comm_get_unique_id: id == NULL"); return GMMIV_ERR_ARG; }
+    if (!transport || !*transport) transport = getenv("GMMIV_COMM_TRANSPORT");
+    if (!transport || !*transport) transport = "rccl";
+    if (!strcmp(transport, "shm")) {
+        const char *dir = getenv("GMMIV_COMM_SHM_DIR");
+        if (!dir || !*dir) dir = "/dev/shm";
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        static std::atomic<unsigned> serial{0};
+        char *id = (char *)id128;
+        memset(id, 0, GMMIV_COMM_ID_BYTES);
+        memcpy(id, SHM_MAGIC, 8);
+        const int n = snprintf(id + 8, GMMIV_COMM_ID_BYTES - 8, "%s/gmmiv_comm_%ld_%lld%09ld_%u", dir, (long)getpid(), (long long)ts.tv_sec, ts.tv_nsec, serial.fetch_add(1));
+        if (n <= 0 || n >= GMMIV_COMM_ID_BYTES - 8) { gmmiv_set_error("comm_get_unique_id: GMMIV_COMM_SHM_DIR too long"); return GMMIV_ERR_ARG; }
+        return GMMIV_OK;
+    }
+    if (strcmp(transport, "rccl")) { gmmiv_set_error("comm_get_unique_id: unknown transport \"%s\" (rccl, shm)", transport); return GMMIV_ERR_ARG; }
     const Rccl *api = rccl();
     if (!api) return GMMIV_ERR_UNSUPPORTED;
     static_assert(sizeof(ncclUniqueId) == GMMIV_COMM_ID_BYTES, "gmmiv.h and rccl.h disagree on the id size");
@@ -148,10 +412,13 @@ int gmmiv_comm_get_unique_id(void *id128)
     return GMMIV_OK;
 }
 
+int gmmiv_comm_get_unique_id(void *id128) { return gmmiv_comm_get_unique_id_for(nullptr, id128); }
+
 int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double timeout_s)
 {
     if (!path || !id128 || rank < 0) { gmmiv_set_error("comm_exchange_id_file: bad argument"); return GMMIV_ERR_ARG; }
     if (rank == 0) {
+        (void)unlink(path); // a file left by a job that died before its communicator existed
         int rc = gmmiv_comm_get_unique_id(id128);
         if (rc) return rc;
         const std::string tmp = std::string(path) + ".tmp";
@@ -159,15 +426,25 @@ int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double 
         if (!f || fwrite(id128, 1, GMMIV_COMM_ID_BYTES, f) != GMMIV_COMM_ID_BYTES) { if (f) fclose(f); gmmiv_set_error("comm_exchange_id_file: cannot write %s", tmp.c_str()); return GMMIV_ERR_ARG; }
         fclose(f);
         if (rename(tmp.c_str(), path) != 0) { gmmiv_set_error("comm_exchange_id_file: cannot rename %s", tmp.c_str()); return GMMIV_ERR_ARG; }
+        std::lock_guard<std::mutex> lk(g_idfile_mu);
+        g_idfiles.emplace_back(std::string((const char *)id128, GMMIV_COMM_ID_BYTES), std::string(path));
         return GMMIV_OK;
     }
+    // Only a file written "now" is this job's: one whose modification time lies more than 30 s before this call is a leftover
+    // of an earlier job at the same path (rank 0 removes its file as soon as the communicator exists, so a leftover means
+    // that job died in between) and is ignored until rank 0 replaces it.
+    struct timespec t_enter;
+    clock_gettime(CLOCK_REALTIME, &t_enter);
     const double step = 0.01;
     for (double waited = 0.0; waited <= timeout_s; waited += step) { // the rename above makes the file appear complete
-        FILE *f = fopen(path, "rb");
-        if (f) {
-            const size_t n = fread(id128, 1, GMMIV_COMM_ID_BYTES, f);
-            fclose(f);
-            if (n == GMMIV_COMM_ID_BYTES) return GMMIV_OK;
+        struct stat sb;
+        if (stat(path, &sb) == 0 && (double)sb.st_mtime >= (double)t_enter.tv_sec - 30.0) {
+            FILE *f = fopen(path, "rb");
+            if (f) {
+                const size_t n = fread(id128, 1, GMMIV_COMM_ID_BYTES, f);
+                fclose(f);
+                if (n == GMMIV_COMM_ID_BYTES) return GMMIV_OK;
+            }
         }
         usleep((useconds_t)(step * 1e6));
     }
@@ -181,7 +458,19 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
     GCHK(hipSetDevice(ctx->device));
     gmmiv_comm *c = new gmmiv_comm();
     c->ctx = ctx; c->world = world; c->rank = rank;
-    if (world > 1) {
+    if (const char *t = getenv("GMMIV_COMM_TIMEOUT_S")) { if (atof(t) > 0) c->timeout_s = atof(t); }
+    if (world > 1 && memcmp(id128, SHM_MAGIC, 8) == 0) {
+        char path[GMMIV_COMM_ID_BYTES - 8 + 1];
+        memcpy(path, (const char *)id128 + 8, GMMIV_COMM_ID_BYTES - 8);
+        path[GMMIV_COMM_ID_BYTES - 8] = 0;
+        int rc = shm_attach(c, path);
+        if (rc) {
+            if (c->addbuf) (void)hipFree(c->addbuf);
+            if (c->shm) munmap((void *)c->shm, c->shm_bytes);
+            delete c;
+            return rc;
+        }
+    } else if (world > 1) {
         c->api = rccl();
         if (!c->api) { delete c; return GMMIV_ERR_UNSUPPORTED; }
         ncclUniqueId id;
@@ -192,6 +481,13 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
             delete c;
             return GMMIV_ERR_HIP;
         }
+        c->backend = "rccl: " + c->api->where;
+    }
+    if (world > 1 && rank == 0) { // every rank has read the id by now (both transports meet inside the create): retire the id file
+        std::lock_guard<std::mutex> lk(g_idfile_mu);
+        const std::string key((const char *)id128, GMMIV_COMM_ID_BYTES);
+        for (size_t i = 0; i < g_idfiles.size(); ++i)
+            if (g_idfiles[i].first == key) { (void)unlink(g_idfiles[i].second.c_str()); g_idfiles.erase(g_idfiles.begin() + i); break; }
     }
     ctx->comms.push_back(c);
     *out = c;
@@ -201,7 +497,7 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
 void gmmiv_comm_destroy(gmmiv_comm *c)
 {
     if (!c) return;
-    gmmiv_comm_orphan(c); // releases RCCL and the staging buffer (no-op when the context already went away)
+    gmmiv_comm_orphan(c); // releases RCCL / the shared mapping and the staging buffers (no-op when the context already went away)
     delete c;
 }
 
@@ -210,7 +506,7 @@ int gmmiv_comm_rank(const gmmiv_comm *c) { return c ? c->rank : -1; }
 const char *gmmiv_comm_backend(const gmmiv_comm *c)
 {
     if (!c) return "";
-    return c->world == 1 || !c->api ? "single rank (no collective library)" : c->api->where.c_str();
+    return c->world == 1 ? "single rank (no collective library)" : c->backend.c_str();
 }
 double gmmiv_comm_take_bytes(gmmiv_comm *c)
 {
@@ -229,14 +525,16 @@ int gmmiv_allreduce_f64(gmmiv_comm *c, double *buf, size_t n)
     GCHK(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     if (gmmiv_is_device_ptr(buf)) {
+        if (c->is_shm()) return shm_allreduce(c, buf, n);
         NCHK(c, c->api->AllReduce(buf, buf, n, ncclFloat64, ncclSum, c->nc, st));
         return GMMIV_OK;
     }
     void *d;
     int rc = c->staged(n * 8, &d);
-    if (rc) return rc;
+    if (rc) { if (c->is_shm()) c->shm->failed.store(1); return rc; }
     GCHK(hipMemcpyAsync(d, buf, n * 8, hipMemcpyHostToDevice, st));
-    NCHK(c, c->api->AllReduce(d, d, n, ncclFloat64, ncclSum, c->nc, st));
+    if (c->is_shm()) { rc = shm_allreduce(c, (double *)d, n); if (rc) return rc; }
+    else NCHK(c, c->api->AllReduce(d, d, n, ncclFloat64, ncclSum, c->nc, st));
     GCHK(hipMemcpyAsync(buf, d, n * 8, hipMemcpyDeviceToHost, st));
     GCHK(hipStreamSynchronize(st));
     return GMMIV_OK;
@@ -255,6 +553,7 @@ int gmmiv_reduce_scatter_f64(gmmiv_comm *c, const double *send, double *recv, si
         if (recv != send) GCHK(hipMemcpyAsync(recv, send, recvcount * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
         return GMMIV_OK;
     }
+    if (c->is_shm()) return shm_reduce_scatter(c, send, recv, recvcount);
     NCHK(c, c->api->ReduceScatter(send, recv, recvcount, ncclFloat64, ncclSum, c->nc, c->ctx->stream));
     return GMMIV_OK;
 }
@@ -271,6 +570,7 @@ int gmmiv_allgather_f64(gmmiv_comm *c, const double *send, double *recv, size_t 
         if (recv != send) GCHK(hipMemcpyAsync(recv, send, sendcount * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
         return GMMIV_OK;
     }
+    if (c->is_shm()) return shm_allgather(c, send, recv, sendcount);
     NCHK(c, c->api->AllGather(send, recv, sendcount, ncclFloat64, c->nc, c->ctx->stream));
     return GMMIV_OK;
 }
@@ -284,14 +584,16 @@ int gmmiv_broadcast_f64(gmmiv_comm *c, double *buf, size_t n, int root)
     GCHK(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     if (gmmiv_is_device_ptr(buf)) {
+        if (c->is_shm()) return shm_broadcast(c, buf, n, root);
         NCHK(c, c->api->Broadcast(buf, buf, n, ncclFloat64, root, c->nc, st));
         return GMMIV_OK;
     }
     void *d;
     int rc = c->staged(n * 8, &d);
-    if (rc) return rc;
+    if (rc) { if (c->is_shm()) c->shm->failed.store(1); return rc; }
     if (c->rank == root) GCHK(hipMemcpyAsync(d, buf, n * 8, hipMemcpyHostToDevice, st));
-    NCHK(c, c->api->Broadcast(d, d, n, ncclFloat64, root, c->nc, st));
+    if (c->is_shm()) { rc = shm_broadcast(c, (double *)d, n, root); if (rc) return rc; }
+    else NCHK(c, c->api->Broadcast(d, d, n, ncclFloat64, root, c->nc, st));
     GCHK(hipMemcpyAsync(buf, d, n * 8, hipMemcpyDeviceToHost, st));
     GCHK(hipStreamSynchronize(st));
     return GMMIV_OK;

@@ -7,7 +7,9 @@ threaded estimateAandC, AccumulateTVStat.cpp:1920-1937, 2036-2044).
 Collectives come in three interchangeable back ends with the same four operations:
   * GmmivCollectives -- the product's own C ABI (gmmiv_comm_*: RCCL over xGMI on the device buffers), what bench.py uses;
   * TorchCollectives -- torch.distributed: "nccl" (= RCCL) with reduce_scatter_tensor / all_gather_into_tensor, or "gloo" in
-    the CPU tests (gloo has no reduce-scatter: it is emulated with one reduce per destination, same bytes on the wire);
+    the CPU tests (gloo has no reduce-scatter: it is emulated with one reduce per destination, same bytes on the wire) and in
+    the multi-process GPU tests where the ranks share one device (device tensors are staged through host copies: gloo moves
+    the bytes, every sum that matters -- the statistics -- is still computed by libgmmiv on the device);
   * LocalCollectives -- a single rank.
 Everything here is orchestration; the arithmetic is done by the callbacks (libgmmiv on a GPU rank)."""
 import time
@@ -65,7 +67,12 @@ class TorchCollectives:
     def allreduce(self, a):
         t = _as_tensor(a)
         self._bytes += t.numel() * 8
-        self.dist.all_reduce(t)
+        if self.backend != "nccl" and t.is_cuda:      # gloo: device tensors travel as host copies
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t)
         return a
 
     def reduce_scatter(self, send, recv):
@@ -77,7 +84,7 @@ class TorchCollectives:
             self.dist.reduce_scatter_tensor(r.view(-1), s)
         else:  # gloo: one reduce per destination
             for g in range(self.world):
-                chunk = s[g * n:(g + 1) * n].clone()
+                chunk = s[g * n:(g + 1) * n].cpu() if s.is_cuda else s[g * n:(g + 1) * n].clone()
                 self.dist.reduce(chunk, dst=g)
                 if g == self.rank:
                     r.view(-1).copy_(chunk)
@@ -91,8 +98,9 @@ class TorchCollectives:
         if self.backend == "nccl":
             self.dist.all_gather_into_tensor(r, s.contiguous())
         else:
-            parts = [s.new_empty(n) for _ in range(self.world)]
-            self.dist.all_gather(parts, s.contiguous())
+            sh = s.cpu() if s.is_cuda else s.contiguous()
+            parts = [sh.new_empty(n) for _ in range(self.world)]
+            self.dist.all_gather(parts, sh)
             for g in range(self.world):
                 r[g * n:(g + 1) * n].copy_(parts[g])
         return recv
@@ -103,21 +111,33 @@ class TorchCollectives:
 
 
 class GmmivCollectives:
-    """The C ABI's communicator (include/gmmiv.h, gmmiv_comm_*): RCCL called by libgmmiv on the context's stream."""
+    """The C ABI's communicator (include/gmmiv.h, gmmiv_comm_*): RCCL (or the shm transport) called by libgmmiv on the
+    context's stream.  Device tensors produced by torch kernels are safe to hand over from ANY torch stream: each call is
+    bracketed by stream waits (capi.Context.ordered) unless torch's current stream already is the context's."""
 
     def __init__(self, comm):
         self.comm = comm
         self.world, self.rank = comm.world, comm.rank
-        self.name = "gmmiv_comm (%s)" % comm.backend()
+        self.backend = comm.backend()
+        self.name = "gmmiv_comm (%s)" % self.backend
+
+    def _ordered(self, *tensors):
+        import contextlib
+        if any(getattr(t, "is_cuda", False) for t in tensors):
+            return self.comm.ctx.ordered()
+        return contextlib.nullcontext()
 
     def allreduce(self, a):
-        return self.comm.allreduce(a)
+        with self._ordered(a):
+            return self.comm.allreduce(a)
 
     def reduce_scatter(self, send, recv):
-        return self.comm.reduce_scatter(send, recv)
+        with self._ordered(send, recv):
+            return self.comm.reduce_scatter(send, recv)
 
     def allgather(self, send, recv):
-        return self.comm.allgather(send, recv)
+        with self._ordered(send, recv):
+            return self.comm.allgather(send, recv)
 
     def take_bytes(self):
         return self.comm.take_bytes()
@@ -133,9 +153,10 @@ def default_collectives():
     return LocalCollectives()
 
 
-def gmmiv_collectives_from_torch(ctx, device=None):
-    """Bootstrap a gmmiv communicator inside an initialised torch.distributed job: rank 0 draws the RCCL id, the id travels
-    through the existing process group, every rank joins.  Returns GmmivCollectives, or LocalCollectives for one rank."""
+def gmmiv_collectives_from_torch(ctx, device=None, transport=None):
+    """Bootstrap a gmmiv communicator inside an initialised torch.distributed job: rank 0 draws the id (transport "rccl", or
+    "shm" for ranks that share a GPU; None = $GMMIV_COMM_TRANSPORT, else rccl), the id travels through the existing process
+    group, every rank joins.  Returns GmmivCollectives (single-rank communicator for one rank)."""
     import torch
     import torch.distributed as dist
     from . import capi
@@ -147,14 +168,14 @@ def gmmiv_collectives_from_torch(ctx, device=None):
     uid, err = bytes(capi.COMM_ID_BYTES), None
     if rank == 0:
         try:
-            uid = capi.Comm.unique_id()
+            uid = capi.Comm.unique_id(transport)
         except Exception as e:      # noqa: BLE001 - re-raised on every rank below
             err = e
     t = torch.tensor(list(uid) + [0 if err else 1], dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.broadcast(t, src=0)
     got = t.cpu().tolist()
     if got[-1] != 1:
-        raise capi.GmmivError("rank 0 could not draw an RCCL unique id%s" % (": %r" % err if err else ""))
+        raise capi.GmmivError("rank 0 could not draw a communicator id%s" % (": %r" % err if err else ""))
     return GmmivCollectives(capi.Comm(ctx, world, rank, bytes(got[:-1])))
 
 
@@ -287,14 +308,21 @@ def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=Non
 def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, phases=None):
     """One full iteration of TotalVariability's EM on utterance-sharded statistics (TotalVariability.cpp:118-169 around
     TVAcc, AccumulateTVStat.cpp): every rank holds the statistics N / F of its own utterances and the full T.
+      ops.recentre()                      (optional) restore the raw first-order statistics and substractM with the CURRENT UBM
+                                          means -- TotalVariability.cpp:123-124 does it at the top of every iteration,
+                                          minDivergence moves the means in between
       ops.tett()                          estimateTETt from the current T (replicated: 3 ms at 2048 x 400)
       ops.estep() -> acc                  resetTmpAcc + estimateAandC over the rank's utterances
       [reduce-scatter / update_t / all-gather: tv_mstep_sharded]
       ops.update_t(A_blk, Cmx_blk, cb)    updateTestimate on the rank's own Gaussians
       ops.min_divergence(acc, T, n)       minDivergence with the all-reduced R, r, meanW (replicated; T and the UBM
                                           means are updated in place on every rank identically)
-    Returns the new T.  phases collects per-phase seconds ("tett", "estep", "reduce_scatter", "update_t", "allgather",
-    "min_divergence")."""
+    ops.stream_context() (optional) returns a context manager under which the whole iteration runs -- a GPU rank returns
+    `torch.cuda.stream(ctx.torch_stream())` so that the torch kernels of the re-layout (pad, permute, cat) are enqueued on the
+    stream libgmmiv launches on, in program order with its kernels and collectives.
+    Returns the new T.  phases collects per-phase seconds ("recentre", "tett", "estep", "reduce_scatter", "update_t",
+    "allgather", "min_divergence")."""
+    import contextlib
     coll = coll or default_collectives()
     sync = (phases or {}).get("sync") or (lambda: None)
 
@@ -304,13 +332,18 @@ def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, pha
             phases[key] = phases.get(key, 0.0) + time.perf_counter() - t0
         return time.perf_counter()
 
-    t0 = time.perf_counter()
-    ops.tett()
-    t0 = lap("tett", t0)
-    acc = ops.estep()
-    t0 = lap("estep", t0)
-    Tn = tv_mstep_sharded(acc, ops.update_t, C, D, rank, world, coll, phases)
-    t0 = time.perf_counter()
-    Tn = ops.min_divergence(acc, Tn, n_sessions_total)
-    lap("min_divergence", t0)
+    cm = ops.stream_context() if hasattr(ops, "stream_context") else contextlib.nullcontext()
+    with cm:
+        t0 = time.perf_counter()
+        if hasattr(ops, "recentre"):
+            ops.recentre()
+            t0 = lap("recentre", t0)
+        ops.tett()
+        t0 = lap("tett", t0)
+        acc = ops.estep()
+        t0 = lap("estep", t0)
+        Tn = tv_mstep_sharded(acc, ops.update_t, C, D, rank, world, coll, phases)
+        t0 = time.perf_counter()
+        Tn = ops.min_divergence(acc, Tn, n_sessions_total)
+        lap("min_divergence", t0)
     return Tn

@@ -555,6 +555,8 @@ int liagpu_io_xml(const char *xml_in, const char *xml_out, const char *raw_out, 
         }
     })
 }
+// width of the extents writeMatrixDB puts in a DB header (4 or 8 bytes; anything else only queries); returns the previous one
+int liagpu_io_db_header_bytes(int bytes) { return setMatrixDBHeaderBytes(bytes); }
 // matrix file -> matrix file in another format; dims = {rows, cols}
 int liagpu_io_matrix_convert(const char *in, const char *fmt_in, const char *out, const char *fmt_out, long *dims)
 {

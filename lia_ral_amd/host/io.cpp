@@ -221,31 +221,66 @@ MixtureGD readMixture(const std::string &path)
 }
 
 // ---- DB matrices and per-id vector files ------------------------------------------------------------------------------------
+// Header width: alize-core's Matrix<T> keeps its extents in `unsigned long` members and (to the best of what can be told
+// without its sources -- alize-core is not in the LIA_RAL tree and no DB file ships with it) writes them with sizeof(member):
+// 2 x 8 bytes from an LP64 build (Linux / macOS), 2 x 4 bytes from an ILP32 or LLP64 build (32-bit, Windows).  The reader
+// takes whichever width makes the file size come out exactly (ambiguity is impossible: with the wide header the upper halves
+// are zero, which read as a 0-column matrix under the narrow interpretation -- only an empty matrix satisfies both, and both
+// readings agree on it); the writer uses this platform's `unsigned long` like an upstream build here would, or the width
+// asked for (setMatrixDBHeaderBytes(4 | 8)) when a file is meant for a build of the other kind.
+static int g_db_header_bytes = (int)sizeof(unsigned long);
+int setMatrixDBHeaderBytes(int bytes)
+{
+    const int prev = g_db_header_bytes;
+    if (bytes == 4 || bytes == 8) g_db_header_bytes = bytes;
+    return prev;
+}
 MatrixD readMatrixDB(const std::string &path)
 {
     const std::vector<unsigned char> b = slurp(path);
     if (b.size() < 8) throw Exception("DB matrix too short [" + path + "]");
-    uint32_t r, c;
-    memcpy(&r, b.data(), 4);
-    memcpy(&c, b.data() + 4, 4);
-    if (b.size() != 8 + 8 * (size_t)r * c) {
-        char msg[256];
-        snprintf(msg, sizeof(msg), "DB matrix [%s]: %zu bytes, expected %zu for %u x %u", path.c_str(), b.size(), 8 + 8 * (size_t)r * c, r, c);
+    uint64_t r = 0, c = 0;
+    size_t hdr = 0;
+    if (b.size() >= 16) { // LP64 writer: two 8-byte extents
+        uint64_t r8, c8;
+        memcpy(&r8, b.data(), 8);
+        memcpy(&c8, b.data() + 8, 8);
+        if (r8 <= (1ull << 40) && c8 <= (1ull << 40) && (r8 == 0 || c8 <= (~(size_t)0 - 16) / 8 / r8) && b.size() == 16 + 8 * (size_t)r8 * (size_t)c8) { r = r8; c = c8; hdr = 16; }
+    }
+    if (!hdr) {           // ILP32 / LLP64 writer: two 4-byte extents
+        uint32_t r4, c4;
+        memcpy(&r4, b.data(), 4);
+        memcpy(&c4, b.data() + 4, 4);
+        if (b.size() == 8 + 8 * (size_t)r4 * c4) { r = r4; c = c4; hdr = 8; }
+    }
+    if (!hdr) {
+        uint32_t r4, c4;
+        memcpy(&r4, b.data(), 4);
+        memcpy(&c4, b.data() + 4, 4);
+        char msg[320];
+        snprintf(msg, sizeof(msg), "DB matrix [%s]: %zu bytes fit neither an 8-byte-extent header nor a 4-byte one (%u x %u would need %zu)",
+                 path.c_str(), b.size(), r4, c4, 8 + 8 * (size_t)r4 * c4);
         throw Exception(msg);
     }
     MatrixD m;
-    m.rows = r; m.cols = c;
+    m.rows = (unsigned long)r; m.cols = (unsigned long)c;
     m.v.resize((size_t)r * c);
-    if (!m.v.empty()) memcpy(m.v.data(), b.data() + 8, 8 * m.v.size());
+    if (!m.v.empty()) memcpy(m.v.data(), b.data() + hdr, 8 * m.v.size());
     return m;
 }
 void writeMatrixDB(const std::string &path, const MatrixD &m)
 {
     std::ofstream o(path.c_str(), std::ios::binary);
     if (!o) throw Exception("cannot write [" + path + "]");
-    const uint32_t r = (uint32_t)m.rows, c = (uint32_t)m.cols;
-    o.write((const char *)&r, 4);
-    o.write((const char *)&c, 4);
+    if (g_db_header_bytes == 8) {
+        const uint64_t r = (uint64_t)m.rows, c = (uint64_t)m.cols;
+        o.write((const char *)&r, 8);
+        o.write((const char *)&c, 8);
+    } else {
+        const uint32_t r = (uint32_t)m.rows, c = (uint32_t)m.cols;
+        o.write((const char *)&r, 4);
+        o.write((const char *)&c, 4);
+    }
     if (!m.v.empty()) o.write((const char *)m.v.data(), 8 * m.v.size());
 }
 MatrixD readMatrix(const std::string &path, const std::string &format)

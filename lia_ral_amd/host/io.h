@@ -46,11 +46,15 @@ MixtureGD readMixture(const std::string &path); // XML when the file starts with
 struct MatrixD { unsigned long rows = 0, cols = 0; std::vector<double> v; };
 MatrixD readMatrixDT(const std::string &path);
 void writeMatrixDT(const std::string &path, const MatrixD &m);
-// DB matrices (saveMatrixFormat DB, the binary twin of DT written by alize-core's Matrix<double>::save): u32 rows, u32 cols, then
-// rows * cols float64, little-endian.  alize-core is not part of the LIA_RAL tree and no DB file ships with it, so this layout is
-// the survey's reading of ALIZE and is NOT pinned by a reference file; DT is (ComputeTest/test/zero.mat).
+// DB matrices (saveMatrixFormat DB, the binary twin of DT written by alize-core's Matrix<double>::save): rows, cols, then
+// rows * cols float64, little-endian.  The two extents are `unsigned long` members written with their own size: 8 bytes each
+// from an LP64 build (Linux), 4 bytes each from a 32-bit / Windows build.  readMatrixDB accepts BOTH (the width is the one that
+// makes the file size come out exactly); writeMatrixDB writes this platform's `unsigned long` width unless
+// setMatrixDBHeaderBytes(4 | 8) says otherwise (returns the previous width).  alize-core is not part of the LIA_RAL tree and
+// no DB file ships with it, so this layout is NOT pinned by a reference file; DT is (ComputeTest/test/zero.mat).
 MatrixD readMatrixDB(const std::string &path);
 void writeMatrixDB(const std::string &path, const MatrixD &m);
+int setMatrixDBHeaderBytes(int bytes);
 MatrixD readMatrix(const std::string &path, const std::string &format);   // "DT" | "DB" (loadMatrixFormat)
 void writeMatrix(const std::string &path, const MatrixD &m, const std::string &format);
 // Per-id vector files: TVAcc::saveWbyFile (AccumulateTVStat.cpp:2799-2822) writes row `session` of W as a 1 x rankT matrix to

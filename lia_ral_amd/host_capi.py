@@ -216,6 +216,11 @@ def io_xml(xml_in, xml_out, raw_out=""):
     return dims, first
 
 
+def io_db_header_bytes(nbytes=0):
+    """Width (4 | 8) of the rows / cols extents writeMatrixDB writes; returns the previous width (0 only queries)."""
+    return int(lib.liagpu_io_db_header_bytes(int(nbytes)))
+
+
 def io_matrix_convert(path_in, fmt_in, path_out, fmt_out):
     dims = np.zeros(2, np.int64)
     _chk(lib.liagpu_io_matrix_convert(path_in.encode(), fmt_in.encode(), path_out.encode(), fmt_out.encode(), dims.ctypes.data_as(_lp)))

@@ -94,15 +94,28 @@ def test_xml_mixture_reads_and_rewrites_the_reference_file(tmp_path):
 
 def test_dt_db_matrices_and_vector_files(tmp_path):
     """DT matrix: the reference's own LIA_SpkDet/ComputeTest/test/zero.mat (32768 x 5) re-written byte for byte; DB (binary, layout
-    unpinned: no DB file ships with LIA_RAL) round-trips through DT; per-id i-vector files (TVAcc::saveWbyFile -> PldaTest::load)."""
+    unpinned: no DB file ships with LIA_RAL) round-trips through DT with BOTH header widths (`unsigned long` extents: 2 x 8 bytes
+    from an LP64 build of ALIZE, 2 x 4 from a 32-bit / Windows one; the reader tells them apart by the file size); per-id i-vector
+    files (TVAcc::saveWbyFile -> PldaTest::load)."""
     import gzip
     from lia_ral_amd import host_capi as h
     zero = tmp_path / "zero.mat"
     zero.write_bytes(gzip.open(os.path.join(REF, "computetest_zero.mat.gz")).read())
-    assert h.io_matrix_convert(str(zero), "DT", str(tmp_path / "z.db"), "DB") == (32768, 5)
-    assert os.path.getsize(tmp_path / "z.db") == 8 + 8 * 32768 * 5
-    assert h.io_matrix_convert(str(tmp_path / "z.db"), "DB", str(tmp_path / "z.dt"), "DT") == (32768, 5)
-    assert filecmp.cmp(zero, tmp_path / "z.dt", shallow=False)
+    assert h.io_db_header_bytes() == struct.calcsize("L") == 8            # default = this platform's unsigned long, like upstream built here
+    for width in (8, 4):
+        prev = h.io_db_header_bytes(width)
+        try:
+            db, dt = tmp_path / ("z%d.db" % width), tmp_path / ("z%d.dt" % width)
+            assert h.io_matrix_convert(str(zero), "DT", str(db), "DB") == (32768, 5)
+            assert os.path.getsize(db) == 2 * width + 8 * 32768 * 5
+            raw = db.read_bytes()
+            assert struct.unpack_from("<QQ" if width == 8 else "<II", raw) == (32768, 5)
+            assert h.io_matrix_convert(str(db), "DB", str(dt), "DT") == (32768, 5)        # read back whatever the width
+            assert filecmp.cmp(zero, dt, shallow=False)
+        finally:
+            h.io_db_header_bytes(prev)
+    (tmp_path / "empty.db").write_bytes(b"\x00" * 16)                       # 0 x 0 with the wide header
+    assert h.io_matrix_convert(str(tmp_path / "empty.db"), "DB", str(tmp_path / "empty.dt"), "DT") == (0, 0)
     rng = np.random.default_rng(0)
     W = rng.normal(size=(5, 40))
     ids = ["spk%d_a" % i for i in range(5)]
@@ -111,6 +124,6 @@ def test_dt_db_matrices_and_vector_files(tmp_path):
         back = h.io_vectors(str(d), ids, ".y", fmt, W)
         assert np.array_equal(back, W.T)                                   # one vector per COLUMN like PldaTest::_models
         assert sorted(os.listdir(d)) == sorted(i + ".y" for i in ids)
-    with pytest.raises(h.HostError, match="expected"):
+    with pytest.raises(h.HostError, match="fit neither"):
         (tmp_path / "bad.db").write_bytes(b"\x02\x00\x00\x00\x03\x00\x00\x00" + b"\x00" * 40)
         h.io_matrix_convert(str(tmp_path / "bad.db"), "DB", str(tmp_path / "o"), "DT")

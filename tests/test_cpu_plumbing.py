@@ -46,6 +46,37 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dp, f)
 
 
+def test_missing_rccl_is_err_unsupported_not_a_crash():
+    """include/gmmiv.h: GMMIV_ERR_UNSUPPORTED when RCCL cannot be loaded (GMMIV_RCCL_LIB names the only library tried).  The
+    message is built from ONE dlerror() call -- two calls appended NULL to a std::string and crashed the process."""
+    import subprocess
+    code = ("import ctypes as ct, sys; sys.path.insert(0, %r); from lia_ral_amd import capi; b = ct.create_string_buffer(128);"
+            "rc = capi.lib.gmmiv_comm_get_unique_id_for(b'rccl', b); print(rc); print(capi.lib.gmmiv_last_error().decode())") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, GMMIV_RCCL_LIB="/nonexistent/librccl_not_here.so"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "-3" and "RCCL not found" in lines[1] and "librccl_not_here" in lines[1]
+
+
+def test_comm_id_transports():
+    """The id rank 0 draws names the transport: "shm" ids carry the magic and a path under GMMIV_COMM_SHM_DIR; an unknown
+    transport is an argument error; world > 1 without an id is refused before anything is touched."""
+    import ctypes as ct
+    from lia_ral_amd import capi
+    uid = capi.Comm.unique_id("shm")
+    assert len(uid) == capi.COMM_ID_BYTES and uid[:8] == b"GMMIVSHM" and b"/gmmiv_comm_" in uid
+    assert capi.Comm.unique_id("shm") != uid                   # unique per draw
+    with pytest.raises(capi.GmmivError, match="unknown transport"):
+        capi.Comm.unique_id("carrier-pigeon")
+    b = ct.create_string_buffer(capi.COMM_ID_BYTES)
+    os.environ["GMMIV_COMM_TRANSPORT"] = "shm"
+    try:
+        assert capi.lib.gmmiv_comm_get_unique_id(b) == 0 and b.raw[:8] == b"GMMIVSHM"      # the environment default
+    finally:
+        del os.environ["GMMIV_COMM_TRANSPORT"]
+
+
 def test_shard_range_partitions():
     from lia_ral_amd.dist import shard_range
     for n in (0, 1, 7, 8, 10_000_001):

@@ -507,16 +507,21 @@ def test_tv_train_dist_single_rank_is_the_plain_loop():
     assert times.shape == (2, 4) and np.all(times > 0)
 
 
-def _tv_rank(rank, world, idfile, q):
+def _tv_rank(rank, world, idfile, q, transport="rccl"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["GMMIV_COMM_TRANSPORT"] = transport        # read by rank 0 when it draws the id (gmmiv_comm_exchange_id_file)
     from lia_ral_amd import host_capi as h
     from lia_ral_amd.dist import shard_range
     C, D, R, U, w, mean, iv, N, F, Tm = _tv_case()
     b, e = shard_range(U, rank, world)
-    Tg, mg, _ = h.tv_train_dist(N[b:e], F[b:e], (w, mean, 1.0 / iv), Tm, 2, world=world, rank=rank, id_file=idfile, n_total=U, device=rank)
-    q.put((rank, Tg, mg))
+    try:
+        Tg, mg, _ = h.tv_train_dist(N[b:e], F[b:e], (w, mean, 1.0 / iv), Tm, 2, world=world, rank=rank, id_file=idfile, n_total=U,
+                                    device=rank if transport == "rccl" else 0)
+        q.put((rank, Tg, mg))
+    except Exception as ex:      # noqa: BLE001 - the parent fails the test with the message
+        q.put((rank, repr(ex), None))
 
 
 def test_tv_train_dist_two_ranks_rccl(tmp_path):
@@ -539,6 +544,80 @@ def test_tv_train_dist_two_ranks_rccl(tmp_path):
     To, mo = _oracle_tv_loop(C, D, U, mean, iv, N, F, Tm, 2)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert relerr(res[0][1], To) < 1e-6 and relerr(res[0][2], mo) < 1e-8
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tv_train_dist_ranks_share_gpu0_shm(world, tmp_path):
+    """The C++ host layer's multi-rank TotalVariability loop (liagpu_tv_train_dist: TVAcc::updateTestimate(comm) = reduce-scatter
+    by padded Gaussian blocks, sharded solve, all-gather; AccumulateTVStat.cpp:974-1005, 1920-1937) with 2 and 3 processes on
+    GPU 0 over the C ABI's shm transport: identical T / means on every rank, equal to the oracle's single-process loop."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_tv_rank, args=(r, world, str(tmp_path / "id"), q, "shm")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r][2] is not None, res[r][1]
+    C, D, R, U, w, mean, iv, N, F, Tm = _tv_case()
+    To, mo = _oracle_tv_loop(C, D, U, mean, iv, N, F, Tm, 2)
+    for r in range(1, world):
+        assert np.array_equal(res[0][1], res[r][1]) and np.array_equal(res[0][2], res[r][2])
+    assert relerr(res[0][1], To) < 1e-6 and relerr(res[0][2], mo) < 1e-8
+    from lia_ral_amd import host_capi as h
+    T1, m1, _ = h.tv_train_dist(N, F, (w, mean, 1.0 / iv), Tm, 2)           # the single-rank HIP loop
+    assert relerr(res[0][1], T1) < 1e-10 and relerr(res[0][2], m1) < 1e-11
+
+
+def _tw_rank(rank, world, idfile, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["GMMIV_COMM_TRANSPORT"] = "shm"
+    from lia_ral_amd import host_capi as h
+    from lia_ral_amd.dist import shard_range
+    C, D, T, x, w0, mean0, cov0, gcov = _tw_case()
+    b, e = shard_range(T, rank, world)
+    try:
+        r = h.train_world_dist(x[b:e], [0], [e - b], w0, mean0, cov0, 2, gcov, world=world, rank=rank, id_file=idfile, init_floor=0.1, final_floor=0.1, device=0)
+        q.put((rank, r["w"], r["mean"], r["cov"], r["llk"]))
+    except Exception as ex:      # noqa: BLE001
+        q.put((rank, repr(ex), None, None, None))
+
+
+def _tw_case():
+    C, D, T = 16, 12, 3001
+    w, mean, iv = make_gmm(C, D, seed=5)
+    x = make_frames(w, mean, iv, T, seed=6)
+    gcov = x.astype(np.float64).var(0)
+    return C, D, T, x, np.full(C, 1.0 / C), mean + 0.3, np.ones((C, D)) * 2.0, gcov
+
+
+def test_train_world_dist_ranks_share_gpu0_shm(tmp_path):
+    """TrainWorld's EM over frame-sharded ranks (trainModelStream(..., comm): ONE gmmiv_allreduce_f64 of the flat accumulator per
+    iteration, AccumulateStat.cpp:286-292) with two processes on GPU 0 over shm == the single-rank run to summation-order accuracy."""
+    import torch.multiprocessing as mp
+    from lia_ral_amd import host_capi as h
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_tw_rank, args=(r, 2, str(tmp_path / "id"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] is not None and res[1][2] is not None, (res[0][1], res[1][1])
+    C, D, T, x, w0, mean0, cov0, gcov = _tw_case()
+    one = h.train_world_dist(x, [0], [T], w0, mean0, cov0, 2, gcov, init_floor=0.1, final_floor=0.1)
+    for k, name in ((1, "w"), (2, "mean"), (3, "cov")):
+        assert np.array_equal(res[0][k], res[1][k])
+        assert relerr(res[0][k], one[name]) < 1e-10, name
+    assert relerr(res[0][4], one["llk"]) < 1e-10
 
 
 def test_train_world_dist_single_rank_matches_train_world():
