@@ -43,8 +43,10 @@ enum { GMMIV_TOP_PARTIAL = 0, GMMIV_TOP_COMPLETE = 1 }; /* computeLLKWithTopDist
 
 /* ---- context --------------------------------------------------------------------------- */
 /* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a private non-blocking one.  A caller whose
- * other work runs on the NULL (legacy default) stream passes hipStreamLegacy ((hipStream_t)1) to have the context launch there:
- * a private stream is NOT ordered with the NULL stream, so buffers written by NULL-stream work must be complete before a call. */
+ * other work runs on the NULL (legacy default) stream -- torch's default stream is that one -- passes GMMIV_STREAM_DEFAULT to
+ * have the context launch there too (hipStreamLegacy, (hipStream_t)1, is taken to mean the same): a private stream is NOT
+ * ordered with the NULL stream, so buffers written by NULL-stream work would have to be complete before each call. */
+#define GMMIV_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out);
 void gmmiv_ctx_destroy(gmmiv_ctx *ctx);
 int gmmiv_ctx_sync(gmmiv_ctx *ctx);

@@ -86,20 +86,20 @@ def _feat(x):
     return x, (F64 if x.dtype == np.float64 else F32), x.shape[0], x.shape[1]
 
 
-HIP_STREAM_LEGACY = 1      # hipStreamLegacy: the NULL stream, as an explicit handle
+STREAM_DEFAULT = -1        # GMMIV_STREAM_DEFAULT: launch on the NULL (legacy default) stream, torch's default stream
 
 
 class Context:
     """stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) or None for a private non-blocking stream.
     The handle 0 -- what torch reports for its DEFAULT stream -- means "the stream torch is using", so it is passed on as
-    hipStreamLegacy: every call of the context is then ordered with the torch kernels around it (a private stream would not be).
+    GMMIV_STREAM_DEFAULT: every call of the context is then ordered with the torch kernels around it (a private stream would not be).
     torch_stream(): the same stream as a torch object, for `with torch.cuda.stream(ctx.torch_stream()):`."""
 
     def __init__(self, device=0, stream=None):
         self._h = ct.c_void_p()
         self.device = int(device)
         if stream is not None and int(stream) == 0:
-            stream = HIP_STREAM_LEGACY
+            stream = STREAM_DEFAULT
         _chk(lib.gmmiv_ctx_create(ct.c_int(device), ct.c_void_p(stream or 0), ct.byref(self._h)))
 
     def stream(self):
@@ -128,7 +128,7 @@ class Context:
     def torch_stream(self):
         import torch
         h = self.stream()
-        if h in (0, HIP_STREAM_LEGACY):
+        if h == 0:         # the NULL stream
             return torch.cuda.default_stream(self.device)
         return torch.cuda.ExternalStream(h, device=self.device)
 

@@ -48,7 +48,8 @@ int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out)
     GCHK(hipSetDevice(device));
     gmmiv_ctx *c = new gmmiv_ctx();
     c->device = device;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    if (stream == GMMIV_STREAM_DEFAULT || stream == (void *)hipStreamLegacy) { c->stream = nullptr; c->own_stream = false; } // the NULL stream itself
+    else if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { GCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->n_cu = prop.multiProcessorCount; c->total_mem = prop.totalGlobalMem; }

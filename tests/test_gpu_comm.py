@@ -158,11 +158,12 @@ def test_bench_cli_emits_the_contract_line(extra):
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline", "collectives"):
+              "config", "roofline", "cpu_baseline", "collectives", "comm", "parity"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f64" and "workload" in d["config"]
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
-    assert "gmmiv_comm" in d["collectives"]
+    assert "gmmiv_comm" in d["collectives"] and d["comm"]["world"] == 1
+    assert d["parity"]["ok"] is True and d["parity"]["max_rel_err"] < d["parity"]["tolerance"] <= 1e-6, d["parity"]   # the oracle check inside the timed number
     if "tv" in extra:
         assert d["finite"] and set(d["phases_ms"]) >= {"tett", "estep", "update_t", "min_divergence"}
