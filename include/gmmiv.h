@@ -55,7 +55,8 @@ int gmmiv_ctx_sync(gmmiv_ctx *ctx);
 void *gmmiv_ctx_stream(gmmiv_ctx *ctx);
 const char *gmmiv_last_error(void);
 const char *gmmiv_version(void);
-/* Runtime knobs; returns the previous value (-1: unknown key).
+/* Runtime knobs; returns the previous value (-1: unknown key).  EVERY option is state of the context it is set on -- two
+ * contexts driven from one host thread keep their own settings, a context keeps its settings whichever thread drives it.
  *   "stats_z" 1        EM / Baum-Welch statistics from stored scaled likelihoods (k_llk_mfma<WZ> + k_stats_z);
  *                      0: the recomputing k_stats_mfma (also used for D > 60 or when the scratch does not fit)
  *   "z_scratch_mb"     likelihood scratch budget in MiB (default 65536, at most a quarter of the device's TOTAL memory):
@@ -65,7 +66,7 @@ const char *gmmiv_version(void);
  *                      from the reference's frame-by-frame accumulation: parity is to a tolerance, see DESIGN.md.)
  *   "z_waves" 8        workgroup shape of k_stats_z (8, 16 or 4 waves)
  *   "z_depth_tv" 4     register sets of k_stats_z's likelihood stream (prefetch distance + 1; 2 or 4) in the N / F mode,
- *   "z_depth_em" 2     and in the EM mode; A/B switches of the calling host thread, bit-identical results
+ *   "z_depth_em" 2     and in the EM mode; bit-identical results
  *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
@@ -74,8 +75,10 @@ const char *gmmiv_version(void);
  *   "tv_acc_mb" 8192   T-matrix E-step: MiB of packed E_u = L_u^-1 + w_u w_u^T kept in HBM before A += N^T E and Cmx += W^T F run
  *                      (one GEMM per super-batch, K = its utterances, instead of one per tv_batch)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
- *                      used for odd orders); A/B switch of the calling host thread (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
- *   "chol_lds" 1       chol_fused.hip stages the 32 panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
+ *                      used for odd orders); A/B switch (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
+ *   "chol_lds" 1       chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
+ *   "kopts_bound"      read-only: 1 when this context's kernel-launcher options are the set bound to the calling thread (they are
+ *                      bound by each call of the context on entry)
  *   "tv_mstep_solve" 1 updateTestimate by blocked substitution through the Cholesky factor of A_c (k_chol_solve_multi);
  *                      0: explicit inverse + GEMM like the reference
  *   "tv_md_device" 1   minDivergence: R normalised and factored on the device (even R); 0: on the host

@@ -9,6 +9,11 @@
 
 static thread_local char g_err[512] = "";
 
+static const gmmiv_kopts g_kopts_default;
+static thread_local const gmmiv_kopts *g_kopts_cur = &g_kopts_default;
+const gmmiv_kopts &gmmiv_kopts_cur() { return *g_kopts_cur; }
+void gmmiv_kopts_bind(const gmmiv_kopts *ko) { g_kopts_cur = ko ? ko : &g_kopts_default; }
+
 void gmmiv_set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -70,6 +75,7 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
         for (hipEvent_t e : c->ev1[i]) (void)hipEventDestroy(e);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (&gmmiv_kopts_cur() == &c->ko) gmmiv_kopts_bind(nullptr); // this thread's binding must not outlive the context
     delete c;
 }
 
@@ -95,7 +101,6 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "prune_log2")) slot = &c->prune_log2;
     else if (!strcmp(key, "stats_z")) slot = &c->stats_z;
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
-    else if (!strcmp(key, "z_waves")) slot = &c->z_waves;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     else if (!strcmp(key, "tv_mstep_solve")) slot = &c->tv_mstep_solve;
@@ -103,22 +108,20 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "tv_acc_mb")) slot = &c->tv_acc_mb;
     else if (!strcmp(key, "topc_fused")) slot = &c->topc_fused;
     else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
-    if (!strcmp(key, "z_tv4")) { // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
-        return gmmk_stats_z_set_tv4((int)value);
-    }
-    if (!strcmp(key, "z_depth_em")) return gmmk_stats_z_set_depth((int)value, 0) / 10; // A/B knobs: stream prefetch depth of k_stats_z (2 / 3 register sets)
-    if (!strcmp(key, "z_depth_tv")) return gmmk_stats_z_set_depth(0, (int)value) % 10;
-    if (!strcmp(key, "gemm_remap")) { // A/B knob: 0 = hardware tile order in k_dgemm
-        return tvk_set_gemm_remap((int)value);
-    }
-    if (!strcmp(key, "gemm_clamp")) { // A/B knob: 0 = cut GEMM tiles on the per-element checked instantiation
-        return tvk_set_gemm_clamp((int)value);
-    }
-    if (!strcmp(key, "gemm_narrow")) return tvk_set_gemm_narrow((int)value); // A/B knob: 0 = 128 x 128 tiles on the strips cut by M / N too
-    if (!strcmp(key, "chol_lds")) return tvk_set_chol_lds((int)value); // A/B knob: 0 = panel rows from memory per wave
-    if (!strcmp(key, "chol_gemm")) { // A/B knob: the GEMM-built batched Cholesky instead of k_chol_left
-        return tvk_set_chol_gemm_path((int)value);
-    }
+    // options read by the kernel launchers: kept in the context's gmmiv_kopts, bound to the calling thread by every call (GBIND)
+    int *ks = nullptr;
+    if (!strcmp(key, "z_waves")) { const long prev = c->ko.z_waves; c->ko.z_waves = (value == 4 || value == 16) ? (int)value : 8; return prev; }
+    if (!strcmp(key, "z_depth_em")) { const long prev = c->ko.z_depth_em; if (value == 2 || value == 4) c->ko.z_depth_em = (int)value; return prev; }
+    if (!strcmp(key, "z_depth_tv")) { const long prev = c->ko.z_depth_tv; if (value == 2 || value == 4) c->ko.z_depth_tv = (int)value; return prev; }
+    if (!strcmp(key, "z_tv4")) ks = &c->ko.z_tv4;                 // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
+    else if (!strcmp(key, "gemm_remap")) ks = &c->ko.gemm_remap;   // A/B knob: 0 = hardware tile order in k_dgemm
+    else if (!strcmp(key, "gemm_clamp")) ks = &c->ko.gemm_clamp;   // A/B knob: 0 = cut GEMM tiles on the per-element checked instantiation
+    else if (!strcmp(key, "gemm_narrow")) ks = &c->ko.gemm_narrow; // A/B knob: 0 = 128 x 128 tiles on the strips cut by M / N too
+    else if (!strcmp(key, "chol_lds")) ks = &c->ko.chol_lds;       // 0 = panel rows from memory per wave
+    else if (!strcmp(key, "chol_gemm")) ks = &c->ko.chol_gemm;     // the GEMM-built batched Cholesky instead of k_chol_left
+    else if (!strcmp(key, "chol_panel")) ks = &c->ko.chol_panel;   // panel width of chol_fused.hip (0 = default, 32, 64)
+    if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
+    if (!strcmp(key, "kopts_bound")) return &gmmiv_kopts_cur() == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?
     if (!slot) return -1;
     long prev = *slot;
     *slot = value;
@@ -152,7 +155,7 @@ long gmmiv_ctx_kernel_launches(gmmiv_ctx *c, const char *name)
 static int gmm_upload(gmmiv_gmm *g, const double *w, const double *mean, const double *covinv)
 {
     gmmiv_ctx *c = g->ctx;
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t CD = (size_t)g->C * g->D;
     auto kind = [](const void *p) { return gmmiv_is_device_ptr(p) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; };
     GCHK(hipMemcpyAsync(g->w, w, g->C * sizeof(double), kind(w), c->stream));
@@ -170,7 +173,7 @@ int gmmiv_gmm_create(gmmiv_ctx *c, int C, int D, const double *w, const double *
     if (!c || !out || !w || !mean || !covinv || C <= 0 || D <= 0) { gmmiv_set_error("gmm_create: bad argument"); return GMMIV_ERR_ARG; }
     const int KS = gmmk_ks_for_dim(D);
     if (!KS) { gmmiv_set_error("gmm_create: vectSize %d not supported (max 80)", D); return GMMIV_ERR_UNSUPPORTED; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     gmmiv_gmm *g = new gmmiv_gmm();
     g->ctx = c; g->C = C; g->D = D; g->KS = KS;
     g->nct = ((C + 15) / 16 + 1) / 2 * 2; // c-tiles of 16, padded to the LLK kernel's stage of 2
@@ -204,7 +207,7 @@ int gmmiv_gmm_set_cov(gmmiv_gmm *g, const double *w, const double *mean, const d
 {
     if (!g || !w || !mean || !cov) { gmmiv_set_error("gmm_set_cov: bad argument"); return GMMIV_ERR_ARG; }
     gmmiv_ctx *c = g->ctx;
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t CD = (size_t)g->C * g->D;
     DevIn<double> i_cov;
     int rc = i_cov.init(c, WS_T0, cov, CD);
@@ -253,7 +256,7 @@ static int check_model(gmmiv_ctx *c, const gmmiv_gmm *g)
 {
     if (!c || !g) { gmmiv_set_error("NULL context or model"); return GMMIV_ERR_ARG; }
     if (g->ctx != c) { gmmiv_set_error("model belongs to a different context"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     return GMMIV_OK;
 }
 
@@ -261,7 +264,7 @@ static int check_model(gmmiv_ctx *c, const gmmiv_gmm *g)
 int gmmiv_frame_moments(gmmiv_ctx *c, const void *x, int dt, int64_t T, int64_t ldx, int D, double *acc)
 {
     if (!c || !acc || T < 0 || D <= 0) { gmmiv_set_error("frame_moments: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     XView xv;
     int rc = xv.init(c, x, dt, T, ldx, D);
     if (rc) return rc;
@@ -283,7 +286,7 @@ int gmmiv_gather_frames(gmmiv_ctx *c, const void *x, int dt, int64_t ldx, int D,
 {
     if (!c || !x || !out || !frame_idx || n < 0 || D <= 0 || ldx < D) { gmmiv_set_error("gather_frames: bad argument"); return GMMIV_ERR_ARG; }
     if (!gmmiv_is_device_ptr(x) || !gmmiv_is_device_ptr(out)) { gmmiv_set_error("gather_frames: x and out must be device arrays"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     DevIn<int64_t> i_idx;
     int rc = i_idx.init(c, WS_T0, frame_idx, (size_t)n);
     if (rc) return rc;
@@ -601,7 +604,6 @@ static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt,
                       double *lse, int *nseg_out, void **part_out)
 {
     int rc;
-    gmmk_stats_z_set_waves((int)c->z_waves);
     const int ngrp = gmmk_stats_z_groups(g->nct);
     int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (c->n_cu * gmmk_stats_z_wg_per_cu() + ngrp - 1) / ngrp;
     nseg = (nseg + 7) / 8 * 8;
@@ -753,7 +755,7 @@ int gmmiv_em_get(gmmiv_ctx *c, int C, int D, const double *acc, const double *pr
                  double *w, double *mean, double *cov)
 {
     if (!c || !acc || !prev_mean || !prev_cov || !w || !mean || !cov || C <= 0 || D <= 0) { gmmiv_set_error("em_get: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t CD = (size_t)C * D;
     DevIn<double> i_acc, i_pm, i_pc;
     DevOut<double> o_w, o_m, o_c;
@@ -775,7 +777,7 @@ int gmmiv_variance_control(gmmiv_ctx *c, int C, int D, double *cov, double floor
 {
     if (!c || C <= 0 || D <= 0 || !cov || !cov_signal) { gmmiv_set_error("variance_control: bad argument"); return GMMIV_ERR_ARG; }
     if (counts && gmmiv_is_device_ptr(counts)) { gmmiv_set_error("variance_control: counts must be a host array"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     DevOut<double> o;
     DevIn<double> i_cs;
     int rc;
@@ -884,8 +886,7 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
             if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
             if ((rc = c->scratch(WS_INV, (size_t)(maxn > 0 ? maxn : 1) * (sizeof(double) + sizeof(int)), &inv))) return rc;
             int *efin = (int *)((double *)inv + (maxn > 0 ? maxn : 1));
-            gmmk_stats_z_set_waves((int)c->z_waves);
-            for (size_t k = 0; k + 1 < cu.size(); ++k) {
+                    for (size_t k = 0; k + 1 < cu.size(); ++k) {
                 const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;
                 c->t_begin("k_llk_mfma", k == 0);
                 GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,

@@ -154,7 +154,7 @@ size_t gmmiv_tv_packed_len(int R) { return (size_t)R * (R + 1) / 2; }
 int gmmiv_tv_subtract_m(gmmiv_ctx *c, int64_t U, int C, int D, const double *N, double *F, const double *means)
 {
     if (!c || U < 0 || C <= 0 || D <= 0 || !N || !F || !means) { gmmiv_set_error("tv_subtract_m: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_m;
     DevOut<double> o_f;
@@ -171,7 +171,7 @@ int gmmiv_tv_subtract_m(gmmiv_ctx *c, int64_t U, int C, int D, const double *N, 
 int gmmiv_tv_tett(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *invvar, double *tett_packed)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !invvar || !tett_packed) { gmmiv_set_error("tv_tett: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D, P = gmmiv_tv_packed_len(R), RR = (size_t)R * R;
     DevIn<double> i_t, i_iv;
     DevOut<double> o;
@@ -202,7 +202,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
                     const double *invvar, const double *tett, double *W, double *A_packed, double *Cmx, double *Rm,
                     double *r, double *meanW, bool accumulate)
 {
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D, P = gmmiv_tv_packed_len(R), RR = (size_t)R * R;
     int rc;
     DevIn<double> i_n, i_f, i_t, i_iv, i_te;
@@ -346,7 +346,7 @@ int gmmiv_tv_estimate_a_and_c(gmmiv_ctx *c, int64_t U, int C, int D, int R, cons
 int gmmiv_tv_update_t(gmmiv_ctx *c, int C, int D, int R, const double *A_packed, const double *Cmx, double *Tm)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !A_packed || !Cmx || !Tm) { gmmiv_set_error("tv_update_t: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D, P = gmmiv_tv_packed_len(R), RR = (size_t)R * R;
     int rc;
     DevIn<double> i_a, i_c;
@@ -387,7 +387,7 @@ int gmmiv_tv_min_divergence(gmmiv_ctx *c, int C, int D, int R, double n_sessions
                             const double *meanW, double *ubm_means, double *Tm)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !(n_sessions > 0) || !Rm || !r || !meanW || !ubm_means || !Tm) { gmmiv_set_error("tv_min_divergence: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D, RR = (size_t)R * R;
     int rc;
     DevOut<double> o_rm, o_r, o_mean, o_t;
@@ -445,7 +445,7 @@ int gmmiv_tv_norm_statistics(gmmiv_ctx *c, int64_t U, int C, int D, const double
                              const double *invvar)
 {
     if (!c || U < 0 || C <= 0 || D <= 0 || !N || !F || !means || !invvar) { gmmiv_set_error("tv_norm_statistics: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_m, i_v;
     DevOut<double> o_f;
@@ -460,7 +460,7 @@ int gmmiv_tv_subtract_m_plus_tw(gmmiv_ctx *c, int64_t U, int C, int D, int R, co
                                 const double *Tm, const double *W)
 {
     if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !means || !Tm || !W) { gmmiv_set_error("tv_subtract_m_plus_tw: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_m, i_t, i_w;
     DevOut<double> o_f;
@@ -488,7 +488,7 @@ int gmmiv_jfa_subtract(gmmiv_ctx *c, int64_t rows, int C, int D, const double *N
 {
     if (!c || rows < 0 || C <= 0 || D <= 0 || !N || !F || nfact < 0 || (Tm && (R <= 0 || !W)) || (Dm && !Z)) { gmmiv_set_error("jfa_subtract: bad argument"); return GMMIV_ERR_ARG; }
     if (rows == 0) return GMMIV_OK;
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     if (!owner && nfact < rows && (Tm || Dm)) { gmmiv_set_error("jfa_subtract: %lld factor rows for %lld statistics rows and no owner map", (long long)nfact, (long long)rows); return GMMIV_ERR_ARG; }
     if (owner && !gmmiv_is_device_ptr(owner))
@@ -531,7 +531,7 @@ int gmmiv_jfa_subtract_sessions(gmmiv_ctx *c, int64_t nspk, const int64_t *sess_
     if (nspk == 0) return GMMIV_OK;
     for (int64_t s = 0; s < nspk; ++s)
         if (sess_begin[s + 1] < sess_begin[s] || sess_begin[0] != 0) { gmmiv_set_error("jfa_subtract_sessions: sess_begin must start at 0 and be non-decreasing"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     const int64_t nsess = sess_begin[nspk];
     if (nsess == 0) return GMMIV_OK;
@@ -563,7 +563,7 @@ int gmmiv_jfa_estimate_z(gmmiv_ctx *c, int64_t nspk, int C, int D, const double 
 {
     if (!c || nspk < 0 || C <= 0 || D <= 0 || !N || !F || !invvar || !Dm || !Z) { gmmiv_set_error("jfa_estimate_z: bad argument"); return GMMIV_ERR_ARG; }
     if (nspk == 0) return GMMIV_OK;
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_f, i_v, i_d;
     DevOut<double> o_z;
@@ -578,7 +578,7 @@ int gmmiv_jfa_estimate_z_and_d(gmmiv_ctx *c, int64_t nspk, int C, int D, const d
                                double *Z)
 {
     if (!c || nspk <= 0 || C <= 0 || D <= 0 || !N || !F || !invvar || !Dm || !Z) { gmmiv_set_error("jfa_estimate_z_and_d: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_f, i_v;
     DevOut<double> o_d, o_z;
@@ -593,7 +593,7 @@ int gmmiv_jfa_estimate_z_and_d(gmmiv_ctx *c, int64_t nspk, int C, int D, const d
 int gmmiv_tv_norm_t(gmmiv_ctx *c, int C, int D, int R, double *Tm, const double *invvar)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !invvar) { gmmiv_set_error("tv_norm_t: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_v;
     DevOut<double> o_t;
@@ -606,7 +606,7 @@ int gmmiv_tv_norm_t(gmmiv_ctx *c, int C, int D, int R, double *Tm, const double 
 int gmmiv_tv_weighted_cov(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *weight, double *Wm)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !weight || !Wm) { gmmiv_set_error("tv_weighted_cov: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_t, i_w;
     DevOut<double> o;
@@ -625,7 +625,7 @@ int gmmiv_tv_weighted_cov(gmmiv_ctx *c, int C, int D, int R, const double *Tm, c
 int gmmiv_tv_approximate_tctc(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *Q, double *Dm)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !Q || !Dm) { gmmiv_set_error("tv_approximate_tctc: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_t, i_q;
     DevOut<double> o;
@@ -650,7 +650,7 @@ int gmmiv_tv_estimate_w_ubm_weight(gmmiv_ctx *c, int64_t U, int C, int D, int R,
                                    const double *Wm, double *W)
 {
     if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !Tm || !Wm || !W) { gmmiv_set_error("tv_estimate_w_ubm_weight: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_f, i_t, i_w;
     DevOut<double> o;
@@ -684,7 +684,7 @@ int gmmiv_tv_estimate_w_eigen(gmmiv_ctx *c, int64_t U, int C, int D, int R, cons
                               const double *Dm, const double *Q, double *W)
 {
     if (!c || U < 0 || C <= 0 || D <= 0 || R <= 0 || !N || !F || !Tm || !Dm || !Q || !W) { gmmiv_set_error("tv_estimate_w_eigen: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t SV = (size_t)C * D;
     DevIn<double> i_n, i_f, i_t, i_d, i_q;
     DevOut<double> o;
@@ -713,7 +713,7 @@ int gmmiv_tv_estimate_w_eigen(gmmiv_ctx *c, int64_t U, int C, int D, int R, cons
 int gmmiv_tv_orthonormalize_t(gmmiv_ctx *c, int R, int64_t SV, double *Tm)
 {
     if (!c || R <= 0 || SV <= 0 || !Tm) { gmmiv_set_error("tv_orthonormalize_t: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     DevOut<double> o;
     int rc;
     if ((rc = o.init(c, WS_T0, Tm, (size_t)R * SV, true))) return rc;
@@ -783,7 +783,7 @@ int gmmiv_iv_normalize(gmmiv_ctx *c, int dim_in, int dim_out, int64_t n, const d
     if (!M && dim_in != dim_out) { gmmiv_set_error("iv_normalize: dim_out must equal dim_in without a rotation matrix"); return GMMIV_ERR_ARG; }
     if (n > 0x7fffffff) { gmmiv_set_error("iv_normalize: too many vectors"); return GMMIV_ERR_UNSUPPORTED; }
     if (n == 0) return GMMIV_OK;
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     DevIn<double> i_x, i_mu, i_m;
     DevOut<double> o;
     int rc;
@@ -838,7 +838,7 @@ static int score_check(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const void *
 {
     if (!c || dim <= 0 || M < 0 || S < 0 || !a || !b || !o) { gmmiv_set_error("%s: bad argument", what); return GMMIV_ERR_ARG; }
     if (M > 0x7fffffff || S > 0x7fffffff) { gmmiv_set_error("%s: too many vectors", what); return GMMIV_ERR_UNSUPPORTED; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     return GMMIV_OK;
 }
 
@@ -945,7 +945,7 @@ int gmmiv_score_apply_trials(gmmiv_ctx *c, int64_t M, int64_t S, const unsigned 
 {
     if (!c || M < 0 || S < 0 || !trials || !scores) { gmmiv_set_error("score_apply_trials: bad argument"); return GMMIV_ERR_ARG; }
     if (M == 0 || S == 0) return GMMIV_OK;
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     DevIn<unsigned char> t;
     DevOut<double> o;
     int rc;
@@ -966,7 +966,7 @@ struct DevSet { // device views shared by the gmmiv_dev_* entry points
     {
         if (!c || dim <= 0 || n <= 0 || nspk <= 0 || !X || !sps) { gmmiv_set_error("%s: bad argument", what); return GMMIV_ERR_ARG; }
         if (gmmiv_is_device_ptr(sps)) { gmmiv_set_error("%s: sessions_per_speaker must be a host array", what); return GMMIV_ERR_ARG; }
-        GCHK(hipSetDevice(c->device));
+        GBIND(c);
         hoff.assign(nspk + 1, 0);
         for (int64_t i = 0; i < nspk; ++i) {
             if (sps[i] <= 0) { gmmiv_set_error("%s: speaker %ld has no session", what, (long)i); return GMMIV_ERR_ARG; }
@@ -1112,7 +1112,7 @@ int gmmiv_dev_scatter_mat(gmmiv_ctx *c, int dim, int64_t n, const double *X, int
 int gmmiv_sym_eigen(gmmiv_ctx *c, int n, const double *A, int rank, double *vect, double *val)
 {
     if (!c || n <= 0 || rank <= 0 || rank > n || !A) { gmmiv_set_error("sym_eigen: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     std::vector<double> a, v, l;
     int rc;
     if ((rc = fetch_host(c, A, (size_t)n * n, a))) return rc;
@@ -1124,7 +1124,7 @@ int gmmiv_sym_eigen(gmmiv_ctx *c, int n, const double *A, int rank, double *vect
 int gmmiv_dev_efr_matrix(gmmiv_ctx *c, int dim, const double *Cov, double *M)
 {
     if (!c || dim <= 0 || !Cov || !M) { gmmiv_set_error("dev_efr_matrix: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     std::vector<double> a, v, l, m((size_t)dim * dim);
     int rc;
     if ((rc = fetch_host(c, Cov, (size_t)dim * dim, a))) return rc;
@@ -1139,7 +1139,7 @@ int gmmiv_dev_efr_matrix(gmmiv_ctx *c, int dim, const double *Cov, double *M)
 int gmmiv_dev_lda(gmmiv_ctx *c, int dim, const double *W, const double *B, int rank, double *ldaMat, double *eigval)
 {
     if (!c || dim <= 0 || rank <= 0 || rank > dim || !W || !B || !ldaMat) { gmmiv_set_error("dev_lda: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     std::vector<double> w, b, U;
     int rc;
     if ((rc = fetch_host(c, W, (size_t)dim * dim, w)) || (rc = fetch_host(c, B, (size_t)dim * dim, b))) return rc;
@@ -1316,7 +1316,7 @@ int gmmiv_plda_precompute(gmmiv_ctx *c, int dim, int rf, int rg, const double *F
                           double *FTJF)
 {
     if (!c || dim <= 0 || rf <= 0 || rg < 0 || !Fm || (rg > 0 && !Gm) || !Sigma || !FTJ || !FTJF) { gmmiv_set_error("plda_precompute: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     DevIn<double> i_f, i_g, i_s;
     DevOut<double> o_j, o_jf;
     int rc;
@@ -1358,7 +1358,7 @@ int gmmiv_plda_precompute(gmmiv_ctx *c, int dim, int rf, int rg, const double *F
 int gmmiv_twocov_model(gmmiv_ctx *c, int dim, const double *W, const double *B, double *G, double *H)
 {
     if (!c || dim <= 0 || !W || !B || !G || !H) { gmmiv_set_error("twocov_model: bad argument"); return GMMIV_ERR_ARG; }
-    GCHK(hipSetDevice(c->device));
+    GBIND(c);
     const size_t dd = (size_t)dim * dim;
     DevIn<double> i_w, i_b;
     DevOut<double> o_g, o_h;

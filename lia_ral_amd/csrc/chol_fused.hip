@@ -34,8 +34,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #endif
 
 // A/B switch of the calling host thread: 0 = every wave fetches the panel rows itself (the round-1 kernels)
-static thread_local int g_chol_lds = 1;
-int tvk_set_chol_lds(int on) { const int prev = g_chol_lds; g_chol_lds = on; return prev; }
+#define g_chol_lds (gmmiv_kopts_cur().chol_lds) // option of the calling context (ctx.h: gmmiv_kopts)
 
 namespace {
 

@@ -13,6 +13,14 @@
 
 void gmmiv_set_error(const char *fmt, ...);
 
+#include "kopts.h"
+
+#define GBIND(c)                                                                                    \
+    do {                                                                                            \
+        GCHK(hipSetDevice((c)->device));                                                            \
+        gmmiv_kopts_bind(&(c)->ko);                                                                 \
+    } while (0)
+
 #define GCHK(expr)                                                                                  \
     do {                                                                                            \
         hipError_t _e = (hipError_t)(expr);                                                         \
@@ -56,7 +64,7 @@ struct gmmiv_ctx {
     long tv_md_device = 1; // minDivergence: R normalised and factored on the device (one workgroup of k_chol_left); 0: on the host
     long tv_mstep_solve = 1; // updateTestimate by substitution through the Cholesky factor (k_chol_solve_multi); 0: explicit inverse + GEMM
     long tv_batch = 1024; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)
-    long z_waves = 8; // waves per workgroup of k_stats_z: 8 (one workgroup per CU) or 4 (two per CU)
+    gmmiv_kopts ko;   // "z_waves", "z_tv4", "z_depth_*", "gemm_*", "chol_*": see gmmiv_kopts above
     // logit scratch budget (MiB): frames are processed in chunks that fit.  Sized for a 288 GB part --
     // fewer, larger launches (64 GiB = 3.4 M frames of a 2048-Gaussian model per chunk); never more
     // than half of the memory that is free when the scratch is first needed.

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kopts.h"
+
 int gmmk_ks_for_dim(int D);   // k-steps (of 4 dims) of the compiled instantiation serving D, 0 = unsupported
 int gmmk_rl_for_ks(int KS);   // row length (doubles) of the LDS frame tile / half-width of an EM partial row
 int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, const double *w, const double *mean,
@@ -56,10 +58,7 @@ int gmmk_topc_scatter(hipStream_t st, long n, int ctop, const long *redo, const 
 int gmmk_posteriors(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp, const double *meanT,
                     const double *ivT, const double *lwc, const double *lse, double *gamma);
 int gmmk_stats_z_groups(int nct);
-void gmmk_stats_z_set_waves(int w);
-int gmmk_stats_z_set_tv4(int on);   // thread-local A/B switch, returns the previous value
 int gmmk_stats_z_wg_per_cu(void);
-int gmmk_stats_z_set_depth(int em, int tv); // stream register sets of k_stats_z per mode (2 or 3; other values leave a mode as it is); returns 10 * em + tv before
 int gmmk_stats_z(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, int nct, const double *zbuf,
                  long nfb, const int *eit, const double *inv, const int *efin, double scale, const long *seg_begin, int nseg,
                  double *out0, double *out1, int mode, int accum, double prune_thr);

@@ -1,0 +1,21 @@
+// kopts.h -- the options of a context that its kernel launchers read (internal).
+#pragma once
+
+// Options that reach the kernel launchers (stats_z.hip, tv_kernels.hip, chol_fused.hip), which see a stream, not a context.
+// They LIVE in the context (gmmiv_ctx::ko); a call binds its context's set to the calling thread on entry (GBIND, together
+// with hipSetDevice) and the launchers read the bound set -- two contexts driven from one thread keep their own settings, one
+// context driven from two threads shows both the same.
+struct gmmiv_kopts {
+    int z_waves = 8;      // workgroup shape of k_stats_z: 8 (one workgroup per CU), 16, or 4 (two per CU)
+    int z_tv4 = 1;        // 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z too
+    int z_depth_em = 2, z_depth_tv = 4; // stream register sets of k_stats_z per mode (measured: EM 30.5 ms (2) / 31.1 (4) per 4 M frames, N / F 14.2 (four tiles, 2) / 13.7 (two tiles, 4) per 3 M)
+    int gemm_remap = 1;   // XCD-aware tile order in k_dgemm
+    int gemm_clamp = 1;   // 0 = cut tiles always on the per-element checked instantiation
+    int gemm_narrow = 1;  // 0 = 128 x 128 tiles on the strips cut by M / N too
+    int chol_lds = 1;     // chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself
+    int chol_gemm = 0;    // 1 = the GEMM-built right-looking factorisation for every order
+    int chol_panel = 0;   // panel width of chol_fused.hip: 0 = the default of the build
+};
+const gmmiv_kopts &gmmiv_kopts_cur();          // the set bound to this thread (the defaults before any call)
+void gmmiv_kopts_bind(const gmmiv_kopts *ko);  // nullptr: back to the defaults
+

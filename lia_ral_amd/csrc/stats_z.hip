@@ -311,20 +311,11 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
 
 // per host thread: a context belongs to one thread at a time and pushes its own option right before the launch,
 // so contexts driven from different threads (one per GPU) cannot see each other's value
-static thread_local int g_stats_z_waves = 8;
-static thread_local int g_stats_z_tv4 = 1; // A/B knob: 0 = two tiles per wave in the N / F mode too
-// stream register sets (prefetch distance + 1) of the 8-wave / two-tile shape, per statistics mode: 2 or 4 (see k_stats_z, ZD)
-static thread_local int g_stats_z_depth_em = 2, g_stats_z_depth_tv = 4; // measured: EM 30.5 ms (2) / 31.1 (4) per 4 M frames, N / F 14.2 (four tiles, 2) / 13.7 (two tiles, 4) per 3 M
-int gmmk_stats_z_set_depth(int em, int tv)
-{
-    const int prev = g_stats_z_depth_em * 10 + g_stats_z_depth_tv;
-    if (em == 2 || em == 4) g_stats_z_depth_em = em;
-    if (tv == 2 || tv == 4) g_stats_z_depth_tv = tv;
-    return prev;
-}
-int gmmk_stats_z_set_tv4(int on) { const int prev = g_stats_z_tv4; g_stats_z_tv4 = on; return prev; }
-void gmmk_stats_z_set_waves(int w) { g_stats_z_waves = (w == 4 || w == 16) ? w : 8; }
-// Gaussian tiles per workgroup: 16 for <8,2> and <16,1>, 8 for <4,2>
+// workgroup shape / stream depth: options of the calling context (ctx.h: gmmiv_kopts, bound per call)
+#define g_stats_z_waves (gmmiv_kopts_cur().z_waves)
+#define g_stats_z_tv4 (gmmiv_kopts_cur().z_tv4)
+#define g_stats_z_depth_em (gmmiv_kopts_cur().z_depth_em)
+#define g_stats_z_depth_tv (gmmiv_kopts_cur().z_depth_tv)
 int gmmk_stats_z_groups(int nct) { const int tpg = g_stats_z_waves == 4 ? 8 : 16; return (nct + tpg - 1) / tpg; }
 int gmmk_stats_z_wg_per_cu(void) { return g_stats_z_waves == 4 ? 2 : 1; }
 

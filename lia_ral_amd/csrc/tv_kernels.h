@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kopts.h"
+
 int tvk_dgemm(hipStream_t st, bool ta, bool tb, int M, int N, int K, double alpha, const double *A, long lda, long sA,
               const double *B, long ldb, long sB, double beta, double *C, long ldc, long sC, int batch);
 int tvk_chol_batched(hipStream_t st, int n, int nb, double *Afull, double *invd, double *panel, int *status);
@@ -10,12 +12,8 @@ int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *
 int tvk_chol_solve_multi_batched(hipStream_t st, int n, int nb, int nrhs, const double *Lf, const double *invd, const double *B, long ldb,
                                  long sB, double *X, long ldx, long sX); // -1: nrhs > 64 or odd n (use the explicit inverse)
 int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read packed lower rows directly
-// A/B switches: thread-local (they act on the launches of the calling host thread); return the previous value
-int tvk_set_chol_gemm_path(int on);
-int tvk_set_chol_lds(int on);   // 0: the panel rows of chol_fused.hip from memory per wave (round 1) instead of LDS
-int tvk_set_gemm_clamp(int on);
-int tvk_set_gemm_narrow(int on); // 0 = 128 x 128 tiles on the strips cut by M / N as well (default: 32-wide tiles on strips of <= 64)
-int tvk_set_gemm_remap(int on);
+// (the A/B switches "chol_gemm", "chol_lds", "gemm_clamp", "gemm_narrow", "gemm_remap" are options of the calling context:
+//  ctx.h, gmmiv_kopts -- the launchers read gmmiv_kopts_cur())
 int tvk_spd_inverse_left_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *U, double *invd, int *status,
                                  const double *Apacked = nullptr, long spk = 0, double diag_add = 0.0);
 int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double *inv, double *X, double *invd,

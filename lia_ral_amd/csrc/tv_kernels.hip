@@ -306,12 +306,11 @@ static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, i
     else k_dgemm<true, true, MODE, AM, AN><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, m_off, n_off, epi);
 }
 
-static thread_local int g_gemm_remap = 1; // A/B knob: XCD-aware tile order
-int tvk_set_gemm_remap(int on) { const int prev = g_gemm_remap; g_gemm_remap = on; return prev; }
-static thread_local int g_gemm_clamp = 1; // A/B knob: 0 = cut tiles always on the per-element checked instantiation
-int tvk_set_gemm_clamp(int on) { const int prev = g_gemm_clamp; g_gemm_clamp = on; return prev; }
-static thread_local int g_gemm_narrow = 1; // A/B knob: 0 = 128 x 128 tiles on the strips too
-int tvk_set_gemm_narrow(int on) { const int prev = g_gemm_narrow; g_gemm_narrow = on; return prev; }
+// A/B knobs of the calling context (ctx.h: gmmiv_kopts, bound per call): XCD-aware tile order; 0 = cut tiles always on the
+// per-element checked instantiation; 0 = 128 x 128 tiles on the strips too
+#define g_gemm_remap (gmmiv_kopts_cur().gemm_remap)
+#define g_gemm_clamp (gmmiv_kopts_cur().gemm_clamp)
+#define g_gemm_narrow (gmmiv_kopts_cur().gemm_narrow)
 
 // grid.z = batch (ksplit == 0) or K layers (ksplit > 0).  Three instantiations: full tiles run MODE 0 (no checks at all) when
 // every K range is a multiple of 16 and the operands allow 16-byte loads; tiles cut by M or N run MODE 2 (the same loads,
@@ -650,8 +649,7 @@ __global__ __launch_bounds__(256) void k_potf2_inv(int n, int kk, int w, double 
         if (_r) return _r;           \
     } while (0)
 
-static thread_local int g_chol_gemm_path = 0; // A/B knob: 1 = the GEMM-built right-looking factorisation for every n
-int tvk_set_chol_gemm_path(int on) { const int prev = g_chol_gemm_path; g_chol_gemm_path = on; return prev; }
+#define g_chol_gemm_path (gmmiv_kopts_cur().chol_gemm) // A/B knob of the calling context: 1 = the GEMM-built right-looking factorisation for every n
 int tvk_chol_accepts_packed(int n) { return n % 2 == 0 && !g_chol_gemm_path; }
 
 // In-place batched Cholesky (lower) of nb SPD matrices [n x n]; invd receives the inverses of the

@@ -64,6 +64,62 @@ int liagpu_train_world(int device, const float *x, long T, int D, const long *se
     })
 }
 
+// mixtureInit (TrainTools.cpp:674-766 multi-stream form with one stream when single_stream == 0, :619-672 when 1): the
+// start-from-scratch model of TrainWorld.  param = nbFrameToSelect (multi) or baggedFrameProbabilityInit (single).
+// w / mean / cov [C], [C x D], [C x D] out; counts [C] (nullable) = frames picked per component.
+int liagpu_mixture_init(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg, int C,
+                        int single_stream, double param, double stream_weight, long min_len, long max_len, const double *global_cov,
+                        double *w, double *mean, double *cov, long *counts)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD world((unsigned long)C, (unsigned long)D);
+        MixtureInitCfg cfg;
+        cfg.baggedMinimalLength = (unsigned long)min_len; cfg.baggedMaximalLength = (unsigned long)max_len;
+        std::vector<unsigned long> cnt;
+        const std::vector<double> gc(global_cov, global_cov + D);
+        if (single_stream) { cfg.baggedFrameProbabilityInit = param; mixtureInitSingleStream(fs, world, segs, gc, cfg, &cnt); }
+        else { cfg.nbFrameToSelect = param; mixtureInit(fs, segs, stream_weight, world, gc, cfg, &cnt); }
+        memcpy(w, world.weights().data(), C * sizeof(double));
+        memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
+        if (counts) for (int k = 0; k < C; ++k) counts[k] = (long)cnt[k];
+    })
+}
+
+// TVAcc::verifyEMLK (AccumulateTVStat.cpp:1654-1688) on given i-vectors: file f = frames [file_begin[f], file_begin[f+1]) of x,
+// its speaker model = UBM with means m + T^T W[row_of_file[f]]; llk_out [nfiles] = getLLK per file, *total = their sum.
+// supervectors_out (nullable) [nfiles x C*D] = getMplusTW of each file's row.
+int liagpu_tv_verify_emlk(int device, const float *x, long T, int D, const long *file_begin, long nfiles, const long *row_of_file, int C,
+                          const double *w, const double *mean, const double *cov, int R, const double *Tmat, long U, const double *W,
+                          long max_llk_computed, double minLLK, double maxLLK, double *llk_out, double *total, double *supervectors_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        TVAcc tv(srv, make_mixture(C, D, w, mean, cov), (unsigned long)R, (unsigned long)U);
+        tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
+        memcpy(tv.getW().data(), W, (size_t)U * R * sizeof(double));
+        std::vector<SegCluster> segs(nfiles);
+        std::vector<unsigned long> rows(nfiles);
+        for (long f = 0; f < nfiles; ++f) {
+            Seg s; s.begin = (unsigned long)file_begin[f]; s.length = (unsigned long)(file_begin[f + 1] - file_begin[f]);
+            segs[f].push_back(s);
+            rows[f] = (unsigned long)row_of_file[f];
+        }
+        std::vector<double> per;
+        *total = tv.verifyEMLK(fs, segs, rows, (unsigned long)max_llk_computed, minLLK, maxLLK, &per);
+        for (size_t f = 0; f < per.size(); ++f) llk_out[f] = per[f];
+        if (supervectors_out) {
+            std::vector<double> Sp;
+            tv.getMplusTW(Sp, rows);
+            memcpy(supervectors_out, Sp.data(), Sp.size() * sizeof(double));
+        }
+    })
+}
+
 // accumulateStatLLK over a cluster (AccumulateStat.cpp:69-94): getMeanLLK of the selected frames, clamped per frame
 int liagpu_mean_llk(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg, int C,
                     const double *w, const double *mean, const double *cov, double minLLK, double maxLLK, double *out)

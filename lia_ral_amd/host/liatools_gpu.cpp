@@ -374,6 +374,107 @@ void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedFrameS
     }
 }
 
+void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedSeg, unsigned long nbBagged, double baggedProbability,
+                    unsigned long minimumLength, unsigned long maximumLength)
+{
+    size_t cur = 0;
+    bool end = selectedSegments.empty();
+    unsigned long beginSeg = 0, lengthSeg = 0;
+    if (!end) { beginSeg = selectedSegments[0].begin; lengthSeg = selectedSegments[0].length; }
+    while (!end) {
+        unsigned long verifyLength = lengthSeg;
+        if (verifyLength < minimumLength) verifyLength = minimumLength;
+        if (verifyLength > maximumLength) verifyLength = maximumLength;
+        const bool moveSeg = lengthSeg <= verifyLength;
+        const unsigned long length = moveSeg ? lengthSeg : verifyLength;
+        if (length > 0)
+            for (unsigned long idx = 0; idx < nbBagged; ++idx)      // one draw per component for this chunk
+                if (baggedFrame(baggedProbability)) {
+                    Seg s;
+                    s.begin = beginSeg; s.length = length; s.source = selectedSegments[cur].source; s.labelCode = idx;
+                    baggedSeg.push_back(s);
+                }
+        if (moveSeg) {
+            ++cur;
+            end = cur >= selectedSegments.size();
+            if (!end) { beginSeg = selectedSegments[cur].begin; lengthSeg = selectedSegments[cur].length; }
+        } else {
+            lengthSeg -= length;
+            beginSeg += length;
+        }
+    }
+}
+
+// the picked frames of every component -> mean; covariance = globalCov; equal weights (TrainTools.cpp:651-658, :745-756)
+static void mixtureFromPicks(FeatureBuffer &fs, const std::vector<SegCluster> &perComponent, MixtureGD &world,
+                             const std::vector<double> &globalCov, std::vector<unsigned long> *frameCount)
+{
+    const unsigned long C = world.getDistribCount(), D = world.getVectSize();
+    if (globalCov.size() != D) throw Exception("mixtureInit: globalCov must have vectSize entries");
+    if (frameCount) frameCount->assign(C, 0);
+    for (unsigned long c = 0; c < C; ++c) {
+        FrameAccGD acc;
+        if (!perComponent[c].empty()) accumulateStatFrame(acc, fs, perComponent[c]);
+        if (acc.getCount() == 0) {
+            char msg[160];
+            snprintf(msg, sizeof(msg), "mixtureInit: no frame was picked for component %lu (too few frames for %lu components)", c, C);
+            throw Exception(msg);
+        }
+        if (frameCount) (*frameCount)[c] = acc.getCount();
+        const std::vector<double> mean = acc.getMeanVect();
+        for (unsigned long i = 0; i < D; ++i) { world.setCov(c, globalCov[i], i); world.setMean(c, mean[i], i); }
+        world.weight(c) = 1.0 / (double)C;      // equalizeWeights
+    }
+    world.computeAll();
+}
+
+void mixtureInit(FeatureBuffer &fs, const SegCluster &selectedSegments, double streamWeight, MixtureGD &world,
+                 const std::vector<double> &globalCov, const MixtureInitCfg &cfg, std::vector<unsigned long> *frameCount)
+{
+    const unsigned long C = world.getDistribCount();
+    const unsigned long total = totalFrame(selectedSegments);
+    if (total == 0) throw Exception("mixtureInit: no frame selected");
+    const unsigned long stream = 0;
+    // the bagging probability of the stream, folded into several passes when it exceeds 1 (TrainTools.cpp:700-708, as written)
+    double proba = (cfg.nbFrameToSelect * streamWeight) / (double)total;
+    unsigned long nbIt = 1;
+    double tmp = proba;
+    while (tmp > 1) {
+        ++nbIt;
+        tmp /= proba / (double)nbIt;
+        // tmp runs 2, 6/p, 24/p^2, ...: for 1 < p < ~4.9 it never returns below 1 and the reference spins forever here
+        if (nbIt > 64) throw Exception("mixtureInit: nbFrameToSelect * weight / totalFrame lies in (1, 4.9): the reference's fold of the bagging probability does not terminate for it (TrainTools.cpp:703-706); select fewer frames per component");
+    }
+    proba = tmp;
+    std::vector<SegCluster> picks(C);
+    for (unsigned long baggedIt = 0; baggedIt < nbIt; ++baggedIt) {
+        SegCluster bagged;
+        srand((unsigned)(((stream + 1) * 100) + (baggedIt + 1)));
+        baggedSegments(selectedSegments, bagged, C, proba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
+        for (const Seg &s : bagged) picks[s.labelCode].push_back(s); // accumulateStatFrame(*frameAcc[seg->labelCode()], ...)
+    }
+    mixtureFromPicks(fs, picks, world, globalCov, frameCount);
+}
+
+void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegCluster &selectedSegments, const std::vector<double> &globalCov,
+                             const MixtureInitCfg &cfg, std::vector<unsigned long> *frameCount)
+{
+    const unsigned long C = world.getDistribCount();
+    double proba = cfg.baggedFrameProbabilityInit / (double)C;
+    unsigned long nbIt = 1;
+    if (proba > 1) {
+        nbIt = (unsigned long)proba + 1;
+        proba /= (double)nbIt;
+    }
+    std::vector<SegCluster> picks(C);
+    for (unsigned long baggedIt = 0; baggedIt < nbIt; ++baggedIt)
+        for (unsigned long c = 0; c < C; ++c) {
+            srand((unsigned)((c + 1) * (baggedIt + 1)));
+            baggedSegments(selectedSegments, picks[c], proba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
+        }
+    mixtureFromPicks(fs, picks, world, globalCov, frameCount);
+}
+
 std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
                                      const std::vector<double> &globalCov, MixtureGD &world, gmmiv_comm *comm)
 {
@@ -832,6 +933,57 @@ void TVAcc::substractMplusTW()
 {
     _srv.check(gmmiv_tv_subtract_m_plus_tw(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
                                            _statF.dev(), _ubm_means.cdev(), _T.cdev(), _W.cdev()));
+}
+void TVAcc::getMplusTW(std::vector<double> &Sp, const std::vector<unsigned long> &rows)
+{
+    // Sp[k] = m + T^T w_rows[k] for all k in one device pass: gmmiv_jfa_subtract computes F -= N (m + W T); with N = -1 and
+    // F = 0 the result IS the supervector (the same entry point serves JFAAcc::getMplusVY...)
+    const size_t n = rows.size();
+    Sp.assign(n * _svSize, 0.0);
+    if (!n) return;
+    std::vector<double> Wsel(n * _rankT);
+    const std::vector<double> &W = _W.chost();
+    for (size_t k = 0; k < n; ++k) {
+        if (rows[k] >= _n_speakers) throw Exception("getMplusTW: row out of range");
+        memcpy(&Wsel[k * _rankT], &W[rows[k] * _rankT], _rankT * sizeof(double));
+    }
+    const std::vector<double> minus1(n * _n_distrib, -1.0);
+    _srv.check(gmmiv_jfa_subtract(_srv.ctx(), (int64_t)n, (int)_n_distrib, (int)_vectSize, minus1.data(), Sp.data(), nullptr, (int64_t)n,
+                                  _ubm_means.cdev(), (int)_rankT, _T.cdev(), Wsel.data(), nullptr, nullptr));
+}
+void TVAcc::getSpeakerModel(MixtureGD &mixture, unsigned long spk)
+{
+    if (mixture.getDistribCount() != _n_distrib || mixture.getVectSize() != _vectSize) throw Exception("getSpeakerModel: model shape differs from the UBM's");
+    std::vector<double> Sp;
+    getMplusTW(Sp, std::vector<unsigned long>(1, spk));
+    for (unsigned long c = 0; c < _n_distrib; ++c)              // svToModel: the means, nothing else
+        for (unsigned long i = 0; i < _vectSize; ++i) mixture.setMean(c, Sp[c * _vectSize + i], i);
+}
+double TVAcc::getLLK(const SegCluster &selectedSegments, const MixtureGD &model, FeatureBuffer &fs, double minLLK, double maxLLK)
+{
+    DeviceMixture dm(_srv, model);
+    return accumulateStatLLK(fs, dm, selectedSegments, minLLK, maxLLK);
+}
+double TVAcc::verifyEMLK(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerFile, const std::vector<unsigned long> &rowOfFile,
+                         unsigned long maxLLKcomputed, double minLLK, double maxLLK, std::vector<double> *perFile)
+{
+    if (rowOfFile.size() != segsPerFile.size()) throw Exception("verifyEMLK: one statistics row per file expected");
+    const size_t n = std::min<size_t>(segsPerFile.size(), (size_t)maxLLKcomputed);
+    std::vector<double> Sp;
+    getMplusTW(Sp, std::vector<unsigned long>(rowOfFile.begin(), rowOfFile.begin() + n));   // every speaker model in one pass
+    if (perFile) perFile->assign(n, 0.0);
+    MixtureGD model = _ubm;                                       // loadMixtureGD(inputWorldFilename) per file in the reference
+    DeviceMixture dm(_srv, model);
+    double total = 0.0;
+    for (size_t f = 0; f < n; ++f) {
+        for (unsigned long c = 0; c < _n_distrib; ++c)
+            for (unsigned long i = 0; i < _vectSize; ++i) model.setMean(c, Sp[f * _svSize + c * _vectSize + i], i);
+        dm.update(model);
+        const double llk = accumulateStatLLK(fs, dm, segsPerFile[f], minLLK, maxLLK);
+        if (perFile) (*perFile)[f] = llk;
+        total += llk;
+    }
+    return total;
 }
 void TVAcc::normTMatrix()
 {

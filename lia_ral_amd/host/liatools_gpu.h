@@ -28,6 +28,7 @@ struct Exception : std::runtime_error {
 struct Seg {
     unsigned long begin = 0, length = 0;
     unsigned long source = 0; // index of the feature file in the FeatureBuffer
+    unsigned long labelCode = 0; // Seg::labelCode(): the multi-cluster baggedSegments tags a segment with the component it was drawn for
 };
 typedef std::vector<Seg> SegCluster;
 unsigned long totalFrame(const SegCluster &c);
@@ -206,6 +207,25 @@ unsigned long computeMeanCov(FeatureBuffer &fs, const SegCluster &seg, std::vect
 // GeneralTools.cpp:455-510 with glibc rand() (baggedFrame :309-314); caller seeds with srand()
 void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedFrameSegment, double baggedProbability,
                     unsigned long minimumLength, unsigned long maximumLength);
+// The multi-selection form (GeneralTools.cpp:330-390): ONE walk over the input segments, nbBagged independent draws per chunk;
+// a chunk drawn for component idx is appended with labelCode = idx (rand() order: chunk-major, component-minor)
+void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedSeg, unsigned long nbBagged, double baggedProbability,
+                    unsigned long minimumLength, unsigned long maximumLength);
+// mixtureInit: the start-from-scratch model of TrainWorld (random picking of frames per component; means = the picked
+// frames' means, covariances = globalCov, equal weights).  glibc srand / rand in the reference's order, like baggedSegments.
+//   multi-stream form, TrainTools.cpp:674-766 -- the one TrainWorld.cpp:177 calls -- for ONE stream of weight streamWeight:
+//     p = nbFrameToSelect * weight / totalFrame (folded into several bagging passes when > 1, :700-708 -- as written that fold
+//     only terminates for p >= ~4.9; for 1 < p < 4.9 the reference spins forever and this layer throws instead), seed
+//     srand((stream + 1) * 100 + baggedIt + 1), one multi-selection baggedSegments pass per iteration;
+//   single-stream form, TrainTools.cpp:619-672: p = baggedFrameProbabilityInit / distribCount, seed
+//     srand((indg + 1) * (baggedIt + 1)) and one plain baggedSegments pass PER COMPONENT.
+// A component that drew no frame has no mean: Exception (FrameAccGD::getMeanVect on an empty accumulator is undefined in
+// the reference).  frameCount (optional) receives the frames picked per component.
+struct MixtureInitCfg { unsigned long baggedMinimalLength = 3, baggedMaximalLength = 7; double nbFrameToSelect = 50; double baggedFrameProbabilityInit = 0.0; };
+void mixtureInit(FeatureBuffer &fs, const SegCluster &selectedSegments, double streamWeight, MixtureGD &world,
+                 const std::vector<double> &globalCov, const MixtureInitCfg &cfg, std::vector<unsigned long> *frameCount = nullptr);
+void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegCluster &selectedSegments, const std::vector<double> &globalCov,
+                             const MixtureInitCfg &cfg, std::vector<unsigned long> *frameCount = nullptr);
 // trainModelStream (TrainTools.cpp:1030-1110), single stream; returns the per-iteration mean llk
 // ("llkPreviousIt").  allReduce, when given, sums the flat accumulator over ranks (RCCL/xGMI).
 // Multi-GPU: frames sharded per rank, ONE all-reduce of the flat EM accumulator per iteration, the collective twin of
@@ -301,6 +321,17 @@ class TVAcc {
     // of Gaussians, T_c = A_c^-1 Cmx_c on the rank's own Gaussians, all-gather of T; R, r and meanW (sums) are all-reduced
     // for minDivergence, whose session count becomes the global one.  comm == NULL or one rank: plain updateTestimate.
     void updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks);
+    // The EM sanity check of TotalVariability (TotalVariability.cpp:132 `if (_checkLLK) tvAcc.verifyEMLK(config)`):
+    //   getMplusTW (:964-971)      Sp = ubm_means + T^T w_spk  -- for a LIST of rows at once: one device pass, Sp [rows x svSize]
+    //   getSpeakerModel (:1533-1545) the UBM with those means (svToModel, SuperVectors.cpp:79-85: means only)
+    //   getLLK (:1626-1651)        mean clamped log-likelihood of the selected frames under a model (computeAndAccumulateLLK loop)
+    //   verifyEMLK (:1654-1688)    sum over the first maxLLKcomputed files of getLLK(file's segments, speaker model of its row);
+    //                              rowOfFile[f] = the statistics row (ndx line) file f belongs to; perFile (optional) = each llk
+    void getMplusTW(std::vector<double> &Sp, const std::vector<unsigned long> &rows);
+    void getSpeakerModel(MixtureGD &mixture, unsigned long spk);
+    double getLLK(const SegCluster &selectedSegments, const MixtureGD &model, FeatureBuffer &fs, double minLLK = -200.0, double maxLLK = 200.0);
+    double verifyEMLK(FeatureBuffer &fs, const std::vector<SegCluster> &segsPerFile, const std::vector<unsigned long> &rowOfFile,
+                      unsigned long maxLLKcomputed, double minLLK = -200.0, double maxLLK = 200.0, std::vector<double> *perFile = nullptr);
     // all host views below download on demand (and re-upload before the next device step, they may be written through)
     std::vector<double> &getT() { return _T.host(); }
     std::vector<double> &getW() { return _W.host(); }

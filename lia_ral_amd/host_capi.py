@@ -57,6 +57,39 @@ def train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, bagged_p=1.0, init_f
     return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk)
 
 
+def mixture_init(x, seg_begin, seg_len, C, global_cov, nb_frame_to_select=50.0, stream_weight=1.0, single_stream_proba=None, min_len=3,
+                 max_len=7, device=0):
+    """mixtureInit: TrainWorld's start-from-scratch model (multi-stream form with one stream; single_stream_proba = the
+    baggedFrameProbabilityInit of the single-stream form).  Returns dict(w, mean, cov, counts)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    gc = np.ascontiguousarray(global_cov, np.float64)
+    w = np.empty(C); mean = np.empty((C, D)); cov = np.empty((C, D)); cnt = np.zeros(C, np.int64)
+    single = single_stream_proba is not None
+    _chk(lib.liagpu_mixture_init(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, int(single),
+                                 ct.c_double(single_stream_proba if single else nb_frame_to_select), ct.c_double(stream_weight),
+                                 ct.c_long(min_len), ct.c_long(max_len), _d(gc), _d(w), _d(mean), _d(cov), cnt.ctypes.data_as(_lp)))
+    return dict(w=w, mean=mean, cov=cov, counts=cnt)
+
+
+def tv_verify_emlk(x, file_begin, row_of_file, ubm, Tmat, W, max_llk_computed=None, min_llk=-200.0, max_llk=200.0, device=0):
+    """TVAcc::verifyEMLK: per-file mean log-likelihood under the speaker model m + T^T w_row; returns (llk [nfiles], total, supervectors)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C = len(w)
+    fb = np.ascontiguousarray(file_begin, np.int64); rows = np.ascontiguousarray(row_of_file, np.int64)
+    nf = len(fb) - 1
+    Tm = np.ascontiguousarray(Tmat, np.float64); Wm = np.ascontiguousarray(W, np.float64)
+    n = nf if max_llk_computed is None else min(nf, max_llk_computed)
+    llk = np.zeros(nf); total = ct.c_double(0.0); sv = np.empty((nf, C * D))
+    _chk(lib.liagpu_tv_verify_emlk(device, x.ctypes.data_as(_fp), ct.c_long(T), D, fb.ctypes.data_as(_lp), ct.c_long(nf), rows.ctypes.data_as(_lp),
+                                   C, _d(w), _d(mean), _d(cov), Tm.shape[0], _d(Tm), ct.c_long(Wm.shape[0]), _d(Wm), ct.c_long(n),
+                                   ct.c_double(min_llk), ct.c_double(max_llk), _d(llk), ct.byref(total), _d(sv)))
+    return llk[:n], total.value, sv
+
+
 def mean_llk(x, seg_begin, seg_len, model, min_llk=-200.0, max_llk=200.0, device=0):
     """accumulateStatLLK: mean clamped log-likelihood of the selected frames."""
     x = np.ascontiguousarray(x, np.float32)

@@ -321,6 +321,81 @@ long orc_bagged_segments(unsigned seed, const long *seg_begin, const long *seg_l
     return n;
 }
 
+/* The multi-selection bagging of mixtureInit (GeneralTools.cpp:330-390): one walk over the segments, nb_bagged draws per chunk,
+ * a chunk kept for component idx is written with label idx.  Seeds the generator itself (TrainTools.cpp:732). */
+long orc_bagged_segments_multi(unsigned seed, const long *seg_begin, const long *seg_len, long nseg, long nb_bagged,
+                               double p, long min_len, long max_len,
+                               long *out_begin, long *out_len, long *out_label, long max_out)
+{
+    srand(seed);
+    long n = 0, s = 0;
+    if (nseg == 0) return 0;
+    long begin = seg_begin[0], len = seg_len[0];
+    int end = 0;
+    while (!end) {
+        long verify = len;
+        if (verify < min_len) verify = min_len;
+        if (verify > max_len) verify = max_len;
+        const int move = len <= verify;
+        const long length = move ? len : verify;
+        if (length > 0)
+            for (long idx = 0; idx < nb_bagged; ++idx)
+                if (bagged_frame(p)) {
+                    if (n < max_out) { out_begin[n] = begin; out_len[n] = length; out_label[n] = idx; }
+                    n++;
+                }
+        if (move) {
+            s++;
+            end = (s >= nseg);
+            if (!end) { begin = seg_begin[s]; len = seg_len[s]; }
+        } else {
+            len -= length;
+            begin += length;
+        }
+    }
+    return n;
+}
+
+/* mixtureInit, multi-stream form with one stream (TrainTools.cpp:674-766): per-component FrameAccGD over the picked frames;
+ * mean[C x D] out (covariances = globalCov and weights = 1/C are the caller's), count[C] = frames picked per component.
+ * x: [T x D] row-major.  Returns 0, or -1 if the scratch for the bagged list was too small. */
+int orc_mixture_init(int C, int D, const double *x, const long *seg_begin, const long *seg_len, long nseg, double stream_weight,
+                     double nb_frame_to_select, long min_len, long max_len, double *mean, double *count)
+{
+    long total = 0;
+    for (long s = 0; s < nseg; ++s) total += seg_len[s];
+    double proba = (nb_frame_to_select * stream_weight) / (double)total;   /* :700 */
+    long nb_it = 1;
+    double tmp = proba;
+    while (tmp > 1) { /* :703-706, as written: tmp runs 2, 6/p, 24/p^2, ... -- it never comes back under 1 for 1 < p < ~4.9 */
+        nb_it++;
+        tmp /= proba / (double)nb_it;
+        if (nb_it > 64) return -2; /* the reference hangs here; the restatement reports it */
+    }
+    proba = tmp;
+    double *sum = (double *)calloc((size_t)C * D, sizeof(double));
+    for (int c = 0; c < C; ++c) count[c] = 0.0;
+    const long cap = (total + nseg + 8) * C;
+    long *ob = (long *)malloc(sizeof(long) * cap), *ol = (long *)malloc(sizeof(long) * cap), *lab = (long *)malloc(sizeof(long) * cap);
+    int rc = 0;
+    for (long it = 0; it < nb_it && !rc; ++it) {
+        const long n = orc_bagged_segments_multi((unsigned)((0 + 1) * 100 + (it + 1)), seg_begin, seg_len, nseg, C, proba, min_len, max_len,
+                                                 ob, ol, lab, cap);
+        if (n > cap) { rc = -1; break; }
+        for (long k = 0; k < n; ++k) {                 /* accumulateStatFrame(*frameAcc[seg->labelCode()], ...) */
+            double *sc = sum + (size_t)lab[k] * D;
+            for (long t = ob[k]; t < ob[k] + ol[k]; ++t) {
+                for (int i = 0; i < D; ++i) sc[i] += x[(size_t)t * D + i];
+                count[lab[k]] += 1.0;
+            }
+        }
+    }
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < D; ++i) mean[(size_t)c * D + i] = sum[(size_t)c * D + i] / count[c];
+    free(sum); free(ob); free(ol); free(lab);
+    return rc;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Rows 11-17: TVAcc (total variability)
  * ------------------------------------------------------------------------------------------- */

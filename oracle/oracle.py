@@ -183,6 +183,21 @@ def bagged_segments(seed, seg_begin, seg_len, p, min_len=3, max_len=7):
     return ob[:n].copy(), ol[:n].copy(), os_[:n].copy()
 
 
+def mixture_init(C, x, seg_begin, seg_len, nb_frame_to_select=50.0, stream_weight=1.0, min_len=3, max_len=7):
+    """mixtureInit (TrainTools.cpp:674-766, one stream): (mean [C x D], frames picked per component)."""
+    x, xp = _d(x)
+    D = x.shape[1]
+    sb, sbp = _l(seg_begin); sl, slp = _l(seg_len)
+    mean = np.empty((C, D)); cnt = np.empty(C)
+    rc = _lib().orc_mixture_init(ct.c_int(C), ct.c_int(D), xp, sbp, slp, ct.c_long(len(sb)), ct.c_double(stream_weight),
+                                 ct.c_double(nb_frame_to_select), ct.c_long(min_len), ct.c_long(max_len),
+                                 mean.ctypes.data_as(c_dp), cnt.ctypes.data_as(c_dp))
+    if rc == -2:
+        raise ValueError("mixtureInit: the reference's probability fold (TrainTools.cpp:703-706) does not terminate for this nbFrameToSelect")
+    assert rc == 0
+    return mean, cnt
+
+
 # ---------------------------------------------------------------- total variability
 def tv_stats(g, x, utt, U):
     x, xp = _d(x)

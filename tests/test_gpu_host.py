@@ -688,3 +688,85 @@ def test_init_t_and_statistics_with_a_file_on_several_lines():
     N2, F2 = ctx.gmm(w, mean, iv).tv_stats_lines(x, fb, lines)        # C ABI directly
     assert np.array_equal(N2, N) and np.array_equal(F2, F)
     ctx.close()
+
+
+@pytest.mark.parametrize("select", [50.0, 2000.0])
+def test_mixture_init_and_train_world_from_scratch(select):
+    """mixtureInit (TrainTools.cpp:674-766, the form TrainWorld.cpp:177 calls): per-component random picking of 3..7-frame chunks
+    with the reference's srand / rand() order (multi-selection baggedSegments, GeneralTools.cpp:330-390), means of the picked
+    frames through gmmiv_frame_moments, covariances = globalCov, equal weights -- against the oracle restatement; then TrainWorld
+    runs FROM SCRATCH (no initial model given) and agrees with the oracle's EM loop started from the oracle's init.  select = 2000 on
+    300 frames drives the bagging probability to 6.67: three bagging passes of p = 0.9 (:700-708); a probability in (1, 4.9) makes the
+    reference's fold loop spin forever -- the host layer reports it instead."""
+    from lia_ral_amd import host_capi as h
+    C, D = 12, 10
+    w, mean, iv = make_gmm(C, D, seed=8)
+    T = 6000 if select == 50.0 else 330
+    x = make_frames(w, mean, iv, T, seed=9)
+    seg_begin, seg_len = ([0, 2600], [2500, 3400]) if select == 50.0 else ([0, 180], [150, 150])
+    sel = np.concatenate([np.arange(b, b + n) for b, n in zip(seg_begin, seg_len)])
+    s, ss, n = orc.frame_acc(x[sel].astype(np.float64))
+    _, gcov = orc.frame_mean_cov(s, ss, n)
+    got = h.mixture_init(x, seg_begin, seg_len, C, gcov, nb_frame_to_select=select)
+    m_o, cnt_o = orc.mixture_init(C, x.astype(np.float64), seg_begin, seg_len, nb_frame_to_select=select)
+    assert np.array_equal(got["counts"], cnt_o.astype(np.int64)) and got["counts"].min() > 0     # the same frames were drawn
+    assert relerr(got["mean"], m_o) < 1e-12
+    assert np.array_equal(got["cov"], np.tile(gcov, (C, 1))) and np.array_equal(got["w"], np.full(C, 1.0 / C))
+    if select != 50.0:
+        with pytest.raises(h.HostError, match="does not terminate"):
+            h.mixture_init(x, seg_begin, seg_len, C, gcov, nb_frame_to_select=400.0)
+    if select == 50.0:
+        tw = h.train_world(x, seg_begin, seg_len, got["w"], got["mean"], got["cov"], nb_it=3, init_floor=0.5, final_floor=0.05, init_ceil=5.0,
+                           final_ceil=10.0)
+        ref = oracle_train_world(x, np.array(seg_begin), np.array(seg_len), np.full(C, 1.0 / C), m_o, np.tile(gcov, (C, 1)), 3, 1.0, 0.5, 0.05,
+                                 5.0, 10.0)
+        assert np.max(np.abs(tw["llk"] - ref["llk"])) < 1e-9 and np.all(np.diff(tw["llk"]) > 0)   # EM from scratch: llk rises
+        assert relerr(tw["mean"], ref["mean"]) < 1e-8 and relerr(tw["cov"], ref["cov"]) < 1e-8
+
+
+def test_mixture_init_single_stream_form():
+    """The single-stream mixtureInit (TrainTools.cpp:619-672): one plain baggedSegments pass per component, seed (c + 1)(it + 1),
+    p = baggedFrameProbabilityInit / distribCount -- against the same selection assembled from oracle pieces."""
+    from lia_ral_amd import host_capi as h
+    C, D, T = 6, 8, 4000
+    w, mean, iv = make_gmm(C, D, seed=4)
+    x = make_frames(w, mean, iv, T, seed=5)
+    seg_begin, seg_len = [10, 2100], [1900, 1800]
+    gcov = np.full(D, 1.5)
+    for pinit, nb_it in ((0.3, 1), (7.5, 2)):          # 7.5 / 6 > 1: two bagging passes of p = 0.625
+        got = h.mixture_init(x, seg_begin, seg_len, C, gcov, single_stream_proba=pinit)
+        p = pinit / C
+        if p > 1:
+            assert nb_it == int(p) + 1
+            p /= nb_it
+        for c in range(C):
+            fr = []
+            for it in range(nb_it):
+                bb, bl, _ = orc.bagged_segments((c + 1) * (it + 1), seg_begin, seg_len, p, 3, 7)
+                fr += [np.arange(b, b + n) for b, n in zip(bb, bl)]
+            fr = np.concatenate(fr)
+            assert got["counts"][c] == len(fr)
+            assert relerr(got["mean"][c], x[fr].astype(np.float64).mean(0)) < 1e-12
+
+
+def test_tv_verify_emlk_and_speaker_models():
+    """TVAcc::getMplusTW / getSpeakerModel / getLLK / verifyEMLK (AccumulateTVStat.cpp:964-971, 1533-1545, 1626-1688): the
+    supervector m + T^T w of each file's statistics row, the mean log-likelihood of the file under the UBM with those means, the
+    total over the first `computeLLK` files."""
+    from lia_ral_amd import host_capi as h
+    C, D, R, U = 8, 12, 5, 3
+    w, mean, iv = make_gmm(C, D, seed=11)
+    rng = np.random.default_rng(12)
+    Tm = rng.normal(0, 0.3, (R, C * D)); W = rng.normal(size=(U, R))
+    x = make_frames(w, mean, iv, 1700, seed=13)
+    file_begin = [0, 400, 900, 1000, 1700]; rows = [0, 1, 1, 2]      # two files on statistics row 1
+    llk, total, sv = h.tv_verify_emlk(x, file_begin, rows, (w, mean, 1.0 / iv), Tm, W)
+    sv_ref = mean.ravel()[None, :] + W[rows] @ Tm
+    assert relerr(sv, sv_ref) < 1e-13
+    ref = []
+    for f in range(4):
+        gm = orc.Gmm(w, sv_ref[f].reshape(C, D), iv)
+        ref.append(orc.llk(gm, x[file_begin[f]:file_begin[f + 1]].astype(np.float64)).mean())
+    assert np.max(np.abs(llk - np.array(ref))) < 1e-9 and abs(total - sum(ref)) < 1e-8
+    llk2, total2, _ = h.tv_verify_emlk(x, file_begin, rows, (w, mean, 1.0 / iv), Tm, W, max_llk_computed=2)   # config "computeLLK 2"
+    assert len(llk2) == 2 and abs(total2 - sum(ref[:2])) < 1e-8

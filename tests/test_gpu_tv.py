@@ -405,3 +405,50 @@ def test_tv_estep_batching_does_not_change_the_statistics(ctx):
         outs.append(g)
     ctx.set_option("tv_batch", prev_b)
     assert relerr(outs[0]["A"], outs[1]["A"]) < 1e-12 and np.array_equal(outs[0]["W"], outs[1]["W"])
+
+
+def test_options_are_state_of_the_context_not_of_the_thread():
+    """gmmiv_ctx_set_option: the kernel-launcher options ("z_waves", "z_depth_*", "z_tv4", "chol_lds", "chol_gemm", "gemm_*")
+    live in the context.  Two contexts on ONE thread keep different settings and each call runs with its own context's set; one
+    context driven from a SECOND thread shows that thread the same settings."""
+    import threading
+    import torch
+    from lia_ral_amd import capi
+    a = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    b = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    assert a.set_option("z_waves", 4) == 8 and b.set_option("z_waves", 16) == 8         # b did not see a's 4
+    assert a.set_option("chol_gemm", 1) == 0 and b.set_option("chol_gemm", 0) == 0
+    assert a.set_option("gemm_narrow", 0) == 1 and b.set_option("gemm_narrow", 1) == 1
+    assert a.set_option("z_depth_tv", 2) == 4 and b.set_option("z_depth_tv", 4) == 4
+    C, D, R, U = 8, 12, 12, 9
+    rng = np.random.default_rng(5)
+    N = rng.gamma(0.8, 3.0, (U, C)); F = rng.normal(size=(U, C * D)); Tm = rng.normal(0, 0.1, (R, C * D)); iv = rng.uniform(0.5, 2, C * D)
+    Wo = orc.tv_estimate_w(N, F, Tm, iv, orc.tv_tett(Tm, iv, C, D))
+
+    def run(ctx):
+        return ctx.tv_estimate_w(N, F, Tm, iv, ctx.tv_tett(Tm, iv, C, D), C, D)
+    Wa = run(a)
+    assert a.set_option("kopts_bound", 0) == 1 and b.set_option("kopts_bound", 0) == 0  # a's call bound a's set to this thread
+    Wb = run(b)
+    assert a.set_option("kopts_bound", 0) == 0 and b.set_option("kopts_bound", 0) == 1
+    assert relerr(Wa, Wo) < 1e-9 and relerr(Wb, Wo) < 1e-9                               # GEMM-built and fused factorisations
+    w, mean, ivm = make_gmm(32, 20, seed=2)
+    x = make_frames(w, mean, ivm, 700, seed=3)
+    ga, gb = a.gmm(w, mean, ivm), b.gmm(w, mean, ivm)
+    Na, Fa = ga.tv_stats(x, [0, 300, 700]); Nb, Fb = gb.tv_stats(x, [0, 300, 700])      # k_stats_z <4 waves> and <16 waves>
+    assert np.array_equal(Na, Nb) and np.array_equal(Fa, Fb)                              # the shapes are bit-identical by construction
+    seen = {}
+
+    def other_thread():
+        seen["bound_before"] = (a.set_option("kopts_bound", 0), b.set_option("kopts_bound", 0))
+        seen["a"] = (a.set_option("z_waves", 4), a.set_option("chol_gemm", 1), a.set_option("gemm_narrow", 0), a.set_option("z_depth_tv", 2))
+        seen["b"] = (b.set_option("z_waves", 16), b.set_option("chol_gemm", 0), b.set_option("gemm_narrow", 1), b.set_option("z_depth_tv", 4))
+        seen["W"] = run(a)
+        seen["bound_after"] = (a.set_option("kopts_bound", 0), b.set_option("kopts_bound", 0))
+    th = threading.Thread(target=other_thread)
+    th.start(); th.join()
+    assert seen["bound_before"] == (0, 0) and seen["bound_after"] == (1, 0)
+    assert seen["a"] == (4, 1, 0, 2) and seen["b"] == (16, 0, 1, 4)                       # the settings followed the contexts
+    assert np.array_equal(seen["W"], Wa)                                                  # same context, other thread: same launches
+    assert a.set_option("no_such_option", 1) == -1
+    ga.close(); gb.close(); a.close(); b.close()

@@ -2,6 +2,7 @@
 C oracle for them is cross-checked here against an independent numpy restatement of the same
 formulas, so that a slip in the oracle cannot silently become the GPU's target."""
 import numpy as np
+import pytest
 
 from conftest import make_frames, make_gmm
 from oracle import oracle as orc
@@ -269,3 +270,40 @@ def test_init_t_box_muller_chain_matches_numpy_restatement():
                 break
         ref[e] = y * iv.sum() * 0.001
     assert np.allclose(got.ravel(), ref, rtol=1e-13, atol=0)
+
+
+def test_mixture_init_against_a_python_walk_with_glibc_rand():
+    """orc.mixture_init (TrainTools.cpp:674-766 + GeneralTools.cpp:330-390) against a straight Python walk that calls glibc's
+    srand / rand through ctypes: chunk-major, component-minor draws; seed (stream + 1) * 100 + it + 1; p folded into several
+    passes when it exceeds one."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.rand.restype = ctypes.c_int
+    RAND_MAX = 2147483647
+    rng = np.random.default_rng(1)
+    for T, segs, select in ((900, [(0, 400), (450, 450)], 30.0), (120, [(5, 100)], 700.0)):   # p = 7: three passes of 6 / 7
+        C, D = 5, 3
+        x = rng.normal(size=(T, D))
+        sb = [b for b, _ in segs]; sl = [n for _, n in segs]
+        mean, cnt = orc.mixture_init(C, x, sb, sl, nb_frame_to_select=select)
+        total = sum(sl)
+        proba = select / total
+        nb_it, tmp = 1, proba
+        while tmp > 1:
+            nb_it += 1
+            tmp /= proba / nb_it
+        proba = tmp
+        s = np.zeros((C, D)); n = np.zeros(C)
+        for it in range(nb_it):
+            libc.srand(100 + it + 1)
+            for b, ln in segs:
+                while ln > 0:
+                    length = min(ln, min(max(ln, 3), 7))
+                    for c in range(C):
+                        if libc.rand() / RAND_MAX < proba:
+                            s[c] += x[b:b + length].sum(0); n[c] += length
+                    b += length; ln -= length
+        assert np.array_equal(n, cnt) and n.min() > 0
+        assert np.allclose(mean, s / n[:, None], rtol=1e-13, atol=1e-13)
+    with pytest.raises(ValueError, match="does not terminate"):     # 1 < p < 4.9: the reference's fold loop never ends
+        orc.mixture_init(5, rng.normal(size=(120, 3)), [5], [100], nb_frame_to_select=160.0)
