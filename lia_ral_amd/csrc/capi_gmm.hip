@@ -119,7 +119,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "gemm_narrow")) ks = &c->ko.gemm_narrow; // A/B knob: 0 = 128 x 128 tiles on the strips cut by M / N too
     else if (!strcmp(key, "chol_lds")) ks = &c->ko.chol_lds;       // 0 = panel rows from memory per wave
     else if (!strcmp(key, "chol_gemm")) ks = &c->ko.chol_gemm;     // the GEMM-built batched Cholesky instead of k_chol_left
-    else if (!strcmp(key, "chol_panel")) ks = &c->ko.chol_panel;   // panel width of chol_fused.hip (0 = default, 32, 64)
+    else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
     if (!strcmp(key, "kopts_bound")) return &gmmiv_kopts_cur() == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?
     if (!slot) return -1;

@@ -33,6 +33,25 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CHOL_ABL 0
 #endif
 
+// CHOL_PROF (compile-time, tools/chol_probe.sh): waves 0 and 1 of workgroup 0 leave s_memtime stamps at the phase boundaries of
+// every panel in a device array the probe prints (kernel 0 = k_chol_left, 1 = k_trinv_left, 2 = k_uut; [kernel][wave][panel][16])
+#ifndef CHOL_PROF
+#define CHOL_PROF 0
+#endif
+long long *g_chol_prof = nullptr; // device address of the stamp array once a -DCHOL_PROF build has launched a kernel
+#if CHOL_PROF
+__device__ long long g_chol_prof_dev[3 * 2 * 32 * 16];
+#define PROF_INIT(kid, wv, ln) long long *prof_ = (blockIdx.x == 0 && (wv) < 2 && (ln) == 0) ? g_chol_prof_dev + ((kid) * 2 + (wv)) * 32 * 16 : nullptr; int prof_i_ = 0
+#define PROF_PANEL(p) do { if (prof_) { prof_ = prof_ - (prof_ - g_chol_prof_dev) % (32 * 16) + ((p) & 31) * 16; prof_i_ = 0; } } while (0)
+#define STAMP() do { if (prof_ && prof_i_ < 16) prof_[prof_i_++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+static void prof_host_init() { if (!g_chol_prof) { void *p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_chol_prof_dev)) == hipSuccess) { g_chol_prof = (long long *)p; (void)hipMemset(p, 0, sizeof(long long) * 3 * 2 * 32 * 16); } } }
+#else
+#define PROF_INIT(kid, wv, ln) do { } while (0)
+#define PROF_PANEL(p) do { } while (0)
+#define STAMP() do { } while (0)
+static void prof_host_init() {}
+#endif
+
 // A/B switch of the calling host thread: 0 = every wave fetches the panel rows itself (the round-1 kernels)
 #define g_chol_lds (gmmiv_kopts_cur().chol_lds) // option of the calling context (ctx.h: gmmiv_kopts)
 
@@ -137,15 +156,40 @@ __device__ __forceinline__ void rowdot_n(int cnt, const double *pa0, const doubl
 // n = 400) is staged ONCE per panel by the whole workgroup; a wave then reads its A operands with 8 ds_read_b128 per chunk.
 // Row stride S (doubles) with S / 2 odd: the 16 lanes of a b128 read (16 different rows, same column) hit 16 distinct 4-bank groups.
 __device__ __forceinline__ int pan_stride(int n) { return (n & 2) ? n : n + 2; }   // n even: S / 2 odd
-// rows row0 .. row0 + 31 (clamped to n - 1), columns [kbase, kbase + klen) of the row-major matrix X -> pan[row][0 .. klen)
+// rows row0 .. row0 + 31 (clamped to n - 1), columns [kbase, kbase + klen) of the row-major matrix X -> pan[row][0 .. klen).
+// Thread t serves row t >> 4 and the 16-byte segments (t & 15) + 16 i of it (16 threads = 256 contiguous bytes per step).  The
+// loads of a batch are ALL issued before the first LDS store: written as "load, store, next" hipcc waits vmcnt(0) in every trip
+// -- one full L2 / MALL latency per 16-byte segment and thread, up to 13 in a row at n = 400, 10 us per panel: that loop, not
+// the barriers, was the 37 % of k_chol_left that remained with all arithmetic compiled out (round 2's ablation).  Loads past
+// the row's end are clamped to its last segment (never stored).
+template <int NB>
+__device__ __forceinline__ void stage_batch(double *prow, const double *xrow, int segs, int s0)
+{
+    d2 v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        int sg = s0 + 16 * u;
+        sg = sg < segs ? sg : segs - 1;
+        v[u] = *(const d2 *)(xrow + 2 * sg);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+        if (s0 + 16 * u < segs) *(d2 *)(prow + 2 * (s0 + 16 * u)) = v[u];
+}
 __device__ __forceinline__ void stage_panel(double *pan, int S, const double *X, long n, long row0, int kbase, int klen, int tid)
 {
     const int segs = klen >> 1; // 16-byte segments per row
-    for (int e = tid; e < 32 * segs; e += 512) {
-        const int row = e / segs, seg = e - row * segs;
-        long r = row0 + row;
-        r = r < n ? r : n - 1;
-        *(d2 *)(pan + row * S + 2 * seg) = *(const d2 *)(X + r * n + kbase + 2 * seg);
+    if (segs <= 0) return;
+    const int row = tid >> 4;
+    long r = row0 + row;
+    r = r < n ? r : n - 1;
+    const double *xrow = X + r * n + kbase;
+    double *prow = pan + row * S;
+    int s0 = tid & 15;
+    for (; s0 + 16 * 7 < segs; s0 += 16 * 8) stage_batch<8>(prow, xrow, segs, s0);   // full batches of 8 segments per thread
+    if (s0 < segs) {
+        if (s0 + 16 * 3 < segs) stage_batch<8>(prow, xrow, segs, s0);
+        else stage_batch<4>(prow, xrow, segs, s0);
     }
 }
 template <int CNT> struct TileOps { d2 b[CNT][4]; };
@@ -311,8 +355,11 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
     const int slot = wave == 0 ? 7 : (wave == 4 ? 6 : (wave < 4 ? wave - 1 : wave - 2));
     int bad = 0;
     d4 acc[TW][2];
+    PROF_INIT(0, wave, lane0);
 
     for (int j0 = 0; j0 < n_; j0 += 32) {
+        PROF_PANEL(j0 >> 5);
+        STAMP(); // 0: panel start
         // lane-derived indices are recomputed per panel: laundered, so that the compiler does not hoist every address
         // expression of the panel body out of the loop and keep (spill) it for the whole kernel
         int lane = lane0;
@@ -379,7 +426,9 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                         slab[wave][i][k] = (i < w && k < w) ? acc[u][ct][r] : (i == k ? unit : 0.0);
                     }
         }
+        STAMP(); // 1: diagonal update done, partial written
         __syncthreads(); // the 8 partial updates are in LDS
+        STAMP(); // 2
         // step 2, wave 0: row i = lane & 31 of the block in registers, factor, invert
         const int li = lane & 31;
         if (use_lds && wave == 0) { // the summed block moves to pj: the slab memory is about to become the panel buffer
@@ -402,11 +451,13 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 for (int k = 0; k < 32; ++k) pj[li][k] = a[k];
             }
         }
+        STAMP(); // 3: (wave 0) slabs summed into pj
         if (use_lds && j0 > 0) {
             __syncthreads(); // wave 0 has taken the block: the slab memory is free
             stage_panel(pan, S, Lm, n, j0, 0, j0, tid);
             __syncthreads(); // the panel rows are in LDS for everybody (wave 0 included: it takes its tiles last)
         }
+        STAMP(); // 4: panel staged
         if (wave == 0) {
             double a[32];
             if (use_lds) {
@@ -484,6 +535,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
             __builtin_amdgcn_s_setprio(0);
         }
 
+        STAMP(); // 5: (wave 0) block factored and inverted
         // ---------------- off-diagonal tiles, TW per wave and group ----------------
         for (int g = 0; g < ngroups; ++g) {
             int cnt = mine - TW * g;
@@ -498,12 +550,14 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 pb[u] = Lm + r * n + 8 * q;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    if (u < cnt) acc[u][ct] = chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
+                    if (u < cnt) acc[u][ct] = (CHOL_ABL & 64) ? d4{0.0, 0.0, 0.0, 0.0} : chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
                 }
             }
             if (!(CHOL_ABL & 4)) rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
             if (g == 0) {
+                STAMP(); // 6: k-loops of the first tile group done
                 __syncthreads(); // inv(L_jj) and L_jj are in LDS
+                STAMP(); // 7
                 chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
             }
             if (cnt > 0 && !(CHOL_ABL & 2)) {
@@ -530,8 +584,235 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
             __syncthreads();
             chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
         }
+        STAMP(); // 8: all tile groups solved and stored (issued)
         if (CHOL_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads(); // the panel is in memory (and pj / linv are free) before the next one reads it
+        STAMP(); // 9: panel end
+    }
+    if (wave == 0 && lane0 == 0 && bad) status[blockIdx.x] = 1;
+}
+
+// ---- round 3: the same factorisation with the panel staged FIRST ------------------------------------------------------------
+// Time stamps of one workgroup (tools/chol_probe.hip, s_memtime, uncontended: 276 us per system of order 400, 13 panels) showed
+// wave 0 alone on the critical path: 21 % of it in the diagonal block's update (its operands were panel rows fetched from L2
+// right after the barrier that publishes them: one exposed memory round trip per panel), 7 % in wave 0 summing the eight partial
+// blocks by itself, 36 % in the factor / invert sweep, 18 % in wave 0's own off-diagonal tiles that it starts only after the sweep
+// while the other seven waves wait at the barrier.  Here:
+//   1. the panel rows L[j0 .. j0+31][0 .. j0) are staged into LDS first (they are needed there anyway);
+//   2. the diagonal update D = A_jj - P P^T runs from LDS on all eight waves: 4 output tiles x 2 k-halves, no global operand,
+//      two partial blocks instead of eight (the half with k < j0 / 2 starts from the source block, whose loads were issued
+//      before the staging);
+//   3. wave 0 adds the two partials while it loads its row for the sweep (64 LDS reads instead of 256 + a barrier);
+//   4. wave 0 owns no off-diagonal tile while another wave has fewer than two: the sweep is the longest serial piece of a panel.
+// One workgroup barrier less per panel.  Results are bitwise those of k_chol_left<true> up to the summation order of the diagonal
+// update (two k-halves instead of eight k-ranges).
+__device__ __forceinline__ void diag_from_lds(const double *la, const double *lb, int kb, int ke, d4 &acc)
+{
+    for (int k = kb; k < ke; k += 32) {
+        d2 a[4], b[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            a[v] = *(const d2 *)(la + k + 2 * v);
+            b[v] = *(const d2 *)(lb + k + 2 * v);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = MFMA_F64(-a[e >> 1][e & 1], b[e >> 1][e & 1], acc);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
+                                                       long spk, double diag_add)
+{
+    __shared__ __attribute__((aligned(16))) double pj[32][34];
+    __shared__ __attribute__((aligned(16))) double linv[32][34];
+    __shared__ __attribute__((aligned(16))) double col[2][32];
+    __shared__ __attribute__((aligned(16))) double part[2][32][34]; // the two k-halves of the diagonal block's update
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[]; // the panel rows L[j0 .. j0 + 31][0 .. j0)
+    double *pan = dyn_lds;
+    const int S = pan_stride(n_);
+    const long n = n_;
+    double *Lm = Afull + (size_t)blockIdx.x * n * n;
+    const double *Apk = Apacked ? Apacked + (size_t)blockIdx.x * spk : nullptr;
+    double *iv = invd + (size_t)blockIdx.x * sinv;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    int bad = 0;
+    d4 acc[TW][2];
+    PROF_INIT(0, wave, lane0);
+
+    for (int j0 = 0; j0 < n_; j0 += 32) {
+        PROF_PANEL(j0 >> 5);
+        STAMP(); // 0: panel start
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int i16 = lane & 15, q = lane >> 4, perm = 4 * (i16 & 3) + (i16 >> 2);
+        const int w = (n_ - j0) < 32 ? (n_ - j0) : 32;
+        const int below = n_ - j0 - 32;
+        const int nt = below > 0 ? (below + 15) / 16 : 0;
+        // tile owners: waves 1 2 3 5 6 7 4 take a tile each in turn; wave 0 (the sweep) joins only from the third round on
+        int mine;
+        {
+            const int s7 = wave == 4 ? 6 : (wave < 4 ? wave - 1 : wave - 2); // slot among the seven workers (wave 0: -1)
+            const int first = nt < 14 ? nt : 14;                              // the first two rounds go to the workers alone
+            const int rest = nt - first;                                      // then all eight waves, wave 0 last
+            const int slot8 = wave == 0 ? 7 : s7;
+            mine = (wave == 0 ? 0 : (first > s7 ? (first - s7 + 6) / 7 : 0)) + (rest > slot8 ? (rest - slot8 + 7) / 8 : 0);
+        }
+        const int maxmine = nt <= 14 ? (nt + 6) / 7 : 2 + (nt - 14 + 7) / 8;
+        const int ngroups = (maxmine + TW - 1) / TW; // uniform over the workgroup
+        // tile index of this wave's m-th tile
+        auto tile_of = [&](int m) -> int {
+            const int s7 = wave == 4 ? 6 : (wave < 4 ? wave - 1 : wave - 2);
+            if (wave != 0 && m < 2) { const int t = s7 + 7 * m; if (t < (nt < 14 ? nt : 14)) return t; }
+            const int mm = wave == 0 ? m : m - ((nt < 14 ? nt : 14) > s7 ? (((nt < 14 ? nt : 14) - s7 + 6) / 7) : 0);
+            return 14 + (wave == 0 ? 7 : s7) + 8 * mm;
+        };
+
+        // ---- the source of the diagonal block (half 0 of each of the four output tiles), requested before the staging ----
+        const int du = wave & 1, dct = (wave >> 1) & 1, dh = wave >> 2; // this wave's tile (rows 16 du.., columns 16 dct..) and k-half
+        d4 dacc = d4{0.0, 0.0, 0.0, 0.0};
+        if (dh == 0) {
+            long r = j0 + 16 * du + i16;
+            r = r < n ? r : n - 1;
+            if (w == 32) dacc = chol_src4(Lm, Apk, n, r, j0 + 16 * dct + 4 * q, diag_add);
+            else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = 16 * du + i16, k = 16 * dct + 4 * q + rr;
+                    double v = 0.0;
+                    if (i < w && k < w) {
+                        if (!Apk) v = Lm[(long)(j0 + i) * n + j0 + k];
+                        else if (k <= i) v = Apk[(long)(j0 + i) * (j0 + i + 1) / 2 + j0 + k] + (k == i ? diag_add : 0.0);
+                    }
+                    dacc[rr] = v;
+                }
+            }
+        }
+        // ---- 1. panel rows -> LDS ----
+        if (j0 > 0) stage_panel(pan, S, Lm, n, j0, 0, j0, tid);
+        __syncthreads();
+        STAMP(); // 1: staged
+        // ---- 2. diagonal update from LDS: tile (du, dct), k-half dh ----
+        {
+            const int half = ((j0 >> 5) >> 1) << 5; // whole 32-chunks
+            const int kb = dh == 0 ? 0 : half, ke = dh == 0 ? half : j0;
+            if (!(CHOL_ABL & 8)) diag_from_lds(pan + (16 * dct + perm) * S + 8 * q, pan + (16 * du + i16) * S + 8 * q, kb, ke, dacc);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * du + i16, k = 16 * dct + 4 * q + rr;
+                part[dh][i][k] = (i < w && k < w) ? dacc[rr] : ((i == k && dh == 0) ? 1.0 : 0.0);
+            }
+        }
+        __syncthreads();
+        STAMP(); // 2: the two partial blocks are in LDS
+        // ---- 3. wave 0: factor + invert; the others: off-diagonal tiles ----
+        const int li = lane & 31;
+        if (wave == 0) {
+            double a[32];
+#pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const d2 x = *(const d2 *)&part[0][li][k], y = *(const d2 *)&part[1][li][k];
+                a[k] = x[0] + y[0];
+                a[k + 1] = x[1] + y[1];
+            }
+            __builtin_amdgcn_s_setprio(3);
+            // the sweep of k_chol_left, unchanged.  (Tried: 1 / sqrt(pivot) computed one step ahead by the lane that holds the next
+            // pivot and published through LDS, so that the dozen dependent fp64 instructions run under the step's 30 independent
+            // FMAs -- hipcc keeps the chain in front of them anyway and the extra LDS hop made the sweep 25 % slower; reverted.)
+            const bool lo = lane < 32;
+            double v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = lo ? a[k] : 0.0;
+            if (lo) col[0][li] = v[0];
+#pragma unroll
+            for (int j = 0; j < ((CHOL_ABL & 1) ? 1 : 32); ++j) {
+                const double *cj = col[j & 1];
+                wave_sync();
+                double c[32];
+#pragma unroll
+                for (int k = j; k < 32; ++k) c[k] = cj[k];
+                double dj = c[j];
+                if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
+                double rs = __builtin_amdgcn_rsq(dj);
+                const double hd = 0.5 * dj;
+                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
+                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
+                double sq = dj * rs;
+                sq = __builtin_fma(__builtin_fma(-sq, sq, dj), 0.5 * rs, sq);
+                rs = __builtin_fma(__builtin_fma(-sq, rs, 1.0), rs, rs);
+                const double y = v[j] * rs;
+                const double xj = (j == li) ? rs : (j > li ? -y : 0.0);
+                const double coef = (lo ? -y : xj) * rs;
+                if (j + 1 < 32) {
+                    v[j + 1] = __builtin_fma(coef, c[j + 1], v[j + 1]);
+                    PIN_V(v[j + 1]);
+                    if (lo) col[(j + 1) & 1][li] = v[j + 1];
+                }
+                if (lo) pj[li][j] = (li == j) ? sq : (li > j ? y : 0.0);
+                else linv[j][li] = xj;
+#pragma unroll
+                for (int k = j + 2; k < 32; ++k) {
+                    v[k] = __builtin_fma(coef, c[k], v[k]);
+                    PIN_V(v[k]);
+                }
+            }
+            wave_sync();
+            __builtin_amdgcn_s_setprio(0);
+        }
+        STAMP(); // 3: (wave 0) block factored and inverted
+        long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
+        ra0 = ra0 < n ? ra0 : n - 1;
+        ra1 = ra1 < n ? ra1 : n - 1;
+        const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
+        for (int g = 0; g < ngroups; ++g) {
+            int cnt = mine - TW * g;
+            cnt = cnt < 0 ? 0 : (cnt > TW ? TW : cnt);
+            const double *pb[TW];
+            long rows[TW];
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                const int t = u < cnt ? tile_of(TW * g + u) : 0;
+                long r = j0 + 32 + 16L * t + i16;
+                rows[u] = u < cnt ? r : n;
+                r = r < n ? r : n - 1;
+                pb[u] = Lm + r * n + 8 * q;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    if (u < cnt) acc[u][ct] = (CHOL_ABL & 64) ? d4{0.0, 0.0, 0.0, 0.0} : chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
+                }
+            }
+            if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
+            if (g == 0) {
+                STAMP(); // 4: k-loops of the first tile group done
+                __syncthreads(); // inv(L_jj) and L_jj are in LDS
+                STAMP(); // 5
+                chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
+            }
+            if (cnt > 0 && !(CHOL_ABL & 2)) {
+                LinvOps lo;
+                linv_ops_load(lo, linv, perm, q);
+#pragma unroll
+                for (int u = 0; u < TW; ++u) {
+                    if (u < cnt) {
+                        d4 x0, x1;
+                        tile_trsm(lo, acc[u], x0, x1);
+                        if (rows[u] < n) {
+                            double *p = Lm + rows[u] * n + j0 + 4 * q;
+                            *(d2 *)p = d2{x0[0], x0[1]};
+                            *(d2 *)(p + 2) = d2{x0[2], x0[3]};
+                            *(d2 *)(p + 16) = d2{x1[0], x1[1]};
+                            *(d2 *)(p + 18) = d2{x1[2], x1[3]};
+                        }
+                    }
+                }
+            }
+        }
+        if (ngroups == 0) {
+            __syncthreads();
+            chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
+        }
+        STAMP(); // 6: all tile groups solved and stored (issued)
+        __syncthreads(); // the panel is in memory (and pj / linv / part / pan are free) before the next one reads it
+        STAMP(); // 7: panel end
     }
     if (wave == 0 && lane0 == 0 && bad) status[blockIdx.x] = 1;
 }
@@ -650,7 +931,10 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
     const int perm = 4 * (i16 & 3) + (i16 >> 2);
     const int nfl = n_ & ~31;
     d4 acc[TW][2];
+    PROF_INIT(2, wave, lane);
     for (int j0 = 0; j0 < n_; j0 += 32) {
+        PROF_PANEL(j0 >> 5);
+        STAMP(); // 0
         const int nt = (n_ - j0 + 15) >> 4; // row tiles from the diagonal block down
         const int mine = nt > wave ? (nt - wave + 7) / 8 : 0;
         long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
@@ -662,6 +946,7 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
             if (nfl > j0) stage_panel(pan, S, Um, n, j0, j0, nfl - j0, tid);
             __syncthreads();
         }
+        STAMP(); // 1: staged
         for (int g = 0; TW * g < mine; ++g) {
             int cnt = mine - TW * g;
             cnt = cnt > TW ? TW : cnt;
@@ -693,6 +978,7 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
                 default: break;
                 }
             }
+            STAMP(); // k-loops of a group done
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
                 if (u < cnt && rows[u] < n && Pk) {
@@ -718,6 +1004,7 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
                     }
                 }
             }
+            STAMP(); // stores of a group issued
         }
     }
 }
@@ -839,7 +1126,7 @@ CholLds chol_lds(int n)
 {
     const size_t pan = (size_t)32 * ((n & 2) ? n : n + 2) * sizeof(double), slab = (size_t)8 * 32 * 33 * sizeof(double);
     CholLds r;
-    r.use = g_chol_lds && pan + 20 * 1024 <= 160 * 1024 ? 1 : 0;
+    r.use = g_chol_lds && pan + 36 * 1024 <= 160 * 1024 ? 1 : 0; // static LDS of k_chol_left2: pj, linv, col, part = 35 KB
     r.chol = r.use && pan > slab ? pan : slab;
     r.trinv = r.use ? pan : 16;
     r.uut = r.use ? pan : 16;
@@ -856,11 +1143,19 @@ template <typename K> int chol_attr(K kernel, size_t lds, std::atomic<size_t> (&
     }
     return 0;
 }
-std::atomic<size_t> g_attr_chol[2][16], g_attr_trinv[2][16], g_attr_uut[2][16];
+std::atomic<size_t> g_attr_chol[3][16], g_attr_trinv[2][16], g_attr_uut[2][16];
 int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked, long spk, double diag_add)
 {
+    prof_host_init();
     const CholLds l = chol_lds(n);
     const long sinv = (long)((n + 31) / 32) * 1024;
+    if (l.use && gmmiv_kopts_cur().chol_flow) { // round 3: panel staged first, diagonal update from LDS (k_chol_left2)
+        const size_t pan = (size_t)32 * ((n & 2) ? n : n + 2) * sizeof(double);
+        int rc2 = chol_attr(k_chol_left2, pan, g_attr_chol[2]);
+        if (rc2) return rc2;
+        k_chol_left2<<<nb, 512, pan, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
+        return (int)hipGetLastError();
+    }
     int rc = l.use ? chol_attr(k_chol_left<true>, l.chol, g_attr_chol[1]) : chol_attr(k_chol_left<false>, l.chol, g_attr_chol[0]);
     if (rc) return rc;
     if (l.use) k_chol_left<true><<<nb, 512, l.chol, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
@@ -893,6 +1188,17 @@ int tvk_chol_left_batched(hipStream_t st, int n, int nb, double *Afull, double *
 {
     if (nb <= 0 || n <= 0) return 0;
     return launch_chol(st, n, nb, Afull, invd, status, Apacked, spk, diag_add);
+}
+// the other two steps on their own (tools/chol_probe.hip times them one by one)
+int tvk_trinv_left_batched(hipStream_t st, int n, int nb, const double *Lf, const double *invd, double *U)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    return launch_trinv(st, n, nb, Lf, invd, U);
+}
+int tvk_uut_packed_batched(hipStream_t st, int n, int nb, const double *U, const double *w, double *P, long sp)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    return launch_uut(st, n, nb, U, nullptr, w, P, sp);
 }
 
 // inv[b] = A[b]^-1 through the three one-workgroup-per-matrix kernels; U: scratch nb*n*n (only its upper triangle is used).

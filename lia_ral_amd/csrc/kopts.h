@@ -14,7 +14,7 @@ struct gmmiv_kopts {
     int gemm_narrow = 1;  // 0 = 128 x 128 tiles on the strips cut by M / N too
     int chol_lds = 1;     // chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself
     int chol_gemm = 0;    // 1 = the GEMM-built right-looking factorisation for every order
-    int chol_panel = 0;   // panel width of chol_fused.hip: 0 = the default of the build
+    int chol_flow = 1;    // 1: k_chol_left2 (panel staged first, diagonal update from LDS, wave 0 last in line for tiles); 0: k_chol_left (round 2)
 };
 const gmmiv_kopts &gmmiv_kopts_cur();          // the set bound to this thread (the defaults before any call)
 void gmmiv_kopts_bind(const gmmiv_kopts *ko);  // nullptr: back to the defaults
