@@ -206,14 +206,17 @@ def make_collectives(ctx, dev, world, rank, want, transport=None):
 class GpuTvOps:
     """The per-rank compute of one TotalVariability iteration on device-resident statistics (lia_ral_amd.dist.tv_em_iteration)."""
 
-    def __init__(self, ctx, N, F, Tm, invvar, means, R, F_raw=None):
+    def __init__(self, ctx, N, F, Tm, invvar, means, R, F_raw=None, world=1):
         self.ctx, self.N, self.F, self.T, self.invvar, self.means, self.R = ctx, N, F, Tm, invvar, means, R
         self.F_raw = F_raw          # the uncentred first-order statistics (TVAcc::storeStats), or None: F is centred once and kept
         dev = N.device
         P = R * (R + 1) // 2
         z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
         self.tett_buf = torch.empty((C, P), dtype=torch.float64, device=dev)
-        self.acc = dict(A=z(C, P), Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=torch.empty((N.shape[0], R), dtype=torch.float64, device=dev))
+        Cpad = (C + world - 1) // world * world       # A lives in the reduce-scatter's send buffer (equal Gaussian blocks, zero padded)
+        A_pad = z(Cpad, P)
+        self.acc = dict(A=A_pad[:C], A_pad=A_pad, Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R),
+                        W=torch.empty((N.shape[0], R), dtype=torch.float64, device=dev))
 
     def stream_context(self):
         return torch.cuda.stream(self.ctx.torch_stream())
@@ -325,7 +328,7 @@ def max_over_ranks(dt, world, dev):
     return float(tt.item())
 
 
-def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True):
+def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False):
     """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
     then `steps` EM iterations timed, each the tool's full sequence: restore + substractM, estimateTETt, estimateAandC,
     updateTestimate (sharded), minDivergence.  Returns the JSON fields of the workload."""
@@ -347,7 +350,7 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
     F = torch.empty_like(F_raw)                               # the centred working copy, rebuilt by every iteration's recentre
     gen = torch.Generator(device=dev); gen.manual_seed(5)     # the same initial T on every rank
     Tm = 0.01 * torch.randn((R, C * D), dtype=torch.float64, device=dev, generator=gen)
-    ops = GpuTvOps(ctx, N, F, Tm, invvar, means, R, F_raw=F_raw)
+    ops = GpuTvOps(ctx, N, F, Tm, invvar, means, R, F_raw=F_raw, world=world)
     n_total = U * world
 
     def barrier():
@@ -355,13 +358,13 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
-        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll)
+        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, overlap=overlap)
     coll.take_bytes()
     phases = {"sync": torch.cuda.synchronize}
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases)
+        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases, overlap=overlap)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     nbytes = coll.take_bytes() / max(steps, 1)
@@ -380,6 +383,7 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
                    "partitioning": "utterances sharded per rank; reduce-scatter of A_packed / Cmx by Gaussian blocks, sharded "
                                    "updateTestimate, all-gather of T, all-reduce of R / r / meanW"},
         "phases_ms": ph, "collective_bytes_per_step_per_rank": nbytes, "collectives": coll.name,
+        "overlap": bool(overlap and world > 1 and getattr(coll, "supports_overlap", False)),
         "statistics_once_s": t_stats, "finite": finite,
         "roofline": {"bound": "mfma", "kernel": "E-step (k_dgemm: L, aux, A, Cmx + chol_fused)", "achieved": estep_tf, "peak": PEAK_F64_TFLOPS,
                      "unit": "TFLOP/s", "frac": estep_tf / PEAK_F64_TFLOPS, "traffic": None,
@@ -425,6 +429,9 @@ def main():
                     help="std of the synthetic UBM means (SURVEY 8(d): 2.0; smaller = overlapping Gaussians)")
     ap.add_argument("--em-fused", type=int, default=-1, help="A/B knob: 1 = single-pass cooperative EM kernel, 0 = two-kernel path")
     ap.add_argument("--wg-waves", type=int, default=0, help="A/B knob: waves per workgroup of the MFMA kernels (4 or 8)")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="T-matrix EM: 1 = the reduce-scatter of A starts inside the E-step (under the Cmx GEMM), the all-gather of T is joined "
+                         "inside minDivergence (gmmiv_*_begin / gmmiv_comm_join; bitwise the serial results)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="correctness mode: let the ranks share the visible GPU(s) (rank r on device r %% count) over the C ABI's shm transport")
     args = ap.parse_args()
@@ -489,7 +496,7 @@ def main():
     check = not args.no_cpu_baseline
     if args.workload == "tv":
         res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup,
-                          check=check, cpu=(world == 1))
+                          check=check, cpu=(world == 1), overlap=bool(args.overlap))
         if rank == 0:
             res["comm"] = comm_info
             if coll_note:
@@ -609,7 +616,7 @@ def main():
         if world > 1:          # configs[3] is natively multi-GPU: one T-matrix EM iteration on utterance-sharded statistics
             x = xs = None          # release the 2.4 GB frame block of the EM workload
             torch.cuda.empty_cache()
-            tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1, check=check, cpu=False)
+            tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1, check=check, cpu=False, overlap=bool(args.overlap))
     if rank == 0:
         if secondary:
             out["secondary"] = secondary

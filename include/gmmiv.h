@@ -90,6 +90,18 @@ const char *gmmiv_version(void);
  *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)
  *   "glds", "wg_waves", "em_chunks", "dbg": A/B switches of the measurement tools */
 long gmmiv_ctx_set_option(gmmiv_ctx *ctx, const char *key, long value);
+/* Host callbacks at the two points of a TotalVariability iteration where an exchange can start before the call that produces its
+ * payload has returned (the reference's threaded estimateAandC merges A, Cmx, R, r under one mutex AFTER all workers are done,
+ * AccumulateTVStat.cpp:1920-1937; with one rank per GPU the 1.31 GB reduce-scatter of A can run under the Cmx GEMM instead):
+ *   "tv_a_ready"    inside gmmiv_tv_estimate_a_and_c, right after the LAST `A += N^T E` GEMM has been enqueued on the context's
+ *                   stream and before `Cmx += W^T F` is (device accumulators only) -- the callback typically calls
+ *                   gmmiv_reduce_scatter_f64_begin on A;
+ *   "md_factored"   inside gmmiv_tv_min_divergence, after R has been normalised and factored and before T is read -- the
+ *                   callback joins an all-gather of T that was begun before the call (gmmiv_comm_join) and may finish T's layout.
+ * The callback runs on the calling host thread; anything it enqueues on the context's stream is ordered like the library's own
+ * work.  fn == NULL removes the hook.  Returns 0, or -1 for an unknown point. */
+typedef void (*gmmiv_hook_fn)(void *user);
+int gmmiv_ctx_set_hook(gmmiv_ctx *ctx, const char *point, gmmiv_hook_fn fn, void *user);
 /* Duration (ms, HIP events on the context's stream) of the last call's dominant kernel. */
 double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *ctx, const char **kernel_name);
 /* Same for a named kernel ("k_llk_mfma", "k_stats_z", "k_stats_mfma", ...): TOTAL over its launches
@@ -403,6 +415,16 @@ int gmmiv_reduce_scatter_f64(gmmiv_comm *comm, const double *send, double *recv,
 int gmmiv_allgather_f64(gmmiv_comm *comm, const double *send, double *recv, size_t sendcount);
 /* buf[n] on every rank <- buf of rank `root` (host or device) */
 int gmmiv_broadcast_f64(gmmiv_comm *comm, double *buf, size_t n, int root);
+/* Overlapped forms (device buffers): *_begin orders the collective behind everything enqueued on the context's stream SO FAR and
+ * runs it on the communicator's own side stream -- work enqueued on the context's stream afterwards overlaps with it;
+ * gmmiv_comm_join makes the context's stream wait for every collective begun since the last join (their results may be used
+ * from then on; the buffers must not be touched in between).  Same arithmetic as the plain calls: results are bitwise equal.
+ * All ranks must issue begins, joins and plain collectives of one communicator in the same order.  With one rank, and on the
+ * "shm" transport (whose calls block), *_begin behaves like the plain call and the join is a no-op. */
+int gmmiv_allreduce_f64_begin(gmmiv_comm *comm, double *buf, size_t n);
+int gmmiv_reduce_scatter_f64_begin(gmmiv_comm *comm, const double *send, double *recv, size_t recvcount);
+int gmmiv_allgather_f64_begin(gmmiv_comm *comm, const double *send, double *recv, size_t sendcount);
+int gmmiv_comm_join(gmmiv_comm *comm);
 
 #ifdef __cplusplus
 }

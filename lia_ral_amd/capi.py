@@ -157,6 +157,33 @@ class Context:
     def set_option(self, key, value):
         return lib.gmmiv_ctx_set_option(self._h, key.encode(), ct.c_long(value))
 
+    def set_hook(self, point, fn):
+        """gmmiv_ctx_set_hook: `fn()` is called on the host at `point` ("tv_a_ready": inside tv_estimate_a_and_c once A is
+        complete and before the Cmx GEMM is enqueued; "md_factored": inside tv_min_divergence after R is factored, before T is
+        read).  fn = None removes the hook.  Exceptions raised by fn are kept and re-raised by the next checked call."""
+        if not hasattr(self, "_hooks"):
+            self._hooks = {}
+        if fn is None:
+            self._hooks.pop(point, None)
+            rc = lib.gmmiv_ctx_set_hook(self._h, point.encode(), None, None)
+        else:
+            def tramp(_user, fn=fn):
+                try:
+                    fn()
+                except BaseException as e:      # noqa: BLE001 - a C frame is below us: park it
+                    self._hook_error = e
+            cb = _HOOK_T(tramp)
+            self._hooks[point] = cb             # keep the trampoline alive as long as it is installed
+            rc = lib.gmmiv_ctx_set_hook(self._h, point.encode(), ct.cast(cb, ct.c_void_p), None)
+        if rc != 0:
+            raise GmmivError("unknown hook point %r" % point)
+
+    def _raise_hook_error(self):
+        e = getattr(self, "_hook_error", None)
+        if e is not None:
+            self._hook_error = None
+            raise e
+
     def last_kernel_ms(self):
         name = ct.c_char_p()
         ms = lib.gmmiv_ctx_last_kernel_ms(self._h, ct.byref(name))
@@ -356,6 +383,7 @@ class Context:
         _chk(lib.gmmiv_tv_estimate_a_and_c(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(invvar),
                                            _ptr(tett), _ptr(W), _ptr(acc["A"]), _ptr(acc["Cmx"]), _ptr(acc["Rm"]),
                                            _ptr(acc["r"]), _ptr(acc["meanW"])))
+        self._raise_hook_error()
         acc["W"] = W
         return acc
 
@@ -370,6 +398,7 @@ class Context:
         R = Tm.shape[0]
         _chk(lib.gmmiv_tv_min_divergence(self._h, C, D, R, ct.c_double(n_sessions), _ptr(Rm), _ptr(r), _ptr(meanW),
                                          _ptr(means), _ptr(Tm)))
+        self._raise_hook_error()
         return means, Tm
 
     def tv_orthonormalize_t(self, Tm):
@@ -434,6 +463,8 @@ class Context:
 
 
 COMM_ID_BYTES = 128
+_HOOK_T = ct.CFUNCTYPE(None, ct.c_void_p)
+lib.gmmiv_ctx_set_hook.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_void_p, ct.c_void_p]
 
 
 class Comm:
@@ -501,6 +532,25 @@ class Comm:
         assert self._n(recv) == self.world * self._n(send)
         _chk(lib.gmmiv_allgather_f64(self._h, _ptr(send), _ptr(recv), ct.c_size_t(self._n(send))))
         return recv
+
+    # overlapped forms (device tensors): the collective runs on the communicator's side stream behind what the context's stream
+    # holds so far; join() orders the context's stream behind everything begun since the last join
+    def allreduce_begin(self, a):
+        _chk(lib.gmmiv_allreduce_f64_begin(self._h, _ptr(a), ct.c_size_t(self._n(a))))
+        return a
+
+    def reduce_scatter_begin(self, send, recv):
+        assert self._n(send) == self.world * self._n(recv)
+        _chk(lib.gmmiv_reduce_scatter_f64_begin(self._h, _ptr(send), _ptr(recv), ct.c_size_t(self._n(recv))))
+        return recv
+
+    def allgather_begin(self, send, recv):
+        assert self._n(recv) == self.world * self._n(send)
+        _chk(lib.gmmiv_allgather_f64_begin(self._h, _ptr(send), _ptr(recv), ct.c_size_t(self._n(send))))
+        return recv
+
+    def join(self):
+        _chk(lib.gmmiv_comm_join(self._h))
 
 
 def shard_range(n, rank, world):

@@ -140,6 +140,27 @@ struct gmmiv_comm {
     std::string shm_path, backend;
     void *addbuf = nullptr; // device staging of one slot (the summand of a peer)
     double timeout_s = 300.0;
+    // overlapped collectives (gmmiv_*_begin / gmmiv_comm_join): a side stream forked from / joined to the context's stream by events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool pending = false;
+    int fork_side()
+    {
+        if (!side) {
+            GCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            GCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            GCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        GCHK(hipEventRecord(ev_fork, ctx->stream));
+        GCHK(hipStreamWaitEvent(side, ev_fork, 0));
+        return GMMIV_OK;
+    }
+    int mark_side()
+    {
+        GCHK(hipEventRecord(ev_join, side));
+        pending = true;
+        return GMMIV_OK;
+    }
     int staged(size_t bytes, void **out)
     {
         if (stage_bytes < bytes) {
@@ -356,6 +377,11 @@ void gmmiv_comm_orphan(gmmiv_comm *c)
     if (c->stage) { (void)hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
     if (c->addbuf) { (void)hipFree(c->addbuf); c->addbuf = nullptr; }
     if (c->shm) { munmap((void *)c->shm, c->shm_bytes); c->shm = nullptr; }
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipStreamDestroy(c->side);
+        c->side = nullptr; c->pending = false;
+    }
     auto &v = c->ctx->comms;
     for (size_t i = 0; i < v.size(); ++i)
         if (v[i] == c) { v.erase(v.begin() + i); break; }
@@ -572,6 +598,57 @@ int gmmiv_allgather_f64(gmmiv_comm *c, const double *send, double *recv, size_t 
     }
     if (c->is_shm()) return shm_allgather(c, send, recv, sendcount);
     NCHK(c, c->api->AllGather(send, recv, sendcount, ncclFloat64, c->nc, c->ctx->stream));
+    return GMMIV_OK;
+}
+
+// ---- overlapped forms: the collective runs on the communicator's side stream, behind everything enqueued on the context's
+// stream so far; gmmiv_comm_join orders the context's stream behind it again.  One rank / shm transport: the plain call.
+int gmmiv_allreduce_f64_begin(gmmiv_comm *c, double *buf, size_t n)
+{
+    if (!c || !c->ctx || (!buf && n)) { gmmiv_set_error("allreduce_f64_begin: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
+    if (c->world == 1 || n == 0 || c->is_shm()) return gmmiv_allreduce_f64(c, buf, n);
+    if (!gmmiv_is_device_ptr(buf)) { gmmiv_set_error("allreduce_f64_begin: device buffers only"); return GMMIV_ERR_ARG; }
+    c->bytes_moved += (double)n * 8;
+    GCHK(hipSetDevice(c->ctx->device));
+    int rc = c->fork_side();
+    if (rc) return rc;
+    NCHK(c, c->api->AllReduce(buf, buf, n, ncclFloat64, ncclSum, c->nc, c->side));
+    return c->mark_side();
+}
+
+int gmmiv_reduce_scatter_f64_begin(gmmiv_comm *c, const double *send, double *recv, size_t recvcount)
+{
+    if (!c || !c->ctx || ((!send || !recv) && recvcount)) { gmmiv_set_error("reduce_scatter_f64_begin: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
+    if (c->world == 1 || recvcount == 0 || c->is_shm()) return gmmiv_reduce_scatter_f64(c, send, recv, recvcount);
+    if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("reduce_scatter_f64_begin: device buffers only"); return GMMIV_ERR_ARG; }
+    c->bytes_moved += (double)recvcount * 8 * c->world;
+    GCHK(hipSetDevice(c->ctx->device));
+    int rc = c->fork_side();
+    if (rc) return rc;
+    NCHK(c, c->api->ReduceScatter(send, recv, recvcount, ncclFloat64, ncclSum, c->nc, c->side));
+    return c->mark_side();
+}
+
+int gmmiv_allgather_f64_begin(gmmiv_comm *c, const double *send, double *recv, size_t sendcount)
+{
+    if (!c || !c->ctx || ((!send || !recv) && sendcount)) { gmmiv_set_error("allgather_f64_begin: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
+    if (c->world == 1 || sendcount == 0 || c->is_shm()) return gmmiv_allgather_f64(c, send, recv, sendcount);
+    if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("allgather_f64_begin: device buffers only"); return GMMIV_ERR_ARG; }
+    c->bytes_moved += (double)sendcount * 8 * c->world;
+    GCHK(hipSetDevice(c->ctx->device));
+    int rc = c->fork_side();
+    if (rc) return rc;
+    NCHK(c, c->api->AllGather(send, recv, sendcount, ncclFloat64, c->nc, c->side));
+    return c->mark_side();
+}
+
+int gmmiv_comm_join(gmmiv_comm *c)
+{
+    if (!c || !c->ctx) { gmmiv_set_error("comm_join: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
+    if (!c->pending) return GMMIV_OK;
+    GCHK(hipSetDevice(c->ctx->device));
+    GCHK(hipStreamWaitEvent(c->ctx->stream, c->ev_join, 0));
+    c->pending = false;
     return GMMIV_OK;
 }
 

@@ -128,6 +128,16 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     return prev;
 }
 
+int gmmiv_ctx_set_hook(gmmiv_ctx *c, const char *point, gmmiv_hook_fn fn, void *user)
+{
+    if (!c || !point) return -1;
+    gmmiv_ctx::Hook *h = !strcmp(point, "tv_a_ready") ? &c->hook_tv_a_ready : (!strcmp(point, "md_factored") ? &c->hook_md_factored : nullptr);
+    if (!h) return -1;
+    h->fn = fn;
+    h->user = fn ? user : nullptr;
+    return 0;
+}
+
 double gmmiv_ctx_last_kernel_ms(gmmiv_ctx *c, const char **name)
 {
     if (!c || c->ev_last < 0) return -1.0;

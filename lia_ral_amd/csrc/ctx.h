@@ -65,6 +65,9 @@ struct gmmiv_ctx {
     long tv_mstep_solve = 1; // updateTestimate by substitution through the Cholesky factor (k_chol_solve_multi); 0: explicit inverse + GEMM
     long tv_batch = 1024; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)
     gmmiv_kopts ko;   // "z_waves", "z_tv4", "z_depth_*", "gemm_*", "chol_*": see gmmiv_kopts above
+    // host callbacks at the two points of a T-matrix EM iteration where a collective can start early (gmmiv_ctx_set_hook)
+    struct Hook { gmmiv_hook_fn fn = nullptr; void *user = nullptr; void call() const { if (fn) fn(user); } };
+    Hook hook_tv_a_ready, hook_md_factored;
     // logit scratch budget (MiB): frames are processed in chunks that fit.  Sized for a 288 GB part --
     // fewer, larger launches (64 GiB = 3.4 M frames of a 2048-Gaussian model per chunk); never more
     // than half of the memory that is free when the scratch is first needed.

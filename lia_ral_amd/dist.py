@@ -139,6 +139,25 @@ class GmmivCollectives:
         with self._ordered(send, recv):
             return self.comm.allgather(send, recv)
 
+    # overlapped forms (include/gmmiv.h: gmmiv_*_begin / gmmiv_comm_join)
+    supports_overlap = True
+
+    def allreduce_begin(self, a):
+        with self._ordered(a):
+            return self.comm.allreduce_begin(a)
+
+    def reduce_scatter_begin(self, send, recv):
+        with self._ordered(send, recv):
+            return self.comm.reduce_scatter_begin(send, recv)
+
+    def allgather_begin(self, send, recv):
+        with self._ordered(send, recv):
+            return self.comm.allgather_begin(send, recv)
+
+    def join(self):
+        with self.comm.ctx.ordered():
+            self.comm.join()
+
     def take_bytes(self):
         return self.comm.take_bytes()
 
@@ -286,17 +305,7 @@ def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=Non
     coll.reduce_scatter(A_send, a_mine)
     coll.reduce_scatter(C_send, c_mine)
     t0 = stamp("reduce_scatter", t0)
-    cb = max(0, min(Cb, C - rank * Cb))                                       # real Gaussians of this rank's block
-    t_mine = Cmx.new_zeros((R, Cb * D))
-    if cb > 0:
-        a_in = a_mine[:cb]
-        c_in = c_mine if cb == Cb else c_mine[:, :cb * D].contiguous()
-        tb = update_t(a_in.numpy() if is_np else a_in, c_in.numpy() if is_np else c_in, cb)
-        tb = _as_tensor(tb)
-        if cb == Cb:
-            t_mine = tb.contiguous()
-        else:
-            t_mine[:, :cb * D] = tb
+    t_mine = _update_own_block(update_t, a_mine, c_mine, C, D, Cb, rank, is_np)
     t0 = stamp("update_t", t0)
     gathered = Cmx.new_empty((world, R, Cb * D))
     coll.allgather(t_mine, gathered)
@@ -305,7 +314,90 @@ def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=Non
     return Tn.numpy() if is_np else Tn
 
 
-def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, phases=None):
+def _update_own_block(update_t, a_mine, c_mine, C, D, Cb, rank, is_np):
+    """updateTestimate on the rank's own cb <= Cb real Gaussians (the rest of a padded block stays zero) -> [R x Cb D]."""
+    R = c_mine.shape[0]
+    cb = max(0, min(Cb, C - rank * Cb))
+    t_mine = c_mine.new_zeros((R, Cb * D))
+    if cb > 0:
+        a_in = a_mine[:cb]
+        c_in = c_mine if cb == Cb else c_mine[:, :cb * D].contiguous()
+        tb = _as_tensor(update_t(a_in.numpy() if is_np else a_in, c_in.numpy() if is_np else c_in, cb))
+        if cb == Cb:
+            t_mine = tb.contiguous()
+        else:
+            t_mine[:, :cb * D] = tb
+    return t_mine
+
+
+def _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, t0):
+    """E-step + sharded M-step + minDivergence of one iteration with the exchange started EARLY (option `overlap`):
+      * the reduce-scatter of A (1.31 GB at 2048 x 400) begins from the "tv_a_ready" hook of gmmiv_tv_estimate_a_and_c, i.e. as
+        soon as the last `A += N^T E` GEMM is enqueued, and runs on the communicator's side stream under `Cmx += W^T F` and the
+        batch sums (the reference merges A, Cmx, R, r under one mutex after all workers are done, AccumulateTVStat.cpp:1920-1937);
+        this needs the E-step to accumulate straight into the send buffer: ops.acc["A_pad"] ([Cb * world, P], rows >= C zero,
+        acc["A"] = its first C rows) when C does not divide -- without it the exchange starts after the E-step like the serial order;
+      * the all-gather of the T blocks begins after the rank's own solve and is joined from the "md_factored" hook of
+        gmmiv_tv_min_divergence: it runs under the normalisation and factorisation of R.
+    Same collectives on the same buffers as tv_mstep_sharded, same arithmetic: T and the means are bitwise those of the serial order."""
+    import torch
+    ctx = ops.ctx
+    acc0 = ops.acc
+    A, Cmx = acc0["A"], acc0["Cmx"]
+    R, P = Cmx.shape[0], A.shape[1]
+    Cb = block_size(C, world)
+    Cpad = Cb * world
+    A_send = A if Cpad == C else acc0.get("A_pad")
+    a_mine = A.new_empty((Cb, P)); c_mine = Cmx.new_empty((R, Cb * D))
+    begun = []
+
+    def a_ready():
+        if A_send is not None:
+            coll.reduce_scatter_begin(A_send, a_mine)
+            begun.append("A")
+    ctx.set_hook("tv_a_ready", a_ready)
+    try:
+        acc = ops.estep()
+    finally:
+        ctx.set_hook("tv_a_ready", None)
+    t0 = lap("estep", t0)
+    small = torch.cat([acc[k].reshape(-1) for k in ("Rm", "r", "meanW")])
+    if not begun:                                   # no send buffer the E-step could write into: pad now, exchange now
+        A_send = A.new_zeros((Cpad, P)); A_send[:C] = A
+        coll.reduce_scatter_begin(A_send, a_mine)
+    coll.allreduce_begin(small)
+    if Cpad != C:
+        Cp = Cmx.new_zeros((R, Cpad * D)); Cp[:, :C * D] = Cmx
+    else:
+        Cp = Cmx
+    C_send = Cp.view(R, world, Cb * D).permute(1, 0, 2).contiguous()
+    coll.reduce_scatter_begin(C_send, c_mine)
+    coll.join()
+    o = 0
+    for k in ("Rm", "r", "meanW"):
+        t = acc[k]
+        t.copy_(small[o:o + t.numel()].view_as(t)); o += t.numel()
+    t0 = lap("reduce_scatter", t0)
+    t_mine = _update_own_block(ops.update_t, a_mine, c_mine, C, D, Cb, rank, False)
+    t0 = lap("update_t", t0)
+    gathered = Cmx.new_empty((world, R, Cb * D))
+    coll.allgather_begin(t_mine, gathered)
+    Tn = Cmx.new_empty((R, C * D))
+
+    def md_factored():                              # R is factored, T is about to be read: T must have arrived
+        coll.join()
+        Tn.copy_(gathered.permute(1, 0, 2).reshape(R, Cpad * D)[:, :C * D])
+    t0 = lap("allgather", t0)
+    ctx.set_hook("md_factored", md_factored)
+    try:
+        Tn = ops.min_divergence(acc, Tn, n_sessions_total)
+    finally:
+        ctx.set_hook("md_factored", None)
+    lap("min_divergence", t0)
+    return Tn
+
+
+def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, phases=None, overlap=False):
     """One full iteration of TotalVariability's EM on utterance-sharded statistics (TotalVariability.cpp:118-169 around
     TVAcc, AccumulateTVStat.cpp): every rank holds the statistics N / F of its own utterances and the full T.
       ops.recentre()                      (optional) restore the raw first-order statistics and substractM with the CURRENT UBM
@@ -320,6 +412,8 @@ def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, pha
     ops.stream_context() (optional) returns a context manager under which the whole iteration runs -- a GPU rank returns
     `torch.cuda.stream(ctx.torch_stream())` so that the torch kernels of the re-layout (pad, permute, cat) are enqueued on the
     stream libgmmiv launches on, in program order with its kernels and collectives.
+    overlap = True (GmmivCollectives only): the reduce-scatter of A starts inside the E-step and the all-gather of T is joined
+    inside minDivergence (_tv_overlapped); bitwise the same T and means as the serial order.
     Returns the new T.  phases collects per-phase seconds ("recentre", "tett", "estep", "reduce_scatter", "update_t",
     "allgather", "min_divergence")."""
     import contextlib
@@ -340,6 +434,8 @@ def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, pha
             t0 = lap("recentre", t0)
         ops.tett()
         t0 = lap("tett", t0)
+        if overlap and world > 1 and getattr(coll, "supports_overlap", False) and hasattr(ops, "ctx") and hasattr(ops, "acc"):
+            return _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, t0)
         acc = ops.estep()
         t0 = lap("estep", t0)
         Tn = tv_mstep_sharded(acc, ops.update_t, C, D, rank, world, coll, phases)

@@ -414,9 +414,20 @@ int liagpu_tv_stats_lines(int device, const float *x, long T, int D, const long 
 // exchange is reduce-scatter(A, Cmx) / all-gather(T) / all-reduce(R, r, meanW) on device buffers (TVAcc::updateTestimate(comm)).
 // U_total = utterances over all ranks (the session count of minDivergence).  times_ms (nullable, 4 x nbIt): wall-clock of
 // estimateTETt / estimateAandC / updateTestimate (with its collectives) / minDivergence per iteration.
+int liagpu_tv_train_dist2(int device, int world, int rank, const char *id_file, long U, long U_total, int C, int D, const double *w,
+                          const double *mean, const double *cov, int R, const double *N, const double *F, double *Tmat, int nbIt,
+                          int minDiv, int overlap, double *mean_out, double *times_ms);
 int liagpu_tv_train_dist(int device, int world, int rank, const char *id_file, long U, long U_total, int C, int D, const double *w,
                          const double *mean, const double *cov, int R, const double *N, const double *F, double *Tmat, int nbIt,
                          int minDiv, double *mean_out, double *times_ms)
+{
+    return liagpu_tv_train_dist2(device, world, rank, id_file, U, U_total, C, D, w, mean, cov, R, N, F, Tmat, nbIt, minDiv, 0, mean_out, times_ms);
+}
+// the same with the exchange started early when overlap != 0 (TVAcc::setOverlap: the reduce-scatter of A from inside estimateAandC,
+// the all-gather of T joined inside minDivergence); bitwise the results of overlap == 0
+int liagpu_tv_train_dist2(int device, int world, int rank, const char *id_file, long U, long U_total, int C, int D, const double *w,
+                          const double *mean, const double *cov, int R, const double *N, const double *F, double *Tmat, int nbIt,
+                          int minDiv, int overlap, double *mean_out, double *times_ms)
 {
     GUARD({
         GpuServer srv(device);
@@ -432,6 +443,7 @@ int liagpu_tv_train_dist(int device, int world, int rank, const char *id_file, l
         tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
         tv.setStats(N, F);
         tv.storeStats();
+        if (overlap) tv.setOverlap(comm);
         auto now = [&]() { srv.check(gmmiv_ctx_sync(srv.ctx())); return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         for (int it = 0; it < nbIt; ++it) {
@@ -445,6 +457,7 @@ int liagpu_tv_train_dist(int device, int world, int rank, const char *id_file, l
             tv.updateTestimate(comm, (unsigned long)U_total);
             auto t3 = now();
             if (minDiv) tv.minDivergence();
+            else tv.finishT();
             auto t4 = now();
             if (times_ms) { times_ms[4 * it] = ms(t0, t1); times_ms[4 * it + 1] = ms(t1, t2); times_ms[4 * it + 2] = ms(t2, t3); times_ms[4 * it + 3] = ms(t3, t4); }
         }

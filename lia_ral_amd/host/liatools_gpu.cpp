@@ -720,7 +720,7 @@ TVAcc::TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned
     : _srv(srv), _ubm(ubm), _dubm(srv, ubm), _rankT(rankT), _n_speakers(nSpeakers), _n_distrib(ubm.getDistribCount()),
       _vectSize(ubm.getVectSize()), _svSize(ubm.getDistribCount() * ubm.getVectSize())
 {
-    for (DVec *v : {&_ubm_means, &_ubm_invvar, &_statN, &_statF, &_cN, &_cF, &_T, &_W, &_TETt, &_A, &_Cmx, &_R, &_r, &_meanW}) v->bind(srv);
+    for (DVec *v : {&_ubm_means, &_ubm_invvar, &_statN, &_statF, &_cN, &_cF, &_T, &_W, &_TETt, &_A, &_Cmx, &_R, &_r, &_meanW, &_aMine, &_tAll, &_tMine}) v->bind(srv);
     _n_sessions_global = _n_speakers;
     _ubm_means.set(_ubm.means());       // supervector of means / inverse variances (AccumulateTVStat.cpp:154-162)
     _ubm_invvar.set(_ubm.covInvs());
@@ -734,7 +734,10 @@ TVAcc::TVAcc(GpuServer &srv, const MixtureGD &ubm, unsigned long rankT, unsigned
 
 void TVAcc::resetTmpAcc()
 {
-    _A.assign(_n_distrib * gmmiv_tv_packed_len((int)_rankT), 0.0);
+    // with an overlap communicator A lives in the reduce-scatter's send buffer: equal blocks of Gaussians, the last one zero padded
+    const size_t world = _ovComm ? (size_t)gmmiv_comm_world(_ovComm) : 1;
+    const size_t Cpad = (_n_distrib + world - 1) / world * world;
+    _A.assign(Cpad * gmmiv_tv_packed_len((int)_rankT), 0.0);
     _Cmx.assign(_rankT * _svSize, 0.0);
     _R.assign(_rankT * _rankT, 0.0);
     _r.assign(_rankT, 0.0);
@@ -763,12 +766,50 @@ void TVAcc::restoreStats()
     _statN.copyFrom(_cN); _statF.copyFrom(_cF);
 }
 
+void TVAcc::setOverlap(gmmiv_comm *comm)
+{
+    finishT();
+    _ovComm = (comm && gmmiv_comm_world(comm) > 1) ? comm : nullptr;
+    _aBegun = false;
+}
+void TVAcc::hookAReady(void *self)
+{
+    TVAcc *t = (TVAcc *)self;
+    const size_t P = gmmiv_tv_packed_len((int)t->_rankT), world = (size_t)gmmiv_comm_world(t->_ovComm), Cb = (t->_n_distrib + world - 1) / world;
+    // an error here cannot leave through the C frames of libgmmiv: it is kept in gmmiv_last_error() and the begin is retried
+    // in the serial position by updateTestimate
+    t->_aBegun = gmmiv_reduce_scatter_f64_begin(t->_ovComm, t->_A.cdev(), t->_aMine.dev(), Cb * P) == 0;
+}
+void TVAcc::gatherIntoT()
+{
+    const int world = gmmiv_comm_world(_ovComm);
+    const size_t C = _n_distrib, D = _vectSize, R = _rankT, Cb = (C + world - 1) / world;
+    hipStream_t st = (hipStream_t)_srv.stream();
+    _srv.check(gmmiv_comm_join(_ovComm));
+    for (int g = 0; g < world; ++g) {
+        const size_t g0 = g * Cb, gb = g0 >= C ? 0 : std::min(Cb, C - g0);
+        if (gb) hipcheck(hipMemcpy2DAsync(_T.dev() + g0 * D, C * D * 8, _tAll.cdev() + (size_t)g * R * Cb * D, Cb * D * 8, gb * D * 8, R, hipMemcpyDeviceToDevice, st),
+                         "updateTestimate: gather T");
+    }
+    _tPending = false;
+}
+void TVAcc::hookMdFactored(void *self)
+{
+    TVAcc *t = (TVAcc *)self;
+    try { if (t->_tPending) t->gatherIntoT(); } catch (...) { /* reported by finishT() right after the call */ }
+}
+void TVAcc::finishT()
+{
+    if (_tPending) gatherIntoT();
+}
+
 // updateTestimate on utterance-sharded statistics: rank g owns the Gaussians [g Cb, (g + 1) Cb), Cb = ceil(C / world).
 void TVAcc::updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks)
 {
     _n_sessions_global = nSessionsAllRanks;
     const int world = comm ? gmmiv_comm_world(comm) : 1, rank = comm ? gmmiv_comm_rank(comm) : 0;
     if (world <= 1) { updateTestimate(); return; }
+    const bool ov = _ovComm != nullptr && _ovComm == comm; // overlapped order: every collective of the step on the side stream
     const size_t P = gmmiv_tv_packed_len((int)_rankT), C = _n_distrib, D = _vectSize, R = _rankT;
     const size_t Cb = (C + world - 1) / world, Cpad = Cb * world;
     // the small sums in one all-reduce: [R x R | R | R]
@@ -778,14 +819,19 @@ void TVAcc::updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks)
     hipcheck(hipMemcpyAsync(small.dev(), _R.cdev(), R * R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pack");
     hipcheck(hipMemcpyAsync(small.dev() + R * R, _r.cdev(), R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pack");
     hipcheck(hipMemcpyAsync(small.dev() + R * R + R, _meanW.cdev(), R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pack");
-    _srv.check(gmmiv_allreduce_f64(comm, small.dev(), small.size()));
-    hipcheck(hipMemcpyAsync(_R.dev(), small.cdev(), R * R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
-    hipcheck(hipMemcpyAsync(_r.dev(), small.cdev() + R * R, R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
-    hipcheck(hipMemcpyAsync(_meanW.dev(), small.cdev() + R * R + R, R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
+    DVec aSend(_srv), cSend(_srv), aMineLocal(_srv), cMine(_srv), tMineLocal(_srv), tAllLocal(_srv);
+    DVec &aMine = ov ? _aMine : aMineLocal, &tAll = ov ? _tAll : tAllLocal, &tMine = ov ? _tMine : tMineLocal;
+    if (ov) {
+        if (!_aBegun) { // the hook did not run (host accumulators) or failed: begin A now, in its serial position
+            aMine.assign(Cb * P, 0.0);
+            _srv.check(gmmiv_reduce_scatter_f64_begin(comm, _A.cdev(), aMine.dev(), Cb * P));
+        }
+        _aBegun = false;
+        _srv.check(gmmiv_allreduce_f64_begin(comm, small.dev(), small.size()));
+    } else _srv.check(gmmiv_allreduce_f64(comm, small.dev(), small.size()));
     // A: row blocks are contiguous (padded with empty Gaussians when C does not divide); Cmx: [world][R][Cb D]
-    DVec aSend(_srv), cSend(_srv), aMine(_srv), cMine(_srv), tMine(_srv), tAll(_srv);
     const double *aSrc = _A.cdev();
-    if (Cpad != C) {
+    if (Cpad != C && !ov) {
         aSend.assign(Cpad * P, 0.0);
         hipcheck(hipMemcpyAsync(aSend.dev(), _A.cdev(), C * P * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: pad A");
         aSrc = aSend.cdev();
@@ -796,9 +842,18 @@ void TVAcc::updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks)
         if (cb) hipcheck(hipMemcpy2DAsync(cSend.dev() + (size_t)g * R * Cb * D, Cb * D * 8, _Cmx.cdev() + c0 * D, C * D * 8, cb * D * 8, R, hipMemcpyDeviceToDevice, st),
                          "updateTestimate: block Cmx");
     }
-    aMine.assign(Cb * P, 0.0); cMine.assign(R * Cb * D, 0.0);
-    _srv.check(gmmiv_reduce_scatter_f64(comm, aSrc, aMine.dev(), Cb * P));
-    _srv.check(gmmiv_reduce_scatter_f64(comm, cSend.cdev(), cMine.dev(), R * Cb * D));
+    cMine.assign(R * Cb * D, 0.0);
+    if (ov) {
+        _srv.check(gmmiv_reduce_scatter_f64_begin(comm, cSend.cdev(), cMine.dev(), R * Cb * D));
+        _srv.check(gmmiv_comm_join(comm));
+    } else {
+        aMine.assign(Cb * P, 0.0);
+        _srv.check(gmmiv_reduce_scatter_f64(comm, aSrc, aMine.dev(), Cb * P));
+        _srv.check(gmmiv_reduce_scatter_f64(comm, cSend.cdev(), cMine.dev(), R * Cb * D));
+    }
+    hipcheck(hipMemcpyAsync(_R.dev(), small.cdev(), R * R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
+    hipcheck(hipMemcpyAsync(_r.dev(), small.cdev() + R * R, R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
+    hipcheck(hipMemcpyAsync(_meanW.dev(), small.cdev() + R * R + R, R * 8, hipMemcpyDeviceToDevice, st), "updateTestimate: unpack");
     // the rank's own Gaussians
     const size_t c0 = (size_t)rank * Cb, cb = c0 >= C ? 0 : std::min(Cb, C - c0);
     tMine.assign(R * Cb * D, 0.0);
@@ -811,6 +866,11 @@ void TVAcc::updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks)
             hipcheck(hipMemcpy2DAsync(tMine.dev(), Cb * D * 8, tt.cdev(), cb * D * 8, cb * D * 8, R, hipMemcpyDeviceToDevice, st), "updateTestimate: cut block");
     }
     tAll.assign((size_t)world * R * Cb * D, 0.0);
+    if (ov) { // T stays in flight: minDivergence() joins it once R is factored (finishT() for a caller that skips it)
+        _srv.check(gmmiv_allgather_f64_begin(comm, tMine.cdev(), tAll.dev(), R * Cb * D)); // tMine = _tMine: it outlives this call
+        _tPending = true;
+        return;
+    }
     _srv.check(gmmiv_allgather_f64(comm, tMine.cdev(), tAll.dev(), R * Cb * D));
     for (int g = 0; g < world; ++g) {
         const size_t g0 = g * Cb, gb = g0 >= C ? 0 : std::min(Cb, C - g0);
@@ -900,10 +960,20 @@ void TVAcc::estimateW()
 }
 void TVAcc::estimateAandC()
 {
+    finishT();
     resetTmpAcc(); // the reference zeroes A, C, R, r, meanW at entry (:1712-1722)
-    _srv.check(gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
-                                         _statF.cdev(), _T.cdev(), _ubm_invvar.cdev(), _TETt.cdev(), _W.dev(), _A.dev(), _Cmx.dev(),
-                                         _R.dev(), _r.dev(), _meanW.dev()));
+    if (_ovComm) { // the reduce-scatter of A starts from inside the call, as soon as A is complete (under the Cmx GEMM)
+        const size_t world = (size_t)gmmiv_comm_world(_ovComm), Cb = (_n_distrib + world - 1) / world;
+        _aMine.assign(Cb * gmmiv_tv_packed_len((int)_rankT), 0.0);
+        _aBegun = false;
+        (void)_A.dev(); (void)_aMine.dev(); // both resident before the hook hands them to the collective
+        gmmiv_ctx_set_hook(_srv.ctx(), "tv_a_ready", &TVAcc::hookAReady, this);
+    }
+    const int rc = gmmiv_tv_estimate_a_and_c(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, (int)_rankT, _statN.cdev(),
+                                             _statF.cdev(), _T.cdev(), _ubm_invvar.cdev(), _TETt.cdev(), _W.dev(), _A.dev(), _Cmx.dev(),
+                                             _R.dev(), _r.dev(), _meanW.dev());
+    if (_ovComm) gmmiv_ctx_set_hook(_srv.ctx(), "tv_a_ready", nullptr, nullptr);
+    _srv.check(rc);
     // _meanW stays the SUM of the i-vectors on the device (the all-reduce payload of the sharded form); minDivergence divides (:1791-1794)
 }
 void TVAcc::updateTestimate()
@@ -915,8 +985,13 @@ void TVAcc::minDivergence()
     // _n_sessions == number of statistics rows in TotalVariability (one session per line)
     std::vector<double> mw = _meanW.chost();                      // meanW /= n (:1791-1794), R floats
     for (double &v : mw) v /= (double)_n_sessions_global;
-    _srv.check(gmmiv_tv_min_divergence(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, (double)_n_sessions_global, _R.dev(), _r.dev(),
-                                       mw.data(), _ubm_means.dev(), _T.dev()));
+    if (_tPending) gmmiv_ctx_set_hook(_srv.ctx(), "md_factored", &TVAcc::hookMdFactored, this); // T is still arriving: joined once R is factored
+    double *Td = _T.dev();
+    const int rc = gmmiv_tv_min_divergence(_srv.ctx(), (int)_n_distrib, (int)_vectSize, (int)_rankT, (double)_n_sessions_global, _R.dev(), _r.dev(),
+                                           mw.data(), _ubm_means.dev(), Td);
+    gmmiv_ctx_set_hook(_srv.ctx(), "md_factored", nullptr, nullptr);
+    _srv.check(rc);
+    finishT(); // no-op unless the hook could not run
 }
 
 void TVAcc::orthonormalizeT()

@@ -321,6 +321,13 @@ class TVAcc {
     // of Gaussians, T_c = A_c^-1 Cmx_c on the rank's own Gaussians, all-gather of T; R, r and meanW (sums) are all-reduced
     // for minDivergence, whose session count becomes the global one.  comm == NULL or one rank: plain updateTestimate.
     void updateTestimate(gmmiv_comm *comm, unsigned long nSessionsAllRanks);
+    // Overlapped exchange (option; bitwise the results of the serial order): with a communicator set here, estimateAandC()
+    // accumulates A in the reduce-scatter's (block-padded) send buffer and BEGINS that reduce-scatter from the "tv_a_ready" hook of
+    // gmmiv_tv_estimate_a_and_c -- it runs on the communicator's side stream under the Cmx GEMM -- and updateTestimate(comm, n)
+    // leaves the all-gather of T in flight for minDivergence(), which joins it from the "md_factored" hook (after R is factored).
+    // A caller that skips minDivergence() calls finishT() before anything reads T.  comm == NULL: serial order again.
+    void setOverlap(gmmiv_comm *comm);
+    void finishT();
     // The EM sanity check of TotalVariability (TotalVariability.cpp:132 `if (_checkLLK) tvAcc.verifyEMLK(config)`):
     //   getMplusTW (:964-971)      Sp = ubm_means + T^T w_spk  -- for a LIST of rows at once: one device pass, Sp [rows x svSize]
     //   getSpeakerModel (:1533-1545) the UBM with those means (svToModel, SuperVectors.cpp:79-85: means only)
@@ -348,6 +355,13 @@ class TVAcc {
     DeviceMixture _dubm;
     unsigned long _rankT, _n_speakers, _n_distrib, _vectSize, _svSize, _n_sessions_global;
     DVec _ubm_means, _ubm_invvar, _statN, _statF, _cN, _cF, _T, _W, _TETt, _A, _Cmx, _R, _r, _meanW;
+    // overlapped exchange
+    gmmiv_comm *_ovComm = nullptr;
+    DVec _aMine, _tAll, _tMine;
+    bool _aBegun = false, _tPending = false;
+    static void hookAReady(void *self);
+    static void hookMdFactored(void *self);
+    void gatherIntoT();
 };
 
 // ---- AccumulateJFAStat.h: JFAAcc, M_{s,h} = m + V y_s + U x_h + D z_s (AccumulateJFAStat.cpp) ---------------------------

@@ -294,16 +294,17 @@ def tv_stats_lines(x, file_begin, lines, ubm, device=0):
     return N, F
 
 
-def tv_train_dist(N, F, ubm, Tmat, nb_it, world=1, rank=0, id_file="", n_total=None, min_div=True, device=0):
-    """One rank of a multi-GPU TotalVariability run (liagpu_tv_train_dist); returns (T, means, times_ms [nb_it x 4])."""
+def tv_train_dist(N, F, ubm, Tmat, nb_it, world=1, rank=0, id_file="", n_total=None, min_div=True, device=0, overlap=False):
+    """One rank of a multi-GPU TotalVariability run (liagpu_tv_train_dist2); returns (T, means, times_ms [nb_it x 4]).
+    overlap: TVAcc::setOverlap -- the reduce-scatter of A starts inside estimateAandC, the all-gather of T is joined inside minDivergence."""
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
     C, D = mean.shape
     N = np.ascontiguousarray(N, np.float64); F = np.ascontiguousarray(F, np.float64)
     Tm = np.array(Tmat, np.float64)
     R = Tm.shape[0]
     means = np.empty(C * D); times = np.zeros((nb_it, 4))
-    _chk(lib.liagpu_tv_train_dist(device, world, rank, id_file.encode(), ct.c_long(N.shape[0]), ct.c_long(n_total or N.shape[0]), C, D, _d(w),
-                                  _d(mean), _d(cov), R, _d(N), _d(F), _d(Tm), nb_it, int(min_div), _d(means), _d(times)))
+    _chk(lib.liagpu_tv_train_dist2(device, world, rank, id_file.encode(), ct.c_long(N.shape[0]), ct.c_long(n_total or N.shape[0]), C, D, _d(w),
+                                   _d(mean), _d(cov), R, _d(N), _d(F), _d(Tm), nb_it, int(min_div), int(overlap), _d(means), _d(times)))
     return Tm, means, times
 
 

@@ -97,6 +97,54 @@ def test_tv_em_iterations_on_device_match_oracle_loop():
     ctx.close()
 
 
+def test_iteration_hooks_and_begin_join_single_rank():
+    """gmmiv_ctx_set_hook: "tv_a_ready" fires once inside tv_estimate_a_and_c when the accumulators are device arrays (never for
+    host accumulators: there is nothing on the device to exchange), "md_factored" once inside tv_min_divergence; an exception
+    raised in a hook surfaces from the call; unknown points are refused.  gmmiv_*_begin / gmmiv_comm_join on one rank are the
+    plain calls."""
+    import torch
+    from lia_ral_amd import capi
+    C, D, R, U = 8, 12, 10, 20
+    rng = np.random.default_rng(1)
+    N = rng.gamma(0.8, 3.0, (U, C)); F = rng.normal(size=(U, C * D)); Tm = rng.normal(0, 0.1, (R, C * D)); iv = rng.uniform(0.5, 2, C * D)
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    te = ctx.tv_tett(Tm, iv, C, D)
+    calls = []
+    ctx.set_hook("tv_a_ready", lambda: calls.append("a"))
+    ctx.set_hook("md_factored", lambda: calls.append("md"))
+    P = R * (R + 1) // 2
+    z = lambda *s: torch.zeros(s, dtype=torch.float64, device="cuda")
+    acc = dict(A=z(C, P), Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=z(U, R))
+    ctx.tv_estimate_a_and_c(dv(N), dv(F), dv(Tm), dv(iv), dv(te), C, D, acc=acc)
+    assert calls == ["a"]
+    host = ctx.tv_estimate_a_and_c(N, F, Tm, iv, te, C, D)                  # host accumulators: no hook
+    assert calls == ["a"] and relerr(acc["A"].cpu().numpy(), host["A"]) < 1e-13
+    Td, means = dv(Tm), dv(rng.normal(size=C * D))
+    ctx.tv_min_divergence(acc["Rm"].clone(), acc["r"].clone(), acc["meanW"] / U, means, Td, U, C, D)
+    assert calls == ["a", "md"]
+    ctx.set_hook("md_factored", None)
+    ctx.tv_min_divergence(acc["Rm"].clone(), acc["r"].clone(), acc["meanW"] / U, means, dv(Tm), U, C, D)
+    assert calls == ["a", "md"]
+
+    def boom():
+        raise ValueError("from the hook")
+    ctx.set_hook("tv_a_ready", boom)
+    with pytest.raises(ValueError, match="from the hook"):
+        ctx.tv_estimate_a_and_c(dv(N), dv(F), dv(Tm), dv(iv), dv(te), C, D, acc=acc)
+    ctx.set_hook("tv_a_ready", None)
+    with pytest.raises(capi.GmmivError):
+        ctx.set_hook("no_such_point", lambda: None)
+    comm = capi.Comm(ctx, 1, 0)
+    a = torch.arange(100, dtype=torch.float64, device="cuda"); out = torch.empty_like(a)
+    comm.allreduce_begin(a); comm.reduce_scatter_begin(a, out); comm.join()
+    assert torch.equal(out, a)
+    out.zero_(); comm.allgather_begin(a, out); comm.join(); comm.join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, a)
+    comm.close(); ctx.close()
+
+
 def _rank_main(rank, world, idfile, q):
     sys.path.insert(0, ROOT)
     import torch

@@ -507,7 +507,7 @@ def test_tv_train_dist_single_rank_is_the_plain_loop():
     assert times.shape == (2, 4) and np.all(times > 0)
 
 
-def _tv_rank(rank, world, idfile, q, transport="rccl"):
+def _tv_rank(rank, world, idfile, q, transport="rccl", overlap=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -518,7 +518,7 @@ def _tv_rank(rank, world, idfile, q, transport="rccl"):
     b, e = shard_range(U, rank, world)
     try:
         Tg, mg, _ = h.tv_train_dist(N[b:e], F[b:e], (w, mean, 1.0 / iv), Tm, 2, world=world, rank=rank, id_file=idfile, n_total=U,
-                                    device=rank if transport == "rccl" else 0)
+                                    device=rank if transport == "rccl" else 0, overlap=overlap)
         q.put((rank, Tg, mg))
     except Exception as ex:      # noqa: BLE001 - the parent fails the test with the message
         q.put((rank, repr(ex), None))
@@ -546,15 +546,18 @@ def test_tv_train_dist_two_ranks_rccl(tmp_path):
     assert relerr(res[0][1], To) < 1e-6 and relerr(res[0][2], mo) < 1e-8
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_tv_train_dist_ranks_share_gpu0_shm(world, tmp_path):
-    """The C++ host layer's multi-rank TotalVariability loop (liagpu_tv_train_dist: TVAcc::updateTestimate(comm) = reduce-scatter
+def test_tv_train_dist_ranks_share_gpu0_shm(world, overlap, tmp_path):
+    """overlap: TVAcc::setOverlap (reduce-scatter of A begun from the "tv_a_ready" hook into the padded send buffer A lives in, the
+    all-gather of T joined from the "md_factored" hook) -- the same assertions hold, in particular equality with the single-rank loop.
+    The C++ host layer's multi-rank TotalVariability loop (liagpu_tv_train_dist: TVAcc::updateTestimate(comm) = reduce-scatter
     by padded Gaussian blocks, sharded solve, all-gather; AccumulateTVStat.cpp:974-1005, 1920-1937) with 2 and 3 processes on
     GPU 0 over the C ABI's shm transport: identical T / means on every rank, equal to the oracle's single-process loop."""
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_tv_rank, args=(r, world, str(tmp_path / "id"), q, "shm")) for r in range(world)]
+    procs = [mpc.Process(target=_tv_rank, args=(r, world, str(tmp_path / "id"), q, "shm", overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = {r[0]: r for r in (q.get(timeout=300) for _ in range(world))}
@@ -571,6 +574,13 @@ def test_tv_train_dist_ranks_share_gpu0_shm(world, tmp_path):
     from lia_ral_amd import host_capi as h
     T1, m1, _ = h.tv_train_dist(N, F, (w, mean, 1.0 / iv), Tm, 2)           # the single-rank HIP loop
     assert relerr(res[0][1], T1) < 1e-10 and relerr(res[0][2], m1) < 1e-11
+    other = _TV_SHM_RESULTS.get((world, not overlap))                       # serial and overlapped order: bitwise the same T and means
+    if other is not None:
+        assert np.array_equal(other[0], res[0][1]) and np.array_equal(other[1], res[0][2])
+    _TV_SHM_RESULTS[(world, overlap)] = (res[0][1], res[0][2])
+
+
+_TV_SHM_RESULTS = {}
 
 
 def _tw_rank(rank, world, idfile, q):

@@ -49,7 +49,7 @@ def _case():
 class DeviceTvOps:
     """The per-rank compute of lia_ral_amd.dist.tv_em_iteration on device-resident statistics (libgmmiv)."""
 
-    def __init__(self, ctx, C, D, R, N, F, Tm, iv, means):
+    def __init__(self, ctx, C, D, R, N, F, Tm, iv, means, world=1):
         import torch
         self.ctx, self.C, self.D, self.R = ctx, C, D, R
         dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -58,7 +58,8 @@ class DeviceTvOps:
         P = R * (R + 1) // 2
         z = lambda *s: torch.zeros(s, dtype=torch.float64, device="cuda")
         self.te = z(C, P)
-        self.acc = dict(A=z(C, P), Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=z(N.shape[0], R))
+        A_pad = z((C + world - 1) // world * world, P)     # the reduce-scatter's send buffer: equal Gaussian blocks, zero padded
+        self.acc = dict(A=A_pad[:C], A_pad=A_pad, Cmx=z(R, C * D), Rm=z(R, R), r=z(R), meanW=z(R), W=z(N.shape[0], R))
 
     def stream_context(self):
         import torch
@@ -86,8 +87,9 @@ class DeviceTvOps:
         return Tn
 
 
-def _run_rank(rank, world, transport, port, idfile):
-    """One rank: returns (T, means, em_acc, backend name) as numpy."""
+def _run_rank(rank, world, transport, port, idfile, overlap=False):
+    """One rank: returns (T, means, em_acc, backend name) as numpy.  overlap: the whole thing twice -- serial order, then with the
+    exchange started early (gmmiv_*_begin / hooks) from the same initial state -- and the bitwise comparison instead of the EM leg."""
     import torch
     from lia_ral_amd import capi
     from lia_ral_amd import dist as gd
@@ -108,9 +110,21 @@ def _run_rank(rank, world, transport, port, idfile):
         coll = gd.GmmivCollectives(capi.Comm(ctx, world, rank, uid))
     C, D, R, U, w, mean, iv, N, F, Tm, x = _case()
     b, e = gd.shard_range(U, rank, world)
-    ops = DeviceTvOps(ctx, C, D, R, N[b:e], F[b:e], Tm, iv, mean)
+    ops = DeviceTvOps(ctx, C, D, R, N[b:e], F[b:e], Tm, iv, mean, world)
     for _ in range(2):
         Tg = gd.tv_em_iteration(ops, U, C, D, rank, world, coll)
+    if overlap:
+        ops2 = DeviceTvOps(ctx, C, D, R, N[b:e], F[b:e], Tm, iv, mean, world)
+        fired = []
+        for _ in range(2):
+            ph = {}
+            T2 = gd.tv_em_iteration(ops2, U, C, D, rank, world, coll, ph, overlap=True)
+            fired.append(sorted(ph))
+        torch.cuda.synchronize()
+        same = bool(torch.equal(T2, Tg) and torch.equal(ops2.means, ops.means))
+        out = (Tg.cpu().numpy(), ops.means.cpu().numpy(), np.array([float(same)]), coll.name + " " + repr(fired[-1]))
+        ctx.close()
+        return out
     # UBM EM statistics of this rank's frames + the all-reduce of the flat accumulator
     g = ctx.gmm(w, mean, iv)
     xd = torch.from_numpy(x).cuda()
@@ -129,10 +143,10 @@ def _run_rank(rank, world, transport, port, idfile):
     return out
 
 
-def _rank_main(rank, world, transport, port, idfile, q):
+def _rank_main(rank, world, transport, port, idfile, q, overlap=False):
     sys.path.insert(0, ROOT)
     try:
-        q.put((rank, _run_rank(rank, world, transport, port, idfile)))
+        q.put((rank, _run_rank(rank, world, transport, port, idfile, overlap)))
     except Exception as ex:      # noqa: BLE001 - reported to the parent, which fails the test
         import traceback
         q.put((rank, "rank %d: %r\n%s" % (rank, ex, traceback.format_exc())))
@@ -189,6 +203,34 @@ def test_sharded_tv_em_and_ubm_em_on_one_gpu(world, transport, tmp_path, single_
     og = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
     a = res[0][2]
     assert relerr(a[:C], og["occ"]) < 1e-9 and relerr(a[C:C + C * D], og["sx"].ravel()) < 1e-9
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_exchange_is_bitwise_the_serial_order(world, tmp_path, single_rank):
+    """tv_em_iteration(overlap=True): the reduce-scatter of A begins from the "tv_a_ready" hook inside gmmiv_tv_estimate_a_and_c
+    (into the padded send buffer the E-step accumulates in), the all-gather of T is joined from the "md_factored" hook inside
+    gmmiv_tv_min_divergence -- through gmmiv_*_begin / gmmiv_comm_join of the C ABI, 2 and 3 ranks on GPU 0 over shm.  Two iterations
+    from the same initial state give bitwise the T and means of the serial order (and the single-rank result to 1e-11)."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_main, args=(r, world, "shm", 0, str(tmp_path / "comm.id"), q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, payload = q.get(timeout=600)
+        assert not isinstance(payload, str), payload
+        res[r] = payload
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    T1, m1, _, _ = single_rank
+    for r in range(world):
+        Tg, mg, same, name = res[r]
+        assert same[0] == 1.0, name
+        assert "reduce_scatter" in name and "allgather" in name and "min_divergence" in name
+        assert relerr(Tg, T1) < 1e-11 and relerr(mg, m1) < 1e-11
 
 
 def _shm_rank(rank, world, idfile, n, q):
