@@ -64,6 +64,37 @@ int liagpu_train_world(int device, const float *x, long T, int D, const long *se
     })
 }
 
+// TrainWorld (TrainWorld.cpp:101-191) with NO initial model ("World model init from scratch", :175-178): global mean / covariance
+// (or use01: 0 / 1, :158-169), mixtureInit with C components, trainModelStream.  w / mean / cov [C], [C x D], [C x D] are outputs only.
+int liagpu_train_world_scratch(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                               int C, double nbFrameToSelect, int use01, double *w, double *mean, double *cov, int nbTrainIt,
+                               double baggedFrameProbability, double initVarFloor, double finalVarFloor, double initVarCeil,
+                               double finalVarCeil, long initRand, double *global_cov_out, double *llk_it_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        std::vector<double> gm(D, 0.0), gc(D, 1.0);                    // initialize01
+        if (!use01) computeMeanCov(fs, segs, gm, gc);
+        if (global_cov_out) memcpy(global_cov_out, gc.data(), D * sizeof(double));
+        MixtureGD world((unsigned long)C, (unsigned long)D);
+        MixtureInitCfg icfg;
+        icfg.nbFrameToSelect = nbFrameToSelect;
+        mixtureInit(fs, segs, 1.0, world, gc, icfg);
+        TrainCfg cfg;
+        cfg.nbTrainIt = nbTrainIt; cfg.baggedFrameProbability = baggedFrameProbability;
+        cfg.initVarianceFlooring = initVarFloor; cfg.finalVarianceFlooring = finalVarFloor;
+        cfg.initVarianceCeiling = initVarCeil; cfg.finalVarianceCeiling = finalVarCeil;
+        cfg.initRand = (unsigned long)initRand;
+        std::vector<double> llk = trainModelStream(cfg, fs, segs, gc, world);
+        memcpy(w, world.weights().data(), C * sizeof(double));
+        memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
+        if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
+    })
+}
+
 // mixtureInit (TrainTools.cpp:674-766 multi-stream form with one stream when single_stream == 0, :619-672 when 1): the
 // start-from-scratch model of TrainWorld.  param = nbFrameToSelect (multi) or baggedFrameProbabilityInit (single).
 // w / mean / cov [C], [C x D], [C x D] out; counts [C] (nullable) = frames picked per component.

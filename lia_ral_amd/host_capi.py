@@ -57,6 +57,19 @@ def train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, bagged_p=1.0, init_f
     return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk)
 
 
+def train_world_scratch(x, seg_begin, seg_len, C, nb_it, nb_frame_to_select=50.0, use01=False, bagged_p=1.0, init_floor=0.0, final_floor=0.0,
+                        init_ceil=10.0, final_ceil=10.0, init_rand=0, device=0):
+    """TrainWorld with no initial model: computeMeanCov (or use01), mixtureInit, trainModelStream (liagpu_train_world_scratch)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    w = np.empty(C); mean = np.empty((C, D)); cov = np.empty((C, D)); gc = np.empty(D); llk = np.empty(nb_it)
+    _chk(lib.liagpu_train_world_scratch(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, ct.c_double(nb_frame_to_select),
+                                        int(use01), _d(w), _d(mean), _d(cov), nb_it, ct.c_double(bagged_p), ct.c_double(init_floor),
+                                        ct.c_double(final_floor), ct.c_double(init_ceil), ct.c_double(final_ceil), ct.c_long(init_rand), _d(gc), _d(llk)))
+    return dict(w=w, mean=mean, cov=cov, global_cov=gc, llk=llk)
+
+
 def mixture_init(x, seg_begin, seg_len, C, global_cov, nb_frame_to_select=50.0, stream_weight=1.0, single_stream_proba=None, min_len=3,
                  max_len=7, device=0):
     """mixtureInit: TrainWorld's start-from-scratch model (multi-stream form with one stream; single_stream_proba = the

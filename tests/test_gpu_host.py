@@ -732,6 +732,10 @@ def test_mixture_init_and_train_world_from_scratch(select):
                                  5.0, 10.0)
         assert np.max(np.abs(tw["llk"] - ref["llk"])) < 1e-9 and np.all(np.diff(tw["llk"]) > 0)   # EM from scratch: llk rises
         assert relerr(tw["mean"], ref["mean"]) < 1e-8 and relerr(tw["cov"], ref["cov"]) < 1e-8
+        one = h.train_world_scratch(x, seg_begin, seg_len, C, 3, nb_frame_to_select=select, init_floor=0.5, final_floor=0.05, init_ceil=5.0,
+                                    final_ceil=10.0)                                            # the whole tool in one call
+        assert relerr(one["mean"], tw["mean"]) < 1e-9 and relerr(one["cov"], tw["cov"]) < 1e-9 and np.max(np.abs(one["llk"] - tw["llk"])) < 1e-9
+        assert relerr(one["global_cov"], gcov) < 1e-12
 
 
 def test_mixture_init_single_stream_form():
