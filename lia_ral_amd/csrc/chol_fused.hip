@@ -71,14 +71,18 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-constexpr int TW = 3; // row tiles per wave and pass: 2 x (2 + TW) x 16 operand VGPRs in flight + TW x 16 accumulators
+// TW = row tiles per wave and pass (2 x (2 + TW) x 16 operand VGPRs in flight + TW x 16 accumulators) is a template parameter of
+// the kernels, deduced by the helpers below from the arrays they are handed.  Round 2 ran TW = 3 everywhere; measured per 1024
+// systems of order 400 (tools/chol_probe.hip): k_chol_left2 1.31 / 1.21 / 1.11 ms for TW = 3 / 2 / 1, k_trinv_left 0.85 / 0.82 /
+// 0.80, k_uut 1.39 / 1.12 / 1.17, TW = 4: 1.67 / 0.96 / 1.49 -- these kernels are bound by latency, not by operand reuse: fewer
+// tiles per pass mean more, shorter passes that balance better over the waves, and no spilled accumulators.
 
 // One 32-wide k chunk of operands: the 32 panel rows (a0 / a1: rows perm(i16), 16 + perm(i16)) and CNT row tiles,
 // 64 contiguous bytes per lane and row.
 template <int CNT> struct RowOps { d2 a0[4], a1[4], b[CNT][4]; };
 
-template <int CNT>
-__device__ __forceinline__ void rows_load(RowOps<CNT> &o, const double *pa0, const double *pa1, const double *(&pb)[TW], int k)
+template <int CNT, int TWT>
+__device__ __forceinline__ void rows_load(RowOps<CNT> &o, const double *pa0, const double *pa1, const double *(&pb)[TWT], int k)
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -90,8 +94,8 @@ __device__ __forceinline__ void rows_load(RowOps<CNT> &o, const double *pa0, con
 #pragma unroll
         for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + 2 * v);
 }
-template <int CNT, bool NEG>
-__device__ __forceinline__ void rows_mfma(const RowOps<CNT> &o, d4 (&acc)[TW][2])
+template <int CNT, bool NEG, int TWT>
+__device__ __forceinline__ void rows_mfma(const RowOps<CNT> &o, d4 (&acc)[TWT][2])
 {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -116,9 +120,9 @@ __device__ __forceinline__ void rows_mfma(const RowOps<CNT> &o, d4 (&acc)[TW][2]
 // double-buffered one chunk ahead.  Every load is unconditional (the last prefetch is clamped to the final chunk and
 // thrown away): with a conditional prefetch the compiler merges "issued" and "not issued" at the join and waits
 // vmcnt(0), i.e. for the prefetch itself.
-template <int CNT, bool NEG>
-__device__ __forceinline__ void rowdot(const double *pa0, const double *pa1, const double *(&pb)[TW], int kb, int ke,
-                                       d4 (&acc)[TW][2])
+template <int CNT, bool NEG, int TWT>
+__device__ __forceinline__ void rowdot(const double *pa0, const double *pa1, const double *(&pb)[TWT], int kb, int ke,
+                                       d4 (&acc)[TWT][2])
 {
     if (ke - kb < 32) return;
     RowOps<CNT> A, B;
@@ -137,14 +141,15 @@ __device__ __forceinline__ void rowdot(const double *pa0, const double *pa1, con
     }
     if (k < ke) rows_mfma<CNT, NEG>(A, acc);
 }
-template <bool NEG>
-__device__ __forceinline__ void rowdot_n(int cnt, const double *pa0, const double *pa1, const double *(&pb)[TW], int kb,
-                                         int ke, d4 (&acc)[TW][2])
+template <bool NEG, int TWT>
+__device__ __forceinline__ void rowdot_n(int cnt, const double *pa0, const double *pa1, const double *(&pb)[TWT], int kb,
+                                         int ke, d4 (&acc)[TWT][2])
 {
     switch (cnt) { // wave-uniform
     case 1: rowdot<1, NEG>(pa0, pa1, pb, kb, ke, acc); break;
-    case 2: rowdot<2, NEG>(pa0, pa1, pb, kb, ke, acc); break;
-    case 3: rowdot<3, NEG>(pa0, pa1, pb, kb, ke, acc); break;
+    case 2: rowdot<(TWT >= 2 ? 2 : TWT), NEG>(pa0, pa1, pb, kb, ke, acc); break;
+    case 3: rowdot<(TWT >= 3 ? 3 : TWT), NEG>(pa0, pa1, pb, kb, ke, acc); break;
+    case 4: rowdot<(TWT >= 4 ? 4 : TWT), NEG>(pa0, pa1, pb, kb, ke, acc); break;
     default: break;
     }
 }
@@ -194,8 +199,8 @@ __device__ __forceinline__ void stage_panel(double *pan, int S, const double *X,
 }
 template <int CNT> struct TileOps { d2 b[CNT][4]; };
 struct PanOps { d2 a0[4], a1[4]; };
-template <int CNT>
-__device__ __forceinline__ void tiles_load(TileOps<CNT> &o, const double *(&pb)[TW], int k)
+template <int CNT, int TWT>
+__device__ __forceinline__ void tiles_load(TileOps<CNT> &o, const double *(&pb)[TWT], int k)
 {
 #pragma unroll
     for (int u = 0; u < CNT; ++u)
@@ -210,8 +215,8 @@ __device__ __forceinline__ void pan_load(PanOps &o, const double *la0, const dou
         o.a1[v] = *(const d2 *)(la1 + kl + 2 * v);
     }
 }
-template <int CNT, bool NEG>
-__device__ __forceinline__ void pan_mfma(const PanOps &a, const TileOps<CNT> &o, d4 (&acc)[TW][2])
+template <int CNT, bool NEG, int TWT>
+__device__ __forceinline__ void pan_mfma(const PanOps &a, const TileOps<CNT> &o, d4 (&acc)[TWT][2])
 {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -227,9 +232,9 @@ __device__ __forceinline__ void pan_mfma(const PanOps &a, const TileOps<CNT> &o,
 // rowdot with the panel rows in LDS (la0 / la1: the lane's two panel rows + 8 q, LDS column = k - kbase); tile rows still come
 // from memory, register double-buffered one chunk ahead; the LDS operands of the next chunk are requested before the MFMAs of
 // the current one.
-template <int CNT, bool NEG>
-__device__ __forceinline__ void rowdot_lds(const double *la0, const double *la1, const double *(&pb)[TW], int kb, int ke, int kbase,
-                                           d4 (&acc)[TW][2])
+template <int CNT, bool NEG, int TWT>
+__device__ __forceinline__ void rowdot_lds(const double *la0, const double *la1, const double *(&pb)[TWT], int kb, int ke, int kbase,
+                                           d4 (&acc)[TWT][2])
 {
     // (A third rotating operand buffer -- tile rows requested two chunks ahead -- was tried: 120-137 spilled VGPRs in all three
     // kernels and the gain of the LDS panel gone.  Two buffers it is.)
@@ -257,15 +262,16 @@ __device__ __forceinline__ void rowdot_lds(const double *la0, const double *la1,
 }
 // dispatcher over the tile count; the operand source is a template parameter of the kernels (two code paths in one kernel cost
 // 150 spilled VGPRs)
-template <bool LDS, bool NEG>
+template <bool LDS, bool NEG, int TWT>
 __device__ __forceinline__ void rowdot_sel(int cnt, const double *pa0, const double *pa1, const double *la0, const double *la1,
-                                           const double *(&pb)[TW], int kb, int ke, int kbase, d4 (&acc)[TW][2])
+                                           const double *(&pb)[TWT], int kb, int ke, int kbase, d4 (&acc)[TWT][2])
 {
     if (!LDS) { rowdot_n<NEG>(cnt, pa0, pa1, pb, kb, ke, acc); return; }
     switch (cnt) {
     case 1: rowdot_lds<1, NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
-    case 2: rowdot_lds<2, NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
-    case 3: rowdot_lds<3, NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
+    case 2: rowdot_lds<(TWT >= 2 ? 2 : TWT), NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
+    case 3: rowdot_lds<(TWT >= 3 ? 3 : TWT), NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
+    case 4: rowdot_lds<(TWT >= 4 ? 4 : TWT), NEG>(la0, la1, pb, kb, ke, kbase, acc); break;
     default: break;
     }
 }
@@ -337,6 +343,7 @@ template <bool use_lds>
 __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
                                                       long spk, double diag_add)
 {
+    constexpr int TW = 3;
     __shared__ __attribute__((aligned(16))) double pj[32][34];
     __shared__ __attribute__((aligned(16))) double linv[32][34];
     __shared__ __attribute__((aligned(16))) double col[2][32];
@@ -620,6 +627,7 @@ __device__ __forceinline__ void diag_from_lds(const double *la, const double *lb
     }
 }
 
+template <int TW>
 __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
                                                        long spk, double diag_add)
 {
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
 // for the row tiles c < i0.  U[c][k] = 0 for k < c: a tile's k range starts at its own 32-block (whose diagonal
 // block is stored with its zeros), and tiles of one wave (128 rows apart) join the k loop one after the other.
 // Only the upper triangle (plus the diagonal blocks) of U is written; nothing else of U is ever read.
-template <bool use_lds>
+template <bool use_lds, int TW>
 __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__restrict__ Lfull, const double *__restrict__ invd,
                                                        long sinv, double *Ufull)
 {
@@ -897,9 +905,9 @@ __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__r
 // inv = U U^T = A^-1:  inv[i][j] = sum_{k >= max(i, j)} U[i][k] U[j][k]  -- rows x rows again.  Panels of 32 columns
 // j0.., row tiles i >= j0, k from the tile's own 32-block to n (a last partial chunk is masked).  Each tile is
 // written to both triangles.  No synchronisation at all: U is only read.
-template <int CNT>
-__device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1, const double *(&pb)[TW], int kt, int n, int q,
-                                            d4 (&acc)[TW][2])
+template <int CNT, int TWT>
+__device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1, const double *(&pb)[TWT], int kt, int n, int q,
+                                            d4 (&acc)[TWT][2])
 {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -915,7 +923,7 @@ __device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1
 }
 // packed != NULL: instead of the full matrix, E = inv + w w^T goes out as PACKED lower rows (stride sp) -- what the T-matrix
 // E-step accumulates (A_c += N_uc E_u): no full inverse in memory, no matrix-vector pass, no pack pass.
-template <bool use_lds>
+template <bool use_lds, int TW>
 __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv,
                                                 const double *__restrict__ wv, double *__restrict__ packed, long sp)
 {
@@ -973,8 +981,8 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
             if (nfl < n_) {
                 switch (cnt) {
                 case 1: rowdot_tail<1>(pa0, pa1, pb, nfl, n_, q, acc); break;
-                case 2: rowdot_tail<2>(pa0, pa1, pb, nfl, n_, q, acc); break;
-                case 3: rowdot_tail<3>(pa0, pa1, pb, nfl, n_, q, acc); break;
+                case 2: rowdot_tail<(TW >= 2 ? 2 : TW)>(pa0, pa1, pb, nfl, n_, q, acc); break;
+                case 3: rowdot_tail<(TW >= 3 ? 3 : TW)>(pa0, pa1, pb, nfl, n_, q, acc); break;
                 default: break;
                 }
             }
@@ -1151,9 +1159,9 @@ int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int 
     const long sinv = (long)((n + 31) / 32) * 1024;
     if (l.use && gmmiv_kopts_cur().chol_flow) { // round 3: panel staged first, diagonal update from LDS (k_chol_left2)
         const size_t pan = (size_t)32 * ((n & 2) ? n : n + 2) * sizeof(double);
-        int rc2 = chol_attr(k_chol_left2, pan, g_attr_chol[2]);
+        int rc2 = chol_attr(k_chol_left2<1>, pan, g_attr_chol[2]);
         if (rc2) return rc2;
-        k_chol_left2<<<nb, 512, pan, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
+        k_chol_left2<1><<<nb, 512, pan, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
         return (int)hipGetLastError();
     }
     int rc = l.use ? chol_attr(k_chol_left<true>, l.chol, g_attr_chol[1]) : chol_attr(k_chol_left<false>, l.chol, g_attr_chol[0]);
@@ -1166,19 +1174,19 @@ int launch_trinv(hipStream_t st, int n, int nb, const double *Lf, const double *
 {
     const CholLds l = chol_lds(n);
     const long sinv = (long)((n + 31) / 32) * 1024;
-    int rc = l.use ? chol_attr(k_trinv_left<true>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false>, l.trinv, g_attr_trinv[0]);
+    int rc = l.use ? chol_attr(k_trinv_left<true, 1>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false, 3>, l.trinv, g_attr_trinv[0]);
     if (rc) return rc;
-    if (l.use) k_trinv_left<true><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
-    else k_trinv_left<false><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
+    if (l.use) k_trinv_left<true, 1><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
+    else k_trinv_left<false, 3><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
     return (int)hipGetLastError();
 }
 int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, const double *w, double *packed, long sp)
 {
     const CholLds l = chol_lds(n);
-    int rc = l.use ? chol_attr(k_uut<true>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false>, l.uut, g_attr_uut[0]);
+    int rc = l.use ? chol_attr(k_uut<true, 2>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false, 3>, l.uut, g_attr_uut[0]);
     if (rc) return rc;
-    if (l.use) k_uut<true><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
-    else k_uut<false><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
+    if (l.use) k_uut<true, 2><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
+    else k_uut<false, 3><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
     return (int)hipGetLastError();
 }
 } // namespace
