@@ -77,6 +77,7 @@ const char *gmmiv_version(void);
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
  *                      used for odd orders); A/B switch (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
  *   "chol_lds" 1       chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
+ *   "chol_flow" 1      batched Cholesky k_chol_left2 (panel staged first, diagonal update from LDS on all waves); 0: round 2's k_chol_left
  *   "kopts_bound"      read-only: 1 when this context's kernel-launcher options are the set bound to the calling thread (they are
  *                      bound by each call of the context on entry)
  *   "tv_mstep_solve" 1 updateTestimate by blocked substitution through the Cholesky factor of A_c (k_chol_solve_multi);
