@@ -82,11 +82,20 @@ def cpu_baseline(w, mean, iv, seed):
     logical, phys = os.cpu_count() or 1, physical_cores()
     counts = sorted({1, max(1, phys // 4), max(1, phys // 2), phys, logical})
     g = orc.Gmm(w, mean, iv)
-    x = make_frames(w, mean, iv, 4000 * max(counts), seed=seed).astype(np.float64)
-    orc.em_accumulate(g, x[:2000], fast=True, threads=min(8, logical))       # warm-up / page-in
+    # Every point runs for about TARGET_S seconds: the frame count of a point is sized from the single-thread rate (assuming half
+    # of linear scaling), so that the many-thread points measure the steady loop and not thread start-up and cold 2 MB accumulators
+    # (round 2 gave every thread 4000 frames: 5-10 s points at 128 / 256 threads that were mostly start-up).
+    TARGET_S, MAX_FRAMES = 2.5, 3_000_000
+    probe = make_frames(w, mean, iv, 6000, seed=seed).astype(np.float64)
+    orc.em_accumulate(g, probe[:2000], fast=True, threads=1)                   # warm-up / page-in
+    t = time.time()
+    orc.em_accumulate(g, probe[2000:], fast=True, threads=1)
+    r1 = 4000 / max(time.time() - t, 1e-6)                                     # frames per second of one thread
+    frames_of = {th: int(min(MAX_FRAMES, max(4000 * th, r1 * th * 0.5 * TARGET_S))) for th in counts}
+    x = make_frames(w, mean, iv, max(frames_of.values()), seed=seed + 1).astype(np.float64)
     sweep = []
     for th in counts:
-        frames = 4000 * th
+        frames = frames_of[th]
         t = time.time()
         orc.em_accumulate(g, x[:frames], fast=True, threads=th)
         dt = time.time() - t
@@ -94,9 +103,10 @@ def cpu_baseline(w, mean, iv, seed):
     best = max(sweep, key=lambda r: r["gpairs_per_s"])
     return {"value": best["gpairs_per_s"], "unit": "Gframe-Gaussian/s", "cores": best["threads"], "kind": "port",
             "single_thread": sweep[0]["gpairs_per_s"], "logical_cores": logical, "physical_cores": phys, "sweep": sweep,
-            "sample": "4000 frames per thread x %d Gaussians, one EM statistics pass per thread count (oracle/oracle_mt.c, gcc -O3 "
-                      "-ffast-math like the reference; a restatement of the reference loops, not the original binary), %.1f s in all"
-                      % (C, sum(r["seconds"] for r in sweep))}
+            "sample": "one EM statistics pass per thread count over %s frames x %d Gaussians (each point sized for ~%.1f s from the "
+                      "single-thread rate; oracle/oracle_mt.c, gcc -O3 -ffast-math like the reference; a restatement of the reference "
+                      "loops, not the original binary), %.1f s in all"
+                      % ("/".join(str(r["frames"]) for r in sweep), C, TARGET_S, sum(r["seconds"] for r in sweep))}
 
 
 def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000, R=400, check=True):
