@@ -82,29 +82,31 @@ def cpu_baseline(w, mean, iv, seed):
     logical, phys = os.cpu_count() or 1, physical_cores()
     counts = sorted({1, max(1, phys // 4), max(1, phys // 2), phys, logical})
     g = orc.Gmm(w, mean, iv)
-    # Every point runs for about TARGET_S seconds: the frame count of a point is sized from the single-thread rate (assuming half
-    # of linear scaling), so that the many-thread points measure the steady loop and not thread start-up and cold 2 MB accumulators
-    # (round 2 gave every thread 4000 frames: 5-10 s points at 128 / 256 threads that were mostly start-up).
-    TARGET_S, MAX_FRAMES = 2.5, 3_000_000
+    # Every point runs for about TARGET_S seconds: its frame count is sized from the aggregate rate the PREVIOUS point measured (the
+    # first from a short single-thread probe), at least 4000 frames per thread -- the many-thread points then time the steady loop
+    # (private 2 MB accumulators that no longer fit the last-level cache: the rate FALLS past ~32 threads on a 128-core host) and
+    # not thread start-up (round 2 gave every thread 4000 frames whatever the rate).
+    TARGET_S, MAX_FRAMES = 2.5, 1_500_000
     probe = make_frames(w, mean, iv, 6000, seed=seed).astype(np.float64)
     orc.em_accumulate(g, probe[:2000], fast=True, threads=1)                   # warm-up / page-in
     t = time.time()
     orc.em_accumulate(g, probe[2000:], fast=True, threads=1)
-    r1 = 4000 / max(time.time() - t, 1e-6)                                     # frames per second of one thread
-    frames_of = {th: int(min(MAX_FRAMES, max(4000 * th, r1 * th * 0.5 * TARGET_S))) for th in counts}
-    x = make_frames(w, mean, iv, max(frames_of.values()), seed=seed + 1).astype(np.float64)
+    rate = 4000 / max(time.time() - t, 1e-6)                                   # frames per second, all threads of the last point together
+    base = make_frames(w, mean, iv, 150_000, seed=seed + 1).astype(np.float64)  # 150 k distinct frames, repeated: the loop's cost does not depend on them
+    x = np.tile(base, (MAX_FRAMES // base.shape[0], 1))
     sweep = []
     for th in counts:
-        frames = frames_of[th]
+        frames = int(min(MAX_FRAMES, max(4000 * th, rate * TARGET_S)))
         t = time.time()
         orc.em_accumulate(g, x[:frames], fast=True, threads=th)
         dt = time.time() - t
+        rate = frames / dt
         sweep.append({"threads": th, "frames": frames, "seconds": dt, "gpairs_per_s": frames * C / dt / 1e9})
     best = max(sweep, key=lambda r: r["gpairs_per_s"])
     return {"value": best["gpairs_per_s"], "unit": "Gframe-Gaussian/s", "cores": best["threads"], "kind": "port",
             "single_thread": sweep[0]["gpairs_per_s"], "logical_cores": logical, "physical_cores": phys, "sweep": sweep,
             "sample": "one EM statistics pass per thread count over %s frames x %d Gaussians (each point sized for ~%.1f s from the "
-                      "single-thread rate; oracle/oracle_mt.c, gcc -O3 -ffast-math like the reference; a restatement of the reference "
+                      "rate of the point before; oracle/oracle_mt.c, gcc -O3 -ffast-math like the reference; a restatement of the reference "
                       "loops, not the original binary), %.1f s in all"
                       % ("/".join(str(r["frames"]) for r in sweep), C, TARGET_S, sum(r["seconds"] for r in sweep))}
 
