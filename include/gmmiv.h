@@ -86,6 +86,8 @@ const char *gmmiv_version(void);
  *   "topc_fused" 1     DETERMINE_TOP_DISTRIBS with the candidates collected in the epilogue of the MFMA log-likelihood kernel
  *                      (k_llk_mfma<TC> + k_topc_rank; C' <= 16, C <= 2048, D <= 64); 0 or not applicable: "topc_z".
  *                      "topc_fallbacks" counts the calls the fused path handed on (candidate list overflow / margin check)
+ *   "topc_overlap" 0   fused path on more than 262 144 frames: 1 = the ranking of a sub-chunk runs on a side stream beside the
+ *                      log-likelihood kernel of the next one (bitwise the same results; measured slower, hence off)
  *   "topc_z" 1         DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (k_llk_mfma<WZ> + k_topc_from_z, direct form only
  *                      for the candidates); 0: the direct-form VALU kernel for every Gaussian
  *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)

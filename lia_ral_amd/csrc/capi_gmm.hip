@@ -74,6 +74,7 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
         for (hipEvent_t e : c->ev0[i]) (void)hipEventDestroy(e);
         for (hipEvent_t e : c->ev1[i]) (void)hipEventDestroy(e);
     }
+    c->topc_pipe_free();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (&gmmiv_kopts_cur() == &c->ko) gmmiv_kopts_bind(nullptr); // this thread's binding must not outlive the context
     delete c;
@@ -107,6 +108,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "tv_md_device")) slot = &c->tv_md_device;
     else if (!strcmp(key, "tv_acc_mb")) slot = &c->tv_acc_mb;
     else if (!strcmp(key, "topc_fused")) slot = &c->topc_fused;
+    else if (!strcmp(key, "topc_overlap")) slot = &c->topc_overlap;
     else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
     // options read by the kernel launchers: kept in the context's gmmiv_kopts, bound to the calling thread by every call (GBIND)
     int *ks = nullptr;
@@ -383,26 +385,30 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
         int64_t Tf = (int64_t)(budget / per_frame / 1.2) / 256 * 256;
         if (Tf >= 256) {
             const int64_t first = T < Tf ? (T + 255) / 256 * 256 : Tf;
+            const int stats = getenv("GMMIV_TOPC_STATS") != nullptr;
+            const int64_t SUB = 262144; // frames per sub-chunk of the pipelined form below: 1024 workgroups of k_llk_mfma<TC>
+            const bool pipelined = c->topc_overlap && !stats && T > SUB && Tf >= 2 * SUB;
+            const int64_t nsub = pipelined ? (T + SUB - 1) / SUB : 1;
+            const int64_t nalloc = pipelined && first < 2 * SUB ? 2 * SUB : first; // two candidate sets of SUB frames fit
             void *cand, *cnt, *th, *sl, *flg;
-            if ((rc = c->scratch(WS_Z, (size_t)first * per_frame, &cand))) return rc;
-            if ((rc = c->scratch(WS_EIT, (size_t)first * sizeof(int), &cnt))) return rc;
-            if ((rc = c->scratch(WS_INV, (size_t)first * (sizeof(double) + sizeof(int)), &sl))) return rc;
-            if ((rc = c->scratch(WS_LSE, (size_t)first * sizeof(double), &th))) return rc;
-            if ((rc = c->scratch(WS_FLAGS, 64, &flg))) return rc;
+            if ((rc = c->scratch(WS_Z, (size_t)nalloc * per_frame, &cand))) return rc;
+            if ((rc = c->scratch(WS_EIT, (size_t)nalloc * sizeof(int), &cnt))) return rc;
+            if ((rc = c->scratch(WS_INV, (size_t)nalloc * (sizeof(double) + sizeof(int)), &sl))) return rc;
+            if ((rc = c->scratch(WS_LSE, (size_t)nalloc * sizeof(double), &th))) return rc;
+            if ((rc = c->scratch(WS_FLAGS, (size_t)nsub * 64, &flg))) return rc;
             int *efin = (int *)((double *)sl + first);
             void *redo;
-            if ((rc = c->scratch(WS_SEG, (size_t)first * sizeof(long), &redo))) return rc;
-            const int stats = getenv("GMMIV_TOPC_STATS") != nullptr;
+            if ((rc = c->scratch(WS_SEG, (size_t)nalloc * sizeof(long), &redo))) return rc;
             int krc = 0;
             bool whole = false; // too many frames failed the fused path: the paths below redo the call
-            for (int64_t c0 = 0; c0 < T && krc == 0 && !whole; c0 += Tf) {
-                const int64_t n = (T - c0) < Tf ? (T - c0) : Tf;
+            // one chunk [c0, c0 + n): k_llk_mfma<TC> + k_topc_rank on the context's stream, flags read back, failed frames redone
+            auto run_chunk = [&](int64_t c0, int64_t n) -> int {
                 GCHK(hipMemsetAsync(flg, 0, 64, c->stream));
                 c->t_begin("k_llk_mfma", c0 == 0);
                 krc = gmmk_llk_topc(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (int)c->use_glds,
                                     ctop, (double *)cand, (int *)cnt, (double *)th, (double *)sl, efin);
                 c->t_end();
-                if (krc) break;
+                if (krc) return GMMIV_OK;
                 int *oi = o_idx.d + (size_t)c0 * ctop;
                 double *olk = o_lk.d ? o_lk.d + (size_t)c0 * ctop : nullptr, *onlk = o_nlk.d ? o_nlk.d + c0 : nullptr;
                 double *onllk = o_nllk.d ? o_nllk.d + c0 : nullptr, *onw = o_nw.d ? o_nw.d + c0 : nullptr, *ollk = o_llk.d ? o_llk.d + c0 : nullptr;
@@ -411,7 +417,7 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
                                      (const double *)th, (const double *)sl, efin, g->mean, g->iv, g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE,
                                      min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, (int *)flg, (long *)redo, stats);
                 c->t_end();
-                if (krc) break;
+                if (krc) return GMMIV_OK;
                 int hf[16] = {0};
                 GCHK(hipMemcpyAsync(hf, flg, 64, hipMemcpyDeviceToHost, c->stream));
                 GCHK(hipStreamSynchronize(c->stream));
@@ -421,14 +427,15 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
                             (double)*(unsigned long long *)&hf[10] / (double)n);
                 const int64_t nr = hf[0];
                 c->topc_fallbacks += nr;
-                if (nr == 0) continue;
-                if (nr > n / 8 + 64) { whole = true; break; }
+                if (nr == 0) return GMMIV_OK;
+                if (nr > n / 8 + 64) { whole = true; return GMMIV_OK; }
                 // the few frames whose list overflowed / piled up / failed the margin: direct form for every Gaussian
                 // (k_topc_determine) on a gathered copy, results scattered back
                 void *gx, *t_idx, *t_d;
-                if ((rc = c->scratch(WS_PART, (size_t)nr * g->D * esize(dt), &gx))) return rc;
-                if ((rc = c->scratch(WS_T6, (size_t)nr * ctop * sizeof(int), &t_idx))) return rc;
-                if ((rc = c->scratch(WS_T7, (size_t)nr * (ctop + 4) * sizeof(double), &t_d))) return rc;
+                int rc2;
+                if ((rc2 = c->scratch(WS_PART, (size_t)nr * g->D * esize(dt), &gx))) return rc2;
+                if ((rc2 = c->scratch(WS_T6, (size_t)nr * ctop * sizeof(int), &t_idx))) return rc2;
+                if ((rc2 = c->scratch(WS_T7, (size_t)nr * (ctop + 4) * sizeof(double), &t_d))) return rc2;
                 double *t_lk = (double *)t_d, *t_nlk = t_lk + (size_t)nr * ctop, *t_nllk = t_nlk + nr, *t_nw = t_nllk + nr, *t_llk = t_nw + nr;
                 GCHK(gmmk_gather_frames(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, (const long *)redo, nr, gx));
                 c->t_begin("k_topc_determine", c0 == 0);
@@ -437,6 +444,70 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
                 c->t_end();
                 GCHK(gmmk_topc_scatter(c->stream, nr, ctop, (const long *)redo, (const int *)t_idx, t_lk, t_nlk, t_nllk, t_nw, t_llk, oi, olk, onlk,
                                        onllk, onw, ollk));
+                return GMMIV_OK;
+            };
+            // Pipelined form (option "topc_overlap", OFF by default -- measured slower, see ctx.h; T > one sub-chunk): the ranking of sub-chunk i runs on a side stream
+            // BESIDE the log-likelihood kernel of sub-chunk i + 1 -- k_topc_rank is bound by L2 gathers and latency (2.25 ms per
+            // 10^6 frames), k_llk_mfma<TC> by the matrix cores (11.2 ms): two sets of candidate scratch, events between the streams,
+            // no host synchronisation inside the loop (the flag words of every sub-chunk land in pinned host memory and are looked at
+            // once, at the end; a sub-chunk with failed frames -- never observed on real data -- is simply run again through the serial
+            // form above).  Same kernels on the same frames: bitwise the results of the serial form.
+            if (pipelined) {
+                rc = c->topc_pipe_init((size_t)nsub);
+                if (rc) return rc;
+                void *cand2 = cand, *cnt2 = cnt, *th2 = th, *sl2 = sl, *redo2 = redo, *flg2 = flg; // the same scratch, cut in two sets
+                GCHK(hipMemsetAsync(flg2, 0, (size_t)nsub * 64, c->stream));
+                hipStream_t side = c->topc_side;
+                GCHK(hipEventRecord(c->topc_ev_k1[0], c->stream)); // everything enqueued so far (inputs, the memset) precedes the side stream's first kernel
+                GCHK(hipStreamWaitEvent(side, c->topc_ev_k1[0], 0));
+                for (int64_t i = 0; i < nsub && krc == 0; ++i) {
+                    const int set = (int)(i & 1);
+                    const int64_t c0 = i * SUB, n = (T - c0) < SUB ? (T - c0) : SUB;
+                    double *cand_s = (double *)cand2 + (size_t)set * SUB * (per_frame / 8);
+                    int *cnt_s = (int *)cnt2 + (size_t)set * SUB;
+                    double *th_s = (double *)th2 + (size_t)set * SUB;
+                    double *sl_s = (double *)sl2 + (size_t)set * SUB;                       // [2][SUB] doubles, then [2][SUB] ints
+                    int *ef_s = (int *)((double *)sl2 + 2 * SUB) + (size_t)set * SUB;
+                    long *redo_s = (long *)redo2 + (size_t)set * SUB;
+                    int *flg_s = (int *)flg2 + (size_t)i * 16;
+                    if (i >= 2) GCHK(hipStreamWaitEvent(c->stream, c->topc_ev_rank[set], 0)); // the set's previous ranking has read its candidates
+                    if (i == 0) c->t_begin("k_llk_mfma", true);
+                    krc = gmmk_llk_topc(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (int)c->use_glds,
+                                        ctop, cand_s, cnt_s, th_s, sl_s, ef_s);
+                    if (i == 0) c->t_end();
+                    if (krc) break;
+                    GCHK(hipEventRecord(c->topc_ev_k1[set], c->stream));
+                    GCHK(hipStreamWaitEvent(side, c->topc_ev_k1[set], 0));
+                    int *oi = o_idx.d + (size_t)c0 * ctop;
+                    double *olk = o_lk.d ? o_lk.d + (size_t)c0 * ctop : nullptr, *onlk = o_nlk.d ? o_nlk.d + c0 : nullptr;
+                    double *onllk = o_nllk.d ? o_nllk.d + c0 : nullptr, *onw = o_nw.d ? o_nw.d + c0 : nullptr, *ollk = o_llk.d ? o_llk.d + c0 : nullptr;
+                    krc = gmmk_topc_rank(side, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->C, cand_s, cnt_s, th_s, sl_s, ef_s, g->mean, g->iv,
+                                         g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, flg_s, redo_s, 0);
+                    if (krc) break;
+                    GCHK(hipMemcpyAsync(c->topc_hflags + (size_t)i * 16, flg_s, 64, hipMemcpyDeviceToHost, side));
+                    GCHK(hipEventRecord(c->topc_ev_rank[set], side));
+                }
+                // join: the context's stream continues behind the last rankings; the host looks at the flags
+                GCHK(hipStreamWaitEvent(c->stream, c->topc_ev_rank[0], 0));
+                GCHK(hipStreamWaitEvent(c->stream, c->topc_ev_rank[1], 0));
+                GCHK(hipStreamSynchronize(side));
+                GCHK(hipStreamSynchronize(c->stream));
+                if (krc == 0) {
+                    int64_t failed = 0;
+                    for (int64_t i = 0; i < nsub; ++i) failed += c->topc_hflags[(size_t)i * 16];
+                    if (failed > T / 8 + 64) { whole = true; c->topc_fallbacks += failed; }
+                    else
+                        for (int64_t i = 0; i < nsub && krc == 0 && !whole; ++i)
+                            if (c->topc_hflags[(size_t)i * 16] > 0) { // rare: this sub-chunk again, serially, with the redo of its failed frames
+                                const int64_t c0 = i * SUB, n = (T - c0) < SUB ? (T - c0) : SUB;
+                                if ((rc = run_chunk(c0, n))) return rc;
+                            }
+                }
+            } else {
+                for (int64_t c0 = 0; c0 < T && krc == 0 && !whole; c0 += Tf) {
+                    const int64_t n = (T - c0) < Tf ? (T - c0) : Tf;
+                    if ((rc = run_chunk(c0, n))) return rc;
+                }
             }
             if (krc > 0) GCHK(krc);
             done = krc == 0 && !whole;

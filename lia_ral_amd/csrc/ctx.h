@@ -58,6 +58,41 @@ struct gmmiv_ctx {
     // them back (stats_z.hip) instead of recomputing them; 0: the recomputing k_stats_mfma
     long stats_z = 1;
     long topc_fused = 1; // DETERMINE_TOP_DISTRIBS with the candidates collected inside k_llk_mfma<TC> (no likelihood round trip); 0: topc_z
+    // fused top-C, OPT-IN: rank sub-chunk i on a side stream beside the log-likelihood kernel of sub-chunk i + 1.  Measured SLOWER
+    // (10^6 frames: 13.48 -> 14.16 ms, 4 x 10^6: 52.3 -> 59.7): k_topc_rank's workgroups take LDS and wave slots from k_llk_mfma<TC>,
+    // which loses more than the 2.25 ms the ranking would have cost behind it.  Bitwise the serial results (tested); off.
+    long topc_overlap = 0;
+    hipStream_t topc_side = nullptr;
+    hipEvent_t topc_ev_k1[2] = {nullptr, nullptr}, topc_ev_rank[2] = {nullptr, nullptr};
+    int *topc_hflags = nullptr; // pinned: 16 flag words per sub-chunk
+    size_t topc_hflags_n = 0;
+    int topc_pipe_init(size_t nsub)
+    {
+        if (!topc_side) {
+            GCHK(hipStreamCreateWithFlags(&topc_side, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                GCHK(hipEventCreateWithFlags(&topc_ev_k1[i], hipEventDisableTiming));
+                GCHK(hipEventCreateWithFlags(&topc_ev_rank[i], hipEventDisableTiming));
+            }
+        }
+        if (topc_hflags_n < nsub) {
+            if (topc_hflags) { (void)hipHostFree(topc_hflags); topc_hflags = nullptr; topc_hflags_n = 0; }
+            GCHK(hipHostMalloc((void **)&topc_hflags, nsub * 64, hipHostMallocDefault));
+            topc_hflags_n = nsub;
+        }
+        memset(topc_hflags, 0, nsub * 64);
+        return GMMIV_OK;
+    }
+    void topc_pipe_free()
+    {
+        if (topc_side) {
+            (void)hipStreamSynchronize(topc_side);
+            for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(topc_ev_k1[i]); (void)hipEventDestroy(topc_ev_rank[i]); }
+            (void)hipStreamDestroy(topc_side);
+            topc_side = nullptr;
+        }
+        if (topc_hflags) { (void)hipHostFree(topc_hflags); topc_hflags = nullptr; topc_hflags_n = 0; }
+    }
     long topc_fallbacks = 0; // calls the fused path handed to the slower paths (list overflow / margin check); read with set_option
     long topc_z = 1;     // DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (topc_z.hip); 0: the direct-form VALU kernel
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)

@@ -457,3 +457,31 @@ def test_fused_top_c_redoes_piled_up_frames_exactly(ctx):
         assert np.array_equal(e["idx"], d["idx"]) and np.max(np.abs(e["llk"] - d["llk"])) < 1e-9
         assert np.max(np.abs(e["nontop_llk"] - d["nontop_llk"])) < 1e-9
     ctx.set_option("topc_fused", 1); ctx.set_option("topc_z", 1)
+
+
+def test_fused_top_c_pipelined_sub_chunks_are_bitwise_the_serial_form(ctx):
+    """gmmiv_llk_determine_top on more than one sub-chunk of 262 144 frames (option "topc_overlap"; off by default, it measured slower): the ranking of
+    sub-chunk i runs on a side stream beside the log-likelihood kernel of sub-chunk i + 1, two sets of candidate scratch, flags read once at
+    the end, sub-chunks with failed frames run again serially.  Same kernels on the same frames: every output is BITWISE the serial
+    form's, failed frames included (a few frames drawn from 100 identical low-weight Gaussians pile up more than 64 survivors), and the
+    frames around the sub-chunk boundaries agree with the oracle."""
+    C, D, T, ctop = 256, 60, 600_000, 10
+    w, mean, iv = make_gmm(C, D, seed=31)
+    mean[100:200] = mean[100]; iv[100:200] = iv[100]; w[100:200] = 5e-5; w /= w.sum()     # ~0.5 % of the frames come from the pile
+    x = make_frames(w, mean, iv, T, seed=32)
+    g = ctx.gmm(w, mean, iv)
+    out = {}
+    for ov in (0, 1):
+        ctx.set_option("topc_overlap", ov)
+        ctx.set_option("topc_fallbacks", 0)
+        out[ov] = g.llk_determine_top(x, ctop, True)
+        out[ov]["redone"] = ctx.set_option("topc_fallbacks", 0)
+    ctx.set_option("topc_overlap", 0)
+    for k in ("idx", "lk", "nontop_lk", "nontop_llk", "nontop_w", "llk"):
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert 0 < out[0]["redone"] == out[1]["redone"] < T // 8
+    rows = np.concatenate([np.arange(0, 1500), np.arange(262144 - 700, 262144 + 700), np.arange(524288 - 700, 524288 + 700), np.arange(T - 1500, T)])
+    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x[rows].astype(np.float64), ctop, True)
+    assert np.array_equal(out[1]["idx"][rows], do["idx"])
+    assert np.max(np.abs(out[1]["llk"][rows] - do["llk"])) < 1e-9 and relerr(out[1]["lk"][rows], do["lk"]) < 1e-10
+    g.close()
