@@ -236,9 +236,8 @@ class GpuTvOps:
     def recentre(self):
         """TotalVariability.cpp:123-124: the statistics are reloaded and substractM runs at the top of EVERY iteration --
         minDivergence has moved the UBM means since the last one."""
-        if self.F_raw is not None:
-            self.F.copy_(self.F_raw)                                    # TVAcc::restoreStats
-            self.ctx.tv_subtract_m(self.N, self.F, self.means, C, D)    # TVAcc::substractM with the current means
+        if self.F_raw is not None:                                      # TVAcc::restoreStats + substractM with the current means, one pass
+            self.ctx.tv_subtract_m_to(self.N, self.F_raw, self.F, self.means, C, D)
 
     def tett(self):
         self.ctx.tv_tett(self.T, self.invvar, C, D, out=self.tett_buf)

@@ -213,6 +213,11 @@ int gmmiv_tv_stats_lines(gmmiv_ctx *ctx, const gmmiv_gmm *g, const void *x, int 
  */
 int gmmiv_tv_subtract_m(gmmiv_ctx *ctx, int64_t U, int C, int D, const double *N, double *F,
                         const double *ubm_means);
+/* F_dst = F_src - N ubm_means, out of place (F_dst may be F_src): TotalVariability reloads N / F and calls substractM at the top of
+ * every iteration (TotalVariability.cpp:123-124, substractM works in place); with the pristine statistics kept in HBM the restore
+ * and the centring are ONE pass over F instead of a copy and a read-modify-write. */
+int gmmiv_tv_subtract_m_to(gmmiv_ctx *ctx, int64_t U, int C, int D, const double *N, const double *F_src, double *F_dst,
+                           const double *ubm_means);
 size_t gmmiv_tv_packed_len(int R);
 int gmmiv_tv_tett(gmmiv_ctx *ctx, int C, int D, int R, const double *Tm, const double *invvar,
                   double *tett_packed);

@@ -214,6 +214,11 @@ class Context:
         _chk(lib.gmmiv_tv_subtract_m(self._h, ct.c_int64(U), C, D, _ptr(N), _ptr(F), _ptr(means)))
         return F
 
+    def tv_subtract_m_to(self, N, F_src, F_dst, means, C, D):
+        """F_dst = F_src - N means (restoreStats + substractM in one pass); F_dst may be F_src."""
+        _chk(lib.gmmiv_tv_subtract_m_to(self._h, ct.c_int64(N.shape[0]), C, D, _ptr(N), _ptr(F_src), _ptr(F_dst), _ptr(means)))
+        return F_dst
+
     def tv_tett(self, Tm, invvar, C, D, out=None):
         R = Tm.shape[0]
         if out is None:

@@ -168,6 +168,30 @@ int gmmiv_tv_subtract_m(gmmiv_ctx *c, int64_t U, int C, int D, const double *N, 
     return o_f.finish();
 }
 
+// F_dst = F_src - N ubm_means: restoreStats + substractM of a TotalVariability iteration in one pass over the statistics
+int gmmiv_tv_subtract_m_to(gmmiv_ctx *c, int64_t U, int C, int D, const double *N, const double *F_src, double *F_dst, const double *means)
+{
+    if (!c || U < 0 || C <= 0 || D <= 0 || !N || !F_src || !F_dst || !means) { gmmiv_set_error("tv_subtract_m_to: bad argument"); return GMMIV_ERR_ARG; }
+    GBIND(c);
+    const size_t SV = (size_t)C * D;
+    DevIn<double> i_n, i_m, i_f;
+    DevOut<double> o_f;
+    int rc;
+    if ((rc = i_n.init(c, WS_T0, N, (size_t)U * C))) return rc;
+    if ((rc = i_m.init(c, WS_T1, means, SV))) return rc;
+    if ((rc = i_f.init(c, WS_T3, F_src, (size_t)U * SV))) return rc;
+    if ((rc = o_f.init(c, WS_T2, F_dst, (size_t)U * SV, false))) return rc;
+    c->t_begin("k_subtract_m");
+    int krc = tvk_subtract_m_to(c->stream, U, C, D, i_n.d, i_f.d, o_f.d, i_m.d);
+    if (krc < 0) { // odd vectSize or unaligned rows: copy, then the in-place kernel
+        if (o_f.d != i_f.d) GCHK(hipMemcpyAsync(o_f.d, i_f.d, (size_t)U * SV * 8, hipMemcpyDeviceToDevice, c->stream));
+        krc = tvk_subtract_m(c->stream, U, C, D, i_n.d, o_f.d, i_m.d);
+    }
+    GCHK(krc);
+    c->t_end();
+    return o_f.finish();
+}
+
 int gmmiv_tv_tett(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const double *invvar, double *tett_packed)
 {
     if (!c || C <= 0 || D <= 0 || R <= 0 || !Tm || !invvar || !tett_packed) { gmmiv_set_error("tv_tett: bad argument"); return GMMIV_ERR_ARG; }

@@ -13,6 +13,7 @@ int tvk_chol_solve_multi_batched(hipStream_t st, int n, int nb, int nrhs, const 
                                  long sB, double *X, long ldx, long sX); // -1: nrhs > 64 or odd n (use the explicit inverse)
 int tvk_trinv_left_batched(hipStream_t st, int n, int nb, const double *Lf, const double *invd, double *U);      // U = L^-T (chol_fused.hip)
 int tvk_uut_packed_batched(hipStream_t st, int n, int nb, const double *U, const double *w, double *P, long sp); // P = packed(U U^T + w w^T)
+int tvk_subtract_m_to(hipStream_t st, long U, int C, int D, const double *N, const double *Fs, double *Fd, const double *means); // -1: odd D / unaligned
 int tvk_chol_accepts_packed(int n); // 1 when the batched factorisation can read packed lower rows directly
 // (the A/B switches "chol_gemm", "chol_lds", "gemm_clamp", "gemm_narrow", "gemm_remap" are options of the calling context:
 //  ctx.h, gmmiv_kopts -- the launchers read gmmiv_kopts_cur())

@@ -463,6 +463,27 @@ __global__ void k_subtract_m(long U, int C, int D, const double *__restrict__ N,
     }
 }
 
+// Fd[u,c,:] = Fs[u,c,:] - mean[c,:] * N[u,c]: restore + substractM in ONE pass (TotalVariability reloads F and centres it at the
+// top of every iteration; the copy-then-subtract pair moved the statistics twice).  One thread per 16-byte pair, D even.
+__global__ void k_subtract_m_to(long U, int C, int D, const double *__restrict__ N, const double *__restrict__ Fs, double *__restrict__ Fd,
+                                const double *__restrict__ means)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const size_t SV2 = (size_t)C * D / 2, tot = (size_t)U * SV2;
+    const unsigned D2 = (unsigned)D / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t u = e / SV2;
+        const unsigned k2 = (unsigned)(e - u * SV2);
+        const double n = N[u * C + k2 / D2];
+        const d2 m = *(const d2 *)(means + 2 * (size_t)k2);
+        const d2 f = __builtin_nontemporal_load((const d2 *)(Fs + 2 * e));
+        d2 o;
+        o[0] = f[0] - m[0] * n;
+        o[1] = f[1] - m[1] * n;
+        *(d2 *)(Fd + 2 * e) = o;
+    }
+}
+
 // out[i][k] = in[i][k] * scale[k]
 __global__ void k_scale_cols(long rows, long cols, const double *__restrict__ in, const double *__restrict__ scale,
                              double *__restrict__ out)
@@ -1078,6 +1099,13 @@ int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double
 {
     if (U <= 0) return 0;
     k_subtract_m<<<2048, 256, 0, st>>>(U, C, D, N, F, means);
+    return (int)hipGetLastError();
+}
+int tvk_subtract_m_to(hipStream_t st, long U, int C, int D, const double *N, const double *Fs, double *Fd, const double *means)
+{
+    if (U <= 0) return 0;
+    if ((D & 1) || (((uintptr_t)Fs | (uintptr_t)Fd | (uintptr_t)means) & 15)) return -1; // the caller copies + subtracts in place
+    k_subtract_m_to<<<4096, 256, 0, st>>>(U, C, D, N, Fs, Fd, means);
     return (int)hipGetLastError();
 }
 int tvk_scale_cols(hipStream_t st, long rows, long cols, const double *in, const double *scale, double *out)

@@ -394,8 +394,8 @@ int liagpu_tv_train(int device, long U, int C, int D, const double *w, const dou
         tv.setStats(N, F);         // one upload; everything below stays on the device until getT()
         tv.storeStats();
         for (int it = 0; it < nbIt; ++it) {
-            if (it) tv.restoreStats();   // the reference reloads N and F from disk every iteration (:152-153): device-to-device here
-            tv.substractM();
+            if (it) tv.restoreStatsAndSubstractM(); // the reference reloads N and F from disk every iteration (:152-153) and centres
+            else tv.substractM();                   // them in place: one device pass over F here
             tv.estimateTETt();
             tv.estimateAandC();
             tv.updateTestimate();
@@ -478,8 +478,8 @@ int liagpu_tv_train_dist2(int device, int world, int rank, const char *id_file, 
         auto now = [&]() { srv.check(gmmiv_ctx_sync(srv.ctx())); return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         for (int it = 0; it < nbIt; ++it) {
-            if (it) tv.restoreStats();
-            tv.substractM();
+            if (it) tv.restoreStatsAndSubstractM();
+            else tv.substractM();
             auto t0 = now();
             tv.estimateTETt();
             auto t1 = now();

@@ -765,6 +765,14 @@ void TVAcc::restoreStats()
     if (_cN.size() != _statN.size() || _cF.size() != _statF.size()) throw Exception("TVAcc::restoreStats: nothing stored");
     _statN.copyFrom(_cN); _statF.copyFrom(_cF);
 }
+// restoreStats() + substractM() of an iteration (TotalVariability.cpp:123-124) in one pass over F: F = stored F - N m
+void TVAcc::restoreStatsAndSubstractM()
+{
+    if (_cN.size() != _statN.size() || _cF.size() != _statF.size()) throw Exception("TVAcc::restoreStatsAndSubstractM: nothing stored");
+    _statN.copyFrom(_cN);
+    _srv.check(gmmiv_tv_subtract_m_to(_srv.ctx(), (int64_t)_n_speakers, (int)_n_distrib, (int)_vectSize, _statN.cdev(), _cF.cdev(), _statF.dev(),
+                                      _ubm_means.cdev()));
+}
 
 void TVAcc::setOverlap(gmmiv_comm *comm)
 {

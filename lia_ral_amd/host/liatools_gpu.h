@@ -317,6 +317,7 @@ class TVAcc {
     // (TotalVariability.cpp:152-153); here the pristine statistics are kept on the device instead
     void storeStats();
     void restoreStats();
+    void restoreStatsAndSubstractM();  // both steps of an iteration's start in one pass over F (gmmiv_tv_subtract_m_to)
     // Multi-GPU form of updateTestimate for utterance-sharded statistics: reduce-scatter of A / Cmx by blocks
     // of Gaussians, T_c = A_c^-1 Cmx_c on the rank's own Gaussians, all-gather of T; R, r and meanW (sums) are all-reduced
     // for minDivergence, whose session count becomes the global one.  comm == NULL or one rank: plain updateTestimate.

@@ -39,6 +39,13 @@ def test_ivector_extraction(ctx, C, D, R, U):
     p = tv_problem(C, D, R, U, seed=R)
     F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
     Fg = ctx.tv_subtract_m(p["N"], p["F"].copy(), p["mean"].ravel(), C, D)
+    # restore + substractM in one pass (gmmiv_tv_subtract_m_to): out of place and in place, host and device arrays, bitwise the two-step result
+    assert np.array_equal(ctx.tv_subtract_m_to(p["N"], p["F"], np.empty_like(p["F"]), p["mean"].ravel(), C, D), Fg)
+    import torch
+    Fd = torch.from_numpy(p["F"].copy()).cuda()
+    ctx.tv_subtract_m_to(torch.from_numpy(p["N"]).cuda(), Fd, Fd, torch.from_numpy(p["mean"].ravel().copy()).cuda(), C, D)
+    torch.cuda.synchronize(); ctx.sync()
+    assert np.array_equal(Fd.cpu().numpy(), Fg)
     assert relerr(Fg, F0) < 1e-13
     invvar = p["iv"].ravel()
     te_o = orc.tv_tett(p["Tm"], invvar, C, D)
