@@ -339,7 +339,7 @@ def max_over_ranks(dt, world, dev):
     return float(tt.item())
 
 
-def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False):
+def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False, force=False):
     """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
     then `steps` EM iterations timed, each the tool's full sequence: restore + substractM, estimateTETt, estimateAandC,
     updateTestimate (sharded), minDivergence.  Returns the JSON fields of the workload."""
@@ -369,13 +369,13 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
-        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, overlap=overlap)
+        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, overlap=overlap, force_collectives=force)
     coll.take_bytes()
     phases = {"sync": torch.cuda.synchronize}
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases, overlap=overlap)
+        gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases, overlap=overlap, force_collectives=force)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     nbytes = coll.take_bytes() / max(steps, 1)
@@ -394,7 +394,7 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
                    "partitioning": "utterances sharded per rank; reduce-scatter of A_packed / Cmx by Gaussian blocks, sharded "
                                    "updateTestimate, all-gather of T, all-reduce of R / r / meanW"},
         "phases_ms": ph, "collective_bytes_per_step_per_rank": nbytes, "collectives": coll.name,
-        "overlap": bool(overlap and world > 1 and getattr(coll, "supports_overlap", False)),
+        "overlap": bool(overlap and (world > 1 or force) and getattr(coll, "supports_overlap", False)),
         "statistics_once_s": t_stats, "finite": finite,
         "roofline": {"bound": "mfma", "kernel": "E-step (k_dgemm: L, aux, A, Cmx + chol_fused)", "achieved": estep_tf, "peak": PEAK_F64_TFLOPS,
                      "unit": "TFLOP/s", "frac": estep_tf / PEAK_F64_TFLOPS, "traffic": None,
@@ -443,6 +443,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=0,
                     help="T-matrix EM: 1 = the reduce-scatter of A starts inside the E-step (under the Cmx GEMM), the all-gather of T is joined "
                          "inside minDivergence (gmmiv_*_begin / gmmiv_comm_join; bitwise the serial results)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="one rank only: build the communicator through RCCL anyway (GMMIV_COMM_FORCE_RCCL=1) and walk the sharded "
+                         "exchange of the T-matrix workload with it -- every RCCL call of the step executes on this one GPU")
     ap.add_argument("--share-gpu", action="store_true",
                     help="correctness mode: let the ranks share the visible GPU(s) (rank r on device r %% count) over the C ABI's shm transport")
     args = ap.parse_args()
@@ -496,6 +499,9 @@ def main():
     if args.em_fused >= 0:
         ctx.set_option("em_fused", args.em_fused)
     g = ctx.gmm(w, mean, iv)
+    force = bool(args.force_collectives and world == 1)
+    if force:
+        os.environ["GMMIV_COMM_FORCE_RCCL"] = "1"
     coll, coll_note = make_collectives(ctx, dev, world, rank, args.collectives, "shm" if shared else None)
     if coll.world != world:
         print("bench.py: the communicator spans %d rank(s), the job %d" % (coll.world, world), file=sys.stderr, flush=True)
@@ -507,7 +513,7 @@ def main():
     check = not args.no_cpu_baseline
     if args.workload == "tv":
         res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup,
-                          check=check, cpu=(world == 1), overlap=bool(args.overlap))
+                          check=check, cpu=(world == 1), overlap=bool(args.overlap), force=force)
         if rank == 0:
             res["comm"] = comm_info
             if coll_note:

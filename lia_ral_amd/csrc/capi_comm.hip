@@ -172,6 +172,7 @@ struct gmmiv_comm {
         return GMMIV_OK;
     }
     bool is_shm() const { return shm != nullptr; }
+    bool local() const { return world == 1 && !nc; } // one rank and no collective library behind it: every collective is an identity / a copy
     double *slot(int r) const { return (double *)((char *)shm + SHM_HDR_BYTES + (size_t)r * shm->slot_bytes); }
     size_t slot_elems() const { return (size_t)(shm->slot_bytes / 8); }
     int fail(const char *what)
@@ -485,7 +486,7 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
     gmmiv_comm *c = new gmmiv_comm();
     c->ctx = ctx; c->world = world; c->rank = rank;
     if (const char *t = getenv("GMMIV_COMM_TIMEOUT_S")) { if (atof(t) > 0) c->timeout_s = atof(t); }
-    if (world > 1 && memcmp(id128, SHM_MAGIC, 8) == 0) {
+    if (world > 1 && id128 && memcmp(id128, SHM_MAGIC, 8) == 0) {
         char path[GMMIV_COMM_ID_BYTES - 8 + 1];
         memcpy(path, (const char *)id128 + 8, GMMIV_COMM_ID_BYTES - 8);
         path[GMMIV_COMM_ID_BYTES - 8] = 0;
@@ -496,11 +497,18 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
             delete c;
             return rc;
         }
-    } else if (world > 1) {
+    } else if (world > 1 || (getenv("GMMIV_COMM_FORCE_RCCL") && *getenv("GMMIV_COMM_FORCE_RCCL") == '1')) {
+        // (GMMIV_COMM_FORCE_RCCL=1: a ONE-rank communicator goes through RCCL as well -- every entry point below then executes its
+        //  RCCL call, side stream and events included, on a one-GPU machine: the check that the dlopen'ed symbols, data types and
+        //  stream arguments are right before a multi-GPU node ever sees them)
         c->api = rccl();
         if (!c->api) { delete c; return GMMIV_ERR_UNSUPPORTED; }
         ncclUniqueId id;
-        memcpy(&id, id128, sizeof(id));
+        if (id128) memcpy(&id, id128, sizeof(id));
+        else { // one forced rank without an id: draw it here
+            ncclResult_t gr = c->api->GetUniqueId(&id);
+            if (gr != ncclSuccess) { gmmiv_set_error("ncclGetUniqueId -> %s", c->api->GetErrorString(gr)); delete c; return GMMIV_ERR_HIP; }
+        }
         ncclResult_t r = c->api->CommInitRank(&c->nc, world, id, rank);
         if (r != ncclSuccess) {
             gmmiv_set_error("ncclCommInitRank(world %d, rank %d, device %d) -> %s", world, rank, ctx->device, c->api->GetErrorString(r));
@@ -532,7 +540,7 @@ int gmmiv_comm_rank(const gmmiv_comm *c) { return c ? c->rank : -1; }
 const char *gmmiv_comm_backend(const gmmiv_comm *c)
 {
     if (!c) return "";
-    return c->world == 1 ? "single rank (no collective library)" : c->backend.c_str();
+    return c->local() ? "single rank (no collective library)" : c->backend.c_str();
 }
 double gmmiv_comm_take_bytes(gmmiv_comm *c)
 {
@@ -547,7 +555,7 @@ int gmmiv_allreduce_f64(gmmiv_comm *c, double *buf, size_t n)
 {
     if (!c || !c->ctx || (!buf && n)) { gmmiv_set_error("allreduce_f64: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)n * 8;
-    if (c->world == 1 || n == 0) return GMMIV_OK;
+    if (c->local() || n == 0) return GMMIV_OK;
     GCHK(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     if (gmmiv_is_device_ptr(buf)) {
@@ -575,7 +583,7 @@ int gmmiv_reduce_scatter_f64(gmmiv_comm *c, const double *send, double *recv, si
     if (recvcount == 0) return GMMIV_OK;
     if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("reduce_scatter_f64: device buffers only"); return GMMIV_ERR_ARG; }
     GCHK(hipSetDevice(c->ctx->device));
-    if (c->world == 1) {
+    if (c->local()) {
         if (recv != send) GCHK(hipMemcpyAsync(recv, send, recvcount * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
         return GMMIV_OK;
     }
@@ -592,7 +600,7 @@ int gmmiv_allgather_f64(gmmiv_comm *c, const double *send, double *recv, size_t 
     if (sendcount == 0) return GMMIV_OK;
     if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("allgather_f64: device buffers only"); return GMMIV_ERR_ARG; }
     GCHK(hipSetDevice(c->ctx->device));
-    if (c->world == 1) {
+    if (c->local()) {
         if (recv != send) GCHK(hipMemcpyAsync(recv, send, sendcount * 8, hipMemcpyDeviceToDevice, c->ctx->stream));
         return GMMIV_OK;
     }
@@ -606,7 +614,7 @@ int gmmiv_allgather_f64(gmmiv_comm *c, const double *send, double *recv, size_t 
 int gmmiv_allreduce_f64_begin(gmmiv_comm *c, double *buf, size_t n)
 {
     if (!c || !c->ctx || (!buf && n)) { gmmiv_set_error("allreduce_f64_begin: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
-    if (c->world == 1 || n == 0 || c->is_shm()) return gmmiv_allreduce_f64(c, buf, n);
+    if (c->local() || n == 0 || c->is_shm()) return gmmiv_allreduce_f64(c, buf, n);
     if (!gmmiv_is_device_ptr(buf)) { gmmiv_set_error("allreduce_f64_begin: device buffers only"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)n * 8;
     GCHK(hipSetDevice(c->ctx->device));
@@ -619,7 +627,7 @@ int gmmiv_allreduce_f64_begin(gmmiv_comm *c, double *buf, size_t n)
 int gmmiv_reduce_scatter_f64_begin(gmmiv_comm *c, const double *send, double *recv, size_t recvcount)
 {
     if (!c || !c->ctx || ((!send || !recv) && recvcount)) { gmmiv_set_error("reduce_scatter_f64_begin: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
-    if (c->world == 1 || recvcount == 0 || c->is_shm()) return gmmiv_reduce_scatter_f64(c, send, recv, recvcount);
+    if (c->local() || recvcount == 0 || c->is_shm()) return gmmiv_reduce_scatter_f64(c, send, recv, recvcount);
     if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("reduce_scatter_f64_begin: device buffers only"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)recvcount * 8 * c->world;
     GCHK(hipSetDevice(c->ctx->device));
@@ -632,7 +640,7 @@ int gmmiv_reduce_scatter_f64_begin(gmmiv_comm *c, const double *send, double *re
 int gmmiv_allgather_f64_begin(gmmiv_comm *c, const double *send, double *recv, size_t sendcount)
 {
     if (!c || !c->ctx || ((!send || !recv) && sendcount)) { gmmiv_set_error("allgather_f64_begin: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
-    if (c->world == 1 || sendcount == 0 || c->is_shm()) return gmmiv_allgather_f64(c, send, recv, sendcount);
+    if (c->local() || sendcount == 0 || c->is_shm()) return gmmiv_allgather_f64(c, send, recv, sendcount);
     if (!gmmiv_is_device_ptr(send) || !gmmiv_is_device_ptr(recv)) { gmmiv_set_error("allgather_f64_begin: device buffers only"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)sendcount * 8 * c->world;
     GCHK(hipSetDevice(c->ctx->device));
@@ -657,7 +665,7 @@ int gmmiv_broadcast_f64(gmmiv_comm *c, double *buf, size_t n, int root)
 {
     if (!c || !c->ctx || (!buf && n) || root < 0 || root >= c->world) { gmmiv_set_error("broadcast_f64: bad argument (or the context was destroyed)"); return GMMIV_ERR_ARG; }
     c->bytes_moved += (double)n * 8;
-    if (c->world == 1 || n == 0) return GMMIV_OK;
+    if (c->local() || n == 0) return GMMIV_OK;
     GCHK(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     if (gmmiv_is_device_ptr(buf)) {

@@ -251,7 +251,7 @@ def block_size(C, world):
     return (int(C) + int(world) - 1) // int(world)
 
 
-def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=None):
+def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=None, force_collectives=False):
     """Distributed M-step of the T-matrix EM, the layout SURVEY.md 8(e) prefers.  T_c = A_c^-1 Cmx_c is independent per
     Gaussian (TVAcc::updateTestimate, AccumulateTVStat.cpp:981-1000), so rank g OWNS the Gaussians [g Cb, (g+1) Cb),
     Cb = ceil(C / world):
@@ -288,8 +288,8 @@ def tv_mstep_sharded(acc, update_t, C, D, rank=0, world=1, coll=None, phases=Non
     for k in ("Rm", "r", "meanW"):
         t = _as_tensor(acc[k])
         t.copy_(small[o:o + t.numel()].view_as(t)); o += t.numel()
-    if world == 1:
-        t0 = stamp("reduce_scatter", t0)
+    if world == 1 and not force_collectives:   # (force_collectives: one rank still walks the exchange -- a one-rank RCCL communicator
+        t0 = stamp("reduce_scatter", t0)       #  then executes every collective of the step on a one-GPU machine)
         Tn = update_t(acc["A"], acc["Cmx"], C)
         stamp("update_t", t0)
         return Tn
@@ -397,7 +397,7 @@ def _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, 
     return Tn
 
 
-def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, phases=None, overlap=False):
+def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, phases=None, overlap=False, force_collectives=False):
     """One full iteration of TotalVariability's EM on utterance-sharded statistics (TotalVariability.cpp:118-169 around
     TVAcc, AccumulateTVStat.cpp): every rank holds the statistics N / F of its own utterances and the full T.
       ops.recentre()                      (optional) restore the raw first-order statistics and substractM with the CURRENT UBM
@@ -414,6 +414,9 @@ def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, pha
     stream libgmmiv launches on, in program order with its kernels and collectives.
     overlap = True (GmmivCollectives only): the reduce-scatter of A starts inside the E-step and the all-gather of T is joined
     inside minDivergence (_tv_overlapped); bitwise the same T and means as the serial order.
+    force_collectives = True: a single rank walks the sharded exchange too (one block of all Gaussians) instead of calling
+    update_t directly -- with a one-rank RCCL communicator (GMMIV_COMM_FORCE_RCCL=1) the whole step, overlapped or not, then runs its
+    RCCL calls on a one-GPU machine.
     Returns the new T.  phases collects per-phase seconds ("recentre", "tett", "estep", "reduce_scatter", "update_t",
     "allgather", "min_divergence")."""
     import contextlib
@@ -434,11 +437,11 @@ def tv_em_iteration(ops, n_sessions_total, C, D, rank=0, world=1, coll=None, pha
             t0 = lap("recentre", t0)
         ops.tett()
         t0 = lap("tett", t0)
-        if overlap and world > 1 and getattr(coll, "supports_overlap", False) and hasattr(ops, "ctx") and hasattr(ops, "acc"):
+        if overlap and (world > 1 or force_collectives) and getattr(coll, "supports_overlap", False) and hasattr(ops, "ctx") and hasattr(ops, "acc"):
             return _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, t0)
         acc = ops.estep()
         t0 = lap("estep", t0)
-        Tn = tv_mstep_sharded(acc, ops.update_t, C, D, rank, world, coll, phases)
+        Tn = tv_mstep_sharded(acc, ops.update_t, C, D, rank, world, coll, phases, force_collectives)
         t0 = time.perf_counter()
         Tn = ops.min_divergence(acc, Tn, n_sessions_total)
         lap("min_divergence", t0)

@@ -145,6 +145,82 @@ def test_iteration_hooks_and_begin_join_single_rank():
     comm.close(); ctx.close()
 
 
+def test_every_rccl_entry_point_executes_with_one_rank(monkeypatch):
+    """GMMIV_COMM_FORCE_RCCL=1: a ONE-rank communicator is built through RCCL (ncclGetUniqueId, ncclCommInitRank) and every collective
+    of the ABI -- plain and overlapped (side stream, fork / join events), device and host buffers -- executes its RCCL call on the one
+    GPU of this box: the dlopen'ed symbols, data-type / reduction enums and stream arguments are exercised before a multi-GPU node ever
+    sees them.  With one rank every collective must return its input."""
+    import torch
+    from lia_ral_amd import capi
+    monkeypatch.setenv("GMMIV_COMM_FORCE_RCCL", "1")
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    comm = capi.Comm(ctx, 1, 0)
+    assert comm.world == 1 and "rccl" in comm.backend(), comm.backend()
+    n = 1 << 20
+    a = torch.randn(n, dtype=torch.float64, device="cuda")
+    ref = a.clone()
+    comm.allreduce(a)
+    out = torch.zeros_like(a)
+    comm.reduce_scatter(a, out)
+    g = torch.zeros_like(a)
+    comm.allgather(out, g)
+    comm.broadcast(g, 0)
+    h = np.arange(1000.0)
+    comm.allreduce(h); comm.broadcast(h, 0)
+    torch.cuda.synchronize(); ctx.sync()
+    assert torch.equal(a, ref) and torch.equal(out, ref) and torch.equal(g, ref) and np.array_equal(h, np.arange(1000.0))
+    # overlapped forms: the collective runs on the side stream behind the kernel enqueued before it, the join orders the rest behind it
+    b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    b.add_(ref)                                   # enqueued BEFORE the begin: the collective must see it
+    out2 = torch.zeros_like(b); g2 = torch.zeros_like(b)
+    comm.allreduce_begin(b)
+    comm.reduce_scatter_begin(b, out2)
+    comm.allgather_begin(out2, g2)
+    comm.join()
+    s = g2.sum()                                  # enqueued AFTER the join: must see the gathered data
+    torch.cuda.synchronize()
+    assert torch.equal(g2, ref) and float(s) == float(ref.sum())
+    assert comm.take_bytes() == (4 * n + 2 * 1000 + 3 * n) * 8
+    comm.close(); ctx.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_tv_iteration_through_one_rank_rccl(overlap, monkeypatch):
+    """The sharded TotalVariability iteration of lia_ral_amd.dist with a ONE-rank RCCL communicator (GMMIV_COMM_FORCE_RCCL=1,
+    force_collectives): small all-reduce, reduce-scatter of A and Cmx, all-gather of T all go through RCCL on this GPU -- in the
+    overlapped order the reduce-scatter of A really runs on the communicator's side stream while `Cmx += W^T F` runs on the context's,
+    started from the "tv_a_ready" hook, and the all-gather is joined from "md_factored".  Two iterations: bitwise the T and means of
+    the plain single-rank iteration (which calls update_t directly) -- for a single rank the exchange is the identity."""
+    import torch
+    from lia_ral_amd import capi
+    from lia_ral_amd import dist as gd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_multirank import DeviceTvOps, _case
+    C, D, R, U, w, mean, iv, N, F, Tm, x = _case()
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            ctx = capi.Context(0, side.cuda_stream)
+            plain = DeviceTvOps(ctx, C, D, R, N, F, Tm, iv, mean)
+            local = gd.GmmivCollectives(capi.Comm(ctx, 1, 0))
+            for _ in range(2):
+                T0 = gd.tv_em_iteration(plain, U, C, D, 0, 1, local)
+            monkeypatch.setenv("GMMIV_COMM_FORCE_RCCL", "1")
+            coll = gd.GmmivCollectives(capi.Comm(ctx, 1, 0))
+            assert "rccl" in coll.name
+            ops = DeviceTvOps(ctx, C, D, R, N, F, Tm, iv, mean)
+            for _ in range(2):
+                ph = {}
+                T1 = gd.tv_em_iteration(ops, U, C, D, 0, 1, coll, ph, overlap=overlap, force_collectives=True)
+            torch.cuda.synchronize()
+            assert {"reduce_scatter", "update_t", "allgather", "min_divergence"} <= set(ph)
+            assert coll.take_bytes() > 0
+            assert torch.equal(T1, T0) and torch.equal(ops.means, plain.means)
+            ctx.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+
+
 def _rank_main(rank, world, idfile, q):
     sys.path.insert(0, ROOT)
     import torch
