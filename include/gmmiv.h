@@ -76,6 +76,8 @@ const char *gmmiv_version(void);
  *                      (one GEMM per super-batch, K = its utterances, instead of one per tv_batch)
  *   "chol_gemm" 0      1: the GEMM-built right-looking batched Cholesky / inverse instead of chol_fused.hip (always
  *                      used for odd orders); A/B switch (like "gemm_remap", "gemm_clamp", "gemm_narrow", "z_tv4")
+ *   "gemm_nt80" 1      split-K NT products whose N is a multiple of 80 but not of 128 (aux = F (T Sigma^-1)^T at rank 400) on 128 x 80
+ *                      tiles instead of 128 x 128 tiles + a 16-column strip; 0: the latter (A/B switch)
  *   "chol_lds" 1       chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
  *   "chol_flow" 1      batched Cholesky k_chol_left2 (panel staged first, diagonal update from LDS on all waves); 0: round 2's k_chol_left
  *   "kopts_bound"      read-only: 1 when this context's kernel-launcher options are the set bound to the calling thread (they are

@@ -119,6 +119,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "gemm_remap")) ks = &c->ko.gemm_remap;   // A/B knob: 0 = hardware tile order in k_dgemm
     else if (!strcmp(key, "gemm_clamp")) ks = &c->ko.gemm_clamp;   // A/B knob: 0 = cut GEMM tiles on the per-element checked instantiation
     else if (!strcmp(key, "gemm_narrow")) ks = &c->ko.gemm_narrow; // A/B knob: 0 = 128 x 128 tiles on the strips cut by M / N too
+    else if (!strcmp(key, "gemm_nt80")) ks = &c->ko.gemm_nt80;     // A/B knob: 0 = no 128 x 80 tiles for N = 5 x 80 (aux at rank 400)
     else if (!strcmp(key, "chol_lds")) ks = &c->ko.chol_lds;       // 0 = panel rows from memory per wave
     else if (!strcmp(key, "chol_gemm")) ks = &c->ko.chol_gemm;     // the GEMM-built batched Cholesky instead of k_chol_left
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)

@@ -1,6 +1,7 @@
 // tv_kernels.hip -- fp64 building blocks of the i-vector path on gfx950: a strided-batched MFMA
 // GEMM (v_mfma_f64_16x16x4_f64, LDS-tiled 128x128x16), a batched blocked Cholesky / SPD inverse
 // built from it, and the small element-wise / packing kernels around them.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "devutil.h"
@@ -35,24 +36,32 @@ struct DgemmEpi { const double *rv, *cv; double br, bc, cst; int mode; int remap
 // M or N cut off a 128-multiple (MODE 2 only): 1 x 4 (32 x 128) below, 4 x 1 (128 x 32) to the right -- with R = 400 = 3 x 128 + 16
 // a 128-row strip tile spends 7/8 of its MFMAs on clamped duplicates (Cmx += W^T F at 400 x 122880 x 1024: 2.04 ms against 1.55 ms
 // for 384 rows).
-template <bool TA, bool TB, int MODE, int AM = 4, int AN = 4>
+// WM x WN: the wave grid of the workgroup (2 x 2 everywhere but one shape).  <AM 2, AN 5, WM 4, WN 1> is a 128 x 80 tile for NT products
+// whose N is a multiple of 80 but not of 128 -- R = 400 = 5 x 80: `aux = F (T Sigma^-1)^T` (1024 x 400 x 122880, split-K) ran three
+// 128-wide tile columns plus a 16-column strip that re-read all of F beside the interior grid (2.0 ms where the interior alone takes
+// 1.5); with 80-wide tiles there is no strip.  The B tile is staged 96 rows wide (three passes of 32 rows, the last one clamped to
+// the tile's own last row) because the XOR swizzle moves a column inside its group of 32.
+template <bool TA, bool TB, int MODE, int AM = 4, int AN = 4, int WM = 2, int WN = 2>
 __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                   long lda, long sA, const double *__restrict__ B, long ldb, long sB,
                                                   double beta, double *__restrict__ C, long ldc, long sC, int ksplit, int m_off, int n_off,
                                                   DgemmEpi epi)
 {
-    constexpr int BM = 32 * AM, BN = 32 * AN, BK = 16;
-    static_assert(MODE == 2 || (AM == 4 && AN == 4), "narrow tiles exist for the clamped strips only");
-    constexpr int NLA = BM / 32, NLB = BN / 32;           // 16-byte staging loads per thread and k-tile
+    constexpr int BM = 16 * AM * WM, BN = 16 * AN * WN, BK = 16;
+    constexpr int BNP = (BN + 31) / 32 * 32;              // staged width of the B tile (whole passes of 32 rows / columns)
+    static_assert(WM * WN == 4, "four waves");
+    static_assert(MODE == 2 || (AM == 4 && AN == 4) || (WM == 4 && WN == 1), "narrow tiles exist for the clamped strips only");
+    static_assert((WM == 2 && WN == 2) || (MODE == 0 && !TA && TB && BM % 32 == 0), "the 4 x 1 wave grid serves interior NT tiles");
+    constexpr int NLA = BM / 32, NLB = BNP / 32;          // 16-byte staging loads per thread and k-tile
     constexpr int HA = BM / 2, HB = BN / 2;               // column pairs of an m- (n-) fastest operand tile
     constexpr int KSA = 256 / HA, KSB = 256 / HB;         // k rows covered by one such load of the workgroup
     __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
-    __shared__ __attribute__((aligned(16))) double Bs[2][BK][BN];
+    __shared__ __attribute__((aligned(16))) double Bs[2][BK][BNP];
     typedef double d2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     // Tile order.  Hardware order is blockIdx.x (N tiles) fastest and workgroup i lands on XCD i % 8: the ~512 resident tiles
     // of a wide GEMM then share one row panel of op(A) and stream 512 different column panels of op(B) -- every B panel comes
     // from HBM once per M tile row.  remap: XCD x takes the N tiles n = 8 g + x and walks the M tiles fastest, so a B panel is
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
         for (int i = 0; i < 4; ++i) {
             long ri = ma + 32 * i, ci = nb_ + 32 * i;
             if (MODE == 2) { ri = ri < M - 1 ? ri : M - 1; ci = ci < N - 1 ? ci : N - 1; }
+            if (BNP != BN) ci = ci < n0 + BN - 1 ? ci : n0 + BN - 1; // the padded part of the last staging pass: the tile's own last row again
             oa[i] = TA ? (long)(KSA * i) * lda : ri * lda;
             ob[i] = TB ? ci * ldb : (long)(KSB * i) * ldb;
         }
@@ -306,6 +316,14 @@ static void launch_dgemm_e(hipStream_t st, bool ta, bool tb, dim3 grid, int M, i
     else k_dgemm<true, true, MODE, AM, AN><<<grid, 256, 0, st>>>(M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, m_off, n_off, epi);
 }
 
+// NT product on 128 x 80 tiles (no bounds checks at all): M a multiple of 128, N of 80, every K range of 16, 16-byte aligned rows
+static void launch_dgemm_nt80(hipStream_t st, int M, int N, int K, double alpha, const double *A, long lda, const double *B, long ldb,
+                              double beta, double *C, long ldc, long sC, int ksplit, int nz)
+{
+    DgemmEpi epi{nullptr, nullptr, 0.0, 0.0, 0.0, 0, 0};
+    k_dgemm<false, true, 0, 2, 5, 4, 1><<<dim3(N / 80, M / 128, nz), 256, 0, st>>>(M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, sC, ksplit, 0, 0, epi);
+}
+
 // A/B knobs of the calling context (ctx.h: gmmiv_kopts, bound per call): XCD-aware tile order; 0 = cut tiles always on the
 // per-element checked instantiation; 0 = 128 x 128 tiles on the strips too
 #define g_gemm_remap (gmmiv_kopts_cur().gemm_remap)
@@ -442,7 +460,11 @@ int tvk_dgemm_splitk(hipStream_t st, bool ta, bool tb, int M, int N, int K, doub
     int kc = ((K + nz - 1) / nz + 15) / 16 * 16;
     nz = (K + kc - 1) / kc;
     dim3 grid((N + 127) / 128, (M + 127) / 128, nz);
-    launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, slabs, N, (long)M * N, kc);
+    // N = 5 x 80 (the i-vector rank 400) on full row tiles: 80-wide tiles, no strip (option "gemm_nt80", default on)
+    const bool nt80 = gmmiv_kopts_cur().gemm_nt80 && !ta && tb && M % 128 == 0 && N % 80 == 0 && N % 128 != 0 && K % 16 == 0 &&
+                      (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0;
+    if (nt80) launch_dgemm_nt80(st, M, N, K, alpha, A, lda, B, ldb, 0.0, slabs, N, (long)M * N, kc, nz);
+    else launch_dgemm(st, ta, tb, grid, M, N, K, alpha, A, lda, 0, B, ldb, 0, 0.0, slabs, N, (long)M * N, kc);
     const long tot = (long)M * N;
     k_splitk_reduce<<<(unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256), 256, 0, st>>>(M, N, nz, slabs, beta, C, ldc);
     return (int)hipGetLastError();

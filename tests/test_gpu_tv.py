@@ -459,3 +459,29 @@ def test_options_are_state_of_the_context_not_of_the_thread():
     assert np.array_equal(seen["W"], Wa)                                                  # same context, other thread: same launches
     assert a.set_option("no_such_option", 1) == -1
     ga.close(); gb.close(); a.close(); b.close()
+
+
+@pytest.mark.parametrize("R", [160, 400])
+def test_aux_on_80_wide_tiles(R):
+    """aux = F (T Sigma^-1)^T of estimateW (AccumulateTVStat.cpp:2147-2152) is a split-K NT product with N = R columns: for R a multiple of
+    80 (and not of 128) on full row tiles it runs on 128 x 80 tiles with a 4 x 1 wave grid instead of 128 x 128 tiles plus a strip that
+    re-reads all of F (option "gemm_nt80").  256 utterances (two row tiles), K = 3840 (split-K): same i-vectors with the option on and off,
+    and the oracle's on a few rows."""
+    import torch
+    from lia_ral_amd import capi
+    C, D, U = 64, 60, 256
+    rng = np.random.default_rng(R)
+    N = rng.gamma(0.8, 3.0, (U, C)); F = rng.normal(size=(U, C * D)) * np.sqrt(np.repeat(N, D, 1) + 0.1)
+    Tm = rng.normal(0, 0.03, (R, C * D)); iv = rng.uniform(0.5, 2, C * D)
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    te = ctx.tv_tett(Tm, iv, C, D)
+    W = {}
+    for on in (1, 0):
+        ctx.set_option("gemm_nt80", on)
+        W[on] = ctx.tv_estimate_w(N, F, Tm, iv, te, C, D)
+    ctx.set_option("gemm_nt80", 1)
+    assert relerr(W[1], W[0]) < 1e-13
+    rows = [0, 1, 127, 128, 255]
+    Wo = orc.tv_estimate_w(N[rows], F[rows], Tm, iv, orc.tv_tett(Tm, iv, C, D))
+    assert relerr(W[1][rows], Wo) < 1e-10
+    ctx.close()
