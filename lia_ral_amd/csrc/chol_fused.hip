@@ -167,34 +167,35 @@ __device__ __forceinline__ int pan_stride(int n) { return (n & 2) ? n : n + 2; }
 // -- one full L2 / MALL latency per 16-byte segment and thread, up to 13 in a row at n = 400, 10 us per panel: that loop, not
 // the barriers, was the 37 % of k_chol_left that remained with all arithmetic compiled out (round 2's ablation).  Loads past
 // the row's end are clamped to its last segment (never stored).
-template <int NB>
+template <int NB, int TPR>
 __device__ __forceinline__ void stage_batch(double *prow, const double *xrow, int segs, int s0)
 {
     d2 v[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        int sg = s0 + 16 * u;
+        int sg = s0 + TPR * u;
         sg = sg < segs ? sg : segs - 1;
         v[u] = *(const d2 *)(xrow + 2 * sg);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u)
-        if (s0 + 16 * u < segs) *(d2 *)(prow + 2 * (s0 + 16 * u)) = v[u];
+        if (s0 + TPR * u < segs) *(d2 *)(prow + 2 * (s0 + TPR * u)) = v[u];
 }
+template <int TPR = 16> // threads per panel row: 16 for a workgroup of 512, 32 for 1024
 __device__ __forceinline__ void stage_panel(double *pan, int S, const double *X, long n, long row0, int kbase, int klen, int tid)
 {
     const int segs = klen >> 1; // 16-byte segments per row
     if (segs <= 0) return;
-    const int row = tid >> 4;
+    const int row = tid / TPR;
     long r = row0 + row;
     r = r < n ? r : n - 1;
     const double *xrow = X + r * n + kbase;
     double *prow = pan + row * S;
-    int s0 = tid & 15;
-    for (; s0 + 16 * 7 < segs; s0 += 16 * 8) stage_batch<8>(prow, xrow, segs, s0);   // full batches of 8 segments per thread
+    int s0 = tid % TPR;
+    for (; s0 + TPR * 7 < segs; s0 += TPR * 8) stage_batch<8, TPR>(prow, xrow, segs, s0);   // full batches of 8 segments per thread
     if (s0 < segs) {
-        if (s0 + 16 * 3 < segs) stage_batch<8>(prow, xrow, segs, s0);
-        else stage_batch<4>(prow, xrow, segs, s0);
+        if (s0 + TPR * 3 < segs) stage_batch<8, TPR>(prow, xrow, segs, s0);
+        else stage_batch<4, TPR>(prow, xrow, segs, s0);
     }
 }
 template <int CNT> struct TileOps { d2 b[CNT][4]; };
@@ -831,8 +832,8 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
 // for the row tiles c < i0.  U[c][k] = 0 for k < c: a tile's k range starts at its own 32-block (whose diagonal
 // block is stored with its zeros), and tiles of one wave (128 rows apart) join the k loop one after the other.
 // Only the upper triangle (plus the diagonal blocks) of U is written; nothing else of U is ever read.
-template <bool use_lds, int TW>
-__global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__restrict__ Lfull, const double *__restrict__ invd,
+template <bool use_lds, int TW, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double *__restrict__ Lfull, const double *__restrict__ invd,
                                                        long sinv, double *Ufull)
 {
     __shared__ __attribute__((aligned(16))) double linv[32][34];
@@ -848,16 +849,16 @@ __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__r
     d4 acc[TW][2];
     for (int i0 = 0; i0 < n_; i0 += 32) {
         const int w = (n_ - i0) < 32 ? (n_ - i0) : 32;
-        for (int e = tid; e < 1024; e += 512) {
+        for (int e = tid; e < 1024; e += NWV * 64) {
             const int i = e >> 5, k = e & 31;
             const double v = iv[(size_t)(i0 >> 5) * 1024 + e];
             linv[i][k] = v;
             if (i < w && k < w) Um[(long)(i0 + k) * n + i0 + i] = v; // diagonal block of U = inv(L_ii)^T
         }
-        if (use_lds && i0 > 0) stage_panel(pan, S, Lm, n, i0, 0, i0, tid);
+        if (use_lds && i0 > 0) stage_panel<2 * NWV>(pan, S, Lm, n, i0, 0, i0, tid);
         __syncthreads();
         const int nt = i0 >> 4; // full row tiles above the diagonal block
-        const int mine = nt > wave ? (nt - wave + 7) / 8 : 0;
+        const int mine = nt > wave ? (nt - wave + NWV - 1) / NWV : 0;
         long ra0 = i0 + perm, ra1 = i0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(512, 1) void k_trinv_left(int n_, const double *__r
             int ks[TW + 1];
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                long r0 = 16L * (wave + 8 * (TW * g + u));
+                long r0 = 16L * (wave + NWV * (TW * g + u));
                 r0 = u < cnt ? r0 : 16L * wave; // unused slots alias a valid tile
                 rows[u] = r0 + i16;
                 pb[u] = Um + rows[u] * n + 8 * q;
@@ -923,8 +924,8 @@ __device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1
 }
 // packed != NULL: instead of the full matrix, E = inv + w w^T goes out as PACKED lower rows (stride sp) -- what the T-matrix
 // E-step accumulates (A_c += N_uc E_u): no full inverse in memory, no matrix-vector pass, no pack pass.
-template <bool use_lds, int TW>
-__global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv,
+template <bool use_lds, int TW, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__restrict__ Ufull, double *__restrict__ inv,
                                                 const double *__restrict__ wv, double *__restrict__ packed, long sp)
 {
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[]; // use_lds: the panel rows U[j0 .. j0 + 31][j0 .. nfl)
@@ -944,14 +945,14 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
         PROF_PANEL(j0 >> 5);
         STAMP(); // 0
         const int nt = (n_ - j0 + 15) >> 4; // row tiles from the diagonal block down
-        const int mine = nt > wave ? (nt - wave + 7) / 8 : 0;
+        const int mine = nt > wave ? (nt - wave + NWV - 1) / NWV : 0;
         long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
         const double *pa0 = Um + ra0 * n + 8 * q, *pa1 = Um + ra1 * n + 8 * q;
         if (use_lds) {
             if (j0 > 0) __syncthreads(); // every wave is done with the previous panel's rows
-            if (nfl > j0) stage_panel(pan, S, Um, n, j0, j0, nfl - j0, tid);
+            if (nfl > j0) stage_panel<2 * NWV>(pan, S, Um, n, j0, j0, nfl - j0, tid);
             __syncthreads();
         }
         STAMP(); // 1: staged
@@ -963,7 +964,7 @@ __global__ __launch_bounds__(512, 1) void k_uut(int n_, const double *__restrict
             int ks[TW + 1];
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                long r0 = j0 + 16L * (wave + 8 * (TW * g + u));
+                long r0 = j0 + 16L * (wave + NWV * (TW * g + u));
                 r0 = u < cnt ? r0 : j0 + 16L * wave;
                 rows[u] = r0 + i16;
                 const long rc = rows[u] < n ? rows[u] : n - 1;
@@ -1151,7 +1152,7 @@ template <typename K> int chol_attr(K kernel, size_t lds, std::atomic<size_t> (&
     }
     return 0;
 }
-std::atomic<size_t> g_attr_chol[3][16], g_attr_trinv[2][16], g_attr_uut[2][16];
+std::atomic<size_t> g_attr_chol[3][16], g_attr_trinv[3][16], g_attr_uut[3][16];
 int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked, long spk, double diag_add)
 {
     prof_host_init();
@@ -1174,6 +1175,12 @@ int launch_trinv(hipStream_t st, int n, int nb, const double *Lf, const double *
 {
     const CholLds l = chol_lds(n);
     const long sinv = (long)((n + 31) / 32) * 1024;
+    if (l.use && gmmiv_kopts_cur().chol_waves == 16) { // 16 waves of 128 VGPRs, one row tile per wave and pass: twice the waves to cover a stalled one
+        int rc16 = chol_attr(k_trinv_left<true, 1, 16>, l.trinv, g_attr_trinv[2]);
+        if (rc16) return rc16;
+        k_trinv_left<true, 1, 16><<<nb, 1024, l.trinv, st>>>(n, Lf, invd, sinv, U);
+        return (int)hipGetLastError();
+    }
     int rc = l.use ? chol_attr(k_trinv_left<true, 1>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false, 3>, l.trinv, g_attr_trinv[0]);
     if (rc) return rc;
     if (l.use) k_trinv_left<true, 1><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
@@ -1183,6 +1190,12 @@ int launch_trinv(hipStream_t st, int n, int nb, const double *Lf, const double *
 int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, const double *w, double *packed, long sp)
 {
     const CholLds l = chol_lds(n);
+    if (l.use && gmmiv_kopts_cur().chol_waves == 16) {
+        int rc16 = chol_attr(k_uut<true, 1, 16>, l.uut, g_attr_uut[2]);
+        if (rc16) return rc16;
+        k_uut<true, 1, 16><<<nb, 1024, l.uut, st>>>(n, U, inv, w, packed, sp);
+        return (int)hipGetLastError();
+    }
     int rc = l.use ? chol_attr(k_uut<true, 2>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false, 3>, l.uut, g_attr_uut[0]);
     if (rc) return rc;
     if (l.use) k_uut<true, 2><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);

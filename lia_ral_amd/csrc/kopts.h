@@ -15,6 +15,9 @@ struct gmmiv_kopts {
     int gemm_nt80 = 1;    // split-K NT products with N a multiple of 80 (not of 128) on full row tiles: 128 x 80 tiles, no strip; 0: 128 x 128 + strip
     int chol_lds = 1;     // chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself
     int chol_gemm = 0;    // 1 = the GEMM-built right-looking factorisation for every order
+    // k_trinv_left / k_uut: 8 waves of 256 VGPRs, or (A/B) 16 waves of 128, one row tile per wave and pass -- twice the waves per SIMD
+    // to cover a stalled one, but 30 / 66 spilled VGPRs and twice the LDS operand reads: 0.80 -> 0.96 and 1.13 -> 1.67 ms per 1024 systems
+    int chol_waves = 8;
     int chol_flow = 1;    // 1: k_chol_left2 (panel staged first, diagonal update from LDS, wave 0 last in line for tiles); 0: k_chol_left (round 2)
 };
 const gmmiv_kopts &gmmiv_kopts_cur();          // the set bound to this thread (the defaults before any call)

@@ -19,6 +19,11 @@ extern long long *g_chol_prof; // chol_fused.hip, -DCHOL_PROF builds: device buf
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 400, nb = argc > 2 ? atoi(argv[2]) : 1024, reps = argc > 3 ? atoi(argv[3]) : 5;
+    static gmmiv_kopts ko; // the launchers read the options bound to the thread: CHOL_WAVES / CHOL_FLOW / CHOL_LDS select the variants
+    if (getenv("CHOL_WAVES")) ko.chol_waves = atoi(getenv("CHOL_WAVES"));
+    if (getenv("CHOL_FLOW")) ko.chol_flow = atoi(getenv("CHOL_FLOW"));
+    if (getenv("CHOL_LDS")) ko.chol_lds = atoi(getenv("CHOL_LDS"));
+    gmmiv_kopts_bind(&ko);
     const long P = (long)n * (n + 1) / 2, nn = (long)n * n, nblk = (n + 31) / 32;
     std::vector<double> hp((size_t)nb * P), haux((size_t)nb * n);
     srand(7);
