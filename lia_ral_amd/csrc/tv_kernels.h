@@ -33,7 +33,7 @@ int tvk_md_normalize(hipStream_t st, int R, double n_sessions, double *Rm, doubl
 int tvk_lower_to_upper(hipStream_t st, int n, const double *L, double *U);                       // U = L^T, zero below the diagonal
 int tvk_batched_matvec(hipStream_t st, int n, int nb, const double *Mx, const double *x, double *y);
 int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const double *Mx, double *y);
-int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv);
+int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv, long ld = 0); // ld: row stride of X and Y (0: n)
 int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out);
 int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const double *y, double *out);
 int tvk_splitk_count(int M, int N, int K, int n_cu);

@@ -1241,12 +1241,12 @@ int tvk_vecmat_add(hipStream_t st, int rows, long cols, const double *x, const d
 // scoring helpers
 // -------------------------------------------------------------------------------------------
 // q[j] = sum_i X[i][j] * Y[i][j]  for column-vectors matrices [dim x n] (diag(X^T Y))
-__global__ void k_coldot(int dim, long n, const double *__restrict__ X, const double *__restrict__ Y,
+__global__ void k_coldot(int dim, long n, long ld, const double *__restrict__ X, const double *__restrict__ Y,
                          double *__restrict__ qv)
 {
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < (size_t)n; j += (size_t)gridDim.x * blockDim.x) {
         double s = 0.0;
-        for (int i = 0; i < dim; ++i) s = __builtin_fma(X[(size_t)i * n + j], Y[(size_t)i * n + j], s);
+        for (int i = 0; i < dim; ++i) s = __builtin_fma(X[(size_t)i * ld + j], Y[(size_t)i * ld + j], s);
         qv[j] = s;
     }
 }
@@ -1292,11 +1292,11 @@ int tvk_axpby(hipStream_t st, long n, double a, const double *x, double b, const
     return (int)hipGetLastError();
 }
 
-int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv)
+int tvk_coldot(hipStream_t st, int dim, long n, const double *X, const double *Y, double *qv, long ld)
 {
     if (n <= 0) return 0;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    k_coldot<<<blocks, 256, 0, st>>>(dim, n, X, Y, qv);
+    k_coldot<<<blocks, 256, 0, st>>>(dim, n, ld > 0 ? ld : n, X, Y, qv);
     return (int)hipGetLastError();
 }
 int tvk_add_transpose(hipStream_t st, int n, const double *a, const double *b, double *out)
