@@ -34,7 +34,8 @@ def tv_problem(C, D, R, U, seed=0, frames=200):
 
 
 @pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 5), (64, 60, 50, 9), (32, 20, 100, 40), (128, 60, 400, 3),
-                                     (16, 12, 35, 6), (16, 12, 34, 300), (8, 12, 450, 4)])   # odd order (GEMM-built path), > 1 tile pass
+                                     (16, 12, 35, 6), (16, 12, 34, 300), (8, 12, 450, 4),    # odd order (GEMM-built path), > 1 tile pass
+                                     (4, 12, 512, 3)])   # order 512: the panel rows no longer fit LDS -- the kernels that fetch them per wave
 def test_ivector_extraction(ctx, C, D, R, U):
     p = tv_problem(C, D, R, U, seed=R)
     F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
@@ -57,7 +58,7 @@ def test_ivector_extraction(ctx, C, D, R, U):
     assert relerr(W_g, W_o) < 1e-9          # north_star bar is 1e-6
 
 
-@pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 30), (32, 20, 40, 300), (8, 12, 35, 20), (8, 12, 450, 5)])
+@pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 30), (32, 20, 40, 300), (8, 12, 35, 20), (8, 12, 450, 5), (4, 12, 512, 4)])   # 512: inverse through the non-LDS kernels
 def test_tv_em_iteration(ctx, C, D, R, U):
     p = tv_problem(C, D, R, U, seed=7, frames=120)
     invvar = p["iv"].ravel()
