@@ -849,11 +849,28 @@ struct ScoreArgs {
     DevIn<double> m, s;
     DevOut<double> sc;
     double *qm = nullptr, *qs = nullptr;
+    // row strides of the vector matrices as the GEMMs see them.  _models [dim x M] / _segments [dim x S] have the vector count as
+    // their row stride: with an ODD count no row but the first starts on 16 bytes and every GEMM of the rule would run on the
+    // per-element checked instantiation (1.5 x slower); such a matrix is copied once into an even-stride block.
+    int64_t ldm = 0, lds = 0;
+    static int even_stride(gmmiv_ctx *c, int slot, int dim, int64_t n, DevIn<double> &v, int64_t *ld)
+    {
+        *ld = n;
+        if ((n & 1) == 0 || n < 2) return GMMIV_OK;
+        void *p;
+        int rc = c->scratch(slot, (size_t)dim * (n + 1) * 8, &p);
+        if (rc) return rc;
+        GCHK(hipMemcpy2DAsync(p, (n + 1) * 8, v.d, n * 8, n * 8, dim, hipMemcpyDeviceToDevice, c->stream));
+        v.d = (const double *)p;
+        *ld = n + 1;
+        return GMMIV_OK;
+    }
     int init(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double *models, const double *segs, double *scores, bool load = false)
     {
         int rc;
         if ((rc = m.init(c, WS_T0, models, (size_t)dim * M))) return rc;
         if ((rc = s.init(c, WS_T1, segs, (size_t)dim * S))) return rc;
+        if ((rc = even_stride(c, WS_T9, dim, M, m, &ldm)) || (rc = even_stride(c, WS_TIV, dim, S, s, &lds))) return rc;
         if ((rc = sc.init(c, WS_T2, scores, (size_t)M * S, load))) return rc;
         void *p;
         if ((rc = c->scratch(WS_T3, (size_t)(M + S) * 8, &p))) return rc;
@@ -878,12 +895,12 @@ int gmmiv_score_cosine(gmmiv_ctx *c, int dim, int64_t M, int64_t S, const double
     if (M == 0 || S == 0) return GMMIV_OK;
     ScoreArgs a;
     if ((rc = a.init(c, dim, M, S, models, segs, scores))) return rc;
-    GCHK(tvk_coldot(c->stream, dim, M, a.m.d, a.m.d, a.qm));
-    GCHK(tvk_coldot(c->stream, dim, S, a.s.d, a.s.d, a.qs));
+    GCHK(tvk_coldot(c->stream, dim, M, a.m.d, a.m.d, a.qm, a.ldm));
+    GCHK(tvk_coldot(c->stream, dim, S, a.s.d, a.s.d, a.qs, a.lds));
     c->t_begin("k_dgemm(score)");
     GCHK(tvk_rsqrt_vec(c->stream, M, a.qm));   // the normalisation rides in the GEMM epilogue: x 1/|m| x 1/|s|
     GCHK(tvk_rsqrt_vec(c->stream, S, a.qs));
-    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, M, a.s.d, S, a.sc.d, S, 1, a.qm, a.qs, 0.0, 0.0, 0.0));
+    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, 1.0, a.m.d, a.ldm, a.s.d, a.lds, a.sc.d, S, 1, a.qm, a.qs, 0.0, 0.0, 0.0));
     c->t_end();
     return a.sc.finish();
 }
@@ -895,22 +912,23 @@ static int quad_score(gmmiv_ctx *c, ScoreArgs &a, int dim, int64_t M, int64_t S,
 {
     int rc;
     void *p;
-    if (ldm <= 0) ldm = M;
+    if (ldm <= 0) ldm = a.ldm > 0 ? a.ldm : M;
+    const int64_t lds = a.lds > 0 ? a.lds : S;
     const size_t nn = (size_t)dim * dim;
     if ((rc = c->scratch(WS_T4, nn * 8, &p))) return rc;
     double *Qsym = (double *)p;
-    const size_t mx = (size_t)dim * (ldm > S ? ldm : S);
+    const size_t mx = (size_t)dim * (ldm > lds ? ldm : lds);
     if ((rc = c->scratch(WS_T5, mx * 8, &p))) return rc;
     double *Y = (double *)p;
     GCHK(tvk_dgemm(c->stream, false, false, dim, (int)M, dim, 1.0, Qm, dim, 0, a.m.d, ldm, 0, 0.0, Y, ldm, 0, 1));
     GCHK(tvk_coldot(c->stream, dim, M, a.m.d, Y, a.qm, ldm));
-    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qs, dim, 0, a.s.d, S, 0, 0.0, Y, S, 0, 1));
-    GCHK(tvk_coldot(c->stream, dim, S, a.s.d, Y, a.qs));
+    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qs, dim, 0, a.s.d, lds, 0, 0.0, Y, lds, 0, 1));
+    GCHK(tvk_coldot(c->stream, dim, S, a.s.d, Y, a.qs, lds));
     GCHK(tvk_add_transpose(c->stream, dim, Qcross, Qcross, Qsym));
-    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qsym, dim, 0, a.s.d, S, 0, 0.0, Y, S, 0, 1));
+    GCHK(tvk_dgemm(c->stream, false, false, dim, (int)S, dim, 1.0, Qsym, dim, 0, a.s.d, lds, 0, 0.0, Y, lds, 0, 1));
     c->t_begin("k_dgemm(score)");
     // ccross m^T Y s + bm q_m + bs q_s + cst in ONE pass over the M x S matrix (GEMM epilogue)
-    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, ccross, a.m.d, ldm, Y, S, a.sc.d, S, 2, a.qm, a.qs, bm, bs, cst, beta));
+    GCHK(tvk_dgemm_epi(c->stream, true, false, (int)M, (int)S, dim, ccross, a.m.d, ldm, Y, lds, a.sc.d, S, 2, a.qm, a.qs, bm, bs, cst, beta));
     c->t_end();
     return GMMIV_OK;
 }
@@ -1481,7 +1499,7 @@ int gmmiv_score_plda(gmmiv_ctx *c, int rf, int64_t M, int64_t S, const double *m
         void *q;
         const int64_t ldq = Mr + (Mr & 1);
         if ((rc = c->scratch(WS_T7, (size_t)rf * ldq * 8, &q))) return rc;
-        GCHK(hipMemcpy2DAsync(q, ldq * 8, a.m.d + m0, M * 8, Mr * 8, rf, hipMemcpyDeviceToDevice, c->stream));
+        GCHK(hipMemcpy2DAsync(q, ldq * 8, a.m.d + m0, a.ldm * 8, Mr * 8, rf, hipMemcpyDeviceToDevice, c->stream));
         sub.m.d = (const double *)q;
         sub.sc.d = a.sc.d + (size_t)m0 * S;
         sub.qm = a.qm + m0;
