@@ -1129,6 +1129,9 @@ int tvk_chol_solve_multi_batched(hipStream_t st, int n, int nb, int nrhs, const 
 }
 
 // Dynamic LDS of the three kernels and whether the panel rows fit next to the static arrays (160 KB per workgroup on gfx950)
+#ifndef CHOL_TW_NOLDS
+#define CHOL_TW_NOLDS 2 // row tiles per wave and pass of the kernels that fetch the panel rows per wave (orders whose panel does not fit LDS): order 600, 512 systems, trinv + U U^T 4.15 / 4.09 / 4.81 ms for 3 / 2 / 1
+#endif
 namespace {
 struct CholLds { int use; size_t chol, trinv, uut; };
 CholLds chol_lds(int n)
@@ -1181,10 +1184,10 @@ int launch_trinv(hipStream_t st, int n, int nb, const double *Lf, const double *
         k_trinv_left<true, 1, 16><<<nb, 1024, l.trinv, st>>>(n, Lf, invd, sinv, U);
         return (int)hipGetLastError();
     }
-    int rc = l.use ? chol_attr(k_trinv_left<true, 1>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false, 3>, l.trinv, g_attr_trinv[0]);
+    int rc = l.use ? chol_attr(k_trinv_left<true, 1>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false, CHOL_TW_NOLDS>, l.trinv, g_attr_trinv[0]);
     if (rc) return rc;
     if (l.use) k_trinv_left<true, 1><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
-    else k_trinv_left<false, 3><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
+    else k_trinv_left<false, CHOL_TW_NOLDS><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
     return (int)hipGetLastError();
 }
 int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, const double *w, double *packed, long sp)
@@ -1196,10 +1199,10 @@ int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, cons
         k_uut<true, 1, 16><<<nb, 1024, l.uut, st>>>(n, U, inv, w, packed, sp);
         return (int)hipGetLastError();
     }
-    int rc = l.use ? chol_attr(k_uut<true, 2>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false, 3>, l.uut, g_attr_uut[0]);
+    int rc = l.use ? chol_attr(k_uut<true, 2>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false, CHOL_TW_NOLDS>, l.uut, g_attr_uut[0]);
     if (rc) return rc;
     if (l.use) k_uut<true, 2><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
-    else k_uut<false, 3><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
+    else k_uut<false, CHOL_TW_NOLDS><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
     return (int)hipGetLastError();
 }
 } // namespace
