@@ -339,7 +339,10 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
                          int ksplit, DgemmEpi epi = DgemmEpi{nullptr, nullptr, 0.0, 0.0, 0.0, 0, 0})
 {
     epi.remap = g_gemm_remap && grid.x >= 16; // wide enough for the per-XCD column order to mean something
-    const bool kfull = K % 2 == 0 && (ksplit <= 0 || ksplit % 16 == 0); // a partial last k-tile is handled in the kernel (even K)
+    // a partial last k-tile is handled in the kernel; K must be even only when an operand has k as its FASTEST index (16-byte pairs
+    // along k).  A^T B products (ta && !tb: `A += N^T E`, `Cmx += W^T F` with K = the number of utterances) take any K -- with an odd
+    // utterance count they used to fall to the per-element checked instantiation as a whole
+    const bool kfull = (K % 2 == 0 || (ta && !tb)) && (ksplit <= 0 || ksplit % 16 == 0);
     const bool aligned = (((size_t)A | (size_t)B) % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0 && sA % 2 == 0 && sB % 2 == 0;
     const bool clamp_ok = g_gemm_clamp && (!ta || (M % 2 == 0 && M >= 2)) && (tb || (N % 2 == 0 && N >= 2));
     const int fm = M / 128, fn = N / 128; // full tiles
