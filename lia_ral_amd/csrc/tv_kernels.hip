@@ -359,9 +359,10 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
     // interior grid and add their full latency.  They go to a side stream (forked and joined with events) and run
     // beside the interior tiles; the tiles are disjoint, so there is no ordering between the launches to keep.
     const bool has_strips = (int)grid.x > fn || (int)grid.y > fm;
-    // one side stream + event pair per device (a process may hold contexts on several devices)
+    // one side stream + event pair per device AND per host thread (a process may hold contexts on several devices, and two contexts
+    // on one device may be driven from two threads at once: a shared event pair would let one thread's fork overwrite the other's)
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-    static Side sides[16];
+    static thread_local Side sides[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
     hipStream_t side = nullptr;
