@@ -405,8 +405,8 @@ typedef struct gmmiv_comm gmmiv_comm;
 int gmmiv_comm_get_unique_id(void *id128);
 int gmmiv_comm_get_unique_id_for(const char *transport, void *id128);
 /* rank 0: creates the id and publishes it at `path` (atomically; a file already there is removed first); other ranks: wait up
- * to timeout_s for it and read it (a file last modified more than 30 s before the call is taken for a dead job's leftover and
- * ignored).  Rank 0 removes the file again as soon as its gmmiv_comm_create on that id has succeeded -- every rank has read
+ * to timeout_s for it and read it (a file last modified more than 10 minutes before the call is taken for a dead job's leftover
+ * and ignored).  Rank 0 removes the file again as soon as its gmmiv_comm_create on that id has succeeded -- every rank has read
  * the id by then -- so a path can be reused by the next job. */
 int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double timeout_s);
 int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gmmiv_comm **out);

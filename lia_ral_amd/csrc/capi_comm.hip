@@ -457,15 +457,16 @@ int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double 
         g_idfiles.emplace_back(std::string((const char *)id128, GMMIV_COMM_ID_BYTES), std::string(path));
         return GMMIV_OK;
     }
-    // Only a file written "now" is this job's: one whose modification time lies more than 30 s before this call is a leftover
-    // of an earlier job at the same path (rank 0 removes its file as soon as the communicator exists, so a leftover means
-    // that job died in between) and is ignored until rank 0 replaces it.
+    // Only a recent file is this job's: one whose modification time lies more than 10 minutes before this call is a leftover of
+    // an earlier job at the same path (rank 0 removes its file as soon as the communicator exists, so a leftover means that job
+    // died in between) and is ignored until rank 0 replaces it.  The window is wide on purpose: the ranks of one job may reach this
+    // call minutes apart (a cold `import torch` on a fresh box takes 1-2 minutes).
     struct timespec t_enter;
     clock_gettime(CLOCK_REALTIME, &t_enter);
     const double step = 0.01;
     for (double waited = 0.0; waited <= timeout_s; waited += step) { // the rename above makes the file appear complete
         struct stat sb;
-        if (stat(path, &sb) == 0 && (double)sb.st_mtime >= (double)t_enter.tv_sec - 30.0) {
+        if (stat(path, &sb) == 0 && (double)sb.st_mtime >= (double)t_enter.tv_sec - 600.0) {
             FILE *f = fopen(path, "rb");
             if (f) {
                 const size_t n = fread(id128, 1, GMMIV_COMM_ID_BYTES, f);
