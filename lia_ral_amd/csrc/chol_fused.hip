@@ -19,11 +19,22 @@
 // v_readlane broadcasts, fully unrolled), inverts the 32 x 32 factor (column c in lane c) and publishes
 // inv(L_jj) in LDS while the other waves are still busy with their tiles; it takes off-diagonal tiles last.
 #include <atomic>
+#include <type_traits>
 
 #include "devutil.h"
 #include "tv_kernels.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// k mapping of the row x row dot products: of a 32-wide chunk starting at k, lane quarter q holds the eight columns
+// k + KOFF_V v + KOFF_Q q + {0, 1}, v = 0..3, for BOTH operands (any bijection works as long as they agree).  With (2, 8) the four
+// quarters of a row read 64 contiguous bytes per load instruction, so a 128-byte line is fetched by two instructions; the round-1..3
+// mapping (8, 2) gave every lane 64 contiguous bytes of its own, every line was touched by FOUR instructions 16 bytes at a time, and
+// the k-loops -- which wait for these loads, not for the MFMAs -- thrashed the 32 KB L1 as soon as more chunks were in flight.
+#ifndef KOFF_Q
+#define KOFF_Q 2
+#define KOFF_V 8
+#endif
 
 // CHOL_ABL (compile-time, timing experiments only -- tools/chol_ablate.sh; results are wrong when != 0), k_chol_left: 1 = no factorisation /
 // inversion sweep of the diagonal block, 2 = no triangular solve + stores of the tiles, 4 = no k-loops of the off-diagonal tiles,
@@ -86,13 +97,13 @@ __device__ __forceinline__ void rows_load(RowOps<CNT> &o, const double *pa0, con
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        o.a0[v] = *(const d2 *)(pa0 + k + 2 * v);
-        o.a1[v] = *(const d2 *)(pa1 + k + 2 * v);
+        o.a0[v] = *(const d2 *)(pa0 + k + KOFF_V * v);
+        o.a1[v] = *(const d2 *)(pa1 + k + KOFF_V * v);
     }
 #pragma unroll
     for (int u = 0; u < CNT; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + 2 * v);
+        for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + KOFF_V * v);
 }
 template <int CNT, bool NEG, int TWT>
 __device__ __forceinline__ void rows_mfma(const RowOps<CNT> &o, d4 (&acc)[TWT][2])
@@ -206,14 +217,14 @@ __device__ __forceinline__ void tiles_load(TileOps<CNT> &o, const double *(&pb)[
 #pragma unroll
     for (int u = 0; u < CNT; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + 2 * v);
+        for (int v = 0; v < 4; ++v) o.b[u][v] = *(const d2 *)(pb[u] + k + KOFF_V * v);
 }
 __device__ __forceinline__ void pan_load(PanOps &o, const double *la0, const double *la1, int kl)
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        o.a0[v] = *(const d2 *)(la0 + kl + 2 * v);
-        o.a1[v] = *(const d2 *)(la1 + kl + 2 * v);
+        o.a0[v] = *(const d2 *)(la0 + kl + KOFF_V * v);
+        o.a1[v] = *(const d2 *)(la1 + kl + KOFF_V * v);
     }
 }
 template <int CNT, bool NEG, int TWT>
@@ -261,6 +272,16 @@ __device__ __forceinline__ void rowdot_lds(const double *la0, const double *la1,
     }
     if (k < ke) pan_mfma<CNT, NEG>(xa, A, acc);
 }
+// (Round 3 tried to request the tile rows further ahead, on the theory that the k-loops wait for memory LATENCY -- ~3 k cycles per
+// chunk next to 0.5 k of MFMAs in the stamps: (a) four rotating 32-wide buffers refilled behind their MFMAs, tail steps guarded by
+// wave-uniform ifs -- hipcc answers the guarded blocks with s_waitcnt vmcnt(0) at the loop head: k_chol_left2 0.97 -> 1.32 ms,
+// k_trinv_left 0.78 -> 0.97; (b) 64-wide tile-row chunks in two buffers, LDS operands on 32-wide steps, precise waits: 0.97 -> 1.20
+// (spills) and 0.78 -> 0.82 (none); (c) k_chol_left2 alone (its tile rows come from L2: 1.2 TB/s of fetches against 4.6 for
+// k_trinv_left), three rotating 32-wide buffers, a main loop without conditionals, LDS operands on half steps, no spills, exact
+// vmcnt waits: 0.962 -> 0.984.  More requests in flight never helped: seven waves x 4 KB per chunk per ~3.2 k cycles x 256 CUs are
+// 5.5 TB/s of tile rows that no other wave shares -- the loops are bound by the THROUGHPUT of the memory path (L2 / fabric / HBM,
+// 64-byte pieces of 16 rows per instruction), not by its latency.  What would help is fewer passes over L (Cholesky
+// family), not deeper queues.)
 // dispatcher over the tile count; the operand source is a template parameter of the kernels (two code paths in one kernel cost
 // 150 spilled VGPRs)
 template <bool LDS, bool NEG, int TWT>
@@ -322,9 +343,10 @@ __device__ __forceinline__ void chol_block_out(const double (*pj)[34], const dou
 // PACKED lower rows (r (r + 1) / 2 + c, the layout the L = N TETt GEMM produces) with diag_add on the diagonal -- the
 // unpack kernel (a 2 x 1.3 GB round trip per 1024 systems of order 400) disappears.  Entries above the diagonal come out
 // as whatever follows in the packed array; the factorisation never uses them.
-__device__ __forceinline__ d4 chol_src4(const double *Lm, const double *Apk, long n, long r, long c0, double diag_add)
+template <bool PK> // PK: the source is the packed lower-row input (Apk), else the full matrix itself
+__device__ __forceinline__ d4 chol_src4t(const double *Lm, const double *Apk, long n, long r, long c0, double diag_add)
 {
-    if (!Apk) {
+    if (!PK) {
         const double *p = Lm + r * n + c0;
         const d2 lo = *(const d2 *)p, hi = *(const d2 *)(p + 2);
         return d4{lo[0], lo[1], hi[0], hi[1]};
@@ -332,22 +354,186 @@ __device__ __forceinline__ d4 chol_src4(const double *Lm, const double *Apk, lon
     const double *p = Apk + r * (r + 1) / 2 + c0;
     d4 v = {p[0], p[1], p[2], p[3]};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (c0 + k == r) v[k] += diag_add;
+    for (int k = 0; k < 4; ++k) v[k] += (c0 + k == r) ? diag_add : 0.0;
     return v;
+}
+__device__ __forceinline__ d4 chol_src4(const double *Lm, const double *Apk, long n, long r, long c0, double diag_add)
+{
+    return Apk ? chol_src4t<true>(Lm, Apk, n, r, c0, diag_add) : chol_src4t<false>(Lm, Apk, n, r, c0, diag_add);
 }
 
 // Afull[b]: n x n row-major, lower triangle read, overwritten by the factor (diagonal blocks: upper part zeroed;
 // elsewhere the upper triangle is left as it was).  invd[b][kb][32][32]: inverse of the kb-th 32 x 32 diagonal
 // block of the factor (zero padded).  status[b] = 1 on a non-positive pivot.  n must be even (16-byte rows).
+// Factorisation and inversion of the 32 x 32 diagonal block by ONE wave in ONE sweep over its columns, one FMA stream for both:
+// lanes 0..31 hold row i = lane of the (updated, symmetric) block, lanes 32..63 the running sums of column i = lane - 32 of
+// X = L^-1 (v[] either way; a[] is read on lanes < 32 only).  Results: blk[0] = pj[i][j] = L[i][j] (zeros above the diagonal),
+// blk[1] = linv[j][i] = X[j][i]; bad = 1 when a pivot is not a positive normal number (the pivot is replaced by 1).
+//
+// This sweep is the longest serial piece of a panel (round 3's in-kernel stamps: 43 % of k_chol_left2 at order 400, ~680 cycles
+// per column), so what sits on the column-to-column dependence is kept minimal (CHOL_SWEEP 1):
+//   * the recurrence runs on UNSCALED columns (the L D L^T form): v[k] += coef c[k] with coef = -v[j] / d_j needs 1 / d_j only
+//     (v_rcp_f64 + two Newton steps = 5 dependent instructions) -- sqrt(d_j) and 1 / sqrt(d_j) (17 dependent instructions) scale
+//     the OUTPUT and are evaluated once per block after the loop, by lane j for its own pivot, not once per column on the chain;
+//   * the pivot d_j and the next column's entry c[j + 1] come out of the registers of lanes j and j + 1 with v_readlane (4 per
+//     column: no SGPR spilling), so the LDS round trip of a column (write by 32 lanes, broadcast reads) is off the chain: it only
+//     feeds the 30 - j updates that nothing waits for;
+//   * no exec-masked branches (both halves store through one per-lane address): the 32 columns are one scheduling region.
+// CHOL_SWEEP 0 = the round-1..3 form (column through LDS, rsqrt chain per column), kept for A/B runs of tools/chol_probe.
+#ifndef CHOL_SWEEP
+#define CHOL_SWEEP 1
+#endif
+__device__ __forceinline__ void rsqrt_sqrt(double dj, double &rs, double &sq)
+{
+    // 1/sqrt(d) and sqrt(d) from v_rsq_f64 + Newton / Goldschmidt steps (a dozen dependent FMAs instead of the ~60 instructions
+    // of an IEEE sqrt followed by an IEEE divide)
+    rs = __builtin_amdgcn_rsq(dj);
+    const double hd = 0.5 * dj;
+    rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
+    rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
+    sq = dj * rs;
+    sq = __builtin_fma(__builtin_fma(-sq, sq, dj), 0.5 * rs, sq);
+    rs = __builtin_fma(__builtin_fma(-sq, rs, 1.0), rs, rs);
+}
+// one column of sweep32 (CHOL_SWEEP 1); J is a template parameter so that every loop bound is a constant for the front end.
+// c[] holds column J - 1 on entry (entries k >= J + 1) and column J on exit (k >= J + 2): every entry is reloaded right behind the
+// update that consumed it (one buffer: two would cost 60 more VGPRs next to v[], and the kernel is at its cap of 256), a whole
+// step before it is needed.  A scheduling barrier behind every chunk keeps the loads where they are written (hipcc otherwise sinks
+// them to their first use, and the LDS latency lands on the chain).
+template <int J>
+__device__ __forceinline__ void sweep_column(double (&v)[32], double (&c)[32], double &cprev, int lane, double (*col)[64], double *piv,
+                                             int &bad)
+{
+    // v[J] is final: pivot and the next column's entry from the registers of lanes J, J + 1
+    const int ph = __builtin_amdgcn_readlane(__double2hiint(v[J]), J), pl = __builtin_amdgcn_readlane(__double2loint(v[J]), J);
+    const bool okp = ph > 0 && ph < 0x7ff00000; // positive, normal, finite (scalar test on the high word)
+    if (!okp) bad = 1;
+    const double dj = okp ? __hiloint2double(ph, pl) : 1.0;
+    piv[J] = dj; // uniform store
+    const double *cj = col[J & 1];
+    // the updates of step J - 1 (k = J + 1 .. 31, the next pivot's column first) in six chunks under the dependent chain of 1 / d_J
+    constexpr int NF = J > 0 ? 31 - J : 0, CS = (NF + 5) / 6;
+#define DCHUNK(ci)                                                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < CS; ++kk)                                                                                \
+    {                                                                                                                                \
+        const int k = J + 1 + (ci) * CS + kk;                                                                                        \
+        if (k < 32) {                                                                                                                \
+            v[k] = __builtin_fma(cprev, c[k], v[k]);                                                                                 \
+            PIN_V(v[k]);                                                                                                             \
+            if (k >= J + 2) c[k] = cj[k];                                                                                            \
+        }                                                                                                                            \
+    }                                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    if (J == 0) {
+#pragma unroll
+        for (int k = 2; k < 32; ++k) c[k] = cj[k];
+    }
+    double r = __builtin_amdgcn_rcp(dj);
+    PIN_V(r);
+    DCHUNK(0)
+    double e = __builtin_fma(-dj, r, 1.0);
+    PIN_V(e);
+    DCHUNK(1)
+    r = __builtin_fma(e, r, r);
+    PIN_V(r);
+    DCHUNK(2)
+    e = __builtin_fma(-dj, r, 1.0);
+    PIN_V(e);
+    DCHUNK(3)
+    r = __builtin_fma(e, r, r);
+    PIN_V(r);
+    DCHUNK(4)
+    const double coef = -v[J] * r;
+    DCHUNK(5)
+#undef DCHUNK
+    if (J + 1 < 32) {
+        const double cn = readlane_f64(v[J], J + 1);
+        v[(J + 1) & 31] = __builtin_fma(coef, cn, v[(J + 1) & 31]);
+        PIN_V(v[(J + 1) & 31]);
+        col[(J + 1) & 1][lane] = v[(J + 1) & 31];
+        wave_sync(); // compiler-level only: LDS is in order per wave
+    }
+    cprev = coef;
+}
+template <int J>
+__device__ __forceinline__ void sweep_columns(double (&v)[32], double (&c)[32], double &cprev, int lane, double (*col)[64], double *piv,
+                                              int &bad)
+{
+    if constexpr (J < ((CHOL_ABL & 1) ? 1 : 32)) {
+        sweep_column<J>(v, c, cprev, lane, col, piv, bad);
+        sweep_columns<J + 1>(v, c, cprev, lane, col, piv, bad);
+    }
+}
+__device__ __forceinline__ void sweep32(const double (&a)[32], int lane, double (*col)[64], double *piv, double (*blk)[32][34], int &bad)
+{
+    const bool lo = lane < 32;
+    const int li = lane & 31;
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = lo ? a[k] : 0.0;
+    col[0][lane] = v[0]; // lanes >= 32 write the unused upper half: no branch
+#if CHOL_SWEEP
+    // lanes >= 32 run the SAME recurrence on u = -v started from the unit vector e_i (u[k] += (-u[j] / d_j) c[k]): X[j][i] = u[j] / sqrt(d_j)
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = lo ? v[k] : (k == li ? 1.0 : 0.0);
+    double c[32];       // the column the pending updates use
+    double cprev = 0.0; // coef of step j - 1
+    wave_sync();
+    sweep_columns<0>(v, c, cprev, lane, col, piv, bad);
+    // (the updates of step 31 do not exist: k >= 33)
+    // output: column j of both results is the unscaled column times 1 / sqrt(d_j), evaluated once per block by lanes j / 32 + j
+    wave_sync();
+    double rs, sq;
+    rsqrt_sqrt(piv[li], rs, sq);
+    col[0][lane] = rs;
+    wave_sync();
+    double *out = &blk[0][0][0] + (lo ? li * 34 : 32 * 34 + li);
+    const int step = lo ? 1 : 34;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const double y = v[j] * col[0][j];
+        out[j * step] = lane == j ? sq : (lane < j ? 0.0 : y); // lanes < 32: zeros above the diagonal, sqrt(d_j) on it
+    }
+#else
+#pragma unroll
+    for (int j = 0; j < ((CHOL_ABL & 1) ? 1 : 32); ++j) {
+        const double *cj = col[j & 1];
+        wave_sync();
+        double c[32];
+#pragma unroll
+        for (int k = j; k < 32; ++k) c[k] = cj[k];
+        double dj = c[j];
+        if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
+        double rs, sq;
+        rsqrt_sqrt(dj, rs, sq);
+        const double y = v[j] * rs;
+        const double xj = (j == li) ? rs : (j > li ? -y : 0.0);
+        const double coef = (lo ? -y : xj) * rs;
+        if (j + 1 < 32) {
+            v[j + 1] = __builtin_fma(coef, c[j + 1], v[j + 1]);
+            PIN_V(v[j + 1]);
+            if (lo) col[(j + 1) & 1][li] = v[j + 1];
+        }
+        if (lo) blk[0][li][j] = (li == j) ? sq : (li > j ? y : 0.0);
+        else blk[1][j][li] = xj;
+#pragma unroll
+        for (int k = j + 2; k < 32; ++k) {
+            v[k] = __builtin_fma(coef, c[k], v[k]);
+            PIN_V(v[k]);
+        }
+    }
+#endif
+    wave_sync();
+}
+
 template <bool use_lds>
 __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
                                                       long spk, double diag_add)
 {
     constexpr int TW = 3;
-    __shared__ __attribute__((aligned(16))) double pj[32][34];
-    __shared__ __attribute__((aligned(16))) double linv[32][34];
-    __shared__ __attribute__((aligned(16))) double col[2][32];
+    __shared__ __attribute__((aligned(16))) double blk[2][32][34]; // the factored diagonal block and its inverse (sweep32)
+    double (*pj)[34] = blk[0], (*linv)[34] = blk[1];
+    __shared__ __attribute__((aligned(16))) double col[2][64], piv[32];
     // dynamic: the partial updates of the diagonal block, one per wave (slab[8][32][33]) -- and, once wave 0 has taken them into its
     // registers, the panel rows L[j0 .. j0 + 31][0 .. j0) for the off-diagonal tiles (use_lds; the two never live at the same time)
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
@@ -381,7 +567,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
         long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
-        const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
+        const double *pa0 = Lm + ra0 * n + KOFF_Q * q, *pa1 = Lm + ra1 * n + KOFF_Q * q;
 
         // ---------------- diagonal block ----------------
         // step 1, all waves: the update sum_{k < j0} L[j0 + i][k] L[j0 + c][k] of the 32 x 32 block is cut in 8 k ranges
@@ -394,7 +580,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
             for (int u = 0; u < 2; ++u) {
                 long r = j0 + 16 * u + i16;
                 rr[u] = r < n ? r : n - 1;
-                pb[u] = Lm + rr[u] * n + 8 * q;
+                pb[u] = Lm + rr[u] * n + KOFF_Q * q;
                 acc[u][0] = acc[u][1] = d4{0.0, 0.0, 0.0, 0.0};
             }
             pb[2] = pb[0];
@@ -489,57 +675,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 }
             }
             __builtin_amdgcn_s_setprio(3); // the serial part: do not queue behind the MFMA stream of the wave sharing this SIMD
-            // Factorisation and inversion of the 32 x 32 block in ONE sweep over its columns, ONE FMA stream for both:
-            // lanes 0..31 hold row i = lane of the block, lanes 32..63 the running sums of column i = lane - 32 of
-            // X = L^-1 (v[] either way).  Column j goes through LDS (uniform-address reads = broadcasts):
-            // c[k] = unscaled L[k][j].  With y = v[j] / sqrt(d):
-            //   lanes < 32 :  L[i][j] = y,                       v[k] -= y L[k][j]        = fma(-y rs, c[k], v[k])
-            //   lanes >= 32:  X[j][i] = delta_ij rs - [j > i] y, v[k] += L[k][j] X[j][i]  = fma(X[j][i] rs, c[k], v[k])
-            // The next column's entry is updated FIRST and written out before the rest of the step, so that its LDS
-            // round trip overlaps the remaining FMAs.
-            // Scheduling notes: v_readlane would do for the broadcasts, but hipcc hoists all 31 of a step and spills the
-            // SGPRs through v_writelane; and VALU instructions carry no ordering chain, so without the PIN after every
-            // update the FMAs of ALL steps sink below ALL the LDS reads (1500 spilled VGPRs).
-            const bool lo = lane < 32;
-            double v[32];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) v[k] = lo ? a[k] : 0.0;
-            if (lo) col[0][li] = v[0];
-#pragma unroll
-            for (int j = 0; j < ((CHOL_ABL & 1) ? 1 : 32); ++j) {
-                const double *cj = col[j & 1];
-                wave_sync();
-                double c[32];
-#pragma unroll
-                for (int k = j; k < 32; ++k) c[k] = cj[k];
-                double dj = c[j];
-                if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
-                // 1/sqrt(d) and sqrt(d) from v_rsq_f64 + Newton / Goldschmidt steps (a dozen dependent FMAs instead of the
-                // ~60 instructions of an IEEE sqrt followed by an IEEE divide): this chain is the serial part of the kernel
-                double rs = __builtin_amdgcn_rsq(dj);
-                const double hd = 0.5 * dj;
-                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
-                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
-                double sq = dj * rs;
-                sq = __builtin_fma(__builtin_fma(-sq, sq, dj), 0.5 * rs, sq);
-                rs = __builtin_fma(__builtin_fma(-sq, rs, 1.0), rs, rs);
-                const double y = v[j] * rs;
-                const double xj = (j == li) ? rs : (j > li ? -y : 0.0);
-                const double coef = (lo ? -y : xj) * rs;
-                if (j + 1 < 32) {
-                    v[j + 1] = __builtin_fma(coef, c[j + 1], v[j + 1]);
-                    PIN_V(v[j + 1]);
-                    if (lo) col[(j + 1) & 1][li] = v[j + 1];
-                }
-                if (lo) pj[li][j] = (li == j) ? sq : (li > j ? y : 0.0);
-                else linv[j][li] = xj;
-#pragma unroll
-                for (int k = j + 2; k < 32; ++k) {
-                    v[k] = __builtin_fma(coef, c[k], v[k]);
-                    PIN_V(v[k]);
-                }
-            }
-            wave_sync();
+            sweep32(a, lane, col, piv, blk, bad); // factor + invert, results in pj / linv
             __builtin_amdgcn_s_setprio(0);
         }
 
@@ -555,13 +691,13 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                 long r = j0 + 32 + 16L * (slot + 8 * (TW * g + u)) + i16;
                 rows[u] = r;
                 r = r < n ? r : n - 1;
-                pb[u] = Lm + r * n + 8 * q;
+                pb[u] = Lm + r * n + KOFF_Q * q;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     if (u < cnt) acc[u][ct] = (CHOL_ABL & 64) ? d4{0.0, 0.0, 0.0, 0.0} : chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
                 }
             }
-            if (!(CHOL_ABL & 4)) rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
+            if (!(CHOL_ABL & 4)) rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, 0, j0, 0, acc);
             if (g == 0) {
                 STAMP(); // 6: k-loops of the first tile group done
                 __syncthreads(); // inv(L_jj) and L_jj are in LDS
@@ -620,8 +756,8 @@ __device__ __forceinline__ void diag_from_lds(const double *la, const double *lb
         d2 a[4], b[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            a[v] = *(const d2 *)(la + k + 2 * v);
-            b[v] = *(const d2 *)(lb + k + 2 * v);
+            a[v] = *(const d2 *)(la + k + KOFF_V * v);
+            b[v] = *(const d2 *)(lb + k + KOFF_V * v);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc = MFMA_F64(-a[e >> 1][e & 1], b[e >> 1][e & 1], acc);
@@ -632,9 +768,9 @@ template <int TW>
 __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, double *invd, long sinv, int *status, const double *Apacked,
                                                        long spk, double diag_add)
 {
-    __shared__ __attribute__((aligned(16))) double pj[32][34];
-    __shared__ __attribute__((aligned(16))) double linv[32][34];
-    __shared__ __attribute__((aligned(16))) double col[2][32];
+    __shared__ __attribute__((aligned(16))) double blk[2][32][34]; // the factored diagonal block and its inverse (sweep32)
+    double (*pj)[34] = blk[0], (*linv)[34] = blk[1];
+    __shared__ __attribute__((aligned(16))) double col[2][64], piv[32];
     __shared__ __attribute__((aligned(16))) double part[2][32][34]; // the two k-halves of the diagonal block's update
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[]; // the panel rows L[j0 .. j0 + 31][0 .. j0)
     double *pan = dyn_lds;
@@ -704,7 +840,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
         {
             const int half = ((j0 >> 5) >> 1) << 5; // whole 32-chunks
             const int kb = dh == 0 ? 0 : half, ke = dh == 0 ? half : j0;
-            if (!(CHOL_ABL & 8)) diag_from_lds(pan + (16 * dct + perm) * S + 8 * q, pan + (16 * du + i16) * S + 8 * q, kb, ke, dacc);
+            if (!(CHOL_ABL & 8)) diag_from_lds(pan + (16 * dct + perm) * S + KOFF_Q * q, pan + (16 * du + i16) * S + KOFF_Q * q, kb, ke, dacc);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = 16 * du + i16, k = 16 * dct + 4 * q + rr;
@@ -713,9 +849,60 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
         }
         __syncthreads();
         STAMP(); // 2: the two partial blocks are in LDS
-        // ---- 3. wave 0: factor + invert; the others: off-diagonal tiles ----
-        const int li = lane & 31;
+        long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
+        ra0 = ra0 < n ? ra0 : n - 1;
+        ra1 = ra1 < n ? ra1 : n - 1;
+        const double *pa0 = Lm + ra0 * n + KOFF_Q * q, *pa1 = Lm + ra1 * n + KOFF_Q * q;
+        // operand rows (pb), output rows and tile count of group g
+        auto group_setup = [&](int g, const double *(&pb)[TW], long (&rows)[TW]) __attribute__((always_inline)) -> int {
+            int cnt = mine - TW * g;
+            cnt = cnt < 0 ? 0 : (cnt > TW ? TW : cnt);
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                const int t = u < cnt ? tile_of(TW * g + u) : 0;
+                long r = j0 + 32 + 16L * t + i16;
+                rows[u] = u < cnt ? r : n;
+                r = r < n ? r : n - 1;
+                pb[u] = Lm + r * n + KOFF_Q * q;
+            }
+            return cnt;
+        };
+        auto group_src = [&](auto pk, int cnt, const long (&rows)[TW], d4 (&ac)[TW][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < TW; ++u)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    if (u < cnt) {
+                        const long r = rows[u] < n ? rows[u] : n - 1;
+                        ac[u][ct] = (CHOL_ABL & 64) ? d4{0.0, 0.0, 0.0, 0.0} : chol_src4t<decltype(pk)::value>(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
+                    }
+        };
+        auto group_solve = [&](int cnt, const long (&rows)[TW], const LinvOps &lo, const d4 (&ac)[TW][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u < cnt) {
+                    d4 x0, x1;
+                    tile_trsm(lo, ac[u], x0, x1);
+                    if (rows[u] < n) {
+                        double *p = Lm + rows[u] * n + j0 + 4 * q;
+                        *(d2 *)p = d2{x0[0], x0[1]};
+                        *(d2 *)(p + 2) = d2{x0[2], x0[3]};
+                        *(d2 *)(p + 16) = d2{x1[0], x1[1]};
+                        *(d2 *)(p + 18) = d2{x1[2], x1[3]};
+                    }
+                }
+            }
+        };
+        // ---- 3. wave 0: factor + invert; the others: the k-loops of ALL their tiles (up to MAXG groups; the accumulators wait in
+        //         registers), so that the sweep -- the longest serial piece of a panel -- has the whole off-diagonal update beside
+        //         it, not only the first tile of every wave (stamps of the previous form, panel 1 of 13 at order 400: sweep 14.3 k
+        //         cycles, first k-loops 9.1 k, then 27.5 k for the two remaining tiles of every wave AFTER the barrier).  The sources
+        //         of all tiles are requested before the first k-loop: one memory round trip, not one per group. ----
+        constexpr int MAXG = (4 + TW - 1) / TW; // four tiles per wave cover orders up to ~500
+        d4 accs[MAXG][TW][2];
+        const int npre = wave == 0 ? 0 : (ngroups < MAXG ? ngroups : MAXG);
         if (wave == 0) {
+            const int li = lane & 31;
             double a[32];
 #pragma unroll
             for (int k = 0; k < 32; k += 2) {
@@ -724,100 +911,67 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
                 a[k + 1] = x[1] + y[1];
             }
             __builtin_amdgcn_s_setprio(3);
-            // the sweep of k_chol_left, unchanged.  (Tried: 1 / sqrt(pivot) computed one step ahead by the lane that holds the next
-            // pivot and published through LDS, so that the dozen dependent fp64 instructions run under the step's 30 independent
-            // FMAs -- hipcc keeps the chain in front of them anyway and the extra LDS hop made the sweep 25 % slower; reverted.)
-            const bool lo = lane < 32;
-            double v[32];
+            sweep32(a, lane, col, piv, blk, bad); // factor + invert, results in pj / linv
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            // one branch on the kind of source around ALL the requests, and no guard per group (a group this wave does not have
+            // re-reads tile 0's source -- cached, unused): any branch between the requests makes hipcc wait for each of them
+            if (Apk) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) v[k] = lo ? a[k] : 0.0;
-            if (lo) col[0][li] = v[0];
-#pragma unroll
-            for (int j = 0; j < ((CHOL_ABL & 1) ? 1 : 32); ++j) {
-                const double *cj = col[j & 1];
-                wave_sync();
-                double c[32];
-#pragma unroll
-                for (int k = j; k < 32; ++k) c[k] = cj[k];
-                double dj = c[j];
-                if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
-                double rs = __builtin_amdgcn_rsq(dj);
-                const double hd = 0.5 * dj;
-                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
-                rs = rs * __builtin_fma(-hd * rs, rs, 1.5);
-                double sq = dj * rs;
-                sq = __builtin_fma(__builtin_fma(-sq, sq, dj), 0.5 * rs, sq);
-                rs = __builtin_fma(__builtin_fma(-sq, rs, 1.0), rs, rs);
-                const double y = v[j] * rs;
-                const double xj = (j == li) ? rs : (j > li ? -y : 0.0);
-                const double coef = (lo ? -y : xj) * rs;
-                if (j + 1 < 32) {
-                    v[j + 1] = __builtin_fma(coef, c[j + 1], v[j + 1]);
-                    PIN_V(v[j + 1]);
-                    if (lo) col[(j + 1) & 1][li] = v[j + 1];
+                for (int g = 0; g < MAXG; ++g) {
+                    const double *pb[TW];
+                    long rows[TW];
+                    group_setup(g, pb, rows);
+                    group_src(std::true_type{}, TW, rows, accs[g]);
                 }
-                if (lo) pj[li][j] = (li == j) ? sq : (li > j ? y : 0.0);
-                else linv[j][li] = xj;
+            } else {
 #pragma unroll
-                for (int k = j + 2; k < 32; ++k) {
-                    v[k] = __builtin_fma(coef, c[k], v[k]);
-                    PIN_V(v[k]);
+                for (int g = 0; g < MAXG; ++g) {
+                    const double *pb[TW];
+                    long rows[TW];
+                    group_setup(g, pb, rows);
+                    group_src(std::false_type{}, TW, rows, accs[g]);
                 }
             }
-            wave_sync();
-            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g)
+                if (g < npre) {
+                    const double *pb[TW];
+                    long rows[TW];
+                    const int cnt = group_setup(g, pb, rows);
+                    if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, 0, j0, 0, accs[g]);
+                }
         }
-        STAMP(); // 3: (wave 0) block factored and inverted
-        long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
-        ra0 = ra0 < n ? ra0 : n - 1;
-        ra1 = ra1 < n ? ra1 : n - 1;
-        const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
-        for (int g = 0; g < ngroups; ++g) {
-            int cnt = mine - TW * g;
-            cnt = cnt < 0 ? 0 : (cnt > TW ? TW : cnt);
+        STAMP(); // 3: (wave 0) block factored and inverted / (others) k-loops done
+        __syncthreads(); // inv(L_jj) and L_jj are in LDS
+        STAMP(); // 4
+        chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
+        if (!(CHOL_ABL & 2)) {
+            LinvOps lo;
+            linv_ops_load(lo, linv, perm, q);
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g)
+                if (g < npre) {
+                    const double *pb[TW];
+                    long rows[TW];
+                    const int cnt = group_setup(g, pb, rows);
+                    group_solve(cnt, rows, lo, accs[g]);
+                }
+        }
+        STAMP(); // 5: the tiles of the first phase solved and stored (issued)
+        // ---- 4. what is left: wave 0's own tiles, and groups beyond MAXG (orders above ~500) ----
+        for (int g = npre; g < ngroups; ++g) {
             const double *pb[TW];
             long rows[TW];
-#pragma unroll
-            for (int u = 0; u < TW; ++u) {
-                const int t = u < cnt ? tile_of(TW * g + u) : 0;
-                long r = j0 + 32 + 16L * t + i16;
-                rows[u] = u < cnt ? r : n;
-                r = r < n ? r : n - 1;
-                pb[u] = Lm + r * n + 8 * q;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    if (u < cnt) acc[u][ct] = (CHOL_ABL & 64) ? d4{0.0, 0.0, 0.0, 0.0} : chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
-                }
-            }
-            if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, 0, j0, 0, acc);
-            if (g == 0) {
-                STAMP(); // 4: k-loops of the first tile group done
-                __syncthreads(); // inv(L_jj) and L_jj are in LDS
-                STAMP(); // 5
-                chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
-            }
+            const int cnt = group_setup(g, pb, rows);
+            if (Apk) group_src(std::true_type{}, cnt, rows, acc);
+            else group_src(std::false_type{}, cnt, rows, acc);
+            if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, 0, j0, 0, acc);
             if (cnt > 0 && !(CHOL_ABL & 2)) {
                 LinvOps lo;
                 linv_ops_load(lo, linv, perm, q);
-#pragma unroll
-                for (int u = 0; u < TW; ++u) {
-                    if (u < cnt) {
-                        d4 x0, x1;
-                        tile_trsm(lo, acc[u], x0, x1);
-                        if (rows[u] < n) {
-                            double *p = Lm + rows[u] * n + j0 + 4 * q;
-                            *(d2 *)p = d2{x0[0], x0[1]};
-                            *(d2 *)(p + 2) = d2{x0[2], x0[3]};
-                            *(d2 *)(p + 16) = d2{x1[0], x1[1]};
-                            *(d2 *)(p + 18) = d2{x1[2], x1[3]};
-                        }
-                    }
-                }
+                group_solve(cnt, rows, lo, acc);
             }
-        }
-        if (ngroups == 0) {
-            __syncthreads();
-            chol_block_out(pj, linv, Lm, iv, n, j0, w, tid);
         }
         STAMP(); // 6: all tile groups solved and stored (issued)
         __syncthreads(); // the panel is in memory (and pj / linv / part / pan are free) before the next one reads it
@@ -862,7 +1016,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double
         long ra0 = i0 + perm, ra1 = i0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
-        const double *pa0 = Lm + ra0 * n + 8 * q, *pa1 = Lm + ra1 * n + 8 * q;
+        const double *pa0 = Lm + ra0 * n + KOFF_Q * q, *pa1 = Lm + ra1 * n + KOFF_Q * q;
         for (int g = 0; TW * g < mine; ++g) {
             int cnt = mine - TW * g;
             cnt = cnt > TW ? TW : cnt;
@@ -874,7 +1028,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double
                 long r0 = 16L * (wave + NWV * (TW * g + u));
                 r0 = u < cnt ? r0 : 16L * wave; // unused slots alias a valid tile
                 rows[u] = r0 + i16;
-                pb[u] = Um + rows[u] * n + 8 * q;
+                pb[u] = Um + rows[u] * n + KOFF_Q * q;
                 ks[u] = (int)(r0 >> 5) << 5;
                 acc[u][0] = acc[u][1] = d4{0.0, 0.0, 0.0, 0.0};
             }
@@ -882,7 +1036,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double
 #pragma unroll
             for (int s = 0; s < TW; ++s)
                 if (s < cnt)
-                    rowdot_sel<use_lds, true>(s + 1, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, ks[s],
+                    rowdot_sel<use_lds, true>(s + 1, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, ks[s],
                                               (s + 1 < cnt) ? ks[s + 1] : i0, 0, acc);
             LinvOps lo;
             linv_ops_load(lo, linv, perm, q);
@@ -912,11 +1066,12 @@ __device__ __forceinline__ void rowdot_tail(const double *pa0, const double *pa1
 {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const bool ok = kt + 8 * q + e < n;
-        const double x0 = ok ? pa0[kt + e] : 0.0, x1 = ok ? pa1[kt + e] : 0.0;
+        const int eo = KOFF_V * (e >> 1) + (e & 1); // element e of the lane's eight: column kt + eo + KOFF_Q q
+        const bool ok = kt + eo + KOFF_Q * q < n;
+        const double x0 = ok ? pa0[kt + eo] : 0.0, x1 = ok ? pa1[kt + eo] : 0.0;
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
-            const double y = ok ? pb[u][kt + e] : 0.0;
+            const double y = ok ? pb[u][kt + eo] : 0.0;
             acc[u][0] = MFMA_F64(x0, y, acc[u][0]);
             acc[u][1] = MFMA_F64(x1, y, acc[u][1]);
         }
@@ -949,7 +1104,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
         long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
-        const double *pa0 = Um + ra0 * n + 8 * q, *pa1 = Um + ra1 * n + 8 * q;
+        const double *pa0 = Um + ra0 * n + KOFF_Q * q, *pa1 = Um + ra1 * n + KOFF_Q * q;
         if (use_lds) {
             if (j0 > 0) __syncthreads(); // every wave is done with the previous panel's rows
             if (nfl > j0) stage_panel<2 * NWV>(pan, S, Um, n, j0, j0, nfl - j0, tid);
@@ -968,7 +1123,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
                 r0 = u < cnt ? r0 : j0 + 16L * wave;
                 rows[u] = r0 + i16;
                 const long rc = rows[u] < n ? rows[u] : n - 1;
-                pb[u] = Um + rc * n + 8 * q;
+                pb[u] = Um + rc * n + KOFF_Q * q;
                 const int k0 = (int)(r0 >> 5) << 5;
                 ks[u] = k0 < nfl ? k0 : nfl;
                 acc[u][0] = acc[u][1] = d4{0.0, 0.0, 0.0, 0.0};
@@ -977,7 +1132,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
 #pragma unroll
             for (int s = 0; s < TW; ++s)
                 if (s < cnt)
-                    rowdot_sel<use_lds, false>(s + 1, pa0, pa1, pan + perm * S + 8 * q, pan + (16 + perm) * S + 8 * q, pb, ks[s],
+                    rowdot_sel<use_lds, false>(s + 1, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, ks[s],
                                                (s + 1 < cnt) ? ks[s + 1] : nfl, j0, acc);
             if (nfl < n_) {
                 switch (cnt) {
@@ -1144,6 +1299,9 @@ CholLds chol_lds(int n)
     r.uut = r.use ? pan : 16;
     return r;
 }
+#ifndef CHOL_TW_FLOW
+#define CHOL_TW_FLOW 1 // tiles per wave and k-loop of k_chol_left2 (tools/chol_probe.sh build -DCHOL_TW_FLOW=2 for A/B runs)
+#endif
 template <typename K> int chol_attr(K kernel, size_t lds, std::atomic<size_t> (&done)[16])
 {
     int dev = 0;
@@ -1163,9 +1321,9 @@ int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int 
     const long sinv = (long)((n + 31) / 32) * 1024;
     if (l.use && gmmiv_kopts_cur().chol_flow) { // round 3: panel staged first, diagonal update from LDS (k_chol_left2)
         const size_t pan = (size_t)32 * ((n & 2) ? n : n + 2) * sizeof(double);
-        int rc2 = chol_attr(k_chol_left2<1>, pan, g_attr_chol[2]);
+        int rc2 = chol_attr(k_chol_left2<CHOL_TW_FLOW>, pan, g_attr_chol[2]);
         if (rc2) return rc2;
-        k_chol_left2<1><<<nb, 512, pan, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
+        k_chol_left2<CHOL_TW_FLOW><<<nb, 512, pan, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
         return (int)hipGetLastError();
     }
     int rc = l.use ? chol_attr(k_chol_left<true>, l.chol, g_attr_chol[1]) : chol_attr(k_chol_left<false>, l.chol, g_attr_chol[0]);
