@@ -90,6 +90,9 @@ const char *gmmiv_version(void);
  *                      "topc_fallbacks" counts the calls the fused path handed on (candidate list overflow / margin check)
  *   "topc_overlap" 0   fused path on more than 262 144 frames: 1 = the ranking of a sub-chunk runs on a side stream beside the
  *                      log-likelihood kernel of the next one (bitwise the same results; measured slower, hence off)
+ *   "topc_rank_direct" 0  fused path: k_topc_rank ranks the survivors of the final threshold on their MFMA logits and re-evaluates them in
+ *                      the reference's direct form only when another survivor lies within 1e-6 of a selected one (same selection and
+ *                      order; selected likelihoods differ by < 1e-11 relative); 1 = direct form for every frame (the round-2 behaviour)
  *   "topc_z" 1         DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (k_llk_mfma<WZ> + k_topc_from_z, direct form only
  *                      for the candidates); 0: the direct-form VALU kernel for every Gaussian
  *   "timing" 0         1: record HIP events around the kernels (gmmiv_ctx_kernel_ms)

@@ -57,6 +57,7 @@ struct gmmiv_ctx {
     // 1 (default): the log-likelihood kernel leaves the logits in HBM and the statistics kernel reads
     // them back (stats_z.hip) instead of recomputing them; 0: the recomputing k_stats_mfma
     long stats_z = 1;
+    long topc_rank_direct = 0; // k_topc_rank: 1 = every frame's survivors re-evaluated in the direct form (round 2); 0 = only near-ties
     long topc_fused = 1; // DETERMINE_TOP_DISTRIBS with the candidates collected inside k_llk_mfma<TC> (no likelihood round trip); 0: topc_z
     // fused top-C, OPT-IN: rank sub-chunk i on a side stream beside the log-likelihood kernel of sub-chunk i + 1.  Measured SLOWER
     // (10^6 frames: 13.48 -> 14.16 ms, 4 x 10^6: 52.3 -> 59.7): k_topc_rank's workgroups take LDS and wave slots from k_llk_mfma<TC>,

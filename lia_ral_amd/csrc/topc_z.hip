@@ -257,14 +257,17 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
                                                    int stats)
 {
     // flag[0] = number of frames handed to the direct-form kernel (their indices in redo[]); flag[1..4] = reasons (list overflow,
-    // more than 64 survivors, fewer than ctop, margin); with `stats` also flag[5] / [6,7] = max / sum of the list lengths and
-    // flag[8] / [10,11] of the survivor counts (global atomics from every wave: measurement runs only)
+    // more than 64 survivors, fewer than ctop, margin); with `stats & 1` also flag[5] / [6,7] = max / sum of the list lengths,
+    // flag[8] / [10,11] of the survivor counts and flag[12] = frames whose survivors were re-evaluated in the direct form (global
+    // atomics from every wave: measurement runs only)
     __shared__ double xs[4][64 + 1];
     __shared__ unsigned bmap[4][64];      // Gaussians 32 l .. 32 l + 31 of the frame's list (C <= 2048)
     __shared__ double sz[4][TOPC_CAP];    // logits in canonical order
     __shared__ int si[4][TOPC_CAP];
     __shared__ int ord[4][64];
+    __shared__ double ordz[4][64];        // MFMA logits of the survivors, in the order of ord
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool force_direct = (stats & 2) != 0; // option "topc_rank_direct": every frame's survivors in the direct form (round 2)
     const long t = (long)blockIdx.x * 4 + wave;
     const bool live = t < n;
     for (int d = lane; d < D; d += 64) xs[wave][d] = live ? feat_load<XT>::get(x, t * ldx + d) : 0.0;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     if (!live) return;
     const double NINF = -__builtin_inf();
     const int ncr = cnt[t];
-    if (stats && lane == 0) { atomicMax(&flag[5], ncr); atomicAdd((unsigned long long *)&flag[6], (unsigned long long)ncr); }
+    if ((stats & 1) && lane == 0) { atomicMax(&flag[5], ncr); atomicAdd((unsigned long long *)&flag[6], (unsigned long long)ncr); }
     if (ncr > TOPC_CAP) { if (lane == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[1], 1); } return; } // list overflow: the direct-form kernel redoes the frame
     // the list length as a SCALAR: the four 64-record slices below are skipped wave-uniformly when the list ends before them (mean
     // length 68 of 256: slices 2 and 3 almost never exist, and a skipped slice costs a branch instead of its predicated
@@ -338,18 +341,32 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         if (hit) {
             const int pos = ns + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (pos < 64) ord[wave][pos] = si[wave][k];
+            if (pos < 64) { ord[wave][pos] = si[wave][k]; ordz[wave][pos] = z; }
         }
         ns += __builtin_popcountll(mask);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (stats && lane == 0) { atomicMax(&flag[8], ns); atomicAdd((unsigned long long *)&flag[10], (unsigned long long)ns); }
+    if ((stats & 1) && lane == 0) { atomicMax(&flag[8], ns); atomicAdd((unsigned long long *)&flag[10], (unsigned long long)ns); }
     if (ns > 64 || ns < (ctop < C ? ctop : C)) { if (lane == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[ns > 64 ? 2 : 3], 1); } return; } // a pile-up of near-equal logits
     const int ci = lane < ns ? ord[wave][lane] : 0x7fffffff;
     __builtin_amdgcn_wave_barrier();
     const bool cd = lane < ns && ci < C;
+    // Ranking on the MFMA logits first (|z_mfma - z_direct| ~ 1e-12): the order -- and with it the selection -- is the order of the
+    // direct form whenever no survivor lies within 1e-6 of a SELECTED one; only then (ties, duplicated Gaussians: ~1e-5 of the
+    // frames of real data) are the survivors re-evaluated in the reference's direct form below.  Round 2 did that for every frame:
+    // 15 survivors x 960 B of model rows gathered from L2 per frame were most of this kernel's 2.3 ms per 10^6 frames.
+    double zc = cd ? ordz[wave][lane] : NINF;
+    int rank = 0;
+    bool near = false;
+    for (int jj = 0; jj < ns; ++jj) {
+        const double zj = readlane_f64u(zc, jj);
+        const int cj = __builtin_amdgcn_readlane(ci, jj);
+        if (jj != lane && (zj > zc || (zj == zc && cj < ci))) ++rank;
+        near |= jj != lane && __builtin_fabs(zj - zc) <= 1e-6;
+    }
+    if (force_direct || __builtin_amdgcn_ballot_w64(cd && rank < ctop && near) != 0) { // wave-uniform
     // The survivors' logits in the reference's direct form, FOUR lanes per survivor (16 survivors per pass): lane `sub` of a
     // group takes the dimension pairs sub, sub + 4, ... of the survivor's own rows of the row-major model (16-byte loads), the
     // group's partial sums meet through two quad exchanges.  (One lane per survivor left 3/4 of the wave idle behind 120 loads.)
@@ -380,12 +397,14 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double zc = cd ? sz[wave][lane] : NINF;
-    int rank = 0;
+    zc = cd ? sz[wave][lane] : NINF;
+    rank = 0;
     for (int jj = 0; jj < ns; ++jj) {
         const double zj = readlane_f64u(zc, jj);
         const int cj = __builtin_amdgcn_readlane(ci, jj);
         if (jj != lane && (zj > zc || (zj == zc && cj < ci))) ++rank;
+    }
+    if ((stats & 1) && lane == 0) atomicAdd(&flag[12], 1);
     }
     const bool sel = cd && rank < ctop;
     const double M = wave_max_f64_dpp(zc);

@@ -459,6 +459,35 @@ def test_fused_top_c_redoes_piled_up_frames_exactly(ctx):
     ctx.set_option("topc_fused", 1); ctx.set_option("topc_z", 1)
 
 
+def test_fused_top_c_ranks_on_mfma_logits_and_resolves_ties_in_the_direct_form(ctx):
+    """k_topc_rank ranks the survivors on their MFMA logits and re-evaluates them in the reference's direct form only when another
+    survivor lies within 1e-6 of a selected one.  A mixture with three PAIRS of identical Gaussians makes exact ties inside the
+    selection (reference order: lowest index first, TopGauss.cpp:167-193): indices must equal the oracle's on every frame, and the
+    result must agree with the form that re-evaluates every frame (option topc_rank_direct, what round 2 did)."""
+    C, D, T, ctop = 512, 60, 4000, 10
+    w, mean, iv = make_gmm(C, D, seed=31, spread=0.5)
+    for a, b in ((7, 300), (8, 9), (100, 511)):
+        mean[b] = mean[a]; iv[b] = iv[a]; w[b] = w[a]
+    w /= w.sum()
+    x = make_frames(w, mean, iv, T, seed=32).astype(np.float32)
+    g = ctx.gmm(w, mean, iv)
+    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x.astype(np.float64), ctop, True)
+    res = {}
+    for direct in (0, 1):
+        ctx.set_option("topc_rank_direct", direct)
+        res[direct] = g.llk_determine_top(x, ctop, True)
+    ctx.set_option("topc_rank_direct", 0)
+    tied = sum(1 for t in range(T) if any(p in do["idx"][t] for p in (7, 8, 100)))
+    assert tied > 50                                   # the tie-breaking rule was exercised
+    for direct in (0, 1):
+        d = res[direct]
+        assert np.array_equal(d["idx"], do["idx"]), direct
+        assert np.max(np.abs(d["llk"] - do["llk"])) < 1e-9 and relerr(d["lk"], do["lk"]) < 1e-10
+        big = do["nontop_lk"] > 1e-250
+        assert relerr(d["nontop_lk"][big], do["nontop_lk"][big]) < 1e-9
+    assert relerr(res[0]["lk"], res[1]["lk"]) < 1e-11
+
+
 def test_fused_top_c_pipelined_sub_chunks_are_bitwise_the_serial_form(ctx):
     """gmmiv_llk_determine_top on more than one sub-chunk of 262 144 frames (option "topc_overlap"; off by default, it measured slower): the ranking of
     sub-chunk i runs on a side stream beside the log-likelihood kernel of sub-chunk i + 1, two sets of candidate scratch, flags read once at
