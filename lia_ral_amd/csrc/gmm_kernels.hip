@@ -113,6 +113,12 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 #ifndef K1_ABL
 #define K1_ABL 0
 #endif
+// K1_PLAIN_SHARED 1: the plain log-likelihood (MODE 0) runs the epilogue of the stored-likelihood variant without its stores -- one
+// exponent per frame ROW (DPP row maximum), every exponential evaluated, no skip logic; 0: per-lane exponents, pairs 57 binades
+// below the row's maximum skipped bit-exactly
+#ifndef K1_PLAIN_SHARED
+#define K1_PLAIN_SHARED 1
+#endif
 template <int KS, typename XT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict__ x, long T, long ldx, int D,
                                                   const double *__restrict__ Pt, int nct,
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             }
             return;
         }
-        if (WZ) {
+        if (WZ || (MODE == 0 && K1_PLAIN_SHARED)) {
             // stored-likelihood variant: E is shared by the 16 lanes of a frame row (DPP row maximum
             // of the exponents), every pair's exponential is evaluated and kept
             // The argument reduction of the 16 exponentials comes first: its integer part is the binary
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
             // previous iteration have had a whole iteration to land: wait for them HERE, before this
             // iteration's stores are issued, so that those stay in flight across the barrier.
             // (__syncthreads() would wait vmcnt(0) after the stores: an HBM write round trip per tile.)
+            if (!WZ) return; // plain log-likelihood with the shared row exponent: nothing is stored
             if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // unconditional stores: zbuf / eit cover the whole grid (nfb = 16 blocks per workgroup)
             double *zw = zbuf + ((((size_t)(te * GT)) * nfb + (tb >> 4)) * 64 + lane) * 4;
