@@ -35,6 +35,20 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define KOFF_Q 2
 #define KOFF_V 8
 #endif
+// The LDS copy of the panel rows keeps the round-1..3 placement, which is free of bank conflicts for the 16-lane groups of
+// ds_read_b128 (row stride = an odd number of 16-byte units, lane quarter q 64 bytes on): stage_panel stores the 16-byte units of
+// every 32-column chunk TRANSPOSED as a 4 x 4 block (logical unit 4 v + q -> physical unit 4 q + v), so lane quarter q finds its
+// columns 8 v + 2 q, + 1 at physical offset 8 q + 2 v.  (With the (2, 8) offsets on the LDS side too: SQ_LDS_BANK_CONFLICT 8.5 M ->
+// 32 M cycles of 92 M LDS cycles in k_chol_left2, 0 -> 20.6 M of 46 M in k_uut.)
+#if KOFF_Q == 2
+#define LOFF_Q 8
+#define LOFF_V 2
+#define PAN_UNIT(sg) (((sg) & ~15) | (((sg) & 3) << 2) | (((sg) >> 2) & 3))
+#else
+#define LOFF_Q KOFF_Q
+#define LOFF_V KOFF_V
+#define PAN_UNIT(sg) (sg)
+#endif
 
 // CHOL_ABL (compile-time, timing experiments only -- tools/chol_ablate.sh; results are wrong when != 0), k_chol_left: 1 = no factorisation /
 // inversion sweep of the diagonal block, 2 = no triangular solve + stores of the tiles, 4 = no k-loops of the off-diagonal tiles,
@@ -190,7 +204,7 @@ __device__ __forceinline__ void stage_batch(double *prow, const double *xrow, in
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u)
-        if (s0 + TPR * u < segs) *(d2 *)(prow + 2 * (s0 + TPR * u)) = v[u];
+        if (s0 + TPR * u < segs) *(d2 *)(prow + 2 * PAN_UNIT(s0 + TPR * u)) = v[u];
 }
 template <int TPR = 16> // threads per panel row: 16 for a workgroup of 512, 32 for 1024
 __device__ __forceinline__ void stage_panel(double *pan, int S, const double *X, long n, long row0, int kbase, int klen, int tid)
@@ -223,8 +237,8 @@ __device__ __forceinline__ void pan_load(PanOps &o, const double *la0, const dou
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        o.a0[v] = *(const d2 *)(la0 + kl + KOFF_V * v);
-        o.a1[v] = *(const d2 *)(la1 + kl + KOFF_V * v);
+        o.a0[v] = *(const d2 *)(la0 + kl + LOFF_V * v);
+        o.a1[v] = *(const d2 *)(la1 + kl + LOFF_V * v);
     }
 }
 template <int CNT, bool NEG, int TWT>
@@ -697,7 +711,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left(int n_, double *Afull, dou
                     if (u < cnt) acc[u][ct] = (CHOL_ABL & 64) ? d4{0.0, 0.0, 0.0, 0.0} : chol_src4(Lm, Apk, n, r, j0 + 16 * ct + 4 * q, diag_add);
                 }
             }
-            if (!(CHOL_ABL & 4)) rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, 0, j0, 0, acc);
+            if (!(CHOL_ABL & 4)) rowdot_sel<use_lds, true>(cnt, pa0, pa1, pan + perm * S + LOFF_Q * q, pan + (16 + perm) * S + LOFF_Q * q, pb, 0, j0, 0, acc);
             if (g == 0) {
                 STAMP(); // 6: k-loops of the first tile group done
                 __syncthreads(); // inv(L_jj) and L_jj are in LDS
@@ -756,8 +770,8 @@ __device__ __forceinline__ void diag_from_lds(const double *la, const double *lb
         d2 a[4], b[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            a[v] = *(const d2 *)(la + k + KOFF_V * v);
-            b[v] = *(const d2 *)(lb + k + KOFF_V * v);
+            a[v] = *(const d2 *)(la + k + LOFF_V * v);
+            b[v] = *(const d2 *)(lb + k + LOFF_V * v);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc = MFMA_F64(-a[e >> 1][e & 1], b[e >> 1][e & 1], acc);
@@ -840,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
         {
             const int half = ((j0 >> 5) >> 1) << 5; // whole 32-chunks
             const int kb = dh == 0 ? 0 : half, ke = dh == 0 ? half : j0;
-            if (!(CHOL_ABL & 8)) diag_from_lds(pan + (16 * dct + perm) * S + KOFF_Q * q, pan + (16 * du + i16) * S + KOFF_Q * q, kb, ke, dacc);
+            if (!(CHOL_ABL & 8)) diag_from_lds(pan + (16 * dct + perm) * S + LOFF_Q * q, pan + (16 * du + i16) * S + LOFF_Q * q, kb, ke, dacc);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = 16 * du + i16, k = 16 * dct + 4 * q + rr;
@@ -939,7 +953,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
                     const double *pb[TW];
                     long rows[TW];
                     const int cnt = group_setup(g, pb, rows);
-                    if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, 0, j0, 0, accs[g]);
+                    if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + LOFF_Q * q, pan + (16 + perm) * S + LOFF_Q * q, pb, 0, j0, 0, accs[g]);
                 }
         }
         STAMP(); // 3: (wave 0) block factored and inverted / (others) k-loops done
@@ -966,7 +980,7 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
             const int cnt = group_setup(g, pb, rows);
             if (Apk) group_src(std::true_type{}, cnt, rows, acc);
             else group_src(std::false_type{}, cnt, rows, acc);
-            if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, 0, j0, 0, acc);
+            if (!(CHOL_ABL & 4)) rowdot_sel<true, true>(cnt, pa0, pa1, pan + perm * S + LOFF_Q * q, pan + (16 + perm) * S + LOFF_Q * q, pb, 0, j0, 0, acc);
             if (cnt > 0 && !(CHOL_ABL & 2)) {
                 LinvOps lo;
                 linv_ops_load(lo, linv, perm, q);
@@ -1036,7 +1050,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double
 #pragma unroll
             for (int s = 0; s < TW; ++s)
                 if (s < cnt)
-                    rowdot_sel<use_lds, true>(s + 1, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, ks[s],
+                    rowdot_sel<use_lds, true>(s + 1, pa0, pa1, pan + perm * S + LOFF_Q * q, pan + (16 + perm) * S + LOFF_Q * q, pb, ks[s],
                                               (s + 1 < cnt) ? ks[s + 1] : i0, 0, acc);
             LinvOps lo;
             linv_ops_load(lo, linv, perm, q);
@@ -1132,7 +1146,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
 #pragma unroll
             for (int s = 0; s < TW; ++s)
                 if (s < cnt)
-                    rowdot_sel<use_lds, false>(s + 1, pa0, pa1, pan + perm * S + KOFF_Q * q, pan + (16 + perm) * S + KOFF_Q * q, pb, ks[s],
+                    rowdot_sel<use_lds, false>(s + 1, pa0, pa1, pan + perm * S + LOFF_Q * q, pan + (16 + perm) * S + LOFF_Q * q, pb, ks[s],
                                                (s + 1 < cnt) ? ks[s + 1] : nfl, j0, acc);
             if (nfl < n_) {
                 switch (cnt) {
