@@ -111,6 +111,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "topc_overlap")) slot = &c->topc_overlap;
     else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
     else if (!strcmp(key, "topc_rank_direct")) slot = &c->topc_rank_direct;
+    else if (!strcmp(key, "topc_rank2")) slot = &c->topc_rank2;
     // options read by the kernel launchers: kept in the context's gmmiv_kopts, bound to the calling thread by every call (GBIND)
     int *ks = nullptr;
     if (!strcmp(key, "z_waves")) { const long prev = c->ko.z_waves; c->ko.z_waves = (value == 4 || value == 16) ? (int)value : 8; return prev; }
@@ -401,7 +402,7 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
             if ((rc = c->scratch(WS_FLAGS, (size_t)nsub * 64, &flg))) return rc;
             int *efin = (int *)((double *)sl + first);
             void *redo;
-            if ((rc = c->scratch(WS_SEG, (size_t)nalloc * sizeof(long), &redo))) return rc;
+            if ((rc = c->scratch(WS_SEG, (size_t)nalloc * 2 * sizeof(long), &redo))) return rc; // second half: the frames k_topc_rank2 hands to k_topc_rank
             int krc = 0;
             bool whole = false; // too many frames failed the fused path: the paths below redo the call
             // one chunk [c0, c0 + n): k_llk_mfma<TC> + k_topc_rank on the context's stream, flags read back, failed frames redone
@@ -418,7 +419,8 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
                 c->t_begin("k_topc_rank", c0 == 0);
                 krc = gmmk_topc_rank(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->C, (const double *)cand, (const int *)cnt,
                                      (const double *)th, (const double *)sl, efin, g->mean, g->iv, g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE,
-                                     min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, (int *)flg, (long *)redo, stats | (c->topc_rank_direct ? 2 : 0));
+                                     min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, (int *)flg, (long *)redo,
+                                     stats | (c->topc_rank_direct ? 2 : 0) | (c->topc_rank2 ? 0 : 4), (long *)redo + nalloc);
                 c->t_end();
                 if (krc) return GMMIV_OK;
                 int hf[16] = {0};
@@ -485,7 +487,8 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
                     double *olk = o_lk.d ? o_lk.d + (size_t)c0 * ctop : nullptr, *onlk = o_nlk.d ? o_nlk.d + c0 : nullptr;
                     double *onllk = o_nllk.d ? o_nllk.d + c0 : nullptr, *onw = o_nw.d ? o_nw.d + c0 : nullptr, *ollk = o_llk.d ? o_llk.d + c0 : nullptr;
                     krc = gmmk_topc_rank(side, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->C, cand_s, cnt_s, th_s, sl_s, ef_s, g->mean, g->iv,
-                                         g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, flg_s, redo_s, c->topc_rank_direct ? 2 : 0);
+                                         g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, flg_s, redo_s,
+                                         (c->topc_rank_direct ? 2 : 0) | (c->topc_rank2 ? 0 : 4), (long *)redo2 + nalloc + (size_t)set * SUB);
                     if (krc) break;
                     GCHK(hipMemcpyAsync(c->topc_hflags + (size_t)i * 16, flg_s, 64, hipMemcpyDeviceToHost, side));
                     GCHK(hipEventRecord(c->topc_ev_rank[set], side));

@@ -239,6 +239,25 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v)
     v += dpp_f64_0x128(v); v += dpp_f64_0x124(v); v += dpp_f64_0x122(v); v += dpp_f64_0x121(v);
     return (readlane_f64u(v, 0) + readlane_f64u(v, 16)) + (readlane_f64u(v, 32) + readlane_f64u(v, 48));
 }
+// the same per HALF wave (lanes 0..31 / 32..63 each get their own half's result); hi = lane >= 32
+__device__ __forceinline__ double half_sum_f64_dpp(double v, bool hi)
+{
+    v += dpp_f64_0x128(v); v += dpp_f64_0x124(v); v += dpp_f64_0x122(v); v += dpp_f64_0x121(v);
+    const double a = readlane_f64u(v, 0) + readlane_f64u(v, 16), b = readlane_f64u(v, 32) + readlane_f64u(v, 48);
+    return hi ? b : a;
+}
+__device__ __forceinline__ double half_max_f64_dpp(double v, bool hi)
+{
+    v = fmax(v, dpp_f64_0x128(v)); v = fmax(v, dpp_f64_0x124(v)); v = fmax(v, dpp_f64_0x122(v)); v = fmax(v, dpp_f64_0x121(v));
+    const double a = fmax(readlane_f64u(v, 0), readlane_f64u(v, 16)), b = fmax(readlane_f64u(v, 32), readlane_f64u(v, 48));
+    return hi ? b : a;
+}
+__device__ __forceinline__ double half_min_f64_dpp(double v, bool hi)
+{
+    v = fmin(v, dpp_f64_0x128(v)); v = fmin(v, dpp_f64_0x124(v)); v = fmin(v, dpp_f64_0x122(v)); v = fmin(v, dpp_f64_0x121(v));
+    const double a = fmin(readlane_f64u(v, 0), readlane_f64u(v, 16)), b = fmin(readlane_f64u(v, 32), readlane_f64u(v, 48));
+    return hi ? b : a;
+}
 __device__ __forceinline__ double wave_max_f64_dpp(double v)
 {
     v = fmax(v, dpp_f64_0x128(v)); v = fmax(v, dpp_f64_0x124(v)); v = fmax(v, dpp_f64_0x122(v)); v = fmax(v, dpp_f64_0x121(v));

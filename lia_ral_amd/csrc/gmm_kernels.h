@@ -51,7 +51,7 @@ int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long
 int gmmk_topc_rank(hipStream_t st, int x_f64, const void *x, long n, long ldx, int D, int C, const double *cand, const int *cnt,
                    const double *theta, const double *slow, const int *efin, const double *mean, const double *iv, const double *lwc,
                    const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
-                   double *nw, double *llk, int *flag, long *redo, int stats);
+                   double *nw, double *llk, int *flag, long *redo, int stats, long *wide);
 int gmmk_topc_scatter(hipStream_t st, long n, int ctop, const long *redo, const int *sidx, const double *slk, const double *snlk,
                       const double *snllk, const double *snw, const double *sllk, int *idx, double *lk, double *nlk, double *nllk, double *nw,
                       double *llk);

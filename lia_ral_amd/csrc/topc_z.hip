@@ -246,7 +246,7 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
 // (slow 2^Efin) + the appended ones below theta (from their MFMA logits) + the rejected survivors (direct form).
 #define TOPC_CAP 256
 template <typename XT>
-__global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, long n, long ldx, int D, int C, const double *__restrict__ cand,
+__device__ __forceinline__ void topc_rank_frame(const long t, const void *__restrict__ x, long n, long ldx, int D, int C, const double *__restrict__ cand,
                                                    const int *__restrict__ cnt, const double *__restrict__ theta,
                                                    const double *__restrict__ slow, const int *__restrict__ efin,
                                                    const double *__restrict__ mean, const double *__restrict__ iv,
@@ -268,8 +268,7 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     __shared__ double ordz[4][64];        // MFMA logits of the survivors, in the order of ord
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool force_direct = (stats & 2) != 0; // option "topc_rank_direct": every frame's survivors in the direct form (round 2)
-    const long t = (long)blockIdx.x * 4 + wave;
-    const bool live = t < n;
+    const bool live = t >= 0 && t < n;
     for (int d = lane; d < D; d += 64) xs[wave][d] = live ? feat_load<XT>::get(x, t * ldx + d) : 0.0;
     bmap[wave][lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -450,6 +449,251 @@ __global__ __launch_bounds__(256) void k_topc_rank(const void *__restrict__ x, l
     }
 }
 
+// one wave per frame: frame blockIdx.x * 4 + wave
+#define TOPC_RANK_PARAMS                                                                                                              \
+    const void *__restrict__ x, long n, long ldx, int D, int C, const double *__restrict__ cand, const int *__restrict__ cnt,          \
+        const double *__restrict__ theta, const double *__restrict__ slow, const int *__restrict__ efin,                               \
+        const double *__restrict__ mean, const double *__restrict__ iv, const double *__restrict__ lwc, const double *__restrict__ w,  \
+        int ctop, int complete, double lo, double hi, int *__restrict__ idx_out, double *__restrict__ lk_out,                          \
+        double *__restrict__ nontop_lk, double *__restrict__ nontop_llk, double *__restrict__ nontop_w, double *__restrict__ llk_out,  \
+        int *__restrict__ flag, long *__restrict__ redo, int stats
+#define TOPC_RANK_FWD                                                                                                                  \
+    x, n, ldx, D, C, cand, cnt, theta, slow, efin, mean, iv, lwc, w, ctop, complete, lo, hi, idx_out, lk_out, nontop_lk, nontop_llk,    \
+        nontop_w, llk_out, flag, redo, stats
+template <typename XT> __global__ __launch_bounds__(256) void k_topc_rank(TOPC_RANK_PARAMS)
+{
+    topc_rank_frame<XT>((long)blockIdx.x * 4 + (threadIdx.x >> 6), TOPC_RANK_FWD);
+}
+// the same routine on the frames list[0 .. *list_n) -- the ones k_topc_rank2 passed on (more than 128 records or more than 32
+// survivors) -- a small fixed grid striding over them.  (A kernel of its own: with the loop around it the routine takes 138 VGPRs
+// instead of 28, which cost the every-frame form half its speed when the two shared one kernel.)
+template <typename XT> __global__ __launch_bounds__(256) void k_topc_rank_list(TOPC_RANK_PARAMS, const long *__restrict__ list, const int *__restrict__ list_n)
+{
+    const int wave = threadIdx.x >> 6;
+    const long cntl = *list_n;
+    for (long i0 = (long)blockIdx.x * 4; i0 < cntl; i0 += (long)gridDim.x * 4) { // workgroup-uniform trip count
+        const long i = i0 + wave;
+        topc_rank_frame<XT>(i < cntl ? list[i] : -1, TOPC_RANK_FWD);
+        __syncthreads(); // keep the waves of a workgroup in step between frames
+    }
+}
+
+// Two frames per wave (lanes 0..31 / 32..63), eight per workgroup: k_topc_rank above is bound by VALU issue -- ~1170 vector
+// instructions per one-frame wave (PMC) for ~70 records and ~15 survivors, i.e. most lanes idle most of the time.  Same steps, same
+// canonical order, same rules; what differs: records in four slices of 32 (lists of more than 128 records), survivors one per lane
+// (more than 32) -- such frames go to `wide` (count in flag[13]) and k_topc_rank does them in list mode right behind this kernel, no
+// host round trip; the reductions run per half wave (row rotations + 4 v_readlane, a select per half); the rank loop reads survivor jj
+// of both halves (4 v_readlane, a select).  A frame that is handed on or fails a check only clears
+// `alive` for its half: the other half carries on.  The direct form is taken by BOTH halves when either needs it (wave-uniform).
+#define TOPC_CAP2 128
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, long n, long ldx, int D, int C, const double *__restrict__ cand,
+                                                    const int *__restrict__ cnt, const double *__restrict__ theta,
+                                                    const double *__restrict__ slow, const int *__restrict__ efin,
+                                                    const double *__restrict__ mean, const double *__restrict__ iv,
+                                                    const double *__restrict__ lwc, const double *__restrict__ w, int ctop, int complete,
+                                                    double lo, double hi, int *__restrict__ idx_out, double *__restrict__ lk_out,
+                                                    double *__restrict__ nontop_lk, double *__restrict__ nontop_llk,
+                                                    double *__restrict__ nontop_w, double *__restrict__ llk_out, int *__restrict__ flag, long *__restrict__ redo,
+                                                    int stats, long *__restrict__ wide)
+{
+    __shared__ double xs[8][64 + 1];
+    __shared__ unsigned bmap[8][64];
+    __shared__ double sz[8][TOPC_CAP2];
+    __shared__ int si[8][TOPC_CAP2];
+    __shared__ int ord[8][64];
+    __shared__ double ordz[8][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
+    const bool hi2 = lane >= 32;
+    const int f = wave * 2 + (hi2 ? 1 : 0);
+    const bool force_direct = (stats & 2) != 0;
+    const long t = (long)blockIdx.x * 8 + f;
+    const bool live = t < n;
+    const long tc = live ? t : 0; // clamped: dead halves read frame 0's scalars and never write
+    for (int d = l32; d < D; d += 32) xs[f][d] = live ? feat_load<XT>::get(x, t * ldx + d) : 0.0;
+    bmap[f][l32] = 0u;
+    bmap[f][l32 + 32] = 0u;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    wsync();
+    const double NINF = -__builtin_inf();
+    const int ncr = live ? cnt[tc] : 0;
+    bool alive = live;
+    if ((stats & 1) && live && l32 == 0) { atomicMax(&flag[5], ncr); atomicAdd((unsigned long long *)&flag[6], (unsigned long long)ncr); }
+    if (alive && ncr > TOPC_CAP2) { // long list: the one-frame kernel (it hands lists beyond its own capacity to the direct-form kernel)
+        if (l32 == 0) wide[atomicAdd(&flag[13], 1)] = t;
+        alive = false;
+    }
+    const int nc = alive ? ncr : 0;
+    const int nc0 = __builtin_amdgcn_readlane(nc, 0), nc1 = __builtin_amdgcn_readlane(nc, 32);
+    const int ncmax = nc0 > nc1 ? nc0 : nc1; // scalar: slices beyond both lists are skipped wave-uniformly
+    double zl[4];
+    int cl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = l32 + 32 * j;
+        zl[j] = NINF; cl[j] = -1;
+        if (32 * j < ncmax && k < nc) {
+            const d2 rec = *(const d2 *)(cand + 2 * ((size_t)t * TOPC_CAP + k));
+            zl[j] = rec[0];
+            cl[j] = (int)__double_as_longlong(rec[1]);
+            atomicOr(&bmap[f][(cl[j] >> 5) & 63], 1u << (cl[j] & 31));
+        }
+    }
+    wsync();
+    // exclusive prefix of the word populations (two words per lane) -> canonical position of every record
+    {
+        const unsigned w0 = bmap[f][2 * l32], w1 = bmap[f][2 * l32 + 1];
+        const int p0 = __builtin_popcount(w0), p1 = __builtin_popcount(w1);
+        int inc = p0 + p1;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(inc, o, 32); if (l32 >= o) inc += v; }
+        ord[f][2 * l32] = inc - p0 - p1; // reused as the prefix table until the survivors are compacted
+        ord[f][2 * l32 + 1] = inc - p1;
+    }
+    wsync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (32 * j < ncmax && cl[j] >= 0) {
+            const int wd = (cl[j] >> 5) & 63;
+            const int pos = ord[f][wd] + __builtin_popcount(bmap[f][wd] & ((1u << (cl[j] & 31)) - 1u));
+            sz[f][pos] = zl[j];
+            si[f][pos] = cl[j];
+        }
+    wsync();
+    const double th = theta[tc];
+    const int ef = efin[tc];
+    const double lnE = (double)ef * 0.6931471805599453;
+    // canonical order from here on: lane l looks at records l, l + 32, ...; survivors (logit >= theta) are compacted in that order
+    int ns = 0;
+    double zrej[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        zrej[j] = NINF;
+        if (32 * j >= ncmax) continue; // wave-uniform
+        const int k = l32 + 32 * j;
+        const double z = k < nc ? sz[f][k] : NINF;
+        const bool hit = k < nc && z >= th;
+        zrej[j] = (k < nc && !hit) ? z : NINF;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        const unsigned m32 = hi2 ? (unsigned)(mask >> 32) : (unsigned)mask;
+        if (hit) {
+            const int pos = ns + __builtin_popcount(m32 & ((1u << l32) - 1u));
+            if (pos < 32) { ord[f][pos] = si[f][k]; ordz[f][pos] = z; }
+        }
+        ns += __builtin_popcount(m32);
+    }
+    wsync();
+    if ((stats & 1) && alive && l32 == 0) { atomicMax(&flag[8], ns); atomicAdd((unsigned long long *)&flag[10], (unsigned long long)ns); }
+    if (alive && ns > 32) { // more survivors than lanes: the one-frame kernel
+        if (l32 == 0) wide[atomicAdd(&flag[13], 1)] = t;
+        alive = false;
+    }
+    if (alive && ns < (ctop < C ? ctop : C)) {
+        if (l32 == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[3], 1); }
+        alive = false;
+    }
+    const int nsv = alive ? ns : 0;
+    const int ns0 = __builtin_amdgcn_readlane(nsv, 0), ns1 = __builtin_amdgcn_readlane(nsv, 32);
+    const int nsmax = ns0 > ns1 ? ns0 : ns1;
+    if (nsmax == 0) return; // both frames handed on (or dead): wave-uniform
+    const int ci = l32 < nsv ? ord[f][l32] : 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    const bool cd = l32 < nsv && ci < C;
+    // rank on the MFMA logits; ties go to the earlier survivor = the lower Gaussian index (canonical order)
+    double zc = cd ? ordz[f][l32] : NINF;
+    int rank = 0;
+    bool near = false;
+    for (int jj = 0; jj < nsmax; ++jj) {
+        const double za = readlane_f64u(zc, jj), zb = readlane_f64u(zc, jj + 32);
+        const double zj = hi2 ? zb : za;
+        if (jj != l32 && (zj > zc || (zj == zc && jj < l32))) ++rank;
+        near |= jj != l32 && __builtin_fabs(zj - zc) <= 1e-6;
+    }
+    if (force_direct || __builtin_amdgcn_ballot_w64(cd && rank < ctop && near) != 0) { // wave-uniform: both frames
+        // the survivors' logits in the reference's direct form, four lanes per survivor (8 survivors per half and pass)
+        for (int p0 = 0; p0 < nsmax; p0 += 8) {
+            const int cj = p0 + (l32 >> 2), sub = l32 & 3;
+            const int c = cj < nsv ? ord[f][cj] : 0x7fffffff;
+            double acc = 0.0;
+            if (c < C) {
+                const double *mu = mean + (size_t)c * D, *vi = iv + (size_t)c * D, *xr = xs[f];
+                if ((D & 1) == 0) {
+                    for (int pr = sub; pr < (D >> 1); pr += 4) {
+                        const d2 m2 = *(const d2 *)(mu + 2 * pr), v2 = *(const d2 *)(vi + 2 * pr);
+                        const double dx0 = xr[2 * pr] - m2[0], dx1 = xr[2 * pr + 1] - m2[1];
+                        acc = __builtin_fma(dx0 * dx0, v2[0], acc);
+                        acc = __builtin_fma(dx1 * dx1, v2[1], acc);
+                    }
+                } else {
+                    for (int d = sub; d < D; d += 4) {
+                        const double dx = xr[d] - mu[d];
+                        acc = __builtin_fma(dx * dx, vi[d], acc);
+                    }
+                }
+            }
+            acc += shfl_xor_f64(acc, 1);
+            acc += shfl_xor_f64(acc, 2);
+            if (sub == 0 && cj < nsv) ordz[f][cj] = c < C ? __builtin_fma(-0.5, acc, lwc[c]) : NINF;
+        }
+        wsync();
+        zc = cd ? ordz[f][l32] : NINF;
+        rank = 0;
+        for (int jj = 0; jj < nsmax; ++jj) {
+            const double za = readlane_f64u(zc, jj), zb = readlane_f64u(zc, jj + 32);
+            const double zj = hi2 ? zb : za;
+            if (jj != l32 && (zj > zc || (zj == zc && jj < l32))) ++rank;
+        }
+        if ((stats & 1) && alive && l32 == 0) atomicAdd(&flag[12], 1);
+    }
+    const bool sel = cd && rank < ctop;
+    const double M = half_max_f64_dpp(zc, hi2);
+    const double zmin = half_min_f64_dpp(sel ? zc : __builtin_inf(), hi2);
+    // every Gaussian outside the survivors has an MFMA logit below theta: it must not be able to overtake the weakest selected
+    if (alive && ns > ctop && th > zmin - 1e-6) {
+        if (l32 == 0) { redo[atomicAdd(&flag[0], 1)] = t; atomicAdd(&flag[4], 1); }
+        alive = false;
+    }
+    // remainder relative to M: never-appended likelihoods + appended below theta + rejected survivors
+    double srel = 0.0;
+    {
+        const double sl = slow[tc];
+        if (sl > 0.0) srel = exp(log(sl) + lnE - M);
+    }
+    double sr = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (32 * j < ncmax) sr += zrej[j] > NINF ? gexp(zrej[j] - M) : 0.0; // wave-uniform skip
+    srel += half_sum_f64_dpp(sr, hi2);
+    srel += half_sum_f64_dpp((cd && !sel) ? gexp(zc - M) : 0.0, hi2);
+    const double st = half_sum_f64_dpp(sel ? gexp(zc - M) : 0.0, hi2);
+    if (sel && alive) {
+        idx_out[t * ctop + rank] = ci;
+        if (lk_out) lk_out[t * ctop + rank] = exp(zc);
+        ord[f][32 + rank] = ci; // the upper half of the row is free (survivors use 0..31)
+    }
+    if (l32 == 0 && alive) {
+        const double rest_llk = srel > 0.0 ? M + log(srel) : NINF;
+        if (nontop_llk) nontop_llk[t] = rest_llk;
+        if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+        if (llk_out) {
+            const double tot = complete ? st + srel : st;
+            llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+        }
+    }
+    if (nontop_w) {
+        wsync();
+        if (l32 == 0 && alive) {
+            double snsw = 1.0;
+            for (int k = 0; k < ctop; ++k) snsw -= w[ord[f][32 + k]];
+            nontop_w[t] = snsw;
+        }
+    }
+}
+
 // results of the frames redone by the direct-form kernel (rows i of the s* arrays) -> rows redo[i] of the caller's arrays
 __global__ void k_topc_scatter(long n, int ctop, const long *__restrict__ redo, const int *__restrict__ sidx, const double *__restrict__ slk,
                                const double *__restrict__ snlk, const double *__restrict__ snllk, const double *__restrict__ snw,
@@ -481,17 +725,28 @@ int gmmk_topc_scatter(hipStream_t st, long n, int ctop, const long *redo, const 
 int gmmk_topc_rank(hipStream_t st, int x_f64, const void *x, long n, long ldx, int D, int C, const double *cand, const int *cnt,
                    const double *theta, const double *slow, const int *efin, const double *mean, const double *iv, const double *lwc,
                    const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
-                   double *nw, double *llk, int *flag, long *redo, int stats)
+                   double *nw, double *llk, int *flag, long *redo, int stats, long *wide)
 {
+    // stats: bit 0 = list / survivor statistics (global atomics), bit 1 = direct form for every frame, bit 2 = one frame per wave only;
+    // wide = n longs of device memory for the frames the two-frame kernel hands to the one-frame kernel (NULL: one frame per wave)
     if (n <= 0) return 0;
     if (C > 2048 || D > 64 || ctop > 16) return -1; // the index bitmap / frame row / threshold rule of this path
-    const unsigned grid = (unsigned)((n + 3) / 4);
-    if (x_f64)
-        k_topc_rank<double><<<grid, 256, 0, st>>>(x, n, ldx, D, C, cand, cnt, theta, slow, efin, mean, iv, lwc, w, ctop, complete, lo, hi, idx, lk,
-                                                  nlk, nllk, nw, llk, flag, redo, stats);
-    else
-        k_topc_rank<float><<<grid, 256, 0, st>>>(x, n, ldx, D, C, cand, cnt, theta, slow, efin, mean, iv, lwc, w, ctop, complete, lo, hi, idx, lk,
-                                                 nlk, nllk, nw, llk, flag, redo, stats);
+    const bool two = wide && !(stats & 4);
+    stats &= 3;
+#define TOPC_RANK_ARGS x, n, ldx, D, C, cand, cnt, theta, slow, efin, mean, iv, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk, flag, redo, stats
+    if (two) {
+        const unsigned grid2 = (unsigned)((n + 7) / 8);
+        if (x_f64) k_topc_rank2<double><<<grid2, 256, 0, st>>>(TOPC_RANK_ARGS, wide);
+        else k_topc_rank2<float><<<grid2, 256, 0, st>>>(TOPC_RANK_ARGS, wide);
+        // the frames it passed on (count in flag[13], known to the device only): a small fixed grid strides over the list
+        if (x_f64) k_topc_rank_list<double><<<128, 256, 0, st>>>(TOPC_RANK_ARGS, wide, flag + 13);
+        else k_topc_rank_list<float><<<128, 256, 0, st>>>(TOPC_RANK_ARGS, wide, flag + 13);
+    } else {
+        const unsigned grid = (unsigned)((n + 3) / 4);
+        if (x_f64) k_topc_rank<double><<<grid, 256, 0, st>>>(TOPC_RANK_ARGS);
+        else k_topc_rank<float><<<grid, 256, 0, st>>>(TOPC_RANK_ARGS);
+    }
+#undef TOPC_RANK_ARGS
     return (int)hipGetLastError();
 }
 

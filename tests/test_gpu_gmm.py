@@ -488,6 +488,35 @@ def test_fused_top_c_ranks_on_mfma_logits_and_resolves_ties_in_the_direct_form(c
     assert relerr(res[0]["lk"], res[1]["lk"]) < 1e-11
 
 
+@pytest.mark.parametrize("spread,ctop", [(2.0, 10), (0.3, 10), (0.1, 16), (2.0, 1)])
+def test_fused_top_c_two_frames_per_wave_matches_one_frame_per_wave(ctx, spread, ctop):
+    """k_topc_rank2 (two frames per wave; frames with more than 128 records or more than 32 survivors are passed to k_topc_rank in
+    list mode without a host round trip) against k_topc_rank on every frame: identical indices, values to 1e-12 (the half-wave
+    sums add in another order) -- on separated, overlapping and very flat mixtures (the flat one has wide frames) and an odd frame
+    count (a dead half wave).  Both against the oracle."""
+    C, D, T = 2048, 60, 3001
+    w, mean, iv = make_gmm(C, D, seed=41, spread=spread)
+    x = make_frames(w, mean, iv, T, seed=42).astype(np.float32)
+    g = ctx.gmm(w, mean, iv)
+    res = {}
+    for two in (1, 0):
+        ctx.set_option("topc_rank2", two)
+        ctx.set_option("topc_fallbacks", 0)
+        res[two] = g.llk_determine_top(x, ctop, complete=True)
+        res[two]["fallbacks"] = ctx.set_option("topc_fallbacks", 0)
+    ctx.set_option("topc_rank2", 1)
+    assert np.array_equal(res[1]["idx"], res[0]["idx"])
+    for k in ("lk", "nontop_lk", "llk", "nontop_w"):
+        assert relerr(res[1][k], res[0][k]) < 1e-12, k
+    fin = np.isfinite(res[0]["nontop_llk"])
+    assert np.array_equal(fin, np.isfinite(res[1]["nontop_llk"]))
+    assert np.max(np.abs(res[1]["nontop_llk"][fin] - res[0]["nontop_llk"][fin])) < 1e-10
+    assert res[1]["fallbacks"] == res[0]["fallbacks"]     # passing a frame on to the one-frame kernel is not a fallback
+    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x[:600].astype(np.float64), ctop, True)
+    assert np.array_equal(res[1]["idx"][:600], do["idx"])
+    assert np.max(np.abs(res[1]["llk"][:600] - do["llk"])) < 1e-9
+
+
 def test_fused_top_c_pipelined_sub_chunks_are_bitwise_the_serial_form(ctx):
     """gmmiv_llk_determine_top on more than one sub-chunk of 262 144 frames (option "topc_overlap"; off by default, it measured slower): the ranking of
     sub-chunk i runs on a side stream beside the log-likelihood kernel of sub-chunk i + 1, two sets of candidate scratch, flags read once at
