@@ -252,8 +252,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
         // sacc * 2^E >= 2^nref already, so such a term (both of its terms together) is < 2^-54 of the sum -- skipping is bit-exact.
         // All branches are wave-uniform (ballots): every VALU instruction here is MFMA time.
         if (TC) {
-            // refresh schedule (wave-uniform): every stage up to 8, every 2nd up to 16, every 4th up to 32, then every 8th, and the last
-            const bool refresh = te < 8 || (te < 16 && (te & 1) == 1) || (te < 32 && (te & 3) == 3) || (te & 7) == 7 || te == ntiles - 1;
+            // refresh schedule (wave-uniform): after stages 0, 1, 3, 7, 15, 31, ... and the last.  A refresh is ~400 VALU instructions per
+            // wave (eight rows x six knock-out rounds), an appended record far less: round 2 refreshed 21 times in 64 stages (every stage
+            // up to 8, every 2nd up to 16, every 4th up to 32, every 8th after: 70 records per frame, TC_SCHED 0); measured per 10^6
+            // frames, log-likelihood kernel + ranking: 21 refreshes 11.19 + 1.11 ms (70 records), 15: 10.93 + 1.12 (73), 12: 10.80 + 1.12
+            // (74), these 7: 10.50 + 1.17 (87), the same without stage 0: 11.3 + 1.2 (111), 5 refreshes: 13.9 + 1.4 (134).
+#ifndef TC_SCHED
+#define TC_SCHED 1
+#endif
+            const bool refresh = TC_SCHED == 0 ? (te < 8 || (te < 16 && (te & 1) == 1) || (te < 32 && (te & 3) == 3) || (te & 7) == 7 || te == ntiles - 1)
+                                               : ((te & (te + 1)) == 0 || te == ntiles - 1);
             const int kth = dbg > 0 ? dbg : 16;          // TC: the launcher passes ctop here
             // one half (16 frames) at a time: the temporaries of 4 rows, not 8, are live
 #pragma unroll

@@ -485,7 +485,10 @@ template <typename XT> __global__ __launch_bounds__(256) void k_topc_rank_list(T
 // host round trip; the reductions run per half wave (row rotations + 4 v_readlane, a select per half); the rank loop reads survivor jj
 // of both halves (4 v_readlane, a select).  A frame that is handed on or fails a check only clears
 // `alive` for its half: the other half carries on.  The direct form is taken by BOTH halves when either needs it (wave-uniform).
+#ifndef TOPC_CAP2
 #define TOPC_CAP2 128
+#endif
+#define TOPC_NSL2 (TOPC_CAP2 / 32)
 template <typename XT>
 __global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, long n, long ldx, int D, int C, const double *__restrict__ cand,
                                                     const int *__restrict__ cnt, const double *__restrict__ theta,
@@ -530,10 +533,10 @@ __global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, 
     const int nc = alive ? ncr : 0;
     const int nc0 = __builtin_amdgcn_readlane(nc, 0), nc1 = __builtin_amdgcn_readlane(nc, 32);
     const int ncmax = nc0 > nc1 ? nc0 : nc1; // scalar: slices beyond both lists are skipped wave-uniformly
-    double zl[4];
-    int cl[4];
+    double zl[TOPC_NSL2];
+    int cl[TOPC_NSL2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TOPC_NSL2; ++j) {
         const int k = l32 + 32 * j;
         zl[j] = NINF; cl[j] = -1;
         if (32 * j < ncmax && k < nc) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, 
     }
     wsync();
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TOPC_NSL2; ++j)
         if (32 * j < ncmax && cl[j] >= 0) {
             const int wd = (cl[j] >> 5) & 63;
             const int pos = ord[f][wd] + __builtin_popcount(bmap[f][wd] & ((1u << (cl[j] & 31)) - 1u));
@@ -569,9 +572,9 @@ __global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, 
     const double lnE = (double)ef * 0.6931471805599453;
     // canonical order from here on: lane l looks at records l, l + 32, ...; survivors (logit >= theta) are compacted in that order
     int ns = 0;
-    double zrej[4];
+    double zrej[TOPC_NSL2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TOPC_NSL2; ++j) {
         zrej[j] = NINF;
         if (32 * j >= ncmax) continue; // wave-uniform
         const int k = l32 + 32 * j;
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, 
     }
     double sr = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TOPC_NSL2; ++j)
         if (32 * j < ncmax) sr += zrej[j] > NINF ? gexp(zrej[j] - M) : 0.0; // wave-uniform skip
     srel += half_sum_f64_dpp(sr, hi2);
     srel += half_sum_f64_dpp((cd && !sel) ? gexp(zc - M) : 0.0, hi2);
