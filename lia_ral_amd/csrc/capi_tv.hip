@@ -288,6 +288,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
     const int nz = tvk_splitk_count(BC, R, (int)SV, c->n_cu);
     size_t slab_doubles = (size_t)nz * BC * R;
     if (accumulate && slab_doubles < (size_t)TVK_BATCH_SUM_SLABS * P) slab_doubles = (size_t)TVK_BATCH_SUM_SLABS * P; // also the partial sums of sum_u E_u
+    if (accumulate && slab_doubles < TVK_NARROW_SLABS_DOUBLES(R)) slab_doubles = TVK_NARROW_SLABS_DOUBLES(R); // ... and of sum_u w_u
     if ((rc = c->scratch(WS_SLAB, slab_doubles * 8, &p))) { free_owned(); return rc; }
     double *slabs = (double *)p;
     InvWs ws;
@@ -335,8 +336,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         if (s0 + SB >= U && d_a == A_packed) c->hook_tv_a_ready.call();
         GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, (int)ns, 1.0, Ws, R, 0, Fs, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
         GCHK(tvk_batch_sum(c->stream, (long)P, (int)ns, Lp0, (long)P, d_rp, slabs)); // slabs (split-K workspace of aux) is free again
-        GCHK(tvk_batch_sum(c->stream, R, (int)ns, Ws, R, d_r));
-        GCHK(tvk_batch_sum(c->stream, R, (int)ns, Ws, R, d_mw));
+        GCHK(tvk_colsum_narrow(c->stream, R, (int)ns, Ws, R, d_r, d_mw, slabs)); // r and meanW both accumulate sum_u w_u; slabs is free again (stream order)
     }
     }
     if (accumulate) {

@@ -28,6 +28,8 @@ int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, con
 int tvk_merge_rows(hipStream_t st, long ndst, long width, const long *off, const long *rows, const double *src, double *dst);
 #define TVK_BATCH_SUM_SLABS 16
 int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride, double *dst, double *tmp = nullptr); // tmp: SLABS * n doubles
+#define TVK_NARROW_SLABS_DOUBLES(n) ((size_t)32 * (size_t)(n))
+int tvk_colsum_narrow(hipStream_t st, int n, int nb, const double *src, long stride, double *dst, double *dst2, double *tmp); // tmp: 32 * n doubles
 int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full);
 int tvk_md_normalize(hipStream_t st, int R, double n_sessions, double *Rm, double *r, double *work); // Rm, work <- Rm / n - (r / n)(r / n)^T ; r /= n
 int tvk_lower_to_upper(hipStream_t st, int n, const double *L, double *U);                       // U = L^T, zero below the diagonal

@@ -585,6 +585,40 @@ __global__ void k_batch_sum_fin(long n, int ny, const double *__restrict__ tmp, 
     }
 }
 
+// column sums of a NARROW matrix (n of a few hundred columns: sum_u w_u over thousands of utterances) into one or two accumulators.
+// k_batch_sum gives such a matrix two workgroups whose threads each walk all nb rows -- 0.63 ms for 2048 x 400, twice per E-step
+// (r and meanW both accumulate sum_u w_u), 3 % of a T-matrix iteration.  Here slab y of 64-column group x is a workgroup: its four waves
+// take the slab's rows in turn, meet in LDS, and tmp[y][e] gets the slab's sum; k_colsum_narrow_fin adds the slabs in fixed order.
+#define TVK_NARROW_SLABS 32
+__global__ __launch_bounds__(256) void k_colsum_narrow_part(int n, int nb, int rows_per, const double *__restrict__ src, long stride,
+                                                            double *__restrict__ tmp)
+{
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, e = blockIdx.x * 64 + lane;
+    const int b0 = blockIdx.y * rows_per, b1 = b0 + rows_per < nb ? b0 + rows_per : nb;
+    double s0 = 0.0, s1 = 0.0;
+    if (e < n) {
+        int b = b0 + wave;
+        for (; b + 4 < b1; b += 8) {
+            s0 += src[(size_t)b * stride + e];
+            s1 += src[(size_t)(b + 4) * stride + e];
+        }
+        if (b < b1) s0 += src[(size_t)b * stride + e];
+    }
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && e < n) tmp[(size_t)blockIdx.y * n + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ void k_colsum_narrow_fin(int n, int ny, const double *__restrict__ tmp, double *__restrict__ dst, double *__restrict__ dst2)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int y = 0; y < ny; ++y) s += tmp[(size_t)y * n + e];
+    dst[e] += s;
+    if (dst2) dst2[e] += s;
+}
+
 // full symmetric [n x n] += unpack(packed lower [n(n+1)/2])
 __global__ void k_add_unpacked(int n, const double *__restrict__ packed, double *__restrict__ full)
 {
@@ -1186,6 +1220,20 @@ int tvk_batch_sum(hipStream_t st, long n, int nb, const double *src, long stride
         return (int)hipGetLastError();
     }
     k_batch_sum<<<blocks, 256, 0, st>>>(n, nb, src, stride, dst);
+    return (int)hipGetLastError();
+}
+// dst[e] += sum_b src[b * stride + e] (and dst2, when given) for a narrow matrix; tmp: TVK_NARROW_SLABS * n doubles
+int tvk_colsum_narrow(hipStream_t st, int n, int nb, const double *src, long stride, double *dst, double *dst2, double *tmp)
+{
+    if (nb <= 0 || n <= 0) return 0;
+    if (!tmp || nb < 64) {
+        k_batch_sum<<<(n + 255) / 256, 256, 0, st>>>(n, nb, src, stride, dst);
+        if (dst2) k_batch_sum<<<(n + 255) / 256, 256, 0, st>>>(n, nb, src, stride, dst2);
+        return (int)hipGetLastError();
+    }
+    const int rows_per = (nb + TVK_NARROW_SLABS - 1) / TVK_NARROW_SLABS, ny = (nb + rows_per - 1) / rows_per;
+    k_colsum_narrow_part<<<dim3((n + 63) / 64, ny), 256, 0, st>>>(n, nb, rows_per, src, stride, tmp);
+    k_colsum_narrow_fin<<<(n + 255) / 256, 256, 0, st>>>(n, ny, tmp, dst, dst2);
     return (int)hipGetLastError();
 }
 int tvk_add_unpacked(hipStream_t st, int n, const double *packed, double *full)
