@@ -937,19 +937,27 @@ __global__ void k_dev_spk_sums(int dim, long n, const double *__restrict__ X, lo
     for (long j = off[c]; j < off[c + 1]; ++j) s += X[k * n + j];
     ssum[e] = s;
 }
-// mean[k] = sum_c ssum[k,c] / n ; smean[k,c] = ssum[k,c] / count_c
-__global__ void k_dev_means(int dim, long n, long nspk, const long *__restrict__ off, const double *__restrict__ ssum,
-                            double *__restrict__ mean, double *__restrict__ smean)
+// mean[k] = sum_c ssum[k,c] / n ; smean[k,c] = ssum[k,c] / count_c.  One workgroup per dimension k, its threads stride over the
+// speakers (coalesced; the first version gave each of the `dim` threads a whole row to walk: 0.63 ms for 400 x 20 k speakers),
+// partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_dev_means(int dim, long n, long nspk, const long *__restrict__ off, const double *__restrict__ ssum,
+                                                   double *__restrict__ mean, double *__restrict__ smean)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= dim) return;
+    __shared__ double part[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
     double s = 0.0;
-    for (long c = 0; c < nspk; ++c) {
+    for (long c = tid; c < nspk; c += 256) {
         const double v = ssum[(size_t)k * nspk + c];
         s += v;
         smean[(size_t)k * nspk + c] = v / (double)(off[c + 1] - off[c]);
     }
-    mean[k] = s / (double)n;
+    part[tid] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) part[tid] += part[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) mean[k] = part[0] / (double)n;
 }
 // mode 0: out = X - mean ; 1: out = X - smean[class] ; 2: out = (X - smean[class]) / sqrt(count[class])
 __global__ void k_dev_center(int dim, long n, int mode, const double *__restrict__ X, const double *__restrict__ mean,
@@ -988,7 +996,7 @@ __global__ void k_dev_expand(int rows, long n, long nspk, const double *__restri
 int tvk_dev_means(hipStream_t st, int dim, long n, const double *X, long nspk, const long *off, double *ssum, double *mean, double *smean)
 {
     k_dev_spk_sums<<<(unsigned)(((long)dim * nspk + 255) / 256), 256, 0, st>>>(dim, n, X, nspk, off, ssum);
-    k_dev_means<<<(dim + 255) / 256, 256, 0, st>>>(dim, n, nspk, off, ssum, mean, smean);
+    k_dev_means<<<dim, 256, 0, st>>>(dim, n, nspk, off, ssum, mean, smean);
     return (int)hipGetLastError();
 }
 static unsigned ew_blocks(long n);
