@@ -33,6 +33,28 @@ def tv_problem(C, D, R, U, seed=0, frames=200):
     return dict(w=w, mean=mean, iv=iv, N=N, F=F, Tm=Tm, C=C, D=D, R=R, U=U)
 
 
+@pytest.mark.parametrize("R,where", [(96, 0), (400, 0), (400, 37), (400, 399), (512, 130), (35, 20)])
+def test_ivector_extraction_reports_a_system_that_is_not_positive_definite(ctx, R, where):
+    """The batched factorisation flags a non-positive pivot (first column, inside a diagonal block, last column; every kernel variant:
+    LDS panels, per-wave panel rows at order 512, the GEMM-built path at an odd order) and the call fails with a numeric error instead
+    of returning i-vectors of a broken system; the healthy utterances of the same batch are not what decides the status."""
+    from lia_ral_amd import capi
+    C, D, U = 4, 12, 5
+    p = tv_problem(C, D, R, U, seed=R + where)
+    invvar = p["iv"].ravel()
+    te = ctx.tv_tett(p["Tm"], invvar, C, D)                    # [C, P] packed lower rows
+    F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
+    W = ctx.tv_estimate_w(p["N"], F0, p["Tm"], invvar, te, C, D)
+    assert np.isfinite(W).all()
+    bad = te.copy()
+    d = where * (where + 1) // 2 + where                        # packed position of diagonal element `where`
+    bad[:, d] = -1e6                                            # L_u = I + sum_c N_uc TETt_c gets a hugely negative pivot there
+    with pytest.raises(capi.GmmivError):
+        ctx.tv_estimate_w(p["N"], F0, p["Tm"], invvar, bad, C, D)
+    W2 = ctx.tv_estimate_w(p["N"], F0, p["Tm"], invvar, te, C, D)   # the context is usable afterwards
+    assert np.array_equal(W2, W)
+
+
 @pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 5), (64, 60, 50, 9), (32, 20, 100, 40), (128, 60, 400, 3),
                                      (16, 12, 35, 6), (16, 12, 34, 300), (8, 12, 450, 4),    # odd order (GEMM-built path), > 1 tile pass
                                      (4, 12, 512, 3)])   # order 512: the panel rows no longer fit LDS -- the kernels that fetch them per wave
