@@ -80,7 +80,8 @@ def test_ivector_extraction(ctx, C, D, R, U):
     assert relerr(W_g, W_o) < 1e-9          # north_star bar is 1e-6
 
 
-@pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 30), (32, 20, 40, 300), (8, 12, 35, 20), (8, 12, 450, 5), (4, 12, 512, 4)])   # 512: inverse through the non-LDS kernels
+@pytest.mark.parametrize("C,D,R,U", [(16, 12, 4, 30), (32, 20, 40, 300), (8, 12, 35, 20), (8, 12, 450, 5), (4, 12, 512, 4),   # 512: inverse through the non-LDS kernels
+                                     (32, 12, 80, 33), (32, 60, 160, 70), (64, 60, 400, 9)])   # R = 80 k, C D = 128 m (no strips in N), odd K = 17 / 35 / 5 in the A^T B products
 def test_tv_em_iteration(ctx, C, D, R, U):
     p = tv_problem(C, D, R, U, seed=7, frames=120)
     invvar = p["iv"].ravel()
