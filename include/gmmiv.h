@@ -92,6 +92,8 @@ const char *gmmiv_version(void);
  *                      log-likelihood kernel of the next one (bitwise the same results; measured slower, hence off)
  *   "topc_rank2" 1     fused path: the ranking kernel handles two frames per wave (k_topc_rank2; frames with more than 128 candidate
  *                      records or more than 32 survivors go through the one-frame kernel right behind it); 0 = one frame per wave
+ *   "topc_use_lanes" 4  USE_TOP_DISTRIBS with at most 16 candidates: four lanes per candidate read 64 contiguous bytes of its model row per
+ *                      instruction (k_topc_use4, one frame per wave); 1 = one lane per candidate (k_topc_use16, four frames per wave)
  *   "topc_rank_direct" 0  fused path: k_topc_rank ranks the survivors of the final threshold on their MFMA logits and re-evaluates them in
  *                      the reference's direct form only when another survivor lies within 1e-6 of a selected one (same selection and
  *                      order; selected likelihoods differ by < 1e-11 relative); 1 = direct form for every frame (the round-2 behaviour)

@@ -112,6 +112,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
     else if (!strcmp(key, "topc_rank_direct")) slot = &c->topc_rank_direct;
     else if (!strcmp(key, "topc_rank2")) slot = &c->topc_rank2;
+    else if (!strcmp(key, "topc_use_lanes")) slot = &c->topc_use_lanes;
     // options read by the kernel launchers: kept in the context's gmmiv_kopts, bound to the calling thread by every call (GBIND)
     int *ks = nullptr;
     if (!strcmp(key, "z_waves")) { const long prev = c->ko.z_waves; c->ko.z_waves = (value == 4 || value == 16) ? (int)value : 8; return prev; }
@@ -583,9 +584,10 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     if ((rc = i_n.init(c, WS_T1, nontop_llk, (size_t)T))) return rc;
     if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T, false))) return rc;
     c->t_begin("k_topc_use");
-    // 16 lanes per frame when the selection fits a DPP row (topc_z.hip); else one wave per frame
+    // four lanes per candidate, one frame per wave ("topc_use_lanes" 1: one lane per candidate, four frames per wave) when the
+    // selection has at most 16 entries (topc_z.hip); else one wave per frame
     int krc = c->topc_z ? gmmk_topc_use16(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
-                                          mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d)
+                                          mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d, (int)c->topc_use_lanes)
                         : -1;
     if (krc == -1)
         krc = gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,

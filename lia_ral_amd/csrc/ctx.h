@@ -57,6 +57,7 @@ struct gmmiv_ctx {
     // 1 (default): the log-likelihood kernel leaves the logits in HBM and the statistics kernel reads
     // them back (stats_z.hip) instead of recomputing them; 0: the recomputing k_stats_mfma
     long stats_z = 1;
+    long topc_use_lanes = 4;   // USE_TOP_DISTRIBS: lanes per candidate -- 4 (k_topc_use4, one frame per wave) or 1 (k_topc_use16, four frames per wave)
     long topc_rank2 = 1;       // k_topc_rank2 (two frames per wave) + k_topc_rank on the frames it passes on; 0 = k_topc_rank for every frame
     long topc_rank_direct = 0; // k_topc_rank: 1 = every frame's survivors re-evaluated in the direct form (round 2); 0 = only near-ties
     long topc_fused = 1; // DETERMINE_TOP_DISTRIBS with the candidates collected inside k_llk_mfma<TC> (no likelihood round trip); 0: topc_z

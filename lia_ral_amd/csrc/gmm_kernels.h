@@ -68,6 +68,6 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
                      const double *w, int ctop, int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
                      double *nw, double *llk, int *flag);
 int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
-                    const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk);
+                    const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk, int four);
 int gmmk_post_from_z(hipStream_t st, long n, int C, int nct, const double *zbuf, long nfb, const int *eit, const double *inv,
                      const int *efin, double *gamma);

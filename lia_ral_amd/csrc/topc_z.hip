@@ -810,11 +810,72 @@ __global__ __launch_bounds__(256) void k_topc_use16(const void *__restrict__ x, 
     }
 }
 
+// The same with FOUR lanes per candidate and one frame per wave (16 candidate slots x 4): k_topc_use16 is bound by the address
+// path, not by bytes -- every load instruction of a wave touches 40 different 128-byte lines (40 busy lanes, one row each, 16
+// bytes at a time), 600 line look-ups per frame.  Here the four lanes of a candidate read 64 contiguous bytes of its row per
+// instruction: 10 half lines per instruction, 160 per frame; the partial sums of a candidate meet with two quad exchanges.
+// 1.22 -> 0.97 ms per 10^6 frames and client model.  (Measured and dropped: two lanes per candidate with two frames per wave --
+// quarter lines, back on the address path: 1.25 ms; four lanes with four frames per wave one after the other and ONE tail for the
+// four -- fewer waves in flight cost more than the shared reductions / exponentials / logarithm save: 1.04 ms.)
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_use4(const void *__restrict__ x, long T, long ldx, int D, const double *__restrict__ mean,
+                                                   const double *__restrict__ iv, const double *__restrict__ lwc, int C, int ctop,
+                                                   const int *__restrict__ idx, const double *__restrict__ nontop_llk, int complete,
+                                                   double lo, double hi, double *__restrict__ llk_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 2, sub = lane & 3;
+    const long t = (long)blockIdx.x * 4 + wave;
+    if (t >= T) return; // wave-uniform
+    const double NINF = -__builtin_inf();
+    const int c = slot < ctop ? idx[t * ctop + slot] : -1;
+    const bool live = (unsigned)c < (unsigned)C; // an index outside the model (a caller's stale / mis-strided vector) is skipped, never dereferenced
+    const int cc = live ? c : 0;
+    const d2 *mu = (const d2 *)(mean + (size_t)cc * D), *vi = (const d2 *)(iv + (size_t)cc * D);
+    const int np = D >> 1; // dimension pairs
+    double acc = 0.0;
+    for (int p0 = 0; p0 < np; p0 += 16) {
+        d2 m[4], v[4];
+        double x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { // all loads of the batch first
+            const int p = p0 + sub + 4 * u, pc = p < np ? p : np - 1;
+            m[u] = mu[pc];
+            v[u] = vi[pc];
+            x0[u] = feat_load<XT>::get(x, t * ldx + 2 * pc);
+            x1[u] = feat_load<XT>::get(x, t * ldx + 2 * pc + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = p0 + sub + 4 * u < np;
+            const double dx0 = x0[u] - m[u][0], dx1 = x1[u] - m[u][1];
+            const double a1 = __builtin_fma(dx1 * dx1, v[u][1], __builtin_fma(dx0 * dx0, v[u][0], acc));
+            acc = ok ? a1 : acc;
+        }
+    }
+    acc += __hiloint2double(dpp_i32<0xB1>(__double2hiint(acc)), dpp_i32<0xB1>(__double2loint(acc))); // quad_perm [1 0 3 2]
+    acc += __hiloint2double(dpp_i32<0x4E>(__double2hiint(acc)), dpp_i32<0x4E>(__double2loint(acc))); // quad_perm [2 3 0 1]
+    const double z = live ? __builtin_fma(-0.5, acc, lwc[cc]) : NINF;
+    const double r = (complete && nontop_llk) ? nontop_llk[t] : NINF;
+    const double M = wave_max_f64_dpp(fmax(z, r));
+    const double s0 = wave_sum_f64_dpp((live && sub == 0) ? gexp(z - M) : 0.0);
+    if (lane == 0) {
+        const double s = r > NINF ? s0 + gexp(r - M) : s0;
+        llk_out[t] = fmin(fmax(M + log(s), lo), hi);
+    }
+}
+
 int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
-                    const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk)
+                    const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk,
+                    int four)
 {
     if (T <= 0) return 0;
     if (ctop > 16 || D % 2 != 0) return -1; // the caller keeps the one-wave-per-frame kernel
+    if (four == 4) { // four lanes per candidate, one frame per wave
+        const unsigned grid4 = (unsigned)((T + 3) / 4);
+        if (x_f64) k_topc_use4<double><<<grid4, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
+        else k_topc_use4<float><<<grid4, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
+        return (int)hipGetLastError();
+    }
     const unsigned grid = (unsigned)((T + 15) / 16);
     const size_t lds = (size_t)16 * (D + 1) * sizeof(double);
     if (x_f64) k_topc_use16<double><<<grid, 256, lds, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);

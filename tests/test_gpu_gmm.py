@@ -104,6 +104,38 @@ def test_top_c_matches_oracle(ctx, C, D, T, ctop, complete):
     assert np.max(np.abs(lc - lco)) < 1e-9
 
 
+@pytest.mark.parametrize("C,D,T,ctop,dtype", [(64, 60, 1001, 10, np.float32), (64, 62, 37, 16, np.float64), (16, 2, 9, 3, np.float32),
+                                              (256, 64, 130, 1, np.float32), (32, 34, 6, 7, np.float64)])
+def test_use_top_lane_layouts_agree(ctx, C, D, T, ctop, dtype):
+    """USE_TOP_DISTRIBS: k_topc_use4 (four lanes per candidate, one frame per wave; the default) and k_topc_use16 (one lane, four
+    frames) against each other and the oracle -- dimension counts with a masked last batch, frame counts that leave waves without
+    a frame, and index vectors with entries outside the model (skipped, never dereferenced, by both)."""
+    w, mean, iv = make_gmm(C, D, seed=C + D)
+    x = make_frames(w, mean, iv, T, seed=T).astype(dtype)
+    world = ctx.gmm(w, mean, iv)
+    client = ctx.gmm(w, mean + np.random.default_rng(7).normal(0, 0.2, mean.shape), iv * 1.1)
+    d = world.llk_determine_top(x, ctop, True)
+    res = {}
+    for lanes in (4, 1):
+        ctx.set_option("topc_use_lanes", lanes)
+        res[lanes] = client.llk_use_top(x, d["idx"], d["nontop_llk"], True)
+    ctx.set_option("topc_use_lanes", 4)
+    assert np.max(np.abs(res[4] - res[1])) < 1e-12
+    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x.astype(np.float64), ctop, True)
+    oc = orc.Gmm(w, mean + np.random.default_rng(7).normal(0, 0.2, mean.shape), iv * 1.1)
+    assert np.max(np.abs(res[4] - orc.llk_use_top(oc, x.astype(np.float64), do["idx"], do["nontop_lk"], True))) < 1e-9
+    if ctop > 1:
+        bad = d["idx"].copy()
+        bad[::3, 0] = -1
+        bad[1::3, ctop - 1] = C + 5
+        out = {}
+        for lanes in (4, 1):
+            ctx.set_option("topc_use_lanes", lanes)
+            out[lanes] = client.llk_use_top(x, bad, d["nontop_llk"], False)
+        ctx.set_option("topc_use_lanes", 4)
+        assert np.isfinite(out[4]).all() and np.max(np.abs(out[4] - out[1])) < 1e-12
+
+
 def test_kat1_on_gpu(ctx, golden_dir):
     """ComputeTest golden LLRs (test1.validate.res) through the HIP path."""
     k = np.load(os.path.join(golden_dir, "kat1_computetest.npz"))
