@@ -171,6 +171,14 @@ int gmmiv_llk_use_top(gmmiv_ctx *ctx, const gmmiv_gmm *client, const void *x, in
                       int64_t ldx, int ctop, const int32_t *idx, const double *nontop_llk, int mode,
                       double min_llk, double max_llk, double *llk_out);
 
+/* The same for SEVERAL client models on one test segment -- the client loop of ComputeTest.cpp:170-207 (every model of an ndx line
+ * is scored on the same frames with the same world indices) as ONE call: llk_out is [n_clients][T] (host or device), row i what
+ * gmmiv_llk_use_top returns for clients[i].  All clients must have the dimension count of clients[0]; one launch when the
+ * four-lanes-per-candidate kernel applies (ctop <= 16, even dimension count), client by client otherwise. */
+int gmmiv_llk_use_top_multi(gmmiv_ctx *ctx, int n_clients, const gmmiv_gmm *const *clients, const void *x, int x_dtype, int64_t T,
+                            int64_t ldx, int ctop, const int32_t *idx, const double *nontop_llk, int mode,
+                            double min_llk, double max_llk, double *llk_out);
+
 /* ---- MixtureGDStat::computeAndAccumulateOcc + getOccVect (AccumulateTVStat.cpp:302,334-335;
  * FactorAnalysis.cpp:204-205): the full posterior vector of every frame,
  * gamma[t*C + c] = w_c lk_c(x_t) / sum_c' w_c' lk_c'(x_t)   (row-major [T x C]). */

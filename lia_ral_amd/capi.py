@@ -622,6 +622,22 @@ class Gmm:
                                    ct.c_double(min_llk), ct.c_double(max_llk), _ptr(out)))
         return out
 
+    @staticmethod
+    def llk_use_top_multi(clients, x, idx, nontop_llk, complete=True, min_llk=-200.0, max_llk=200.0):
+        """USE_TOP_DISTRIBS for a list of client models on the same frames and world indices (ComputeTest's client loop) in one
+        call: [len(clients), T]."""
+        x, dt, T, ldx = _feat(x)
+        idx = np.ascontiguousarray(idx, np.int32)
+        n = len(clients)
+        out = np.empty((n, T))
+        if n == 0:
+            return out
+        arr = (ct.c_void_p * n)(*[g._h for g in clients])
+        _chk(lib.gmmiv_llk_use_top_multi(clients[0].ctx._h, n, arr, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), idx.shape[1],
+                                         _ptr(idx), _ptr(_f64(nontop_llk)), TOP_COMPLETE if complete else TOP_PARTIAL,
+                                         ct.c_double(min_llk), ct.c_double(max_llk), _ptr(out)))
+        return out
+
     def occ(self, x):
         """Posterior vectors [T x C] (computeAndAccumulateOcc / getOccVect)."""
         x, dt, T, ldx = _feat(x)

@@ -597,6 +597,52 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     return o_llk.finish();
 }
 
+int gmmiv_llk_use_top_multi(gmmiv_ctx *c, int n_clients, const gmmiv_gmm *const *clients, const void *x, int dt, int64_t T, int64_t ldx,
+                            int ctop, const int32_t *idx, const double *nontop_llk, int mode, double min_llk, double max_llk,
+                            double *llk_out)
+{
+    if (!c) { gmmiv_set_error("use_top_multi: null context"); return GMMIV_ERR_ARG; }
+    if (n_clients < 0 || (n_clients > 0 && !clients)) { gmmiv_set_error("use_top_multi: bad client list"); return GMMIV_ERR_ARG; }
+    if (n_clients == 0) return GMMIV_OK;
+    int rc;
+    for (int i = 0; i < n_clients; ++i) {
+        if ((rc = check_model(c, clients[i]))) return rc;
+        if (clients[i]->D != clients[0]->D) { gmmiv_set_error("use_top_multi: client %d has %d dimensions, client 0 has %d", i, clients[i]->D, clients[0]->D); return GMMIV_ERR_ARG; }
+        if (ctop > clients[i]->C) { gmmiv_set_error("use_top_multi: topDistribsCount %d exceeds mixtureDistribCount %d of client %d", ctop, clients[i]->C, i); return GMMIV_ERR_ARG; }
+    }
+    if (T < 0 || !idx || !llk_out || ctop <= 0 || ctop > 64) { gmmiv_set_error("use_top_multi: bad argument"); return GMMIV_ERR_ARG; }
+    if (mode == GMMIV_TOP_COMPLETE && !nontop_llk) { gmmiv_set_error("use_top_multi: COMPLETE mode needs nontop_llk"); return GMMIV_ERR_ARG; }
+    const gmmiv_gmm *g0 = clients[0];
+    // one launch for all clients when the four-lanes-per-candidate kernel applies; otherwise client by client (same results either way)
+    const bool batched = c->topc_z && c->topc_use_lanes == 4 && ctop <= 16 && g0->D % 2 == 0 && n_clients <= 65535 && T > 0;
+    if (!batched) {
+        for (int i = 0; i < n_clients; ++i)
+            if ((rc = gmmiv_llk_use_top(c, clients[i], x, dt, T, ldx, ctop, idx, nontop_llk, mode, min_llk, max_llk, llk_out + (size_t)i * T))) return rc;
+        return GMMIV_OK;
+    }
+    GBIND(c);
+    XView xv;
+    if ((rc = xv.init(c, x, dt, T, ldx, g0->D))) return rc;
+    DevIn<int32_t> i_idx;
+    DevIn<double> i_n;
+    DevOut<double> o_llk;
+    if ((rc = i_idx.init(c, WS_T0, idx, (size_t)T * ctop))) return rc;
+    if ((rc = i_n.init(c, WS_T1, nontop_llk, (size_t)T))) return rc;
+    if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T * n_clients, false))) return rc;
+    struct Rec { const double *mean, *iv, *lwc; long C; };
+    std::vector<Rec> recs((size_t)n_clients);
+    for (int i = 0; i < n_clients; ++i) recs[i] = Rec{clients[i]->mean, clients[i]->iv, clients[i]->lwc, (long)clients[i]->C};
+    void *drec;
+    if ((rc = c->scratch(WS_T3, recs.size() * sizeof(Rec), &drec))) return rc;
+    GCHK(hipMemcpyAsync(drec, recs.data(), recs.size() * sizeof(Rec), hipMemcpyHostToDevice, c->stream));
+    GCHK(hipStreamSynchronize(c->stream)); // recs lives on this stack frame
+    c->t_begin("k_topc_use");
+    GCHK(gmmk_topc_use4_multi(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g0->D, drec, n_clients, ctop, i_idx.d, i_n.d, mode == GMMIV_TOP_COMPLETE,
+                              min_llk, max_llk, o_llk.d));
+    c->t_end();
+    return o_llk.finish();
+}
+
 int gmmiv_occ(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, double *gamma)
 {
     int rc = check_model(c, g);

@@ -69,5 +69,7 @@ int gmmk_topc_from_z(hipStream_t st, int x_f64, const void *x, long n, long ldx,
                      double *nw, double *llk, int *flag);
 int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
                     const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk, int four);
+int gmmk_topc_use4_multi(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const void *clients, int n_clients, int ctop,
+                         const int *idx, const double *nllk, int complete, double lo, double hi, double *llk); // clients: device array of {mean, iv, lwc, (long) C}
 int gmmk_post_from_z(hipStream_t st, long n, int C, int nct, const double *zbuf, long nfb, const int *eit, const double *inv,
                      const int *efin, double *gamma);

@@ -864,6 +864,69 @@ __global__ __launch_bounds__(256) void k_topc_use4(const void *__restrict__ x, l
     }
 }
 
+// k_topc_use4 for SEVERAL client models in one launch (blockIdx.y = client): ComputeTest scores every test segment against all
+// its clients with the same world indices; one launch per client costs a launch, a copy back and a host synchronisation each --
+// 3000-frame segments run at a fifth of the kernel's rate that way.  Model pointers come from a device array; llk_out is
+// [n_clients][T].  Same arithmetic as k_topc_use4, statement for statement.
+struct TopcClient { const double *mean, *iv, *lwc; long C; };
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_use4_multi(const void *__restrict__ x, long T, long ldx, int D, const TopcClient *__restrict__ clients,
+                                                         int ctop, const int *__restrict__ idx, const double *__restrict__ nontop_llk,
+                                                         int complete, double lo, double hi, double *__restrict__ llk_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 2, sub = lane & 3;
+    const long t = (long)blockIdx.x * 4 + wave;
+    if (t >= T) return; // wave-uniform
+    const TopcClient cl = clients[blockIdx.y];
+    const double NINF = -__builtin_inf();
+    const int c = slot < ctop ? idx[t * ctop + slot] : -1;
+    const bool live = c >= 0 && (long)c < cl.C;
+    const int cc = live ? c : 0;
+    const d2 *mu = (const d2 *)(cl.mean + (size_t)cc * D), *vi = (const d2 *)(cl.iv + (size_t)cc * D);
+    const int np = D >> 1;
+    double acc = 0.0;
+    for (int p0 = 0; p0 < np; p0 += 16) {
+        d2 m[4], v[4];
+        double x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + sub + 4 * u, pc = p < np ? p : np - 1;
+            m[u] = mu[pc];
+            v[u] = vi[pc];
+            x0[u] = feat_load<XT>::get(x, t * ldx + 2 * pc);
+            x1[u] = feat_load<XT>::get(x, t * ldx + 2 * pc + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = p0 + sub + 4 * u < np;
+            const double dx0 = x0[u] - m[u][0], dx1 = x1[u] - m[u][1];
+            const double a1 = __builtin_fma(dx1 * dx1, v[u][1], __builtin_fma(dx0 * dx0, v[u][0], acc));
+            acc = ok ? a1 : acc;
+        }
+    }
+    acc += __hiloint2double(dpp_i32<0xB1>(__double2hiint(acc)), dpp_i32<0xB1>(__double2loint(acc)));
+    acc += __hiloint2double(dpp_i32<0x4E>(__double2hiint(acc)), dpp_i32<0x4E>(__double2loint(acc)));
+    const double z = live ? __builtin_fma(-0.5, acc, cl.lwc[cc]) : NINF;
+    const double r = (complete && nontop_llk) ? nontop_llk[t] : NINF;
+    const double M = wave_max_f64_dpp(fmax(z, r));
+    const double s0 = wave_sum_f64_dpp((live && sub == 0) ? gexp(z - M) : 0.0);
+    if (lane == 0) {
+        const double s = r > NINF ? s0 + gexp(r - M) : s0;
+        llk_out[(size_t)blockIdx.y * T + t] = fmin(fmax(M + log(s), lo), hi);
+    }
+}
+// clients: DEVICE array of n_clients {mean, iv, lwc, C} records (host-side layout: three pointers and a long, 32 bytes)
+int gmmk_topc_use4_multi(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const void *clients, int n_clients, int ctop,
+                         const int *idx, const double *nllk, int complete, double lo, double hi, double *llk)
+{
+    if (T <= 0 || n_clients <= 0) return 0;
+    if (ctop > 16 || D % 2 != 0 || n_clients > 65535) return -1;
+    const dim3 grid((unsigned)((T + 3) / 4), (unsigned)n_clients);
+    if (x_f64) k_topc_use4_multi<double><<<grid, 256, 0, st>>>(x, T, ldx, D, (const TopcClient *)clients, ctop, idx, nllk, complete, lo, hi, llk);
+    else k_topc_use4_multi<float><<<grid, 256, 0, st>>>(x, T, ldx, D, (const TopcClient *)clients, ctop, idx, nllk, complete, lo, hi, llk);
+    return (int)hipGetLastError();
+}
+
 int gmmk_topc_use16(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean, const double *iv,
                     const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete, double lo, double hi, double *llk,
                     int four)

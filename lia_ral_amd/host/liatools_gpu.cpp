@@ -590,7 +590,7 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     DevBuf dIdx((size_t)n * topDistribsCount * sizeof(int32_t)), dNllk((size_t)n * sizeof(double));
     int32_t *idx = (int32_t *)dIdx.p;
     double *nllk = (double *)dNllk.p;
-    std::vector<double> llkw(n), llkc(n);
+    std::vector<double> llkw(n), llkc(n * clients.size());
     // world: DETERMINE_TOP_DISTRIBS on every frame (worldDecime = 1)
     srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount, mode,
                                       minLLK, maxLLK, idx, nullptr, nullptr, nllk, nullptr, llkw.data()));
@@ -601,14 +601,17 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
         for (size_t i = b; i < e; ++i) s += v[i];
         return e > b ? s / (double)(e - b) : 0.0;
     };
+    // clients: USE_TOP_DISTRIBS with the world's indices (+ the world's non-top remainder if COMPLETE), all models of the line in ONE call
+    // (a launch, a copy back and a synchronisation per client cost more than the kernel on segments of a few thousand frames)
+    std::vector<const gmmiv_gmm *> handles(clients.size());
+    for (size_t ci = 0; ci < clients.size(); ++ci) handles[ci] = clients[ci]->handle();
+    srv.check(gmmiv_llk_use_top_multi(srv.ctx(), (int)handles.size(), handles.data(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(),
+                                      topDistribsCount, idx, nllk, mode, minLLK, maxLLK, llkc.data()));
     for (size_t ci = 0; ci < clients.size(); ++ci) {
-        // clients: USE_TOP_DISTRIBS with the world's indices (+ the world's non-top remainder if COMPLETE)
-        srv.check(gmmiv_llk_use_top(srv.ctx(), clients[ci]->handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount,
-                                    idx, nllk, mode, minLLK, maxLLK, llkc.data()));
         size_t off = 0;
         for (size_t s = 0; s < nseg; ++s) {
             const size_t len = segmentalMode ? selectedSegments[s].length : n;
-            out[s * clients.size() + ci] = meanOver(llkc, off, off + len) - meanOver(llkw, off, off + len);
+            out[s * clients.size() + ci] = meanOver(llkc, ci * n + off, ci * n + off + len) - meanOver(llkw, off, off + len);
             off += len;
         }
     }

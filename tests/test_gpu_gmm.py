@@ -136,6 +136,28 @@ def test_use_top_lane_layouts_agree(ctx, C, D, T, ctop, dtype):
         assert np.isfinite(out[4]).all() and np.max(np.abs(out[4] - out[1])) < 1e-12
 
 
+@pytest.mark.parametrize("C,D,T,ctop,n_clients", [(256, 60, 3001, 10, 7), (64, 13, 50, 5, 3), (64, 60, 40, 20, 2), (128, 32, 1, 16, 1)])
+def test_use_top_for_several_clients_in_one_call(ctx, C, D, T, ctop, n_clients):
+    """gmmiv_llk_use_top_multi (ComputeTest's client loop as one call) returns, row by row, exactly what gmmiv_llk_use_top returns
+    for each client -- on the batched kernel (ctop <= 16, even D) and on the client-by-client fallback (odd D, ctop > 16), COMPLETE
+    and PARTIAL; a client with another dimension count is refused."""
+    from lia_ral_amd import capi
+    w, mean, iv = make_gmm(C, D, seed=3 * C + D)
+    x = make_frames(w, mean, iv, T, seed=T + 9).astype(np.float32)
+    world = ctx.gmm(w, mean, iv)
+    rng = np.random.default_rng(11)
+    clients = [ctx.gmm(w, mean + rng.normal(0, 0.15, mean.shape), iv * (1.0 + 0.05 * i)) for i in range(n_clients)]
+    for complete in (True, False):
+        d = world.llk_determine_top(x, ctop, complete)
+        one = np.stack([g.llk_use_top(x, d["idx"], d["nontop_llk"], complete) for g in clients])
+        many = capi.Gmm.llk_use_top_multi(clients, x, d["idx"], d["nontop_llk"], complete)
+        assert many.shape == (n_clients, T) and np.array_equal(many, one)
+    if n_clients > 1 and D > 2:
+        w2, m2, iv2 = make_gmm(C, D - 1, seed=1)
+        with pytest.raises(capi.GmmivError):
+            capi.Gmm.llk_use_top_multi([clients[0], ctx.gmm(w2, m2, iv2)], x, d["idx"], d["nontop_llk"], True)
+
+
 def test_kat1_on_gpu(ctx, golden_dir):
     """ComputeTest golden LLRs (test1.validate.res) through the HIP path."""
     k = np.load(os.path.join(golden_dir, "kat1_computetest.npz"))
