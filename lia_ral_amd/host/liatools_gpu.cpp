@@ -488,8 +488,10 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, con
     std::vector<double> llkIt;
     DeviceMixture dworld(fs.server(), world);
     const unsigned long stream = 0;
+    // ONE accumulator for all iterations (the reference creates a MixtureStat per iteration; resetEM() below is the same state): no
+    // device allocation / release (each a device synchronisation) inside the loop
+    EMAcc emAcc(dworld, world);
     for (unsigned long trainIt = 0; trainIt < cfg.nbTrainIt; ++trainIt) {
-        EMAcc emAcc(dworld, world);
         const double varianceFlooring = setItParameter(cfg.initVarianceFlooring, cfg.finalVarianceFlooring, (int)cfg.nbTrainIt, (int)trainIt);
         const double varianceCeiling = setItParameter(cfg.initVarianceCeiling, cfg.finalVarianceCeiling, (int)cfg.nbTrainIt, (int)trainIt);
         const unsigned long nbTotalFrame = totalFrame(selectedSegments);
@@ -556,8 +558,8 @@ void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const Mix
                 const MAPCfg &mapCfg)
 {
     DeviceMixture dclient(fs.server(), clientMixture);
+    EMAcc emAcc(dclient, clientMixture); // one accumulator for all iterations (see trainModelStream)
     for (unsigned long trainIt = 0; trainIt < mapCfg.nbTrainIt; ++trainIt) {
-        EMAcc emAcc(dclient, clientMixture);
         SegCluster bagged;
         baggedSegments(selectedSegments, bagged, mapCfg.baggedFrameProbability, 3, 7); // before srand(), as the reference
         emAcc.resetEM();
