@@ -163,6 +163,58 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
             "solve_ms": times["solve_ms"], "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "fused_stats": fused}
 
 
+def computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, T=1_000_000, ctop=10, n_clients=4, check=True):
+    """BASELINE.json configs[0]'s path at scale (ComputeTest.cpp:154-207): DETERMINE_TOP_DISTRIBS on the 2048-Gaussian world model
+    for T frames per GPU, then USE_TOP_DISTRIBS for a few mean-adapted client models in one call.  The checker leg compares the first
+    256 frames with the CPU oracle: exact indices, per-frame log-likelihoods of world and clients."""
+    from lia_ral_amd import capi
+    import ctypes as ct
+    x = synth_frames(w, mean, iv, T, dev, seed=991 + rank)
+    rng = np.random.default_rng(17)
+    cm = [mean + rng.normal(0, 0.1, mean.shape) for _ in range(n_clients)]
+    clients = [ctx.gmm(w, m, iv) for m in cm]
+    idx = torch.empty((T, ctop), dtype=torch.int32, device=dev)
+    nllk = torch.empty(T, dtype=torch.float64, device=dev)
+    llkw = torch.empty(T, dtype=torch.float64, device=dev)
+    llkc = torch.empty((n_clients, T), dtype=torch.float64, device=dev)
+    handles = (ct.c_void_p * n_clients)(*[c._h for c in clients])
+
+    def world_pass():
+        capi._chk(capi.lib.gmmiv_llk_determine_top(ctx._h, g._h, capi._ptr(x), capi.F32, ct.c_int64(T), ct.c_int64(D), ctop, capi.TOP_COMPLETE,
+                                                   ct.c_double(-200.0), ct.c_double(200.0), capi._ptr(idx), None, None, capi._ptr(nllk), None, capi._ptr(llkw)))
+
+    def client_pass():
+        capi._chk(capi.lib.gmmiv_llk_use_top_multi(ctx._h, n_clients, handles, capi._ptr(x), capi.F32, ct.c_int64(T), ct.c_int64(D), ctop, capi._ptr(idx),
+                                                   capi._ptr(nllk), capi.TOP_COMPLETE, ct.c_double(-200.0), ct.c_double(200.0), capi._ptr(llkc)))
+
+    def timed(f):
+        f(); torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter(); f(); torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    tw = max_over_ranks(timed(world_pass), world, dev)
+    tc = max_over_ranks(timed(client_pass), world, dev)
+    parity = None
+    if rank == 0 and check:
+        from oracle import oracle as orc
+        n = 256
+        xo = x[:n].cpu().numpy().astype(np.float64)
+        do = orc.llk_determine_top(orc.Gmm(w, mean, iv), xo, ctop, True)
+        same_idx = bool(np.array_equal(idx[:n].cpu().numpy(), do["idx"]))
+        err = float(np.max(np.abs(llkw[:n].cpu().numpy() - do["llk"])))
+        for i in range(n_clients):
+            lco = orc.llk_use_top(orc.Gmm(w, cm[i], iv), xo, do["idx"], do["nontop_lk"], True)
+            err = max(err, float(np.max(np.abs(llkc[i, :n].cpu().numpy() - lco))))
+        parity = {"frames_checked": n, "indices_identical": same_idx, "max_abs_err_llk": err, "tolerance": 1e-9, "ok": same_idx and err < 1e-9,
+                  "what": "top-%d indices of the world pass (exact) and per-frame log-likelihoods of world and %d client models vs the CPU oracle" % (ctop, n_clients)}
+    return {"metric": "ComputeTest: top-%d world pass, frame-Gaussian pairs/s; client pass, frames/s per client model" % ctop,
+            "world_pass_gpairs_per_s": T * C * world / tw / 1e9, "world_pass_ms": tw * 1e3,
+            "client_pass_mframes_per_s_per_client": T * n_clients * world / tc / 1e6, "client_pass_ms": tc * 1e3,
+            "frames_per_gpu": T, "clients": n_clients, "parity": parity}
+
+
 def ivector_parity(x, frames, w, mean, iv, Tm, W, rows):
     """The CHECKER leg of the secondary (untimed): the i-vectors of a few utterances recomputed end to end by the CPU oracle
     (Baum-Welch statistics, substractM, estimateTETt, estimateW) from the same frames; north_star tolerance 1e-6 relative."""
@@ -626,10 +678,12 @@ def main():
                  "k_stats_tflops": KERNEL_FLOP[sname] * Td * C / (dense_k[1] * 1e-3) / 1e12}
         del xd, accd
     secondary = None
+    computetest = None
     tv_em = None
     if not args.no_secondary:
         g.set(w, mean, iv)     # back to the seed model for the i-vector slice
         secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
+        computetest = computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
         if world > 1:          # configs[3] is natively multi-GPU: one T-matrix EM iteration on utterance-sharded statistics
             x = xs = None          # release the 2.4 GB frame block of the EM workload
             torch.cuda.empty_cache()
@@ -637,6 +691,8 @@ def main():
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
+        if computetest:
+            out["computetest"] = computetest
         if tv_em:
             out["tv_em"] = tv_em
         if dense:
