@@ -70,6 +70,8 @@ const char *gmmiv_version(void);
  *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
+ *   "tv_tett_direct" 1 estimateTETt as one kernel that computes the lower triangles only and writes them packed (D <= 64); 0 = batched
+ *                      GEMM into full matrices + pack
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one
  *                      system L_u; workspace 4 x tv_batch x R^2 doubles)
  *   "tv_acc_mb" 8192   T-matrix E-step: MiB of packed E_u = L_u^-1 + w_u w_u^T kept in HBM before A += N^T E and Cmx += W^T F run

@@ -103,6 +103,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "stats_z")) slot = &c->stats_z;
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
+    else if (!strcmp(key, "tv_tett_direct")) slot = &c->tv_tett_direct;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     else if (!strcmp(key, "tv_mstep_solve")) slot = &c->tv_mstep_solve;
     else if (!strcmp(key, "tv_md_device")) slot = &c->tv_md_device;

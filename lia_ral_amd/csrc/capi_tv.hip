@@ -203,6 +203,13 @@ int gmmiv_tv_tett(gmmiv_ctx *c, int C, int D, int R, const double *Tm, const dou
     if ((rc = i_t.init(c, WS_T0, Tm, (size_t)R * SV))) return rc;
     if ((rc = i_iv.init(c, WS_T1, invvar, SV))) return rc;
     if ((rc = o.init(c, WS_T2, tett_packed, (size_t)C * P, false))) return rc;
+    if (c->tv_tett_direct) { // one kernel: lower triangle only, written packed (tv_kernels.hip: k_tett_packed); D <= 64
+        c->t_begin("k_tett_packed");
+        const int krc = tvk_tett_packed(c->stream, C, D, R, i_t.d, i_iv.d, o.d);
+        c->t_end();
+        if (krc == 0) return o.finish();
+        if (krc != -1) GCHK(krc);
+    }
     void *p;
     if ((rc = c->scratch(WS_T3, (size_t)R * SV * 8, &p))) return rc;
     double *Tiv = (double *)p;

@@ -24,6 +24,7 @@ int tvk_spd_inverse_batched(hipStream_t st, int n, int nb, double *Afull, double
 int tvk_subtract_m(hipStream_t st, long U, int C, int D, const double *N, double *F, const double *means);
 int tvk_scale_cols(hipStream_t st, long rows, long cols, const double *in, const double *scale, double *out);
 int tvk_unpack_sym(hipStream_t st, int n, int nb, const double *packed, long sp, double *full, double diag_add);
+int tvk_tett_packed(hipStream_t st, int C, int D, int R, const double *T, const double *iv, double *out); // -1: shape not served (D > 64)
 int tvk_pack_sym(hipStream_t st, int n, int nb, const double *full, long sf, const double *w, double *packed, long sp);
 int tvk_merge_rows(hipStream_t st, long ndst, long width, const long *off, const long *rows, const double *src, double *dst);
 #define TVK_BATCH_SUM_SLABS 16

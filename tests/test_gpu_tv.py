@@ -33,6 +33,25 @@ def tv_problem(C, D, R, U, seed=0, frames=200):
     return dict(w=w, mean=mean, iv=iv, N=N, F=F, Tm=Tm, C=C, D=D, R=R, U=U)
 
 
+@pytest.mark.parametrize("C,D,R", [(5, 60, 400), (3, 13, 35), (2, 64, 450), (7, 1, 16), (4, 60, 1), (3, 38, 161), (2, 66, 40)])
+def test_tett_packed_kernel_matches_the_gemm_form_and_the_oracle(ctx, C, D, R):
+    """estimateTETt: k_tett_packed (lower triangle only, written packed; the default) against the batched GEMM + pack form and the
+    oracle -- orders with a partial last tile, more rows than one LDS pass holds, dimension counts that are not a multiple of 4,
+    and one (D = 66) that the kernel does not serve (GEMM form either way)."""
+    rng = np.random.default_rng(C * 1000 + D * 10 + R)
+    Tm = rng.normal(0, 0.3, (R, C * D))
+    invvar = rng.uniform(0.5, 2.0, C * D)
+    out = {}
+    for direct in (1, 0):
+        ctx.set_option("tv_tett_direct", direct)
+        out[direct] = ctx.tv_tett(Tm, invvar, C, D)
+    ctx.set_option("tv_tett_direct", 1)
+    il = np.tril_indices(R)
+    ref = orc.tv_tett(Tm, invvar, C, D)[:, il[0], il[1]]
+    assert out[1].shape == ref.shape
+    assert relerr(out[1], ref) < 1e-13 and relerr(out[0], ref) < 1e-13 and relerr(out[1], out[0]) < 1e-13
+
+
 @pytest.mark.parametrize("R,where", [(96, 0), (400, 0), (400, 37), (400, 399), (512, 130), (35, 20)])
 def test_ivector_extraction_reports_a_system_that_is_not_positive_definite(ctx, R, where):
     """The batched factorisation flags a non-positive pivot (first column, inside a diagonal block, last column; every kernel variant:
