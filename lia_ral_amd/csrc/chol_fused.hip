@@ -10,14 +10,15 @@
 //
 // Workgroup = 8 waves.  The panel is cut in row tiles of 16; a wave owns up to 4 of them and computes each
 // tile TRANSPOSED:  D'[c][row] = sum_k L[j0 + c][k] L[row][k]  (MFMA A operand = the 32 panel rows, B operand =
-// the tile's own rows).  Both operands are rows of L with k contiguous: a lane loads 64 contiguous bytes per row
-// and 32 k values (the k order inside a chunk is permuted, identically for A and B).  With the A-operand rows
+// the tile's own rows).  Both operands are rows of L with k contiguous; of a 32-wide k chunk a lane holds four 16-byte
+// pieces (the k order inside a chunk is permuted, identically for A and B: see KOFF_Q / KOFF_V below).  With the A-operand rows
 // taken in the order perm(i) = 4 (i & 3) + (i >> 2), lane (i16, q) ends up holding P[row i16][cols 4q .. 4q+3]
 // in the 4 result registers: one 32-byte load / store per lane, and -- the point of the transposition -- exactly
 // the B-operand layout of the triangular solve  X^T = inv(L_jj) P^T  that follows, again one MFMA chain.
-// Wave 0 owns the diagonal block: updates it first, factors it in registers (row i in lane i, cross-lane
-// v_readlane broadcasts, fully unrolled), inverts the 32 x 32 factor (column c in lane c) and publishes
-// inv(L_jj) in LDS while the other waves are still busy with their tiles; it takes off-diagonal tiles last.
+// Wave 0 owns the diagonal block: it factors and inverts it in one sweep over its columns (sweep32: row i of the block
+// in lane i, column i of the inverse in lane 32 + i) and publishes both in LDS while the other waves run the k-loops of
+// their tiles; it takes off-diagonal tiles last.  k_chol_left2 (the default) stages the panel rows in LDS first and updates
+// the diagonal block from there on all waves; k_chol_left is the round-2 form.
 #include <atomic>
 #include <type_traits>
 
