@@ -13,6 +13,8 @@ dev = torch.device("cuda", 0)
 ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
 ctx.set_option("gemm_clamp", int(os.environ.get("GEMM_CLAMP", "1")))
 ctx.set_option("gemm_remap", int(os.environ.get("GEMM_REMAP", "1")))
+if os.environ.get("TV_BATCH"):
+    ctx.set_option("tv_batch", int(os.environ["TV_BATCH"]))   # utterances per batch of the E-step (default 1024)
 ctx.set_option("gemm_nt80", int(os.environ.get("GEMM_NT80", "1")))   # aux on 128 x 80 tiles (R = 400 = 5 x 80) instead of 128 x 128 + strip
 C, D, R = 2048, 60, 400
 P = R * (R + 1) // 2
