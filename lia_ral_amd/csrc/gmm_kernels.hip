@@ -1132,8 +1132,15 @@ int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long
     if (T <= 0) return 0;
     if (ctop < 1 || ctop > 16) return -1;
     use_glds = (use_glds & 1) | (ctop << 8); // the kernel's dbg argument carries ctop in this mode
+    // A workgroup walks the whole model for its frames (64 stages of ~10 us with two waves per SIMD): a call of up to one round of
+    // workgroups takes 0.65 ms whatever its length -- ComputeTest's segments of a few thousand frames.  Short calls run 4-wave
+    // workgroups (128 frames, one wave per SIMD: half the time per stage); per-frame results do not depend on the workgroup shape.
+    const bool small = T <= 32768;
 #define CASE(K)                                                                                                                    \
     case K:                                                                                                                        \
+        if (small)                                                                                                                 \
+            return x_f64 ? launch_llk<K, double, 4, 2>(st, x, T, ldx, D, Pt, nct, theta, use_glds, cand, 0, cnt, slow, efin)        \
+                         : launch_llk<K, float, 4, 2>(st, x, T, ldx, D, Pt, nct, theta, use_glds, cand, 0, cnt, slow, efin);        \
         return x_f64 ? launch_llk<K, double, 8, 2>(st, x, T, ldx, D, Pt, nct, theta, use_glds, cand, 0, cnt, slow, efin)            \
                      : launch_llk<K, float, 8, 2>(st, x, T, ldx, D, Pt, nct, theta, use_glds, cand, 0, cnt, slow, efin);
     switch (KS) {
