@@ -1091,6 +1091,7 @@ int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx,
              double *lse, int use_glds, int wg_waves)
 {
     if (T <= 0) return 0;
+    if (T <= 32768) wg_waves = 4; // short calls: one round of 4-wave workgroups, half the time per stage (see gmmk_llk_topc)
 #define CASE(K)                                                                                      \
     case K:                                                                                          \
         if (wg_waves == 8)                                                                           \
@@ -1112,8 +1113,12 @@ int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ld
                double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin)
 {
     if (T <= 0) return 0;
+    const bool small = T <= 32768; // one round of 4-wave workgroups: half the time per stage (see gmmk_llk_topc); same blocks, same values
 #define CASE(K)                                                                                                              \
     case K:                                                                                                                  \
+        if (small)                                                                                                           \
+            return x_f64 ? launch_llk<K, double, 4, 1>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin) \
+                         : launch_llk<K, float, 4, 1>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin); \
         return x_f64 ? launch_llk<K, double, 8, 1>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin)   \
                      : launch_llk<K, float, 8, 1>(st, x, T, ldx, D, Pt, nct, lse, use_glds, zbuf, nfb, eit, inv, efin);
     switch (KS) {
