@@ -92,6 +92,9 @@ const char *gmmiv_version(void);
  *                      "topc_fallbacks" counts the calls the fused path handed on (candidate list overflow / margin check)
  *   "topc_overlap" 0   fused path on more than 262 144 frames: 1 = the ranking of a sub-chunk runs on a side stream beside the
  *                      log-likelihood kernel of the next one (bitwise the same results; measured slower, hence off)
+ *   "short_calls" 1    log-likelihood kernels: a call of at most 32 768 frames runs 4-wave workgroups (one round, one wave per SIMD: 0.3 ms
+ *                      instead of 0.55 for the walk through a 2048-Gaussian model); 0 = the 8-wave workgroups of long calls.  Per-frame
+ *                      results are the same either way.
  *   "topc_rank2" 1     fused path: the ranking kernel handles two frames per wave (k_topc_rank2; frames with more than 128 candidate
  *                      records or more than 32 survivors go through the one-frame kernel right behind it); 0 = one frame per wave
  *   "topc_use_lanes" 4  USE_TOP_DISTRIBS with at most 16 candidates: four lanes per candidate read 64 contiguous bytes of its model row per

@@ -127,6 +127,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "chol_lds")) ks = &c->ko.chol_lds;       // 0 = panel rows from memory per wave
     else if (!strcmp(key, "chol_gemm")) ks = &c->ko.chol_gemm;     // the GEMM-built batched Cholesky instead of k_chol_left
     else if (!strcmp(key, "chol_waves")) ks = &c->ko.chol_waves;   // 16 = k_trinv_left / k_uut on 1024-thread workgroups
+    else if (!strcmp(key, "short_calls")) ks = &c->ko.short_calls; // 0 = calls of at most 32768 frames on the kernel shapes of long calls
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
     if (!strcmp(key, "kopts_bound")) return &gmmiv_kopts_cur() == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?

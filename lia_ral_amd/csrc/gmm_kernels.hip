@@ -1091,7 +1091,7 @@ int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx,
              double *lse, int use_glds, int wg_waves)
 {
     if (T <= 0) return 0;
-    if (T <= 32768) wg_waves = 4; // short calls: one round of 4-wave workgroups, half the time per stage (see gmmk_llk_topc)
+    if (T <= 32768 && gmmiv_kopts_cur().short_calls) wg_waves = 4; // short calls: one round of 4-wave workgroups, half the time per stage (see gmmk_llk_topc)
 #define CASE(K)                                                                                      \
     case K:                                                                                          \
         if (wg_waves == 8)                                                                           \
@@ -1113,7 +1113,7 @@ int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ld
                double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin)
 {
     if (T <= 0) return 0;
-    const bool small = T <= 32768; // one round of 4-wave workgroups: half the time per stage (see gmmk_llk_topc); same blocks, same values
+    const bool small = T <= 32768 && gmmiv_kopts_cur().short_calls; // one round of 4-wave workgroups: half the time per stage (see gmmk_llk_topc); same blocks, same values
 #define CASE(K)                                                                                                              \
     case K:                                                                                                                  \
         if (small)                                                                                                           \
@@ -1140,7 +1140,7 @@ int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long
     // A workgroup walks the whole model for its frames (64 stages of ~10 us with two waves per SIMD): a call of up to one round of
     // workgroups takes 0.65 ms whatever its length -- ComputeTest's segments of a few thousand frames.  Short calls run 4-wave
     // workgroups (128 frames, one wave per SIMD: half the time per stage); per-frame results do not depend on the workgroup shape.
-    const bool small = T <= 32768;
+    const bool small = T <= 32768 && gmmiv_kopts_cur().short_calls;
 #define CASE(K)                                                                                                                    \
     case K:                                                                                                                        \
         if (small)                                                                                                                 \

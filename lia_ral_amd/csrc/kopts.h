@@ -12,6 +12,7 @@ struct gmmiv_kopts {
     int gemm_remap = 1;   // XCD-aware tile order in k_dgemm
     int gemm_clamp = 1;   // 0 = cut tiles always on the per-element checked instantiation
     int gemm_narrow = 1;  // 0 = 128 x 128 tiles on the strips cut by M / N too
+    int short_calls = 1;  // log-likelihood kernels: calls of at most 32768 frames on 4-wave workgroups (half the latency); 0 = the 8-wave shape of long calls
     int gemm_nt80 = 1;    // split-K NT products with N a multiple of 80 (not of 128) on full row tiles: 128 x 80 tiles, no strip; 0: 128 x 128 + strip
     int chol_lds = 1;     // chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself
     int chol_gemm = 0;    // 1 = the GEMM-built right-looking factorisation for every order

@@ -158,6 +158,25 @@ def test_use_top_for_several_clients_in_one_call(ctx, C, D, T, ctop, n_clients):
             capi.Gmm.llk_use_top_multi([clients[0], ctx.gmm(w2, m2, iv2)], x, d["idx"], d["nontop_llk"], True)
 
 
+@pytest.mark.parametrize("T", [1, 129, 3000, 32768])
+def test_short_calls_run_other_workgroup_shapes_with_the_same_results(ctx, T):
+    """Calls of at most 32 768 frames run the log-likelihood kernels on 4-wave workgroups (option short_calls, default 1); with the
+    option off they run the 8-wave shape of long calls.  Per-frame values, EM accumulators and top-C selections are bitwise the
+    same."""
+    C, D, ctop = 256, 60, 10
+    w, mean, iv = make_gmm(C, D, seed=77)
+    x = make_frames(w, mean, iv, T, seed=T + 3).astype(np.float32)
+    g = ctx.gmm(w, mean, iv)
+    res = {}
+    for short in (1, 0):
+        ctx.set_option("short_calls", short)
+        d = g.llk_determine_top(x, ctop, True)
+        res[short] = (g.llk(x, -1e9, 1e9), g.em_accumulate(x), d["idx"], d["llk"], d["nontop_llk"], d["lk"])
+    ctx.set_option("short_calls", 1)
+    for a, b in zip(res[1], res[0]):
+        assert np.array_equal(a, b)
+
+
 def test_kat1_on_gpu(ctx, golden_dir):
     """ComputeTest golden LLRs (test1.validate.res) through the HIP path."""
     k = np.load(os.path.join(golden_dir, "kat1_computetest.npz"))
