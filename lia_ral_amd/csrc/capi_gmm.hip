@@ -745,7 +745,9 @@ static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt,
     int nseg = c->em_chunks > 0 ? (int)c->em_chunks : (c->n_cu * gmmk_stats_z_wg_per_cu() + ngrp - 1) / ngrp;
     nseg = (nseg + 7) / 8 * 8;
     const int64_t first = T < Tc ? T : Tc;
-    const int64_t cap = (first + 2047) / 2048;
+    // at least 256 frames (four tiles) per segment: with 2048 a pass over 12 000 frames (a TrainTarget client) ran 64 workgroups of
+    // 24 tiles each -- 0.39 ms where 256 workgroups of 6 tiles take 0.12
+    const int64_t cap = (first + 255) / 256;
     if (nseg > cap) nseg = (int)((cap + 7) / 8 * 8);
     const int64_t nchunk = (T + Tc - 1) / Tc;
     // segment bounds relative to the chunk start: one table for full chunks, one for the last chunk
