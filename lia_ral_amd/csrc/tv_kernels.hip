@@ -352,7 +352,11 @@ static void launch_dgemm(hipStream_t st, bool ta, bool tb, dim3 grid, int M, int
         return;
     }
     if (fm == 0 || fn == 0) { // no full tile at all
-        if (clamp_ok) launch_dgemm_e<2>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
+        // a handful of rows (one utterance's L = N TETt: 1 x 80200 x 2048) on 32-row tiles: a 128-row tile would spend 127 / 128 of its MFMAs
+        // on clamped duplicates (0.97 ms where the 1.3 GB of TETt stream in 0.3)
+        if (clamp_ok && g_gemm_narrow && M <= 64 && N > 128)
+            launch_dgemm_e<2, 1, 4>(st, ta, tb, dim3(grid.x, (M + 31) / 32, grid.z), M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
+        else if (clamp_ok) launch_dgemm_e<2>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
         else launch_dgemm_e<1>(st, ta, tb, grid, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, ksplit, 0, 0, epi);
         return;
     }
