@@ -70,6 +70,8 @@ const char *gmmiv_version(void);
  *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
+ *   "tv_stats_split" 1 gmmiv_tv_stats on at most 16 utterances: every utterance in pieces of whole 64-frame tiles (more workgroups for the
+ *                      N / F kernel), summed back in piece order; 0 = one segment per utterance
  *   "tv_tett_direct" 1 estimateTETt as one kernel that computes the lower triangles only and writes them packed (D <= 64); 0 = batched
  *                      GEMM into full matrices + pack
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one

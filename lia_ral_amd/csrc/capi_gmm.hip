@@ -104,6 +104,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
     else if (!strcmp(key, "tv_tett_direct")) slot = &c->tv_tett_direct;
+    else if (!strcmp(key, "tv_stats_split")) slot = &c->tv_stats_split;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     else if (!strcmp(key, "tv_mstep_solve")) slot = &c->tv_mstep_solve;
     else if (!strcmp(key, "tv_md_device")) slot = &c->tv_md_device;
@@ -1025,7 +1026,51 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
             if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
             if ((rc = c->scratch(WS_INV, (size_t)(maxn > 0 ? maxn : 1) * (sizeof(double) + sizeof(int)), &inv))) return rc;
             int *efin = (int *)((double *)inv + (maxn > 0 ? maxn : 1));
-                    for (size_t k = 0; k + 1 < cu.size(); ++k) {
+            // A few utterances (on-line extraction: ONE) give the statistics kernel a few workgroups -- 8 per utterance, each walking all
+            // its frames: 0.39 ms for 3000 frames.  Up to 16 utterances in one chunk are cut into about 32 pieces of whole 64-frame
+            // tiles; the pieces are "utterances" of the kernel, written to scratch rows and summed back in piece order.
+            if (cu.size() == 2 && U <= 16 && c->tv_stats_split) {
+                std::vector<long> pb;
+                std::vector<int> rbh((size_t)U + 1, 0);
+                const int64_t per_utt = 32 / U > 1 ? 32 / U : 1;
+                for (int64_t u = 0; u < U; ++u) {
+                    const int64_t b = utt_begin[u] - utt_begin[0], e = utt_begin[u + 1] - utt_begin[0], len = e - b;
+                    int64_t S = (len + 255) / 256;
+                    S = S < 1 ? 1 : (S > per_utt ? per_utt : S);
+                    const int64_t per = ((len + S - 1) / S + 63) / 64 * 64;
+                    int64_t pos = b;
+                    int cntp = 0;
+                    do { pb.push_back((long)pos); pos = per > 0 && pos + per < e ? pos + per : e; ++cntp; } while (pos < e);
+                    rbh[u + 1] = rbh[u] + cntp;
+                }
+                pb.push_back((long)(utt_begin[U] - utt_begin[0]));
+                const int np = rbh[U];
+                if (np > U) {
+                    void *pseg, *prb, *tn, *tf;
+                    if ((rc = c->scratch(WS_SEG, pb.size() * sizeof(long), &pseg))) return rc;
+                    if ((rc = c->scratch(WS_SMALL, rbh.size() * sizeof(int) + 64, &prb))) return rc;
+                    if ((rc = c->scratch(WS_T2, (size_t)np * g->C * sizeof(double), &tn))) return rc;
+                    if ((rc = c->scratch(WS_T3, (size_t)np * SV * sizeof(double), &tf))) return rc;
+                    GCHK(hipMemcpyAsync(pseg, pb.data(), pb.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
+                    GCHK(hipMemcpyAsync(prb, rbh.data(), rbh.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    GCHK(hipStreamSynchronize(c->stream)); // pb / rbh live on this stack frame
+                    const int64_t c0 = utt_begin[0], n = utt_begin[U] - c0;
+                    c->t_begin("k_llk_mfma", true);
+                    GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,
+                                    (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb, (int *)eit, (double *)inv, efin));
+                    c->t_end();
+                    c->t_begin("k_stats_z", true);
+                    GCHK(gmmk_stats_z(c->stream, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb, nfb,
+                                      (const int *)eit, (const double *)inv, efin, 1.0, (const long *)pseg, np, (double *)tn, (double *)tf, 1, 0,
+                                      c->prune_thr()));
+                    GCHK(gmmk_rows_sum_groups(c->stream, g->C, (int)U, (const int *)prb, (const double *)tn, o_n.d));
+                    GCHK(gmmk_rows_sum_groups(c->stream, (long)SV, (int)U, (const int *)prb, (const double *)tf, o_f.d));
+                    c->t_end();
+                    if ((rc = o_n.finish())) return rc;
+                    return o_f.finish();
+                }
+            }
+            for (size_t k = 0; k + 1 < cu.size(); ++k) {
                 const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;
                 c->t_begin("k_llk_mfma", k == 0);
                 GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,

@@ -101,6 +101,7 @@ struct gmmiv_ctx {
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)
     long tv_md_device = 1; // minDivergence: R normalised and factored on the device (one workgroup of k_chol_left); 0: on the host
     long tv_mstep_solve = 1; // updateTestimate by substitution through the Cholesky factor (k_chol_solve_multi); 0: explicit inverse + GEMM
+    long tv_stats_split = 1; // gmmiv_tv_stats on at most 16 utterances: each utterance in pieces of whole tiles (more workgroups), summed back; 0 = one segment per utterance
     long tv_tett_direct = 1; // estimateTETt by k_tett_packed (lower triangle only, written packed); 0 = batched GEMM + pack
     long tv_batch = 1024; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)
     gmmiv_kopts ko;   // "z_waves", "z_tv4", "z_depth_*", "gemm_*", "chol_*": see gmmiv_kopts above

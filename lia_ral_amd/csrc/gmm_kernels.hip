@@ -1167,6 +1167,24 @@ int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, doub
     return (int)hipGetLastError();
 }
 
+// dst[g][e] = sum of the rows [rb[g], rb[g + 1]) of src (row stride n), e < n: the pieces of a split utterance back into its row
+__global__ void k_rows_sum_groups(long n, const int *__restrict__ rb, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const int g = blockIdx.y, r0 = rb[g], r1 = rb[g + 1];
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)n; e += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += src[(size_t)r * n + e];
+        dst[(size_t)g * n + e] = s;
+    }
+}
+int gmmk_rows_sum_groups(hipStream_t st, long n, int ngroups, const int *rb, const double *src, double *dst)
+{
+    if (n <= 0 || ngroups <= 0) return 0;
+    const unsigned bx = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    k_rows_sum_groups<<<dim3(bx, (unsigned)ngroups), 256, 0, st>>>(n, rb, src, dst);
+    return (int)hipGetLastError();
+}
+
 int gmmk_add_scalar(hipStream_t st, double *dst, double v)
 {
     k_add_scalar<<<1, 1, 0, st>>>(dst, v);

@@ -309,6 +309,31 @@ def test_tv_stats_match_oracle(ctx, C, D):
     assert not N[1].any() and not F[1].any()
 
 
+@pytest.mark.parametrize("lens", [[3000], [1], [70, 0, 5000], [257] * 16, [64, 65, 1000, 333, 2], [40000]])
+def test_tv_stats_of_a_few_utterances_in_pieces_match_one_segment_per_utterance(ctx, lens):
+    """gmmiv_tv_stats on at most 16 utterances cuts them into pieces of whole tiles (more workgroups; option tv_stats_split) and
+    sums the pieces back: N / F against the one-segment-per-utterance form (1e-13: another summation order) and the oracle --
+    one utterance, an empty one in the middle, lengths around the tile and piece sizes."""
+    C, D = 128, 60
+    w, mean, iv = make_gmm(C, D, seed=len(lens) + sum(lens) % 97)
+    T = int(sum(lens))
+    x = make_frames(w, mean, iv, max(T, 1), seed=5)[:T].astype(np.float32)
+    ub = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    g = ctx.gmm(w, mean, iv)
+    out = {}
+    for split in (1, 0):
+        ctx.set_option("tv_stats_split", split)
+        out[split] = g.tv_stats(x, ub)
+    ctx.set_option("tv_stats_split", 1)
+    assert relerr(out[1][0], out[0][0]) < 1e-13 and relerr(out[1][1], out[0][1]) < 1e-13
+    utt = np.repeat(np.arange(len(lens)), lens)
+    No, Fo = orc.tv_stats(orc.Gmm(w, mean, iv), x.astype(np.float64), utt, len(lens))
+    assert relerr(out[1][0], No) < 1e-9 and relerr(out[1][1], Fo) < 1e-9
+    for u, n in enumerate(lens):
+        if n == 0:
+            assert not out[1][0][u].any() and not out[1][1][u].any()
+
+
 @pytest.mark.parametrize("C,D,U", [(128, 60, 7), (2048, 60, 40), (37, 13, 5), (512, 24, 70)])
 def test_tv_stats_fused_single_pass_matches_two_pass(ctx, C, D, U):
     """tv_stats through em_fused.hip: a team of workgroups walks several utterances (ragged, some
