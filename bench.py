@@ -134,6 +134,7 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         t0 = time.perf_counter()
         g.tv_stats(x, ub, N, F)
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        times["k1_ms"] = ctx.kernel_ms("k_llk_mfma"); times["k3_ms"] = ctx.kernel_ms("k_stats_z")
         ctx.tv_subtract_m(N, F, means, C, D)
         ctx.tv_estimate_w(N, F, Tm, invvar, tett, C, D, out=W)
         torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -142,7 +143,17 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         return t2 - t0
 
     run()                      # warm-up (workspace allocation)
-    dt = min(run(), run())
+    NRUN = 3
+    runs = []
+    kms = {"k_llk_mfma": 0.0, "k_stats_z": 0.0}
+    stats_ms = solve_ms = 0.0
+    k1_ms = k3_ms = 0.0
+    for _ in range(NRUN):
+        runs.append(run())
+        stats_ms += times["stats_ms"] / NRUN; solve_ms += times["solve_ms"] / NRUN
+        k1_ms += times["k1_ms"] / NRUN; k3_ms += times["k3_ms"] / NRUN
+    times["stats_ms"], times["solve_ms"] = stats_ms, solve_ms
+    dt = float(np.mean(runs))  # the MEAN of the timed runs
     # the same statistics through the single-pass cooperative kernel (opt-in, em_fused.hip)
     fused = {}
     try:
@@ -158,9 +169,60 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         ctx.set_option("em_fused", 0)
     dt = max_over_ranks(dt, world, dev)
     parity = ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None
+    # 2.67 GFLOP per i-vector end to end = 3000 frames x 2048 x 362 (K1 logits 240 + K3 N / F statistics 122) + 448.5 M (solve)
+    flop_stats = float(frames) * C * (FLOP_PER_PAIR_LLK + 2.0 * (1 + D)); flop_solve = 448.5e6
+    tf = (flop_stats + flop_solve) * U / (dt / 1.0) / 1e12           # this rank's U i-vectors in dt (the slowest rank's time)
+    roof = {"bound": "mfma", "kernel": "IvExtractor end to end: k_llk_mfma<WZ> + k_stats_z<SQ=0> + L / aux GEMMs + chol_fused",
+            "achieved": tf, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_TFLOPS, "traffic": None,
+            "algorithmic_flop_per_ivector": flop_stats + flop_solve,
+            "parts": {"k_llk_mfma": {"ms": k1_ms, "tflops": FLOP_PER_PAIR_LLK * T * C / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None},
+                      "k_stats_z(N,F)": {"ms": k3_ms, "tflops": 2.0 * (1 + D) * T * C / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else None},
+                      "solve (substractM + estimateW)": {"ms": times["solve_ms"], "tflops": flop_solve * U / (times["solve_ms"] * 1e-3) / 1e12}},
+            "time_fractions": {"k_llk_mfma": k1_ms / (dt * 1e3), "k_stats_z": k3_ms / (dt * 1e3), "solve": times["solve_ms"] / (dt * 1e3)}}
     return {"metric": "i-vectors/s (IvExtractor end-to-end, 2048-g UBM, rank 400, 3000-frame utterances)",
             "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "stats_ms": times["stats_ms"],
-            "solve_ms": times["solve_ms"], "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "fused_stats": fused}
+            "solve_ms": times["solve_ms"], "timed_runs_ms": [r * 1e3 for r in runs], "timing": "mean of %d runs after one warm-up" % NRUN,
+            "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "roofline": roof, "fused_stats": fused,
+            "_W": W, "_Tm": Tm, "_seed": 777 + rank}
+
+
+def ivector_cpu_baseline(w, mean, iv, R=400, frames=3000):
+    """The oracle IvExtractor (-O3 -ffast-math like the reference's default build) on the host cores: 1 thread, then a sweep with
+    the reference's split -- contiguous utterance ranges per thread (AccumulateTVStat.cpp:498-507, :2282-2300) -- one utterance
+    per thread (a 3000-frame utterance costs a scalar core several seconds).  TETt is precomputed, like estimateTETt before the threads."""
+    from conftest import make_frames
+    from oracle import oracle as orc
+    logical, phys = os.cpu_count() or 1, physical_cores()
+    g = orc.Gmm(w, mean, iv)
+    rng = np.random.default_rng(5)
+    Tm = rng.normal(0, 0.01, (R, C * D))
+    t = time.time()
+    Tc = np.ascontiguousarray(Tm.reshape(R, C, D).transpose(1, 0, 2))          # TETt_c = T_c Sigma_c^-1 T_c^T: an INPUT of the timed loop
+    te = np.matmul(Tc * iv[:, None, :], Tc.transpose(0, 2, 1)).reshape(C, R * R)  # (numpy / BLAS here; the oracle's own estimateTETt is a 20 GFLOP scalar loop)
+    del Tc
+    t_tett = time.time() - t
+    base = make_frames(w, mean, iv, frames * 4, seed=31).astype(np.float64)
+    sweep = []
+    counts = sorted({1, max(1, phys // 4), phys, logical})
+    budget = 45.0
+    for th in counts:
+        if sweep and budget < 1.5 * sweep[-1]["seconds"]:
+            break
+        U = th                                            # one utterance per thread
+        x = np.tile(base, ((U + 3) // 4, 1))[:U * frames]
+        ub = np.arange(U + 1, dtype=np.int64) * frames
+        t = time.time()
+        orc.iv_extract_mt(g, x, ub, Tm, iv.ravel(), te, threads=th)
+        dt = time.time() - t
+        budget -= dt
+        sweep.append({"threads": th, "utterances": U, "seconds": dt, "ivectors_per_s": U / dt})
+    best = max(sweep, key=lambda r: r["ivectors_per_s"])
+    return {"value": best["ivectors_per_s"], "unit": "i-vectors/s", "cores": best["threads"], "kind": "port",
+            "single_thread": sweep[0]["ivectors_per_s"], "logical_cores": logical, "physical_cores": phys, "sweep": sweep,
+            "tett_once_s": t_tett,
+            "sample": "oracle IvExtractor (statistics + substractM + estimateW, scalar fp64, gcc -O3 -ffast-math; a restatement of the "
+                      "reference loops, not the original binary) on one %d-frame utterance per thread at C=%d, R=%d; TETt precomputed (numpy, "
+                      "%.1f s) and excluded like estimateTETt in the GPU number; %.1f s in all" % (frames, C, R, t_tett, sum(r["seconds"] for r in sweep))}
 
 
 def computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, T=1_000_000, ctop=10, n_clients=4, check=True):
@@ -209,10 +271,113 @@ def computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, T=1_000_000, ct
             err = max(err, float(np.max(np.abs(llkc[i, :n].cpu().numpy() - lco))))
         parity = {"frames_checked": n, "indices_identical": same_idx, "max_abs_err_llk": err, "tolerance": 1e-9, "ok": same_idx and err < 1e-9,
                   "what": "top-%d indices of the world pass (exact) and per-frame log-likelihoods of world and %d client models vs the CPU oracle" % (ctop, n_clients)}
+    llr = (llkc.mean(1) - llkw.mean()).cpu().numpy()       # ComputeTest's file-mode score per client (mean llk_client - mean llk_world)
     return {"metric": "ComputeTest: top-%d world pass, frame-Gaussian pairs/s; client pass, frames/s per client model" % ctop,
+            "_llr": llr, "_client_means": cm, "_seed": 991 + rank,
             "world_pass_gpairs_per_s": T * C * world / tw / 1e9, "world_pass_ms": tw * 1e3,
             "client_pass_mframes_per_s_per_client": T * n_clients * world / tc / 1e6, "client_pass_ms": tc * 1e3,
             "frames_per_gpu": T, "clients": n_clients, "parity": parity}
+
+
+def host_layer(ctx, g, w, mean, iv, x, dev, T, headline_gpairs, secondary, computetest, check=True):
+    """The path through the boundary the reference's tools would call: the C++ host layer (host/liatools_gpu.cpp, the mirror of
+    LIA_SpkTools' driver functions over the C ABI), driver-timed on the same workloads as the torch-driven numbers above --
+    liagpu::trainModelStream (TrainTools.cpp:1030-1110) on the headline's frames at baggedFrameProbability 1.0 and 0.4, IvExtractor
+    (IvExtractor.cpp:70-148) on the secondary's 512-utterance slice, computeTestLLR (ComputeTest.cpp:129-215) on the ComputeTest
+    slice -- each with its time, the ratio to the torch-driven number and parity against it."""
+    from lia_ral_amd import capi
+    from lia_ral_amd import host_capi as h
+    out = {"what": "liagpu::* (libliatools_gpu.so) over the C ABI; features handed over as HOST arrays and uploaded once per tool run "
+                   "(untimed), iterations timed inside the library on the resident buffers"}
+    cov = 1.0 / iv
+    xh = x.cpu().numpy()
+    SEG = 3000
+    begin = np.arange(0, T, SEG, dtype=np.int64); length = np.minimum(SEG, T - begin)
+    FL, CE, NIT = 1e-3, 10.0, 4
+    tw = {}
+    relerr = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+    for p in (1.0, 0.4):
+        r = h.train_world(xh, begin, length, w, mean, cov, NIT, bagged_p=p, init_floor=FL, final_floor=FL, init_ceil=CE, final_ceil=CE)
+        it = r["it_ms"]
+        ms = float(np.median(it[1:]))                       # the first iteration allocates the workspace
+        sel = T * p
+        e = {"bagged_p": p, "frames": T, "iterations": NIT, "ms_per_iteration": ms, "ms_iterations": it.tolist(),
+             "gpairs_per_s_selected_frames": sel * C / ms / 1e6, "ratio_to_headline": sel * C / ms / 1e6 / headline_gpairs,
+             "mean_llk": r["llk"].tolist()}
+        if check:
+            # the same iterations driven from Python through the C ABI on the resident tensor (what the headline times): frames
+            # selected by the checker's restatement of baggedSegments, gathered by torch
+            from oracle import oracle as orc
+            mom = ctx.frame_moments(x)
+            gcov = mom[D:2 * D] / mom[2 * D] - (mom[:D] / mom[2 * D]) ** 2
+            gcov_d = torch.from_numpy(gcov).to(dev)
+            m_d = torch.from_numpy(mean).to(dev); c_d = torch.from_numpy(cov).to(dev); w_d = torch.from_numpy(w).to(dev)
+            g2 = ctx.gmm(w, mean, iv)
+            acc = torch.zeros(g2.em_acc_len(), dtype=torch.float64, device=dev)
+            llks = []
+            for k in range(NIT):
+                if p == 1.0:
+                    xs = x
+                else:
+                    bb, bl, _ = orc.bagged_segments(((k + 1) * 200) + 20 + 1, begin, length, p, 3, 7)
+                    rep = torch.from_numpy(bl).to(dev)
+                    starts = torch.from_numpy(bb).to(dev)
+                    off = torch.cumsum(rep, 0) - rep
+                    idx = torch.repeat_interleave(starts - off, rep) + torch.arange(int(bl.sum()), device=dev)
+                    xs = x.index_select(0, idx)
+                acc.zero_()
+                g2.em_accumulate(xs, acc=acc)
+                a = acc[-2:].cpu().numpy()
+                llks.append(a[0] / a[1])
+                nm = torch.empty_like(m_d); nc = torch.empty_like(c_d)
+                capi._chk(capi.lib.gmmiv_em_get(ctx._h, C, D, capi._ptr(acc), capi._ptr(m_d), capi._ptr(c_d), capi._ptr(w_d), capi._ptr(nm), capi._ptr(nc)))
+                ctx.variance_control(nc, FL, CE, gcov_d, C, D, count=False)
+                g2.set_cov(w_d, nm, nc)
+                m_d, c_d = nm, nc
+            torch.cuda.synchronize()
+            errs = {"w": relerr(r["w"], w_d.cpu().numpy()), "mean": relerr(r["mean"], m_d.cpu().numpy()), "cov": relerr(r["cov"], c_d.cpu().numpy()),
+                    "mean_llk": float(np.max(np.abs(r["llk"] - np.array(llks))))}
+            e["parity"] = {"max_rel_err_model": max(errs["w"], errs["mean"], errs["cov"]), "max_abs_err_mean_llk": errs["mean_llk"], "tolerance": 1e-9,
+                           "ok": bool(max(errs["w"], errs["mean"], errs["cov"]) < 1e-9 and errs["mean_llk"] < 1e-9), "per_output": errs,
+                           "what": "model after %d iterations and per-iteration mean llk: liagpu::trainModelStream vs the same loop driven from "
+                                   "Python through the C ABI (bagging by the checker's baggedSegments restatement, frames gathered by torch)" % NIT}
+            g2.close()
+        tw["p%.1f" % p] = e
+    out["train_world"] = tw
+    del xh
+    if secondary is not None:
+        U, frames, R = secondary["utterances_per_gpu"], 3000, 400
+        xs = synth_frames(w, mean, iv, U * frames, dev, seed=secondary["_seed"])
+        Tm = secondary["_Tm"]
+        ub = np.arange(U + 1, dtype=np.int64) * frames
+        Wh, ms = h.iv_extract(xs.cpu().numpy(), ub, (w, mean, cov), Tm.cpu().numpy(), reps=4)
+        per = ms[1:, [0, 1, 3]].sum(1)                      # statistics + substractM + estimateW of the runs after the first
+        rate = U / (float(np.mean(per)) * 1e-3)
+        e = {"utterances": U, "ms_per_run": float(np.mean(per)), "stages_ms": {"statistics": float(ms[1:, 0].mean()), "substractM": float(ms[1:, 1].mean()),
+             "estimateTETt_once": float(ms[0, 2]), "estimateW": float(ms[1:, 3].mean())}, "ivectors_per_s": rate,
+             "ratio_to_secondary": rate / secondary["value"]}
+        Wt = secondary["_W"].cpu().numpy()
+        err = relerr(Wh, Wt)
+        e["parity"] = {"max_rel_err_vs_torch_driven": err, "tolerance": 1e-9, "ok": bool(err < 1e-9),
+                       "what": "i-vectors of the %d utterances: liagpu::TVAcc (IvExtractor order) vs the torch-driven C-ABI calls of `secondary`" % U}
+        out["iv_extractor"] = e
+        del xs
+    if computetest is not None:
+        Tc, ncl = computetest["frames_per_gpu"], computetest["clients"]
+        xs = synth_frames(w, mean, iv, Tc, dev, seed=computetest["_seed"])
+        cl = [(w, m, cov) for m in computetest["_client_means"]]
+        llr, ms = h.compute_test(xs.cpu().numpy(), [0], [Tc], (w, mean, cov), cl, top_c=10, complete=True, reps=4)
+        t = float(np.mean(ms[1:]))
+        ref_ms = computetest["world_pass_ms"] + computetest["client_pass_ms"]
+        err = float(np.max(np.abs(llr[0] - computetest["_llr"])))
+        out["compute_test"] = {"frames": Tc, "clients": ncl, "ms_per_file": t, "ratio_to_torch_driven": ref_ms / t,
+                               "torch_driven_ms": ref_ms, "llr": llr[0].tolist(),
+                               "note": "computeTestLLR also brings the per-frame log-likelihoods of world and clients back to the host (%d MB) for the "
+                                       "segment means, like the reference's frame loop produces them; the torch-driven passes leave them on the device"
+                                       % ((1 + ncl) * Tc * 8 // 1000000),
+                               "parity": {"max_abs_err_llr_vs_torch_driven": err, "tolerance": 1e-9, "ok": bool(err < 1e-9)}}
+        del xs
+    return out
 
 
 def ivector_parity(x, frames, w, mean, iv, Tm, W, rows):
@@ -233,8 +398,9 @@ def ivector_parity(x, frames, w, mean, iv, Tm, W, rows):
 
 def make_collectives(ctx, dev, world, rank, want, transport=None):
     """The product's collectives (gmmiv_comm_* = RCCL inside libgmmiv).  Every rank must end up with the SAME back end, so
-    the outcome of the communicator set-up is agreed through the launcher's process group; if it failed anywhere, all ranks
-    use torch.distributed's RCCL binding instead and the JSON line says so (`collectives`)."""
+    the outcome of the communicator set-up is agreed through the launcher's process group; if it failed anywhere, EVERY rank exits
+    non-zero -- a line whose data path silently went through another transport would not measure the product.  torch.distributed's
+    RCCL binding is used only when asked for with --collectives torch (and the JSON line says so)."""
     from lia_ral_amd import capi
     from lia_ral_amd import dist as gd
     if world == 1:
@@ -264,7 +430,10 @@ def make_collectives(ctx, dev, world, rank, want, transport=None):
             coll.take_bytes()
             return coll, None
         box["err"] = "probe all-reduce returned a wrong sum"
-    return gd.TorchCollectives(), "gmmiv_comm unavailable on some rank (%s): torch.distributed collectives used" % box.get("err", "timeout")
+    print("bench.py: rank %d: the C ABI's communicator (gmmiv_comm) could not be set up on every rank (%s); refusing to run the data path on "
+          "another transport -- pass --collectives torch to measure with torch.distributed's RCCL binding instead"
+          % (rank, box.get("err", "timeout or failure on another rank")), file=sys.stderr, flush=True)
+    sys.exit(3)
 
 
 class GpuTvOps:
@@ -490,6 +659,7 @@ def main():
     ap.add_argument("--collectives", choices=["gmmiv", "torch"], default="gmmiv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-host-layer", action="store_true", help="skip the host_layer block (the C++ host layer timed on the same workloads)")
     ap.add_argument("--mean-spread", type=float, default=2.0,
                     help="std of the synthetic UBM means (SURVEY 8(d): 2.0; smaller = overlapping Gaussians)")
     ap.add_argument("--em-fused", type=int, default=-1, help="A/B knob: 1 = single-pass cooperative EM kernel, 0 = two-kernel path")
@@ -562,6 +732,8 @@ def main():
         sys.exit(2)
     comm_info = {"world": coll.world, "backend": getattr(coll, "backend", coll.name), "launcher_group": (dist.get_backend() if world > 1 else None),
                  "physical_gpus": min(ndev, world), "gpu_sharing": shared}
+    if hasattr(coll, "comm"):       # what RCCL itself reports for the product's communicator: version code and ncclCommCount
+        comm_info.update(coll.comm.info())
     if shared:
         comm_info["note"] = "ranks SHARE the GPU(s): a correctness run of the multi-rank orchestration, not a scaling measurement"
     check = not args.no_cpu_baseline
@@ -682,10 +854,18 @@ def main():
     secondary = None
     computetest = None
     tv_em = None
+    hostl = None
     if not args.no_secondary:
         g.set(w, mean, iv)     # back to the seed model for the i-vector slice
         secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
         computetest = computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
+        if world == 1 and not args.no_host_layer:
+            hostl = host_layer(ctx, g, w, mean, iv, x, dev, T, value, secondary, computetest, check=check)
+        for blk in (secondary, computetest):     # tensors kept for the host-layer parity, not part of the line
+            for k in [k for k in blk if k.startswith("_")]:
+                del blk[k]
+        if world == 1 and check and rank == 0:
+            secondary["cpu_baseline"] = ivector_cpu_baseline(w, mean, iv)
         if world > 1:          # configs[3] is natively multi-GPU: one T-matrix EM iteration on utterance-sharded statistics
             x = xs = None          # release the 2.4 GB frame block of the EM workload
             torch.cuda.empty_cache()
@@ -695,6 +875,8 @@ def main():
             out["secondary"] = secondary
         if computetest:
             out["computetest"] = computetest
+        if hostl:
+            out["host_layer"] = hostl
         if tv_em:
             out["tv_em"] = tv_em
         if dense:

@@ -150,6 +150,15 @@ int gmmiv_frame_moments(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t T, i
  * resident in HBM.  x, out: DEVICE arrays (out has ld = D); frame_idx: host or device. */
 int gmmiv_gather_frames(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t ldx, int D,
                         const int64_t *frame_idx, int64_t n, void *out);
+/* The same selection given as RUNS of adjacent frames -- what a SegCluster is (a bagged chunk of
+ * baggedSegments is 3..7 frames, GeneralTools.cpp:455-510; a label segment thousands):
+ * runs[3 r + 0 .. 2] = (first source frame, first output row, length); run r copies frames
+ * [src, src + len) to rows [dst, dst + len) of out.  24 bytes per run cross PCIe instead of 8 per
+ * frame.  Runs must not overlap in `out`; long runs should be cut into pieces of <= 64 frames by
+ * the caller (one wavefront moves one run).  x, out: DEVICE arrays; runs: host or device -- with a
+ * device table the call only enqueues on the context's stream (no synchronisation). */
+int gmmiv_gather_runs(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t ldx, int D,
+                      const int64_t *runs, int64_t nrun, void *out);
 
 /* ---- MixtureStat::computeAndAccumulateLLK(f,1.0,TOP_DISTRIBS_NO_ACTION) loop -------------------
  * (LIA_SpkTools/src/AccumulateStat.cpp:69-94, :344-379; AccumulateTVStat.cpp:1644-1648)
@@ -436,6 +445,9 @@ void gmmiv_comm_destroy(gmmiv_comm *comm);
 int gmmiv_comm_world(const gmmiv_comm *comm);
 int gmmiv_comm_rank(const gmmiv_comm *comm);
 const char *gmmiv_comm_backend(const gmmiv_comm *comm); /* "rccl: <path of the library in use>", "shm (...)", or "single rank ..." */
+/* What the collective library itself says about this communicator: *rccl_version = ncclGetVersion's code (e.g. 22105), *rccl_comm_count
+ * = ncclCommCount(comm), the number of ranks RCCL sees.  Both 0 for a single-rank or "shm" communicator (no RCCL behind it). */
+int gmmiv_comm_info(const gmmiv_comm *comm, int *rccl_version, int *rccl_comm_count);
 /* payload bytes this rank passed to collectives since the last call of this function (then reset to 0) */
 double gmmiv_comm_take_bytes(gmmiv_comm *comm);
 /* buf[n] <- sum over ranks (in place; host or device) */

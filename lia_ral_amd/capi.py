@@ -202,6 +202,20 @@ class Context:
         _chk(lib.gmmiv_frame_moments(self._h, _ptr(x), dt, ct.c_int64(T), ct.c_int64(ldx), D, _ptr(acc)))
         return acc
 
+    # ---- frame selection on the device (x, out: torch CUDA tensors)
+    def gather_frames(self, x, frame_idx, out):
+        x, dt, T, ldx = _feat(x)
+        idx = frame_idx if _is_torch(frame_idx) else np.ascontiguousarray(frame_idx, np.int64)
+        _chk(lib.gmmiv_gather_frames(self._h, _ptr(x), dt, ct.c_int64(ldx), x.shape[1], _ptr(idx), ct.c_int64(idx.shape[0]), _ptr(out)))
+        return out
+
+    def gather_runs(self, x, runs, out):
+        """runs [nrun, 3] int64 (source frame, output row, length), host or device."""
+        x, dt, T, ldx = _feat(x)
+        r = runs if _is_torch(runs) else np.ascontiguousarray(runs, np.int64)
+        _chk(lib.gmmiv_gather_runs(self._h, _ptr(x), dt, ct.c_int64(ldx), x.shape[1], _ptr(r), ct.c_int64(r.shape[0]), _ptr(out)))
+        return out
+
     def variance_control(self, cov, flooring, ceiling, cov_signal, C, D, count=True):
         counts = np.zeros(2, np.int64) if count else None
         _chk(lib.gmmiv_variance_control(self._h, C, D, _ptr(cov), ct.c_double(flooring), ct.c_double(ceiling),
@@ -512,6 +526,12 @@ class Comm:
 
     def backend(self):
         return lib.gmmiv_comm_backend(self._h).decode()
+
+    def info(self):
+        """{"rccl_version": ncclGetVersion code, "rccl_comm_count": ncclCommCount} -- zeros when no RCCL is behind the communicator."""
+        v, n = ct.c_int(0), ct.c_int(0)
+        _chk(lib.gmmiv_comm_info(self._h, ct.byref(v), ct.byref(n)))
+        return {"rccl_version": v.value, "rccl_comm_count": n.value}
 
     def take_bytes(self):
         return lib.gmmiv_comm_take_bytes(self._h)

@@ -39,6 +39,8 @@ struct Rccl {
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;            // optional: reported by gmmiv_comm_info
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     std::string where;
 };
 
@@ -87,7 +89,9 @@ void load_rccl()
     g_rccl.ReduceScatter = (decltype(g_rccl.ReduceScatter))sym("ncclReduceScatter");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
-    if (!ok) { dlclose(g_rccl.h); g_rccl.h = nullptr; }
+    if (!ok) { dlclose(g_rccl.h); g_rccl.h = nullptr; return; }
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(g_rccl.h, "ncclGetVersion");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.h, "ncclCommCount");
 }
 
 const Rccl *rccl()
@@ -350,7 +354,12 @@ int shm_attach(gmmiv_comm *c, const char *path)
         c->shm->ready.store(1, std::memory_order_release);
     }
     hipError_t e = hipMalloc(&c->addbuf, (size_t)c->shm->slot_bytes);
-    if (e != hipSuccess) { c->shm->failed.store(1); gmmiv_set_error("gmmiv_comm (shm): hipMalloc of the slot staging failed (%s)", hipGetErrorString(e)); return GMMIV_ERR_HIP; }
+    if (e != hipSuccess) {
+        c->shm->failed.store(1); // peers spinning in the barrier stop waiting
+        if (c->rank == 0) unlink(path);
+        gmmiv_set_error("gmmiv_comm (shm): hipMalloc of the slot staging failed (%s)", hipGetErrorString(e));
+        return GMMIV_ERR_HIP;
+    }
     int rc = c->barrier();
     if (c->rank == 0) unlink(path);
     if (rc) return rc;
@@ -441,16 +450,45 @@ int gmmiv_comm_get_unique_id_for(const char *transport, void *id128)
 
 int gmmiv_comm_get_unique_id(void *id128) { return gmmiv_comm_get_unique_id_for(nullptr, id128); }
 
+// The job's nonce, written behind the id and checked by the readers: a file left at the same path by ANOTHER job (one that died
+// between publishing its id and creating its communicator) carries a different nonce and is never accepted, however recent it is.
+// GMMIV_COMM_JOB if the launcher sets it, else what torch.distributed.run gives every rank of one job (rendezvous address, port and
+// run id); empty when neither exists -- then only the age rule below protects the readers.
+static std::string job_nonce()
+{
+    if (const char *j = getenv("GMMIV_COMM_JOB")) return std::string("job:") + j;
+    const char *port = getenv("MASTER_PORT");
+    if (!port || !*port) return std::string();
+    const char *addr = getenv("MASTER_ADDR"), *run = getenv("TORCHELASTIC_RUN_ID");
+    return std::string("rdzv:") + (addr ? addr : "") + ":" + port + ":" + (run ? run : "");
+}
+
+// rank 0: the id file of `id128` is no longer needed (communicator created, or its creation failed)
+static void retire_id_file(const void *id128)
+{
+    if (!id128) return;
+    std::lock_guard<std::mutex> lk(g_idfile_mu);
+    const std::string key((const char *)id128, GMMIV_COMM_ID_BYTES);
+    for (size_t i = 0; i < g_idfiles.size(); ++i)
+        if (g_idfiles[i].first == key) { (void)unlink(g_idfiles[i].second.c_str()); g_idfiles.erase(g_idfiles.begin() + i); break; }
+}
+
 int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double timeout_s)
 {
     if (!path || !id128 || rank < 0) { gmmiv_set_error("comm_exchange_id_file: bad argument"); return GMMIV_ERR_ARG; }
+    const std::string nonce = job_nonce();
     if (rank == 0) {
         (void)unlink(path); // a file left by a job that died before its communicator existed
         int rc = gmmiv_comm_get_unique_id(id128);
         if (rc) return rc;
         const std::string tmp = std::string(path) + ".tmp";
         FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id128, 1, GMMIV_COMM_ID_BYTES, f) != GMMIV_COMM_ID_BYTES) { if (f) fclose(f); gmmiv_set_error("comm_exchange_id_file: cannot write %s", tmp.c_str()); return GMMIV_ERR_ARG; }
+        if (!f || fwrite(id128, 1, GMMIV_COMM_ID_BYTES, f) != GMMIV_COMM_ID_BYTES || fwrite(nonce.data(), 1, nonce.size(), f) != nonce.size()) {
+            if (f) fclose(f);
+            (void)unlink(tmp.c_str());
+            gmmiv_set_error("comm_exchange_id_file: cannot write %s", tmp.c_str());
+            return GMMIV_ERR_ARG;
+        }
         fclose(f);
         if (rename(tmp.c_str(), path) != 0) { gmmiv_set_error("comm_exchange_id_file: cannot rename %s", tmp.c_str()); return GMMIV_ERR_ARG; }
         std::lock_guard<std::mutex> lk(g_idfile_mu);
@@ -469,9 +507,14 @@ int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double 
         if (stat(path, &sb) == 0 && (double)sb.st_mtime >= (double)t_enter.tv_sec - 600.0) {
             FILE *f = fopen(path, "rb");
             if (f) {
-                const size_t n = fread(id128, 1, GMMIV_COMM_ID_BYTES, f);
+                char buf[GMMIV_COMM_ID_BYTES + 512];
+                const size_t n = fread(buf, 1, sizeof(buf), f);
                 fclose(f);
-                if (n == GMMIV_COMM_ID_BYTES) return GMMIV_OK;
+                // the file of THIS job: a complete id followed by this job's nonce (another job's file is left alone until rank 0 replaces it)
+                if (n >= GMMIV_COMM_ID_BYTES && n - GMMIV_COMM_ID_BYTES == nonce.size() && memcmp(buf + GMMIV_COMM_ID_BYTES, nonce.data(), nonce.size()) == 0) {
+                    memcpy(id128, buf, GMMIV_COMM_ID_BYTES);
+                    return GMMIV_OK;
+                }
             }
         }
         usleep((useconds_t)(step * 1e6));
@@ -496,6 +539,7 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
             if (c->addbuf) (void)hipFree(c->addbuf);
             if (c->shm) munmap((void *)c->shm, c->shm_bytes);
             delete c;
+            if (rank == 0) retire_id_file(id128); // a retry must not find this job's dead id
             return rc;
         }
     } else if (world > 1 || (getenv("GMMIV_COMM_FORCE_RCCL") && *getenv("GMMIV_COMM_FORCE_RCCL") == '1')) {
@@ -503,7 +547,7 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
         //  RCCL call, side stream and events included, on a one-GPU machine: the check that the dlopen'ed symbols, data types and
         //  stream arguments are right before a multi-GPU node ever sees them)
         c->api = rccl();
-        if (!c->api) { delete c; return GMMIV_ERR_UNSUPPORTED; }
+        if (!c->api) { delete c; if (rank == 0) retire_id_file(id128); return GMMIV_ERR_UNSUPPORTED; }
         ncclUniqueId id;
         if (id128) memcpy(&id, id128, sizeof(id));
         else { // one forced rank without an id: draw it here
@@ -514,16 +558,12 @@ int gmmiv_comm_create(gmmiv_ctx *ctx, int world, int rank, const void *id128, gm
         if (r != ncclSuccess) {
             gmmiv_set_error("ncclCommInitRank(world %d, rank %d, device %d) -> %s", world, rank, ctx->device, c->api->GetErrorString(r));
             delete c;
+            if (rank == 0) retire_id_file(id128);
             return GMMIV_ERR_HIP;
         }
         c->backend = "rccl: " + c->api->where;
     }
-    if (world > 1 && rank == 0) { // every rank has read the id by now (both transports meet inside the create): retire the id file
-        std::lock_guard<std::mutex> lk(g_idfile_mu);
-        const std::string key((const char *)id128, GMMIV_COMM_ID_BYTES);
-        for (size_t i = 0; i < g_idfiles.size(); ++i)
-            if (g_idfiles[i].first == key) { (void)unlink(g_idfiles[i].second.c_str()); g_idfiles.erase(g_idfiles.begin() + i); break; }
-    }
+    if (world > 1 && rank == 0) retire_id_file(id128); // every rank has read the id by now (both transports meet inside the create)
     ctx->comms.push_back(c);
     *out = c;
     return GMMIV_OK;
@@ -542,6 +582,16 @@ const char *gmmiv_comm_backend(const gmmiv_comm *c)
 {
     if (!c) return "";
     return c->local() ? "single rank (no collective library)" : c->backend.c_str();
+}
+int gmmiv_comm_info(const gmmiv_comm *c, int *rccl_version, int *rccl_comm_count)
+{
+    if (!c) { gmmiv_set_error("comm_info: NULL communicator"); return GMMIV_ERR_ARG; }
+    if (rccl_version) *rccl_version = 0;
+    if (rccl_comm_count) *rccl_comm_count = 0;
+    if (!c->nc || !c->api) return GMMIV_OK; // single rank / shm transport: no collective library behind this communicator
+    if (rccl_version && c->api->GetVersion) (void)c->api->GetVersion(rccl_version);
+    if (rccl_comm_count && c->api->CommCount) (void)c->api->CommCount(c->nc, rccl_comm_count);
+    return GMMIV_OK;
 }
 double gmmiv_comm_take_bytes(gmmiv_comm *c)
 {

@@ -317,6 +317,23 @@ int gmmiv_gather_frames(gmmiv_ctx *c, const void *x, int dt, int64_t ldx, int D,
     return GMMIV_OK;
 }
 
+int gmmiv_gather_runs(gmmiv_ctx *c, const void *x, int dt, int64_t ldx, int D, const int64_t *runs, int64_t nrun, void *out)
+{
+    if (!c || !x || !out || (!runs && nrun > 0) || nrun < 0 || D <= 0 || ldx < D) { gmmiv_set_error("gather_runs: bad argument"); return GMMIV_ERR_ARG; }
+    if (dt != GMMIV_F32 && dt != GMMIV_F64) { gmmiv_set_error("gather_runs: feature dtype must be GMMIV_F32 or GMMIV_F64"); return GMMIV_ERR_ARG; }
+    if (!gmmiv_is_device_ptr(x) || !gmmiv_is_device_ptr(out)) { gmmiv_set_error("gather_runs: x and out must be device arrays"); return GMMIV_ERR_ARG; }
+    if (nrun == 0) return GMMIV_OK;
+    GBIND(c);
+    DevIn<int64_t> i_runs;
+    int rc = i_runs.init(c, WS_T0, runs, (size_t)nrun * 3);
+    if (rc) return rc;
+    c->t_begin("k_gather_runs");
+    GCHK(gmmk_gather_runs(c->stream, dt == GMMIV_F64, x, ldx, D, (const long *)i_runs.d, nrun, out));
+    c->t_end();
+    if (!gmmiv_is_device_ptr(runs)) GCHK(hipStreamSynchronize(c->stream)); // the host table may be freed
+    return GMMIV_OK;
+}
+
 // ---- LLK ---------------------------------------------------------------------------------
 static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, double **lse_out)
 {

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <time.h>
 
 #include <map>
 #include <string>
@@ -141,7 +143,15 @@ struct gmmiv_ctx {
                 ws_size[slot] = 0;
             }
             size_t want = bytes + bytes / 8;
+            static const bool trace = [] { const char *e = getenv("GMMIV_TRACE_ALLOC"); return e && *e && *e != '0'; }();
+            timespec t0, t1;
+            if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
             hipError_t me = hipMalloc(&ws[slot], want);
+            if (trace) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                fprintf(stderr, "[gmmiv] workspace %d: hipMalloc of %.1f MiB took %.2f ms\n", slot, want / 1048576.0,
+                        (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+            }
             if (me != hipSuccess) {
                 (void)hipGetLastError();
                 ws[slot] = nullptr;

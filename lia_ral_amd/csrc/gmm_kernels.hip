@@ -814,6 +814,35 @@ __global__ __launch_bounds__(256) void k_gather_frames(const XT *__restrict__ x,
     }
 }
 
+// Frame selection by RUNS: run r copies frames [src, src + len) of x to rows [dst, dst + len) of out (ld = D).  One wave per
+// run (a bagged chunk is 3..7 frames, GeneralTools.cpp:455-510; the host cuts longer runs into pieces of <= 64 frames), the
+// rows of a run are adjacent in both buffers, so the wave moves len * D contiguous elements -- 16 bytes per lane when both
+// sides allow it.  The run table costs 24 bytes per run instead of 8 bytes per frame of an index list.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_gather_runs(const XT *__restrict__ x, long ldx, int D, const long *__restrict__ runs,
+                                                     long nrun, XT *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long nw = (long)gridDim.x * (blockDim.x >> 6);
+    constexpr int V = 16 / (int)sizeof(XT);
+    for (long r = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrun; r += nw) {
+        const long src = runs[3 * r], dst = runs[3 * r + 1], len = runs[3 * r + 2];
+        if (ldx == D) {
+            const XT *s = x + src * D;
+            XT *d = out + dst * D;
+            const long tot = len * D;
+            if ((((size_t)s | (size_t)d) & 15) == 0) {
+                const long nv = tot / V;
+                for (long e = lane; e < nv; e += 64) ((float4 *)d)[e] = ((const float4 *)s)[e];
+                for (long e = nv * V + lane; e < tot; e += 64) d[e] = s[e];
+            } else
+                for (long e = lane; e < tot; e += 64) d[e] = s[e];
+        } else
+            for (long i = 0; i < len; ++i)
+                for (int e = lane; e < D; e += 64) out[(dst + i) * D + e] = x[(src + i) * ldx + e];
+    }
+}
+
 // varianceControl (TrainTools.cpp:567-587): floor first, then ceiling; counts[0/1] += hits
 __global__ void k_variance_control(int C, int D, double *__restrict__ cov, double flooring, double ceiling,
                                    const double *__restrict__ cov_signal, unsigned long long *__restrict__ counts)
@@ -1272,6 +1301,16 @@ int gmmk_gather_frames(hipStream_t st, int x_f64, const void *x, long ldx, int D
     const unsigned blocks = (unsigned)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256);
     if (x_f64) k_gather_frames<double><<<blocks, 256, 0, st>>>((const double *)x, ldx, D, idx, n, (double *)out);
     else k_gather_frames<float><<<blocks, 256, 0, st>>>((const float *)x, ldx, D, idx, n, (float *)out);
+    return (int)hipGetLastError();
+}
+
+int gmmk_gather_runs(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *runs, long nrun, void *out)
+{
+    if (nrun <= 0) return 0;
+    const long wgs = (nrun + 3) / 4;
+    const unsigned blocks = (unsigned)(wgs > 16384 ? 16384 : wgs);
+    if (x_f64) k_gather_runs<double><<<blocks, 256, 0, st>>>((const double *)x, ldx, D, runs, nrun, (double *)out);
+    else k_gather_runs<float><<<blocks, 256, 0, st>>>((const float *)x, ldx, D, runs, nrun, (float *)out);
     return (int)hipGetLastError();
 }
 

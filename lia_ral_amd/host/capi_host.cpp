@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
 
 #include "liatools_gpu.h"
 #include "io.h"
@@ -35,6 +36,17 @@ static MixtureGD make_mixture(int C, int D, const double *w, const double *mean,
 extern "C" {
 
 const char *liagpu_last_error(void) { return g_err.c_str(); }
+int liagpu_train_world_timed(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                             int C, double *w, double *mean, double *cov, int nbTrainIt, double baggedFrameProbability,
+                             double initVarFloor, double finalVarFloor, double initVarCeil, double finalVarCeil,
+                             long initRand, double *global_mean_out, double *global_cov_out, double *llk_it_out, double *it_ms_out);
+int liagpu_compute_test_timed(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                              int C, const double *w_world, const double *mean_world, const double *cov_world, int nClients,
+                              const double *w_cl, const double *mean_cl, const double *cov_cl, int topDistribsCount,
+                              int complete, double minLLK, double maxLLK, int segmentalMode, double *llr_out, int reps, double *ms_out);
+int liagpu_iv_extract_timed(int device, const float *x, long T, int D, const long *utt_begin, long U, int C, const double *w,
+                            const double *mean, const double *cov, int R, const double *Tmat, double *W_out, double *N_out,
+                            double *F_out, int reps, double *ms_out);
 
 // TrainWorld: computeMeanCov -> trainModelStream (TrainWorld.cpp:101-191 minus file I/O and mixtureInit)
 int liagpu_train_world(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
@@ -42,11 +54,22 @@ int liagpu_train_world(int device, const float *x, long T, int D, const long *se
                        double initVarFloor, double finalVarFloor, double initVarCeil, double finalVarCeil,
                        long initRand, double *global_mean_out, double *global_cov_out, double *llk_it_out)
 {
+    return liagpu_train_world_timed(device, x, T, D, seg_begin, seg_len, nseg, C, w, mean, cov, nbTrainIt, baggedFrameProbability, initVarFloor,
+                                    finalVarFloor, initVarCeil, finalVarCeil, initRand, global_mean_out, global_cov_out, llk_it_out, nullptr);
+}
+
+// the same, with the wall time of every iteration in it_ms_out[nbTrainIt] (nullable): what bench.py's host_layer block reports
+int liagpu_train_world_timed(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                             int C, double *w, double *mean, double *cov, int nbTrainIt, double baggedFrameProbability,
+                             double initVarFloor, double finalVarFloor, double initVarCeil, double finalVarCeil,
+                             long initRand, double *global_mean_out, double *global_cov_out, double *llk_it_out, double *it_ms_out)
+{
     GUARD({
         GpuServer srv(device);
         FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
         SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
         std::vector<double> gm, gc;
+        std::vector<double> itMs;
         computeMeanCov(fs, segs, gm, gc);
         if (global_mean_out) memcpy(global_mean_out, gm.data(), D * sizeof(double));
         if (global_cov_out) memcpy(global_cov_out, gc.data(), D * sizeof(double));
@@ -56,11 +79,13 @@ int liagpu_train_world(int device, const float *x, long T, int D, const long *se
         cfg.initVarianceFlooring = initVarFloor; cfg.finalVarianceFlooring = finalVarFloor;
         cfg.initVarianceCeiling = initVarCeil; cfg.finalVarianceCeiling = finalVarCeil;
         cfg.initRand = (unsigned long)initRand;
+        if (it_ms_out) cfg.iterationMs = &itMs;
         std::vector<double> llk = trainModelStream(cfg, fs, segs, gc, world);
         memcpy(w, world.weights().data(), C * sizeof(double));
         memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
         memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
         if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
+        if (it_ms_out) memcpy(it_ms_out, itMs.data(), itMs.size() * sizeof(double));
     })
 }
 
@@ -92,6 +117,81 @@ int liagpu_train_world_scratch(int device, const float *x, long T, int D, const 
         memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
         memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
         if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
+    })
+}
+
+// TrainWorld over nStream input streams ("inputStreamList" / "weightStreamList", TrainWorld.cpp:123-137): computeMeanCov over all
+// streams, trainModelStream(fsTab, segTab, weightTab) with componentReduction / normalizeModel.  weight == NULL: 1 / nStream.
+// opts[5] = {componentReduction, targetMixtureDistribCount, normalizeModel, normalizeModelMeanOnly, normalizeModelNbIt}.
+// w / mean / cov hold the C initial components on entry and the *C_out final ones (<= C) on return.
+int liagpu_train_world_streams(int device, int nStream, const float *const *x, const long *T, int D, const long *const *seg_begin,
+                               const long *const *seg_len, const long *nseg, const double *weight, int C, double *w, double *mean,
+                               double *cov, int nbTrainIt, double baggedFrameProbability, double initVarFloor, double finalVarFloor,
+                               double initVarCeil, double finalVarCeil, long initRand, const long *opts, long *C_out,
+                               double *global_mean_out, double *global_cov_out, double *llk_it_out)
+{
+    GUARD({
+        if (nStream <= 0) throw Exception("TrainWorld error:no input stream");
+        GpuServer srv(device);
+        std::vector<std::unique_ptr<FeatureBuffer> > fsTab;
+        std::vector<SegCluster> segTab(nStream);
+        std::vector<TrainStream> streams(nStream);
+        for (int i = 0; i < nStream; ++i) {
+            fsTab.emplace_back(new FeatureBuffer(srv, x[i], (unsigned long)T[i], (unsigned long)D));
+            segTab[i] = make_cluster(seg_begin[i], seg_len[i], nseg[i]);
+        }
+        for (int i = 0; i < nStream; ++i) {
+            streams[i].fs = fsTab[i].get(); streams[i].segs = &segTab[i];
+            streams[i].weight = weight ? weight[i] : 1.0 / (double)nStream;
+        }
+        std::vector<double> gm, gc;
+        computeMeanCov(streams, gm, gc);
+        if (global_mean_out) memcpy(global_mean_out, gm.data(), D * sizeof(double));
+        if (global_cov_out) memcpy(global_cov_out, gc.data(), D * sizeof(double));
+        MixtureGD world = make_mixture(C, D, w, mean, cov);
+        TrainCfg cfg;
+        cfg.nbTrainIt = nbTrainIt; cfg.baggedFrameProbability = baggedFrameProbability;
+        cfg.initVarianceFlooring = initVarFloor; cfg.finalVarianceFlooring = finalVarFloor;
+        cfg.initVarianceCeiling = initVarCeil; cfg.finalVarianceCeiling = finalVarCeil;
+        cfg.initRand = (unsigned long)initRand;
+        if (opts) {
+            cfg.componentReduction = opts[0] != 0; cfg.targetDistribCount = (unsigned long)opts[1];
+            cfg.normalizeModel = opts[2] != 0; cfg.normalizeModelMeanOnly = opts[3] != 0; cfg.normalizeModelNbIt = (unsigned long)opts[4];
+        }
+        std::vector<double> llk = trainModelStream(cfg, streams, gc, world);
+        const unsigned long Co = world.getDistribCount();
+        if (C_out) *C_out = (long)Co;
+        memcpy(w, world.weights().data(), Co * sizeof(double));
+        memcpy(mean, world.means().data(), (size_t)Co * D * sizeof(double));
+        memcpy(cov, world.covs().data(), (size_t)Co * D * sizeof(double));
+        if (llk_it_out) memcpy(llk_it_out, llk.data(), llk.size() * sizeof(double));
+    })
+}
+
+// selectComponent(nbTop) + reduceModel + normalizeWeights, then (optionally) normalizeMixture to N(0, 1): the model edits of
+// TrainTools.cpp:1078-1098 on their own (host arithmetic only -- no device is touched)
+int liagpu_model_reduce_normalize(int C, int D, double *w, double *mean, double *cov, long nbTop, int normalize, int meanOnly, long nbIt,
+                                  long *order_out)
+{
+    GUARD({
+        MixtureGD m = make_mixture(C, D, w, mean, cov);
+        if (order_out) {
+            const std::vector<unsigned long> o = sortByWeight(m);
+            for (int i = 0; i < C; ++i) order_out[i] = (long)o[i];
+        }
+        if (nbTop > 0 && nbTop < C) {
+            std::vector<bool> sel;
+            const unsigned long n = selectComponent(sel, (unsigned long)nbTop, m);
+            MixtureGD out(n, (unsigned long)D);
+            (void)reduceModel(sel, m, out);
+            normalizeWeights(out);
+            m = out;
+        }
+        if (normalize) normalizeMixture(m, std::vector<double>(), std::vector<double>(), true, (unsigned long)nbIt, meanOnly != 0);
+        const unsigned long Co = m.getDistribCount();
+        memcpy(w, m.weights().data(), Co * sizeof(double));
+        memcpy(mean, m.means().data(), (size_t)Co * D * sizeof(double));
+        memcpy(cov, m.covs().data(), (size_t)Co * D * sizeof(double));
     })
 }
 
@@ -189,6 +289,16 @@ int liagpu_compute_test(int device, const float *x, long T, int D, const long *s
                         const double *w_cl, const double *mean_cl, const double *cov_cl, int topDistribsCount,
                         int complete, double minLLK, double maxLLK, int segmentalMode, double *llr_out)
 {
+    return liagpu_compute_test_timed(device, x, T, D, seg_begin, seg_len, nseg, C, w_world, mean_world, cov_world, nClients, w_cl, mean_cl, cov_cl,
+                                     topDistribsCount, complete, minLLK, maxLLK, segmentalMode, llr_out, 1, nullptr);
+}
+
+// the same, computeTestLLR run `reps` times on the resident features and models: ms_out[reps] = wall time of each run (bench.py host_layer)
+int liagpu_compute_test_timed(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
+                              int C, const double *w_world, const double *mean_world, const double *cov_world, int nClients,
+                              const double *w_cl, const double *mean_cl, const double *cov_cl, int topDistribsCount,
+                              int complete, double minLLK, double maxLLK, int segmentalMode, double *llr_out, int reps, double *ms_out)
+{
     GUARD({
         GpuServer srv(device);
         FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
@@ -200,7 +310,15 @@ int liagpu_compute_test(int device, const float *x, long T, int D, const long *s
         for (int i = 0; i < nClients; ++i)
             cl.push_back(new DeviceMixture(srv, make_mixture(C, D, w_cl + (size_t)i * C, mean_cl + i * CD, cov_cl + i * CD)));
         std::vector<double> out;
-        try { out = computeTestLLR(fs, segs, dworld, cl, topDistribsCount, complete != 0, minLLK, maxLLK, segmentalMode != 0); }
+        try {
+            for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {
+                srv.sync();
+                const auto t0 = std::chrono::steady_clock::now();
+                out = computeTestLLR(fs, segs, dworld, cl, topDistribsCount, complete != 0, minLLK, maxLLK, segmentalMode != 0);
+                srv.sync();
+                if (ms_out) ms_out[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+        }
         catch (...) { for (auto p : cl) delete p; throw; }
         for (auto p : cl) delete p;
         memcpy(llr_out, out.data(), out.size() * sizeof(double));
@@ -250,6 +368,15 @@ int liagpu_iv_extract(int device, const float *x, long T, int D, const long *utt
                       const double *mean, const double *cov, int R, const double *Tmat, double *W_out, double *N_out,
                       double *F_out)
 {
+    return liagpu_iv_extract_timed(device, x, T, D, utt_begin, U, C, w, mean, cov, R, Tmat, W_out, N_out, F_out, 1, nullptr);
+}
+
+// the same, the extraction run `reps` times on the resident features: ms_out[reps x 4] = wall time of computeAndAccumulateTVStat,
+// substractM, estimateTETt (first run only: T does not change during extraction, IvExtractor.cpp:136) and estimateW (bench.py host_layer)
+int liagpu_iv_extract_timed(int device, const float *x, long T, int D, const long *utt_begin, long U, int C, const double *w,
+                            const double *mean, const double *cov, int R, const double *Tmat, double *W_out, double *N_out,
+                            double *F_out, int reps, double *ms_out)
+{
     GUARD({
         GpuServer srv(device);
         FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
@@ -261,12 +388,31 @@ int liagpu_iv_extract(int device, const float *x, long T, int D, const long *utt
             if (s.length) lines[u].push_back(s);
         }
         tv.loadT(std::vector<double>(Tmat, Tmat + (size_t)R * C * D));
-        tv.computeAndAccumulateTVStat(fs, lines);
-        if (N_out) memcpy(N_out, tv.getN().data(), tv.getN().size() * sizeof(double));
-        if (F_out) memcpy(F_out, tv.getF().data(), tv.getF().size() * sizeof(double));
-        tv.substractM();
-        tv.estimateTETt();
-        tv.estimateW();
+        auto lap = [&](std::chrono::steady_clock::time_point &t0) {
+            srv.sync();
+            const auto t1 = std::chrono::steady_clock::now();
+            const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            t0 = t1;
+            return ms;
+        };
+        for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {
+            double ms[4] = {0.0, 0.0, 0.0, 0.0};
+            srv.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            tv.computeAndAccumulateTVStat(fs, lines);
+            ms[0] = lap(t0);
+            if (r == 0) {
+                if (N_out) memcpy(N_out, tv.getN().data(), tv.getN().size() * sizeof(double));
+                if (F_out) memcpy(F_out, tv.getF().data(), tv.getF().size() * sizeof(double));
+                t0 = std::chrono::steady_clock::now();
+            }
+            tv.substractM();
+            ms[1] = lap(t0);
+            if (r == 0) { tv.estimateTETt(); ms[2] = lap(t0); }
+            tv.estimateW();
+            ms[3] = lap(t0);
+            if (ms_out) memcpy(ms_out + 4 * r, ms, sizeof(ms));
+        }
         memcpy(W_out, tv.getW().data(), tv.getW().size() * sizeof(double));
     })
 }

@@ -3,7 +3,9 @@
 #include "liatools_gpu.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <memory>
 
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -16,6 +18,23 @@ static void hipcheck(hipError_t e, const char *what)
 {
     if (e != hipSuccess) throw Exception(std::string(what) + ": " + hipGetErrorString(e));
 }
+
+// LIAGPU_TRACE=1: wall time of the host-side stages of a training iteration on stderr (tools/host_world_time.py reads it)
+static bool traceOn()
+{
+    static const int on = [] { const char *e = getenv("LIAGPU_TRACE"); return (e && *e && *e != '0') ? 1 : 0; }();
+    return on != 0;
+}
+struct StageClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap()
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+        return ms;
+    }
+};
 
 unsigned long totalFrame(const SegCluster &c)
 {
@@ -169,31 +188,93 @@ FeatureBuffer::FeatureBuffer(GpuServer &srv, const float *frames, unsigned long 
 }
 FeatureBuffer::~FeatureBuffer()
 {
+    (void)gmmiv_ctx_sync(_srv.ctx()); // kernels / copies in flight may still use the buffers
     if (_dev) (void)hipFree(_dev);
     if (_sel) (void)hipFree(_sel);
+    if (_dRuns) (void)hipFree(_dRuns);
+    if (_hRuns) (void)hipHostFree(_hRuns);
+    if (_runsCopied) (void)hipEventDestroy((hipEvent_t)_runsCopied);
+}
+
+// The cluster as RUNS of adjacent frames (source frame, output row, length) in the pinned table; segments that follow each other
+// in the buffer are merged (at baggedFrameProbability 1 the whole cluster becomes ONE run), then cut into pieces of <= 64 frames
+// (one wavefront of k_gather_runs moves one piece).  Returns the number of merged runs.
+unsigned long FeatureBuffer::buildRuns(const SegCluster &c, unsigned long &nSelected, unsigned long &firstFrame, size_t &nPieces)
+{
+    const size_t kPiece = 64;
+    // worst case: every segment its own run + one extra piece per 64 frames
+    size_t need = c.size() + totalFrame(c) / kPiece + 1;
+    if (need > _runsCap) {
+        if (_runsCopied) hipcheck(hipEventSynchronize((hipEvent_t)_runsCopied), "FeatureBuffer: hipEventSynchronize");
+        if (_hRuns) hipcheck(hipHostFree(_hRuns), "FeatureBuffer: hipHostFree");
+        _hRuns = nullptr; _runsCap = 0;
+        need += need / 4;
+        hipcheck(hipHostMalloc((void **)&_hRuns, need * 3 * sizeof(int64_t), hipHostMallocDefault), "FeatureBuffer: hipHostMalloc(runs)");
+        _runsCap = need;
+    } else if (_runsCopied)
+        hipcheck(hipEventSynchronize((hipEvent_t)_runsCopied), "FeatureBuffer: hipEventSynchronize"); // the last upload has read the table
+    int64_t *t = _hRuns;
+    size_t np = 0;
+    unsigned long dst = 0, nMerged = 0, curSrc = 0, curLen = 0;
+    firstFrame = 0;
+    auto flush = [&]() {
+        while (curLen > 0) {
+            const unsigned long l = curLen < kPiece ? curLen : kPiece;
+            t[3 * np] = (int64_t)curSrc; t[3 * np + 1] = (int64_t)dst; t[3 * np + 2] = (int64_t)l;
+            ++np; curSrc += l; dst += l; curLen -= l;
+        }
+    };
+    for (const Seg &s : c) {
+        if (s.length == 0) continue;
+        const unsigned long b = s.begin + getFirstFeatureIndexOfASource(s.source);
+        if (b + s.length > _n) throw Exception("segment ends after the last frame of the feature buffer");
+        if (nMerged && b == curSrc + curLen) { curLen += s.length; continue; }
+        flush();
+        if (!nMerged) firstFrame = b;
+        ++nMerged;
+        curSrc = b; curLen = s.length;
+    }
+    flush();
+    nSelected = dst;
+    nPieces = np;
+    return nMerged;
 }
 
 const float *FeatureBuffer::select(const SegCluster &c, unsigned long &nSelected)
 {
-    // expand the cluster into the frame index list the reference walks with seekFeature/readFeature
-    std::vector<int64_t> idx;
-    idx.reserve(totalFrame(c));
-    bool contiguous = true;
-    for (const Seg &s : c) {
-        const unsigned long b = s.begin + getFirstFeatureIndexOfASource(s.source);
-        if (b + s.length > _n) throw Exception("segment ends after the last frame of the feature buffer");
-        if (!idx.empty() && (unsigned long)idx.back() + 1 != b) contiguous = false;
-        for (unsigned long i = 0; i < s.length; ++i) idx.push_back((int64_t)(b + i));
-    }
-    nSelected = idx.size();
+    // the frame list the reference walks with seekFeature / readFeature (AccumulateStat.cpp:121-128), as a device matrix: everything
+    // below is ENQUEUED on the context's stream -- the table upload comes from pinned memory -- so the host returns at once and may
+    // prepare the next selection while the kernels of this one run
+    unsigned long first = 0;
+    size_t nPieces = 0;
+    const unsigned long nMerged = buildRuns(c, nSelected, first, nPieces);
     if (nSelected == 0) return _dev;
-    if (contiguous) return _dev + (size_t)idx[0] * _d; // one contiguous run: no copy
+    if (nMerged == 1) return _dev + (size_t)first * _d; // one contiguous run: no copy
+    hipStream_t st = (hipStream_t)_srv.stream();
     if (_selCap < nSelected) {
+        _srv.sync();
         if (_sel) hipcheck(hipFree(_sel), "FeatureBuffer: hipFree");
-        _selCap = nSelected + nSelected / 8;
-        hipcheck(hipMalloc((void **)&_sel, (size_t)_selCap * _d * sizeof(float)), "FeatureBuffer: hipMalloc(select)");
+        _sel = nullptr; _selCap = 0;
+        const unsigned long cap = nSelected + nSelected / 8;
+        hipcheck(hipMalloc((void **)&_sel, (size_t)cap * _d * sizeof(float)), "FeatureBuffer: hipMalloc(select)");
+        _selCap = cap;
     }
-    _srv.check(gmmiv_gather_frames(_srv.ctx(), _dev, GMMIV_F32, (int64_t)_d, (int)_d, idx.data(), (int64_t)nSelected, _sel));
+    if (_dRunsCap < nPieces) {
+        _srv.sync();
+        if (_dRuns) hipcheck(hipFree(_dRuns), "FeatureBuffer: hipFree");
+        _dRuns = nullptr; _dRunsCap = 0;
+        const size_t cap = nPieces + nPieces / 4;
+        hipcheck(hipMalloc((void **)&_dRuns, cap * 3 * sizeof(int64_t)), "FeatureBuffer: hipMalloc(runs)");
+        _dRunsCap = cap;
+    }
+    hipcheck(hipMemcpyAsync(_dRuns, _hRuns, nPieces * 3 * sizeof(int64_t), hipMemcpyHostToDevice, st), "FeatureBuffer: upload(runs)");
+    if (!_runsCopied) {
+        hipEvent_t e;
+        hipcheck(hipEventCreateWithFlags(&e, hipEventDisableTiming), "FeatureBuffer: hipEventCreate");
+        _runsCopied = e;
+    }
+    hipcheck(hipEventRecord((hipEvent_t)_runsCopied, st), "FeatureBuffer: hipEventRecord");
+    _srv.check(gmmiv_gather_runs(_srv.ctx(), _dev, GMMIV_F32, (int64_t)_d, (int)_d, _dRuns, (int64_t)nPieces, _sel));
     return _sel;
 }
 
@@ -278,11 +359,19 @@ std::vector<double> FrameAccGD::getCovVect() const
 double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments, double weight)
 {
     unsigned long n = 0;
+    StageClock clk;
     const float *x = fs.select(selectedSegments, n);
+    const double msSel = clk.lap();
     GpuServer &srv = fs.server();
     const double before = emAcc.getAccumulatedLLK();
+    const double msBefore = clk.lap();
     srv.check(gmmiv_em_accumulate(srv.ctx(), emAcc.mixture().handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), weight, emAcc.acc().dev()));
-    return emAcc.getAccumulatedLLK() - before; // weight * sum log lk of this call (AccumulateStat.cpp:143-152)
+    const double msCall = clk.lap();
+    const double after = emAcc.getAccumulatedLLK();
+    if (traceOn())
+        fprintf(stderr, "[liagpu] accumulateStatEM %lu frames: select %.2f ms, llk before %.2f, gmmiv_em_accumulate (enqueue) %.2f, llk after (waits for the kernels) %.2f\n",
+                n, msSel, msBefore, msCall, clk.lap());
+    return after - before; // weight * sum log lk of this call (AccumulateStat.cpp:143-152)
 }
 double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selectedSegments)
 {
@@ -336,6 +425,15 @@ unsigned long computeMeanCov(FeatureBuffer &fs, const SegCluster &seg, std::vect
 {
     FrameAccGD acc;
     accumulateStatFrame(acc, fs, seg);
+    mean = acc.getMeanVect();
+    cov = acc.getCovVect();
+    return acc.getCount();
+}
+
+unsigned long computeMeanCov(const std::vector<TrainStream> &streams, std::vector<double> &mean, std::vector<double> &cov)
+{
+    FrameAccGD acc;
+    for (const TrainStream &st : streams) accumulateStatFrame(acc, *st.fs, *st.segs);
     mean = acc.getMeanVect();
     cov = acc.getCovVect();
     return acc.getCount();
@@ -475,6 +573,109 @@ void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegClust
     mixtureFromPicks(fs, picks, world, globalCov, frameCount);
 }
 
+// ---- component selection / model normalisation (TrainTools.cpp:175-227, :240-315) ---------------------------------
+namespace {
+struct TabWeightElem { double weight; unsigned long distrib; };
+int compF(const void *op1, const void *op2) // GeneralTools.cpp:277-280: never 0 -- the order of equal weights is the C library's
+{
+    return ((const TabWeightElem *)op1)->weight > ((const TabWeightElem *)op2)->weight ? -1 : 1;
+}
+}
+std::vector<unsigned long> sortByWeight(const MixtureGD &model)
+{
+    const unsigned long C = model.getDistribCount();
+    std::vector<TabWeightElem> tab(C);
+    for (unsigned long i = 0; i < C; ++i) { tab[i].weight = model.weight(i); tab[i].distrib = i; }
+    qsort(tab.data(), C, sizeof(TabWeightElem), compF); // TabWeight::_sortByWeight (GeneralTools.h:157-164): the same libc call
+    std::vector<unsigned long> order(C);
+    for (unsigned long i = 0; i < C; ++i) order[i] = tab[i].distrib;
+    return order;
+}
+unsigned long selectComponent(std::vector<bool> &selectCompA, unsigned long nbTop, const MixtureGD &inputM)
+{
+    const unsigned long C = inputM.getDistribCount();
+    if (nbTop > C) throw Exception("selectComponent: nbTop exceeds the number of components");
+    selectCompA.assign(C, false);
+    const std::vector<unsigned long> order = sortByWeight(inputM);
+    for (unsigned long i = 0; i < nbTop; ++i) selectCompA[order[i]] = true;
+    return nbTop;
+}
+unsigned long selectComponent(std::vector<bool> &selectCompA, double wFactor, const MixtureGD &inputM)
+{
+    const unsigned long C = inputM.getDistribCount();
+    selectCompA.assign(C, true);
+    unsigned long n = C;
+    for (unsigned long i = 0; i < C; ++i)
+        if (inputM.weight(i) < wFactor) { selectCompA[i] = false; --n; }
+    return n;
+}
+double reduceModel(const std::vector<bool> &selectCompA, const MixtureGD &inputM, MixtureGD &outputM)
+{
+    const unsigned long C = inputM.getDistribCount(), D = inputM.getVectSize();
+    unsigned long o = 0;
+    double totW = 0.0;
+    for (unsigned long c = 0; c < C; ++c)
+        if (selectCompA[c]) {
+            if (o >= outputM.getDistribCount()) throw Exception("reduceModel: the output mixture is too small");
+            for (unsigned long i = 0; i < D; ++i) { outputM.setMean(o, inputM.getMean(c, i), i); outputM.setCov(o, inputM.getCov(c, i), i); }
+            outputM.weight(o) = inputM.weight(c);
+            totW += outputM.weight(o);
+            ++o;
+        }
+    outputM.computeAll();
+    return totW;
+}
+void normalizeWeights(MixtureGD &outputM)
+{
+    double totW = 0.0;
+    for (unsigned long c = 0; c < outputM.getDistribCount(); ++c) totW += outputM.weight(c);
+    for (unsigned long c = 0; c < outputM.getDistribCount(); ++c) outputM.weight(c) /= totW;
+}
+void mixtureFusion(const MixtureGD &mixt, std::vector<double> &mean, std::vector<double> &cov, double &wres)
+{
+    // the single Gaussian with the mixture's first and second moments, folded in component by component (gaussianFusion)
+    const unsigned long C = mixt.getDistribCount(), D = mixt.getVectSize();
+    mean.resize(D); cov.resize(D);
+    for (unsigned long k = 0; k < D; ++k) { mean[k] = mixt.getMean(0, k); cov[k] = mixt.getCov(0, k); }
+    wres = mixt.weight(0);
+    double wtmp = wres;
+    for (unsigned long i = 1; i < C; ++i) {
+        const double w1 = mixt.weight(i), a1 = w1 / (w1 + wtmp), a2 = 1.0 - a1;
+        for (unsigned long k = 0; k < D; ++k) {
+            const double d = mixt.getMean(i, k) - mean[k];
+            cov[k] = a1 * mixt.getCov(i, k) + a2 * cov[k] + a1 * a2 * d * d;
+            mean[k] = (a1 * mixt.getMean(i, k)) + (a2 * mean[k]);
+        }
+        wres = w1 + wtmp;
+        wtmp = wres;
+    }
+}
+void normalizeMixture(MixtureGD &mixt, const std::vector<double> &meanSignal, const std::vector<double> &covSignal, bool zeroOne,
+                      unsigned long nbIt, bool meanOnly)
+{
+    const unsigned long C = mixt.getDistribCount(), D = mixt.getVectSize();
+    if (!zeroOne && (meanSignal.size() != D || covSignal.size() != D)) throw Exception("normalizeMixture: meanSignal / covSignal must have vectSize entries");
+    std::vector<double> tm, tc;
+    double wtmp;
+    for (unsigned long it = 0; it < nbIt; ++it) {
+        mixtureFusion(mixt, tm, tc, wtmp);
+        for (unsigned long c = 0; c < C; ++c)
+            for (unsigned long i = 0; i < D; ++i) {
+                double newMean = mixt.getMean(c, i) - tm[i];
+                newMean /= sqrt(tc[i]);
+                if (!zeroOne) { newMean *= covSignal[i]; newMean += meanSignal[i]; }
+                mixt.setMean(c, newMean, i);
+                if (!meanOnly) {
+                    double newCov = mixt.getCov(c, i) / tc[i];
+                    if (!zeroOne) newCov *= covSignal[i];
+                    mixt.setCov(c, newCov, i);
+                }
+            }
+        mixt.computeAll();
+    }
+}
+
+// ---- trainModelStream ----------------------------------------------------------------------------------------------------
 std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
                                      const std::vector<double> &globalCov, MixtureGD &world, gmmiv_comm *comm)
 {
@@ -485,38 +686,135 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, con
                                      const std::vector<double> &globalCov, MixtureGD &world, AllReduceFn allReduce, void *user,
                                      gmmiv_comm *comm)
 {
-    std::vector<double> llkIt;
-    DeviceMixture dworld(fs.server(), world);
-    const unsigned long stream = 0;
-    // ONE accumulator for all iterations (the reference creates a MixtureStat per iteration; resetEM() below is the same state): no
-    // device allocation / release (each a device synchronisation) inside the loop
-    EMAcc emAcc(dworld, world);
+    std::vector<TrainStream> one(1);
+    one[0].fs = &fs; one[0].segs = &selectedSegments; one[0].weight = 1.0; // reserveMem: 1 / nbStream (TrainWorld.cpp:85)
+    return trainModelStream(cfg, one, globalCov, world, allReduce, user, comm);
+}
+
+namespace {
+// one call of accumulateStatEM in the reference's loop nest: (iteration, stream, bagging pass)
+struct EMPass { unsigned long trainIt, stream, baggedIt; double proba; bool lastOfIt; };
+}
+
+std::vector<double> trainModelStream(const TrainCfg &cfg, const std::vector<TrainStream> &streams, const std::vector<double> &globalCov,
+                                     MixtureGD &world, AllReduceFn allReduce, void *user, gmmiv_comm *comm)
+{
+    const unsigned long nbStream = streams.size();
+    if (nbStream == 0) throw Exception("trainModelStream: no input stream");
+    GpuServer &srv = streams[0].fs->server();
+    for (const TrainStream &st : streams) {
+        if (!st.fs || !st.segs) throw Exception("trainModelStream: NULL stream");
+        if (&st.fs->server() != &srv) throw Exception("trainModelStream: every stream must live on the same GpuServer");
+        if (st.fs->getVectSize() != world.getVectSize()) throw Exception("trainModelStream: vectSize of a stream differs from the model's");
+    }
+    const unsigned long initialDistribCount = world.getDistribCount();
+    if (cfg.componentReduction && cfg.targetDistribCount > initialDistribCount)
+        throw Exception("trainModelStream: targetMixtureDistribCount exceeds the number of components");
+    // the reference's loop nest, flattened: the frame selection of a pass depends on seeds only, never on the model, so the bagging
+    // of pass k + 1 (rand() over every chunk: ~3 ms per 10^6 frames) runs on the host WHILE the kernels of pass k run on the device
+    std::vector<unsigned long> total(nbStream);
+    unsigned long nbTotalFrame = 0;
+    for (unsigned long s = 0; s < nbStream; ++s) {
+        total[s] = totalFrame(*streams[s].segs);
+        nbTotalFrame += (unsigned long)((double)total[s] * streams[s].weight);
+    }
+    const double nbFrameToSelect = cfg.baggedFrameProbability * nbTotalFrame;
+    std::vector<EMPass> passes;
     for (unsigned long trainIt = 0; trainIt < cfg.nbTrainIt; ++trainIt) {
+        for (unsigned long s = 0; s < nbStream; ++s) {
+            unsigned long nbBaggedIt = 1;
+            double baggedProba = (nbFrameToSelect * streams[s].weight) / (double)total[s];
+            if (baggedProba > 1) {
+                nbBaggedIt = (unsigned long)baggedProba + 1;
+                baggedProba /= nbBaggedIt;
+            }
+            for (unsigned long b = 0; b < nbBaggedIt; ++b) passes.push_back(EMPass{trainIt, s, b, baggedProba, false});
+        }
+        if (!passes.empty() && passes.back().trainIt == trainIt) passes.back().lastOfIt = true;
+    }
+    struct Prepared { const float *x = nullptr; unsigned long n = 0; double msBag = 0.0, msSel = 0.0; };
+    auto prepare = [&](const EMPass &ps) {
+        Prepared pr;
+        StageClock clk;
+        SegCluster baggedFramesCluster;
+        baggedFramesCluster.reserve((size_t)((double)total[ps.stream] / (double)std::max<unsigned long>(cfg.baggedMinimalLength, 1) * std::min(ps.proba * 1.05 + 0.01, 1.0)) + 16);
+        srand((unsigned)(((ps.trainIt + 1 + cfg.initRand) * 200) + (((ps.stream + 1) * 20) + (ps.baggedIt + 1)))); // TrainTools.cpp:1070
+        baggedSegments(*streams[ps.stream].segs, baggedFramesCluster, ps.proba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
+        pr.msBag = clk.lap();
+        pr.x = streams[ps.stream].fs->select(baggedFramesCluster, pr.n); // enqueued behind the kernels in flight
+        pr.msSel = clk.lap();
+        return pr;
+    };
+
+    std::vector<double> llkIt;
+    // ONE accumulator for all iterations (the reference creates a MixtureStat per iteration; resetEM() is the same state): no device
+    // allocation / release (each a device synchronisation) inside the loop -- rebuilt only when componentReduction shrinks the model
+    std::unique_ptr<DeviceMixture> dworld(new DeviceMixture(srv, world));
+    std::unique_ptr<EMAcc> emAcc(new EMAcc(*dworld, world));
+    emAcc->resetEM();
+    Prepared cur;
+    if (!passes.empty()) cur = prepare(passes[0]);
+    double msBag = 0.0, msSel = 0.0, msEnq = 0.0;
+    if (cfg.iterationMs) cfg.iterationMs->clear();
+    StageClock itClock;
+    for (size_t k = 0; k < passes.size(); ++k) {
+        const EMPass &ps = passes[k];
+        StageClock clk;
+        srv.check(gmmiv_em_accumulate(srv.ctx(), dworld->handle(), cur.x, GMMIV_F32, (int64_t)cur.n, (int64_t)world.getVectSize(), 1.0,
+                                      emAcc->acc().dev()));
+        msEnq += clk.lap();
+        msBag += cur.msBag; msSel += cur.msSel;
+        if (k + 1 < passes.size()) cur = prepare(passes[k + 1]);
+        if (!ps.lastOfIt) continue;
+        const double msPrep = clk.lap();
+        const unsigned long trainIt = ps.trainIt;
         const double varianceFlooring = setItParameter(cfg.initVarianceFlooring, cfg.finalVarianceFlooring, (int)cfg.nbTrainIt, (int)trainIt);
         const double varianceCeiling = setItParameter(cfg.initVarianceCeiling, cfg.finalVarianceCeiling, (int)cfg.nbTrainIt, (int)trainIt);
-        const unsigned long nbTotalFrame = totalFrame(selectedSegments);
-        const double nbFrameToSelect = cfg.baggedFrameProbability * nbTotalFrame;
-        emAcc.resetEM();
-        double llkPreviousIt = 0.0;
-        unsigned long nbBaggedIt = 1;
-        double baggedProba = nbFrameToSelect / (double)nbTotalFrame;
-        if (baggedProba > 1) {
-            nbBaggedIt = (unsigned long)baggedProba + 1;
-            baggedProba /= nbBaggedIt;
-        }
-        for (unsigned long baggedIt = 0; baggedIt < nbBaggedIt; ++baggedIt) {
-            SegCluster baggedFramesCluster;
-            srand((unsigned)(((trainIt + 1 + cfg.initRand) * 200) + (((stream + 1) * 20) + (baggedIt + 1)))); // TrainTools.cpp:1070
-            baggedSegments(selectedSegments, baggedFramesCluster, baggedProba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
-            llkPreviousIt += accumulateStatEM(fs, emAcc, baggedFramesCluster);
-        }
-        if (comm) fs.server().check(gmmiv_allreduce_f64(comm, emAcc.acc().dev(), emAcc.acc().size())); // RCCL on the device accumulator
-        else if (allReduce) allReduce(emAcc.flat().data(), emAcc.flat().size(), user);               // sum over ranks == addAccEM over threads
-        llkPreviousIt = emAcc.getAccumulatedLLK() / emAcc.getEMFeatureCount();
-        world = emAcc.getEM();
+        if (comm) srv.check(gmmiv_allreduce_f64(comm, emAcc->acc().dev(), emAcc->acc().size())); // RCCL on the device accumulator
+        else if (allReduce) allReduce(emAcc->flat().data(), emAcc->flat().size(), user);          // sum over ranks == addAccEM over threads
+        double tail[2];
+        emAcc->acc().get(tail, 2, emAcc->acc().size() - 2); // [sum_t w log lk_t, sum_t w]: waits for the kernels of the iteration
+        const double llkPreviousIt = tail[0] / tail[1];
+        const double msWait = clk.lap();
+        world = emAcc->getEM();
         varianceControl(world, varianceFlooring, varianceCeiling, globalCov);
-        dworld.update(world);
+        bool resized = false;
+        if (cfg.componentReduction) { // TrainTools.cpp:1078-1097
+            const double diff = (double)(initialDistribCount - cfg.targetDistribCount) / (double)cfg.nbTrainIt;
+            unsigned long nbTop = initialDistribCount - (unsigned long)((double)(trainIt + 1) * diff);
+            if (trainIt == cfg.nbTrainIt - 1) nbTop = cfg.targetDistribCount;
+            if (nbTop < world.getDistribCount()) {
+                if (nbTop == 0) throw Exception("trainModelStream: componentReduction leaves no component");
+                std::vector<bool> selectCompA;
+                const unsigned long nbOutputDistrib = selectComponent(selectCompA, nbTop, world);
+                MixtureGD outputM(nbOutputDistrib, world.getVectSize());
+                (void)reduceModel(selectCompA, world, outputM);
+                normalizeWeights(outputM);
+                world = outputM;
+                resized = true;
+            }
+        }
+        if (cfg.normalizeModel) // normalizeMixture(*world, trainCfg, config): target N(0, 1)
+            normalizeMixture(world, std::vector<double>(), std::vector<double>(), true, cfg.normalizeModelMeanOnly ? cfg.normalizeModelNbIt : 1,
+                             cfg.normalizeModelMeanOnly);
+        const double msM = clk.lap();
+        if (resized) {
+            srv.sync();
+            emAcc.reset();
+            dworld.reset(new DeviceMixture(srv, world));
+            emAcc.reset(new EMAcc(*dworld, world));
+        } else {
+            dworld->update(world);
+            emAcc->setModel(world);
+        }
+        emAcc->resetEM();
         llkIt.push_back(llkPreviousIt);
+        if (cfg.iterationMs) { srv.sync(); cfg.iterationMs->push_back(itClock.lap()); }
+        if (traceOn())
+            fprintf(stderr, "[liagpu] trainModelStream it %lu: host baggedSegments %.2f ms + select %.2f (overlapped with the previous pass), enqueue %.2f, "
+                            "next pass prepared in %.2f, wait for the kernels %.2f, getEM + varianceControl %.2f, model update %.2f\n",
+                    trainIt, msBag, msSel, msEnq, msPrep, msWait, msM, clk.lap());
+        msBag = msSel = msEnq = 0.0;
     }
     return llkIt;
 }
@@ -904,6 +1202,7 @@ void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegC
     }
     unsigned long n = 0;
     const float *x = fs.select(all, n);
+    if (&fs.server() != &_srv) fs.server().sync(); // the selection is enqueued on the feature buffer's stream
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), uttBegin.data(),
                               (int64_t)_n_speakers, _statN.dev(), _statF.dev()));
 }
@@ -928,6 +1227,7 @@ void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegC
     if (lineFiles.empty()) lineFiles.push_back(0);
     unsigned long n = 0;
     const float *x = fs.select(all, n);
+    if (&fs.server() != &_srv) fs.server().sync(); // the selection is enqueued on the feature buffer's stream
     _srv.check(gmmiv_tv_stats_lines(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), fileBegin.data(),
                                     (int64_t)segsPerFile.size(), (int64_t)_n_speakers, lineOff.data(), lineFiles.data(), _statN.dev(), _statF.dev()));
 }
@@ -1154,6 +1454,7 @@ void JFAAcc::computeAndAccumulateJFAStat(FeatureBuffer &fs, const std::vector<Se
     }
     unsigned long n = 0;
     const float *x = fs.select(all, n);
+    if (&fs.server() != &_srv) fs.server().sync(); // the selection is enqueued on the feature buffer's stream
     // the frame loop (:544-575) runs once, per session, on the device; a speaker's rows are the sums of its sessions' rows
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), begin.data(),
                               (int64_t)_n_sessions, _N_h.dev(), _F_X_h.dev()));

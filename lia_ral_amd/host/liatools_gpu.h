@@ -88,15 +88,22 @@ class FeatureBuffer {
     unsigned long getFeatureCount() const { return _n; }
     unsigned long getFirstFeatureIndexOfASource(unsigned long s) const { return _first.at(s); }
     const float *device() const { return _dev; }
-    // device matrix [n x D] of the frames selected by the cluster, in cluster order
+    // device matrix [n x D] of the frames selected by the cluster, in cluster order.  The selection is ENQUEUED on the server's
+    // stream (run table from pinned memory + k_gather_runs) and the pointer is valid in stream order: every gmmiv call of the same
+    // server that follows sees the frames; the host does not wait.  A cluster that is one contiguous run is returned in place.
+    // The matrix is overwritten by the next select() -- also in stream order, after the kernels that still read it.
     const float *select(const SegCluster &c, unsigned long &nSelected);
     GpuServer &server() { return _srv; }
 
   private:
+    unsigned long buildRuns(const SegCluster &c, unsigned long &nSelected, unsigned long &firstFrame, size_t &nPieces);
     GpuServer &_srv;
     float *_dev = nullptr, *_sel = nullptr;
     unsigned long _n, _d, _selCap = 0;
     std::vector<unsigned long> _first;
+    int64_t *_hRuns = nullptr, *_dRuns = nullptr; // run table: pinned host copy, device copy
+    size_t _runsCap = 0, _dRunsCap = 0;
+    void *_runsCopied = nullptr;                  // hipEvent_t: the last upload of the pinned table has completed
 };
 
 // MixtureGD / DistribGD: weight(c), getMean/getCov/getCovInv, setMean/setCov, computeAll()
@@ -164,6 +171,7 @@ class EMAcc {
     double getEMFeatureCount() const;   // sum of the frame weights (2 doubles come back from the device)
     double getAccumulatedLLK() const;
     MixtureGD getEM() const; // ML weights / means / covariances; occ == 0 keeps the model's values
+    void setModel(const MixtureGD &model) { _model = model; } // the model the next getEM() falls back to (createAndStoreMixtureStat(*world) of the next iteration)
     void addAccEM(const EMAcc &o);
     std::vector<double> &flat() { return _acc.host(); } // host view of the flat accumulator (downloaded on demand)
     DVec &acc() { return _acc; }                         // the device-resident accumulator = the all-reduce payload
@@ -200,6 +208,17 @@ struct TrainCfg { // TrainTools.cpp:67-93
     unsigned long nbTrainIt = 1;
     double baggedFrameProbability = 1.0;
     unsigned long baggedMinimalLength = 3, baggedMaximalLength = 7, initRand = 0;
+    // componentReduction / targetMixtureDistribCount (:86-91): after every iteration keep the nbTop heaviest components, nbTop going
+    // linearly from the initial count to the target (TrainTools.cpp:1078-1097)
+    bool componentReduction = false;
+    unsigned long targetDistribCount = 0;
+    // normalizeModel (:76-84): after every iteration move the mixture to global mean 0 / variance 1 (normalizeMixture, :287-315);
+    // normalizeModelNbIt only applies with normalizeModelMeanOnly
+    bool normalizeModel = false, normalizeModelMeanOnly = false;
+    unsigned long normalizeModelNbIt = 1;
+    // not a reference parameter: when set, receives the wall time (ms) of every iteration, measured from the end of the previous
+    // iteration's model update to the end of this one's (what bench.py's host_layer block reports)
+    std::vector<double> *iterationMs = nullptr;
 };
 double setItParameter(double begin, double end, int nbIt, int it);                                 // :560-564
 void varianceControl(MixtureGD &model, double flooring, double ceiling, const std::vector<double> &covSignal); // :567-587
@@ -232,6 +251,27 @@ void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegClust
 // MixtureStat::addAccEM (AccumulateStat.cpp:286-292).  The default is the C ABI's own RCCL communicator (comm, on the device
 // accumulator); AllReduceFn is the hook for another transport (it gets the HOST view of the accumulator).
 typedef void (*AllReduceFn)(double *buf, size_t n, void *user);
+// one input stream of TrainWorld ("inputStreamList" / "weightStreamList", TrainWorld.cpp:123-137): fsTab[i], segTab[i], weightTab[i].
+// Every stream's FeatureBuffer lives on the same GpuServer.  weightTab defaults to 1 / nbStream (reserveMem, TrainWorld.cpp:85).
+struct TrainStream { FeatureBuffer *fs = nullptr; const SegCluster *segs = nullptr; double weight = 1.0; };
+// The stream form (TrainTools.cpp:1030-1110): per iteration and stream, baggedProba = p * nbTotalFrame * weight / totalFrame(stream)
+// (folded into nbBaggedIt passes when > 1), seed ((trainIt+1+initRand)*200) + ((stream+1)*20) + (baggedIt+1), ONE accumulator over
+// all streams; then getEM, varianceControl, componentReduction, normalizeModel.  `world` may come back with fewer components.
+// The host prepares the selection of the next pass while the kernels of the current one run (rand() order unchanged: every pass
+// seeds the generator itself).
+std::vector<double> trainModelStream(const TrainCfg &cfg, const std::vector<TrainStream> &streams, const std::vector<double> &globalCov,
+                                     MixtureGD &world, AllReduceFn allReduce = nullptr, void *user = nullptr, gmmiv_comm *comm = nullptr);
+// component selection and model normalisation used by it (TrainTools.cpp:186-227, :240-315; TabWeight: GeneralTools.h:145-183)
+std::vector<unsigned long> sortByWeight(const MixtureGD &model);     // TabWeight::_sortByWeight: qsort, heaviest first
+unsigned long selectComponent(std::vector<bool> &selectCompA, unsigned long nbTop, const MixtureGD &inputM); // the nbTop heaviest
+unsigned long selectComponent(std::vector<bool> &selectCompA, double wFactor, const MixtureGD &inputM);      // weight >= wFactor
+double reduceModel(const std::vector<bool> &selectCompA, const MixtureGD &inputM, MixtureGD &outputM);        // returns the kept weight
+void normalizeWeights(MixtureGD &outputM);
+void mixtureFusion(const MixtureGD &mixt, std::vector<double> &mean, std::vector<double> &cov, double &wres);
+void normalizeMixture(MixtureGD &mixt, const std::vector<double> &meanSignal, const std::vector<double> &covSignal, bool zeroOne,
+                      unsigned long nbIt, bool meanOnly);
+// global mean / covariance over several streams (computeMeanCov(config, fsTab, segTab, nbStream, ...), TrainTools.cpp:593-601)
+unsigned long computeMeanCov(const std::vector<TrainStream> &streams, std::vector<double> &mean, std::vector<double> &cov);
 std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,
                                      const std::vector<double> &globalCov, MixtureGD &world, gmmiv_comm *comm);
 std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, const SegCluster &selectedSegments,

@@ -50,11 +50,47 @@ def train_world(x, seg_begin, seg_len, w, mean, cov, nb_it, bagged_p=1.0, init_f
     w = np.array(w, np.float64); mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
     C = len(w)
     b, l, bp, lp = _segs(seg_begin, seg_len)
-    gm = np.empty(D); gc = np.empty(D); llk = np.empty(nb_it)
-    _chk(lib.liagpu_train_world(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(w), _d(mean),
-                                _d(cov), nb_it, ct.c_double(bagged_p), ct.c_double(init_floor), ct.c_double(final_floor),
-                                ct.c_double(init_ceil), ct.c_double(final_ceil), ct.c_long(init_rand), _d(gm), _d(gc), _d(llk)))
-    return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk)
+    gm = np.empty(D); gc = np.empty(D); llk = np.empty(nb_it); it_ms = np.empty(nb_it)
+    _chk(lib.liagpu_train_world_timed(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(w), _d(mean),
+                                      _d(cov), nb_it, ct.c_double(bagged_p), ct.c_double(init_floor), ct.c_double(final_floor),
+                                      ct.c_double(init_ceil), ct.c_double(final_ceil), ct.c_long(init_rand), _d(gm), _d(gc), _d(llk), _d(it_ms)))
+    return dict(w=w, mean=mean, cov=cov, global_mean=gm, global_cov=gc, llk=llk, it_ms=it_ms)
+
+
+def train_world_streams(xs, seg_begins, seg_lens, w, mean, cov, nb_it, weights=None, bagged_p=1.0, init_floor=0.0, final_floor=0.0,
+                        init_ceil=10.0, final_ceil=10.0, init_rand=0, component_reduction=False, target_distrib_count=0,
+                        normalize_model=False, normalize_mean_only=False, normalize_nb_it=1, device=0):
+    """TrainWorld over several input streams (liagpu_train_world_streams): xs / seg_begins / seg_lens are lists, one entry per stream."""
+    ns = len(xs)
+    xs = [np.ascontiguousarray(x, np.float32) for x in xs]
+    D = xs[0].shape[1]
+    w = np.array(w, np.float64); mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
+    C = len(w)
+    segs = [_segs(b, l) for b, l in zip(seg_begins, seg_lens)]
+    xp = (_fp * ns)(*[x.ctypes.data_as(_fp) for x in xs])
+    Tp = (ct.c_long * ns)(*[x.shape[0] for x in xs])
+    bp = (_lp * ns)(*[s[2] for s in segs]); lp = (_lp * ns)(*[s[3] for s in segs])
+    np_ = (ct.c_long * ns)(*[len(s[0]) for s in segs])
+    wt = None if weights is None else np.ascontiguousarray(weights, np.float64)
+    opts = (ct.c_long * 5)(int(component_reduction), int(target_distrib_count), int(normalize_model), int(normalize_mean_only), int(normalize_nb_it))
+    gm = np.empty(D); gc = np.empty(D); llk = np.empty(nb_it); cout = ct.c_long(0)
+    _chk(lib.liagpu_train_world_streams(device, ns, xp, Tp, D, bp, lp, np_, _d(wt), C, _d(w), _d(mean), _d(cov), nb_it, ct.c_double(bagged_p),
+                                        ct.c_double(init_floor), ct.c_double(final_floor), ct.c_double(init_ceil), ct.c_double(final_ceil),
+                                        ct.c_long(init_rand), opts, ct.byref(cout), _d(gm), _d(gc), _d(llk)))
+    Co = cout.value
+    return dict(w=w[:Co].copy(), mean=mean[:Co].copy(), cov=cov[:Co].copy(), global_mean=gm, global_cov=gc, llk=llk)
+
+
+def model_reduce_normalize(w, mean, cov, nb_top=0, normalize=False, mean_only=False, nb_it=1):
+    """selectComponent(nbTop) + reduceModel + normalizeWeights, then normalizeMixture to N(0,1) (TrainTools.cpp:1078-1098); host only.
+    Returns (w, mean, cov, order) with order = TabWeight's heaviest-first component order of the INPUT model."""
+    w = np.array(w, np.float64); mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
+    C, D = mean.shape
+    order = np.empty(C, np.int64)
+    _chk(lib.liagpu_model_reduce_normalize(C, D, _d(w), _d(mean), _d(cov), ct.c_long(nb_top), int(normalize), int(mean_only), ct.c_long(nb_it),
+                                           order.ctypes.data_as(_lp)))
+    Co = nb_top if 0 < nb_top < C else C
+    return w[:Co].copy(), mean[:Co].copy(), cov[:Co].copy(), order
 
 
 def train_world_scratch(x, seg_begin, seg_len, C, nb_it, nb_frame_to_select=50.0, use01=False, bagged_p=1.0, init_floor=0.0, final_floor=0.0,
@@ -129,8 +165,9 @@ def train_target(x, seg_begin, seg_len, world, nb_it=1, mean_reg=16.0, device=0)
 
 
 def compute_test(x, seg_begin, seg_len, world, clients, top_c=10, complete=True, min_llk=-200.0, max_llk=200.0,
-                 segmental=False, device=0):
-    """world = (w, mean, cov); clients = list of (w, mean, cov).  Returns LLR[n_seg_or_1, n_clients]."""
+                 segmental=False, device=0, reps=0):
+    """world = (w, mean, cov); clients = list of (w, mean, cov).  Returns LLR[n_seg_or_1, n_clients]; with reps > 0 the LLR loop
+    is run that many times on the resident features and (llr, ms[reps]) is returned."""
     x = np.ascontiguousarray(x, np.float32)
     T, D = x.shape
     ww, mw, cw = [np.ascontiguousarray(a, np.float64) for a in world]
@@ -141,10 +178,12 @@ def compute_test(x, seg_begin, seg_len, world, clients, top_c=10, complete=True,
     b, l, bp, lp = _segs(seg_begin, seg_len)
     nout = (len(b) if segmental else 1) * len(clients)
     out = np.empty(nout)
-    _chk(lib.liagpu_compute_test(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(ww), _d(mw),
-                                 _d(cw), len(clients), _d(wc), _d(mc), _d(cc), top_c, int(complete), ct.c_double(min_llk),
-                                 ct.c_double(max_llk), int(segmental), _d(out)))
-    return out.reshape(-1, len(clients))
+    ms = np.zeros(max(reps, 1))
+    _chk(lib.liagpu_compute_test_timed(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(ww), _d(mw),
+                                       _d(cw), len(clients), _d(wc), _d(mc), _d(cc), top_c, int(complete), ct.c_double(min_llk),
+                                       ct.c_double(max_llk), int(segmental), _d(out), max(reps, 1), _d(ms)))
+    out = out.reshape(-1, len(clients))
+    return (out, ms) if reps > 0 else out
 
 
 def compute_test_ex(x, seg_begin, seg_len, world, clients, top_c=10, complete=True, min_llk=-200.0, max_llk=200.0, segmental=False,
@@ -170,7 +209,9 @@ def compute_test_ex(x, seg_begin, seg_len, world, clients, top_c=10, complete=Tr
     return out, win[:nw.value]
 
 
-def iv_extract(x, utt_begin, ubm, Tmat, device=0, return_stats=False):
+def iv_extract(x, utt_begin, ubm, Tmat, device=0, return_stats=False, reps=0):
+    """IvExtractor.  reps > 0: the extraction is run that many times on the resident features; the wall times
+    ms[reps, 4] = (statistics, substractM, estimateTETt [first run only], estimateW) are appended to the result."""
     x = np.ascontiguousarray(x, np.float32)
     T, D = x.shape
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
@@ -179,10 +220,16 @@ def iv_extract(x, utt_begin, ubm, Tmat, device=0, return_stats=False):
     R = Tm.shape[0]
     ub = np.ascontiguousarray(utt_begin, np.int64)
     U = len(ub) - 1
-    W = np.empty((U, R)); N = np.empty((U, C)); F = np.empty((U, C * D))
-    _chk(lib.liagpu_iv_extract(device, x.ctypes.data_as(_fp), ct.c_long(T), D, ub.ctypes.data_as(_lp), ct.c_long(U), C, _d(w),
-                               _d(mean), _d(cov), R, _d(Tm), _d(W), _d(N), _d(F)))
-    return (W, N, F) if return_stats else W
+    W = np.empty((U, R))
+    N = np.empty((U, C)) if return_stats else None
+    F = np.empty((U, C * D)) if return_stats else None
+    ms = np.zeros((max(reps, 1), 4))
+    _chk(lib.liagpu_iv_extract_timed(device, x.ctypes.data_as(_fp), ct.c_long(T), D, ub.ctypes.data_as(_lp), ct.c_long(U), C, _d(w),
+                                     _d(mean), _d(cov), R, _d(Tm), _d(W), _d(N), _d(F), max(reps, 1), _d(ms)))
+    res = (W, N, F) if return_stats else W
+    if reps > 0:
+        return res + (ms,) if return_stats else (W, ms)
+    return res
 
 
 def iv_extract_approx(x, utt_begin, ubm, Tmat, mode, device=0):

@@ -321,6 +321,78 @@ long orc_bagged_segments(unsigned seed, const long *seg_begin, const long *seg_l
     return n;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Row 10 edges: componentReduction and normalizeModel of trainModelStream (TrainTools.cpp:1078-1099)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { double weight; unsigned long distrib; void *distribP; } orc_tab_weight_elem; /* GeneralTools.h:145-149 */
+static int orc_comp_f(const void *op1, const void *op2) /* _compF, GeneralTools.cpp:277-280 */
+{
+    if (((const orc_tab_weight_elem *)op1)->weight > ((const orc_tab_weight_elem *)op2)->weight) return -1;
+    else return 1;
+}
+/* TabWeight::_sortByWeight (GeneralTools.h:157-164): order[i] = i-th heaviest component (qsort: ties as the C library leaves them) */
+void orc_sort_by_weight(int C, const double *w, long *order)
+{
+    orc_tab_weight_elem *tab = (orc_tab_weight_elem *)malloc((size_t)C * sizeof(*tab));
+    for (int i = 0; i < C; ++i) { tab[i].weight = w[i]; tab[i].distrib = (unsigned long)i; tab[i].distribP = 0; }
+    qsort(tab, (size_t)C, sizeof(*tab), orc_comp_f);
+    for (int i = 0; i < C; ++i) order[i] = (long)tab[i].distrib;
+    free(tab);
+}
+/* selectComponent(selectCompA, nbTop, inputM) + reduceModel + normalizeWeights (TrainTools.cpp:197-227): the nb_top heaviest
+ * components, in their ORIGINAL order, weights renormalised to 1.  w / mean / cov are compacted in place; returns nb_top. */
+int orc_reduce_model(int C, int D, double *w, double *mean, double *cov, int nb_top)
+{
+    long *order = (long *)malloc((size_t)C * sizeof(long));
+    char *sel = (char *)calloc((size_t)C, 1);
+    orc_sort_by_weight(C, w, order);
+    for (int i = 0; i < nb_top; ++i) sel[order[i]] = 1;
+    int o = 0;
+    double tot = 0.0;
+    for (int c = 0; c < C; ++c)
+        if (sel[c]) {
+            for (int k = 0; k < D; ++k) { mean[(size_t)o * D + k] = mean[(size_t)c * D + k]; cov[(size_t)o * D + k] = cov[(size_t)c * D + k]; }
+            w[o] = w[c];
+            tot += w[o];
+            o++;
+        }
+    tot = 0.0; /* normalizeWeights recomputes the total over the output model (:223-228) */
+    for (int c = 0; c < o; ++c) tot += w[c];
+    for (int c = 0; c < o; ++c) w[c] /= tot;
+    free(order); free(sel);
+    return o;
+}
+/* normalizeMixture(mixt, fake, fake, zeroOne = true, nbIt, meanOnly) (TrainTools.cpp:287-315) with mixtureFusion / gaussianFusion
+ * (:240-283): tmp = the single Gaussian carrying the mixture's moments (components folded in one by one), then every component
+ * mean <- (mean - tmp.mean) / sqrt(tmp.cov), cov <- cov / tmp.cov (unless meanOnly). */
+void orc_normalize_mixture(int C, int D, const double *w, double *mean, double *cov, int nb_it, int mean_only)
+{
+    double *tm = (double *)malloc((size_t)D * sizeof(double)), *tc = (double *)malloc((size_t)D * sizeof(double));
+    for (int it = 0; it < nb_it; ++it) {
+        double wtmp = w[0], wres = w[0];
+        for (int k = 0; k < D; ++k) { tm[k] = mean[k]; tc[k] = cov[k]; }
+        for (int i = 1; i < C; ++i) { /* gaussianFusion(mixt.getDistrib(i), mixt.weight(i), res, wtmp, res, wres) */
+            const double w1 = w[i], w2 = wtmp;
+            const double a1 = w1 / (w1 + w2), a2 = 1.0 - a1;
+            for (int k = 0; k < D; ++k) {
+                const double d = mean[(size_t)i * D + k] - tm[k];
+                tc[k] = a1 * cov[(size_t)i * D + k] + a2 * tc[k] + a1 * a2 * d * d;
+                tm[k] = (a1 * mean[(size_t)i * D + k]) + (a2 * tm[k]);
+            }
+            wres = w1 + w2;
+            wtmp = wres;
+        }
+        for (int c = 0; c < C; ++c)
+            for (int i = 0; i < D; ++i) {
+                double nm = mean[(size_t)c * D + i] - tm[i];
+                nm /= sqrt(tc[i]);
+                mean[(size_t)c * D + i] = nm;
+                if (!mean_only) cov[(size_t)c * D + i] = cov[(size_t)c * D + i] / tc[i];
+            }
+    }
+    free(tm); free(tc);
+}
+
 /* The multi-selection bagging of mixtureInit (GeneralTools.cpp:330-390): one walk over the segments, nb_bagged draws per chunk,
  * a chunk kept for component idx is written with label idx.  Seeds the generator itself (TrainTools.cpp:732). */
 long orc_bagged_segments_multi(unsigned seed, const long *seg_begin, const long *seg_len, long nseg, long nb_bagged,

@@ -183,6 +183,33 @@ def bagged_segments(seed, seg_begin, seg_len, p, min_len=3, max_len=7):
     return ob[:n].copy(), ol[:n].copy(), os_[:n].copy()
 
 
+def sort_by_weight(w):
+    """TabWeight::_sortByWeight (GeneralTools.h:157-164): component indices, heaviest first (libc qsort)."""
+    w, wp = _d(w)
+    order = np.empty(len(w), np.int64)
+    _lib().orc_sort_by_weight(ct.c_int(len(w)), wp, order.ctypes.data_as(c_lp))
+    return order
+
+
+def reduce_model(w, mean, cov, nb_top):
+    """selectComponent(nbTop) + reduceModel + normalizeWeights (TrainTools.cpp:197-227)."""
+    w = np.array(w, np.float64); mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
+    C, D = mean.shape
+    f = _lib().orc_reduce_model
+    f.restype = ct.c_int
+    n = f(ct.c_int(C), ct.c_int(D), w.ctypes.data_as(c_dp), mean.ctypes.data_as(c_dp), cov.ctypes.data_as(c_dp), ct.c_int(nb_top))
+    return w[:n].copy(), mean[:n].copy(), cov[:n].copy()
+
+
+def normalize_mixture(w, mean, cov, nb_it=1, mean_only=False):
+    """normalizeMixture to N(0, 1) (TrainTools.cpp:287-315)."""
+    w, wp = _d(w)
+    mean = np.array(mean, np.float64); cov = np.array(cov, np.float64)
+    C, D = mean.shape
+    _lib().orc_normalize_mixture(ct.c_int(C), ct.c_int(D), wp, mean.ctypes.data_as(c_dp), cov.ctypes.data_as(c_dp), ct.c_int(nb_it), ct.c_int(int(mean_only)))
+    return mean, cov
+
+
 def mixture_init(C, x, seg_begin, seg_len, nb_frame_to_select=50.0, stream_weight=1.0, min_len=3, max_len=7):
     """mixtureInit (TrainTools.cpp:674-766, one stream): (mean [C x D], frames picked per component)."""
     x, xp = _d(x)
@@ -237,6 +264,23 @@ def tv_estimate_w(N, F, Tm, invvar, TETt, fast=False, threads=0):
     else:
         rc = lib.orc_tv_estimate_w(ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(R), Np, Fp, tp, ivp, tep,
                                    W.ctypes.data_as(c_dp))
+    assert rc == 0
+    return W
+
+
+def iv_extract_mt(g, x, utt_begin, Tm, invvar, TETt, threads=1):
+    """IvExtractor end to end on `threads` threads, utterance ranges per thread like the reference (oracle_mt.c, -O3 -ffast-math
+    build: bench.py's cpu_baseline of the i-vector metric).  x [T, D] fp64, utt_begin [U + 1] -> W [U, R]."""
+    x, xp = _d(x)
+    ub, ubp = _l(utt_begin)
+    U = len(ub) - 1
+    Tm, tp = _d(Tm); invvar, ip = _d(invvar); TETt, tep = _d(TETt)
+    R = Tm.shape[0]
+    W = np.empty((U, R))
+    f = _lib(True).orc_iv_extract_mt
+    f.restype = ct.c_int
+    rc = f(ct.c_int(threads), ct.c_long(U), ct.c_int(g.C), ct.c_int(g.D), ct.c_int(R), *g.args()[2:], xp, ubp, tp, ip, tep,
+           W.ctypes.data_as(c_dp))
     assert rc == 0
     return W
 

@@ -93,3 +93,54 @@ int orc_tv_estimate_w_mt(int nthreads, long U, int C, int D, int R, const double
     free(jobs); free(th);
     return rc;
 }
+
+/* IvExtractor end to end (LIA_SpkDet/IvExtractor/src/IvExtractor.cpp:70-148) with the reference's thread split: contiguous
+ * ranges of statistics rows per thread, for the statistics (AccumulateTVStat.cpp:498-507) and for estimateW (:2282-2300).  Every
+ * worker runs both phases on its own rows: computeAndAccumulateTVStat, substractM, estimateW (TETt is computed once by the
+ * caller, like estimateTETt before the threads start).  x [T x D] fp64 (Feature::getDataVector), utt_begin [U + 1]. */
+void orc_tv_stats(int C, int D, const double *w, const double *mean, const double *covinv,
+                  const double *x, long T, const long *utt, double *N, double *F);
+void orc_tv_subtract_m(long U, int C, int D, const double *N, double *F, const double *ubm_means);
+
+typedef struct {
+    long U; int C, D, R; const double *w, *mean, *covinv, *x; const long *utt_begin;
+    const double *Tm, *invvar, *TETt; double *W; int rc;
+} iv_job;
+
+static void *iv_worker(void *p)
+{
+    iv_job *j = p;
+    if (j->U <= 0) { j->rc = 0; return NULL; }
+    const size_t SV = (size_t)j->C * j->D;
+    const long t0 = j->utt_begin[0], T = j->utt_begin[j->U] - t0;
+    double *N = calloc((size_t)j->U * j->C, sizeof(double)), *F = calloc((size_t)j->U * SV, sizeof(double));
+    long *utt = malloc(sizeof(long) * (T > 0 ? T : 1));
+    for (long u = 0; u < j->U; ++u)
+        for (long t = j->utt_begin[u]; t < j->utt_begin[u + 1]; ++t) utt[t - t0] = u;
+    orc_tv_stats(j->C, j->D, j->w, j->mean, j->covinv, j->x + (size_t)t0 * j->D, T, utt, N, F);
+    orc_tv_subtract_m(j->U, j->C, j->D, N, F, j->mean);
+    j->rc = orc_tv_estimate_w(j->U, j->C, j->D, j->R, N, F, j->Tm, j->invvar, j->TETt, j->W);
+    free(N); free(F); free(utt);
+    return NULL;
+}
+
+int orc_iv_extract_mt(int nthreads, long U, int C, int D, int R, const double *w, const double *mean, const double *covinv,
+                      const double *x, const long *utt_begin, const double *Tm, const double *invvar, const double *TETt, double *W)
+{
+    if (nthreads < 1) nthreads = 1;
+    iv_job *jobs = calloc(nthreads, sizeof(iv_job));
+    pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
+    long per = (U + nthreads - 1) / nthreads;
+    for (int i = 0; i < nthreads; ++i) {
+        long b = i * per, e = b + per > U ? U : b + per;
+        if (b > U) b = e = U;
+        iv_job *j = &jobs[i];
+        j->U = e - b; j->C = C; j->D = D; j->R = R; j->w = w; j->mean = mean; j->covinv = covinv; j->x = x;
+        j->utt_begin = utt_begin + b; j->Tm = Tm; j->invvar = invvar; j->TETt = TETt; j->W = W + (size_t)b * R;
+        pthread_create(&th[i], NULL, iv_worker, j);
+    }
+    int rc = 0;
+    for (int i = 0; i < nthreads; ++i) { pthread_join(th[i], NULL); rc |= jobs[i].rc; }
+    free(jobs); free(th);
+    return rc;
+}

@@ -303,3 +303,54 @@ def test_three_rank_tv_em_iteration_padded_blocks_gloo():
     assert np.allclose(res[0]["T"], Tref, rtol=1e-9, atol=1e-12)
     assert np.allclose(res[0]["means"], mref, rtol=1e-9, atol=1e-12)
     assert res[0]["phases"] == ["allgather", "estep", "min_divergence", "reduce_scatter", "tett", "update_t"]
+
+
+def test_component_selection_and_model_normalisation_host_logic():
+    """selectComponent / reduceModel / normalizeWeights / normalizeMixture of the C++ host layer (TrainTools.cpp:186-227, :240-315;
+    host arithmetic, no device) against the oracle restatement; TabWeight's order is libc qsort's on both sides, ties included."""
+    from lia_ral_amd import host_capi as h
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2)
+    C, D = 40, 7
+    w = rng.dirichlet(np.full(C, 2.0)); w[5] = w[17] = w[30]; w /= w.sum()          # three equal weights
+    mean = rng.normal(size=(C, D)); cov = rng.uniform(0.5, 2.0, (C, D))
+    _, _, _, order = h.model_reduce_normalize(w, mean, cov)
+    assert np.array_equal(order, orc.sort_by_weight(w)) and np.all(np.diff(w[order]) <= 0)
+    for nb_top in (1, 13, 39):
+        gw, gm, gc, _ = h.model_reduce_normalize(w, mean, cov, nb_top=nb_top)
+        ow, om, oc = orc.reduce_model(w, mean, cov, nb_top)
+        assert len(gw) == nb_top and np.array_equal(gw, ow) and np.array_equal(gm, om) and np.array_equal(gc, oc)
+        assert abs(gw.sum() - 1.0) < 1e-14
+    for mean_only, nb_it in ((False, 1), (True, 3)):
+        gw, gm, gc, _ = h.model_reduce_normalize(w, mean, cov, normalize=True, mean_only=mean_only, nb_it=nb_it)
+        om, oc = orc.normalize_mixture(w, mean, cov, nb_it, mean_only)
+        assert np.allclose(gm, om, rtol=0, atol=1e-13) and np.allclose(gc, oc, rtol=1e-13, atol=0)
+        if not mean_only:   # the mixture now has global mean 0 and variance 1
+            m1 = (w[:, None] * gm).sum(0); m2 = (w[:, None] * (gc + gm * gm)).sum(0)
+            assert np.max(np.abs(m1)) < 1e-12 and np.max(np.abs(m2 - 1.0)) < 1e-12
+
+
+def test_id_file_of_another_job_is_never_accepted(tmp_path, monkeypatch):
+    """gmmiv_comm_exchange_id_file: the published id carries the job's nonce (GMMIV_COMM_JOB, else the launcher's rendezvous
+    address / port / run id).  A file left at the same path by a job that died before its communicator existed is recent, but it
+    is another job's: a non-root rank must keep waiting for ITS rank 0 instead of joining with the dead id."""
+    from lia_ral_amd import capi
+    path = str(tmp_path / "id")
+    monkeypatch.setenv("GMMIV_COMM_TRANSPORT", "shm")        # the id is drawn without RCCL (no GPU here)
+    monkeypatch.setenv("GMMIV_COMM_JOB", "job-A")
+    uid_a = capi.Comm.exchange_id_file(path, 0, 5.0)          # rank 0 of job A publishes ... and the job dies
+    assert os.path.exists(path)
+    assert capi.Comm.exchange_id_file(path, 1, 5.0) == uid_a   # a rank of job A reads it
+    monkeypatch.setenv("GMMIV_COMM_JOB", "job-B")
+    with pytest.raises(capi.GmmivError, match="waited"):
+        capi.Comm.exchange_id_file(path, 1, 0.3)              # a rank of job B, arriving before its rank 0: not fooled
+    uid_b = capi.Comm.exchange_id_file(path, 0, 5.0)          # job B's rank 0 replaces the file
+    assert uid_b != uid_a and capi.Comm.exchange_id_file(path, 1, 5.0) == uid_b
+    # no job variable: the launcher's rendezvous settings are the nonce
+    monkeypatch.delenv("GMMIV_COMM_JOB")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", "29512")
+    uid_c = capi.Comm.exchange_id_file(path, 0, 5.0)
+    assert capi.Comm.exchange_id_file(path, 1, 5.0) == uid_c
+    monkeypatch.setenv("MASTER_PORT", "29513")
+    with pytest.raises(capi.GmmivError, match="waited"):
+        capi.Comm.exchange_id_file(path, 1, 0.3)

@@ -784,3 +784,113 @@ def test_tv_verify_emlk_and_speaker_models():
     assert np.max(np.abs(llk - np.array(ref))) < 1e-9 and abs(total - sum(ref)) < 1e-8
     llk2, total2, _ = h.tv_verify_emlk(x, file_begin, rows, (w, mean, 1.0 / iv), Tm, W, max_llk_computed=2)   # config "computeLLK 2"
     assert len(llk2) == 2 and abs(total2 - sum(ref[:2])) < 1e-8
+
+
+def oracle_train_world_streams(xs, segs, weights, w, mean, cov, nb_it, p, fl0, fl1, ce0, ce1, init_rand=0, target=None, normalize=False,
+                               mean_only=False, norm_it=1):
+    """The stream form of trainModelStream (TrainTools.cpp:1030-1110) from oracle pieces: per iteration and stream a bagging pass
+    (or several when the stream's probability exceeds 1), ONE accumulator, then getEM / varianceControl / componentReduction /
+    normalizeModel."""
+    xs = [x.astype(np.float64) for x in xs]
+    sel = [np.concatenate([np.arange(b, b + n) for b, n in zip(sb, sl)]) for sb, sl in segs]
+    s = ss = n = 0
+    for x, se in zip(xs, sel):
+        a, b, c = orc.frame_acc(x[se]); s = s + a; ss = ss + b; n = n + c
+    gmean, gcov = orc.frame_mean_cov(s, ss, n)
+    total = [int(np.sum(sl)) for _, sl in segs]
+    C0 = len(w)
+    llks, frames = [], []
+    for it in range(nb_it):
+        floor = orc.set_it_parameter(fl0, fl1, nb_it, it); ceil = orc.set_it_parameter(ce0, ce1, nb_it, it)
+        nb_total = sum(int(float(t) * wt) for t, wt in zip(total, weights))
+        nb_sel = p * nb_total
+        acc = None
+        g = orc.Gmm(w, mean, 1.0 / cov)
+        for st, (x, (sb, sl)) in enumerate(zip(xs, segs)):
+            proba = nb_sel * weights[st] / float(total[st]); nb_bag = 1
+            if proba > 1:
+                nb_bag = int(proba) + 1; proba /= nb_bag
+            for b in range(nb_bag):
+                seed = ((it + 1 + init_rand) * 200) + ((st + 1) * 20) + (b + 1)
+                bb, bl, _ = orc.bagged_segments(seed, sb, sl, proba, 3, 7)
+                fr = np.concatenate([np.arange(q, q + m) for q, m in zip(bb, bl)]) if len(bb) else np.zeros(0, int)
+                acc = orc.em_accumulate(g, x[fr], acc=acc)
+        llks.append(acc["llk"] / acc["count"]); frames.append(acc["count"])
+        w, mean, cov = orc.em_get(acc, mean, cov)
+        cov, _, _ = orc.variance_control(cov, floor, ceil, gcov)
+        if target is not None:
+            diff = (C0 - target) / float(nb_it)
+            nb_top = C0 - int(float(it + 1) * diff)
+            if it == nb_it - 1:
+                nb_top = target
+            if nb_top < len(w):
+                w, mean, cov = orc.reduce_model(w, mean, cov, nb_top)
+        if normalize:
+            mean, cov = orc.normalize_mixture(w, mean, cov, norm_it if mean_only else 1, mean_only)
+    return dict(w=w, mean=mean, cov=cov, llk=np.array(llks), frames=np.array(frames), global_mean=gmean, global_cov=gcov)
+
+
+@pytest.mark.parametrize("case", ["two_streams", "weights_fold", "reduction", "normalize", "normalize_mean_only"])
+def test_train_model_stream_streams_reduction_normalisation(case):
+    """trainModelStream over nbStream input streams with weightTab (seed term (stream + 1) * 20, probability nbFrameToSelect *
+    weight / totalFrame(stream), folded into several passes when > 1), componentReduction (selectComponent / reduceModel /
+    normalizeWeights) and normalizeModel (TrainTools.cpp:1059-1099) through liagpu::trainModelStream, against the oracle loop."""
+    from lia_ral_amd import host_capi as h
+    C, D = 24, 12
+    w, mean, iv = make_gmm(C, D, seed=15)
+    rng = np.random.default_rng(1)
+    xs = [make_frames(w, mean, iv, 5000, seed=16), make_frames(w, mean, iv, 1800, seed=17)]
+    segs = [(np.array([0, 2600]), np.array([2400, 2300])), (np.array([100, 900]), np.array([700, 800]))]
+    w0 = rng.dirichlet(np.full(C, 5.0)); mean0 = mean + rng.normal(0, 0.5, mean.shape); cov0 = np.ones((C, D)) * 2.0
+    kw = dict(nb_it=3, bagged_p=0.6, init_floor=0.5, final_floor=0.05, init_ceil=5.0, final_ceil=10.0)
+    okw = dict(target=None)
+    weights = [0.5, 0.5]
+    if case == "weights_fold":
+        weights = [0.2, 0.8]        # stream 1: 0.6 * (940 + 1200) * 0.8 / 1500 = 0.68; with p = 1.5 below it exceeds 1 -> 2 passes
+        kw["bagged_p"] = 1.5
+    if case == "reduction":
+        kw.update(component_reduction=True, target_distrib_count=10); okw["target"] = 10
+    if case.startswith("normalize"):
+        mo = case.endswith("mean_only")
+        kw.update(normalize_model=True, normalize_mean_only=mo, normalize_nb_it=2); okw.update(normalize=True, mean_only=mo, norm_it=2)
+    got = h.train_world_streams(xs, [s[0] for s in segs], [s[1] for s in segs], w0, mean0, cov0, weights=weights, **kw)
+    ref = oracle_train_world_streams(xs, segs, weights, w0, mean0, cov0, 3, kw["bagged_p"], 0.5, 0.05, 5.0, 10.0, **okw)
+    assert relerr(got["global_cov"], ref["global_cov"]) < 1e-12 and relerr(got["global_mean"], ref["global_mean"]) < 1e-12
+    assert got["w"].shape == ref["w"].shape and (case != "reduction" or len(got["w"]) == 10)
+    assert np.max(np.abs(got["llk"] - ref["llk"])) < 1e-9
+    assert relerr(got["w"], ref["w"]) < 1e-8 and relerr(got["mean"], ref["mean"]) < 1e-8 and relerr(got["cov"], ref["cov"]) < 1e-8
+    if case == "two_streams":       # default weights = 1 / nbStream (reserveMem, TrainWorld.cpp:85)
+        dflt = h.train_world_streams(xs, [s[0] for s in segs], [s[1] for s in segs], w0, mean0, cov0, **kw)
+        assert np.array_equal(dflt["mean"], got["mean"]) and np.array_equal(dflt["llk"], got["llk"])
+        # one stream through the stream form == the single-stream entry point, bit for bit
+        a = h.train_world_streams(xs[:1], [segs[0][0]], [segs[0][1]], w0, mean0, cov0, **kw)
+        b = h.train_world(xs[0], segs[0][0], segs[0][1], w0, mean0, cov0, **kw)
+        assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["cov"], b["cov"]) and np.array_equal(a["llk"], b["llk"])
+
+
+def test_feature_selection_by_runs_matches_the_frame_list():
+    """gmmiv_gather_runs (run table: source frame, output row, length) against gmmiv_gather_frames (one index per frame) and numpy:
+    bagged 3..7-frame chunks, a long label segment cut into 64-frame pieces, f32 and f64, a row-strided source."""
+    import torch
+    from lia_ral_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(4)
+    for dt, D, ld in [(torch.float32, 60, 60), (torch.float64, 60, 60), (torch.float32, 19, 19), (torch.float32, 33, 40)]:
+        T = 5000
+        xfull = torch.randn(T, ld, dtype=dt, device="cuda")
+        x = xfull[:, :D]
+        begins = np.sort(rng.choice(np.arange(0, T - 8, 8), 300, replace=False)); lens = rng.integers(3, 8, 300)
+        runs = [(int(b), 0, int(l)) for b, l in zip(begins, lens)] + [(1000 + 64 * i, 0, 64) for i in range(20)] + [(4000, 0, 37)]
+        dst = 0; table = []
+        for b, _, l in runs:
+            table.append((b, dst, l)); dst += l
+        table = np.array(table, np.int64)
+        idx = np.concatenate([np.arange(b, b + l) for b, _, l in table])
+        out_r = torch.full((dst, D), -1.0, dtype=dt, device="cuda"); out_f = torch.empty_like(out_r); out_d = torch.empty_like(out_r)
+        ctx.gather_runs(x, table, out_r)
+        ctx.gather_frames(x, idx, out_f)
+        ctx.gather_runs(x, torch.from_numpy(table).cuda(), out_d)     # device table: enqueue only
+        ctx.sync()
+        ref = x.cpu().numpy()[idx]
+        assert np.array_equal(out_r.cpu().numpy(), ref) and np.array_equal(out_f.cpu().numpy(), ref) and np.array_equal(out_d.cpu().numpy(), ref)
+    ctx.close()
