@@ -160,6 +160,14 @@ int gmmiv_gather_frames(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t ldx,
 int gmmiv_gather_runs(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t ldx, int D,
                       const int64_t *runs, int64_t nrun, void *out);
 
+/* ---- segment means of per-frame values (ComputeTest's score per segment, ComputeTest.cpp:181-199) ------
+ * out[r * nseg + s] = mean of v[r * ld + t], t in [seg_begin[s], seg_begin[s+1])  (0 for an empty segment).
+ * v: DEVICE array of nrows rows (the world's and the clients' per-frame log-likelihoods as the llk_* entry points
+ * leave them); seg_begin: nseg + 1 HOST offsets; out: host or device.  The summation order is fixed by the
+ * segment bounds alone (pieces of 8192 frames, added in order). */
+int gmmiv_segment_means(gmmiv_ctx *ctx, const double *v, int64_t ld, int nrows, const int64_t *seg_begin,
+                        int64_t nseg, double *out);
+
 /* ---- MixtureStat::computeAndAccumulateLLK(f,1.0,TOP_DISTRIBS_NO_ACTION) loop -------------------
  * (LIA_SpkTools/src/AccumulateStat.cpp:69-94, :344-379; AccumulateTVStat.cpp:1644-1648)
  * llk_out[T] (nullable) = clamp(log sum_c w_c lk_c(x_t), min_llk, max_llk);
@@ -178,6 +186,21 @@ int gmmiv_llk_determine_top(gmmiv_ctx *ctx, const gmmiv_gmm *world, const void *
                             int64_t T, int64_t ldx, int ctop, int mode, double min_llk, double max_llk,
                             int32_t *idx, double *lk, double *nontop_lk, double *nontop_llk,
                             double *nontop_w, double *llk_out);
+
+/* ---- TopGauss::compute (LIA_SpkTools/src/TopGauss.cpp:136-198): the per-frame Gaussian selection that the factor-analysis
+ * tools store per feature file.  The sorted top list of every frame comes from DETERMINE_TOP_DISTRIBS with topDistribsCount =
+ * cap (1 <= cap <= min(64, C); the reference's "this should be high enough"), then
+ *   top_gauss >= 1 : count[t] = (int)top_gauss                                            (:170)
+ *   top_gauss <  1 : Gaussians are taken, heaviest first, until their cumulative likelihood exceeds top_gauss * exp(llk_t)
+ *                    (the test precedes each addition, :163-167) -- a VARIABLE count per frame, at most cap; *n_capped
+ *                    (HOST, nullable) = frames whose mass was not reached within cap entries;
+ *   snsw[t] = 1 - sum of the selected weights, snsl[t] = max(exp(llk_t) - sum of the selected likelihoods, EPS_LK = 1e-200).
+ * idx [T x cap]: the selected indices of frame t first, -1 behind them -- gmmiv_llk_use_top(ctop = cap, idx, log(snsl)) then
+ * evaluates exactly the stored selection (TopGauss::get, :275-316).  llk_out (nullable) = the clamped per-frame llk of the
+ * DETERMINE pass (its mean is what compute() returns).  All arrays host or device. */
+int gmmiv_topgauss_compute(gmmiv_ctx *ctx, const gmmiv_gmm *ubm, const void *x, int x_dtype, int64_t T, int64_t ldx,
+                           int cap, double top_gauss, int mode, double min_llk, double max_llk, int32_t *idx,
+                           int32_t *count, double *snsw, double *snsl, double *llk_out, int64_t *n_capped);
 
 /* ---- computeAndAccumulateLLK(f,1.0,USE_TOP_DISTRIBS) on a client model ------------------------
  * (ComputeTest.cpp:166-167; StatServer::setTopDistribIndexVector, TopGauss.cpp:297-308)

@@ -216,6 +216,15 @@ class Context:
         _chk(lib.gmmiv_gather_runs(self._h, _ptr(x), dt, ct.c_int64(ldx), x.shape[1], _ptr(r), ct.c_int64(r.shape[0]), _ptr(out)))
         return out
 
+    def segment_means(self, v, seg_begin, out=None):
+        """v: torch CUDA float64 [nrows, ld] (or 1-D); seg_begin: nseg + 1 host offsets -> out [nrows, nseg]."""
+        v2 = v if v.dim() == 2 else v.reshape(1, -1)
+        sb = np.ascontiguousarray(seg_begin, np.int64)
+        if out is None:
+            out = np.empty((v2.shape[0], len(sb) - 1))
+        _chk(lib.gmmiv_segment_means(self._h, _ptr(v2), ct.c_int64(v2.stride(0)), v2.shape[0], _ptr(sb), ct.c_int64(len(sb) - 1), _ptr(out)))
+        return out
+
     def variance_control(self, cov, flooring, ceiling, cov_signal, C, D, count=True):
         counts = np.zeros(2, np.int64) if count else None
         _chk(lib.gmmiv_variance_control(self._h, C, D, _ptr(cov), ct.c_double(flooring), ct.c_double(ceiling),

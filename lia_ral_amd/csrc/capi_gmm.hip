@@ -334,6 +334,45 @@ int gmmiv_gather_runs(gmmiv_ctx *c, const void *x, int dt, int64_t ldx, int D, c
     return GMMIV_OK;
 }
 
+int gmmiv_segment_means(gmmiv_ctx *c, const double *v, int64_t ld, int nrows, const int64_t *seg_begin, int64_t nseg, double *out)
+{
+    if (!c || !v || !seg_begin || !out || nrows < 0 || nseg < 0 || ld < 0) { gmmiv_set_error("segment_means: bad argument"); return GMMIV_ERR_ARG; }
+    if (!gmmiv_is_device_ptr(v)) { gmmiv_set_error("segment_means: v must be a device array"); return GMMIV_ERR_ARG; }
+    if (gmmiv_is_device_ptr(seg_begin)) { gmmiv_set_error("segment_means: seg_begin must be a host array"); return GMMIV_ERR_ARG; }
+    for (int64_t s = 0; s < nseg; ++s)
+        if (seg_begin[s] < 0 || seg_begin[s + 1] < seg_begin[s]) { gmmiv_set_error("segment_means: seg_begin must be non-negative and non-decreasing"); return GMMIV_ERR_ARG; }
+    if (nseg > 0 && nrows > 1 && seg_begin[nseg] > ld) { gmmiv_set_error("segment_means: the last segment ends after the row stride"); return GMMIV_ERR_ARG; }
+    const int64_t npair = (int64_t)nrows * nseg;
+    if (npair == 0) return GMMIV_OK;
+    GBIND(c);
+    const int64_t PIECE = 8192;
+    std::vector<long> tab; // items [3 x nitem] | pair_off [npair + 1] | pair_len [npair]
+    std::vector<long> off(npair + 1, 0), len(npair, 0);
+    for (int r = 0; r < nrows; ++r)
+        for (int64_t s = 0; s < nseg; ++s) {
+            const int64_t p = (int64_t)r * nseg + s;
+            len[p] = (long)(seg_begin[s + 1] - seg_begin[s]);
+            for (int64_t b = seg_begin[s]; b < seg_begin[s + 1]; b += PIECE) {
+                tab.push_back(r); tab.push_back((long)b); tab.push_back((long)(b + PIECE < seg_begin[s + 1] ? b + PIECE : seg_begin[s + 1]));
+            }
+            off[p + 1] = (long)(tab.size() / 3);
+        }
+    const size_t nitem = tab.size() / 3;
+    tab.insert(tab.end(), off.begin(), off.end());
+    tab.insert(tab.end(), len.begin(), len.end());
+    void *dtab, *part;
+    int rc;
+    if ((rc = c->scratch(WS_T8, tab.size() * sizeof(long), &dtab))) return rc;
+    if ((rc = c->scratch(WS_T9, (nitem ? nitem : 1) * sizeof(double), &part))) return rc;
+    DevOut<double> o;
+    if ((rc = o.init(c, WS_T7, out, (size_t)npair, false))) return rc;
+    GCHK(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
+    const long *di = (const long *)dtab;
+    GCHK(gmmk_segment_means(c->stream, v, (long)ld, di, (long)nitem, (double *)part, di + 3 * nitem, di + 3 * nitem + npair + 1, (long)npair, o.d));
+    GCHK(hipStreamSynchronize(c->stream)); // tab is a stack-lifetime vector
+    return o.finish();
+}
+
 // ---- LLK ---------------------------------------------------------------------------------
 static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, double **lse_out)
 {
@@ -584,6 +623,53 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     if ((rc = o_nllk.finish())) return rc;
     if ((rc = o_nw.finish())) return rc;
     return o_llk.finish();
+}
+
+int gmmiv_topgauss_compute(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, int cap, double top_gauss,
+                           int mode, double min_llk, double max_llk, int32_t *idx, int32_t *count, double *snsw, double *snsl,
+                           double *llk_out, int64_t *n_capped)
+{
+    int rc = check_model(c, g);
+    if (rc) return rc;
+    if (T < 0 || !idx || !count || !snsw || !snsl || cap <= 0 || !(top_gauss > 0.0)) { gmmiv_set_error("topgauss_compute: bad argument"); return GMMIV_ERR_ARG; }
+    if (n_capped && gmmiv_is_device_ptr(n_capped)) { gmmiv_set_error("topgauss_compute: n_capped must be a host variable"); return GMMIV_ERR_ARG; }
+    const int fixed = top_gauss >= 1.0 ? (int)top_gauss : 0; // _nbg[t] = (unsigned long)topD, TopGauss.cpp:170
+    if (fixed > cap) { gmmiv_set_error("topgauss_compute: topGauss %d exceeds the list length %d", fixed, cap); return GMMIV_ERR_ARG; }
+    if (n_capped) *n_capped = 0;
+    if (T == 0) return GMMIV_OK;
+    // the sorted top list of every frame (DETERMINE_TOP_DISTRIBS with topDistribsCount = cap), kept on the device
+    void *p;
+    const bool idx_dev = gmmiv_is_device_ptr(idx);
+    int32_t *d_idx = idx;
+    // (slots the DETERMINE pass does not touch: its redo path uses WS_T6 / WS_T7)
+    if (!idx_dev) { if ((rc = c->scratch(WS_LP, (size_t)T * cap * sizeof(int32_t), &p))) return rc; d_idx = (int32_t *)p; }
+    if ((rc = c->scratch(WS_AUX, (size_t)T * cap * sizeof(double), &p))) return rc;
+    double *d_lk = (double *)p;
+    const bool llk_dev = llk_out && gmmiv_is_device_ptr(llk_out);
+    double *d_llk = llk_out;
+    if (!llk_dev) { if ((rc = c->scratch(WS_SLAB, (size_t)T * sizeof(double), &p))) return rc; d_llk = (double *)p; }
+    if ((rc = gmmiv_llk_determine_top(c, g, x, dt, T, ldx, cap, mode, min_llk, max_llk, d_idx, d_lk, nullptr, nullptr, nullptr, d_llk))) return rc;
+    DevOut<int32_t> o_cnt;
+    DevOut<double> o_w, o_l;
+    if ((rc = o_cnt.init(c, WS_T0, count, (size_t)T, false))) return rc;
+    if ((rc = o_w.init(c, WS_T1, snsw, (size_t)T, false))) return rc;
+    if ((rc = o_l.init(c, WS_T2, snsl, (size_t)T, false))) return rc;
+    if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &p))) return rc;
+    unsigned long long *d_cap = (unsigned long long *)p;
+    GCHK(hipMemsetAsync(d_cap, 0, sizeof(unsigned long long), c->stream));
+    GCHK(gmmk_topgauss_select(c->stream, T, cap, top_gauss, fixed, g->w, d_idx, d_lk, d_llk, o_cnt.d, o_w.d, o_l.d, d_cap));
+    if (!idx_dev) GCHK(hipMemcpyAsync(idx, d_idx, (size_t)T * cap * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (llk_out && !llk_dev) GCHK(hipMemcpyAsync(llk_out, d_llk, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (n_capped) {
+        unsigned long long h = 0;
+        GCHK(hipMemcpyAsync(&h, d_cap, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        *n_capped = (int64_t)h;
+    } else if (!idx_dev || (llk_out && !llk_dev))
+        GCHK(hipStreamSynchronize(c->stream));
+    if ((rc = o_cnt.finish())) return rc;
+    if ((rc = o_w.finish())) return rc;
+    return o_l.finish();
 }
 
 int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T, int64_t ldx, int ctop,

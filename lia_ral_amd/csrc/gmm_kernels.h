@@ -35,6 +35,10 @@ int gmmk_variance_control(hipStream_t st, int C, int D, double *cov, double floo
                           const double *cov_signal, unsigned long long *counts);
 int gmmk_reciprocal(hipStream_t st, long n, const double *in, double *out);
 int gmmk_gather_frames(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *idx, long n, void *out);
+int gmmk_segment_means(hipStream_t st, const double *v, long ld, const long *item, long nitem, double *part, const long *pair_off,
+                       const long *pair_len, long npair, double *out);
+int gmmk_topgauss_select(hipStream_t st, long T, int cap, double mass, int fixed_count, const double *w, int *idx, const double *lk,
+                         const double *llk, int *count, double *snsw, double *snsl, unsigned long long *capped);
 int gmmk_gather_runs(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *runs, long nrun, void *out);
 // em_fused.hip: single-pass EM statistics by teams of cooperating workgroups
 size_t gmmk_em_fused_slot_words(int nteams, int ngrp);

@@ -1214,6 +1214,81 @@ int gmmk_rows_sum_groups(hipStream_t st, long n, int ngroups, const int *rb, con
     return (int)hipGetLastError();
 }
 
+// Segment sums of per-frame values (ComputeTest's mean log-likelihood per segment, ComputeTest.cpp:181-199): work item i covers
+// elements [item[3 i + 1], item[3 i + 2]) of row item[3 i] -- at most 8192 of them -- and leaves its sum in part[i]; a pair (row,
+// segment) owns the items [pair_off[p], pair_off[p + 1]) and adds them up in item order: the result does not depend on the launch.
+__global__ __launch_bounds__(256) void k_segment_partials(const double *__restrict__ v, long ld, const long *__restrict__ item,
+                                                          double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const long i = blockIdx.x;
+    const double *row = v + item[3 * i] * ld;
+    double s = 0.0;
+    for (long t = item[3 * i + 1] + threadIdx.x; t < item[3 * i + 2]; t += 256) s += row[t];
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[i] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_segment_finish(const double *__restrict__ part, const long *__restrict__ pair_off, const long *__restrict__ pair_len, long npair,
+                                 double *__restrict__ out)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npair) return;
+    double s = 0.0;
+    for (long i = pair_off[p]; i < pair_off[p + 1]; ++i) s += part[i];
+    out[p] = pair_len[p] > 0 ? s / (double)pair_len[p] : 0.0;
+}
+int gmmk_segment_means(hipStream_t st, const double *v, long ld, const long *item, long nitem, double *part, const long *pair_off,
+                       const long *pair_len, long npair, double *out)
+{
+    if (npair <= 0) return 0;
+    if (nitem > 0) k_segment_partials<<<(unsigned)nitem, 256, 0, st>>>(v, ld, item, part);
+    k_segment_finish<<<(unsigned)((npair + 127) / 128), 128, 0, st>>>(part, pair_off, pair_len, npair, out);
+    return (int)hipGetLastError();
+}
+
+// TopGauss::compute, selection by likelihood mass (topGauss < 1, TopGauss.cpp:162-192): per frame, Gaussians of the sorted top
+// list are taken until their cumulative likelihood passes mass * exp(llk) (test BEFORE each addition, like the reference's loop);
+// a fixed count (topGauss >= 1) when mass_count > 0.  snsw = 1 - sum of the selected weights, snsl = exp(llk) - sum of the
+// selected likelihoods floored at EPS_LK, both subtracted in list order.  Entries of idx past the count become -1 (never
+// dereferenced by the USE kernels).  capped += frames whose mass was not reached inside the list.
+__global__ __launch_bounds__(256) void k_topgauss_select(long T, int cap, double mass, int fixed_count, const double *__restrict__ w,
+                                                         int *__restrict__ idx, const double *__restrict__ lk, const double *__restrict__ llk,
+                                                         int *__restrict__ count, double *__restrict__ snsw, double *__restrict__ snsl,
+                                                         unsigned long long *__restrict__ capped)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const double lk_tot = exp(llk[t]);
+    int *ix = idx + t * cap;
+    const double *lv = lk + t * cap;
+    int n = 0;
+    if (fixed_count > 0) n = fixed_count;
+    else {
+        double val = 0.0;
+        for (int j = 0; j < cap; ++j) {
+            if (val > mass * lk_tot) break;
+            val += lv[j];
+            ++n;
+        }
+        if (n == cap && !(val > mass * lk_tot)) atomicAdd(capped, 1ULL);
+    }
+    double sw = 1.0, sl = lk_tot;
+    for (int j = 0; j < n; ++j) { sw -= w[ix[j]]; sl -= lv[j]; }
+    for (int j = n; j < cap; ++j) ix[j] = -1;
+    count[t] = n;
+    snsw[t] = sw;
+    snsl[t] = sl < 1e-200 ? 1e-200 : sl; // EPS_LK, TopGauss.cpp:67,190
+}
+int gmmk_topgauss_select(hipStream_t st, long T, int cap, double mass, int fixed_count, const double *w, int *idx, const double *lk,
+                         const double *llk, int *count, double *snsw, double *snsl, unsigned long long *capped)
+{
+    if (T <= 0) return 0;
+    k_topgauss_select<<<(unsigned)((T + 255) / 256), 256, 0, st>>>(T, cap, mass, fixed_count, w, idx, lk, llk, count, snsw, snsl, capped);
+    return (int)hipGetLastError();
+}
+
 int gmmk_add_scalar(hipStream_t st, double *dst, double v)
 {
     k_add_scalar<<<1, 1, 0, st>>>(dst, v);

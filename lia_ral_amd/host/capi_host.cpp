@@ -283,6 +283,46 @@ int liagpu_train_target(int device, const float *x, long T, int D, const long *s
     })
 }
 
+// TopGauss (TopGauss.cpp): compute on the selected frames, write the nbGaussian file, read it back into a fresh object, get() on
+// it with `ubm` and (when given) a second model.  out[0] = compute's mean llk, out[1] = get(ubm), out[2] = get(model2),
+// out[3] = frames capped; counts_out[T] / snsw_out[T] / snsl_out[T] (nullable) = what was stored; *nbgcnt_out = total entries.
+int liagpu_topgauss(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg, int C,
+                    const double *w, const double *mean, const double *cov, const double *mean2, double topGauss, int topDistribsCount,
+                    int complete, double minLLK, double maxLLK, const char *path, double *out, long *counts_out, long *idx_out,
+                    double *snsw_out, double *snsl_out, long *nbgcnt_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        DeviceMixture dubm(srv, ubm);
+        TopGauss tg;
+        out[0] = tg.compute(dubm, fs, segs, topGauss, topDistribsCount, complete != 0, minLLK, maxLLK);
+        out[3] = (double)tg.nbCapped();
+        tg.write(path);
+        TopGauss back;
+        back.read(path);
+        if (back.nt() != tg.nt() || back.nbgcnt() != tg.nbgcnt() || back.nbg() != tg.nbg() || back.idx() != tg.idx() || back.snsw() != tg.snsw() ||
+            back.snsl() != tg.snsl())
+            throw Exception("TopGauss: the file does not read back as written");
+        out[1] = back.get(dubm, fs, segs, complete != 0, minLLK, maxLLK);
+        out[2] = 0.0;
+        if (mean2) {
+            MixtureGD m2 = make_mixture(C, D, w, mean2, cov);
+            DeviceMixture d2(srv, m2);
+            out[2] = back.get(d2, fs, segs, complete != 0, minLLK, maxLLK);
+        }
+        if (nbgcnt_out) *nbgcnt_out = (long)back.nbgcnt();
+        for (unsigned long t = 0; t < back.nt(); ++t) {
+            if (counts_out) counts_out[t] = (long)back.nbg()[t];
+            if (snsw_out) snsw_out[t] = back.snsw()[t];
+            if (snsl_out) snsl_out[t] = back.snsl()[t];
+        }
+        if (idx_out) for (unsigned long i = 0; i < back.nbgcnt(); ++i) idx_out[i] = (long)back.idx()[i];
+    })
+}
+
 // ComputeTest for one test file: world + nClients models (same C, D), covariances given as covInv
 int liagpu_compute_test(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg,
                         int C, const double *w_world, const double *mean_world, const double *cov_world, int nClients,

@@ -819,6 +819,112 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, const std::vector<Trai
     return llkIt;
 }
 
+// ---- TopGauss ---------------------------------------------------------------------------------------
+double TopGauss::compute(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &selectedSegments, double topGauss, int topDistribsCount,
+                         bool complete, double minLLK, double maxLLK)
+{
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    const int cap = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), ubm.getDistribCount());
+    std::vector<int32_t> idx((size_t)n * cap), cnt(n);
+    std::vector<double> llk(n);
+    _nt = n;
+    _snsw.assign(n, 0.0); _snsl.assign(n, 0.0);
+    int64_t capped = 0;
+    srv.check(gmmiv_topgauss_compute(srv.ctx(), ubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), cap, topGauss,
+                                     complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL, minLLK, maxLLK, idx.data(), cnt.data(), _snsw.data(),
+                                     _snsl.data(), llk.data(), &capped));
+    _capped = (unsigned long)capped;
+    _nbg.assign(n, 0);
+    _nbgcnt = 0;
+    for (unsigned long t = 0; t < n; ++t) { _nbg[t] = (unsigned long)cnt[t]; _nbgcnt += _nbg[t]; }
+    _idx.clear(); _idx.reserve(_nbgcnt);
+    for (unsigned long t = 0; t < n; ++t)
+        for (int j = 0; j < cnt[t]; ++j) _idx.push_back((unsigned long)idx[(size_t)t * cap + j]);
+    double s = 0.0;
+    for (unsigned long t = 0; t < n; ++t) s += llk[t];
+    return n ? s / (double)n : 0.0;
+}
+
+double TopGauss::get(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &selectedSegments, bool complete, double minLLK, double maxLLK) const
+{
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    if (n != _nt) throw Exception("TopGauss::get: the selection holds another number of frames than the stored one");
+    GpuServer &srv = fs.server();
+    unsigned long cap = 1;
+    for (unsigned long t = 0; t < n; ++t) cap = std::max(cap, _nbg[t]);
+    if (cap > 64) throw Exception("TopGauss::get: more than 64 Gaussians stored for a frame");
+    std::vector<int32_t> idx((size_t)n * cap, -1); // -1: no entry (never dereferenced by the USE kernel)
+    std::vector<double> nllk(n), llk(n);
+    unsigned long b = 0;
+    for (unsigned long t = 0; t < n; ++t) {
+        for (unsigned long j = 0; j < _nbg[t]; ++j) {
+            if (_idx[b + j] >= ubm.getDistribCount()) throw Exception("TopGauss::get: stored Gaussian index out of range");
+            idx[(size_t)t * cap + j] = (int32_t)_idx[b + j];
+        }
+        b += _nbg[t];
+        nllk[t] = log(_snsl[t]);
+    }
+    if (b != _nbgcnt) throw Exception("TopGauss::get: idxBegin != _nbgcnt");
+    if (n == 0) return 0.0;
+    srv.check(gmmiv_llk_use_top(srv.ctx(), ubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), (int)cap, idx.data(), nllk.data(),
+                                complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL, minLLK, maxLLK, llk.data()));
+    double s = 0.0;
+    for (unsigned long t = 0; t < n; ++t) s += llk[t];
+    return s / (double)n;
+}
+
+unsigned long TopGauss::frameToIdx(unsigned long f) const
+{
+    unsigned long cnt = 0;
+    for (unsigned long t = 0; t < f && t < _nbg.size(); ++t) cnt += _nbg[t];
+    return cnt;
+}
+
+void TopGauss::write(const std::string &path) const
+{
+    static_assert(sizeof(unsigned long) == 8, "the reference writes sizeof(unsigned long) bytes per count / index (LP64)");
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) throw Exception("Cannot find nbGaussian file"); // TopGauss.cpp:204
+    bool ok = fwrite(&_nt, sizeof(unsigned long), 1, f) == 1 && fwrite(&_nbgcnt, sizeof(unsigned long), 1, f) == 1;
+    ok = ok && fwrite(_nbg.data(), sizeof(unsigned long), _nbg.size(), f) == _nbg.size();
+    ok = ok && fwrite(_idx.data(), sizeof(unsigned long), _idx.size(), f) == _idx.size();
+    ok = ok && fwrite(_snsw.data(), sizeof(double), _snsw.size(), f) == _snsw.size();
+    ok = ok && fwrite(_snsl.data(), sizeof(double), _snsl.size(), f) == _snsl.size();
+    fclose(f);
+    if (!ok) throw Exception("TopGauss::write: short write on " + path);
+}
+
+void TopGauss::read(const std::string &path)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw Exception("Cannot find nbGaussian file"); // TopGauss.cpp:81
+    unsigned long nt = 0, cnt = 0;
+    bool ok = fread(&nt, sizeof(unsigned long), 1, f) == 1 && fread(&cnt, sizeof(unsigned long), 1, f) == 1;
+    if (ok) {
+        // the sizes come from the file: check them against its length before allocating
+        long here = ftell(f);
+        fseek(f, 0, SEEK_END);
+        const long end = ftell(f);
+        fseek(f, here, SEEK_SET);
+        const unsigned long avail = (unsigned long)(end - here) / 8;
+        ok = nt <= avail && cnt <= avail && 3 * nt + cnt == avail;
+    }
+    if (ok) {
+        _nbg.assign(nt, 0); _idx.assign(cnt, 0); _snsw.assign(nt, 0.0); _snsl.assign(nt, 0.0);
+        ok = fread(_nbg.data(), sizeof(unsigned long), nt, f) == nt && fread(_idx.data(), sizeof(unsigned long), cnt, f) == cnt &&
+             fread(_snsw.data(), sizeof(double), nt, f) == nt && fread(_snsl.data(), sizeof(double), nt, f) == nt;
+    }
+    fclose(f);
+    if (!ok) throw Exception("TopGauss::read: " + path + " is not a complete nbGaussian file");
+    _nt = nt; _nbgcnt = cnt; _capped = 0;
+    unsigned long s = 0;
+    for (unsigned long v : _nbg) s += v;
+    if (s != _nbgcnt) throw Exception("TopGauss::read: " + path + ": the per-frame counts do not add up to the stored total");
+}
+
 // ---- TrainTarget -------------------------------------------------------------------------------------
 void computeMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount)
 {
@@ -890,31 +996,32 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     DevBuf dIdx((size_t)n * topDistribsCount * sizeof(int32_t)), dNllk((size_t)n * sizeof(double));
     int32_t *idx = (int32_t *)dIdx.p;
     double *nllk = (double *)dNllk.p;
-    std::vector<double> llkw(n), llkc(n * clients.size());
+    // the per-frame log-likelihoods stay on the device as well: row 0 = world, rows 1.. = clients; only the segment means -- the
+    // scores ComputeTest prints -- cross PCIe (8 bytes per frame and model did before: 40 MB for 10^6 frames and 4 clients)
+    const size_t nRows = 1 + clients.size();
+    DevBuf dLlk((size_t)n * nRows * sizeof(double));
+    double *llkw = (double *)dLlk.p, *llkc = llkw + n;
     // world: DETERMINE_TOP_DISTRIBS on every frame (worldDecime = 1)
     srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount, mode,
-                                      minLLK, maxLLK, idx, nullptr, nullptr, nllk, nullptr, llkw.data()));
-    const size_t nseg = segmentalMode ? selectedSegments.size() : 1;
-    std::vector<double> out(nseg * clients.size(), 0.0);
-    auto meanOver = [&](const std::vector<double> &v, size_t b, size_t e) {
-        double s = 0.0;
-        for (size_t i = b; i < e; ++i) s += v[i];
-        return e > b ? s / (double)(e - b) : 0.0;
-    };
+                                      minLLK, maxLLK, idx, nullptr, nullptr, nllk, nullptr, llkw));
     // clients: USE_TOP_DISTRIBS with the world's indices (+ the world's non-top remainder if COMPLETE), all models of the line in ONE call
     // (a launch, a copy back and a synchronisation per client cost more than the kernel on segments of a few thousand frames)
     std::vector<const gmmiv_gmm *> handles(clients.size());
     for (size_t ci = 0; ci < clients.size(); ++ci) handles[ci] = clients[ci]->handle();
-    srv.check(gmmiv_llk_use_top_multi(srv.ctx(), (int)handles.size(), handles.data(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(),
-                                      topDistribsCount, idx, nllk, mode, minLLK, maxLLK, llkc.data()));
-    for (size_t ci = 0; ci < clients.size(); ++ci) {
-        size_t off = 0;
-        for (size_t s = 0; s < nseg; ++s) {
-            const size_t len = segmentalMode ? selectedSegments[s].length : n;
-            out[s * clients.size() + ci] = meanOver(llkc, ci * n + off, ci * n + off + len) - meanOver(llkw, off, off + len);
-            off += len;
-        }
-    }
+    if (!clients.empty())
+        srv.check(gmmiv_llk_use_top_multi(srv.ctx(), (int)handles.size(), handles.data(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(),
+                                          topDistribsCount, idx, nllk, mode, minLLK, maxLLK, llkc));
+    const size_t nseg = segmentalMode ? selectedSegments.size() : 1;
+    std::vector<int64_t> segBegin(nseg + 1, 0);
+    if (segmentalMode)
+        for (size_t s = 0; s < nseg; ++s) segBegin[s + 1] = segBegin[s] + (int64_t)selectedSegments[s].length;
+    else
+        segBegin[1] = (int64_t)n;
+    std::vector<double> means(nRows * nseg, 0.0); // [row][segment]
+    srv.check(gmmiv_segment_means(srv.ctx(), llkw, (int64_t)n, (int)nRows, segBegin.data(), (int64_t)nseg, means.data()));
+    std::vector<double> out(nseg * clients.size(), 0.0);
+    for (size_t ci = 0; ci < clients.size(); ++ci)
+        for (size_t s = 0; s < nseg; ++s) out[s * clients.size() + ci] = means[(1 + ci) * nseg + s] - means[s];
     return out;
 }
 

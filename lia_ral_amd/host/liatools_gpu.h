@@ -319,6 +319,37 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
                                    double minLLK, double maxLLK, bool segmentalMode, unsigned long worldDecime,
                                    unsigned long windowSize, unsigned long windowDec, std::vector<WindowOut> *windows);
 
+// ---- TopGauss.h (LIA_SpkTools/src/TopGauss.cpp) -----------------------------------------------------
+// The per-frame Gaussian selection the factor-analysis tools compute once per feature file and cache on disk.
+class TopGauss {
+  public:
+    // compute (:136-198): DETERMINE_TOP_DISTRIBS on every selected frame with a list of topDistribsCount entries (<= 64), then
+    // topGauss >= 1: the (unsigned long)topGauss heaviest Gaussians of every frame; topGauss < 1: Gaussians until their cumulative
+    // likelihood passes topGauss * exp(llk) -- a variable count per frame.  Returns getMeanLLK() of the DETERMINE pass.
+    double compute(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &selectedSegments, double topGauss, int topDistribsCount,
+                   bool complete, double minLLK, double maxLLK);
+    // get (:275-316): mean llk of `ubm` (any model with the UBM's component order) on the stored selection (USE_TOP_DISTRIBS with
+    // setTopDistribIndexVector(index, snsw, snsl) per frame)
+    double get(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &selectedSegments, bool complete, double minLLK, double maxLLK) const;
+    // write / read (:200-224 / :76-98), the reference's binary layout on LP64: _nt, _nbgcnt (unsigned long, 8 bytes, native order),
+    // _nbg[_nt] (unsigned long), _idx[_nbgcnt] (unsigned long), _snsw[_nt], _snsl[_nt] (double)
+    void write(const std::string &path) const;
+    void read(const std::string &path);
+    unsigned long frameToIdx(unsigned long f) const; // :68-74
+    unsigned long nt() const { return _nt; }
+    unsigned long nbgcnt() const { return _nbgcnt; }
+    unsigned long nbCapped() const { return _capped; } // frames whose likelihood mass was not reached within topDistribsCount entries
+    const std::vector<unsigned long> &nbg() const { return _nbg; }
+    const std::vector<unsigned long> &idx() const { return _idx; }
+    const std::vector<double> &snsw() const { return _snsw; }
+    const std::vector<double> &snsl() const { return _snsl; }
+
+  private:
+    unsigned long _nt = 0, _nbgcnt = 0, _capped = 0;
+    std::vector<unsigned long> _nbg, _idx;
+    std::vector<double> _snsw, _snsl;
+};
+
 // ---- AccumulateTVStat.h ----------------------------------------------------------------------------
 class TVAcc {
   public:

@@ -164,6 +164,25 @@ def train_target(x, seg_begin, seg_len, world, nb_it=1, mean_reg=16.0, device=0)
     return wo, mo, co
 
 
+def topgauss(x, seg_begin, seg_len, ubm, top_gauss, path, top_distribs_count=64, model2_mean=None, complete=True, min_llk=-200.0,
+             max_llk=200.0, device=0):
+    """TopGauss::compute -> write(path) -> read(path) -> get (liagpu_topgauss).  Returns dict(llk_compute, llk_get, llk_get_model2,
+    capped, nbg [T], idx (flat), snsw, snsl)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C = len(w)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    n = int(l.sum())
+    cap = min(top_distribs_count, C)
+    out = np.zeros(4); cnt = np.zeros(n, np.int64); idx = np.zeros(n * cap, np.int64); sw = np.zeros(n); sl = np.zeros(n); tot = ct.c_long(0)
+    m2 = None if model2_mean is None else np.ascontiguousarray(model2_mean, np.float64)
+    _chk(lib.liagpu_topgauss(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(w), _d(mean), _d(cov), _d(m2),
+                             ct.c_double(top_gauss), int(top_distribs_count), int(complete), ct.c_double(min_llk), ct.c_double(max_llk),
+                             path.encode(), _d(out), cnt.ctypes.data_as(_lp), idx.ctypes.data_as(_lp), _d(sw), _d(sl), ct.byref(tot)))
+    return dict(llk_compute=out[0], llk_get=out[1], llk_get_model2=out[2], capped=int(out[3]), nbg=cnt, idx=idx[:tot.value].copy(), snsw=sw, snsl=sl)
+
+
 def compute_test(x, seg_begin, seg_len, world, clients, top_c=10, complete=True, min_llk=-200.0, max_llk=200.0,
                  segmental=False, device=0, reps=0):
     """world = (w, mean, cov); clients = list of (w, mean, cov).  Returns LLR[n_seg_or_1, n_clients]; with reps > 0 the LLR loop

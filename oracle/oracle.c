@@ -145,6 +145,66 @@ void orc_llk_use_top(int C, int D, const double *w, const double *mean, const do
     free(cst); free(det);
 }
 
+/* TopGauss::compute (LIA_SpkTools/src/TopGauss.cpp:136-198) on the frames x[T]: per frame the DETERMINE_TOP_DISTRIBS list of
+ * length cap ("topDistribsCount ... should be high enough"), lk_tot = exp(llk) (:160), then
+ *   topD < 1: `if (val > topD*lk_tot) break; val += topV[j].lk; _nbg[t]++` over the sorted list (:163-167; bounded by the list
+ *             length here, by the mixture size in the reference);  topD >= 1: _nbg[t] = (unsigned long)topD (:170);
+ *   snsw = 1 - sum UBM.weight(idx), snsl = lk_tot - sum lk, floored at EPS_LK (:183-192).
+ * Outputs: nbg[T], idx_flat (sum nbg entries, frame after frame: _idx), snsw[T], snsl[T], llk[T]; returns _nbgcnt. */
+long orc_topgauss_compute(int C, int D, const double *w, const double *mean, const double *covinv, const double *x, long T,
+                          int cap, double topD, int complete, double min_llk, double max_llk,
+                          long *nbg, long *idx_flat, double *snsw, double *snsl, double *llk)
+{
+    long *tidx = malloc(sizeof(long) * (size_t)T * cap);
+    double *tlk = malloc(sizeof(double) * (size_t)T * cap), *nl = malloc(sizeof(double) * T), *nw = malloc(sizeof(double) * T);
+    orc_llk_determine_top(C, D, w, mean, covinv, x, T, cap, complete, min_llk, max_llk, tidx, tlk, nl, nw, llk);
+    long cnt = 0;
+    for (long t = 0; t < T; ++t) {
+        const double lk_tot = exp(llk[t]);
+        double val = 0.0;
+        nbg[t] = 0;
+        if (topD < 1.0) {
+            for (int j = 0; j < cap; ++j) {
+                if (val > topD * lk_tot) break;
+                val += tlk[t * cap + j];
+                nbg[t]++;
+            }
+        } else nbg[t] = (long)topD;
+        double sw = 1.0, sl = lk_tot;
+        for (long j = 0; j < nbg[t]; ++j) {
+            idx_flat[cnt + j] = tidx[t * cap + j];
+            sw -= w[tidx[t * cap + j]];
+            sl -= tlk[t * cap + j];
+        }
+        cnt += nbg[t];
+        snsw[t] = sw;
+        snsl[t] = sl < ORC_EPS_LK ? ORC_EPS_LK : sl;
+    }
+    free(tidx); free(tlk); free(nl); free(nw);
+    return cnt;
+}
+
+/* TopGauss::get (TopGauss.cpp:275-316): per frame setTopDistribIndexVector(index, snsw, snsl) + computeAndAccumulateLLK(f, 1.0,
+ * USE_TOP_DISTRIBS) on the stored, variable-length selection; llk[T] out (its mean is what get() returns). */
+void orc_topgauss_get(int C, int D, const double *w, const double *mean, const double *covinv, const double *x, long T,
+                      const long *nbg, const long *idx_flat, const double *snsl, int complete, double min_llk, double max_llk, double *llk)
+{
+    double *cst = malloc(sizeof(double) * C), *det = malloc(sizeof(double) * C);
+    orc_gmm_cst(C, D, covinv, cst, det);
+    long b = 0;
+    for (long t = 0; t < T; ++t) {
+        double s = 0.0;
+        for (long j = 0; j < nbg[t]; ++j) {
+            const long c = idx_flat[b + j];
+            s += w[c] * distrib_lk(D, x + t * D, mean + (size_t)c * D, covinv + (size_t)c * D, cst[c]);
+        }
+        if (complete) s += snsl[t];
+        llk[t] = clamp_llk(s, min_llk, max_llk);
+        b += nbg[t];
+    }
+    free(cst); free(det);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Rows 4-6: EM accumulators, occupation vector, FrameAccGD
  * ------------------------------------------------------------------------------------------- */

@@ -89,6 +89,31 @@ def llk_use_top(g, x, idx, nontop_lk, complete=True, min_llk=-200.0, max_llk=200
     return out
 
 
+def topgauss_compute(g, x, cap, top_gauss, complete=True, min_llk=-200.0, max_llk=200.0):
+    """TopGauss::compute (TopGauss.cpp:136-198) -> dict(nbg [T], idx (flat, frame after frame), snsw, snsl, llk)."""
+    x, xp = _d(x)
+    T = x.shape[0]
+    nbg = np.zeros(T, np.int64); idx = np.zeros(T * cap, np.int64)
+    snsw = np.empty(T); snsl = np.empty(T); llk_ = np.empty(T)
+    f = _lib().orc_topgauss_compute
+    f.restype = ct.c_long
+    n = f(*g.args(), xp, ct.c_long(T), ct.c_int(cap), ct.c_double(top_gauss), ct.c_int(int(complete)), ct.c_double(min_llk),
+          ct.c_double(max_llk), nbg.ctypes.data_as(c_lp), idx.ctypes.data_as(c_lp), snsw.ctypes.data_as(c_dp),
+          snsl.ctypes.data_as(c_dp), llk_.ctypes.data_as(c_dp))
+    return dict(nbg=nbg, idx=idx[:n].copy(), snsw=snsw, snsl=snsl, llk=llk_)
+
+
+def topgauss_get(g, x, nbg, idx, snsl, complete=True, min_llk=-200.0, max_llk=200.0):
+    """TopGauss::get (TopGauss.cpp:275-316): per-frame llk on the stored selection."""
+    x, xp = _d(x)
+    T = x.shape[0]
+    nbg, np_ = _l(nbg); idx, ip = _l(idx); snsl, sp = _d(snsl)
+    out = np.empty(T)
+    _lib().orc_topgauss_get(*g.args(), xp, ct.c_long(T), np_, ip, sp, ct.c_int(int(complete)), ct.c_double(min_llk), ct.c_double(max_llk),
+                            out.ctypes.data_as(c_dp))
+    return out
+
+
 def occ(g, x):
     x, xp = _d(x)
     T = x.shape[0]

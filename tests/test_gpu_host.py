@@ -894,3 +894,75 @@ def test_feature_selection_by_runs_matches_the_frame_list():
         ref = x.cpu().numpy()[idx]
         assert np.array_equal(out_r.cpu().numpy(), ref) and np.array_equal(out_f.cpu().numpy(), ref) and np.array_equal(out_d.cpu().numpy(), ref)
     ctx.close()
+
+
+@pytest.mark.parametrize("top_gauss", [0.9, 0.999, 5.0])
+def test_topgauss_mass_threshold_cache_file_and_get(top_gauss, tmp_path):
+    """TopGauss (LIA_SpkTools/src/TopGauss.cpp): compute with topGauss < 1 -- Gaussians until the cumulative likelihood passes
+    topGauss * exp(llk): a VARIABLE count per frame (:162-167) -- and with a fixed count (:170); sumNonSelectedWeights / LLK with
+    the EPS_LK floor (:183-192); the nbGaussian cache file in the reference's binary layout (:200-224), read back (:76-98) and
+    parsed here independently; get() on the stored selection for the UBM and for a mean-adapted model (:275-316).  Against the
+    oracle restatement: counts and indices exact."""
+    from lia_ral_amd import host_capi as h
+    C, D, T = 128, 20, 3000
+    w, mean, iv = make_gmm(C, D, seed=21, spread=0.7)          # overlapping Gaussians: several carry mass per frame
+    x = make_frames(w, mean, iv, T, seed=22)
+    seg_begin, seg_len = np.array([10, 1500]), np.array([1200, 1400])
+    sel = np.concatenate([np.arange(b, b + n) for b, n in zip(seg_begin, seg_len)])
+    rng = np.random.default_rng(3)
+    mean2 = mean + rng.normal(0, 0.1, mean.shape)
+    path = str(tmp_path / "utt.nbg")
+    cap = 64
+    got = h.topgauss(x, seg_begin, seg_len, (w, mean, 1.0 / iv), top_gauss, path, top_distribs_count=cap, model2_mean=mean2)
+    og = orc.Gmm(w, mean, iv)
+    xs = x[sel].astype(np.float64)
+    ref = orc.topgauss_compute(og, xs, cap, top_gauss)
+    assert np.array_equal(got["nbg"], ref["nbg"]) and np.array_equal(got["idx"], ref["idx"])
+    if top_gauss < 1:
+        assert got["nbg"].min() >= 1 and len(np.unique(got["nbg"])) > 3         # the count really varies
+        assert got["capped"] <= int(np.sum(ref["nbg"] == cap))                   # capped frames have cap entries
+    else:
+        assert np.all(got["nbg"] == int(top_gauss))
+    assert np.max(np.abs(got["snsw"] - ref["snsw"])) < 1e-12
+    assert np.max(np.abs(got["snsl"] - ref["snsl"]) / np.maximum(np.exp(ref["llk"]), 1e-300)) < 1e-9   # relative to the frame likelihood
+    assert abs(got["llk_compute"] - ref["llk"].mean()) < 1e-9
+    llk_o = orc.topgauss_get(og, xs, ref["nbg"], ref["idx"], ref["snsl"])
+    assert abs(got["llk_get"] - llk_o.mean()) < 1e-9
+    llk_o2 = orc.topgauss_get(orc.Gmm(w, mean2, iv), xs, ref["nbg"], ref["idx"], ref["snsl"])
+    assert abs(got["llk_get_model2"] - llk_o2.mean()) < 1e-9
+    # COMPLETE mode on the UBM itself: selection + remainder = the full likelihood
+    assert abs(got["llk_get"] - got["llk_compute"]) < 1e-9
+    # the file, parsed without the library: _nt, _nbgcnt, _nbg, _idx (8-byte unsigned), _snsw, _snsl (double)
+    raw = open(path, "rb").read()
+    nt, cnt = np.frombuffer(raw, np.uint64, 2)
+    assert nt == len(sel) and cnt == got["nbg"].sum() and len(raw) == 8 * (2 + 3 * int(nt) + int(cnt))
+    nbg_f = np.frombuffer(raw, np.uint64, int(nt), 16)
+    idx_f = np.frombuffer(raw, np.uint64, int(cnt), 16 + 8 * int(nt))
+    snsw_f = np.frombuffer(raw, np.float64, int(nt), 16 + 8 * int(nt + cnt))
+    snsl_f = np.frombuffer(raw, np.float64, int(nt), 16 + 8 * int(2 * nt + cnt))
+    assert np.array_equal(nbg_f.astype(np.int64), got["nbg"]) and np.array_equal(idx_f.astype(np.int64), got["idx"])
+    assert np.array_equal(snsw_f, got["snsw"]) and np.array_equal(snsl_f, got["snsl"])
+    # an unwritable path is reported like the reference does (TopGauss.cpp:204)
+    with pytest.raises(h.HostError, match="Cannot find nbGaussian file"):
+        h.topgauss(x, seg_begin, seg_len, (w, mean, 1.0 / iv), top_gauss, str(tmp_path / "no" / "dir.nbg"))
+
+
+def test_segment_means_on_the_device():
+    """gmmiv_segment_means: per-segment means of rows of per-frame values (what ComputeTest prints per segment), ragged and empty
+    segments, a segment longer than one 8192-frame piece; against numpy."""
+    import torch
+    from lia_ral_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(6)
+    n = 40000
+    v = rng.normal(-90, 5, (5, n))
+    vd = torch.from_numpy(v).cuda()
+    sb = np.array([0, 1, 1, 700, 9000, 9000, 30000, n])
+    got = ctx.segment_means(vd, sb)
+    ref = np.array([[v[r, sb[s]:sb[s + 1]].mean() if sb[s + 1] > sb[s] else 0.0 for s in range(len(sb) - 1)] for r in range(5)])
+    assert np.max(np.abs(got - ref)) < 1e-11
+    one = ctx.segment_means(vd[2], np.array([0, n]))
+    assert abs(one[0, 0] - v[2].mean()) < 1e-11
+    again = ctx.segment_means(vd, sb)
+    assert np.array_equal(got, again)           # fixed summation order
+    ctx.close()
