@@ -139,6 +139,37 @@ int gmmiv_gmm_set(gmmiv_gmm *g, const double *w, const double *mean, const doubl
 int gmmiv_gmm_set_cov(gmmiv_gmm *g, const double *w, const double *mean, const double *cov);
 void gmmiv_gmm_destroy(gmmiv_gmm *g);
 
+/* ---- DEGENERATE INPUTS: what every frame-consuming entry point does with them ------------------------------------------
+ * The reference has no defined behaviour here (a NaN feature poisons every accumulator it touches; ALIZE's handling of a frame of
+ * likelihood 0 is not visible from LIA_RAL -- SURVEY.md U1; the one in-tree guard, TopGauss.cpp:247, maps a NaN likelihood to
+ * exp(minLLK)).  This library defines it, and tests/test_gpu_degenerate.py holds every path to it:
+ *
+ * A frame is a ZERO-LIKELIHOOD FRAME when (1) one of its feature values is NaN, infinite or larger than 1e18 in magnitude, or
+ * (2) its log-likelihood log sum_c w_c lk_c(x_t) is not finite or lies below -6.9e5 (2^-1000000: every Gaussian is further
+ * away than any arithmetic can tell apart; the linear-domain arithmetic of the reference gives 0 long before, at -745).  Then
+ *   gmmiv_llk                     llk_t = min_llk (the clamp of log 0); counted in sums like any frame
+ *   gmmiv_llk_determine_top       idx = 0 .. ctop-1 (the tie rule -- lowest index first -- on equal, zero, likelihoods), lk = 0,
+ *                                 nontop_lk = 0, nontop_llk = -inf, nontop_w = 1 - sum of those weights, llk = min_llk
+ *   gmmiv_topgauss_compute        as determine_top; count = cap for a mass threshold (the reference's loop runs to the end), idx as above
+ *   gmmiv_llk_use_top(_multi)     llk_t = min_llk
+ *   gmmiv_occ                     a row of zeros
+ *   gmmiv_em_accumulate           the frame adds NOTHING: no occupancy, no first / second order statistics, nothing to the sum of
+ *                                 log-likelihoods and nothing to the frame count (the M-step weights still sum to 1)
+ *   gmmiv_tv_stats(_lines), gmmiv_jfa statistics    nothing added to N / F
+ *   gmmiv_frame_moments           NOT screened: sums of the raw values, a NaN goes into the sums like in the reference
+ * Frames of kind (1) are found by a screening pass over x at the start of every call (one read of x at HBM speed: 0.3 % of an EM
+ * pass); a call that has any runs on the compacted usable frames and expands its per-frame outputs.  A caller whose features are
+ * known to be clean sets the option "assume_finite" 1 and skips the pass (the C++ host layer checks a FeatureBuffer once, at
+ * upload).  The option "screened_frames" reads the number of frames taken out so far.  Kind (2) is decided per frame where the
+ * log-likelihood kernel finishes a frame -- no per-element work in the hot loops.
+ * Other edges: T = 0 is valid everywhere (outputs untouched, accumulators unchanged); a Gaussian of weight 0 has likelihood 0
+ * (never selected before a Gaussian of positive likelihood, occupancy 0); gmmiv_em_get keeps the previous mean / covariance of a
+ * Gaussian whose occupancy is 0 and gives it weight 0; identical Gaussians tie and the lower index wins.
+ *
+ * gmmiv_count_unusable_frames: the screening pass on its own -- *count = frames of kind (1). */
+int gmmiv_count_unusable_frames(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t T, int64_t ldx, int D,
+                                int64_t *count);
+
 /* ---- FrameAccGD::accumulate loop (LIA_SpkTools/src/AccumulateStat.cpp:387-396) ---------------
  * acc[0..D) += sum x, acc[D..2D) += sum x^2, acc[2D] += T.  mean/cov: sum/n, sumsq/n - mean^2. */
 int gmmiv_frame_moments(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t T, int64_t ldx, int D,

@@ -115,6 +115,8 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "topc_rank_direct")) slot = &c->topc_rank_direct;
     else if (!strcmp(key, "topc_rank2")) slot = &c->topc_rank2;
     else if (!strcmp(key, "topc_use_lanes")) slot = &c->topc_use_lanes;
+    else if (!strcmp(key, "assume_finite")) slot = &c->assume_finite;
+    else if (!strcmp(key, "screened_frames")) slot = &c->screened_frames;
     // options read by the kernel launchers: kept in the context's gmmiv_kopts, bound to the calling thread by every call (GBIND)
     int *ks = nullptr;
     if (!strcmp(key, "z_waves")) { const long prev = c->ko.z_waves; c->ko.z_waves = (value == 4 || value == 16) ? (int)value : 8; return prev; }
@@ -272,6 +274,93 @@ struct XView {
     }
 };
 
+// ---- degenerate inputs (include/gmmiv.h): frames with a non-finite / absurd feature value never reach the kernels ----------
+// Screening = one HBM pass over x per call (skipped with the option "assume_finite"); in the -- rare -- call that has unusable
+// frames, the usable ones are compacted (k_gather_runs), the entry point runs on them and the per-frame outputs are expanded
+// back with the values the rule gives a zero-likelihood frame.  The hot kernels themselves carry no per-element checks.
+struct AssumeFinite {
+    gmmiv_ctx *c; long prev;
+    explicit AssumeFinite(gmmiv_ctx *c_) : c(c_), prev(c_->assume_finite) { c->assume_finite = 1; }
+    ~AssumeFinite() { c->assume_finite = prev; }
+};
+struct Screen {
+    int64_t T = 0, Tg = 0;      // frames of the call, usable frames
+    std::vector<long> map;      // host: compacted row of frame t, -1 = unusable (empty when every frame is usable)
+    const void *xg = nullptr;   // usable frames, compacted (device, ld = D)
+    long *dmap = nullptr;       // device copy of map
+    bool active() const { return !map.empty(); }
+    int init(gmmiv_ctx *c, const XView &xv, int dt, int64_t T_, int D)
+    {
+        T = Tg = T_;
+        if (c->assume_finite || T <= 0) return GMMIV_OK;
+        void *p;
+        int rc;
+        const size_t fbytes = ((size_t)T + 15) / 16 * 16;
+        if ((rc = c->scratch(WS_GFLAG, fbytes + 16, &p))) return rc;
+        unsigned char *flag = (unsigned char *)p;
+        int *any = (int *)(flag + fbytes);
+        GCHK(hipMemsetAsync(flag, 0, fbytes + 16, c->stream));
+        GCHK(gmmk_flag_frames(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, D, flag, any));
+        int h_any = 0;
+        GCHK(hipMemcpyAsync(&h_any, any, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        if (!h_any) return GMMIV_OK;
+        std::vector<unsigned char> hf((size_t)T);
+        GCHK(hipMemcpyAsync(hf.data(), flag, (size_t)T, hipMemcpyDeviceToHost, c->stream));
+        GCHK(hipStreamSynchronize(c->stream));
+        map.assign((size_t)T, -1);
+        std::vector<int64_t> runs; // (source frame, output row, length <= 64)
+        long g = 0;
+        for (int64_t t = 0; t < T;) {
+            if (hf[t]) { ++t; continue; }
+            int64_t e = t;
+            while (e < T && !hf[e] && e - t < 64) { map[e] = g + (e - t); ++e; }
+            runs.push_back(t); runs.push_back(g); runs.push_back(e - t);
+            g += (long)(e - t);
+            t = e;
+        }
+        Tg = g;
+        c->screened_frames += (long)(T - Tg);
+        if ((rc = c->scratch(WS_XG, (size_t)(Tg ? Tg : 1) * D * esize(dt), &p))) return rc;
+        xg = p;
+        if (Tg > 0) {
+            void *dr;
+            if ((rc = c->scratch(WS_G6, runs.size() * sizeof(int64_t), &dr))) return rc;
+            GCHK(hipMemcpyAsync(dr, runs.data(), runs.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            GCHK(gmmk_gather_runs(c->stream, dt == GMMIV_F64, xv.d, xv.ldx, D, (const long *)dr, (long)(runs.size() / 3), p));
+        }
+        if ((rc = c->scratch(WS_GMAP, (size_t)T * sizeof(long), &p))) return rc;
+        dmap = (long *)p;
+        GCHK(hipMemcpyAsync(dmap, map.data(), (size_t)T * sizeof(long), hipMemcpyHostToDevice, c->stream));
+        GCHK(hipStreamSynchronize(c->stream)); // runs is a stack-lifetime vector
+        return GMMIV_OK;
+    }
+    // rows of a per-frame INPUT array (W elements of `bytes` bytes each) for the usable frames, compacted into scratch `slot`
+    int compact_rows(gmmiv_ctx *c, int slot, const void *src_dev, int W, int bytes, const void **out) const
+    {
+        void *p;
+        int rc = c->scratch(slot, (size_t)(Tg ? Tg : 1) * W * bytes, &p);
+        if (rc) return rc;
+        *out = p;
+        if (Tg == 0) return GMMIV_OK;
+        std::vector<int64_t> runs;
+        for (int64_t t = 0; t < T;) {
+            if (map[t] < 0) { ++t; continue; }
+            int64_t e = t;
+            while (e < T && map[e] >= 0 && e - t < 64) ++e;
+            runs.push_back(t); runs.push_back(map[t]); runs.push_back(e - t);
+            t = e;
+        }
+        void *dr;
+        if ((rc = c->scratch(WS_G6, runs.size() * sizeof(int64_t), &dr))) return rc;
+        GCHK(hipMemcpyAsync(dr, runs.data(), runs.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        // rows of W elements of 4 or 8 bytes move like feature rows of that type
+        GCHK(gmmk_gather_runs(c->stream, bytes == 8, src_dev, W, W, (const long *)dr, (long)(runs.size() / 3), p));
+        GCHK(hipStreamSynchronize(c->stream));
+        return GMMIV_OK;
+    }
+};
+
 static int check_model(gmmiv_ctx *c, const gmmiv_gmm *g)
 {
     if (!c || !g) { gmmiv_set_error("NULL context or model"); return GMMIV_ERR_ARG; }
@@ -314,6 +403,35 @@ int gmmiv_gather_frames(gmmiv_ctx *c, const void *x, int dt, int64_t ldx, int D,
     GCHK(gmmk_gather_frames(c->stream, dt == GMMIV_F64, x, ldx, D, (const long *)i_idx.d, n, out));
     c->t_end();
     if (!gmmiv_is_device_ptr(frame_idx)) GCHK(hipStreamSynchronize(c->stream)); // host index list may be freed
+    return GMMIV_OK;
+}
+
+int gmmiv_count_unusable_frames(gmmiv_ctx *c, const void *x, int dt, int64_t T, int64_t ldx, int D, int64_t *count)
+{
+    if (!c || !count || T < 0 || D <= 0) { gmmiv_set_error("count_unusable_frames: bad argument"); return GMMIV_ERR_ARG; }
+    GBIND(c);
+    *count = 0;
+    if (T == 0) return GMMIV_OK;
+    XView xv;
+    int rc = xv.init(c, x, dt, T, ldx, D);
+    if (rc) return rc;
+    void *p;
+    const size_t fbytes = ((size_t)T + 15) / 16 * 16;
+    if ((rc = c->scratch(WS_GFLAG, fbytes + 16, &p))) return rc;
+    unsigned char *flag = (unsigned char *)p;
+    int *any = (int *)(flag + fbytes);
+    GCHK(hipMemsetAsync(flag, 0, fbytes + 16, c->stream));
+    GCHK(gmmk_flag_frames(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, D, flag, any));
+    int h_any = 0;
+    GCHK(hipMemcpyAsync(&h_any, any, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    GCHK(hipStreamSynchronize(c->stream));
+    if (!h_any) return GMMIV_OK;
+    std::vector<unsigned char> hf((size_t)T);
+    GCHK(hipMemcpyAsync(hf.data(), flag, (size_t)T, hipMemcpyDeviceToHost, c->stream));
+    GCHK(hipStreamSynchronize(c->stream));
+    int64_t n = 0;
+    for (int64_t t = 0; t < T; ++t) n += hf[t] ? 1 : 0;
+    *count = n;
     return GMMIV_OK;
 }
 
@@ -394,13 +512,32 @@ int gmmiv_llk(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
     if (T < 0) { gmmiv_set_error("llk: T < 0"); return GMMIV_ERR_ARG; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    Screen sc;
+    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
+    if (sc.active()) { // unusable frames: the call on the usable ones, llk = min_llk (the clamp of log 0) for the others
+        void *tmp, *full, *part;
+        if ((rc = c->scratch(WS_G0, (size_t)(sc.Tg ? sc.Tg : 1) * sizeof(double), &tmp))) return rc;
+        { AssumeFinite af(c); if ((rc = gmmiv_llk(c, g, sc.xg, dt, sc.Tg, g->D, min_llk, max_llk, (double *)tmp, nullptr))) return rc; }
+        DevOut<double> o_llk, o_sum;
+        if ((rc = c->scratch(WS_G1, (size_t)T * sizeof(double), &full))) return rc;
+        if ((rc = o_llk.init(c, WS_T0, llk_out ? llk_out : (double *)full, (size_t)T, false))) return rc;
+        if ((rc = o_sum.init(c, WS_T1, sums, 2, true))) return rc;
+        GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)tmp, o_llk.d, min_llk));
+        if (sums) {
+            if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &part))) return rc;
+            GCHK(gmmk_llk_finalize(c->stream, o_llk.d, T, min_llk, max_llk, nullptr, (double *)part, 1.0, 0.0, o_sum.d, nullptr));
+            GCHK(gmmk_add_scalar(c->stream, o_sum.d + 1, (double)T));
+        }
+        if (llk_out && (rc = o_llk.finish())) return rc;
+        return o_sum.finish();
+    }
     double *lse;
     if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     DevOut<double> o_llk, o_sum;
     if ((rc = o_llk.init(c, WS_T0, llk_out, (size_t)T, false))) return rc;
     if ((rc = o_sum.init(c, WS_T1, sums, 2, true))) return rc;
     void *part;
-    if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &part))) return rc;
+    if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &part))) return rc;
     GCHK(gmmk_llk_finalize(c->stream, lse, T, min_llk, max_llk, o_llk.d, (double *)part, 1.0, 0.0,
                            sums ? o_sum.d : nullptr, nullptr));
     if (sums) GCHK(gmmk_add_scalar(c->stream, o_sum.d + 1, (double)T));
@@ -427,6 +564,52 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     if (!gmmk_topc_frames_per_block(g->Cp64, g->D)) { gmmiv_set_error("determine_top: mixtureDistribCount %d too large for the LDS selection kernel", g->C); return GMMIV_ERR_UNSUPPORTED; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    Screen sc;
+    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
+    if (sc.active()) {
+        // unusable frames are zero-likelihood frames: the lowest ctop indices (the tie rule on equal -- zero -- likelihoods), lk 0,
+        // remainder 0 / -inf, nontop_w = 1 - the weights of those indices, llk = min_llk; the usable frames as usual
+        const size_t n = (size_t)(sc.Tg ? sc.Tg : 1);
+        void *t_idx, *t_lk = nullptr, *t_nlk = nullptr, *t_nllk = nullptr, *t_nw = nullptr, *t_llk = nullptr;
+        if ((rc = c->scratch(WS_G0, n * ctop * sizeof(int32_t), &t_idx))) return rc;
+        if (lk && (rc = c->scratch(WS_G1, n * ctop * sizeof(double), &t_lk))) return rc;
+        if (nontop_lk && (rc = c->scratch(WS_G2, n * sizeof(double), &t_nlk))) return rc;
+        if (nontop_llk && (rc = c->scratch(WS_G3, n * sizeof(double), &t_nllk))) return rc;
+        if (nontop_w && (rc = c->scratch(WS_G4, n * sizeof(double), &t_nw))) return rc;
+        if (llk_out && (rc = c->scratch(WS_G5, n * sizeof(double), &t_llk))) return rc;
+        {
+            AssumeFinite af(c);
+            if ((rc = gmmiv_llk_determine_top(c, g, sc.xg, dt, sc.Tg, g->D, ctop, mode, min_llk, max_llk, (int32_t *)t_idx, (double *)t_lk,
+                                              (double *)t_nlk, (double *)t_nllk, (double *)t_nw, (double *)t_llk))) return rc;
+        }
+        double snsw = 1.0;
+        if (nontop_w) {
+            std::vector<double> hw((size_t)ctop);
+            GCHK(hipMemcpyAsync(hw.data(), g->w, (size_t)ctop * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            GCHK(hipStreamSynchronize(c->stream));
+            for (int k = 0; k < ctop; ++k) snsw -= hw[k];
+        }
+        DevOut<int32_t> o_idx;
+        DevOut<double> o_lk, o_nlk, o_nllk, o_nw, o_llk;
+        if ((rc = o_idx.init(c, WS_T0, idx, (size_t)T * ctop, false))) return rc;
+        if ((rc = o_lk.init(c, WS_T1, lk, (size_t)T * ctop, false))) return rc;
+        if ((rc = o_nlk.init(c, WS_T2, nontop_lk, (size_t)T, false))) return rc;
+        if ((rc = o_nllk.init(c, WS_T3, nontop_llk, (size_t)T, false))) return rc;
+        if ((rc = o_nw.init(c, WS_T4, nontop_w, (size_t)T, false))) return rc;
+        if ((rc = o_llk.init(c, WS_T5, llk_out, (size_t)T, false))) return rc;
+        GCHK(gmmk_expand_rows_i32(c->stream, T, ctop, sc.dmap, (const int *)t_idx, o_idx.d, 0, 1));
+        if (lk) GCHK(gmmk_expand_rows_f64(c->stream, T, ctop, sc.dmap, (const double *)t_lk, o_lk.d, 0.0));
+        if (nontop_lk) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_nlk, o_nlk.d, 0.0));
+        if (nontop_llk) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_nllk, o_nllk.d, -INFINITY));
+        if (nontop_w) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_nw, o_nw.d, snsw));
+        if (llk_out) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_llk, o_llk.d, min_llk));
+        if ((rc = o_idx.finish())) return rc;
+        if ((rc = o_lk.finish())) return rc;
+        if ((rc = o_nlk.finish())) return rc;
+        if ((rc = o_nllk.finish())) return rc;
+        if ((rc = o_nw.finish())) return rc;
+        return o_llk.finish();
+    }
     DevOut<int32_t> o_idx;
     DevOut<double> o_lk, o_nlk, o_nllk, o_nw, o_llk;
     if ((rc = o_idx.init(c, WS_T0, idx, (size_t)T * ctop, false))) return rc;
@@ -654,7 +837,7 @@ int gmmiv_topgauss_compute(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int 
     if ((rc = o_cnt.init(c, WS_T0, count, (size_t)T, false))) return rc;
     if ((rc = o_w.init(c, WS_T1, snsw, (size_t)T, false))) return rc;
     if ((rc = o_l.init(c, WS_T2, snsl, (size_t)T, false))) return rc;
-    if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &p))) return rc;
+    if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &p))) return rc;
     unsigned long long *d_cap = (unsigned long long *)p;
     GCHK(hipMemsetAsync(d_cap, 0, sizeof(unsigned long long), c->stream));
     GCHK(gmmk_topgauss_select(c->stream, T, cap, top_gauss, fixed, g->w, d_idx, d_lk, d_llk, o_cnt.d, o_w.d, o_l.d, d_cap));
@@ -689,6 +872,18 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     if ((rc = i_idx.init(c, WS_T0, idx, (size_t)T * ctop))) return rc;
     if ((rc = i_n.init(c, WS_T1, nontop_llk, (size_t)T))) return rc;
     if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T, false))) return rc;
+    Screen sc;
+    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
+    if (sc.active()) { // unusable frames: llk = min_llk; the others on their own rows of idx / nontop_llk
+        const void *cidx, *cn = nullptr;
+        void *tmp;
+        if ((rc = sc.compact_rows(c, WS_G0, i_idx.d, ctop, 4, &cidx))) return rc;
+        if (i_n.d && (rc = sc.compact_rows(c, WS_G1, i_n.d, 1, 8, &cn))) return rc;
+        if ((rc = c->scratch(WS_G2, (size_t)(sc.Tg ? sc.Tg : 1) * sizeof(double), &tmp))) return rc;
+        { AssumeFinite af(c); if ((rc = gmmiv_llk_use_top(c, g, sc.xg, dt, sc.Tg, g->D, ctop, (const int32_t *)cidx, (const double *)cn, mode, min_llk, max_llk, (double *)tmp))) return rc; }
+        GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)tmp, o_llk.d, min_llk));
+        return o_llk.finish();
+    }
     c->t_begin("k_topc_use");
     // four lanes per candidate, one frame per wave ("topc_use_lanes" 1: one lane per candidate, four frames per wave) when the
     // selection has at most 16 entries (topc_z.hip); else one wave per frame
@@ -729,6 +924,15 @@ int gmmiv_llk_use_top_multi(gmmiv_ctx *c, int n_clients, const gmmiv_gmm *const 
     GBIND(c);
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g0->D))) return rc;
+    {
+        Screen sc;
+        if ((rc = sc.init(c, xv, dt, T, g0->D))) return rc;
+        if (sc.active()) { // unusable frames present: client by client through gmmiv_llk_use_top (which applies the rule)
+            for (int i = 0; i < n_clients; ++i)
+                if ((rc = gmmiv_llk_use_top(c, clients[i], x, dt, T, ldx, ctop, idx, nontop_llk, mode, min_llk, max_llk, llk_out + (size_t)i * T))) return rc;
+            return GMMIV_OK;
+        }
+    }
     DevIn<int32_t> i_idx;
     DevIn<double> i_n;
     DevOut<double> o_llk;
@@ -759,6 +963,15 @@ int gmmiv_occ(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
     DevOut<double> o;
     if ((rc = o.init(c, WS_T0, gamma, (size_t)T * g->C, false))) return rc;
+    Screen sc;
+    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
+    if (sc.active()) { // unusable frames: a row of zeros
+        void *tmp;
+        if ((rc = c->scratch(WS_G0, (size_t)(sc.Tg ? sc.Tg : 1) * g->C * sizeof(double), &tmp))) return rc;
+        { AssumeFinite af(c); if ((rc = gmmiv_occ(c, g, sc.xg, dt, sc.Tg, g->D, (double *)tmp))) return rc; }
+        GCHK(gmmk_expand_rows_f64(c->stream, T, g->C, sc.dmap, (const double *)tmp, o.d, 0.0));
+        return o.finish();
+    }
     // Fast path: logits on the matrix cores (k_llk_mfma<WZ>), posteriors = the stored scaled likelihoods rescaled and transposed
     const int64_t Tcz = c->topc_z ? z_chunk_frames(c, g) : 0;
     if (Tcz > 0 && T > 0) {
@@ -904,6 +1117,15 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if (T == 0) return o.finish();
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    {
+        Screen sc;
+        if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
+        if (sc.active()) { // unusable frames add nothing, anywhere (no occupancy, no statistics, no log-likelihood, no frame count)
+            AssumeFinite af(c);
+            if ((rc = gmmiv_em_accumulate(c, g, sc.xg, dt, sc.Tg, g->D, weight, o.d))) return rc;
+            return o.finish();
+        }
+    }
     if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
         // single-pass path: teams of (nct/8) workgroups, one team per contiguous frame range
         const int ngrp = (g->nct + 7) / 8;
@@ -927,7 +1149,7 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
             if ((rc = c->scratch(WS_PART, (size_t)nteams * Cp * 2 * RL * sizeof(double), &part))) return rc;
             const size_t sw = gmmk_em_fused_slot_words(nteams, ngrp);
             if ((rc = c->scratch(WS_SLOTS, sw * 8, &slots))) return rc;
-            if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
+            if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &small))) return rc;
             GCHK(hipMemsetAsync(slots, 0, sw * 8, c->stream));
             c->t_begin("k_em_fused");
             int krc = gmmk_em_fused(c->stream, g->KS, 1, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, -log(weight),
@@ -943,9 +1165,9 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
                 gmmiv_set_error("em_accumulate(fused): hand-off timed out, fell back to the two-kernel path");
                 goto two_pass;
             }
+            // sum_t weight log lk_t and sum_t weight over the frames that HAVE a likelihood (zero-likelihood frames add nothing anywhere)
             GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
-                                   o.d + nacc - 2));
-            GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
+                                   o.d + nacc - 2, weight, o.d + nacc - 1));
             GCHK(gmmk_em_reduce(c->stream, (const double *)part, nteams, g->C, (int)Cp, g->D, g->KS, o.d));
             return o.finish();
         }
@@ -956,22 +1178,20 @@ two_pass:
         void *lsew, *small, *part;
         int nseg = 0;
         if ((rc = c->scratch(WS_LSE, (size_t)T * sizeof(double), &lsew))) return rc;
-        if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
+        if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &small))) return rc;
         if ((rc = em_stats_z(c, g, xv, dt, T, Tc, weight, (double *)lsew, &nseg, &part))) return rc;
         GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
-                               o.d + nacc - 2));
-        GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
+                               o.d + nacc - 2, weight, o.d + nacc - 1));
         GCHK(gmmk_em_reduce(c->stream, (const double *)part, nseg, g->C, g->nct * 16, g->D, g->KS, o.d));
         return o.finish();
     }
     double *lse;
     if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     void *small;
-    if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &small))) return rc;
+    if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &small))) return rc;
     // sum_t weight * log lk_t  and  sum_t weight
     GCHK(gmmk_llk_finalize(c->stream, lse, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
-                           o.d + nacc - 2));
-    GCHK(gmmk_add_scalar(c->stream, o.d + nacc - 1, weight * (double)T));
+                           o.d + nacc - 2, weight, o.d + nacc - 1));
     // frame chunks: enough workgroups to fill the chip about twice, each >= 4096 frames
     const int nw = c->wg_waves == 8 ? 8 : 4;
     const int ngrp = (g->nct + nw - 1) / nw;
@@ -1029,7 +1249,7 @@ int gmmiv_variance_control(gmmiv_ctx *c, int C, int D, double *cov, double floor
     unsigned long long *dc = nullptr;
     if (counts) {
         void *p;
-        if ((rc = c->scratch(WS_SMALL, 2 * 256 * sizeof(double), &p))) return rc;
+        if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &p))) return rc;
         dc = (unsigned long long *)p;
         GCHK(hipMemsetAsync(dc, 0, 2 * sizeof(unsigned long long), c->stream));
     }
@@ -1059,6 +1279,18 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     if (U > 0x7fffffff / 64) { gmmiv_set_error("tv_stats: too many utterances in one call"); return GMMIV_ERR_UNSUPPORTED; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
+    {
+        Screen sc;
+        if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
+        if (sc.active()) { // unusable frames add nothing to N / F: the utterances keep their usable frames
+            std::vector<long> pre((size_t)T + 1, 0);
+            for (int64_t t = 0; t < T; ++t) pre[t + 1] = pre[t] + (sc.map[t] >= 0 ? 1 : 0);
+            std::vector<int64_t> ub((size_t)U + 1);
+            for (int64_t u = 0; u <= U; ++u) ub[u] = pre[utt_begin[u]];
+            AssumeFinite af(c);
+            return gmmiv_tv_stats(c, g, sc.xg, dt, sc.Tg, g->D, ub.data(), U, N, F);
+        }
+    }
     std::vector<long> h(utt_begin, utt_begin + U + 1);
     void *seg;
     if ((rc = c->scratch(WS_SEG, (U + 1) * sizeof(long), &seg))) return rc;

@@ -33,7 +33,8 @@ void gmmiv_set_error(const char *fmt, ...);
     } while (0)
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
-       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_EIT, WS_INV, WS_COUNT };
+       WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_EIT, WS_INV,
+       WS_XG, WS_GFLAG, WS_GMAP, WS_G0, WS_G1, WS_G2, WS_G3, WS_G4, WS_G5, WS_G6, WS_COUNT }; // WS_XG..: the screened (compacted) form of a call with unusable frames
 
 struct gmmiv_ctx {
     int device = 0;
@@ -98,6 +99,10 @@ struct gmmiv_ctx {
         }
         if (topc_hflags) { (void)hipHostFree(topc_hflags); topc_hflags = nullptr; topc_hflags_n = 0; }
     }
+    // 1: the caller vouches that every feature value is finite and |x| <= 1e18 -- the screening pass over the features (one read of
+    // x per call) is skipped.  The C++ host layer sets it around its calls once a FeatureBuffer has been checked at upload.
+    long assume_finite = 0;
+    long screened_frames = 0; // unusable frames the screening has taken out of calls so far (read with set_option)
     long topc_fallbacks = 0; // calls the fused path handed to the slower paths (list overflow / margin check); read with set_option
     long topc_z = 1;     // DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (topc_z.hip); 0: the direct-form VALU kernel
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)

@@ -11,6 +11,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 #define GMMIV_NEG_BIG (-1.0e300)
+#define GMMIV_ZERO_LLK (-745.1332191019412) // log 2^-1075: a likelihood below it is 0 in fp64 -- include/gmmiv.h, "degenerate inputs"
 #define GMMIV_PAD_LOGIT (-1.0e9) // constant term of padded / zero-weight Gaussians in the packed MFMA model
 
 // exp(x) for x <= ~700, branch-free, no special cases: arguments below -750 give ~0.

@@ -183,10 +183,12 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
         const double Ssum = row_sum_f64(sg * gexp_t(m - M, etab));
         if (i16 == 0) {
             const double lse = M + log(Ssum);
+            // a zero-likelihood frame (include/gmmiv.h, "degenerate inputs"): the largest w_c lk_c rounds to 0 in fp64, or the sum is not finite
+            const bool ok = M > GMMIV_ZERO_LLK && lse > -__builtin_inf() && lse < __builtin_inf();
             const int tl = 4 * wave + q;
-            lse_t[tl] = lse + lse_shift;
+            lse_t[tl] = ok ? lse + lse_shift : 1.0e300;
             const long fr = f0 + (long)k * FT + tl;
-            if (lse_out && grp == 0 && fr < f1) lse_out[fr] = lse;
+            if (lse_out && grp == 0 && fr < f1) lse_out[fr] = ok ? lse : -__builtin_inf();
         }
     };
 

@@ -12,7 +12,8 @@ int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, con
 int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
              double *lse, int use_glds, int wg_waves);
 int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, double hi, double *llk_out,
-                      double *partial, double scale_c, double scale_r, double *dst_clamped, double *dst_raw);
+                      double *partial /* >= 3*256 doubles */, double scale_c, double scale_r, double *dst_clamped,
+                      double *dst_raw, double scale_n = 0.0, double *dst_count = nullptr);
 int gmmk_add_scalar(hipStream_t st, double *dst, double v);
 int gmmk_rows_sum_groups(hipStream_t st, long n, int ngroups, const int *rb, const double *src, double *dst); // dst[g] = sum of src rows [rb[g], rb[g+1])
 int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
@@ -39,6 +40,9 @@ int gmmk_segment_means(hipStream_t st, const double *v, long ld, const long *ite
                        const long *pair_len, long npair, double *out);
 int gmmk_topgauss_select(hipStream_t st, long T, int cap, double mass, int fixed_count, const double *w, int *idx, const double *lk,
                          const double *llk, int *count, double *snsw, double *snsl, unsigned long long *capped);
+int gmmk_flag_frames(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, unsigned char *flag, int *any);
+int gmmk_expand_rows_f64(hipStream_t st, long T, int W, const long *map, const double *src, double *dst, double fill);
+int gmmk_expand_rows_i32(hipStream_t st, long T, int W, const long *map, const int *src, int *dst, int fill, int fill_is_column);
 int gmmk_gather_runs(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *runs, long nrun, void *out);
 // em_fused.hip: single-pass EM statistics by teams of cooperating workgroups
 size_t gmmk_em_fused_slot_words(int nteams, int ngrp);

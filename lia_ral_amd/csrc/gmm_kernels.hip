@@ -107,6 +107,9 @@ __global__ void k_gmm_transpose(int C, int Cp, int D, const double *__restrict__
 // direct-form logits of the survivors, ranking, remainder.  zbuf = the record array, eit = the per-frame candidate counts,
 // inv_out = the non-appended sums (2^-Efin), lse_out = the final thresholds.
 #define TOPC_CAP 256
+// A frame whose largest w_c lk_c = t 2^E (t in [1, 2)) has E < -1075 is a zero-likelihood frame: every term of the reference's
+// linear-domain sum rounds to 0 in fp64 (largest logit below GMMIV_ZERO_LLK = log 2^-1075)
+#define GMMIV_MIN_FRAME_EXP (-1076)
 // K1_ABL (compile-time, timing experiments only -- tools/k1_ablate.sh; results are wrong when != 0): 1 = no epilogue, 2 = exp table read
 // from one address, 4 = no likelihood stores, 8 = no DPP row maximum, 16 = no staging / barrier, 32 = no stores of the running exponents; TC mode: 64 = no hit test / append,
 // 128 = no lane maxima / threshold refresh, 256 = x^2 operands not recomputed (x fed twice)
@@ -530,8 +533,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                 continue;
             }
             if (i16 == 0 && t < T) {
-                lse_out[t] = log(sv) + (double)Em * 0.693147180559945309417;
-                if (WZ) { inv_out[t] = 1.0 / sv; efin_out[t] = Em; }
+                // A ZERO-LIKELIHOOD frame (include/gmmiv.h, "degenerate inputs"): the scaled sum is not a positive finite number, or
+                // even the largest w_c lk_c is below 2^-1075 -- 0 in the fp64 arithmetic of the reference (far below that the integer
+                // exponent of gexp_tab_reduce saturates and nothing in the row is trustworthy).  log-likelihood -inf, scale 0: every
+                // posterior the statistics kernels form from it is 0.
+                const bool ok = sv > 0.0 && sv < __builtin_inf() && Em > GMMIV_MIN_FRAME_EXP;
+                lse_out[t] = ok ? log(sv) + (double)Em * 0.693147180559945309417 : -__builtin_inf();
+                if (WZ) { inv_out[t] = ok ? 1.0 / sv : 0.0; efin_out[t] = ok ? Em : 0; }
             }
         }
     if (TC) { // candidate counts of the workgroup's frames (each wave appended to its own 32 rows only)
@@ -541,40 +549,47 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
     }
 }
 
-// clamp + sums: out[t] = clamp(lse[t]); partial[b] = {sum clamped, sum raw}
+// clamp + sums: out[t] = clamp(lse[t]); partial[b] = {sum clamped, sum raw, frames with a finite raw value}.  A zero-likelihood
+// frame (lse = -inf / NaN) clamps to lo like log(0) does in the reference; the RAW sum -- the EM accumulator's sum of log-likelihoods --
+// and the frame count beside it skip it.
 __global__ __launch_bounds__(256) void k_llk_finalize(const double *__restrict__ lse, long T, double lo,
                                                      double hi, double *__restrict__ llk_out,
                                                      double *__restrict__ partial)
 {
-    __shared__ double red[2][4];
-    double sc = 0.0, sr = 0.0;
+    __shared__ double red[3][4];
+    double sc = 0.0, sr = 0.0, sn = 0.0;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
         const double v = lse[t];
-        const double c = fmin(fmax(v, lo), hi);
+        const double c = fmin(fmax(v, lo), hi); // fmax(NaN, lo) = lo
         if (llk_out) llk_out[t] = c;
         sc += c;
-        sr += v;
+        const bool fin = v > -__builtin_inf() && v < __builtin_inf();
+        sr += fin ? v : 0.0;
+        sn += fin ? 1.0 : 0.0;
     }
     sc = wave_sum_f64(sc);
     sr = wave_sum_f64(sr);
+    sn = wave_sum_f64(sn);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = sc; red[1][wave] = sr; }
+    if (lane == 0) { red[0][wave] = sc; red[1][wave] = sr; red[2][wave] = sn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        partial[3 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[3 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        partial[3 * blockIdx.x + 2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     }
 }
 
-// dst[i] += scale[i] * sum_b partial[b*n + i]   (single block, deterministic order)
-__global__ void k_reduce_partials(const double *__restrict__ partial, int nb, int n, double s0, double s1,
-                                  double *__restrict__ dst0, double *__restrict__ dst1)
+// dst_i += s_i * sum_b partial[b*n + i], i < 3   (single block, deterministic order)
+__global__ void k_reduce_partials(const double *__restrict__ partial, int nb, int n, double s0, double s1, double s2,
+                                  double *__restrict__ dst0, double *__restrict__ dst1, double *__restrict__ dst2)
 {
     if (threadIdx.x < n) {
         double s = 0.0;
         for (int b = 0; b < nb; ++b) s += partial[(size_t)b * n + threadIdx.x];
         if (threadIdx.x == 0 && dst0) *dst0 += s0 * s;
         if (threadIdx.x == 1 && dst1) *dst1 += s1 * s;
+        if (threadIdx.x == 2 && dst2) *dst2 += s2 * s;
     }
 }
 
@@ -669,7 +684,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_stats_mfma(const void *__restric
             stg[i] = v;
         }
         // out-of-range rows get lse = +1e300 -> posterior exp(z - lse) = 0
-        if (tid < FT) stg_lse = (fb + tid < f1) ? lse[fb + tid] + lse_shift : 1.0e300;
+        if (tid < FT) {
+            const double l = (fb + tid < f1) ? lse[fb + tid] : 1.0e300;
+            stg_lse = (l > -__builtin_inf() && l < 1.0e299) ? l + lse_shift : 1.0e300; // a zero-likelihood frame (lse -inf / NaN): posteriors 0
+        }
     };
     auto write_tile = [&](double *dst) {
 #pragma unroll
@@ -899,7 +917,10 @@ __global__ __launch_bounds__(256) void k_topc_determine(
         }
         const double a = lwc[c];
 #pragma unroll
-        for (int f = 0; f < FT; ++f) zs[(size_t)f * Cp + c] = __builtin_fma(-0.5, acc[f], a);
+        for (int f = 0; f < FT; ++f) {
+            const double z = __builtin_fma(-0.5, acc[f], a);
+            zs[(size_t)f * Cp + c] = z == z ? z : -__builtin_inf(); // a NaN logit (non-finite feature) = likelihood 0
+        }
     }
     __syncthreads();
 
@@ -911,12 +932,13 @@ __global__ __launch_bounds__(256) void k_topc_determine(
         double topv = 0.0; // lane j keeps the j-th selected logit
         int topi = 0;
         double M = 0.0;
+        const double TAKEN = __builtin_nan(""); // marks a selected entry: never compares as a candidate again
         for (int k = 0; k < ctop; ++k) {
             double bv = NINF;
             int bc = 0x7fffffff;
-            for (int c = lane; c < Cp; c += 64) {
+            for (int c = lane; c < C; c += 64) { // real Gaussians only: padding can never be selected
                 const double v = z[c];
-                if (v > bv) { bv = v; bc = c; }
+                if (v > bv || (v == bv && c < bc)) { bv = v; bc = c; } // likelihood 0 (-inf) is a candidate too: lowest index first
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -926,25 +948,27 @@ __global__ __launch_bounds__(256) void k_topc_determine(
             }
             if (k == 0) M = bv;
             if (lane == k) { topv = bv; topi = bc; }
-            if (lane == (bc & 63)) z[bc] = NINF;
+            if (lane == (bc & 63)) z[bc] = TAKEN;
         }
-        // non-selected remainder and selected sum, both relative to the largest logit M
+        // non-selected remainder and selected sum, both relative to the largest logit M (M = -inf: a zero-likelihood frame)
+        const bool dead = !(M > GMMIV_ZERO_LLK); // zero-likelihood frame: the lowest indices, lk 0 (the selection loop has put them there only when every logit is -inf: do it here for all)
         double sr = 0.0;
-        for (int c = lane; c < Cp; c += 64) sr += gexp(z[c] - M);
+        for (int c = lane; c < Cp; c += 64) { const double v = z[c]; sr += (v == v && !dead) ? gexp(v - M) : 0.0; }
         sr = wave_sum_f64(sr);
-        double st = (lane < ctop) ? gexp(topv - M) : 0.0;
+        double st = (lane < ctop && !dead) ? gexp(topv - M) : 0.0;
         st = wave_sum_f64(st);
+        if (dead) topi = lane;
         if (lane < ctop) {
             idx_out[t * ctop + lane] = topi;
-            if (lk_out) lk_out[t * ctop + lane] = exp(topv);
+            if (lk_out) lk_out[t * ctop + lane] = dead ? 0.0 : exp(topv);
         }
         if (lane == 0) {
-            const double rest_llk = sr > 0.0 ? M + log(sr) : NINF;
+            const double rest_llk = (sr > 0.0 && !dead) ? M + log(sr) : NINF;
             if (nontop_llk) nontop_llk[t] = rest_llk;
-            if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+            if (nontop_lk) nontop_lk[t] = (sr > 0.0 && !dead) ? exp(rest_llk) : 0.0;
             if (llk_out) {
                 const double tot = complete ? st + sr : st;
-                llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+                llk_out[t] = dead ? lo : fmin(fmax(M + log(tot), lo), hi);
             }
         }
         if (nontop_w) { // 1 - sum of selected weights, subtracted in selection order (TopGauss.cpp:183-186)
@@ -1003,7 +1027,8 @@ __global__ __launch_bounds__(256) void k_posteriors(const void *__restrict__ x, 
     const long t = blockIdx.x;
     for (int d = threadIdx.x; d < D; d += 256) xs[d] = feat_load<XT>::get(x, t * ldx + d);
     __syncthreads();
-    const double l = lse[t];
+    double l = lse[t];
+    if (!(l > -__builtin_inf())) l = __builtin_inf(); // a zero-likelihood frame: a row of zeros
     for (int c = threadIdx.x; c < C; c += 256) {
         double acc = 0.0;
         for (int d = 0; d < D; ++d) {
@@ -1185,14 +1210,14 @@ int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long
 }
 
 int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, double hi, double *llk_out,
-                      double *partial /* >= 2*256 doubles */, double scale_c, double scale_r, double *dst_clamped,
-                      double *dst_raw)
+                      double *partial /* >= 3*256 doubles */, double scale_c, double scale_r, double *dst_clamped,
+                      double *dst_raw, double scale_n, double *dst_count)
 {
     if (T <= 0) return 0;
     int nb = (int)((T + 255) / 256);
     if (nb > 256) nb = 256;
     k_llk_finalize<<<nb, 256, 0, st>>>(lse, T, lo, hi, llk_out, partial);
-    k_reduce_partials<<<1, 64, 0, st>>>(partial, nb, 2, scale_c, scale_r, dst_clamped, dst_raw);
+    k_reduce_partials<<<1, 64, 0, st>>>(partial, nb, 3, scale_c, scale_r, scale_n, dst_clamped, dst_raw, dst_count);
     return (int)hipGetLastError();
 }
 
@@ -1286,6 +1311,71 @@ int gmmk_topgauss_select(hipStream_t st, long T, int cap, double mass, int fixed
 {
     if (T <= 0) return 0;
     k_topgauss_select<<<(unsigned)((T + 255) / 256), 256, 0, st>>>(T, cap, mass, fixed_count, w, idx, lk, llk, count, snsw, snsl, capped);
+    return (int)hipGetLastError();
+}
+
+// Screening of the features (include/gmmiv.h, "degenerate inputs"): a frame with a value that is NaN, infinite or beyond 1e18 in
+// magnitude (its square would leave the range in which the expanded logits are meaningful) is unusable.  flag[t] = 1 for such
+// frames, *any = 1 if there is one.  One pass over x at HBM speed; element-parallel, 16-byte loads on contiguous float rows.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_flag_frames(const XT *__restrict__ x, long T, long ldx, int D, unsigned char *__restrict__ flag,
+                                                     int *__restrict__ any)
+{
+    const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (ldx == D && sizeof(XT) == 4 && (D & 3) == 0 && (((size_t)x) & 15) == 0) {
+        const long nv = T * D / 4;
+        for (long e = i0; e < nv; e += stride) {
+            const float4 v = ((const float4 *)x)[e];
+            const bool bad = !(fabsf(v.x) <= 1e18f) || !(fabsf(v.y) <= 1e18f) || !(fabsf(v.z) <= 1e18f) || !(fabsf(v.w) <= 1e18f);
+            if (bad) { flag[(4 * e) / D] = 1; hit = true; } // D % 4 == 0: the four values belong to one frame
+        }
+    } else {
+        const long n = T * D;
+        for (long e = i0; e < n; e += stride) {
+            const long t = e / D;
+            const double v = (double)x[t * ldx + (e - t * D)];
+            if (!(fabs(v) <= 1e18)) { flag[t] = 1; hit = true; }
+        }
+    }
+    if (hit) *any = 1;
+}
+int gmmk_flag_frames(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, unsigned char *flag, int *any)
+{
+    if (T <= 0) return 0;
+    const long n = T * D;
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256 + 1);
+    if (x_f64) k_flag_frames<double><<<blocks, 256, 0, st>>>((const double *)x, T, ldx, D, flag, any);
+    else k_flag_frames<float><<<blocks, 256, 0, st>>>((const float *)x, T, ldx, D, flag, any);
+    return (int)hipGetLastError();
+}
+
+// Results of a call on the usable frames only, back in the caller's frame order: dst[t][0..W) = src[map[t]][0..W) when map[t] >= 0,
+// else the value the rule gives a zero-likelihood frame: `fill`, or the column number (index lists: the lowest Gaussians).
+template <typename V>
+__global__ __launch_bounds__(256) void k_expand_rows(long T, int W, const long *__restrict__ map, const V *__restrict__ src, V *__restrict__ dst,
+                                                     V fill, int fill_is_column)
+{
+    const long n = T * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long t = e / W;
+        const int j = (int)(e - t * W);
+        const long m = map[t];
+        dst[e] = m >= 0 ? src[m * W + j] : (fill_is_column ? (V)j : fill);
+    }
+}
+int gmmk_expand_rows_f64(hipStream_t st, long T, int W, const long *map, const double *src, double *dst, double fill)
+{
+    if (T <= 0 || W <= 0) return 0;
+    const long n = T * W;
+    k_expand_rows<double><<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, st>>>(T, W, map, src, dst, fill, 0);
+    return (int)hipGetLastError();
+}
+int gmmk_expand_rows_i32(hipStream_t st, long T, int W, const long *map, const int *src, int *dst, int fill, int fill_is_column)
+{
+    if (T <= 0 || W <= 0) return 0;
+    const long n = T * W;
+    k_expand_rows<int><<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, st>>>(T, W, map, src, dst, fill, fill_is_column);
     return (int)hipGetLastError();
 }
 

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256, 2) void k_topc_from_z(const void *__restrict__
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (nc > 64) { if (lane == 0) atomicExch(flag, 1); continue; } // a pile-up of equal values: the direct-form kernel redoes the call
+        // fewer stored likelihoods above 0 than Gaussians to select (a zero-likelihood frame; a frame whose other Gaussians lie more
+        // than 2^-1074 below its best): the ranks beyond nc would stay unwritten -- the direct-form kernel ranks on the logits instead
+        if (nc < (ctop < C ? ctop : C)) { if (lane == 0) atomicExch(flag, 1); continue; }
         const int ci = lane < nc ? ord[wave][lane] : 0x7fffffff;
         __builtin_amdgcn_wave_barrier();
         const double vnext = theta; // every non-candidate is below theta
@@ -423,18 +426,19 @@ __device__ __forceinline__ void topc_rank_frame(const long t, const void *__rest
     srel += wave_sum_f64_dpp(sr);
     srel += wave_sum_f64_dpp((cd && !sel) ? gexp(zc - M) : 0.0);
     const double st = wave_sum_f64_dpp(sel ? gexp(zc - M) : 0.0);
+    const bool dead = !(M > GMMIV_ZERO_LLK); // zero-likelihood frame (include/gmmiv.h): the lowest indices, likelihoods 0, llk = lo
     if (sel) {
-        idx_out[t * ctop + rank] = ci;
-        if (lk_out) lk_out[t * ctop + rank] = exp(zc);
-        ord[wave][rank] = ci;
+        idx_out[t * ctop + rank] = dead ? rank : ci;
+        if (lk_out) lk_out[t * ctop + rank] = dead ? 0.0 : exp(zc);
+        ord[wave][rank] = dead ? rank : ci;
     }
     if (lane == 0) {
-        const double rest_llk = srel > 0.0 ? M + log(srel) : NINF;
+        const double rest_llk = (srel > 0.0 && !dead) ? M + log(srel) : NINF;
         if (nontop_llk) nontop_llk[t] = rest_llk;
-        if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+        if (nontop_lk) nontop_lk[t] = dead ? 0.0 : exp(rest_llk);
         if (llk_out) {
             const double tot = complete ? st + srel : st;
-            llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+            llk_out[t] = dead ? lo : fmin(fmax(M + log(tot), lo), hi);
         }
     }
     if (nontop_w) {
@@ -673,18 +677,19 @@ __global__ __launch_bounds__(256) void k_topc_rank2(const void *__restrict__ x, 
     srel += half_sum_f64_dpp(sr, hi2);
     srel += half_sum_f64_dpp((cd && !sel) ? gexp(zc - M) : 0.0, hi2);
     const double st = half_sum_f64_dpp(sel ? gexp(zc - M) : 0.0, hi2);
+    const bool dead = !(M > GMMIV_ZERO_LLK); // zero-likelihood frame (include/gmmiv.h): the lowest indices, likelihoods 0, llk = lo
     if (sel && alive) {
-        idx_out[t * ctop + rank] = ci;
-        if (lk_out) lk_out[t * ctop + rank] = exp(zc);
-        ord[f][32 + rank] = ci; // the upper half of the row is free (survivors use 0..31)
+        idx_out[t * ctop + rank] = dead ? rank : ci;
+        if (lk_out) lk_out[t * ctop + rank] = dead ? 0.0 : exp(zc);
+        ord[f][32 + rank] = dead ? rank : ci; // the upper half of the row is free (survivors use 0..31)
     }
     if (l32 == 0 && alive) {
-        const double rest_llk = srel > 0.0 ? M + log(srel) : NINF;
+        const double rest_llk = (srel > 0.0 && !dead) ? M + log(srel) : NINF;
         if (nontop_llk) nontop_llk[t] = rest_llk;
-        if (nontop_lk) nontop_lk[t] = exp(rest_llk);
+        if (nontop_lk) nontop_lk[t] = dead ? 0.0 : exp(rest_llk);
         if (llk_out) {
             const double tot = complete ? st + srel : st;
-            llk_out[t] = fmin(fmax(M + log(tot), lo), hi);
+            llk_out[t] = dead ? lo : fmin(fmax(M + log(tot), lo), hi);
         }
     }
     if (nontop_w) {

@@ -73,6 +73,18 @@ GpuServer::GpuServer(int device)
     if (gmmiv_ctx_create(device, nullptr, &_ctx) != 0) throw Exception(gmmiv_last_error());
 }
 GpuServer::~GpuServer() { gmmiv_ctx_destroy(_ctx); }
+void GpuServer::featureBufferCreated(bool clean)
+{
+    ++_buffers;
+    if (!clean) ++_dirtyBuffers;
+    (void)gmmiv_ctx_set_option(_ctx, "assume_finite", _dirtyBuffers == 0 ? 1 : 0);
+}
+void GpuServer::featureBufferDestroyed(bool clean)
+{
+    --_buffers;
+    if (!clean) --_dirtyBuffers;
+    (void)gmmiv_ctx_set_option(_ctx, "assume_finite", (_buffers > 0 && _dirtyBuffers == 0) ? 1 : 0);
+}
 void GpuServer::check(int rc) const
 {
     if (rc != 0) throw Exception(gmmiv_last_error());
@@ -185,10 +197,16 @@ FeatureBuffer::FeatureBuffer(GpuServer &srv, const float *frames, unsigned long 
     const size_t bytes = (size_t)(nFrames ? nFrames : 1) * vectSize * sizeof(float);
     hipcheck(hipMalloc((void **)&_dev, bytes), "FeatureBuffer: hipMalloc");
     if (nFrames) hipcheck(hipMemcpy(_dev, frames, (size_t)nFrames * vectSize * sizeof(float), hipMemcpyHostToDevice), "FeatureBuffer: upload");
+    // screened ONCE here instead of in every call of every iteration
+    int64_t bad = 0;
+    srv.check(gmmiv_count_unusable_frames(srv.ctx(), _dev, GMMIV_F32, (int64_t)nFrames, (int64_t)vectSize, (int)vectSize, &bad));
+    _unusable = (unsigned long)bad;
+    srv.featureBufferCreated(_unusable == 0);
 }
 FeatureBuffer::~FeatureBuffer()
 {
     (void)gmmiv_ctx_sync(_srv.ctx()); // kernels / copies in flight may still use the buffers
+    _srv.featureBufferDestroyed(_unusable == 0);
     if (_dev) (void)hipFree(_dev);
     if (_sel) (void)hipFree(_sel);
     if (_dRuns) (void)hipFree(_dRuns);

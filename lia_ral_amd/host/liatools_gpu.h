@@ -88,6 +88,7 @@ class FeatureBuffer {
     unsigned long getFeatureCount() const { return _n; }
     unsigned long getFirstFeatureIndexOfASource(unsigned long s) const { return _first.at(s); }
     const float *device() const { return _dev; }
+    unsigned long unusableFrames() const { return _unusable; } // frames with a NaN / infinite / absurd value, counted once at upload
     // device matrix [n x D] of the frames selected by the cluster, in cluster order.  The selection is ENQUEUED on the server's
     // stream (run table from pinned memory + k_gather_runs) and the pointer is valid in stream order: every gmmiv call of the same
     // server that follows sees the frames; the host does not wait.  A cluster that is one contiguous run is returned in place.
@@ -99,7 +100,7 @@ class FeatureBuffer {
     unsigned long buildRuns(const SegCluster &c, unsigned long &nSelected, unsigned long &firstFrame, size_t &nPieces);
     GpuServer &_srv;
     float *_dev = nullptr, *_sel = nullptr;
-    unsigned long _n, _d, _selCap = 0;
+    unsigned long _n, _d, _selCap = 0, _unusable = 0;
     std::vector<unsigned long> _first;
     int64_t *_hRuns = nullptr, *_dRuns = nullptr; // run table: pinned host copy, device copy
     size_t _runsCap = 0, _dRunsCap = 0;
@@ -138,12 +139,17 @@ class GpuServer {
     explicit GpuServer(int device = 0);
     ~GpuServer();
     gmmiv_ctx *ctx() { return _ctx; }
+    // FeatureBuffers register here: while every live buffer of this server was found free of unusable frames at upload (non-finite
+    // / absurd values, include/gmmiv.h "degenerate inputs"), the per-call screening pass of the C ABI is switched off
+    void featureBufferCreated(bool clean);
+    void featureBufferDestroyed(bool clean);
     void *stream() { return gmmiv_ctx_stream(_ctx); } // hipStream_t of the context: the host layer's own copies are ordered on it
     void sync() { check(gmmiv_ctx_sync(_ctx)); }
     void check(int rc) const; // throws Exception(gmmiv_last_error()) on rc != 0
 
   private:
     gmmiv_ctx *_ctx = nullptr;
+    long _buffers = 0, _dirtyBuffers = 0;
 };
 
 // Device copy of a MixtureGD

@@ -1,0 +1,199 @@
+"""Degenerate inputs through every frame-consuming entry point of the C ABI, on every kernel path (include/gmmiv.h, "DEGENERATE
+INPUTS"): non-finite and absurd feature values, frames further from every Gaussian than the arithmetic can resolve, a Gaussian
+of weight 0, occupancy 0 in the M-step, identical Gaussians (ties over a whole row), T = 0.  The rule: such a frame is a
+zero-likelihood frame -- llk = min_llk, lowest indices selected, a row of zero posteriors, and it adds nothing to any
+statistic.  No out-of-range index, no fault, no hang (every case runs under pytest-timeout)."""
+import numpy as np
+import pytest
+
+from conftest import make_frames, make_gmm
+from oracle import oracle as orc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+C, D, T = 256, 60, 900
+BAD = {5: np.nan, 9: np.inf, 11: -np.inf, 13: 1e30, 300: np.nan, 899: np.inf}   # frame -> value put into one of its dimensions
+FAR = 17                                                                         # a frame of finite, absurd values (kind 2)
+PATHS = [
+    {},                                            # defaults: fused top-C, stored-likelihood statistics, 8-wave shapes
+    {"topc_fused": 0},                             # top-C from the stored likelihoods
+    {"topc_fused": 0, "topc_z": 0},                # direct-form top-C kernel
+    {"stats_z": 0},                                # recomputing statistics kernel
+    {"wg_waves": 4},                               # 4-wave shapes of the two MFMA kernels
+    {"em_fused": 1},                               # single-pass cooperative EM kernel
+    {"short_calls": 0},
+]
+
+
+def _case():
+    w, mean, iv = make_gmm(C, D, seed=1)
+    x = make_frames(w, mean, iv, T, seed=2)
+    for t, v in BAD.items():
+        x[t, (7 * t) % D] = v
+    x[FAR, :] = 3e17                                # finite and inside the screening bound: every logit is about -1e37
+    zero = sorted(list(BAD) + [FAR])
+    good = np.setdiff1d(np.arange(T), zero)
+    return w, mean, iv, x, zero, good
+
+
+def _ctx(opts):
+    from lia_ral_amd import capi
+    ctx = capi.Context(0)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    return ctx
+
+
+@pytest.mark.parametrize("opts", PATHS, ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()) or "default")
+def test_zero_likelihood_frames_follow_the_rule_on_every_path(opts):
+    w, mean, iv, x, zero, good = _case()
+    ctx = _ctx(opts)
+    g = ctx.gmm(w, mean, iv)
+    og = orc.Gmm(w, mean, iv)
+    xg = x[good].astype(np.float64)
+    ctop = 10
+    # --- gmmiv_llk: min_llk for the zero-likelihood frames, the oracle's values elsewhere; sums count every frame
+    sums = np.zeros(2)
+    l = g.llk(x, sums=sums)
+    assert np.all(l[zero] == -200.0)
+    assert np.max(np.abs(l[good] - orc.llk(og, xg))) < 1e-9
+    assert sums[1] == T and abs(sums[0] - l.sum()) < 1e-6
+    # --- DETERMINE_TOP_DISTRIBS
+    d = g.llk_determine_top(x, ctop)
+    assert d["idx"].min() >= 0 and d["idx"].max() < C
+    do = orc.llk_determine_top(og, xg, ctop, True)
+    assert np.array_equal(d["idx"][good], do["idx"]) and np.max(np.abs(d["llk"][good] - do["llk"])) < 1e-9
+    for t in zero:
+        assert d["idx"][t].tolist() == list(range(ctop)) and np.all(d["lk"][t] == 0.0)
+        assert d["nontop_lk"][t] == 0.0 and d["nontop_llk"][t] == -np.inf and d["llk"][t] == -200.0
+        assert abs(d["nontop_w"][t] - (1.0 - w[:ctop].sum())) < 1e-12
+    # --- USE_TOP_DISTRIBS (one client, several clients)
+    rng = np.random.default_rng(0)
+    cl = [ctx.gmm(w, mean + rng.normal(0, 0.1, mean.shape), iv) for _ in range(3)]
+    u = cl[0].llk_use_top(x, d["idx"], d["nontop_llk"])
+    um = type(cl[0]).llk_use_top_multi(cl, x, d["idx"], d["nontop_llk"])
+    assert np.all(u[zero] == -200.0) and np.all(um[:, zero] == -200.0) and np.isfinite(u).all() and np.isfinite(um).all()
+    assert np.array_equal(um[0], u)
+    # --- posteriors: zero rows; every other row sums to 1
+    o = g.occ(x[:40])
+    for t in range(40):
+        if t in zero:
+            assert np.all(o[t] == 0.0)
+        else:
+            assert abs(o[t].sum() - 1.0) < 1e-9
+    # --- EM statistics: the zero-likelihood frames add nothing, anywhere
+    a = g.split_acc(g.em_accumulate(x))
+    ref = orc.em_accumulate(og, xg)
+    rel = lambda p, q: np.max(np.abs(p - q)) / np.max(np.abs(q))
+    assert a["count"] == len(good) and abs(a["occ"].sum() - len(good)) < 1e-6
+    assert rel(a["occ"], ref["occ"]) < 1e-9 and rel(a["sx"], ref["sx"]) < 1e-9 and rel(a["sxx"], ref["sxx"]) < 1e-9
+    assert abs(a["llk"] - ref["llk"]) < 1e-6 * abs(ref["llk"])
+    # --- Baum-Welch N / F: utterance bounds in the middle of the bad frames, one empty utterance
+    ub = np.array([0, 6, 6, 301, T])
+    N = np.zeros((4, C)); F = np.zeros((4, C * D))
+    g.tv_stats(x, ub, N, F)
+    utt = np.searchsorted(ub, good, side="right") - 1
+    No, Fo = orc.tv_stats(og, xg, utt, 4)
+    assert np.isfinite(N).all() and np.isfinite(F).all()
+    assert rel(N, No) < 1e-9 and rel(F, Fo) < 1e-9
+    if not opts:
+        assert ctx.set_option("screened_frames", 0) >= len(BAD)          # the screening saw them (the far frame is kind 2)
+    for m in cl:
+        m.close()
+    g.close(); ctx.close()
+
+
+def test_call_made_of_unusable_frames_only_and_empty_calls():
+    from lia_ral_amd import capi
+    w, mean, iv, x, zero, good = _case()
+    ctx = capi.Context(0)
+    g = ctx.gmm(w, mean, iv)
+    xb = x[[5, 9, 11]]                               # every frame unusable
+    assert np.all(g.llk(xb) == -200.0)
+    d = g.llk_determine_top(xb, 4)
+    assert np.array_equal(d["idx"], np.tile(np.arange(4), (3, 1))) and np.all(d["llk"] == -200.0)
+    acc = g.em_accumulate(xb)
+    assert np.all(acc == 0.0)
+    N = np.ones((1, C)); F = np.ones((1, C * D))
+    g.tv_stats(xb, np.array([0, 3]), N, F)
+    assert np.all(N == 0.0) and np.all(F == 0.0)     # rows are overwritten: an utterance without a usable frame has empty statistics
+    assert np.all(g.occ(xb) == 0.0)
+    e = np.zeros((0, D), np.float32)                 # T = 0
+    assert g.llk(e).shape == (0,) and g.llk_determine_top(e, 4)["idx"].shape == (0, 4) and g.occ(e).shape == (0, C)
+    acc = np.full(g.em_acc_len(), 3.0)
+    assert np.all(g.em_accumulate(e, acc=acc) == 3.0)                   # accumulators unchanged
+    import ctypes as ct
+    n = ct.c_int64(-1)
+    capi._chk(capi.lib.gmmiv_count_unusable_frames(ctx._h, capi._ptr(x), capi.F32, ct.c_int64(T), ct.c_int64(D), D, ct.byref(n)))
+    assert n.value == len(BAD)
+    g.close(); ctx.close()
+
+
+def test_assume_finite_skips_the_screening_and_clean_data_is_unchanged():
+    """Clean features: identical results with and without the screening pass (bitwise), nothing counted as screened."""
+    from lia_ral_amd import capi
+    w, mean, iv = make_gmm(C, D, seed=1)
+    x = make_frames(w, mean, iv, 3000, seed=4)
+    res = []
+    for af in (0, 1):
+        ctx = capi.Context(0)
+        ctx.set_option("assume_finite", af)
+        g = ctx.gmm(w, mean, iv)
+        res.append((g.llk(x), g.llk_determine_top(x, 10)["idx"], g.em_accumulate(x)))
+        assert ctx.set_option("screened_frames", 0) == 0
+        g.close(); ctx.close()
+    assert all(np.array_equal(p, q) for p, q in zip(res[0], res[1]))
+
+
+@pytest.mark.parametrize("opts", [{}, {"topc_fused": 0}, {"topc_fused": 0, "topc_z": 0}, {"wg_waves": 4}], ids=str)
+def test_weight_zero_gaussian_ties_and_dead_components(opts):
+    w, mean, iv = make_gmm(C, D, seed=1)
+    xs = make_frames(w, mean, iv, 500, seed=3)
+    ctx = _ctx(opts)
+    # a Gaussian of weight 0: likelihood 0 -- never selected, occupancy 0, the M-step keeps its mean / covariance and gives weight 0
+    w0 = w.copy(); w0[3] = 0.0; w0 /= w0.sum()
+    g = ctx.gmm(w0, mean, iv)
+    og = orc.Gmm(w0, mean, iv)
+    l = g.llk(xs)
+    assert np.max(np.abs(l - orc.llk(og, xs.astype(np.float64)))) < 1e-9
+    d = g.llk_determine_top(xs, 10)
+    assert not (d["idx"] == 3).any() and np.array_equal(d["idx"], orc.llk_determine_top(og, xs.astype(np.float64), 10, True)["idx"])
+    acc = g.em_accumulate(xs)
+    a = g.split_acc(acc)
+    assert a["occ"][3] == 0.0 and np.all(a["sx"][3] == 0.0) and np.all(a["sxx"][3] == 0.0) and abs(a["occ"].sum() - 500) < 1e-9
+    wm, mm, cc = g.em_get(acc, mean, 1.0 / iv)
+    assert wm[3] == 0.0 and np.array_equal(mm[3], mean[3]) and np.array_equal(cc[3], (1.0 / iv)[3]) and abs(wm.sum() - 1.0) < 1e-12
+    g.close()
+    # identical Gaussians: every logit of a row is the same -- the lowest indices win, in order; posteriors uniform
+    we = np.full(C, 1.0 / C); me = np.tile(mean[0], (C, 1)); ive = np.tile(iv[0], (C, 1))
+    g = ctx.gmm(we, me, ive)
+    d = g.llk_determine_top(xs, 10)
+    assert np.array_equal(d["idx"], np.tile(np.arange(10), (500, 1))) and np.isfinite(d["llk"]).all()
+    assert np.allclose(d["lk"], d["lk"][:, :1], rtol=1e-12)
+    a = g.split_acc(g.em_accumulate(xs))
+    assert np.allclose(a["occ"], 500.0 / C, rtol=1e-9)
+    o = g.occ(xs[:8])
+    assert np.allclose(o, 1.0 / C, rtol=1e-9)
+    g.close(); ctx.close()
+
+
+def test_host_layer_checks_a_feature_buffer_once_and_trains_past_bad_frames():
+    """liagpu::FeatureBuffer counts the unusable frames once, at upload: the per-call screening of the C ABI is then off for a clean
+    buffer and stays on for a dirty one.  TrainWorld on a stream with NaN / Inf frames inside the selected segment equals TrainWorld
+    on the stream without them (those frames add nothing, not even to the frame count); the global mean / covariance of
+    FrameAccGD is NOT screened -- a NaN goes into the sums like in the reference."""
+    from lia_ral_amd import host_capi as h
+    Cs, Ds, Ts = 16, 12, 4000
+    w, mean, iv = make_gmm(Cs, Ds, seed=5)
+    x = make_frames(w, mean, iv, Ts, seed=6)
+    w0 = np.full(Cs, 1.0 / Cs); mean0 = mean + np.random.default_rng(0).normal(0, 0.3, mean.shape); cov0 = np.ones((Cs, Ds)) * 2.0
+    # floors 0 / ceilings huge: varianceControl never clamps, so the (poisoned) global covariance of the dirty stream is not used
+    kw = dict(nb_it=3, init_floor=0.0, final_floor=0.0, init_ceil=1e30, final_ceil=1e30)
+    a = h.train_world(x, [0], [Ts], w0, mean0, cov0, **kw)
+    xd = np.insert(x, [100, 100, 2500], 0.0, axis=0)                   # three extra frames ...
+    xd[100, 3] = np.nan; xd[101, 0] = np.inf; xd[2502, 5] = -np.inf    # ... that are unusable
+    b = h.train_world(xd, [0], [Ts + 3], w0, mean0, cov0, **kw)
+    assert np.isfinite(a["global_cov"]).all() and not np.isfinite(b["global_cov"]).all()
+    assert np.isfinite(b["mean"]).all() and np.isfinite(b["cov"]).all() and np.isfinite(b["llk"]).all()
+    assert np.allclose(a["mean"], b["mean"], rtol=1e-9, atol=1e-11) and np.allclose(a["cov"], b["cov"], rtol=1e-9, atol=1e-11)
+    assert np.allclose(a["w"], b["w"], rtol=1e-9) and np.allclose(a["llk"], b["llk"], rtol=1e-11)
