@@ -71,7 +71,12 @@ const char *gmmiv_version(void);
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
  *   "tv_stats_split" 1 gmmiv_tv_stats on at most 16 utterances: every utterance in pieces of whole 64-frame tiles (more workgroups for the
- *                      N / F kernel), summed back in piece order; 0 = one segment per utterance
+ *                      N / F kernel), summed back in piece order; 0 = one segment per utterance.  The fp64 summation ORDER of an
+ *                      utterance's row therefore depends on how many utterances share the call (pieces for <= 16, one segment above):
+ *                      the same utterance extracted alone and inside a large batch gives N / F -- and i-vectors -- that agree to about
+ *                      1e-13 relative, not bitwise (both within the 1e-9 of the parity tests); set the option to 0 when a row must not
+ *                      depend on its neighbours
+ *   "assume_finite" 0  1: skip the screening pass for unusable feature values ("DEGENERATE INPUTS" below)
  *   "tv_tett_direct" 1 estimateTETt as one kernel that computes the lower triangles only and writes them packed (D <= 64); 0 = batched
  *                      GEMM into full matrices + pack
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one

@@ -408,10 +408,12 @@ class Context:
         W = acc.get("W")
         if W is None or W.shape[0] != U:
             W = np.empty((U, R))
-        _chk(lib.gmmiv_tv_estimate_a_and_c(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(invvar),
+        self._hook_error = None
+        rc = lib.gmmiv_tv_estimate_a_and_c(self._h, ct.c_int64(U), C, D, R, _ptr(N), _ptr(F), _ptr(Tm), _ptr(invvar),
                                            _ptr(tett), _ptr(W), _ptr(acc["A"]), _ptr(acc["Cmx"]), _ptr(acc["Rm"]),
-                                           _ptr(acc["r"]), _ptr(acc["meanW"])))
-        self._raise_hook_error()
+                                           _ptr(acc["r"]), _ptr(acc["meanW"]))
+        self._raise_hook_error()        # an exception parked by the hook comes first: it is the cause, and it never outlives this call
+        _chk(rc)
         acc["W"] = W
         return acc
 
@@ -424,9 +426,11 @@ class Context:
 
     def tv_min_divergence(self, Rm, r, meanW, means, Tm, n_sessions, C, D):
         R = Tm.shape[0]
-        _chk(lib.gmmiv_tv_min_divergence(self._h, C, D, R, ct.c_double(n_sessions), _ptr(Rm), _ptr(r), _ptr(meanW),
-                                         _ptr(means), _ptr(Tm)))
+        self._hook_error = None
+        rc = lib.gmmiv_tv_min_divergence(self._h, C, D, R, ct.c_double(n_sessions), _ptr(Rm), _ptr(r), _ptr(meanW),
+                                         _ptr(means), _ptr(Tm))
         self._raise_hook_error()
+        _chk(rc)
         return means, Tm
 
     def tv_orthonormalize_t(self, Tm):

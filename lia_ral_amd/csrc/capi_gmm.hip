@@ -914,6 +914,19 @@ int gmmiv_llk_use_top_multi(gmmiv_ctx *c, int n_clients, const gmmiv_gmm *const 
     if (T < 0 || !idx || !llk_out || ctop <= 0 || ctop > 64) { gmmiv_set_error("use_top_multi: bad argument"); return GMMIV_ERR_ARG; }
     if (mode == GMMIV_TOP_COMPLETE && !nontop_llk) { gmmiv_set_error("use_top_multi: COMPLETE mode needs nontop_llk"); return GMMIV_ERR_ARG; }
     const gmmiv_gmm *g0 = clients[0];
+    // a HOST output of [n_clients x T] is staged on the device: bound the staging to 1 GiB by going through the clients in groups
+    // (a long segment scored against thousands of models would otherwise grow the workspace without limit)
+    {
+        const size_t cap = (size_t)1 << 30, row = (size_t)(T > 0 ? T : 1) * sizeof(double);
+        if (n_clients > 1 && !gmmiv_is_device_ptr(llk_out) && (size_t)n_clients * row > cap) {
+            const int per = (int)(cap / row > 0 ? cap / row : 1);
+            for (int i0 = 0; i0 < n_clients; i0 += per) {
+                const int n = n_clients - i0 < per ? n_clients - i0 : per;
+                if ((rc = gmmiv_llk_use_top_multi(c, n, clients + i0, x, dt, T, ldx, ctop, idx, nontop_llk, mode, min_llk, max_llk, llk_out + (size_t)i0 * T))) return rc;
+            }
+            return GMMIV_OK;
+        }
+    }
     // one launch for all clients when the four-lanes-per-candidate kernel applies; otherwise client by client (same results either way)
     const bool batched = c->topc_z && c->topc_use_lanes == 4 && ctop <= 16 && g0->D % 2 == 0 && n_clients <= 65535 && T > 0;
     if (!batched) {

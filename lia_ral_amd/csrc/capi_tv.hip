@@ -340,7 +340,7 @@ static int tv_estep(gmmiv_ctx *c, int64_t U, int C, int D, int R, const double *
         GCHK(tvk_dgemm(c->stream, true, false, C, (int)P, (int)ns, 1.0, Ns, C, 0, Lp0, (long)P, 0, 1.0, d_a, (long)P, 0, 1));
         // A is complete once the last super-batch's GEMM is enqueued: a caller that shards the M-step starts its exchange here,
         // under the Cmx GEMM and the batch sums below (gmmiv_ctx_set_hook "tv_a_ready"; device accumulators only)
-        if (s0 + SB >= U && d_a == A_packed) c->hook_tv_a_ready.call();
+        if (s0 + SB >= U && d_a == A_packed) { c->hook_tv_a_ready.call(); GBIND(c); } // the hook may have driven another context on this thread: bind ours again
         GCHK(tvk_dgemm(c->stream, true, false, R, (int)SV, (int)ns, 1.0, Ws, R, 0, Fs, (long)SV, 0, 1.0, d_c, (long)SV, 0, 1));
         GCHK(tvk_batch_sum(c->stream, (long)P, (int)ns, Lp0, (long)P, d_rp, slabs)); // slabs (split-K workspace of aux) is free again
         GCHK(tvk_colsum_narrow(c->stream, R, (int)ns, Ws, R, d_r, d_mw, slabs)); // r and meanW both accumulate sum_u w_u; slabs is free again (stream order)
@@ -465,7 +465,7 @@ int gmmiv_tv_min_divergence(gmmiv_ctx *c, int C, int D, int R, double n_sessions
         GCHK(hipStreamSynchronize(c->stream)); // the host vectors go out of scope
     }
     // R is factored, T has not been read yet: a caller whose T is still arriving (all-gather begun before the call) joins it here
-    if (o_t.d == Tm) c->hook_md_factored.call();
+    if (o_t.d == Tm) { c->hook_md_factored.call(); GBIND(c); } // (see tv_a_ready)
     // mean += T^T meanW (old T), then T <- Ch T
     GCHK(tvk_vecmat_add(c->stream, R, (long)SV, i_mw.d, o_t.d, o_mean.d));
     if ((rc = c->scratch(WS_T6, (size_t)R * SV * 8, &p))) return rc;

@@ -330,6 +330,22 @@ def _update_own_block(update_t, a_mine, c_mine, C, D, Cb, rank, is_np):
     return t_mine
 
 
+def _fatal_between_collectives(e, rank, world, where):
+    """A rank that fails BETWEEN the begin and the join of an exchange cannot leave the iteration by raising: its peers are already
+    waiting in the collective it will never reach, and they would wait for ever.  With more than one rank the failure is therefore
+    fatal for the job: the error is printed and the process exits (the launcher takes the other ranks down).  One rank: the caller
+    re-raises."""
+    if world <= 1:
+        return
+    import os
+    import sys
+    import traceback
+    sys.stderr.write("[gmmiv] rank %d: failure in %s with collectives in flight -- aborting the job:\n" % (rank, where))
+    traceback.print_exception(type(e), e, e.__traceback__, file=sys.stderr)
+    sys.stderr.flush()
+    os._exit(70)
+
+
 def _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, t0):
     """E-step + sharded M-step + minDivergence of one iteration with the exchange started EARLY (option `overlap`):
       * the reduce-scatter of A (1.31 GB at 2048 x 400) begins from the "tv_a_ready" hook of gmmiv_tv_estimate_a_and_c, i.e. as
@@ -358,6 +374,9 @@ def _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, 
     ctx.set_hook("tv_a_ready", a_ready)
     try:
         acc = ops.estep()
+    except BaseException as e:          # noqa: BLE001
+        _fatal_between_collectives(e, rank, world, "the tv_a_ready hook / E-step")
+        raise
     finally:
         ctx.set_hook("tv_a_ready", None)
     t0 = lap("estep", t0)
@@ -391,6 +410,9 @@ def _tv_overlapped(ops, n_sessions_total, C, D, rank, world, coll, phases, lap, 
     ctx.set_hook("md_factored", md_factored)
     try:
         Tn = ops.min_divergence(acc, Tn, n_sessions_total)
+    except BaseException as e:          # noqa: BLE001
+        _fatal_between_collectives(e, rank, world, "the md_factored hook / minDivergence")
+        raise
     finally:
         ctx.set_hook("md_factored", None)
     lap("min_divergence", t0)
