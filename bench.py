@@ -892,16 +892,22 @@ def main():
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])     # the dominant kernel of the step
             kd = kernels[dom]
-            traffic = None
+            # HBM bytes per launch come from PMC counters, which only a rocprofv3 run can read: the figure of the committed PMC passes
+            # of the SAME command (tools/profile_r04.sh -> profiles/r04/bench_em_pmc_*.txt -> profiles/traffic.json), not of this run
+            traffic = traffic_src = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(dom + "_hbm_bytes_per_launch")
+                    tj = json.load(open(tf))
+                    traffic = tj.get(dom + "_hbm_bytes_per_launch")
+                    traffic_src = tj.get("source")
+                    if traffic and tj.get("frames_per_launch"):      # per launch of THIS run: the bytes scale with the frames of a launch
+                        traffic = traffic / tj["frames_per_launch"] * (T / kd["launches_per_step"])
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kd["tflops"], "peak": PEAK_F64_TFLOPS,
                                "unit": "TFLOP/s", "frac": kd["tflops"] / PEAK_F64_TFLOPS, "traffic": traffic,
-                               "kernel_ms": kd["ms_per_launch"], "launches_per_step": kd["launches_per_step"],
+                               "traffic_source": traffic_src, "kernel_ms": kd["ms_per_launch"], "launches_per_step": kd["launches_per_step"],
                                "algorithmic_flop_per_launch": KERNEL_FLOP[dom] * T * C / kd["launches_per_step"]}
         # the whole EM step against SURVEY 8(d)'s per-pair figure (240 logit + 242 statistics flop; this design
         # executes exactly that: every logit once, every statistic once), over all ranks

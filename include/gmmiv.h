@@ -59,7 +59,7 @@ const char *gmmiv_version(void);
  * contexts driven from one host thread keep their own settings, a context keeps its settings whichever thread drives it.
  *   "stats_z" 1        EM / Baum-Welch statistics from stored scaled likelihoods (k_llk_mfma<WZ> + k_stats_z);
  *                      0: the recomputing k_stats_mfma (also used for D > 60 or when the scratch does not fit)
- *   "z_scratch_mb"     likelihood scratch budget in MiB (default 65536, at most a quarter of the device's TOTAL memory):
+ *   "z_scratch_mb"     likelihood scratch budget in MiB (default 16384, at most a quarter of the device's TOTAL memory):
  *                      frames are processed in chunks that fit.  The chunk length -- and with it the fp64 summation
  *                      order -- depends only on this option, the model shape and the device model, not on the memory
  *                      free at call time: results are bitwise reproducible across runs and ranks.  (The order differs
