@@ -168,6 +168,38 @@ int liagpu_train_world_streams(int device, int nStream, const float *const *x, c
     })
 }
 
+// mixtureInit over nStream input streams (TrainTools.cpp:674-766, the call of TrainWorld.cpp:177): w / mean / cov [C], [C x D], [C x D] out;
+// counts [C] (nullable) = frames picked per component over all streams.  weight == NULL: 1 / nStream.
+int liagpu_mixture_init_streams(int device, int nStream, const float *const *x, const long *T, int D, const long *const *seg_begin,
+                                const long *const *seg_len, const long *nseg, const double *weight, int C, const double *global_cov,
+                                double nbFrameToSelect, long minLen, long maxLen, double *w, double *mean, double *cov, long *counts)
+{
+    GUARD({
+        if (nStream <= 0) throw Exception("mixtureInit: no input stream");
+        GpuServer srv(device);
+        std::vector<std::unique_ptr<FeatureBuffer> > fsTab;
+        std::vector<SegCluster> segTab(nStream);
+        std::vector<TrainStream> streams(nStream);
+        for (int i = 0; i < nStream; ++i) {
+            fsTab.emplace_back(new FeatureBuffer(srv, x[i], (unsigned long)T[i], (unsigned long)D));
+            segTab[i] = make_cluster(seg_begin[i], seg_len[i], nseg[i]);
+        }
+        for (int i = 0; i < nStream; ++i) {
+            streams[i].fs = fsTab[i].get(); streams[i].segs = &segTab[i];
+            streams[i].weight = weight ? weight[i] : 1.0 / (double)nStream;
+        }
+        MixtureGD world((unsigned long)C, (unsigned long)D);
+        MixtureInitCfg cfg;
+        cfg.nbFrameToSelect = nbFrameToSelect; cfg.baggedMinimalLength = (unsigned long)minLen; cfg.baggedMaximalLength = (unsigned long)maxLen;
+        std::vector<unsigned long> cnt;
+        mixtureInit(streams, world, std::vector<double>(global_cov, global_cov + D), cfg, &cnt);
+        memcpy(w, world.weights().data(), C * sizeof(double));
+        memcpy(mean, world.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov, world.covs().data(), (size_t)C * D * sizeof(double));
+        if (counts) for (int c = 0; c < C; ++c) counts[c] = (long)cnt[c];
+    })
+}
+
 // selectComponent(nbTop) + reduceModel + normalizeWeights, then (optionally) normalizeMixture to N(0, 1): the model edits of
 // TrainTools.cpp:1078-1098 on their own (host arithmetic only -- no device is touched)
 int liagpu_model_reduce_normalize(int C, int D, double *w, double *mean, double *cov, long nbTop, int normalize, int meanOnly, long nbIt,

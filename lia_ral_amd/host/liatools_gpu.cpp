@@ -521,16 +521,17 @@ void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedSeg, u
     }
 }
 
-// the picked frames of every component -> mean; covariance = globalCov; equal weights (TrainTools.cpp:651-658, :745-756)
-static void mixtureFromPicks(FeatureBuffer &fs, const std::vector<SegCluster> &perComponent, MixtureGD &world,
-                             const std::vector<double> &globalCov, std::vector<unsigned long> *frameCount)
+// the picked frames of every component (per stream) -> mean; covariance = globalCov; equal weights (TrainTools.cpp:651-658, :745-756)
+static void mixtureFromPicks(const std::vector<FeatureBuffer *> &fsTab, const std::vector<std::vector<SegCluster> > &perStreamComponent,
+                             MixtureGD &world, const std::vector<double> &globalCov, std::vector<unsigned long> *frameCount)
 {
     const unsigned long C = world.getDistribCount(), D = world.getVectSize();
     if (globalCov.size() != D) throw Exception("mixtureInit: globalCov must have vectSize entries");
     if (frameCount) frameCount->assign(C, 0);
     for (unsigned long c = 0; c < C; ++c) {
-        FrameAccGD acc;
-        if (!perComponent[c].empty()) accumulateStatFrame(acc, fs, perComponent[c]);
+        FrameAccGD acc; // ONE accumulator per component over all streams (TrainTools.cpp:686-690)
+        for (size_t s = 0; s < fsTab.size(); ++s)
+            if (!perStreamComponent[s][c].empty()) accumulateStatFrame(acc, *fsTab[s], perStreamComponent[s][c]);
         if (acc.getCount() == 0) {
             char msg[160];
             snprintf(msg, sizeof(msg), "mixtureInit: no frame was picked for component %lu (too few frames for %lu components)", c, C);
@@ -544,32 +545,45 @@ static void mixtureFromPicks(FeatureBuffer &fs, const std::vector<SegCluster> &p
     world.computeAll();
 }
 
+void mixtureInit(const std::vector<TrainStream> &streams, MixtureGD &world, const std::vector<double> &globalCov, const MixtureInitCfg &cfg,
+                 std::vector<unsigned long> *frameCount)
+{
+    const unsigned long C = world.getDistribCount();
+    if (streams.empty()) throw Exception("mixtureInit: no input stream");
+    std::vector<FeatureBuffer *> fsTab(streams.size());
+    std::vector<std::vector<SegCluster> > picks(streams.size(), std::vector<SegCluster>(C));
+    for (size_t stream = 0; stream < streams.size(); ++stream) {
+        fsTab[stream] = streams[stream].fs;
+        const SegCluster &selectedSegments = *streams[stream].segs;
+        const unsigned long total = totalFrame(selectedSegments);
+        if (total == 0) throw Exception("mixtureInit: no frame selected");
+        // the bagging probability of the stream, folded into several passes when it exceeds 1 (TrainTools.cpp:700-708, as written)
+        double proba = (cfg.nbFrameToSelect * streams[stream].weight) / (double)total;
+        unsigned long nbIt = 1;
+        double tmp = proba;
+        while (tmp > 1) {
+            ++nbIt;
+            tmp /= proba / (double)nbIt;
+            // tmp runs 2, 6/p, 24/p^2, ...: for 1 < p < ~4.9 it never returns below 1 and the reference spins forever here
+            if (nbIt > 64) throw Exception("mixtureInit: nbFrameToSelect * weight / totalFrame lies in (1, 4.9): the reference's fold of the bagging probability does not terminate for it (TrainTools.cpp:703-706); select fewer frames per component");
+        }
+        proba = tmp;
+        for (unsigned long baggedIt = 0; baggedIt < nbIt; ++baggedIt) {
+            SegCluster bagged;
+            srand((unsigned)(((stream + 1) * 100) + (baggedIt + 1)));
+            baggedSegments(selectedSegments, bagged, C, proba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
+            for (const Seg &s : bagged) picks[stream][s.labelCode].push_back(s); // accumulateStatFrame(*frameAcc[seg->labelCode()], ...)
+        }
+    }
+    mixtureFromPicks(fsTab, picks, world, globalCov, frameCount);
+}
+
 void mixtureInit(FeatureBuffer &fs, const SegCluster &selectedSegments, double streamWeight, MixtureGD &world,
                  const std::vector<double> &globalCov, const MixtureInitCfg &cfg, std::vector<unsigned long> *frameCount)
 {
-    const unsigned long C = world.getDistribCount();
-    const unsigned long total = totalFrame(selectedSegments);
-    if (total == 0) throw Exception("mixtureInit: no frame selected");
-    const unsigned long stream = 0;
-    // the bagging probability of the stream, folded into several passes when it exceeds 1 (TrainTools.cpp:700-708, as written)
-    double proba = (cfg.nbFrameToSelect * streamWeight) / (double)total;
-    unsigned long nbIt = 1;
-    double tmp = proba;
-    while (tmp > 1) {
-        ++nbIt;
-        tmp /= proba / (double)nbIt;
-        // tmp runs 2, 6/p, 24/p^2, ...: for 1 < p < ~4.9 it never returns below 1 and the reference spins forever here
-        if (nbIt > 64) throw Exception("mixtureInit: nbFrameToSelect * weight / totalFrame lies in (1, 4.9): the reference's fold of the bagging probability does not terminate for it (TrainTools.cpp:703-706); select fewer frames per component");
-    }
-    proba = tmp;
-    std::vector<SegCluster> picks(C);
-    for (unsigned long baggedIt = 0; baggedIt < nbIt; ++baggedIt) {
-        SegCluster bagged;
-        srand((unsigned)(((stream + 1) * 100) + (baggedIt + 1)));
-        baggedSegments(selectedSegments, bagged, C, proba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
-        for (const Seg &s : bagged) picks[s.labelCode].push_back(s); // accumulateStatFrame(*frameAcc[seg->labelCode()], ...)
-    }
-    mixtureFromPicks(fs, picks, world, globalCov, frameCount);
+    std::vector<TrainStream> one(1);
+    one[0].fs = &fs; one[0].segs = &selectedSegments; one[0].weight = streamWeight;
+    mixtureInit(one, world, globalCov, cfg, frameCount);
 }
 
 void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegCluster &selectedSegments, const std::vector<double> &globalCov,
@@ -588,7 +602,7 @@ void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegClust
             srand((unsigned)((c + 1) * (baggedIt + 1)));
             baggedSegments(selectedSegments, picks[c], proba, cfg.baggedMinimalLength, cfg.baggedMaximalLength);
         }
-    mixtureFromPicks(fs, picks, world, globalCov, frameCount);
+    mixtureFromPicks(std::vector<FeatureBuffer *>(1, &fs), std::vector<std::vector<SegCluster> >(1, picks), world, globalCov, frameCount);
 }
 
 // ---- component selection / model normalisation (TrainTools.cpp:175-227, :240-315) ---------------------------------

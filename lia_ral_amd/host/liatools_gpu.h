@@ -247,6 +247,10 @@ void baggedSegments(const SegCluster &selectedSegments, SegCluster &baggedSeg, u
 // A component that drew no frame has no mean: Exception (FrameAccGD::getMeanVect on an empty accumulator is undefined in
 // the reference).  frameCount (optional) receives the frames picked per component.
 struct MixtureInitCfg { unsigned long baggedMinimalLength = 3, baggedMaximalLength = 7; double nbFrameToSelect = 50; double baggedFrameProbabilityInit = 0.0; };
+struct TrainStream;
+// all input streams (fsTab / segTab / weightTab), the form TrainWorld.cpp:177 calls; the one-stream overload below forwards here
+void mixtureInit(const std::vector<TrainStream> &streams, MixtureGD &world, const std::vector<double> &globalCov, const MixtureInitCfg &cfg,
+                 std::vector<unsigned long> *frameCount = nullptr);
 void mixtureInit(FeatureBuffer &fs, const SegCluster &selectedSegments, double streamWeight, MixtureGD &world,
                  const std::vector<double> &globalCov, const MixtureInitCfg &cfg, std::vector<unsigned long> *frameCount = nullptr);
 void mixtureInitSingleStream(FeatureBuffer &fs, MixtureGD &world, const SegCluster &selectedSegments, const std::vector<double> &globalCov,

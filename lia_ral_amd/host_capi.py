@@ -81,6 +81,24 @@ def train_world_streams(xs, seg_begins, seg_lens, w, mean, cov, nb_it, weights=N
     return dict(w=w[:Co].copy(), mean=mean[:Co].copy(), cov=cov[:Co].copy(), global_mean=gm, global_cov=gc, llk=llk)
 
 
+def mixture_init_streams(xs, seg_begins, seg_lens, C, global_cov, weights=None, nb_frame_to_select=50.0, min_len=3, max_len=7, device=0):
+    """mixtureInit over several input streams (liagpu_mixture_init_streams) -> dict(w, mean, cov, counts)."""
+    ns = len(xs)
+    xs = [np.ascontiguousarray(x, np.float32) for x in xs]
+    D = xs[0].shape[1]
+    segs = [_segs(b, l) for b, l in zip(seg_begins, seg_lens)]
+    xp = (_fp * ns)(*[x.ctypes.data_as(_fp) for x in xs])
+    Tp = (ct.c_long * ns)(*[x.shape[0] for x in xs])
+    bp = (_lp * ns)(*[s[2] for s in segs]); lp = (_lp * ns)(*[s[3] for s in segs])
+    np_ = (ct.c_long * ns)(*[len(s[0]) for s in segs])
+    wt = None if weights is None else np.ascontiguousarray(weights, np.float64)
+    gc = np.ascontiguousarray(global_cov, np.float64)
+    w = np.empty(C); mean = np.empty((C, D)); cov = np.empty((C, D)); cnt = np.zeros(C, np.int64)
+    _chk(lib.liagpu_mixture_init_streams(device, ns, xp, Tp, D, bp, lp, np_, _d(wt), C, _d(gc), ct.c_double(nb_frame_to_select), ct.c_long(min_len),
+                                         ct.c_long(max_len), _d(w), _d(mean), _d(cov), cnt.ctypes.data_as(_lp)))
+    return dict(w=w, mean=mean, cov=cov, counts=cnt)
+
+
 def model_reduce_normalize(w, mean, cov, nb_top=0, normalize=False, mean_only=False, nb_it=1):
     """selectComponent(nbTop) + reduceModel + normalizeWeights, then normalizeMixture to N(0,1) (TrainTools.cpp:1078-1098); host only.
     Returns (w, mean, cov, order) with order = TabWeight's heaviest-first component order of the INPUT model."""

@@ -491,8 +491,11 @@ long orc_bagged_segments_multi(unsigned seed, const long *seg_begin, const long 
 /* mixtureInit, multi-stream form with one stream (TrainTools.cpp:674-766): per-component FrameAccGD over the picked frames;
  * mean[C x D] out (covariances = globalCov and weights = 1/C are the caller's), count[C] = frames picked per component.
  * x: [T x D] row-major.  Returns 0, or -1 if the scratch for the bagged list was too small. */
-int orc_mixture_init(int C, int D, const double *x, const long *seg_begin, const long *seg_len, long nseg, double stream_weight,
-                     double nb_frame_to_select, long min_len, long max_len, double *mean, double *count)
+/* one input stream of the multi-stream mixtureInit (TrainTools.cpp:698-735): its bagging probability (:700-708), its seeds
+ * srand((stream + 1) * 100 + baggedIt + 1) (:732), the picked frames added to the per-component sums / counts (ACCUMULATING:
+ * the frame accumulators of a component are shared by all streams, :686-690). */
+int orc_mixture_init_stream(long stream, int C, int D, const double *x, const long *seg_begin, const long *seg_len, long nseg,
+                            double stream_weight, double nb_frame_to_select, long min_len, long max_len, double *sum, double *count)
 {
     long total = 0;
     for (long s = 0; s < nseg; ++s) total += seg_len[s];
@@ -505,13 +508,11 @@ int orc_mixture_init(int C, int D, const double *x, const long *seg_begin, const
         if (nb_it > 64) return -2; /* the reference hangs here; the restatement reports it */
     }
     proba = tmp;
-    double *sum = (double *)calloc((size_t)C * D, sizeof(double));
-    for (int c = 0; c < C; ++c) count[c] = 0.0;
     const long cap = (total + nseg + 8) * C;
     long *ob = (long *)malloc(sizeof(long) * cap), *ol = (long *)malloc(sizeof(long) * cap), *lab = (long *)malloc(sizeof(long) * cap);
     int rc = 0;
     for (long it = 0; it < nb_it && !rc; ++it) {
-        const long n = orc_bagged_segments_multi((unsigned)((0 + 1) * 100 + (it + 1)), seg_begin, seg_len, nseg, C, proba, min_len, max_len,
+        const long n = orc_bagged_segments_multi((unsigned)((stream + 1) * 100 + (it + 1)), seg_begin, seg_len, nseg, C, proba, min_len, max_len,
                                                  ob, ol, lab, cap);
         if (n > cap) { rc = -1; break; }
         for (long k = 0; k < n; ++k) {                 /* accumulateStatFrame(*frameAcc[seg->labelCode()], ...) */
@@ -522,9 +523,18 @@ int orc_mixture_init(int C, int D, const double *x, const long *seg_begin, const
             }
         }
     }
+    free(ob); free(ol); free(lab);
+    return rc;
+}
+int orc_mixture_init(int C, int D, const double *x, const long *seg_begin, const long *seg_len, long nseg, double stream_weight,
+                     double nb_frame_to_select, long min_len, long max_len, double *mean, double *count)
+{
+    double *sum = (double *)calloc((size_t)C * D, sizeof(double));
+    for (int c = 0; c < C; ++c) count[c] = 0.0;
+    const int rc = orc_mixture_init_stream(0, C, D, x, seg_begin, seg_len, nseg, stream_weight, nb_frame_to_select, min_len, max_len, sum, count);
     for (int c = 0; c < C; ++c)
         for (int i = 0; i < D; ++i) mean[(size_t)c * D + i] = sum[(size_t)c * D + i] / count[c];
-    free(sum); free(ob); free(ol); free(lab);
+    free(sum);
     return rc;
 }
 

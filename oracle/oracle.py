@@ -208,6 +208,20 @@ def bagged_segments(seed, seg_begin, seg_len, p, min_len=3, max_len=7):
     return ob[:n].copy(), ol[:n].copy(), os_[:n].copy()
 
 
+def mixture_init_streams(C, xs, segs, weights, nb_frame_to_select=50.0, min_len=3, max_len=7):
+    """mixtureInit over several input streams (TrainTools.cpp:674-766): (mean [C x D], frames picked per component)."""
+    D = np.asarray(xs[0]).shape[1]
+    s = np.zeros((C, D)); cnt = np.zeros(C)
+    f = _lib().orc_mixture_init_stream
+    for st, (x, (sb, sl)) in enumerate(zip(xs, segs)):
+        x, xp = _d(x)
+        sb, sbp = _l(sb); sl, slp = _l(sl)
+        rc = f(ct.c_long(st), ct.c_int(C), ct.c_int(D), xp, sbp, slp, ct.c_long(len(sb)), ct.c_double(weights[st]),
+               ct.c_double(nb_frame_to_select), ct.c_long(min_len), ct.c_long(max_len), s.ctypes.data_as(c_dp), cnt.ctypes.data_as(c_dp))
+        assert rc == 0
+    return s / cnt[:, None], cnt
+
+
 def sort_by_weight(w):
     """TabWeight::_sortByWeight (GeneralTools.h:157-164): component indices, heaviest first (libc qsort)."""
     w, wp = _d(w)

@@ -966,3 +966,24 @@ def test_segment_means_on_the_device():
     again = ctx.segment_means(vd, sb)
     assert np.array_equal(got, again)           # fixed summation order
     ctx.close()
+
+
+def test_mixture_init_over_several_streams():
+    """mixtureInit(ms, fsTab, segTab, weightTab, nbStream, ...) (TrainTools.cpp:674-766, the call of TrainWorld.cpp:177): per stream its own
+    probability nbFrameToSelect * weight / totalFrame and its own seeds (stream + 1) * 100 + baggedIt + 1; ONE frame accumulator per
+    component over all streams -- against the oracle, stream by stream."""
+    from lia_ral_amd import host_capi as h
+    C, D = 10, 8
+    w, mean, iv = make_gmm(C, D, seed=31)
+    xs = [make_frames(w, mean, iv, 5000, seed=32), make_frames(w, mean, iv, 2200, seed=33)]
+    segs = [(np.array([0, 2600]), np.array([2400, 2300])), (np.array([100, 1200]), np.array([900, 950]))]
+    gcov = np.linspace(0.5, 1.5, D)
+    for weights in ([0.5, 0.5], [0.2, 0.8]):
+        got = h.mixture_init_streams(xs, [s[0] for s in segs], [s[1] for s in segs], C, gcov, weights=weights, nb_frame_to_select=60.0)
+        m_o, cnt_o = orc.mixture_init_streams(C, [x.astype(np.float64) for x in xs], segs, weights, nb_frame_to_select=60.0)
+        assert np.array_equal(got["counts"], cnt_o.astype(np.int64)) and got["counts"].min() > 0     # the same frames were drawn in every stream
+        assert relerr(got["mean"], m_o) < 1e-12
+        assert np.array_equal(got["cov"], np.tile(gcov, (C, 1))) and np.array_equal(got["w"], np.full(C, 1.0 / C))
+    one = h.mixture_init_streams(xs[:1], [segs[0][0]], [segs[0][1]], C, gcov, weights=[1.0], nb_frame_to_select=60.0)
+    ref = h.mixture_init(xs[0], segs[0][0], segs[0][1], C, gcov, nb_frame_to_select=60.0)                # the one-stream entry point
+    assert np.array_equal(one["mean"], ref["mean"]) and np.array_equal(one["counts"], ref["counts"])
