@@ -142,8 +142,8 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         times["solve_ms"] = (t2 - t1) * 1e3
         return t2 - t0
 
-    run()                      # warm-up (workspace allocation)
-    NRUN = 3
+    run(); run()               # two warm-ups (workspace allocation, then the allocator's second look at it)
+    NRUN = 5
     runs = []
     kms = {"k_llk_mfma": 0.0, "k_stats_z": 0.0}
     stats_ms = solve_ms = 0.0
@@ -169,6 +169,22 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
         ctx.set_option("em_fused", 0)
     dt = max_over_ranks(dt, world, dev)
     parity = ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None
+    # OPT-IN (not the default, not `value`): the N / F statistics with posteriors below 2^-100 skipped in groups (option "prune_log2":
+    # at most 2^-100 of posterior mass per pair is dropped -- 1e-30 absolute on N / F, invisible in L, aux and the i-vector, but a
+    # Gaussian whose whole occupancy is that small gets different statistics than the reference's sum of denormal-scale terms)
+    pruned = {}
+    try:
+        ctx.set_option("prune_log2", 100)
+        W_all = W.clone()
+        run()
+        pr = [run() for _ in range(NRUN)]
+        pdt = max_over_ranks(float(np.mean(pr)), world, dev)
+        pruned = {"prune_log2": 100, "value": U * world / pdt, "unit": "i-vectors/s", "stats_ms": times["stats_ms"], "k_stats_z_ms": times["k3_ms"],
+                  "max_rel_diff_ivectors_vs_default": float(((W - W_all).abs().max() / W_all.abs().max()).item()),
+                  "parity": ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None}
+        W.copy_(W_all)
+    finally:
+        ctx.set_option("prune_log2", 0)
     # 2.67 GFLOP per i-vector end to end = 3000 frames x 2048 x 362 (K1 logits 240 + K3 N / F statistics 122) + 448.5 M (solve)
     flop_stats = float(frames) * C * (FLOP_PER_PAIR_LLK + 2.0 * (1 + D)); flop_solve = 448.5e6
     tf = (flop_stats + flop_solve) * U / (dt / 1.0) / 1e12           # this rank's U i-vectors in dt (the slowest rank's time)
@@ -181,8 +197,8 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
             "time_fractions": {"k_llk_mfma": k1_ms / (dt * 1e3), "k_stats_z": k3_ms / (dt * 1e3), "solve": times["solve_ms"] / (dt * 1e3)}}
     return {"metric": "i-vectors/s (IvExtractor end-to-end, 2048-g UBM, rank 400, 3000-frame utterances)",
             "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "stats_ms": times["stats_ms"],
-            "solve_ms": times["solve_ms"], "timed_runs_ms": [r * 1e3 for r in runs], "timing": "mean of %d runs after one warm-up" % NRUN,
-            "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "roofline": roof, "fused_stats": fused,
+            "solve_ms": times["solve_ms"], "timed_runs_ms": [r * 1e3 for r in runs], "timing": "mean of %d runs after two warm-ups" % NRUN,
+            "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "roofline": roof, "pruned_posteriors": pruned, "fused_stats": fused,
             "_W": W, "_Tm": Tm, "_seed": 777 + rank}
 
 
