@@ -388,9 +388,8 @@ def host_layer(ctx, g, w, mean, iv, x, dev, T, headline_gpairs, secondary, compu
         err = float(np.max(np.abs(llr[0] - computetest["_llr"])))
         out["compute_test"] = {"frames": Tc, "clients": ncl, "ms_per_file": t, "ratio_to_torch_driven": ref_ms / t,
                                "torch_driven_ms": ref_ms, "llr": llr[0].tolist(),
-                               "note": "computeTestLLR also brings the per-frame log-likelihoods of world and clients back to the host (%d MB) for the "
-                                       "segment means, like the reference's frame loop produces them; the torch-driven passes leave them on the device"
-                                       % ((1 + ncl) * Tc * 8 // 1000000),
+                               "note": "computeTestLLR keeps the per-frame log-likelihoods of world and clients on the device and reads back the segment means "
+                                       "(gmmiv_segment_means); its buffers live in the server's grow-only workspace",
                                "parity": {"max_abs_err_llr_vs_torch_driven": err, "tolerance": 1e-9, "ok": bool(err < 1e-9)}}
         del xs
     return out

@@ -72,7 +72,26 @@ GpuServer::GpuServer(int device)
 {
     if (gmmiv_ctx_create(device, nullptr, &_ctx) != 0) throw Exception(gmmiv_last_error());
 }
-GpuServer::~GpuServer() { gmmiv_ctx_destroy(_ctx); }
+GpuServer::~GpuServer()
+{
+    (void)gmmiv_ctx_sync(_ctx);
+    for (void *p : _ws) if (p) (void)hipFree(p);
+    gmmiv_ctx_destroy(_ctx);
+}
+void *GpuServer::workspace(int slot, size_t bytes)
+{
+    if (slot < 0 || slot >= 8) throw Exception("GpuServer::workspace: bad slot");
+    if (bytes == 0) bytes = 8;
+    if (_wsBytes[slot] < bytes) {
+        sync(); // kernels in flight may still use the old block
+        if (_ws[slot]) hipcheck(hipFree(_ws[slot]), "GpuServer::workspace: hipFree");
+        _ws[slot] = nullptr; _wsBytes[slot] = 0;
+        const size_t want = bytes + bytes / 8;
+        hipcheck(hipMalloc(&_ws[slot], want), "GpuServer::workspace: hipMalloc");
+        _wsBytes[slot] = want;
+    }
+    return _ws[slot];
+}
 void GpuServer::featureBufferCreated(bool clean)
 {
     ++_buffers;
@@ -1020,19 +1039,12 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     topDistribsCount = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), world.getDistribCount());
     // the world's top-C' indices and non-top remainder STAY on the device for the client passes (40 bytes per frame that every
     // client would otherwise upload again); only the per-frame log-likelihoods come back for the segment means
-    struct DevBuf {
-        void *p = nullptr;
-        explicit DevBuf(size_t bytes) { hipcheck(hipMalloc(&p, bytes ? bytes : 8), "computeTestLLR: hipMalloc"); }
-        ~DevBuf() { if (p) (void)hipFree(p); }
-    };
-    DevBuf dIdx((size_t)n * topDistribsCount * sizeof(int32_t)), dNllk((size_t)n * sizeof(double));
-    int32_t *idx = (int32_t *)dIdx.p;
-    double *nllk = (double *)dNllk.p;
+    int32_t *idx = (int32_t *)srv.workspace(0, (size_t)n * topDistribsCount * sizeof(int32_t));
+    double *nllk = (double *)srv.workspace(1, (size_t)n * sizeof(double));
     // the per-frame log-likelihoods stay on the device as well: row 0 = world, rows 1.. = clients; only the segment means -- the
     // scores ComputeTest prints -- cross PCIe (8 bytes per frame and model did before: 40 MB for 10^6 frames and 4 clients)
     const size_t nRows = 1 + clients.size();
-    DevBuf dLlk((size_t)n * nRows * sizeof(double));
-    double *llkw = (double *)dLlk.p, *llkc = llkw + n;
+    double *llkw = (double *)srv.workspace(2, (size_t)n * nRows * sizeof(double)), *llkc = llkw + n;
     // world: DETERMINE_TOP_DISTRIBS on every frame (worldDecime = 1)
     srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), topDistribsCount, mode,
                                       minLLK, maxLLK, idx, nullptr, nullptr, nllk, nullptr, llkw));

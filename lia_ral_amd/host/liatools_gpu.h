@@ -145,11 +145,16 @@ class GpuServer {
     void featureBufferDestroyed(bool clean);
     void *stream() { return gmmiv_ctx_stream(_ctx); } // hipStream_t of the context: the host layer's own copies are ordered on it
     void sync() { check(gmmiv_ctx_sync(_ctx)); }
+    // grow-only device workspace of the host layer itself (slot 0..7): the per-file buffers of computeTestLLR live here instead of
+    // a hipMalloc / hipFree pair -- two device synchronisations -- per test file.  Contents do not survive a growth.
+    void *workspace(int slot, size_t bytes);
     void check(int rc) const; // throws Exception(gmmiv_last_error()) on rc != 0
 
   private:
     gmmiv_ctx *_ctx = nullptr;
     long _buffers = 0, _dirtyBuffers = 0;
+    void *_ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t _wsBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // Device copy of a MixtureGD
