@@ -117,8 +117,10 @@ struct gmmiv_ctx {
     Hook hook_tv_a_ready, hook_md_factored;
     // logit scratch budget (MiB): frames are processed in chunks that fit.  16 GiB = 0.85 M frames of a 2048-Gaussian model per
     // chunk.  Measured on 10 M frames (tools/alloc_time.py): 8 GiB 125.3, 16 GiB 126.4, 32 GiB 126.8, 64 GiB 126.9 G pairs/s -- but a
-    // hipMalloc above ~16 GiB takes the driver's slow path (fresh VRAM is cleared first): 1.1 s for 30 GB, 2.3 s for 60 GB on the FIRST
-    // call of a context, against 0.25 ms for 14 GB.  Rounds 1-3 used 64 GiB: 0.4 % more throughput for 2.3 s and 46 GB.
+    // large hipMalloc can take seconds: VRAM that earlier allocations (of this or of an earlier process) have dirtied is cleared at ~26 GB/s
+    // when it is handed out again -- once the driver's clean pool (about 60 GB on a fresh box, tools/malloc_probe_torch.py) is used up:
+    // 1.1 s for 30 GB, 2.3 s for 60 GB on the FIRST call of a context in a process that had held other buffers, against 0.25 ms for
+    // 14 GB.  Rounds 1-3 used 64 GiB: 0.4 % more throughput for up to 2.3 s and 46 GB.
     long z_scratch_mb = 16384;
     int n_cu = 256;
     // gmmiv_score_plda: K_n = (n FTJF + I)^-1 and log det K_n per session count n, kept while FTJF stays the same matrix
