@@ -315,6 +315,51 @@ int liagpu_train_target(int device, const float *x, long T, int D, const long *s
     })
 }
 
+static MAPCfg make_map_cfg(const char *method, int nbTrainIt, double baggedP, int flags, const double *reg, double alphaMean, const long *norm)
+{
+    MAPCfg cfg;
+    cfg.method = method ? method : "MAPOccDep";
+    cfg.nbTrainIt = (unsigned long)nbTrainIt; cfg.baggedFrameProbability = baggedP;
+    cfg.meanAdapt = (flags & 1) != 0; cfg.varAdapt = (flags & 2) != 0; cfg.weightAdapt = (flags & 4) != 0;
+    if (reg) { cfg.meanReg = reg[0]; cfg.varReg = reg[1]; cfg.weightReg = reg[2]; }
+    cfg.meanAlpha = alphaMean;
+    if (norm) { cfg.normalizeModel = norm[0] != 0; cfg.normalizeModelMeanOnly = norm[1] != 0; cfg.normalizeModelNbIt = (unsigned long)norm[2]; }
+    return cfg;
+}
+
+// TrainTarget with every MAPCfg parameter (TrainTools.cpp:95-147): method = MAPAlgo, flags bit 0 / 1 / 2 = meanAdapt / varAdapt /
+// weightAdapt, reg[3] = MAPRegFactorMean / Var / Weight, alphaMean = MAPAlphaMean, norm[3] = normalizeModel, MeanOnly, NbIt (nullable)
+int liagpu_train_target_ex(int device, const float *x, long T, int D, const long *seg_begin, const long *seg_len, long nseg, int C,
+                           const double *w, const double *mean, const double *cov, const char *method, int nbTrainIt, double baggedP,
+                           int flags, const double *reg, double alphaMean, const long *norm, double *w_out, double *mean_out, double *cov_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, x, (unsigned long)T, (unsigned long)D);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        MixtureGD world = make_mixture(C, D, w, mean, cov);
+        MixtureGD client = world;
+        adaptModel(fs, segs, world, client, make_map_cfg(method, nbTrainIt, baggedP, flags, reg, alphaMean, norm));
+        memcpy(w_out, client.weights().data(), C * sizeof(double));
+        memcpy(mean_out, client.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov_out, client.covs().data(), (size_t)C * D * sizeof(double));
+    })
+}
+
+// computeMAP on its own (TrainTools.cpp:543-556; host arithmetic only -- no device is touched): w / mean / cov = the ML estimate in, the
+// adapted model out
+int liagpu_compute_map(int C, int D, const double *w0, const double *mean0, const double *cov0, double *w, double *mean, double *cov,
+                       double frameCount, const char *method, int flags, const double *reg, double alphaMean)
+{
+    GUARD({
+        MixtureGD init = make_mixture(C, D, w0, mean0, cov0), client = make_mixture(C, D, w, mean, cov);
+        computeMAP(init, client, (unsigned long)frameCount, make_map_cfg(method, 1, 1.0, flags, reg, alphaMean, nullptr));
+        memcpy(w, client.weights().data(), C * sizeof(double));
+        memcpy(mean, client.means().data(), (size_t)C * D * sizeof(double));
+        memcpy(cov, client.covs().data(), (size_t)C * D * sizeof(double));
+    })
+}
+
 // TopGauss (TopGauss.cpp): compute on the selected frames, write the nbGaussian file, read it back into a fresh object, get() on
 // it with `ubm` and (when given) a second model.  out[0] = compute's mean llk, out[1] = get(ubm), out[2] = get(model2),
 // out[3] = frames capped; counts_out[T] / snsw_out[T] / snsl_out[T] (nullable) = what was stored; *nbgcnt_out = total entries.

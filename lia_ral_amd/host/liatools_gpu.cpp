@@ -1009,6 +1009,45 @@ void computeMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCf
     client = tmp;
 }
 
+void computeModelBasedMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount)
+{
+    computeMAPOccDep(initModel, client, cfg, frameCount); // TrainTools.cpp:491-536 repeats :445-489 statement for statement
+}
+void computeMAPConst(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg)
+{
+    const unsigned long C = initModel.getDistribCount(), D = initModel.getVectSize();
+    MixtureGD tmp = initModel;
+    if (cfg.meanAdapt) {
+        const double alpha = cfg.meanAlpha;
+        for (unsigned long c = 0; c < C; ++c)
+            for (unsigned long i = 0; i < D; ++i) tmp.setMean(c, (alpha * tmp.getMean(c, i)) + ((1 - alpha) * client.getMean(c, i)), i);
+    }
+    client = tmp; // variances and weights of the init model (the var / weight branches are "TODO" in the reference); no computeAll there either
+}
+void computeMAPConst2(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg)
+{
+    const unsigned long C = initModel.getDistribCount(), D = initModel.getVectSize();
+    MixtureGD tmp = initModel;
+    if (cfg.meanAdapt) {
+        const double alpha = cfg.meanAlpha;
+        for (unsigned long c = 0; c < C; ++c)
+            for (unsigned long i = 0; i < D; ++i) {
+                const double res = ((alpha * tmp.weight(c) * tmp.getMean(c, i)) + ((1 - alpha) * client.weight(c) * client.getMean(c, i))) /
+                                   (tmp.weight(c) * alpha + client.weight(c) * (1 - alpha));
+                tmp.setMean(c, res, i);
+            }
+    }
+    client = tmp;
+}
+void computeMAP(const MixtureGD &initModel, MixtureGD &client, unsigned long frameCount, const MAPCfg &cfg)
+{
+    if (cfg.method == "MAPConst") computeMAPConst(initModel, client, cfg);
+    else if (cfg.method == "MAPOccDep") computeMAPOccDep(initModel, client, cfg, (double)frameCount);
+    else if (cfg.method == "MAPConst2") computeMAPConst2(initModel, client, cfg);
+    else if (cfg.method == "MAPModelBased") computeModelBasedMAPOccDep(initModel, client, cfg, (double)frameCount);
+    // else: "mapAlgo unknown, No adaptation will be perform" (TrainTools.cpp:555) -- the client keeps its ML estimate
+}
+
 void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const MixtureGD &aprioriModel, MixtureGD &clientMixture,
                 const MAPCfg &mapCfg)
 {
@@ -1021,8 +1060,12 @@ void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const Mix
         srand((unsigned)trainIt);
         accumulateStatEM(fs, emAcc, bagged);
         clientMixture = emAcc.getEM();
-        computeMAPOccDep(aprioriModel, clientMixture, mapCfg, (double)(unsigned long)emAcc.getEMFeatureCount());
+        computeMAP(aprioriModel, clientMixture, (unsigned long)emAcc.getEMFeatureCount(), mapCfg);
+        if (mapCfg.normalizeModel) // normalizeMixture(clientMixture, mapCfg, config), TrainTools.cpp:898: target N(0, 1)
+            normalizeMixture(clientMixture, std::vector<double>(), std::vector<double>(), true,
+                             mapCfg.normalizeModelMeanOnly ? mapCfg.normalizeModelNbIt : 1, mapCfg.normalizeModelMeanOnly);
         dclient.update(clientMixture);
+        emAcc.setModel(clientMixture);
     }
 }
 

@@ -294,13 +294,22 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, FeatureBuffer &fs, con
                                      AllReduceFn allReduce = nullptr, void *user = nullptr, gmmiv_comm *comm = nullptr);
 
 // ---- TrainTarget: MAP adaptation (TrainTools.cpp:445-489 computeMAPOccDep, :871-904 adaptModel) ----
-struct MAPCfg { // MAPCfg::MAPCfg, TrainTools.cpp:95-140 (subset: method MAPOccDep)
+struct MAPCfg { // MAPCfg::MAPCfg, TrainTools.cpp:95-147
+    std::string method = "MAPOccDep"; // MAPAlgo: MAPOccDep, MAPModelBased (regulation factors), MAPConst, MAPConst2 (constant alpha)
     unsigned long nbTrainIt = 1;
     double baggedFrameProbability = 1.0;
     bool meanAdapt = true, varAdapt = false, weightAdapt = false;
     double meanReg = 16.0, varReg = 16.0, weightReg = 16.0; // MAPRegFactorMean / Var / Weight
+    double meanAlpha = 0.75;                                  // MAPAlphaMean: a-priori probability of the init model (MAPConst / MAPConst2)
+    bool normalizeModel = false, normalizeModelMeanOnly = false; // :125-135, applied after every iteration's MAP step (:898)
+    unsigned long normalizeModelNbIt = 1;
 };
-void computeMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount);
+void computeMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount);              // :445-489
+void computeModelBasedMAPOccDep(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg, double frameCount);    // :491-536 (the same arithmetic)
+void computeMAPConst(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg);                                  // :356-384 (means only)
+void computeMAPConst2(const MixtureGD &initModel, MixtureGD &client, const MAPCfg &cfg);                                 // :390-420 (means only, weight-balanced)
+// computeMAP (:543-556): dispatch on cfg.method; an unknown method leaves the client as it is (the reference prints a warning)
+void computeMAP(const MixtureGD &initModel, MixtureGD &client, unsigned long frameCount, const MAPCfg &cfg);
 // client model = MAP(aprioriModel, EM estimate on the selected frames), nbTrainIt times
 void adaptModel(FeatureBuffer &fs, const SegCluster &selectedSegments, const MixtureGD &aprioriModel,
                 MixtureGD &clientMixture, const MAPCfg &mapCfg);

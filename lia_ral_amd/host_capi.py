@@ -182,6 +182,37 @@ def train_target(x, seg_begin, seg_len, world, nb_it=1, mean_reg=16.0, device=0)
     return wo, mo, co
 
 
+def _map_flags(mean, var, weight):
+    return int(mean) | (int(var) << 1) | (int(weight) << 2)
+
+
+def train_target_ex(x, seg_begin, seg_len, world, method="MAPOccDep", nb_it=1, bagged_p=1.0, mean=True, var=False, weight=False,
+                    reg=(16.0, 16.0, 16.0), alpha_mean=0.75, normalize=False, normalize_mean_only=False, normalize_nb_it=1, device=0):
+    """TrainTarget (adaptModel, TrainTools.cpp:871-904) with every MAPCfg parameter -> (w, mean, cov)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, D = x.shape
+    w, m, c = [np.ascontiguousarray(a, np.float64) for a in world]
+    C = len(w)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    r = np.ascontiguousarray(reg, np.float64)
+    norm = (ct.c_long * 3)(int(normalize), int(normalize_mean_only), int(normalize_nb_it))
+    wo = np.empty(C); mo = np.empty((C, D)); co = np.empty((C, D))
+    _chk(lib.liagpu_train_target_ex(device, x.ctypes.data_as(_fp), ct.c_long(T), D, bp, lp, ct.c_long(len(b)), C, _d(w), _d(m), _d(c), method.encode(),
+                                    nb_it, ct.c_double(bagged_p), _map_flags(mean, var, weight), _d(r), ct.c_double(alpha_mean), norm, _d(wo), _d(mo), _d(co)))
+    return wo, mo, co
+
+
+def compute_map(method, init, client, frame_count, mean=True, var=False, weight=False, reg=(16.0, 16.0, 16.0), alpha_mean=0.75):
+    """computeMAP (TrainTools.cpp:543-556) on its own, host arithmetic only: init / client = (w, mean, cov) -> adapted (w, mean, cov)."""
+    w0, m0, c0 = [np.ascontiguousarray(a, np.float64) for a in init]
+    w, m, c = [np.array(a, np.float64, order="C", copy=True) for a in client]
+    C, D = m0.shape
+    r = np.ascontiguousarray(reg, np.float64)
+    _chk(lib.liagpu_compute_map(C, D, _d(w0), _d(m0), _d(c0), _d(w), _d(m), _d(c), ct.c_double(frame_count), method.encode(),
+                                _map_flags(mean, var, weight), _d(r), ct.c_double(alpha_mean)))
+    return w, m, c
+
+
 def topgauss(x, seg_begin, seg_len, ubm, top_gauss, path, top_distribs_count=64, model2_mean=None, complete=True, min_llk=-200.0,
              max_llk=200.0, device=0):
     """TopGauss::compute -> write(path) -> read(path) -> get (liagpu_topgauss).  Returns dict(llk_compute, llk_get, llk_get_model2,

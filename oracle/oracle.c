@@ -320,6 +320,56 @@ void orc_map_occdep_mean(int C, int D, const double *mean_world, const double *w
     }
 }
 
+/* computeMAP (LIA_SpkTools/src/TrainTools.cpp:543-556) and the four methods it dispatches to.  init = the a-priori model, client =
+ * the ML estimate (in) / the adapted model (out); method 0 MAPOccDep (:445-489) and 3 MAPModelBased (:491-536) -- the same
+ * statements --, 1 MAPConst (:356-384), 2 MAPConst2 (:390-420).  flags: bit 0 mean, 1 variance, 2 weight adaptation; reg[3] the
+ * regulation factors, alpha_mean the constant of the two Const methods (their variance / weight branches are TODO in the reference:
+ * the result carries the init model's variances and weights). */
+void orc_compute_map(int method, int C, int D, const double *w0, const double *mean0, const double *cov0, double *w, double *mean, double *cov,
+                     double frame_count, int flags, const double *reg, double alpha_mean)
+{
+    const size_t CD = (size_t)C * D;
+    double *tw = malloc(sizeof(double) * C), *tm = malloc(sizeof(double) * CD), *tc = malloc(sizeof(double) * CD);
+    memcpy(tw, w0, sizeof(double) * C); memcpy(tm, mean0, sizeof(double) * CD); memcpy(tc, cov0, sizeof(double) * CD);
+    if (method == 0 || method == 3) {
+        if (flags & 3)
+            for (int c = 0; c < C; ++c) {
+                const double alpha = w[c] * frame_count;
+                if (flags & 1) {
+                    const double a = alpha / (alpha + reg[0]);
+                    for (int k = 0; k < D; ++k) tm[(size_t)c * D + k] = ((1 - a) * mean0[(size_t)c * D + k]) + (a * mean[(size_t)c * D + k]);
+                }
+                if (flags & 2) {
+                    const double a = alpha / (alpha + reg[1]);
+                    for (int k = 0; k < D; ++k)
+                        tc[(size_t)c * D + k] = ((1 - a) * cov0[(size_t)c * D + k]) + (a * cov[(size_t)c * D + k]) +
+                                                (((1 - a) * a) * pow(mean0[(size_t)c * D + k] - mean[(size_t)c * D + k], 2));
+                }
+            }
+        if (flags & 4) {
+            double sum = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const double alpha = w[c] * frame_count, a = alpha / (alpha + reg[2]);
+                tw[c] = a * w[c] + ((1 - a) * w0[c]);
+                sum += tw[c];
+            }
+            for (int c = 0; c < C; ++c) tw[c] /= sum;
+        }
+    } else if (method == 1) {
+        if (flags & 1)
+            for (size_t e = 0; e < CD; ++e) tm[e] = (alpha_mean * tm[e]) + ((1 - alpha_mean) * mean[e]);
+    } else if (method == 2) {
+        if (flags & 1)
+            for (int c = 0; c < C; ++c)
+                for (int k = 0; k < D; ++k) {
+                    const size_t e = (size_t)c * D + k;
+                    tm[e] = ((alpha_mean * tw[c] * tm[e]) + ((1 - alpha_mean) * w[c] * mean[e])) / (tw[c] * alpha_mean + w[c] * (1 - alpha_mean));
+                }
+    } else { free(tw); free(tm); free(tc); return; } /* unknown method: no adaptation (:555) */
+    memcpy(w, tw, sizeof(double) * C); memcpy(mean, tm, sizeof(double) * CD); memcpy(cov, tc, sizeof(double) * CD);
+    free(tw); free(tm); free(tc);
+}
+
 /* FrameAccGD::accumulate / getMeanVect / getCovVect: sum x, sum x^2, n; mean, BIASED diagonal
  * covariance sum x^2/n - mean^2 (AccumulateStat.cpp:387-396, TrainTools.cpp:593-601; pinned by KAT-4). */
 void orc_frame_acc(int D, const double *x, long T, double *sum, double *sumsq, double *count)

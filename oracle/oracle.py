@@ -182,6 +182,21 @@ def map_occdep_mean(mean_world, w_ml, mean_ml, frame_count, reg):
     return out
 
 
+MAP_METHODS = {"MAPOccDep": 0, "MAPConst": 1, "MAPConst2": 2, "MAPModelBased": 3}
+
+
+def compute_map(method, init, client, frame_count, mean=True, var=False, weight=False, reg=(16.0, 16.0, 16.0), alpha_mean=0.75):
+    """computeMAP (TrainTools.cpp:543-556): init / client = (w, mean, cov); returns the adapted (w, mean, cov)."""
+    w0, m0, c0 = [np.ascontiguousarray(a, np.float64) for a in init]
+    w, m, c = [np.array(a, np.float64, order="C", copy=True) for a in client]
+    C, D = m0.shape
+    r = np.ascontiguousarray(reg, np.float64)
+    _lib().orc_compute_map(ct.c_int(MAP_METHODS.get(method, -1)), ct.c_int(C), ct.c_int(D), w0.ctypes.data_as(c_dp), m0.ctypes.data_as(c_dp),
+                           c0.ctypes.data_as(c_dp), w.ctypes.data_as(c_dp), m.ctypes.data_as(c_dp), c.ctypes.data_as(c_dp), ct.c_double(frame_count),
+                           ct.c_int(int(mean) | (int(var) << 1) | (int(weight) << 2)), r.ctypes.data_as(c_dp), ct.c_double(alpha_mean))
+    return w, m, c
+
+
 def frame_acc(x):
     x, xp = _d(x)
     T, D = x.shape

@@ -354,3 +354,31 @@ def test_id_file_of_another_job_is_never_accepted(tmp_path, monkeypatch):
     monkeypatch.setenv("MASTER_PORT", "29513")
     with pytest.raises(capi.GmmivError, match="waited"):
         capi.Comm.exchange_id_file(path, 1, 0.3)
+
+
+def test_compute_map_methods_host_logic():
+    """computeMAP (TrainTools.cpp:543-556) and the four methods it dispatches to -- MAPOccDep, MAPModelBased (the same statements),
+    MAPConst, MAPConst2 -- with mean / variance / weight adaptation, in the C++ host layer against the oracle restatement (host
+    arithmetic, no device).  An unknown method leaves the ML estimate as it is, like the reference ("No adaptation will be perform")."""
+    from lia_ral_amd import host_capi as h
+    from oracle import oracle as orc
+    rng = np.random.default_rng(4)
+    C, D = 12, 6
+    init = (rng.dirichlet(np.ones(C)), rng.normal(size=(C, D)), rng.uniform(0.5, 2.0, (C, D)))
+    client = (rng.dirichlet(np.ones(C)), init[1] + rng.normal(0, 0.3, (C, D)), rng.uniform(0.5, 2.0, (C, D)))
+    for method in ("MAPOccDep", "MAPModelBased", "MAPConst", "MAPConst2"):
+        for mean, var, weight in ((True, False, False), (True, True, True), (False, True, False)):
+            kw = dict(mean=mean, var=var, weight=weight, reg=(14.0, 9.0, 20.0), alpha_mean=0.6)
+            got = h.compute_map(method, init, client, 731.0, **kw)
+            ref = orc.compute_map(method, init, client, 731.0, **kw)
+            for g, r in zip(got, ref):
+                assert np.allclose(g, r, rtol=1e-14, atol=0), method
+            if method.startswith("MAPConst"):       # means only: variances and weights are the init model's
+                assert np.array_equal(got[0], init[0]) and np.array_equal(got[2], init[2])
+                assert mean == (not np.array_equal(got[1], init[1]))
+    same = h.compute_map("MLLR?", init, client, 731.0)
+    assert all(np.array_equal(a, b) for a, b in zip(same, client))
+    # MAPOccDep, mean only, one component by hand
+    w, m, c = h.compute_map("MAPOccDep", init, client, 100.0, reg=(10.0, 10.0, 10.0))
+    a = client[0][3] * 100.0 / (client[0][3] * 100.0 + 10.0)
+    assert np.allclose(m[3], (1 - a) * init[1][3] + a * client[1][3], rtol=1e-15) and np.array_equal(c, init[2]) and np.array_equal(w, init[0])

@@ -987,3 +987,41 @@ def test_mixture_init_over_several_streams():
     one = h.mixture_init_streams(xs[:1], [segs[0][0]], [segs[0][1]], C, gcov, weights=[1.0], nb_frame_to_select=60.0)
     ref = h.mixture_init(xs[0], segs[0][0], segs[0][1], C, gcov, nb_frame_to_select=60.0)                # the one-stream entry point
     assert np.array_equal(one["mean"], ref["mean"]) and np.array_equal(one["counts"], ref["counts"])
+
+
+@pytest.mark.parametrize("method,opts", [("MAPOccDep", dict(var=True, weight=True)), ("MAPModelBased", dict()), ("MAPConst", dict()),
+                                         ("MAPConst2", dict()), ("MAPOccDep", dict(normalize=True))])
+def test_adapt_model_methods_and_normalisation(method, opts):
+    """adaptModel (TrainTools.cpp:871-904): per iteration baggedSegments (before srand(trainIt), as written), EM statistics on the HIP path,
+    computeMAP with the configured method, optional normalizeMixture -- against the same loop assembled from oracle pieces."""
+    from lia_ral_amd import host_capi as h
+    C, D, T = 16, 10, 5000
+    w, mean, iv = make_gmm(C, D, seed=41)
+    x = make_frames(w, mean, iv, T, seed=42)
+    rng = np.random.default_rng(5)
+    world = (w, mean + rng.normal(0, 0.2, mean.shape), 1.0 / iv)
+    seg_begin, seg_len = np.array([0, 2600]), np.array([2400, 2300])
+    nb_it, p, reg, alpha = 2, 0.7, (12.0, 8.0, 30.0), 0.6
+    opts = dict(opts)
+    normalize = opts.pop("normalize", False)
+    kw = dict(mean=True, var=False, weight=False); kw.update(opts)
+    import ctypes as ct
+    libc = ct.CDLL("libc.so.6")
+    # adaptModel bags BEFORE it seeds (baggedSegments, then srand(trainIt), :880-883): iteration 0 draws from the state the process is in
+    # -- set here through the same libc --, iteration it > 0 from srand(it - 1)
+    libc.srand(777)
+    got = h.train_target_ex(x, seg_begin, seg_len, world, method=method, nb_it=nb_it, bagged_p=p, reg=reg, alpha_mean=alpha, normalize=normalize, **kw)
+    xd = x.astype(np.float64)
+    cw, cm, cc = [np.array(a, np.float64) for a in world]
+    for it in range(nb_it):
+        bb, bl, _ = orc.bagged_segments(777 if it == 0 else it - 1, seg_begin, seg_len, p, 3, 7)
+        fr = np.concatenate([np.arange(b, b + n) for b, n in zip(bb, bl)])
+        acc = orc.em_accumulate(orc.Gmm(cw, cm, 1.0 / cc), xd[fr])
+        mw, mm, mc = orc.em_get(acc, cm, cc)
+        cw, cm, cc = orc.compute_map(method, world, (mw, mm, mc), float(int(acc["count"])), reg=reg, alpha_mean=alpha, **kw)
+        if normalize:
+            cm, cc = orc.normalize_mixture(cw, cm, cc, 1, False)
+    assert relerr(got[0], cw) < 1e-9 and relerr(got[1], cm) < 1e-9 and relerr(got[2], cc) < 1e-9
+    if normalize:       # global moments of the adapted mixture: mean 0, variance 1
+        m1 = (got[0][:, None] * got[1]).sum(0); m2 = (got[0][:, None] * (got[2] + got[1] ** 2)).sum(0)
+        assert np.max(np.abs(m1)) < 1e-10 and np.max(np.abs(m2 - 1.0)) < 1e-10
