@@ -200,6 +200,28 @@ int liagpu_mixture_init_streams(int device, int nStream, const float *const *x, 
     })
 }
 
+// meanLikelihood over several feature servers (GeneralTools.cpp:599-607), optionally weighted by one decision value per server (:610-624)
+int liagpu_mean_llk_streams(int device, int nStream, const float *const *x, const long *T, int D, const long *const *seg_begin,
+                            const long *const *seg_len, const long *nseg, const double *decision, int C, const double *w, const double *mean,
+                            const double *cov, double minLLK, double maxLLK, double *out)
+{
+    GUARD({
+        GpuServer srv(device);
+        std::vector<std::unique_ptr<FeatureBuffer> > fsTab;
+        std::vector<SegCluster> segTab(nStream);
+        std::vector<TrainStream> streams(nStream);
+        for (int i = 0; i < nStream; ++i) {
+            fsTab.emplace_back(new FeatureBuffer(srv, x[i], (unsigned long)T[i], (unsigned long)D));
+            segTab[i] = make_cluster(seg_begin[i], seg_len[i], nseg[i]);
+        }
+        for (int i = 0; i < nStream; ++i) { streams[i].fs = fsTab[i].get(); streams[i].segs = &segTab[i]; }
+        MixtureGD model = make_mixture(C, D, w, mean, cov);
+        DeviceMixture dm(srv, model);
+        *out = decision ? meanLikelihood(streams, dm, std::vector<double>(decision, decision + nStream), minLLK, maxLLK)
+                        : meanLikelihood(streams, dm, minLLK, maxLLK);
+    })
+}
+
 // selectComponent(nbTop) + reduceModel + normalizeWeights, then (optionally) normalizeMixture to N(0, 1): the model edits of
 // TrainTools.cpp:1078-1098 on their own (host arithmetic only -- no device is touched)
 int liagpu_model_reduce_normalize(int C, int D, double *w, double *mean, double *cov, long nbTop, int normalize, int meanOnly, long nbIt,

@@ -425,6 +425,32 @@ double accumulateStatLLK(FeatureBuffer &fs, DeviceMixture &m, const SegCluster &
     return sums[1] > 0 ? sums[0] / sums[1] : 0.0;
 }
 
+void accumulateStatLLK(LLKAcc &llkAcc, FeatureBuffer &fs, DeviceMixture &m, const SegCluster &selectedSegments, double weight, double minLLK,
+                       double maxLLK)
+{
+    unsigned long n = 0;
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    double sums[2] = {0.0, 0.0};
+    srv.check(gmmiv_llk(srv.ctx(), m.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), minLLK, maxLLK, nullptr, sums));
+    llkAcc.sumLLK += weight * sums[0]; // computeAndAccumulateLLK(f, weight): sum of w llk, sum of w
+    llkAcc.sumWeight += weight * sums[1];
+}
+double meanLikelihood(const std::vector<TrainStream> &streams, DeviceMixture &model, double minLLK, double maxLLK)
+{
+    LLKAcc acc;
+    for (const TrainStream &st : streams) accumulateStatLLK(acc, *st.fs, model, *st.segs, 1.0, minLLK, maxLLK);
+    return acc.getMeanLLK();
+}
+double meanLikelihood(const std::vector<TrainStream> &streams, DeviceMixture &model, const std::vector<double> &decision, double minLLK,
+                      double maxLLK)
+{
+    if (decision.size() != streams.size()) throw Exception("meanLikelihood: one decision weight per feature server expected");
+    LLKAcc acc;
+    for (size_t i = 0; i < streams.size(); ++i) accumulateStatLLK(acc, *streams[i].fs, model, *streams[i].segs, decision[i], minLLK, maxLLK);
+    return acc.getMeanLLK();
+}
+
 void accumulateStatFrame(FrameAccGD &frameAcc, FeatureBuffer &fs, const SegCluster &selectedSegments)
 {
     if (frameAcc.acc.empty()) {

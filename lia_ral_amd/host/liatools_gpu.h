@@ -210,6 +210,22 @@ double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selec
 // accumulateStatLLK (AccumulateStat.cpp:69-94): mean clamped llk over the cluster (getMeanLLK)
 double accumulateStatLLK(FeatureBuffer &fs, DeviceMixture &m, const SegCluster &selectedSegments, double minLLK,
                          double maxLLK);
+// MixtureStat in LLK mode: resetLLK / computeAndAccumulateLLK(f, weight) (batched) / getMeanLLK = sum w llk / sum w -- the accumulator the
+// meanLikelihood family drives over one cluster, over several streams (GeneralTools.cpp:589-607) and over weighted feature servers
+// (`decision[nbFs]` as the frame weight: AccumulateStat.cpp:344-379, GeneralTools.cpp:610-624)
+struct LLKAcc {
+    double sumLLK = 0.0, sumWeight = 0.0;
+    void resetLLK() { sumLLK = sumWeight = 0.0; }
+    double getMeanLLK() const { return sumWeight > 0.0 ? sumLLK / sumWeight : 0.0; }
+    double getAccumulatedLLK() const { return sumLLK; }
+    double getAccumulatedLLKFeatureCount() const { return sumWeight; }
+};
+void accumulateStatLLK(LLKAcc &llkAcc, FeatureBuffer &fs, DeviceMixture &m, const SegCluster &selectedSegments, double weight, double minLLK,
+                       double maxLLK);
+struct TrainStream;
+double meanLikelihood(const std::vector<TrainStream> &streams, DeviceMixture &model, double minLLK, double maxLLK);                  // :599-607
+double meanLikelihood(const std::vector<TrainStream> &streams, DeviceMixture &model, const std::vector<double> &decision, double minLLK,
+                      double maxLLK);                                                                                                  // :610-624
 // accumulateStatFrame (AccumulateStat.cpp:387-410)
 void accumulateStatFrame(FrameAccGD &frameAcc, FeatureBuffer &fs, const SegCluster &selectedSegments);
 

@@ -169,6 +169,24 @@ def mean_llk(x, seg_begin, seg_len, model, min_llk=-200.0, max_llk=200.0, device
     return out.value
 
 
+def mean_llk_streams(xs, seg_begins, seg_lens, model, decision=None, min_llk=-200.0, max_llk=200.0, device=0):
+    """meanLikelihood over several feature servers, optionally weighted by one decision value per server (GeneralTools.cpp:599-624)."""
+    ns = len(xs)
+    xs = [np.ascontiguousarray(x, np.float32) for x in xs]
+    D = xs[0].shape[1]
+    w, m, c = [np.ascontiguousarray(a, np.float64) for a in model]
+    segs = [_segs(b, l) for b, l in zip(seg_begins, seg_lens)]
+    xp = (_fp * ns)(*[x.ctypes.data_as(_fp) for x in xs])
+    Tp = (ct.c_long * ns)(*[x.shape[0] for x in xs])
+    bp = (_lp * ns)(*[s[2] for s in segs]); lp = (_lp * ns)(*[s[3] for s in segs])
+    np_ = (ct.c_long * ns)(*[len(s[0]) for s in segs])
+    dec = None if decision is None else np.ascontiguousarray(decision, np.float64)
+    out = ct.c_double(0.0)
+    _chk(lib.liagpu_mean_llk_streams(device, ns, xp, Tp, D, bp, lp, np_, _d(dec), len(w), _d(w), _d(m), _d(c), ct.c_double(min_llk),
+                                     ct.c_double(max_llk), ct.byref(out)))
+    return out.value
+
+
 def train_target(x, seg_begin, seg_len, world, nb_it=1, mean_reg=16.0, device=0):
     """TrainTarget: mean-only MAPOccDep adaptation of the world model; returns (w, mean, cov)."""
     x = np.ascontiguousarray(x, np.float32)

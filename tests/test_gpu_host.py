@@ -1025,3 +1025,25 @@ def test_adapt_model_methods_and_normalisation(method, opts):
     if normalize:       # global moments of the adapted mixture: mean 0, variance 1
         m1 = (got[0][:, None] * got[1]).sum(0); m2 = (got[0][:, None] * (got[2] + got[1] ** 2)).sum(0)
         assert np.max(np.abs(m1)) < 1e-10 and np.max(np.abs(m2 - 1.0)) < 1e-10
+
+
+def test_mean_likelihood_over_streams_and_decision_weights():
+    """meanLikelihood on a set of input streams (GeneralTools.cpp:599-607) and with one decision weight per feature server
+    (computeAndAccumulateLLK(f, weight): :610-624, AccumulateStat.cpp:344-379): sum w llk / sum w, against the oracle."""
+    from lia_ral_amd import host_capi as h
+    C, D = 16, 10
+    w, mean, iv = make_gmm(C, D, seed=51)
+    xs = [make_frames(w, mean, iv, 1500, seed=52), make_frames(w, mean, iv, 900, seed=53) * 1.5]
+    segs = [(np.array([0, 800]), np.array([700, 650])), (np.array([50]), np.array([800]))]
+    og = orc.Gmm(w, mean, iv)
+    llk = []
+    for x, (sb, sl) in zip(xs, segs):
+        fr = np.concatenate([np.arange(b, b + n) for b, n in zip(sb, sl)])
+        llk.append(orc.llk(og, x[fr].astype(np.float64)))
+    model = (w, mean, 1.0 / iv)
+    got = h.mean_llk_streams(xs, [s[0] for s in segs], [s[1] for s in segs], model)
+    assert abs(got - np.concatenate(llk).mean()) < 1e-9
+    dec = [0.25, 2.0]
+    got = h.mean_llk_streams(xs, [s[0] for s in segs], [s[1] for s in segs], model, decision=dec)
+    ref = sum(d * l.sum() for d, l in zip(dec, llk)) / sum(d * len(l) for d, l in zip(dec, llk))
+    assert abs(got - ref) < 1e-9
