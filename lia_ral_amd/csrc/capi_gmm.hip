@@ -9,10 +9,12 @@
 
 static thread_local char g_err[512] = "";
 
-static const gmmiv_kopts g_kopts_default;
-static thread_local const gmmiv_kopts *g_kopts_cur = &g_kopts_default;
-const gmmiv_kopts &gmmiv_kopts_cur() { return *g_kopts_cur; }
-void gmmiv_kopts_bind(const gmmiv_kopts *ko) { g_kopts_cur = ko ? ko : &g_kopts_default; }
+// The bound set is a COPY (52 bytes per call): a thread that last drove a context which another thread has destroyed since holds no
+// pointer into freed memory; g_kopts_src is kept for the identity test of "kopts_bound" only and never dereferenced.
+static thread_local gmmiv_kopts g_kopts_val;
+static thread_local const gmmiv_kopts *g_kopts_src = nullptr;
+const gmmiv_kopts &gmmiv_kopts_cur() { return g_kopts_val; }
+void gmmiv_kopts_bind(const gmmiv_kopts *ko) { g_kopts_val = ko ? *ko : gmmiv_kopts(); g_kopts_src = ko; }
 
 void gmmiv_set_error(const char *fmt, ...)
 {
@@ -76,7 +78,7 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
     }
     c->topc_pipe_free();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
-    if (&gmmiv_kopts_cur() == &c->ko) gmmiv_kopts_bind(nullptr); // this thread's binding must not outlive the context
+    if (g_kopts_src == &c->ko) gmmiv_kopts_bind(nullptr); // back to the defaults on this thread
     delete c;
 }
 
@@ -133,7 +135,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "short_calls")) ks = &c->ko.short_calls; // 0 = calls of at most 32768 frames on the kernel shapes of long calls
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
-    if (!strcmp(key, "kopts_bound")) return &gmmiv_kopts_cur() == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?
+    if (!strcmp(key, "kopts_bound")) return g_kopts_src == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?
     if (!slot) return -1;
     long prev = *slot;
     *slot = value;
