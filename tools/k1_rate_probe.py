@@ -28,3 +28,21 @@ for T in (786432, 768000, 1536000, 3145728):
     print("T %8d: EM  K1 %.3f ms/Mframe (%d launches)  K2 %.3f | TV (%d utt) K1 %.3f ms/Mframe (%d launches)  K3 %.3f" % (
         T, k1 / T * 1e6, n1, k2 / T * 1e6, U, t1 / (U * 3000) * 1e6, m1, t3 / (U * 3000) * 1e6), flush=True)
     del N, F
+
+# what precedes K1 matters?  EM's K1 right after a tv_stats call (K3 last) against EM's K1 right after an EM call (K2 last)
+T = 768000; U = 256
+N = torch.empty((U, C), dtype=torch.float64, device=dev); F = torch.empty((U, C * D), dtype=torch.float64, device=dev)
+ub = np.arange(U + 1, dtype=np.int64) * 3000
+for label, pre in (("after EM (K2)", lambda: g.em_accumulate(x[:T], acc=acc)), ("after tv_stats (K3)", lambda: g.tv_stats(x[:T], ub, N, F)),
+                   ("after a 1 GB memset", lambda: F.zero_())):
+    ts = []
+    for rep in range(4):
+        pre(); torch.cuda.synchronize()
+        acc.zero_(); g.em_accumulate(x[:T], acc=acc); torch.cuda.synchronize()
+        ts.append(ctx.kernel_ms("k_llk_mfma"))
+    print("EM K1 on %d frames %s: %s ms" % (T, label, ["%.3f" % t for t in ts]), flush=True)
+ts = []
+for rep in range(4):
+    g.em_accumulate(x[:T], acc=acc); torch.cuda.synchronize()
+    g.tv_stats(x[:T], ub, N, F); torch.cuda.synchronize(); ts.append(ctx.kernel_ms("k_llk_mfma"))
+print("TV K1 on %d frames after EM (K2): %s ms" % (T, ["%.3f" % t for t in ts]), flush=True)

@@ -51,3 +51,6 @@ grep -h '^{"metric"' "$OUT/bench_all.log" > "$OUT/bench_all_under_rocprof.json"
 ( cd $ROOT && LIAGPU_TRACE=1 timeout 600 python tools/host_world_time.py 10000000 1.0 0.4 > "$OUT/host_world_time.txt" 2>&1 )
 ( cd $ROOT && timeout 600 python tools/alloc_time.py > "$OUT/alloc_time.txt" 2>&1 )
 ls -la "$OUT"
+# 9. the secondary metric on its own under the kernel trace
+kt iv_secondary python tools/iv_secondary.py
+grep -h '^{"metric"' "$OUT/iv_secondary.log" > "$OUT/iv_secondary_under_rocprof.json"
