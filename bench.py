@@ -13,6 +13,12 @@ estimateAandC, reduce-scatter of A / Cmx by Gaussian blocks, sharded updateTesti
 N > 1 the default (EM) run also reports that iteration as `tv_em`.  The collectives are the C ABI's own (gmmiv_comm_*: RCCL
 called by libgmmiv on the device buffers); torch.distributed only launches the ranks and carries the 128-byte RCCL id.
 
+Beside the headline the line carries (one GPU): `secondary` -- IvExtractor end to end on 512 utterances, i-vectors/s, with its own `roofline`
+(2.67 GFLOP per i-vector), `cpu_baseline` (oracle IvExtractor, thread sweep over utterance ranges), parity and the opt-in pruned rate;
+`computetest` -- ComputeTest's world / client passes; `host_layer` -- the same three workloads through the C++ host layer
+(libliatools_gpu.so: liagpu::trainModelStream at baggedFrameProbability 1.0 and 0.4, IvExtractor, computeTestLLR), each with its time, the ratio
+to the torch-driven number and parity against it; `dense_data`, `kernels`, `roofline`, `step_roofline`, `cpu_baseline`.
+
 Launch: python bench.py --gpus N (N > 1 without a launcher's WORLD_SIZE: bench.py starts its N ranks itself, like the reference
 tools start their own worker threads, AccumulateStat.cpp:234-299) | python -m torch.distributed.run --nproc-per-node N bench.py
 --gpus N.  The number of ranks must equal --gpus and every rank needs its own GPU -- anything else exits non-zero, unless
