@@ -77,6 +77,8 @@ const char *gmmiv_version(void);
  *                      1e-13 relative, not bitwise (both within the 1e-9 of the parity tests); set the option to 0 when a row must not
  *                      depend on its neighbours
  *   "assume_finite" 0  1: skip the screening pass for unusable feature values ("DEGENERATE INPUTS" below)
+ *   "screened_frames", "zero_llk_frames"   counters of the frames of kind (1) / kind (2) of "DEGENERATE INPUTS" (read: returns the
+ *                      count so far and stores `value`)
  *   "tv_tett_direct" 1 estimateTETt as one kernel that computes the lower triangles only and writes them packed (D <= 64); 0 = batched
  *                      GEMM into full matrices + pack
  *   "tv_batch" 1024    utterances per batch of the i-vector solve / T-matrix E-step (one workgroup factors one
@@ -150,8 +152,10 @@ void gmmiv_gmm_destroy(gmmiv_gmm *g);
  * exp(minLLK)).  This library defines it, and tests/test_gpu_degenerate.py holds every path to it:
  *
  * A frame is a ZERO-LIKELIHOOD FRAME when (1) one of its feature values is NaN, infinite or larger than 1e18 in magnitude, or
- * (2) its log-likelihood log sum_c w_c lk_c(x_t) is not finite or lies below -6.9e5 (2^-1000000: every Gaussian is further
- * away than any arithmetic can tell apart; the linear-domain arithmetic of the reference gives 0 long before, at -745).  Then
+ * (2) its likelihood is 0 in fp64: the LARGEST term w_c lk_c(x_t) lies below 2^-1075 = exp(-745.13) (so every term of the
+ * reference's linear-domain sum rounds to 0 and log of it is -inf), or the log-sum is not finite.  The decision is made on the
+ * largest logit, threshold log 2^-1075 = -745.1332 (GMMIV_ZERO_LLK in csrc/devutil.h), on every path; a frame whose best Gaussian
+ * is at -744 is an ordinary frame, one at -746 is a zero-likelihood frame (tests/test_gpu_degenerate.py pins both sides).  Then
  *   gmmiv_llk                     llk_t = min_llk (the clamp of log 0); counted in sums like any frame
  *   gmmiv_llk_determine_top       idx = 0 .. ctop-1 (the tie rule -- lowest index first -- on equal, zero, likelihoods), lk = 0,
  *                                 nontop_lk = 0, nontop_llk = -inf, nontop_w = 1 - sum of those weights, llk = min_llk
@@ -165,8 +169,13 @@ void gmmiv_gmm_destroy(gmmiv_gmm *g);
  * Frames of kind (1) are found by a screening pass over x at the start of every call (one read of x at HBM speed: 0.3 % of an EM
  * pass); a call that has any runs on the compacted usable frames and expands its per-frame outputs.  A caller whose features are
  * known to be clean sets the option "assume_finite" 1 and skips the pass (the C++ host layer checks a FeatureBuffer once, at
- * upload).  The option "screened_frames" reads the number of frames taken out so far.  Kind (2) is decided per frame where the
- * log-likelihood kernel finishes a frame -- no per-element work in the hot loops.
+ * upload -- and decides per call, from the buffer the call reads).  The option "screened_frames" reads the number of frames of kind (1)
+ * taken out so far.  Kind (2) is decided per frame where the log-likelihood kernel finishes a frame -- no per-element work in the hot
+ * loops -- and COUNTED on the device by the entry points that drop such a frame from a sum: gmmiv_llk, gmmiv_em_accumulate,
+ * gmmiv_tv_stats(_lines) (and the JFA statistics built on it), gmmiv_occ.  gmmiv_ctx_set_option(ctx, "zero_llk_frames", v) returns
+ * the count so far and stores v (0 to reset); the read waits for the context's stream, the counting never does.  Not counted: the
+ * top-C entry points (a zero-likelihood frame is visible there as llk = min_llk with lk = 0) and the opt-in "em_fused" form of
+ * gmmiv_tv_stats.
  * Other edges: T = 0 is valid everywhere (outputs untouched, accumulators unchanged); a Gaussian of weight 0 has likelihood 0
  * (never selected before a Gaussian of positive likelihood, occupancy 0); gmmiv_em_get keeps the previous mean / covariance of a
  * Gaussian whose occupancy is 0 and gives it weight 0; identical Gaussians tie and the lower index wins.

@@ -454,13 +454,26 @@ int gmmiv_comm_get_unique_id(void *id128) { return gmmiv_comm_get_unique_id_for(
 // between publishing its id and creating its communicator) carries a different nonce and is never accepted, however recent it is.
 // GMMIV_COMM_JOB if the launcher sets it, else what torch.distributed.run gives every rank of one job (rendezvous address, port and
 // run id); empty when neither exists -- then only the age rule below protects the readers.
-static std::string job_nonce()
+// The file carries a FIXED-LENGTH tag of it ("n1:" + 16 hex digits of its 64-bit FNV-1a hash): a job name or rendezvous address of
+// any length compares equal on every rank (round 4 wrote the raw string and read at most 512 bytes of it back -- a longer nonce could
+// never match and the other ranks spun until the timeout without a word).
+static std::string job_nonce_raw()
 {
     if (const char *j = getenv("GMMIV_COMM_JOB")) return std::string("job:") + j;
     const char *port = getenv("MASTER_PORT");
     if (!port || !*port) return std::string();
     const char *addr = getenv("MASTER_ADDR"), *run = getenv("TORCHELASTIC_RUN_ID");
     return std::string("rdzv:") + (addr ? addr : "") + ":" + port + ":" + (run ? run : "");
+}
+static const size_t NONCE_TAG_BYTES = 19;
+static std::string job_nonce()
+{
+    const std::string raw = job_nonce_raw();
+    unsigned long long h = 1469598103934665603ULL;
+    for (unsigned char ch : raw) { h ^= ch; h *= 1099511628211ULL; }
+    char tag[32];
+    snprintf(tag, sizeof tag, "n1:%016llx", h);
+    return std::string(tag, NONCE_TAG_BYTES);
 }
 
 // rank 0: the id file of `id128` is no longer needed (communicator created, or its creation failed)
@@ -502,24 +515,33 @@ int gmmiv_comm_exchange_id_file(const char *path, int rank, void *id128, double 
     struct timespec t_enter;
     clock_gettime(CLOCK_REALTIME, &t_enter);
     const double step = 0.01;
+    int seen_other = 0, seen_stale = 0, seen_short = 0; // why files that WERE there have been passed over (reported on timeout)
     for (double waited = 0.0; waited <= timeout_s; waited += step) { // the rename above makes the file appear complete
         struct stat sb;
-        if (stat(path, &sb) == 0 && (double)sb.st_mtime >= (double)t_enter.tv_sec - 600.0) {
-            FILE *f = fopen(path, "rb");
-            if (f) {
-                char buf[GMMIV_COMM_ID_BYTES + 512];
-                const size_t n = fread(buf, 1, sizeof(buf), f);
-                fclose(f);
-                // the file of THIS job: a complete id followed by this job's nonce (another job's file is left alone until rank 0 replaces it)
-                if (n >= GMMIV_COMM_ID_BYTES && n - GMMIV_COMM_ID_BYTES == nonce.size() && memcmp(buf + GMMIV_COMM_ID_BYTES, nonce.data(), nonce.size()) == 0) {
-                    memcpy(id128, buf, GMMIV_COMM_ID_BYTES);
-                    return GMMIV_OK;
+        if (stat(path, &sb) == 0) {
+            if ((double)sb.st_mtime < (double)t_enter.tv_sec - 600.0) seen_stale = 1;
+            else {
+                FILE *f = fopen(path, "rb");
+                if (f) {
+                    char buf[GMMIV_COMM_ID_BYTES + NONCE_TAG_BYTES + 1];
+                    const size_t n = fread(buf, 1, sizeof(buf), f);
+                    fclose(f);
+                    // the file of THIS job: a complete id followed by this job's tag (another job's file is left alone until rank 0 replaces it)
+                    if (n == GMMIV_COMM_ID_BYTES + NONCE_TAG_BYTES && memcmp(buf + GMMIV_COMM_ID_BYTES, nonce.data(), NONCE_TAG_BYTES) == 0) {
+                        memcpy(id128, buf, GMMIV_COMM_ID_BYTES);
+                        return GMMIV_OK;
+                    }
+                    if (n == GMMIV_COMM_ID_BYTES + NONCE_TAG_BYTES) seen_other = 1;
+                    else seen_short = 1; // no tag / another layout: written by another build of the library
                 }
             }
         }
         usleep((useconds_t)(step * 1e6));
     }
-    gmmiv_set_error("comm_exchange_id_file: rank %d waited %.0f s for %s", rank, timeout_s, path);
+    gmmiv_set_error("comm_exchange_id_file: rank %d waited %.0f s for %s%s%s%s", rank, timeout_s, path,
+                    seen_other ? " -- a file was there, but it carries ANOTHER job's tag (GMMIV_COMM_JOB / MASTER_ADDR:MASTER_PORT:TORCHELASTIC_RUN_ID differ between the ranks?)" : "",
+                    seen_short ? " -- a file without this build's job tag was there (rank 0 runs another build of libgmmiv?)" : "",
+                    seen_stale ? " -- a file older than 10 minutes was there and was ignored as a leftover" : "");
     return GMMIV_ERR_HIP;
 }
 

@@ -60,6 +60,13 @@ int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out)
     else { GCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->n_cu = prop.multiProcessorCount; c->total_mem = prop.totalGlobalMem; }
+    if (hipMalloc((void **)&c->d_zero_llk, sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_zero_llk, 0, sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        gmmiv_set_error("ctx_create: hipMalloc of the context's device counters failed");
+        return GMMIV_ERR_HIP;
+    }
     *out = c;
     return GMMIV_OK;
 }
@@ -77,6 +84,7 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
         for (hipEvent_t e : c->ev1[i]) (void)hipEventDestroy(e);
     }
     c->topc_pipe_free();
+    if (c->d_zero_llk) (void)hipFree(c->d_zero_llk);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (g_kopts_src == &c->ko) gmmiv_kopts_bind(nullptr); // back to the defaults on this thread
     delete c;
@@ -135,6 +143,13 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "short_calls")) ks = &c->ko.short_calls; // 0 = calls of at most 32768 frames on the kernel shapes of long calls
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
+    if (!strcmp(key, "zero_llk_frames")) { // the device counter of kind-(2) frames: reading it waits for the stream (the counting itself never does)
+        unsigned long long prev = 0, nv = value > 0 ? (unsigned long long)value : 0;
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(&prev, c->d_zero_llk, sizeof prev, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(c->d_zero_llk, &nv, sizeof nv, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        return (long)prev;
+    }
     if (!strcmp(key, "kopts_bound")) return g_kopts_src == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?
     if (!slot) return -1;
     long prev = *slot;
@@ -494,6 +509,9 @@ int gmmiv_segment_means(gmmiv_ctx *c, const double *v, int64_t ld, int nrows, co
 }
 
 // ---- LLK ---------------------------------------------------------------------------------
+// zero-likelihood frames of kind (2) among the n frames whose log-sums K1 has just left in `lse` -> the context's device counter
+static int count_dead(gmmiv_ctx *c, const double *lse, int64_t n) { return gmmk_count_dead(c->stream, lse, (long)n, c->d_zero_llk); }
+
 static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, double **lse_out)
 {
     void *lse;
@@ -502,6 +520,7 @@ static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, in
     c->t_begin("k_llk_mfma");
     GCHK(gmmk_llk(c->stream, g->KS, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->Pt, g->nct, (double *)lse, (int)(c->use_glds | (c->dbg << 8)), (int)c->wg_waves));
     c->t_end();
+    GCHK(count_dead(c, (const double *)lse, T)); // every caller of run_lse is a statistics / likelihood entry point
     *lse_out = (double *)lse;
     return GMMIV_OK;
 }
@@ -1004,6 +1023,7 @@ int gmmiv_occ(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
             GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lz,
                             (int)c->use_glds, (double *)zb, nfb, (int *)eit, (double *)inv, efin));
             c->t_end();
+            GCHK(count_dead(c, (const double *)lz, n));
             c->t_begin("k_post_from_z", c0 == 0);
             GCHK(gmmk_post_from_z(c->stream, n, g->C, g->nct, (const double *)zb, nfb, (const int *)eit, (const double *)inv, efin,
                                   o.d + (size_t)c0 * g->C));
@@ -1109,6 +1129,7 @@ static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt,
         GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, lse + c0,
                         (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb, (int *)eit, (double *)inv, efin));
         c->t_end();
+        GCHK(count_dead(c, lse + c0, n));
         c->t_begin("k_stats_z", k == 0);
         GCHK(gmmk_stats_z(c->stream, g->KS, 1, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb, nfb,
                           (const int *)eit, (const double *)inv, efin, weight, (const long *)seg + (k == nchunk - 1 ? nseg + 1 : 0), nseg,
@@ -1180,6 +1201,7 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
                 gmmiv_set_error("em_accumulate(fused): hand-off timed out, fell back to the two-kernel path");
                 goto two_pass;
             }
+            GCHK(count_dead(c, (const double *)lsew, T));
             // sum_t weight log lk_t and sum_t weight over the frames that HAVE a likelihood (zero-likelihood frames add nothing anywhere)
             GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
                                    o.d + nacc - 2, weight, o.d + nacc - 1));
@@ -1416,6 +1438,7 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
                     GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,
                                     (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb, (int *)eit, (double *)inv, efin));
                     c->t_end();
+                    GCHK(count_dead(c, (const double *)lsew, n));
                     c->t_begin("k_stats_z", true);
                     GCHK(gmmk_stats_z(c->stream, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb, nfb,
                                       (const int *)eit, (const double *)inv, efin, 1.0, (const long *)pseg, np, (double *)tn, (double *)tf, 1, 0,
@@ -1433,6 +1456,7 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
                 GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)lsew,
                                 (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zb, nfb, (int *)eit, (double *)inv, efin));
                 c->t_end();
+                GCHK(count_dead(c, (const double *)lsew, n));
                 c->t_begin("k_stats_z", k == 0);
                 GCHK(gmmk_stats_z(c->stream, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zb,
                                   nfb, (const int *)eit, (const double *)inv, efin, 1.0, (const long *)seg + u0 + k, (int)(u1 - u0),

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "devutil.h"
+#include "lds_attr.h"
 #include "tv_kernels.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1317,18 +1318,6 @@ CholLds chol_lds(int n)
 #ifndef CHOL_TW_FLOW
 #define CHOL_TW_FLOW 1 // tiles per wave and k-loop of k_chol_left2 (tools/chol_probe.sh build -DCHOL_TW_FLOW=2 for A/B runs)
 #endif
-template <typename K> int chol_attr(K kernel, size_t lds, std::atomic<size_t> (&done)[16])
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (done[dev].load(std::memory_order_acquire) < lds) {
-        const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        done[dev].store(lds, std::memory_order_release);
-    }
-    return 0;
-}
-std::atomic<size_t> g_attr_chol[3][16], g_attr_trinv[3][16], g_attr_uut[3][16];
 int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int *status, const double *Apacked, long spk, double diag_add)
 {
     prof_host_init();
@@ -1336,12 +1325,12 @@ int launch_chol(hipStream_t st, int n, int nb, double *Afull, double *invd, int 
     const long sinv = (long)((n + 31) / 32) * 1024;
     if (l.use && gmmiv_kopts_cur().chol_flow) { // round 3: panel staged first, diagonal update from LDS (k_chol_left2)
         const size_t pan = (size_t)32 * ((n & 2) ? n : n + 2) * sizeof(double);
-        int rc2 = chol_attr(k_chol_left2<CHOL_TW_FLOW>, pan, g_attr_chol[2]);
+        int rc2 = (int)gmmiv_lds_attr<k_chol_left2<CHOL_TW_FLOW>>(pan);
         if (rc2) return rc2;
         k_chol_left2<CHOL_TW_FLOW><<<nb, 512, pan, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
         return (int)hipGetLastError();
     }
-    int rc = l.use ? chol_attr(k_chol_left<true>, l.chol, g_attr_chol[1]) : chol_attr(k_chol_left<false>, l.chol, g_attr_chol[0]);
+    int rc = l.use ? (int)gmmiv_lds_attr<k_chol_left<true>>(l.chol) : (int)gmmiv_lds_attr<k_chol_left<false>>(l.chol);
     if (rc) return rc;
     if (l.use) k_chol_left<true><<<nb, 512, l.chol, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
     else k_chol_left<false><<<nb, 512, l.chol, st>>>(n, Afull, invd, sinv, status, Apacked, spk, diag_add);
@@ -1352,12 +1341,12 @@ int launch_trinv(hipStream_t st, int n, int nb, const double *Lf, const double *
     const CholLds l = chol_lds(n);
     const long sinv = (long)((n + 31) / 32) * 1024;
     if (l.use && gmmiv_kopts_cur().chol_waves == 16) { // 16 waves of 128 VGPRs, one row tile per wave and pass: twice the waves to cover a stalled one
-        int rc16 = chol_attr(k_trinv_left<true, 1, 16>, l.trinv, g_attr_trinv[2]);
+        int rc16 = (int)gmmiv_lds_attr<k_trinv_left<true, 1, 16>>(l.trinv);
         if (rc16) return rc16;
         k_trinv_left<true, 1, 16><<<nb, 1024, l.trinv, st>>>(n, Lf, invd, sinv, U);
         return (int)hipGetLastError();
     }
-    int rc = l.use ? chol_attr(k_trinv_left<true, 1>, l.trinv, g_attr_trinv[1]) : chol_attr(k_trinv_left<false, CHOL_TW_NOLDS>, l.trinv, g_attr_trinv[0]);
+    int rc = l.use ? (int)gmmiv_lds_attr<k_trinv_left<true, 1>>(l.trinv) : (int)gmmiv_lds_attr<k_trinv_left<false, CHOL_TW_NOLDS>>(l.trinv);
     if (rc) return rc;
     if (l.use) k_trinv_left<true, 1><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
     else k_trinv_left<false, CHOL_TW_NOLDS><<<nb, 512, l.trinv, st>>>(n, Lf, invd, sinv, U);
@@ -1367,12 +1356,12 @@ int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, cons
 {
     const CholLds l = chol_lds(n);
     if (l.use && gmmiv_kopts_cur().chol_waves == 16) {
-        int rc16 = chol_attr(k_uut<true, 1, 16>, l.uut, g_attr_uut[2]);
+        int rc16 = (int)gmmiv_lds_attr<k_uut<true, 1, 16>>(l.uut);
         if (rc16) return rc16;
         k_uut<true, 1, 16><<<nb, 1024, l.uut, st>>>(n, U, inv, w, packed, sp);
         return (int)hipGetLastError();
     }
-    int rc = l.use ? chol_attr(k_uut<true, 2>, l.uut, g_attr_uut[1]) : chol_attr(k_uut<false, CHOL_TW_NOLDS>, l.uut, g_attr_uut[0]);
+    int rc = l.use ? (int)gmmiv_lds_attr<k_uut<true, 2>>(l.uut) : (int)gmmiv_lds_attr<k_uut<false, CHOL_TW_NOLDS>>(l.uut);
     if (rc) return rc;
     if (l.use) k_uut<true, 2><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);
     else k_uut<false, CHOL_TW_NOLDS><<<nb, 512, l.uut, st>>>(n, U, inv, w, packed, sp);

@@ -103,6 +103,9 @@ struct gmmiv_ctx {
     // x per call) is skipped.  The C++ host layer sets it around its calls once a FeatureBuffer has been checked at upload.
     long assume_finite = 0;
     long screened_frames = 0; // unusable frames the screening has taken out of calls so far (read with set_option)
+    // kind (2) of the same rule: frames whose likelihood under the call's model is 0 in fp64, counted ON THE DEVICE (k_count_dead after the
+    // log-likelihood kernel of gmmiv_llk / _em_accumulate / _tv_stats(_lines) / _occ: no host synchronisation); option "zero_llk_frames" reads it
+    unsigned long long *d_zero_llk = nullptr;
     long topc_fallbacks = 0; // calls the fused path handed to the slower paths (list overflow / margin check); read with set_option
     long topc_z = 1;     // DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (topc_z.hip); 0: the direct-form VALU kernel
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)

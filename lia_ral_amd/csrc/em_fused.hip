@@ -21,6 +21,7 @@
 // placement; liveness needs all workgroups of the grid resident (grid <= CUs x resident workgroups
 // per CU) -- every spin is bounded and reports through `err`, and the host then falls back.
 #include "devutil.h"
+#include "lds_attr.h"
 #include "gmm_kernels.h"
 
 #define EMF_NBUF 4      // hand-off slots (>= 2 * lookahead + 2 with lookahead 1)
@@ -361,13 +362,11 @@ static int launch_fused(hipStream_t st, const void *x, long ldx, int D, int C, c
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     const size_t lds = ((size_t)3 * EMF_FT * (RL + 32) + 8 * EMF_FT * 2 + EMF_FT + 32) * sizeof(double);
-    static int blocks_per_cu = -1;
-    if (blocks_per_cu < 0) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_em_fused<KS, XT, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_em_fused<KS, XT, SQ>, 512, lds));
-        blocks_per_cu = nb;
-    }
+    HIPCHK((gmmiv_lds_attr<k_em_fused<KS, XT, SQ>>(lds))); // per (device, kernel): lds_attr.h
+    // resident workgroups per CU: asked per call (a host-side computation of the runtime, microseconds) -- a process-wide
+    // cache would hand device 0's answer to a context on another device
+    int blocks_per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_em_fused<KS, XT, SQ>, 512, lds));
     if (query_blocks) { *query_blocks = blocks_per_cu; return 0; }
     if (blocks_per_cu < 1 || nteams * ngrp > n_cu * blocks_per_cu) return (int)hipErrorCooperativeLaunchTooLarge;
     const unsigned grid = (unsigned)(8 * ngrp * ((nteams + 7) / 8));

@@ -15,6 +15,7 @@ int gmmk_llk_finalize(hipStream_t st, const double *lse, long T, double lo, doub
                       double *partial /* >= 3*256 doubles */, double scale_c, double scale_r, double *dst_clamped,
                       double *dst_raw, double scale_n = 0.0, double *dst_count = nullptr);
 int gmmk_add_scalar(hipStream_t st, double *dst, double v);
+int gmmk_count_dead(hipStream_t st, const double *lse, long T, unsigned long long *cnt); // *cnt += frames whose lse is not finite (zero-likelihood frames)
 int gmmk_rows_sum_groups(hipStream_t st, long n, int ngroups, const int *rb, const double *src, double *dst); // dst[g] = sum of src rows [rb[g], rb[g+1])
 int gmmk_stats(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt,
                int nct, const double *lse, double lse_shift, const long *seg_begin, int nseg, double *out0,

@@ -11,6 +11,7 @@
 // The top-C kernels evaluate the direct form (x-mu)^2 iv on the VALU like the reference does.
 #include <atomic>
 #include "devutil.h"
+#include "lds_attr.h"
 #include "gmm_kernels.h"
 
 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -580,6 +581,29 @@ __global__ __launch_bounds__(256) void k_llk_finalize(const double *__restrict__
     }
 }
 
+// frames of kind (2) of include/gmmiv.h "DEGENERATE INPUTS": the log-likelihood kernel has left lse = -inf (or a NaN) for them.
+// Counted into the context's device counter (option "zero_llk_frames"); one atomic per block that found any -- none on ordinary data.
+__global__ __launch_bounds__(256) void k_count_dead(const double *__restrict__ lse, long T, unsigned long long *__restrict__ cnt)
+{
+    unsigned n = 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
+        const double v = lse[t];
+        n += (v > -__builtin_inf() && v < __builtin_inf()) ? 0u : 1u;
+    }
+    const unsigned long long b = __ballot(n > 0);
+    if (b == 0) return; // wave-uniform
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(cnt, (unsigned long long)n);
+}
+int gmmk_count_dead(hipStream_t st, const double *lse, long T, unsigned long long *cnt)
+{
+    if (T <= 0 || !cnt) return 0;
+    long nb = (T + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    k_count_dead<<<(unsigned)nb, 256, 0, st>>>(lse, T, cnt);
+    return (int)hipGetLastError();
+}
+
 // dst_i += s_i * sum_b partial[b*n + i], i < 3   (single block, deterministic order)
 __global__ void k_reduce_partials(const double *__restrict__ partial, int nb, int n, double s0, double s1, double s2,
                                   double *__restrict__ dst0, double *__restrict__ dst1, double *__restrict__ dst2)
@@ -1126,14 +1150,7 @@ static int launch_llk(hipStream_t st, const void *x, long T, long ldx, int D, co
 {
     constexpr int NR = 2 * KS + 2;
     const size_t lds = 2 * 2 * NR * 64 * sizeof(double) + GEXP_TAB_N * sizeof(double) + (MODE == 2 ? NW * 32 * sizeof(int) : 0); // two model stages + the exp table (+ TC: candidate counters)
-    static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
-    int attr_dev = 0;
-    if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
-    std::atomic<bool> &attr_set = attr_done[attr_dev];
-    if (!attr_set.load(std::memory_order_acquire)) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_llk_mfma<KS, XT, NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
+    HIPCHK((gmmiv_lds_attr<k_llk_mfma<KS, XT, NW, MODE>>(lds))); // per (device, kernel): lds_attr.h
     const unsigned grid = (unsigned)((T + NW * 32 - 1) / (NW * 32));
     k_llk_mfma<KS, XT, NW, MODE><<<grid, NW * 64, lds, st>>>(x, T, ldx, D, Pt, nct, lse, use_glds & 1, use_glds >> 8, zbuf, nfb, eit, inv, efin);
     return (int)hipGetLastError();
@@ -1392,14 +1409,7 @@ static int launch_stats_p(hipStream_t st, const void *x, long ldx, int D, int C,
 {
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     const size_t lds = (2 * 64 * (RL + 32) + 32) * sizeof(double);
-    static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
-    int attr_dev = 0;
-    if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
-    std::atomic<bool> &attr_set = attr_done[attr_dev];
-    if (!attr_set.load(std::memory_order_acquire)) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_stats_mfma<KS, SQ, XT, NW, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
+    HIPCHK((gmmiv_lds_attr<k_stats_mfma<KS, SQ, XT, NW, PRUNE>>(lds))); // per (device, kernel): lds_attr.h
     const int ngrp = (nct + NW - 1) / NW;
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
     const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1); // floor(e/D) == umulhi(e, magicD) for e < 2^16
@@ -1506,11 +1516,7 @@ static int launch_topc(hipStream_t st, const void *x, long T, long ldx, int D, i
                        double hi, int *idx, double *lk, double *nlk, double *nllk, double *nw, double *llk)
 {
     const size_t lds = (size_t)FT * (Cp + D) * sizeof(double);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_topc_determine<FT, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    HIPCHK((gmmiv_lds_attr<k_topc_determine<FT, XT>>(lds))); // per (device, kernel): lds_attr.h
     const unsigned grid = (unsigned)((T + FT - 1) / FT);
     k_topc_determine<FT, XT><<<grid, 256, lds, st>>>(x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi,
                                                      idx, lk, nlk, nllk, nw, llk);

@@ -22,6 +22,7 @@
 // (1 / S_t = 0).
 #include <atomic>
 #include "devutil.h"
+#include "lds_attr.h"
 #include "gmm_kernels.h"
 
 // NW = 8: one 8-wave workgroup per CU, 64-frame tiles; NW = 4: two independent 4-wave workgroups per
@@ -327,14 +328,7 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
     constexpr int RL = ((4 * KS + 2 + 31) / 32) * 32;
     constexpr int PF = TPW > 2 ? TPW / 2 : 1;
     const size_t lds = (size_t)2 * FT * (RL + 32) * sizeof(double) + (size_t)2 * NW * PF * FT * sizeof(double); // two frame tiles + posterior factors
-    static std::atomic<bool> attr_done[16]; // the attribute is per device; contexts of different host threads may race here (setting it twice is harmless)
-    int attr_dev = 0;
-    if (hipGetDevice(&attr_dev) != hipSuccess || attr_dev < 0 || attr_dev >= 16) attr_dev = 0;
-    std::atomic<bool> &attr_set = attr_done[attr_dev];
-    if (!attr_set.load(std::memory_order_acquire)) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT, ZD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.store(true, std::memory_order_release);
-    }
+    HIPCHK((gmmiv_lds_attr<k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT, ZD>>(lds))); // per (device, kernel): lds_attr.h
     const int ngrp = (nct + TPW * NW - 1) / (TPW * NW);
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
     const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);

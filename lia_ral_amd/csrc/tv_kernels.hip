@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "devutil.h"
+#include "lds_attr.h"
 #include "tv_kernels.h"
 
 // -------------------------------------------------------------------------------------------
@@ -1334,13 +1335,7 @@ int tvk_tett_packed(hipStream_t st, int C, int D, int R, const double *T, const 
     const size_t lds = (size_t)JH * RS * 8;
 #define TETT_CASE(K)                                                                                                                  \
     case K: {                                                                                                                         \
-        static std::atomic<size_t> done[16];                                                                                          \
-        int dev = 0;                                                                                                                  \
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;                                                        \
-        if (done[dev].load(std::memory_order_acquire) < lds) {                                                                        \
-            if (hipFuncSetAttribute((const void *)k_tett_packed<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
-            done[dev].store(lds, std::memory_order_release);                                                                          \
-        }                                                                                                                             \
+        if (gmmiv_lds_attr<k_tett_packed<K>>(lds) != hipSuccess) return -2; /* per (device, kernel): lds_attr.h */                                                     \
         k_tett_packed<K><<<C, 256, lds, st>>>(R, D, SV, JH, T, iv, out, P);                                                           \
     } break;
     switch (KS) {

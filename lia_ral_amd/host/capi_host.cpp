@@ -865,6 +865,34 @@ int liagpu_jfa_dot_product(int device, long nTest, int C, int D, const double *w
     })
 }
 
+// Baum-Welch statistics of a TVAcc that lives on ONE server from the frames of a FeatureBuffer that lives on ANOTHER (the
+// reference hands any FeatureServer to any accumulator, AccumulateTVStat.cpp:281-351).  The accumulator's server also owns a clean
+// buffer (x_own): the screening decision of the call must follow the buffer that is READ -- a dirty x there must not poison N / F.
+// unusable_out[2] = unusable frames of (the accumulator's own buffer, the foreign buffer) as counted at upload.
+int liagpu_tv_stats_cross_server(int device, const float *x_own, long T_own, const float *x, long T, int D, const long *utt_begin, long U,
+                                 int C, const double *w, const double *mean, const double *cov, double *N_out, double *F_out,
+                                 long *unusable_out, long *assume_finite_after)
+{
+    GUARD({
+        GpuServer srvAcc(device), srvFeat(device);
+        FeatureBuffer own(srvAcc, x_own, (unsigned long)T_own, (unsigned long)D);
+        FeatureBuffer fs(srvFeat, x, (unsigned long)T, (unsigned long)D);
+        MixtureGD ubm = make_mixture(C, D, w, mean, cov);
+        TVAcc tv(srvAcc, ubm, 2, (unsigned long)U);
+        std::vector<SegCluster> lines(U);
+        for (long u = 0; u < U; ++u) {
+            Seg s; s.begin = (unsigned long)utt_begin[u]; s.length = (unsigned long)(utt_begin[u + 1] - utt_begin[u]); s.source = 0;
+            if (s.length) lines[u].push_back(s);
+        }
+        tv.computeAndAccumulateTVStat(fs, lines);
+        memcpy(N_out, tv.getN().data(), tv.getN().size() * sizeof(double));
+        memcpy(F_out, tv.getF().data(), tv.getF().size() * sizeof(double));
+        if (unusable_out) { unusable_out[0] = (long)own.unusableFrames(); unusable_out[1] = (long)fs.unusableFrames(); }
+        // the option is the user's again once the call has returned (it was 0 before: never set)
+        if (assume_finite_after) *assume_finite_after = gmmiv_ctx_set_option(srvAcc.ctx(), "assume_finite", 0);
+    })
+}
+
 // JFA statistics from frames (JFAAcc::computeAndAccumulateJFAStat, :515-577): sessions = utterance ranges, grouped by speaker
 int liagpu_jfa_stats(int device, const float *x, long T, int D, const long *sess_begin, long nspk, const long *sessPerSpk, int C,
                      const double *w, const double *mean, const double *cov, double *N, double *N_h, double *F_X, double *F_X_h)

@@ -92,18 +92,16 @@ void *GpuServer::workspace(int slot, size_t bytes)
     }
     return _ws[slot];
 }
-void GpuServer::featureBufferCreated(bool clean)
+// DEGENERATE INPUTS (include/gmmiv.h): whether the C ABI may skip its per-call screening pass is decided PER CALL from the
+// FeatureBuffer whose frames the call reads -- never as a context-wide setting: a TVAcc / JFAAcc may be handed the frames of a
+// buffer that lives on ANOTHER server, and a clean buffer on this server says nothing about those.  A value the
+// user set on the context is honoured (assume_finite 1 = "my data are clean") and restored when the call returns or throws.
+FiniteScope::FiniteScope(GpuServer &srv, const FeatureBuffer &fs) : _ctx(srv.ctx())
 {
-    ++_buffers;
-    if (!clean) ++_dirtyBuffers;
-    (void)gmmiv_ctx_set_option(_ctx, "assume_finite", _dirtyBuffers == 0 ? 1 : 0);
+    _prev = gmmiv_ctx_set_option(_ctx, "assume_finite", 0);
+    if (_prev > 0 || fs.unusableFrames() == 0) (void)gmmiv_ctx_set_option(_ctx, "assume_finite", 1);
 }
-void GpuServer::featureBufferDestroyed(bool clean)
-{
-    --_buffers;
-    if (!clean) --_dirtyBuffers;
-    (void)gmmiv_ctx_set_option(_ctx, "assume_finite", (_buffers > 0 && _dirtyBuffers == 0) ? 1 : 0);
-}
+FiniteScope::~FiniteScope() { (void)gmmiv_ctx_set_option(_ctx, "assume_finite", _prev > 0 ? 1 : 0); }
 void GpuServer::check(int rc) const
 {
     if (rc != 0) throw Exception(gmmiv_last_error());
@@ -218,14 +216,16 @@ FeatureBuffer::FeatureBuffer(GpuServer &srv, const float *frames, unsigned long 
     if (nFrames) hipcheck(hipMemcpy(_dev, frames, (size_t)nFrames * vectSize * sizeof(float), hipMemcpyHostToDevice), "FeatureBuffer: upload");
     // screened ONCE here instead of in every call of every iteration
     int64_t bad = 0;
-    srv.check(gmmiv_count_unusable_frames(srv.ctx(), _dev, GMMIV_F32, (int64_t)nFrames, (int64_t)vectSize, (int)vectSize, &bad));
+    if (gmmiv_count_unusable_frames(srv.ctx(), _dev, GMMIV_F32, (int64_t)nFrames, (int64_t)vectSize, (int)vectSize, &bad) != 0) {
+        (void)hipFree(_dev); // the destructor does not run for a half-built object
+        _dev = nullptr;
+        throw Exception(gmmiv_last_error());
+    }
     _unusable = (unsigned long)bad;
-    srv.featureBufferCreated(_unusable == 0);
 }
 FeatureBuffer::~FeatureBuffer()
 {
     (void)gmmiv_ctx_sync(_srv.ctx()); // kernels / copies in flight may still use the buffers
-    _srv.featureBufferDestroyed(_unusable == 0);
     if (_dev) (void)hipFree(_dev);
     if (_sel) (void)hipFree(_sel);
     if (_dRuns) (void)hipFree(_dRuns);
@@ -400,6 +400,7 @@ double accumulateStatEM(FeatureBuffer &fs, EMAcc &emAcc, const SegCluster &selec
     const float *x = fs.select(selectedSegments, n);
     const double msSel = clk.lap();
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     const double before = emAcc.getAccumulatedLLK();
     const double msBefore = clk.lap();
     srv.check(gmmiv_em_accumulate(srv.ctx(), emAcc.mixture().handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), weight, emAcc.acc().dev()));
@@ -420,6 +421,7 @@ double accumulateStatLLK(FeatureBuffer &fs, DeviceMixture &m, const SegCluster &
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     double sums[2] = {0.0, 0.0};
     srv.check(gmmiv_llk(srv.ctx(), m.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), minLLK, maxLLK, nullptr, sums));
     return sums[1] > 0 ? sums[0] / sums[1] : 0.0;
@@ -431,6 +433,7 @@ void accumulateStatLLK(LLKAcc &llkAcc, FeatureBuffer &fs, DeviceMixture &m, cons
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     double sums[2] = {0.0, 0.0};
     srv.check(gmmiv_llk(srv.ctx(), m.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), minLLK, maxLLK, nullptr, sums));
     llkAcc.sumLLK += weight * sums[0]; // computeAndAccumulateLLK(f, weight): sum of w llk, sum of w
@@ -460,6 +463,7 @@ void accumulateStatFrame(FrameAccGD &frameAcc, FeatureBuffer &fs, const SegClust
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     srv.check(gmmiv_frame_moments(srv.ctx(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), (int)fs.getVectSize(), frameAcc.acc.data()));
 }
 
@@ -837,8 +841,11 @@ std::vector<double> trainModelStream(const TrainCfg &cfg, const std::vector<Trai
     for (size_t k = 0; k < passes.size(); ++k) {
         const EMPass &ps = passes[k];
         StageClock clk;
-        srv.check(gmmiv_em_accumulate(srv.ctx(), dworld->handle(), cur.x, GMMIV_F32, (int64_t)cur.n, (int64_t)world.getVectSize(), 1.0,
-                                      emAcc->acc().dev()));
+        {
+            FiniteScope fin(srv, *streams[ps.stream].fs); // screening follows the stream's own buffer
+            srv.check(gmmiv_em_accumulate(srv.ctx(), dworld->handle(), cur.x, GMMIV_F32, (int64_t)cur.n, (int64_t)world.getVectSize(), 1.0,
+                                          emAcc->acc().dev()));
+        }
         msEnq += clk.lap();
         msBag += cur.msBag; msSel += cur.msSel;
         if (k + 1 < passes.size()) cur = prepare(passes[k + 1]);
@@ -903,6 +910,7 @@ double TopGauss::compute(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     const int cap = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), ubm.getDistribCount());
     std::vector<int32_t> idx((size_t)n * cap), cnt(n);
     std::vector<double> llk(n);
@@ -930,6 +938,7 @@ double TopGauss::get(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &se
     const float *x = fs.select(selectedSegments, n);
     if (n != _nt) throw Exception("TopGauss::get: the selection holds another number of frames than the stored one");
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     unsigned long cap = 1;
     for (unsigned long t = 0; t < n; ++t) cap = std::max(cap, _nbg[t]);
     if (cap > 64) throw Exception("TopGauss::get: more than 64 Gaussians stored for a frame");
@@ -1103,6 +1112,7 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
     // a model with fewer Gaussians than topDistribsCount selects all of them (the row stride of idx follows the clamped count)
     topDistribsCount = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), world.getDistribCount());
@@ -1169,6 +1179,7 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
     unsigned long n = 0;
     const float *x = fs.select(selectedSegments, n);
     GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     const int mode = complete ? GMMIV_TOP_COMPLETE : GMMIV_TOP_PARTIAL;
     const int ctop = (int)std::min<unsigned long>((unsigned long)std::max(topDistribsCount, 1), world.getDistribCount());
     std::vector<int32_t> idx((size_t)n * ctop);
@@ -1423,6 +1434,7 @@ void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegC
     unsigned long n = 0;
     const float *x = fs.select(all, n);
     if (&fs.server() != &_srv) fs.server().sync(); // the selection is enqueued on the feature buffer's stream
+    FiniteScope fin(_srv, fs); // the frames may come from another server's buffer: the decision follows the buffer, not this context
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), uttBegin.data(),
                               (int64_t)_n_speakers, _statN.dev(), _statF.dev()));
 }
@@ -1448,6 +1460,7 @@ void TVAcc::computeAndAccumulateTVStat(FeatureBuffer &fs, const std::vector<SegC
     unsigned long n = 0;
     const float *x = fs.select(all, n);
     if (&fs.server() != &_srv) fs.server().sync(); // the selection is enqueued on the feature buffer's stream
+    FiniteScope fin(_srv, fs); // the frames may come from another server's buffer: the decision follows the buffer, not this context
     _srv.check(gmmiv_tv_stats_lines(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), fileBegin.data(),
                                     (int64_t)segsPerFile.size(), (int64_t)_n_speakers, lineOff.data(), lineFiles.data(), _statN.dev(), _statF.dev()));
 }
@@ -1676,6 +1689,7 @@ void JFAAcc::computeAndAccumulateJFAStat(FeatureBuffer &fs, const std::vector<Se
     const float *x = fs.select(all, n);
     if (&fs.server() != &_srv) fs.server().sync(); // the selection is enqueued on the feature buffer's stream
     // the frame loop (:544-575) runs once, per session, on the device; a speaker's rows are the sums of its sessions' rows
+    FiniteScope fin(_srv, fs); // the frames may come from another server's buffer: the decision follows the buffer, not this context
     _srv.check(gmmiv_tv_stats(_srv.ctx(), _dubm.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), begin.data(),
                               (int64_t)_n_sessions, _N_h.dev(), _F_X_h.dev()));
     // speaker rows = sums of the speaker's session rows (once per statistics pass; on the host views)

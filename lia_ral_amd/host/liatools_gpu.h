@@ -139,10 +139,6 @@ class GpuServer {
     explicit GpuServer(int device = 0);
     ~GpuServer();
     gmmiv_ctx *ctx() { return _ctx; }
-    // FeatureBuffers register here: while every live buffer of this server was found free of unusable frames at upload (non-finite
-    // / absurd values, include/gmmiv.h "degenerate inputs"), the per-call screening pass of the C ABI is switched off
-    void featureBufferCreated(bool clean);
-    void featureBufferDestroyed(bool clean);
     void *stream() { return gmmiv_ctx_stream(_ctx); } // hipStream_t of the context: the host layer's own copies are ordered on it
     void sync() { check(gmmiv_ctx_sync(_ctx)); }
     // grow-only device workspace of the host layer itself (slot 0..7): the per-file buffers of computeTestLLR live here instead of
@@ -152,9 +148,23 @@ class GpuServer {
 
   private:
     gmmiv_ctx *_ctx = nullptr;
-    long _buffers = 0, _dirtyBuffers = 0;
     void *_ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t _wsBytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// Scope of ONE frame-consuming call of the C ABI on `srv`'s context with frames of `fs`: the per-call screening pass is skipped
+// (assume_finite) iff that buffer was found free of unusable frames at upload, or the user had set the option; the previous
+// value comes back at scope exit.  The decision follows the buffer actually read, which may belong to another server.
+class FiniteScope {
+  public:
+    FiniteScope(GpuServer &srv, const FeatureBuffer &fs);
+    ~FiniteScope();
+    FiniteScope(const FiniteScope &) = delete;
+    FiniteScope &operator=(const FiniteScope &) = delete;
+
+  private:
+    gmmiv_ctx *_ctx;
+    long _prev;
 };
 
 // Device copy of a MixtureGD

@@ -494,6 +494,21 @@ def jfa_dot_product(ubm, N, F, V, U, Dm, client_sv, device=0):
                                     _d(U), _d(Dm), ct.c_long(client_sv.shape[0]), _d(client_sv), _d(sc)))
     return sc
 
+def tv_stats_cross_server(x_own, x, utt_begin, ubm, device=0):
+    """N / F of a TVAcc on one GpuServer from the frames of a FeatureBuffer on ANOTHER server; the accumulator's server holds
+    the (clean) buffer x_own.  -> N, F, (unusable frames of x_own, of x), assume_finite of the accumulator's context afterwards."""
+    w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]
+    C, D = mean.shape
+    x_own = np.ascontiguousarray(x_own, np.float32); x = np.ascontiguousarray(x, np.float32)
+    ub = np.ascontiguousarray(utt_begin, np.int64)
+    U = len(ub) - 1
+    N = np.empty((U, C)); F = np.empty((U, C * D))
+    bad = (ct.c_long * 2)(); af = ct.c_long(-7)
+    _chk(lib.liagpu_tv_stats_cross_server(device, x_own.ctypes.data_as(_fp), ct.c_long(x_own.shape[0]), x.ctypes.data_as(_fp), ct.c_long(x.shape[0]), D,
+                                          ub.ctypes.data_as(_lp), ct.c_long(U), C, _d(w), _d(mean), _d(cov), _d(N), _d(F), bad, ct.byref(af)))
+    return N, F, (bad[0], bad[1]), af.value
+
+
 def jfa_stats(x, sess_begin, sess_per_spk, ubm, device=0):
     """JFAAcc::computeAndAccumulateJFAStat on float32 frames: returns N, N_h, F_X, F_X_h."""
     w, mean, cov = [np.ascontiguousarray(a, np.float64) for a in ubm]

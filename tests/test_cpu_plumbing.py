@@ -46,6 +46,27 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dp, f)
 
 
+def test_lds_attribute_is_raised_in_one_place_per_device_and_kernel():
+    """A launch with more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize raised on EVERY device
+    it runs on.  csrc/lds_attr.h is the one helper that does it, keyed by (device, kernel); a call anywhere else -- round 4
+    had two sites behind a process-wide `static` -- would break the one-context-per-GPU-from-one-process mode gmmiv.h promises
+    (the reference gives each worker thread private servers: AccumulateTVStat.cpp:392-393, 422-423)."""
+    csrc = os.path.join(ROOT, "lia_ral_amd", "csrc")
+    users = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        txt = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+        if f == "lds_attr.h":
+            assert txt.count("hipFuncSetAttribute(") == 1 and "GMMIV_LDS_ATTR_MAX_DEV" in txt
+            continue
+        assert "hipFuncSetAttribute" not in txt, "%s sets a function attribute outside lds_attr.h" % f
+        users += len(re.findall(r"gmmiv_lds_attr<", txt))
+        # every launch that passes a run-time LDS size is preceded by the helper in the same function: no `static` size caches left
+        assert not re.search(r"static\s+(size_t|int|bool)\s+(attr_\w+|blocks_per_cu)\b", txt), f
+    assert users >= 12      # k_llk_mfma, k_stats_mfma, k_topc_determine, k_stats_z, k_em_fused, k_tett_packed, the Cholesky family
+
+
 def test_missing_rccl_is_err_unsupported_not_a_crash():
     """include/gmmiv.h: GMMIV_ERR_UNSUPPORTED when RCCL cannot be loaded (GMMIV_RCCL_LIB names the only library tried).  The
     message is built from ONE dlerror() call -- two calls appended NULL to a std::string and crashed the process."""
@@ -352,7 +373,18 @@ def test_id_file_of_another_job_is_never_accepted(tmp_path, monkeypatch):
     uid_c = capi.Comm.exchange_id_file(path, 0, 5.0)
     assert capi.Comm.exchange_id_file(path, 1, 5.0) == uid_c
     monkeypatch.setenv("MASTER_PORT", "29513")
+    with pytest.raises(capi.GmmivError, match="ANOTHER job's tag"):          # the timeout says WHY the file that was there did not count
+        capi.Comm.exchange_id_file(path, 1, 0.3)
+    # a nonce of any length works: the file carries a fixed-length tag of it (512 raw bytes were the limit, silently)
+    monkeypatch.setenv("GMMIV_COMM_JOB", "J" * 3000)
+    uid_d = capi.Comm.exchange_id_file(path, 0, 5.0)
+    assert os.path.getsize(path) == 128 + 19 and capi.Comm.exchange_id_file(path, 1, 5.0) == uid_d
+    monkeypatch.setenv("GMMIV_COMM_JOB", "J" * 2999 + "K")
     with pytest.raises(capi.GmmivError, match="waited"):
+        capi.Comm.exchange_id_file(path, 1, 0.3)
+    with open(path, "wb") as f:                                              # a file of a build that wrote no tag
+        f.write(b"x" * 128)
+    with pytest.raises(capi.GmmivError, match="without this build's job tag"):
         capi.Comm.exchange_id_file(path, 1, 0.3)
 
 

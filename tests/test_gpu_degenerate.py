@@ -103,6 +103,79 @@ def test_zero_likelihood_frames_follow_the_rule_on_every_path(opts):
     g.close(); ctx.close()
 
 
+def _logits(w, mean, iv, x):
+    """log(w_c lk_c(x_t)) in the log domain (numpy): the reference of the boundary test -- the linear-domain oracle holds a
+    likelihood of exp(-744) in one or two denormal bits and cannot serve there."""
+    x = np.asarray(x, np.float64)
+    a = np.log(w) + 0.5 * np.sum(np.log(iv), 1) - 0.5 * D * np.log(2 * np.pi)
+    d = x[:, None, :] - mean[None]
+    return a[None] - 0.5 * np.einsum("tcd,cd->tc", d * d, iv)
+
+
+def _frame_at(w, mean, iv, target, seed):
+    """A float32 frame whose LARGEST logit is `target` (+- 1e-2): mu_0 + s u, s by bisection."""
+    u = np.random.default_rng(seed).normal(0, 1, D) / np.sqrt(iv[0])
+    lo, hi = 0.0, 1e3
+    for _ in range(200):
+        s = 0.5 * (lo + hi)
+        z = _logits(w, mean, iv, (mean[0] + s * u).astype(np.float32)[None]).max()
+        lo, hi = (s, hi) if z > target else (lo, s)
+    xf = (mean[0] + lo * u).astype(np.float32)
+    assert abs(_logits(w, mean, iv, xf[None]).max() - target) < 1e-2
+    return xf
+
+
+@pytest.mark.parametrize("opts", PATHS, ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()) or "default")
+def test_kind_2_threshold_is_log_2_pow_minus_1075_on_every_path(opts):
+    """include/gmmiv.h: a frame is a zero-likelihood frame of kind (2) when its largest w_c lk_c lies below 2^-1075 = exp(-745.13).
+    One frame at -744 (ordinary: it counts everywhere, its values are the log-domain ones) and one at -746.5 (dropped, and COUNTED
+    by "zero_llk_frames") through every statistics / likelihood entry point (the header said -6.9e5)."""
+    w, mean, iv = make_gmm(C, D, seed=1)
+    x = make_frames(w, mean, iv, 200, seed=3)
+    A, B = 50, 120
+    x[A] = _frame_at(w, mean, iv, -744.0, 11)
+    x[B] = _frame_at(w, mean, iv, -746.5, 12)
+    z = _logits(w, mean, iv, x)
+    m = z.max(1, keepdims=True)
+    lse = (m + np.log(np.exp(z - m).sum(1, keepdims=True)))[:, 0]
+    live = np.setdiff1d(np.arange(200), [B])
+    ctx = _ctx(opts)
+    g = ctx.gmm(w, mean, iv)
+    assert ctx.set_option("zero_llk_frames", 0) == 0
+    # gmmiv_llk
+    l = g.llk(x, min_llk=-1e4, max_llk=1e4)
+    assert l[B] == -1e4 and np.max(np.abs(l[live] - lse[live])) < 1e-9 and abs(l[A] - lse[A]) < 1e-9 and lse[A] > -745.0
+    assert ctx.set_option("zero_llk_frames", 0) == 1
+    # posteriors
+    o = g.occ(x)
+    gam = np.exp(z - lse[:, None])
+    assert np.all(o[B] == 0.0) and abs(o[A].sum() - 1.0) < 1e-9 and np.max(np.abs(o[live] - gam[live])) < 1e-9
+    assert ctx.set_option("zero_llk_frames", 0) == 1
+    # EM statistics: frame A is in (count, occupancy, sums), frame B adds nothing
+    a = g.split_acc(g.em_accumulate(x))
+    xl = x[live].astype(np.float64)
+    rel = lambda p, q: np.max(np.abs(p - q)) / np.max(np.abs(q))
+    assert a["count"] == 199 and abs(a["occ"].sum() - 199) < 1e-6
+    assert rel(a["occ"], gam[live].sum(0)) < 1e-9 and rel(a["sx"], gam[live].T @ xl) < 1e-9 and rel(a["sxx"], gam[live].T @ (xl * xl)) < 1e-9
+    assert abs(a["llk"] - lse[live].sum()) < 1e-6
+    assert ctx.set_option("zero_llk_frames", 0) == 1
+    # Baum-Welch N / F, A and B in different utterances
+    ub = np.array([0, 100, 200])
+    N = np.zeros((2, C)); F = np.zeros((2, C * D))
+    g.tv_stats(x, ub, N, F)
+    No = np.stack([gam[:100].sum(0), gam[live][live >= 100].sum(0)])
+    Fo = np.stack([(gam[:100].T @ x[:100].astype(np.float64)).ravel(), (gam[live][live >= 100].T @ x[live][live >= 100].astype(np.float64)).ravel()])
+    assert rel(N, No) < 1e-9 and rel(F, Fo) < 1e-9 and abs(N[0].sum() - 100) < 1e-6 and abs(N[1].sum() - 99) < 1e-6
+    if not opts.get("em_fused"):                     # the opt-in single-pass N / F kernel keeps no per-frame log-sum to count from (gmmiv.h)
+        assert ctx.set_option("zero_llk_frames", 0) == 1
+    # top-C: B gets the lowest indices and min_llk, A its true selection
+    d = g.llk_determine_top(x, 5, min_llk=-1e4, max_llk=1e4)
+    assert d["idx"][B].tolist() == [0, 1, 2, 3, 4] and d["llk"][B] == -1e4 and np.all(d["lk"][B] == 0.0)
+    assert d["idx"][A].tolist() == np.argsort(-z[A], kind="stable")[:5].tolist() and abs(d["llk"][A] - lse[A]) < 1e-9
+    assert ctx.set_option("screened_frames", 0) == 0
+    g.close(); ctx.close()
+
+
 def test_call_made_of_unusable_frames_only_and_empty_calls():
     from lia_ral_amd import capi
     w, mean, iv, x, zero, good = _case()
@@ -197,3 +270,31 @@ def test_host_layer_checks_a_feature_buffer_once_and_trains_past_bad_frames():
     assert np.isfinite(b["mean"]).all() and np.isfinite(b["cov"]).all() and np.isfinite(b["llk"]).all()
     assert np.allclose(a["mean"], b["mean"], rtol=1e-9, atol=1e-11) and np.allclose(a["cov"], b["cov"], rtol=1e-9, atol=1e-11)
     assert np.allclose(a["w"], b["w"], rtol=1e-9) and np.allclose(a["llk"], b["llk"], rtol=1e-11)
+
+
+def test_screening_follows_the_buffer_that_is_read_not_the_accumulators_server():
+    """a TVAcc on server A (which owns only CLEAN buffers) handed the frames of a DIRTY buffer on server B must
+    still screen them -- `assume_finite` is decided per call from the FeatureBuffer actually read (liagpu::FiniteScope), not from
+    the buffers registered with the accumulator's context, and the context's own option is untouched afterwards."""
+    from lia_ral_amd import host_capi as h
+    Cs, Ds = 32, 20
+    w, mean, iv = make_gmm(Cs, Ds, seed=7)
+    own = make_frames(w, mean, iv, 300, seed=8)                  # clean, lives on the accumulator's server
+    x = make_frames(w, mean, iv, 1200, seed=9)
+    bad = [3, 400, 401, 1199]
+    xd = x.copy()
+    xd[3, 0] = np.nan; xd[400, 5] = np.inf; xd[401, 7] = -np.inf; xd[1199, 2] = 1e30
+    ub = np.array([0, 300, 300, 800, 1200])
+    N, F, cnt, af = h.tv_stats_cross_server(own, xd, ub, (w, mean, 1.0 / iv))
+    assert cnt == (0, len(bad)) and af == 0
+    assert np.isfinite(N).all() and np.isfinite(F).all()         # before the fix: 0 x NaN poisoned F
+    good = np.setdiff1d(np.arange(1200), bad)
+    utt = np.searchsorted(ub, good, side="right") - 1
+    No, Fo = orc.tv_stats(orc.Gmm(w, mean, iv), x[good].astype(np.float64), utt, 4)
+    rel = lambda p, q: np.max(np.abs(p - q)) / np.max(np.abs(q))
+    assert rel(N, No) < 1e-9 and rel(F, Fo) < 1e-9
+    # and a clean foreign buffer gives the plain statistics (the screening pass is skipped for it)
+    N2, F2, cnt2, af2 = h.tv_stats_cross_server(own, x, ub, (w, mean, 1.0 / iv))
+    utt2 = np.searchsorted(ub, np.arange(1200), side="right") - 1
+    No2, Fo2 = orc.tv_stats(orc.Gmm(w, mean, iv), x.astype(np.float64), utt2, 4)
+    assert cnt2 == (0, 0) and af2 == 0 and rel(N2, No2) < 1e-9 and rel(F2, Fo2) < 1e-9
