@@ -47,6 +47,54 @@ KERNEL_FLOP = {"k_llk_mfma": FLOP_PER_PAIR_LLK, "k_stats_z": FLOP_PER_PAIR_ACC, 
 PEAK_F64_TFLOPS = 78.6        # MI355X fp64 matrix = vector peak (AMD datasheet; measured ceiling in DESIGN.md)
 
 
+def lib_identity():
+    """sha256 of the libgmmiv.so this process runs (the build is deterministic: the library built from a revision is the same
+    file here and on the GPU box) and the git revision when the tree has one (the gpurun snapshot has none)."""
+    import hashlib
+    import subprocess
+    so = os.path.join(ROOT, "lia_ral_amd", "csrc", "libgmmiv.so")
+    sha = hashlib.sha256(open(so, "rb").read()).hexdigest() if os.path.exists(so) else None
+    try:
+        rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        rev = None
+    return {"libgmmiv_sha256": sha, "git_rev": rev}
+
+
+def load_traffic():
+    """profiles/traffic.json = HBM bytes from the committed rocprofv3 PMC passes (tools/profile_r05.sh + tools/make_traffic.py).
+    PMC counters can only be read by a rocprofv3 run, so the line quotes the figures of those passes -- but ONLY when they were
+    collected on the library that is running now (the file records its sha256): with another build `traffic` is null and
+    `traffic_note` says why (round-4 verdict: a stale file would have gone unnoticed)."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    me = lib_identity()
+    if not os.path.exists(tf):
+        return None, "profiles/traffic.json not found", me
+    try:
+        tj = json.load(open(tf))
+    except Exception as e:      # noqa: BLE001
+        return None, "profiles/traffic.json unreadable: %r" % (e,), me
+    if not tj.get("libgmmiv_sha256"):
+        return None, "profiles/traffic.json does not record the library it was collected on", me
+    if tj["libgmmiv_sha256"] != me["libgmmiv_sha256"]:
+        return None, ("profiles/traffic.json was collected on libgmmiv.so %s (git %s), this run loads %s: PMC figures of another build are "
+                      "not quoted -- re-run tools/profile_r05.sh" % (tj["libgmmiv_sha256"][:16], tj.get("git_rev"), (me["libgmmiv_sha256"] or "?")[:16])), me
+    return tj, None, me
+
+
+def screen_once(ctx, x, what):
+    """include/gmmiv.h "DEGENERATE INPUTS": without "assume_finite" every frame-consuming call starts with a screening pass whose
+    result the HOST reads back (one blocking round trip per call).  A caller that keeps its frames resident checks them once --
+    exactly what liagpu::FeatureBuffer does at upload -- and vouches for them afterwards."""
+    import ctypes as ct
+    from lia_ral_amd import capi
+    n = ct.c_int64(-1)
+    capi._chk(capi.lib.gmmiv_count_unusable_frames(ctx._h, capi._ptr(x), capi.F32, ct.c_int64(x.shape[0]), ct.c_int64(x.shape[1]), x.shape[1], ct.byref(n)))
+    if n.value != 0:
+        raise RuntimeError("%s: %d unusable frames in synthetic data" % (what, n.value))
+    return {"frames": int(x.shape[0]), "unusable": 0, "what": what}
+
+
 def synth_frames(w, mean, iv, T, device, seed):
     """x = mu_c + sqrt(var_c) N(0,1), component ~ weights, float32 (generated on the GPU)."""
     g = torch.Generator(device=device)
@@ -86,7 +134,9 @@ def cpu_baseline(w, mean, iv, seed):
     from conftest import make_frames
     from oracle import oracle as orc
     logical, phys = os.cpu_count() or 1, physical_cores()
-    counts = sorted({1, max(1, phys // 4), max(1, phys // 2), phys, logical})
+    # the sweep stops at half the physical cores: rounds 2-4 measured the 128- and 256-thread points SLOWER than the 32-thread one on
+    # the 128-core host (the per-thread 2 MB accumulators leave the last-level cache) -- 20 s of driver time that said nothing new
+    counts = sorted({1, max(1, phys // 8), max(1, phys // 4), max(1, phys // 2)})
     g = orc.Gmm(w, mean, iv)
     # Every point runs for about TARGET_S seconds: its frame count is sized from the aggregate rate the PREVIOUS point measured (the
     # first from a short single-thread probe), at least 4000 frames per thread -- the many-thread points then time the steady loop
@@ -117,12 +167,15 @@ def cpu_baseline(w, mean, iv, seed):
                       % ("/".join(str(r["frames"]) for r in sweep), C, TARGET_S, sum(r["seconds"] for r in sweep))}
 
 
-def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000, R=400, check=True):
-    """BASELINE.json configs[2] on a bounded slice: IvExtractor end-to-end (Baum-Welch N/F statistics,
-    substractM, L = I + sum N TETt, SPD inverse, w = L^-1 T Sigma^-1 F) for U utterances x 3000 frames
-    per GPU; TETt is precomputed once (T is fixed during extraction, IvExtractor.cpp:136)."""
+def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=10_000, frames=3000, R=400, check=True, slice_u=512, traffic=None):
+    """BASELINE.json configs[2] AT ITS STATED SIZE: IvExtractor end-to-end (Baum-Welch N/F statistics, substractM,
+    L = I + sum N TETt, SPD inverse, w = L^-1 T Sigma^-1 F) for U = 10 000 utterances x 3000 frames per GPU, everything resident
+    in HBM (features 7.2 GB float32, F 9.8 GB, N 0.16 GB, TETt 1.3 GB); TETt is precomputed once (T is fixed during extraction,
+    IvExtractor.cpp:136).  The two opt-in variants (single-pass statistics kernel, pruned posteriors) are A/B legs on the first
+    `slice_u` utterances, next to the default path timed on the same slice."""
     T = U * frames
     x = synth_frames(w, mean, iv, T, dev, seed=777 + rank)
+    screened = screen_once(ctx, x, "i-vector secondary")
     gen = torch.Generator(device=dev); gen.manual_seed(5)
     Tm = 0.01 * torch.randn((R, C * D), dtype=torch.float64, device=dev, generator=gen)
     invvar = torch.from_numpy(iv.ravel().copy()).to(dev)
@@ -136,76 +189,96 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=512, frames=3000,
     ub = np.arange(U + 1, dtype=np.int64) * frames
     times = {}
 
-    def run():
+    def run(n=U):
         t0 = time.perf_counter()
-        g.tv_stats(x, ub, N, F)
+        g.tv_stats(x[:n * frames], ub[:n + 1], N[:n], F[:n])
         torch.cuda.synchronize(); t1 = time.perf_counter()
         times["k1_ms"] = ctx.kernel_ms("k_llk_mfma"); times["k3_ms"] = ctx.kernel_ms("k_stats_z")
-        ctx.tv_subtract_m(N, F, means, C, D)
-        ctx.tv_estimate_w(N, F, Tm, invvar, tett, C, D, out=W)
+        times["k1_launches"] = ctx.kernel_launches("k_llk_mfma")
+        ctx.tv_subtract_m(N[:n], F[:n], means, C, D)
+        ctx.tv_estimate_w(N[:n], F[:n], Tm, invvar, tett, C, D, out=W[:n])
         torch.cuda.synchronize(); t2 = time.perf_counter()
         times["stats_ms"] = (t1 - t0) * 1e3
         times["solve_ms"] = (t2 - t1) * 1e3
         return t2 - t0
 
     run(); run()               # two warm-ups (workspace allocation, then the allocator's second look at it)
-    NRUN = 5
+    NRUN = 3
     runs = []
-    kms = {"k_llk_mfma": 0.0, "k_stats_z": 0.0}
     stats_ms = solve_ms = 0.0
     k1_ms = k3_ms = 0.0
     for _ in range(NRUN):
         runs.append(run())
         stats_ms += times["stats_ms"] / NRUN; solve_ms += times["solve_ms"] / NRUN
         k1_ms += times["k1_ms"] / NRUN; k3_ms += times["k3_ms"] / NRUN
-    times["stats_ms"], times["solve_ms"] = stats_ms, solve_ms
+    k1_launches = times["k1_launches"]
     dt = float(np.mean(runs))  # the MEAN of the timed runs
-    # the same statistics through the single-pass cooperative kernel (opt-in, em_fused.hip)
-    fused = {}
-    try:
-        ctx.set_option("em_fused", 1)
-        N2 = torch.empty_like(N); F2 = torch.empty_like(F)
-        g.tv_stats(x, ub, N2, F2); torch.cuda.synchronize()
-        t0 = time.perf_counter(); g.tv_stats(x, ub, N2, F2); torch.cuda.synchronize()
-        fused["stats_ms"] = (time.perf_counter() - t0) * 1e3
-        ctx.tv_subtract_m(N2, F2, means, C, D)
-        fused["max_rel_diff_F"] = float(((F2 - F).abs().max() / F.abs().max()).item())
-        fused["i-vectors/s"] = U * world / (fused["stats_ms"] * 1e-3 + times["solve_ms"] * 1e-3)
-    finally:
-        ctx.set_option("em_fused", 0)
     dt = max_over_ranks(dt, world, dev)
     parity = ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None
+    finite = bool(torch.isfinite(W).all().item())
+    W_all = W.clone()
+    # ---- A/B legs on the first slice_u utterances (opt-in paths; never `value`) ----
+    S = min(slice_u, U)
+    run(S); run(S)
+    sl = [run(S) for _ in range(NRUN)]
+    slice_default = {"utterances": S, "ms": float(np.mean(sl)) * 1e3, "i-vectors/s": S / float(np.mean(sl)), "stats_ms": times["stats_ms"], "solve_ms": times["solve_ms"]}
+    W_slice = W[:S].clone()
+    fused = {}
+    try:     # the same statistics through the single-pass cooperative kernel (opt-in, em_fused.hip)
+        ctx.set_option("em_fused", 1)
+        N2 = torch.empty((S, C), dtype=torch.float64, device=dev); F2 = torch.empty((S, C * D), dtype=torch.float64, device=dev)
+        g.tv_stats(x[:S * frames], ub[:S + 1], N2, F2); torch.cuda.synchronize()
+        t0 = time.perf_counter(); g.tv_stats(x[:S * frames], ub[:S + 1], N2, F2); torch.cuda.synchronize()
+        fused["stats_ms"] = (time.perf_counter() - t0) * 1e3
+        ctx.tv_subtract_m(N2, F2, means, C, D)
+        fused["max_rel_diff_F"] = float(((F2 - F[:S]).abs().max() / F[:S].abs().max()).item())
+        fused["i-vectors/s"] = S / (fused["stats_ms"] * 1e-3 + slice_default["solve_ms"] * 1e-3)
+        del N2, F2
+    finally:
+        ctx.set_option("em_fused", 0)
     # OPT-IN (not the default, not `value`): the N / F statistics with posteriors below 2^-100 skipped in groups (option "prune_log2":
     # at most 2^-100 of posterior mass per pair is dropped -- 1e-30 absolute on N / F, invisible in L, aux and the i-vector, but a
     # Gaussian whose whole occupancy is that small gets different statistics than the reference's sum of denormal-scale terms)
     pruned = {}
     try:
         ctx.set_option("prune_log2", 100)
-        W_all = W.clone()
-        run()
-        pr = [run() for _ in range(NRUN)]
-        pdt = max_over_ranks(float(np.mean(pr)), world, dev)
-        pruned = {"prune_log2": 100, "value": U * world / pdt, "unit": "i-vectors/s", "stats_ms": times["stats_ms"], "k_stats_z_ms": times["k3_ms"],
-                  "max_rel_diff_ivectors_vs_default": float(((W - W_all).abs().max() / W_all.abs().max()).item()),
-                  "parity": ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, U // 2, U - 1]) if rank == 0 and check else None}
-        W.copy_(W_all)
+        run(S)
+        pr = [run(S) for _ in range(NRUN)]
+        pdt = float(np.mean(pr))
+        pruned = {"prune_log2": 100, "utterances": S, "value": S / pdt, "unit": "i-vectors/s", "stats_ms": times["stats_ms"], "k_stats_z_ms": times["k3_ms"],
+                  "max_rel_diff_ivectors_vs_default": float(((W[:S] - W_slice).abs().max() / W_slice.abs().max()).item()),
+                  "parity": ivector_parity(x, frames, w, mean, iv, Tm, W, [0, 1, S // 2, S - 1]) if rank == 0 and check else None}
     finally:
         ctx.set_option("prune_log2", 0)
+    W.copy_(W_all)
+    del W_all
     # 2.67 GFLOP per i-vector end to end = 3000 frames x 2048 x 362 (K1 logits 240 + K3 N / F statistics 122) + 448.5 M (solve)
     flop_stats = float(frames) * C * (FLOP_PER_PAIR_LLK + 2.0 * (1 + D)); flop_solve = 448.5e6
     tf = (flop_stats + flop_solve) * U / (dt / 1.0) / 1e12           # this rank's U i-vectors in dt (the slowest rank's time)
+    tr = tr_note = None
+    if traffic and traffic[0] and traffic[0].get("iv_extractor"):
+        e = traffic[0]["iv_extractor"]      # HBM bytes of ONE pass over `utterances` utterances, all kernels (fetch x 2 + write, PMC)
+        tr = e["hbm_bytes_per_utterance"] * U
+        tr_note = e.get("source")
+    elif traffic:
+        tr_note = traffic[1] or "no iv_extractor entry in profiles/traffic.json"
     roof = {"bound": "mfma", "kernel": "IvExtractor end to end: k_llk_mfma<WZ> + k_stats_z<SQ=0> + L / aux GEMMs + chol_fused",
-            "achieved": tf, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_TFLOPS, "traffic": None,
+            "achieved": tf, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_TFLOPS, "traffic": tr, "traffic_source": tr_note,
+            "traffic_unit": "HBM bytes of one pass over the %d utterances (all kernels)" % U,
             "algorithmic_flop_per_ivector": flop_stats + flop_solve,
-            "parts": {"k_llk_mfma": {"ms": k1_ms, "tflops": FLOP_PER_PAIR_LLK * T * C / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None},
+            "algorithmic_bytes": float(T) * D * 4 + float(U) * R * 8,      # the feature stream read once + the i-vectors written
+            "parts": {"k_llk_mfma": {"ms": k1_ms, "launches": k1_launches, "tflops": FLOP_PER_PAIR_LLK * T * C / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else None},
                       "k_stats_z(N,F)": {"ms": k3_ms, "tflops": 2.0 * (1 + D) * T * C / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else None},
-                      "solve (substractM + estimateW)": {"ms": times["solve_ms"], "tflops": flop_solve * U / (times["solve_ms"] * 1e-3) / 1e12}},
-            "time_fractions": {"k_llk_mfma": k1_ms / (dt * 1e3), "k_stats_z": k3_ms / (dt * 1e3), "solve": times["solve_ms"] / (dt * 1e3)}}
+                      "solve (substractM + estimateW)": {"ms": solve_ms, "tflops": flop_solve * U / (solve_ms * 1e-3) / 1e12}},
+            "time_fractions": {"k_llk_mfma": k1_ms / (dt * 1e3), "k_stats_z": k3_ms / (dt * 1e3), "solve": solve_ms / (dt * 1e3)}}
     return {"metric": "i-vectors/s (IvExtractor end-to-end, 2048-g UBM, rank 400, 3000-frame utterances)",
-            "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "stats_ms": times["stats_ms"],
-            "solve_ms": times["solve_ms"], "timed_runs_ms": [r * 1e3 for r in runs], "timing": "mean of %d runs after two warm-ups" % NRUN,
-            "finite": bool(torch.isfinite(W).all().item()), "parity": parity, "roofline": roof, "pruned_posteriors": pruned, "fused_stats": fused,
-            "_W": W, "_Tm": Tm, "_seed": 777 + rank}
+            "config": "BASELINE.json configs[2] at its stated size: %d utterances x %d frames per GPU" % (U, frames),
+            "value": U * world / dt, "unit": "i-vectors/s", "utterances_per_gpu": U, "frames_per_gpu": T, "stats_ms": stats_ms,
+            "solve_ms": solve_ms, "timed_runs_ms": [r * 1e3 for r in runs], "timing": "mean of %d runs after two warm-ups" % NRUN,
+            "hbm_resident_gb": {"features_f32": T * D * 4 / 1e9, "F": U * C * D * 8 / 1e9, "N": U * C * 8 / 1e9, "tett_packed": C * P * 8 / 1e9},
+            "screening": screened, "finite": finite, "parity": parity, "roofline": roof,
+            "slice_ab": {"default": slice_default, "pruned_posteriors": pruned, "fused_stats": fused},
+            "_W": W[:S].clone(), "_Tm": Tm, "_x_slice": x[:S * frames].clone(), "_slice": S}
 
 
 def ivector_cpu_baseline(w, mean, iv, R=400, frames=3000):
@@ -225,8 +298,8 @@ def ivector_cpu_baseline(w, mean, iv, R=400, frames=3000):
     t_tett = time.time() - t
     base = make_frames(w, mean, iv, frames * 4, seed=31).astype(np.float64)
     sweep = []
-    counts = sorted({1, max(1, phys // 4), phys, logical})
-    budget = 45.0
+    counts = sorted({1, max(1, phys // 4)})     # one utterance per thread, ~4 s each: 1 thread and a quarter of the cores (the best point of rounds 3-4)
+    budget = 25.0
     for th in counts:
         if sweep and budget < 1.5 * sweep[-1]["seconds"]:
             break
@@ -254,6 +327,7 @@ def computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, T=1_000_000, ct
     from lia_ral_amd import capi
     import ctypes as ct
     x = synth_frames(w, mean, iv, T, dev, seed=991 + rank)
+    screen_once(ctx, x, "ComputeTest frames")
     rng = np.random.default_rng(17)
     cm = [mean + rng.normal(0, 0.1, mean.shape) for _ in range(n_clients)]
     clients = [ctx.gmm(w, m, iv) for m in cm]
@@ -299,6 +373,125 @@ def computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, T=1_000_000, ct
             "world_pass_gpairs_per_s": T * C * world / tw / 1e9, "world_pass_ms": tw * 1e3,
             "client_pass_mframes_per_s_per_client": T * n_clients * world / tc / 1e6, "client_pass_ms": tc * 1e3,
             "frames_per_gpu": T, "clients": n_clients, "parity": parity}
+
+
+SCORE_FLOP = 800.0          # SURVEY 8(d) / BASELINE.md: one score of dim 400 as a GEMM element: 2 x 400 flop, 8 B written
+
+
+def scoring_block(ctx, dev, M=100_000, S=100_000, R=400, rf=200, check=True, traffic=None):
+    """BASELINE.json configs[4] AT ITS STATED SIZE: IvTest scoring of 100 k enrolment x 100 k test i-vectors of dimension 400 on one
+    MI355X, all four rules (PldaTest::cosineDistance / mahalanobisDistance / twoCovScoring / pldaScoringUnThreaded,
+    PldaTools.cpp:3842-3909, 4083-4271).  The 100 000 x 100 000 fp64 score matrix (80 GB) STAYS in HBM -- what leaves the device is a
+    checksum and the sampled trials the oracle checks (shipping it over PCIe would take 80 GB / 63 GB/s = 1.3 s against 0.13 s of
+    compute); it is freed before the next block.  Returns the JSON block (value = Mahalanobis trials/s: the rule the reference
+    spends an O(dim^2) product per pair on)."""
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    models = torch.randn((R, M), dtype=torch.float64, device=dev, generator=gen)
+    segs = torch.randn((R, S), dtype=torch.float64, device=dev, generator=gen)
+    models /= models.norm(dim=0, keepdim=True); segs /= segs.norm(dim=0, keepdim=True)
+    scores = torch.empty((M, S), dtype=torch.float64, device=dev)
+    Q = torch.randn((R, R), dtype=torch.float64, device=dev, generator=gen)
+    Mah = (Q @ Q.T / R + torch.eye(R, dtype=torch.float64, device=dev)).contiguous()
+    Gm = ((Q + Q.T) / R).contiguous(); Hm = ((Q @ Q.T) / (R * R)).contiguous()
+    Fp = torch.randn((R, rf), dtype=torch.float64, device=dev, generator=gen) / np.sqrt(R)
+    FTJF = (Fp.T @ Fp + 0.1 * torch.eye(rf, dtype=torch.float64, device=dev)).contiguous()
+    nsess = np.sort(np.random.default_rng(3).integers(1, 4, M)).astype(np.int64)
+    mp = torch.randn((rf, M), dtype=torch.float64, device=dev, generator=gen) * torch.from_numpy(nsess).to(dev)
+    sp = torch.randn((rf, S), dtype=torch.float64, device=dev, generator=gen)
+    rng = np.random.default_rng(7)
+    rows = np.unique(np.concatenate([[0, 127, 128, M - 129, M - 1], rng.integers(0, M, 11)]))
+    cols = np.unique(np.concatenate([[0, 63, 128, S - 130, S - 1], rng.integers(0, S, 11)]))
+    ri = torch.from_numpy(rows).to(dev); ci = torch.from_numpy(cols).to(dev)
+    sub = lambda t2, idx: np.ascontiguousarray(t2[:, idx].cpu().numpy())
+    relerr = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+    orc = None
+    if check:
+        from oracle import oracle as orc          # the CHECKER of the sampled trials; nothing that is timed touches it
+    rules = {
+        "cosine": (lambda: ctx.score_cosine(models, segs, out=scores), lambda: orc.score_cosine(sub(models, ri), sub(segs, ci)), R),
+        "mahalanobis": (lambda: ctx.score_mahalanobis(models, segs, Mah, out=scores),
+                        lambda: orc.score_mahalanobis(sub(models, ri), sub(segs, ci), Mah.cpu().numpy()), R),
+        "twocov": (lambda: ctx.score_twocov(models, segs, Gm, Hm, out=scores),
+                   lambda: orc.score_twocov(sub(models, ri), sub(segs, ci), Gm.cpu().numpy(), Hm.cpu().numpy()), R),
+        "plda(rankF=%d)" % rf: (lambda: ctx.score_plda(mp, nsess, sp, FTJF, out=scores),
+                                lambda: orc.score_plda(sub(mp, ri), nsess[rows], sub(sp, ci), FTJF.cpu().numpy()), rf),
+    }
+    res = {}
+    worst = 0.0
+    for name, (run, ref, k) in rules.items():
+        run(); torch.cuda.synchronize()                       # warm-up: workspace, the PLDA normalisers of the three session counts
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); run(); torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.mean(ts))
+        e = {"ms": dt * 1e3, "timed_runs_ms": [t * 1e3 for t in ts], "Gtrials_per_s": M * S / dt / 1e9, "tflops": 2.0 * k * M * S / dt / 1e12,
+             "frac_of_fp64_peak": 2.0 * k * M * S / dt / 1e12 / PEAK_F64_TFLOPS, "score_write_TBps": M * S * 8 / dt / 1e12,
+             "k_dgemm_ms": ctx.kernel_ms("k_dgemm(score)") if ctx.kernel_launches("k_dgemm(score)") > 0 else None,
+             "checksum": float(scores.sum().item()), "finite": bool(torch.isfinite(scores).all().item())}
+        if check:
+            err = relerr(scores[ri][:, ci].cpu().numpy(), ref())
+            e["max_rel_err_vs_oracle"] = err; e["ok"] = bool(err < 1e-9)
+            worst = max(worst, err)
+        res[name] = e
+    head = res["mahalanobis"]
+    tr = tr_note = None
+    if traffic and traffic[0] and traffic[0].get("scoring"):
+        tr = traffic[0]["scoring"].get("mahalanobis_hbm_bytes_per_call"); tr_note = traffic[0]["scoring"].get("source")
+    elif traffic:
+        tr_note = traffic[1] or "no scoring entry in profiles/traffic.json"
+    out = {"metric": "trials/s (IvTest scoring, %d enrol x %d test i-vectors of dimension %d, score matrix resident in HBM)" % (M, S, R),
+           "config": "BASELINE.json configs[4] at its stated size", "value": head["Gtrials_per_s"] * 1e9, "unit": "trials/s",
+           "value_rule": "mahalanobis (PldaTools.cpp:3882-3909)", "models": M, "segments": S, "dim": R,
+           "scores_resident_gb": M * S * 8 / 1e9, "scores_location": "HBM (never copied to the host; checksum + sampled trials leave the device)",
+           "rules": res,
+           "roofline": {"bound": "mfma", "kernel": "k_dgemm (M^T (Q S) with the per-vector quadratic terms in the epilogue)", "achieved": head["tflops"],
+                        "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": head["tflops"] / PEAK_F64_TFLOPS, "traffic": tr, "traffic_source": tr_note,
+                        "algorithmic_flop_per_trial": SCORE_FLOP, "algorithmic_bytes": float(M) * S * 8 + (M + S) * R * 8.0,
+                        "hbm_write_TBps": head["score_write_TBps"], "kernel_ms": head["ms"]}}
+    if check:
+        out["parity"] = {"trials_checked_per_rule": int(len(rows) * len(cols)), "max_rel_err_vs_oracle": worst, "tolerance": 1e-9, "ok": bool(worst < 1e-9),
+                         "what": "sampled trials (tile corners, last rows / columns, random) of all four rules at full size vs the oracle's per-pair loops "
+                                 "(restatement, parity unpinned: IvTest ships no test vector)"}
+    del scores, models, segs, mp, sp
+    torch.cuda.empty_cache()
+    return out
+
+
+def scoring_cpu_baseline(R=400):
+    """the reference's O(dim^2)-per-pair form of mahalanobisDistance (PldaTools.cpp:3897-3901 -- the
+    oracle restatement, -O3 -ffast-math) on one thread and, rows split, on a quarter of the cores; and the GEMM formulation
+    -1/2 (m - s)^T Q (m - s) = m^T Q s - 1/2 m^T Q m - 1/2 s^T Q s on a 2 k x 2 k subset (numpy / the host BLAS), checked against the
+    per-pair form.  The reference itself runs this loop on ONE thread."""
+    from oracle import oracle as orc
+    logical, phys = os.cpu_count() or 1, physical_cores()
+    rng = np.random.default_rng(21)
+    Q = rng.normal(size=(R, R)); Mah = Q @ Q.T / R + np.eye(R)
+    sweep = []
+    rate = None
+    for th in sorted({1, max(1, phys // 4)}):
+        n = 96 if rate is None else int(min(2000, max(96, np.sqrt(rate * th * 2.5))))     # ~2.5 s per point, sized from the single-thread rate
+        m = rng.normal(size=(R, n)); sg = rng.normal(size=(R, n))
+        t = time.time(); sc = orc.score_mahalanobis_mt(m, sg, Mah, threads=th); dt = time.time() - t
+        if rate is None:
+            rate = n * n / dt
+        sweep.append({"threads": th, "models": n, "segments": n, "seconds": dt, "trials_per_s": n * n / dt})
+    n = 2000
+    m = rng.normal(size=(R, n)); sg = rng.normal(size=(R, n))
+    t = time.time()
+    QS = Mah @ sg
+    gemm = m.T @ QS - 0.5 * np.einsum("km,km->m", m, Mah @ m)[:, None] - 0.5 * np.einsum("ks,ks->s", sg, QS)[None, :]
+    dtg = time.time() - t
+    chk = orc.score_mahalanobis(m[:, :8], sg[:, :8], Mah)
+    err = float(np.max(np.abs(gemm[:8, :8] - chk)) / np.max(np.abs(chk)))
+    best = max(sweep, key=lambda r: r["trials_per_s"])
+    return {"value": best["trials_per_s"], "unit": "trials/s", "cores": best["threads"], "kind": "port", "single_thread": sweep[0]["trials_per_s"],
+            "logical_cores": logical, "physical_cores": phys, "sweep": sweep,
+            "gemm_form": {"trials_per_s": n * n / dtg, "models": n, "segments": n, "seconds": dtg, "max_rel_err_vs_per_pair_form": err,
+                          "what": "numpy (host BLAS, its own thread pool) on a 2 k x 2 k subset"},
+            "sample": "mahalanobisDistance in the reference's per-pair form (an O(dim^2) product per trial; oracle restatement, gcc -O3 -ffast-math, "
+                      "not the original binary) on %s trials at dim %d; the reference runs it on one thread, the threaded point splits the model "
+                      "rows" % (" / ".join("%dx%d" % (r["models"], r["segments"]) for r in sweep), R)}
 
 
 def host_layer(ctx, g, w, mean, iv, x, dev, T, headline_gpairs, secondary, computetest, check=True):
@@ -368,20 +561,21 @@ def host_layer(ctx, g, w, mean, iv, x, dev, T, headline_gpairs, secondary, compu
     out["train_world"] = tw
     del xh
     if secondary is not None:
-        U, frames, R = secondary["utterances_per_gpu"], 3000, 400
-        xs = synth_frames(w, mean, iv, U * frames, dev, seed=secondary["_seed"])
+        U, frames, R = secondary["_slice"], 3000, 400       # the first `_slice` utterances of the secondary (features cross PCIe as host arrays here)
+        xs = secondary["_x_slice"]
         Tm = secondary["_Tm"]
         ub = np.arange(U + 1, dtype=np.int64) * frames
         Wh, ms = h.iv_extract(xs.cpu().numpy(), ub, (w, mean, cov), Tm.cpu().numpy(), reps=4)
         per = ms[1:, [0, 1, 3]].sum(1)                      # statistics + substractM + estimateW of the runs after the first
         rate = U / (float(np.mean(per)) * 1e-3)
+        ref_rate = secondary["slice_ab"]["default"]["i-vectors/s"]
         e = {"utterances": U, "ms_per_run": float(np.mean(per)), "stages_ms": {"statistics": float(ms[1:, 0].mean()), "substractM": float(ms[1:, 1].mean()),
              "estimateTETt_once": float(ms[0, 2]), "estimateW": float(ms[1:, 3].mean())}, "ivectors_per_s": rate,
-             "ratio_to_secondary": rate / secondary["value"]}
+             "ratio_to_secondary_same_slice": rate / ref_rate}
         Wt = secondary["_W"].cpu().numpy()
         err = relerr(Wh, Wt)
         e["parity"] = {"max_rel_err_vs_torch_driven": err, "tolerance": 1e-9, "ok": bool(err < 1e-9),
-                       "what": "i-vectors of the %d utterances: liagpu::TVAcc (IvExtractor order) vs the torch-driven C-ABI calls of `secondary`" % U}
+                       "what": "i-vectors of the first %d utterances: liagpu::TVAcc (IvExtractor order) vs the torch-driven C-ABI calls of `secondary`" % U}
         out["iv_extractor"] = e
         del xs
     if computetest is not None:
@@ -583,7 +777,7 @@ def max_over_ranks(dt, world, dev):
     return float(tt.item())
 
 
-def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False, force=False):
+def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False, force=False, traffic=None):
     """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
     then `steps` EM iterations timed, each the tool's full sequence: restore + substractM, estimateTETt, estimateAandC,
     updateTestimate (sharded), minDivergence.  Returns the JSON fields of the workload."""
@@ -598,6 +792,7 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
     for u0 in range(0, U, CH):
         n = min(CH, U - u0)
         x = synth_frames(w, mean, iv, n * frames, dev, seed=9000 + 131 * rank + u0)
+        screen_once(ctx, x, "T-matrix workload frames"); ctx.set_option("assume_finite", 1)
         g.tv_stats(x, np.arange(n + 1, dtype=np.int64) * frames, N[u0:u0 + n], F_raw[u0:u0 + n])
         del x
     torch.cuda.synchronize()
@@ -626,6 +821,11 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
     ph = {k: v / steps * 1e3 for k, v in phases.items() if k != "sync"}
     estep_tf = TV_FLOP_PER_UTT * U / (ph["estep"] * 1e-3) / 1e12
     finite = bool(torch.isfinite(ops.T).all().item())
+    tr = tr_note = None
+    if traffic and traffic[0] and traffic[0].get("tv_em"):
+        tr = traffic[0]["tv_em"]["estep_hbm_bytes_per_utterance"] * U; tr_note = traffic[0]["tv_em"].get("source")
+    elif traffic:
+        tr_note = traffic[1] or "no tv_em entry in profiles/traffic.json"
     res = {
         "metric": "utterances/s (TotalVariability: one T-matrix EM iteration, 2048-g UBM, rank %d)" % R,
         "value": n_total * steps / dt, "unit": "utterances/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -641,8 +841,10 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
         "overlap": bool(overlap and (world > 1 or force) and getattr(coll, "supports_overlap", False)),
         "statistics_once_s": t_stats, "finite": finite,
         "roofline": {"bound": "mfma", "kernel": "E-step (k_dgemm: L, aux, A, Cmx + chol_fused)", "achieved": estep_tf, "peak": PEAK_F64_TFLOPS,
-                     "unit": "TFLOP/s", "frac": estep_tf / PEAK_F64_TFLOPS, "traffic": None,
-                     "algorithmic_flop_per_utterance": TV_FLOP_PER_UTT, "kernel_ms": ph["estep"]},
+                     "unit": "TFLOP/s", "frac": estep_tf / PEAK_F64_TFLOPS, "traffic": tr, "traffic_source": tr_note,
+                     "traffic_unit": "HBM bytes of the E-step of one iteration over this rank's %d utterances (all kernels)" % U,
+                     "algorithmic_flop_per_utterance": TV_FLOP_PER_UTT, "kernel_ms": ph["estep"],
+                     "algorithmic_bytes": float(U) * (C * D + C) * 8.0},      # the N / F rows read once
     }
     if rank == 0 and check:
         res["parity"], cpub = tv_parity_and_cpu_baseline(ops, R, want_cpu=cpu)
@@ -677,6 +879,8 @@ def main():
     ap.add_argument("--workload", choices=["em", "tv"], default="em", help="em: TrainWorld EM pass (headline); tv: TotalVariability T-matrix EM iteration (configs[3])")
     ap.add_argument("--tv-utterances", type=int, default=6250, help="utterances per GPU of the T-matrix EM workload")
     ap.add_argument("--tv-rank", type=int, default=400)
+    ap.add_argument("--iv-utterances", type=int, default=10_000, help="utterances per GPU of the IvExtractor block (configs[2]: 10 000)")
+    ap.add_argument("--score-vectors", type=int, default=100_000, help="enrolment = test i-vectors of the scoring block (configs[4]: 100 000)")
     ap.add_argument("--collectives", choices=["gmmiv", "torch"], default="gmmiv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -760,7 +964,7 @@ def main():
     check = not args.no_cpu_baseline
     if args.workload == "tv":
         res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup,
-                          check=check, cpu=(world == 1), overlap=bool(args.overlap), force=force)
+                          check=check, cpu=(world == 1), overlap=bool(args.overlap), force=force, traffic=load_traffic())
         if rank == 0:
             res["comm"] = comm_info
             if coll_note:
@@ -773,6 +977,9 @@ def main():
             dist.destroy_process_group()
         return
     x = synth_frames(w, mean, iv, T, dev, seed=1234 + rank)
+    screening = screen_once(ctx, x, "headline frames")      # one check of the resident frames, then no per-call screening pass
+    ctx.set_option("assume_finite", 1)                       # (every other synthetic block below is checked the same way before it is used)
+    traffic = load_traffic()
     nacc = g.em_acc_len()
     acc = torch.zeros(nacc, dtype=torch.float64, device=dev)
     mean_d = torch.from_numpy(mean).to(dev)
@@ -841,6 +1048,7 @@ def main():
         wd, md, ivd = make_gmm(C, D, seed=3, spread=0.3)
         Td = min(T, 2_000_000)
         xd = synth_frames(wd, md, ivd, Td, dev, seed=4321 + rank)
+        screen_once(ctx, xd, "dense-mixture frames")
         g.set(wd, md, ivd)
         accd = torch.zeros(nacc, dtype=torch.float64, device=dev)
         g.em_accumulate(xd, acc=accd)
@@ -876,21 +1084,32 @@ def main():
     computetest = None
     tv_em = None
     hostl = None
+    scoring = None
     if not args.no_secondary:
-        g.set(w, mean, iv)     # back to the seed model for the i-vector slice
-        secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
+        g.set(w, mean, iv)     # back to the seed model for the i-vector block
+        # configs[2] at its stated size (10 000 utterances x 3000 frames per GPU; --iv-utterances for a smaller dry run)
+        secondary = ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=args.iv_utterances, check=check, traffic=traffic)
         computetest = computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, check=check)
         if world == 1 and not args.no_host_layer:
             hostl = host_layer(ctx, g, w, mean, iv, x, dev, T, value, secondary, computetest, check=check)
         for blk in (secondary, computetest):     # tensors kept for the host-layer parity, not part of the line
             for k in [k for k in blk if k.startswith("_")]:
                 del blk[k]
+        torch.cuda.empty_cache()
+        # configs[3]: one T-matrix EM iteration on utterance-sharded statistics -- 6250 utterances per GPU (50 k over 8 GPUs), at
+        # world 1 too: the per-GPU share is what one MI355X does in the 8-GPU job
+        x_keep = x
+        x = xs = None              # release the 2.4 GB frame block of the EM workload (the CPU baseline below makes its own frames)
+        del x_keep
+        torch.cuda.empty_cache()
+        tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1, check=check, cpu=(world == 1),
+                            overlap=bool(args.overlap), traffic=traffic)
+        torch.cuda.empty_cache()
+        if world == 1:             # configs[4] is a single-GPU workload (model blocks shard without any exchange: lia_ral_amd.dist.score_model_block)
+            scoring = scoring_block(ctx, dev, M=args.score_vectors, S=args.score_vectors, check=check, traffic=traffic)
         if world == 1 and check and rank == 0:
             secondary["cpu_baseline"] = ivector_cpu_baseline(w, mean, iv)
-        if world > 1:          # configs[3] is natively multi-GPU: one T-matrix EM iteration on utterance-sharded statistics
-            x = xs = None          # release the 2.4 GB frame block of the EM workload
-            torch.cuda.empty_cache()
-            tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1, check=check, cpu=False, overlap=bool(args.overlap))
+            scoring["cpu_baseline"] = scoring_cpu_baseline()
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
@@ -900,6 +1119,10 @@ def main():
             out["host_layer"] = hostl
         if tv_em:
             out["tv_em"] = tv_em
+        if scoring:
+            out["scoring"] = scoring
+        out["screening"] = screening
+        out["library"] = traffic[2]
         if dense:
             out["dense_data"] = dense
         # per kernel: total ms per step, launches per step (frame chunks), algorithmic TFLOP/s
@@ -914,20 +1137,17 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])     # the dominant kernel of the step
             kd = kernels[dom]
             # HBM bytes per launch come from PMC counters, which only a rocprofv3 run can read: the figure of the committed PMC passes
-            # of the SAME command (tools/profile_r04.sh -> profiles/r04/bench_em_pmc_*.txt -> profiles/traffic.json), not of this run
-            traffic = traffic_src = None
-            tf = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tf):
-                try:
-                    tj = json.load(open(tf))
-                    traffic = tj.get(dom + "_hbm_bytes_per_launch")
-                    traffic_src = tj.get("source")
-                    if traffic and tj.get("frames_per_launch"):      # per launch of THIS run: the bytes scale with the frames of a launch
-                        traffic = traffic / tj["frames_per_launch"] * (T / kd["launches_per_step"])
-                except Exception:
-                    traffic = None
+            # of the SAME command on the SAME library build (load_traffic), scaled to the frames of a launch of this run -- else null
+            tj, traffic_note, _ = traffic
+            tr = traffic_src = None
+            if tj and tj.get(dom + "_hbm_bytes_per_launch") and tj.get("frames_per_launch"):
+                tr = tj[dom + "_hbm_bytes_per_launch"] / tj["frames_per_launch"] * (T / kd["launches_per_step"])
+                traffic_src = tj.get("source")
+            else:
+                traffic_src = traffic_note or "no entry for %s in profiles/traffic.json" % dom
+            traffic_val = tr
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kd["tflops"], "peak": PEAK_F64_TFLOPS,
-                               "unit": "TFLOP/s", "frac": kd["tflops"] / PEAK_F64_TFLOPS, "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": kd["tflops"] / PEAK_F64_TFLOPS, "traffic": traffic_val,
                                "traffic_source": traffic_src, "kernel_ms": kd["ms_per_launch"], "launches_per_step": kd["launches_per_step"],
                                "algorithmic_flop_per_launch": KERNEL_FLOP[dom] * T * C / kd["launches_per_step"]}
         # the whole EM step against SURVEY 8(d)'s per-pair figure (240 logit + 242 statistics flop; this design

@@ -442,6 +442,18 @@ def score_mahalanobis(models, segs, Mah, trials=None):
     return out
 
 
+def score_mahalanobis_mt(models, segs, Mah, threads=1):
+    """The per-pair form of mahalanobisDistance (liboracle_fast.so, -O3 -ffast-math) with the model rows split over `threads`
+    pthreads -- bench.py's cpu_baseline leg for config 5 only."""
+    m, mp = _d(models); s, sp = _d(segs)
+    dim, M = m.shape; S = s.shape[1]
+    out = np.zeros((M, S))
+    f = _lib(True).orc_score_mahalanobis_mt
+    f.restype = None
+    f(ct.c_int(int(threads)), ct.c_int(dim), ct.c_long(M), ct.c_long(S), mp, sp, _d(Mah)[1], out.ctypes.data_as(c_dp))
+    return out
+
+
 def twocov_model(Wm, Bm):
     Wm, wp = _d(Wm); Bm, bp = _d(Bm)
     n = Wm.shape[0]

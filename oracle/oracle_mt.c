@@ -144,3 +144,43 @@ int orc_iv_extract_mt(int nthreads, long U, int C, int D, int R, const double *w
     free(jobs); free(th);
     return rc;
 }
+
+/* IvTest Mahalanobis scoring in the reference's per-pair form (PldaTest::mahalanobisDistance, PldaTools.cpp:3882-3909: an O(dim^2)
+ * matrix-vector product per (model, segment) pair) with the model rows split over threads.  The reference runs this loop on ONE
+ * thread; the split exists so that bench.py can quote a many-core figure next to the single-thread one (BASELINE.md section 3,
+ * config 5).  models [dim x M], segs [dim x S], scores [M x S]. */
+void orc_score_mahalanobis(int dim, long M, long S, const double *models, const double *segs,
+                           const double *Mah, const unsigned char *trials, double *scores);
+
+typedef struct { int dim; long M, S; const double *models, *segs, *Mah; double *scores; } mah_job;
+
+static void *mah_worker(void *p)
+{
+    mah_job *j = p;
+    if (j->M > 0) orc_score_mahalanobis(j->dim, j->M, j->S, j->models, j->segs, j->Mah, NULL, j->scores);
+    return NULL;
+}
+
+void orc_score_mahalanobis_mt(int nthreads, int dim, long M, long S, const double *models, const double *segs, const double *Mah,
+                              double *scores)
+{
+    if (nthreads < 1) nthreads = 1;
+    mah_job *jobs = calloc(nthreads, sizeof(mah_job));
+    pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
+    double **blk = calloc(nthreads, sizeof(double *));
+    const long per = (M + nthreads - 1) / nthreads;
+    for (int i = 0; i < nthreads; ++i) {
+        long b = i * per, e = b + per > M ? M : b + per;
+        if (b > M) b = e = M;
+        mah_job *j = &jobs[i];
+        const long n = e - b;
+        /* the scalar routine addresses models as [dim x M] with stride M: hand every worker a compact [dim x n] copy of its columns */
+        blk[i] = malloc(sizeof(double) * (size_t)dim * (n > 0 ? n : 1));
+        for (int k = 0; k < dim; ++k)
+            for (long m = 0; m < n; ++m) blk[i][(size_t)k * n + m] = models[(size_t)k * M + b + m];
+        j->dim = dim; j->M = n; j->S = S; j->models = blk[i]; j->segs = segs; j->Mah = Mah; j->scores = scores + (size_t)b * S;
+        pthread_create(&th[i], NULL, mah_worker, j);
+    }
+    for (int i = 0; i < nthreads; ++i) { pthread_join(th[i], NULL); free(blk[i]); }
+    free(jobs); free(th); free(blk);
+}
