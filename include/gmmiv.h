@@ -90,6 +90,11 @@ const char *gmmiv_version(void);
  *   "gemm_nt80" 1      split-K NT products whose N is a multiple of 80 but not of 128 (aux = F (T Sigma^-1)^T at rank 400) on 128 x 80
  *                      tiles instead of 128 x 128 tiles + a 16-column strip; 0: the latter (A/B switch)
  *   "chol_lds" 1       chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
+ *   "k1_pc" 0          1: the log-likelihood pass as a producer / consumer pipeline (llk_pc.hip: four MFMA waves hand their logit tiles
+ *                      through LDS to four exponential waves; D <= 60, calls of more than 32 768 frames).  Bitwise the default kernel's
+ *                      results; MEASURED SLOWER (0.59 against 0.74 of the fp64 peak: on gfx950 an f64 MFMA occupies the vector ALUs, VALU
+ *                      work of another wave does not overlap with a saturated matrix pipe -- profiles/r05/k1_pc_ablation.txt); kept as the
+ *                      record of that experiment
  *   "chol_flow" 1      batched Cholesky k_chol_left2 (panel staged first, diagonal update from LDS on all waves); 0: round 2's k_chol_left
  *   "kopts_bound"      read-only: 1 when this context's kernel-launcher options are the set bound to the calling thread (they are
  *                      bound by each call of the context on entry)

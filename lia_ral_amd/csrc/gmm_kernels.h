@@ -56,6 +56,9 @@ int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ld
                double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin);
 // k_llk_mfma<TC>: candidates of the top-C' selection collected in the log-likelihood kernel (see gmm_kernels.hip), ranked by
 // gmmk_topc_rank (topc_z.hip)
+// llk_pc.hip: the same pass with role-split waves (option "k1_pc"); zbuf == NULL: plain log-likelihood
+int gmmk_llk_pc(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct, double *lse,
+                double *zbuf, long nfb, int *eit, double *inv, int *efin);
 int gmmk_topc_cap(void);
 int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct, int use_glds,
                   int ctop, double *cand, int *cnt, double *theta, double *slow, int *efin);

@@ -234,6 +234,30 @@ def test_em_accumulates_weights_and_chunks(ctx):
     assert relerr(wn, wo) < 1e-9 and relerr(mn, mo) < 1e-9 and relerr(cn, co) < 1e-8
 
 
+def test_k1_producer_consumer_is_bitwise_the_alternating_kernel(ctx):
+    """llk_pc.hip (option "k1_pc", round-5 experiment, off by default): four MFMA waves hand their logit tiles through LDS to four
+    exponential waves.  Same arithmetic on the same values in the same order per frame row as k_llk_mfma: the EM accumulator, the
+    Baum-Welch N / F rows, the posterior matrix and the plain per-frame log-likelihoods are BITWISE those of the default kernel (a
+    call of more than 32 768 frames -- shorter ones keep the 4-wave kernel -- with a ragged last workgroup), and the oracle's."""
+    w, mean, iv = make_gmm(512, 60, seed=21)
+    T = 40_000 + 77
+    x = make_frames(w, mean, iv, T, seed=22)
+    g = ctx.gmm(w, mean, iv)
+    ub = np.array([0, 10_000, 10_000, 33_333, T])
+    out = {}
+    for pc in (0, 1):
+        ctx.set_option("k1_pc", pc)
+        N = np.zeros((4, 512)); F = np.zeros((4, 512 * 60))
+        g.tv_stats(x, ub, N, F)
+        out[pc] = (g.em_accumulate(x), g.llk(x), N, F, g.occ(x[:33_000]))
+    ctx.set_option("k1_pc", 0)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    ref = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
+    a = g.split_acc(out[1][0])
+    assert a["count"] == T and relerr(a["occ"], ref["occ"]) < 1e-9 and relerr(a["sx"], ref["sx"]) < 1e-9 and relerr(a["sxx"], ref["sxx"]) < 1e-9
+
+
 def test_workgroup_shapes_agree(ctx):
     """4-wave and 8-wave workgroup variants of the two MFMA kernels compute the same sums."""
     w, mean, iv = make_gmm(2048, 60, seed=21)

@@ -34,15 +34,20 @@ def _free_port():
     return p
 
 
-def _case():
+def _case(kind="small"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_frames, make_gmm
-    C, D, R, U = 7, 12, 10, 60                       # 7 Gaussians: blocks of 4 + 3 on two ranks, 3 + 3 + 1 on three
+    if kind == "north_star":
+        # BASELINE.json north_star's own split: the 2048-Gaussian x 60-dim UBM over 8 ranks = blocks of 256 Gaussians, no padding;
+        # the EM all-reduce is the real 247 810-double accumulator (rank 40 and 320 utterances keep the oracle loop in seconds)
+        C, D, R, U, nfr = 2048, 60, 40, 320, 8003
+    else:
+        C, D, R, U, nfr = 7, 12, 10, 60, 5003        # 7 Gaussians: blocks of 4 + 3 on two ranks, 3 + 3 + 1 on three
     rng = np.random.default_rng(3)
     w, mean, iv = make_gmm(C, D, seed=3)
     N = rng.gamma(0.8, 3.0, (U, C)); F = rng.normal(size=(U, C * D)) * 3 + np.repeat(N, D, 1) * mean.ravel()
     Tm = rng.normal(0, 0.05, (R, C * D))
-    x = make_frames(w, mean, iv, 5003, seed=9)       # the EM leg: 5003 frames, not divisible either
+    x = make_frames(w, mean, iv, nfr, seed=9)        # the EM leg: a frame count no world size divides
     return C, D, R, U, w, mean, iv, N, F, Tm, x
 
 
@@ -87,7 +92,7 @@ class DeviceTvOps:
         return Tn
 
 
-def _run_rank(rank, world, transport, port, idfile, overlap=False):
+def _run_rank(rank, world, transport, port, idfile, overlap=False, kind="small", nb_it=2):
     """One rank: returns (T, means, em_acc, backend name) as numpy.  overlap: the whole thing twice -- serial order, then with the
     exchange started early (gmmiv_*_begin / hooks) from the same initial state -- and the bitwise comparison instead of the EM leg."""
     import torch
@@ -106,12 +111,12 @@ def _run_rank(rank, world, transport, port, idfile, overlap=False):
     else:
         os.environ["GMMIV_COMM_TRANSPORT"] = "shm"         # rank 0 draws a shm id
         os.environ["GMMIV_COMM_SHM_SLOT_MB"] = "1"         # (payloads larger than a slot: test_shm_collectives_chunked)
-        uid = capi.Comm.exchange_id_file(idfile, rank, 120.0)
+        uid = capi.Comm.exchange_id_file(idfile, rank, 300.0)
         coll = gd.GmmivCollectives(capi.Comm(ctx, world, rank, uid))
-    C, D, R, U, w, mean, iv, N, F, Tm, x = _case()
+    C, D, R, U, w, mean, iv, N, F, Tm, x = _case(kind)
     b, e = gd.shard_range(U, rank, world)
     ops = DeviceTvOps(ctx, C, D, R, N[b:e], F[b:e], Tm, iv, mean, world)
-    for _ in range(2):
+    for _ in range(nb_it):
         Tg = gd.tv_em_iteration(ops, U, C, D, rank, world, coll)
     if overlap:
         ops2 = DeviceTvOps(ctx, C, D, R, N[b:e], F[b:e], Tm, iv, mean, world)
@@ -143,10 +148,10 @@ def _run_rank(rank, world, transport, port, idfile, overlap=False):
     return out
 
 
-def _rank_main(rank, world, transport, port, idfile, q, overlap=False):
+def _rank_main(rank, world, transport, port, idfile, q, overlap=False, kind="small", nb_it=2):
     sys.path.insert(0, ROOT)
     try:
-        q.put((rank, _run_rank(rank, world, transport, port, idfile, overlap)))
+        q.put((rank, _run_rank(rank, world, transport, port, idfile, overlap, kind, nb_it)))
     except Exception as ex:      # noqa: BLE001 - reported to the parent, which fails the test
         import traceback
         q.put((rank, "rank %d: %r\n%s" % (rank, ex, traceback.format_exc())))
@@ -200,6 +205,48 @@ def test_sharded_tv_em_and_ubm_em_on_one_gpu(world, transport, tmp_path, single_
         assert relerr(Tg, T1) < 1e-11 and relerr(mg, m1) < 1e-11          # == the single-rank HIP iteration
         assert relerr(Tg, To) < 1e-6 and relerr(mg, mo) < 1e-8             # == the oracle's TotalVariability loop
         assert relerr(accg[:-2], acc1[:-2]) < 1e-11 and accg[-1] == x.shape[0] and abs(accg[-2] - acc1[-2]) < 1e-9 * abs(acc1[-2])
+    og = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
+    a = res[0][2]
+    assert relerr(a[:C], og["occ"]) < 1e-9 and relerr(a[C:C + C * D], og["sx"].ravel()) < 1e-9
+
+
+@pytest.mark.timeout(1500)
+def test_north_star_eight_way_split_of_the_2048_gaussian_ubm_on_one_gpu(tmp_path):
+    """BASELINE.json north_star's exact partitioning, executed: EIGHT ranks (processes) on GPU 0 over the C ABI's shm transport, the
+    2048-Gaussian x 60-dim UBM in blocks of 256 Gaussians (no padding) -- reduce-scatter of A_packed / Cmx by those blocks, rank g's
+    updateTestimate on ITS 256 Gaussians (AccumulateTVStat.cpp:981-1000), all-gather of T, the all-reduce of R / r / meanW,
+    minDivergence -- and the TrainWorld all-reduce of the real 247 810-double EM accumulator (AccumulateStat.cpp:286-292).  Every
+    rank ends bitwise equal; equal to the single-rank HIP run (summation order differs: 1e-10) and to the oracle's loop."""
+    import torch
+    import torch.multiprocessing as mp
+    world, kind, nb_it = 8, "north_star", 1
+    try:
+        T1, m1, acc1, _ = _run_rank(0, 1, None, 0, "", False, kind, nb_it)
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_main, args=(r, world, "shm", 0, str(tmp_path / "comm.id"), q, False, kind, nb_it)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, payload = q.get(timeout=1200)
+        assert not isinstance(payload, str), payload
+        res[r] = payload
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    C, D, R, U, w, mean, iv, N, F, Tm, x = _case(kind)
+    assert C % world == 0 and C // world == 256 and acc1.size == 247810
+    To, mo = _oracle_loop(C, D, U, mean, iv, N, F, Tm, nb_it)
+    for r in range(world):
+        Tg, mg, accg, name = res[r]
+        assert "shm" in name and "8 ranks" in name
+        assert np.array_equal(Tg, res[0][0]) and np.array_equal(mg, res[0][1]) and np.array_equal(accg, res[0][2])
+        assert relerr(Tg, T1) < 1e-10 and relerr(mg, m1) < 1e-10
+        assert relerr(Tg, To) < 1e-6 and relerr(mg, mo) < 1e-8
+        assert relerr(accg[:-2], acc1[:-2]) < 1e-10 and accg[-1] == x.shape[0] and abs(accg[-2] - acc1[-2]) < 1e-9 * abs(acc1[-2])
     og = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
     a = res[0][2]
     assert relerr(a[:C], og["occ"]) < 1e-9 and relerr(a[C:C + C * D], og["sx"].ravel()) < 1e-9
