@@ -143,7 +143,14 @@ long gmmiv_ctx_kernel_launches(gmmiv_ctx *ctx, const char *kernel_name);
 
 /* ---- model: MixtureGD / DistribGD ----------------------------------------------------------
  * w[C], mean[C*D], covinv[C*D] (DistribGD::getMeanVect / getCovInvVect, MixtureGD::weight(c);
- * LIA_SpkTools/src/AccumulateTVStat.cpp:154-162).  cst/det are derived like computeAll(). */
+ * LIA_SpkTools/src/AccumulateTVStat.cpp:154-162).  cst/det are derived like computeAll().
+ * SHAPES.  mixtureDistribCount, vectSize and topDistribsCount are free configuration keys of the reference
+ * (LIA_SpkDet/TrainWorld/cfg/TrainWorld.cfg, ComputeTest.cpp:129-215) and none of them is refused here: vectSize <= 80 runs the fp64
+ * MFMA kernels (compiled for D <= 16 / 32 / 60 / 80; the stored-likelihood statistics path for D <= 60); a larger vectSize (<= 4096)
+ * runs generic paths with the same results -- logits in the reference's direct form on the vector ALUs, statistics as
+ * gamma^T [x | 1 | x^2] on the fp64 GEMM -- at about a tenth of the rate.  The fused / stored-likelihood top-C selection serves
+ * topDistribsCount <= 16 / <= 60, the LDS selection kernel <= 64 with up to ~4 700 Gaussians; anything beyond (8192 Gaussians,
+ * topDistribsCount 100, ...) goes through an any-shape selection kernel whose logit rows live in device scratch. */
 int gmmiv_gmm_create(gmmiv_ctx *ctx, int C, int D, const double *w, const double *mean,
                      const double *covinv, gmmiv_gmm **out);
 int gmmiv_gmm_set(gmmiv_gmm *g, const double *w, const double *mean, const double *covinv);

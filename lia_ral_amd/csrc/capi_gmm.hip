@@ -212,7 +212,9 @@ int gmmiv_gmm_create(gmmiv_ctx *c, int C, int D, const double *w, const double *
 {
     if (!c || !out || !w || !mean || !covinv || C <= 0 || D <= 0) { gmmiv_set_error("gmm_create: bad argument"); return GMMIV_ERR_ARG; }
     const int KS = gmmk_ks_for_dim(D);
-    if (!KS) { gmmiv_set_error("gmm_create: vectSize %d not supported (max 80)", D); return GMMIV_ERR_UNSUPPORTED; }
+    if (!KS) { gmmiv_set_error("gmm_create: vectSize %d not supported (max %d)", D, GMMK_MAX_DIM); return GMMIV_ERR_UNSUPPORTED; }
+    // KS == GMMK_KS_GENERIC (vectSize > 80): no packed MFMA model; every entry point takes its generic path (VALU logits in the
+    // reference's direct form, statistics as gamma^T [x | 1 | x^2] on the fp64 GEMM) -- slower, same results, nothing refused
     GBIND(c);
     gmmiv_gmm *g = new gmmiv_gmm();
     g->ctx = c; g->C = C; g->D = D; g->KS = KS;
@@ -221,7 +223,7 @@ int gmmiv_gmm_create(gmmiv_ctx *c, int C, int D, const double *w, const double *
     const size_t CD = (size_t)C * D;
     const int Cpa = g->Cp64 > g->nct * 16 ? g->Cp64 : g->nct * 16;
     struct { void **p; size_t n; } need[] = {{(void **)&g->w, (size_t)C}, {(void **)&g->mean, CD}, {(void **)&g->iv, CD}, {(void **)&g->a, (size_t)Cpa},
-                                           {(void **)&g->lwc, (size_t)Cpa}, {(void **)&g->Pt, (size_t)g->nct * (2 * KS + 2) * 64},
+                                           {(void **)&g->lwc, (size_t)Cpa}, {(void **)&g->Pt, KS == GMMK_KS_GENERIC ? (size_t)64 : (size_t)g->nct * (2 * KS + 2) * 64},
                                            {(void **)&g->meanT, (size_t)D * g->Cp64}, {(void **)&g->ivT, (size_t)D * g->Cp64}};
     for (auto &a : need) {
         const hipError_t e = hipMalloc(a.p, a.n * sizeof(double));
@@ -513,11 +515,45 @@ int gmmiv_segment_means(gmmiv_ctx *c, const double *v, int64_t ld, int nrows, co
 // zero-likelihood frames of kind (2) among the n frames whose log-sums K1 has just left in `lse` -> the context's device counter
 static int count_dead(gmmiv_ctx *c, const double *lse, int64_t n) { return gmmk_count_dead(c->stream, lse, (long)n, c->d_zero_llk); }
 
+static const void *x_at(const XView &xv, int dt, int64_t frame);
+// DETERMINE_TOP_DISTRIBS by the any-shape kernel (k_topc_determine_big), frames in chunks whose logit rows fit 1 GiB of scratch
+static int topc_big(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, int ctop, int complete, double lo, double hi,
+                    int *idx, double *lk, double *nlk, double *nllk, double *nw, double *llk)
+{
+    if (T <= 0) return GMMIV_OK;
+    int64_t per = (int64_t)(((size_t)1 << 30) / ((size_t)g->Cp64 * sizeof(double))) / 4 * 4;
+    if (per < 4) per = 4;
+    if (per > T) per = (T + 3) / 4 * 4;
+    void *zs;
+    int rc = c->scratch(WS_Z, gmmk_topc_big_scratch_doubles((long)per, g->Cp64) * sizeof(double), &zs);
+    if (rc) return rc;
+    c->t_begin("k_topc_determine");
+    for (int64_t c0 = 0; c0 < T; c0 += per) {
+        const int64_t n = T - c0 < per ? T - c0 : per;
+        int krc = gmmk_topc_determine_big(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), (long)n, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc,
+                                          g->w, ctop, complete, lo, hi, idx + (size_t)c0 * ctop, lk ? lk + (size_t)c0 * ctop : nullptr,
+                                          nlk ? nlk + c0 : nullptr, nllk ? nllk + c0 : nullptr, nw ? nw + c0 : nullptr, llk ? llk + c0 : nullptr,
+                                          (double *)zs);
+        if (krc == -1) { gmmiv_set_error("vectSize %d exceeds the generic kernels' bound", g->D); return GMMIV_ERR_UNSUPPORTED; }
+        GCHK(krc);
+    }
+    c->t_end();
+    return GMMIV_OK;
+}
+
 static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, double **lse_out)
 {
     void *lse;
     int rc = c->scratch(WS_LSE, (size_t)(T > 0 ? T : 1) * sizeof(double), &lse);
     if (rc) return rc;
+    if (g->KS == GMMK_KS_GENERIC) { // no MFMA instantiation: log sum_c w_c lk_c in the direct form (the top-1 pass of the any-shape kernel, COMPLETE)
+        void *ix;
+        if ((rc = c->scratch(WS_EIT, (size_t)(T > 0 ? T : 1) * sizeof(int), &ix))) return rc;
+        if ((rc = topc_big(c, g, xv, dt, T, 1, 1, -INFINITY, INFINITY, (int *)ix, nullptr, nullptr, nullptr, nullptr, (double *)lse))) return rc;
+        GCHK(count_dead(c, (const double *)lse, T));
+        *lse_out = (double *)lse;
+        return GMMIV_OK;
+    }
     c->t_begin("k_llk_mfma");
     GCHK(gmmk_llk(c->stream, g->KS, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->Pt, g->nct, (double *)lse, (int)(c->use_glds | (c->dbg << 8)), (int)c->wg_waves));
     c->t_end();
@@ -582,8 +618,8 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     // no silent clamp: the stride of idx / lk is the caller's ctop, so a caller that asks for more than the model has must
     // clamp on its side (liagpu::computeTestLLR and the Python binding do) -- otherwise its buffers and use_top disagree
     if (ctop > g->C) { gmmiv_set_error("determine_top: topDistribsCount %d exceeds mixtureDistribCount %d (clamp it at the call site)", ctop, g->C); return GMMIV_ERR_ARG; }
-    if (ctop > 64) { gmmiv_set_error("determine_top: topDistribsCount %d > 64 not supported", ctop); return GMMIV_ERR_UNSUPPORTED; }
-    if (!gmmk_topc_frames_per_block(g->Cp64, g->D)) { gmmiv_set_error("determine_top: mixtureDistribCount %d too large for the LDS selection kernel", g->C); return GMMIV_ERR_UNSUPPORTED; }
+    // (topDistribsCount > 64, or a model whose logit rows do not fit LDS -- about 4 700 Gaussians --, go through the any-shape kernel at
+    //  the end of this function: mixtureDistribCount / vectSize / topDistribsCount are free keys of the reference, ComputeTest.cpp:129-215)
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
     Screen sc;
@@ -815,7 +851,9 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
         GCHK(hipStreamSynchronize(c->stream));
         done = hflag == 0;
     }
-    if (!done) {
+    if (!done && (ctop > 64 || !gmmk_topc_frames_per_block(g->Cp64, g->D))) {
+        if ((rc = topc_big(c, g, xv, dt, T, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_idx.d, o_lk.d, o_nlk.d, o_nllk.d, o_nw.d, o_llk.d))) return rc;
+    } else if (!done) {
         c->t_begin("k_topc_determine");
         GCHK(gmmk_topc_determine(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc,
                                  g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_idx.d, o_lk.d, o_nlk.d,
@@ -883,7 +921,7 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
 {
     int rc = check_model(c, g);
     if (rc) return rc;
-    if (T < 0 || !idx || !llk_out || ctop <= 0 || ctop > 64) { gmmiv_set_error("use_top: bad argument"); return GMMIV_ERR_ARG; }
+    if (T < 0 || !idx || !llk_out || ctop <= 0) { gmmiv_set_error("use_top: bad argument"); return GMMIV_ERR_ARG; }
     if (ctop > g->C) { gmmiv_set_error("use_top: topDistribsCount %d exceeds mixtureDistribCount %d", ctop, g->C); return GMMIV_ERR_ARG; }
     if (mode == GMMIV_TOP_COMPLETE && !nontop_llk) { gmmiv_set_error("use_top: COMPLETE mode needs nontop_llk"); return GMMIV_ERR_ARG; }
     XView xv;
@@ -909,10 +947,12 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     c->t_begin("k_topc_use");
     // four lanes per candidate, one frame per wave ("topc_use_lanes" 1: one lane per candidate, four frames per wave) when the
     // selection has at most 16 entries (topc_z.hip); else one wave per frame
-    int krc = c->topc_z ? gmmk_topc_use16(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
+    int krc = ctop > 64 ? gmmk_topc_use_big(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
+                                            mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d)
+              : c->topc_z ? gmmk_topc_use16(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
                                           mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d, (int)c->topc_use_lanes)
                         : -1;
-    if (krc == -1)
+    if (krc == -1 && ctop <= 64)
         krc = gmmk_topc_use(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, g->D, g->mean, g->iv, g->lwc, g->C, ctop, i_idx.d, i_n.d,
                             mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, o_llk.d);
     GCHK(krc);
@@ -933,7 +973,7 @@ int gmmiv_llk_use_top_multi(gmmiv_ctx *c, int n_clients, const gmmiv_gmm *const 
         if (clients[i]->D != clients[0]->D) { gmmiv_set_error("use_top_multi: client %d has %d dimensions, client 0 has %d", i, clients[i]->D, clients[0]->D); return GMMIV_ERR_ARG; }
         if (ctop > clients[i]->C) { gmmiv_set_error("use_top_multi: topDistribsCount %d exceeds mixtureDistribCount %d of client %d", ctop, clients[i]->C, i); return GMMIV_ERR_ARG; }
     }
-    if (T < 0 || !idx || !llk_out || ctop <= 0 || ctop > 64) { gmmiv_set_error("use_top_multi: bad argument"); return GMMIV_ERR_ARG; }
+    if (T < 0 || !idx || !llk_out || ctop <= 0) { gmmiv_set_error("use_top_multi: bad argument"); return GMMIV_ERR_ARG; }
     if (mode == GMMIV_TOP_COMPLETE && !nontop_llk) { gmmiv_set_error("use_top_multi: COMPLETE mode needs nontop_llk"); return GMMIV_ERR_ARG; }
     const gmmiv_gmm *g0 = clients[0];
     // a HOST output of [n_clients x T] is staged on the device: bound the staging to 1 GiB by going through the clients in groups
@@ -1089,6 +1129,34 @@ static int64_t z_chunk_frames(gmmiv_ctx *c, const gmmiv_gmm *g)
 }
 static const void *x_at(const XView &xv, int dt, int64_t frame) { return (const char *)xv.d + (size_t)frame * xv.ldx * esize(dt); }
 
+// ---- statistics of a model WITHOUT an MFMA instantiation (vectSize > 80): gamma[t][c] = exp(z_tc - lse_t) by the direct-form VALU
+// kernel (k_posteriors), then S[C x NC] (+)= gamma^T [x | 1 | x^2 | 0] on the fp64 GEMM (k_dgemm), frames in chunks whose posterior
+// block fits 512 MiB.  S: sum_t g x | sum_t g | sum_t g x^2.  The same sums as MixtureStat::computeAndAccumulateEM
+// (AccumulateStat.cpp:103-152) / TVAcc::computeAndAccumulateTVStat (AccumulateTVStat.cpp:332-348), any vectSize.
+static int generic_gamma_gemm(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t t0, int64_t n, const double *lse, bool sq, int NC,
+                              double *S)
+{
+    int rc;
+    int64_t per = (int64_t)(((size_t)512 << 20) / ((size_t)g->C * sizeof(double)));
+    if (per < 64) per = 64;
+    per = per / 2 * 2; // an even K keeps the aligned GEMM instantiation
+    void *gam, *xa;
+    const int64_t first = n < per ? n : per;
+    if ((rc = c->scratch(WS_Z, (size_t)(first > 0 ? first : 1) * g->C * sizeof(double), &gam))) return rc;
+    if ((rc = c->scratch(WS_INV, (size_t)(first > 0 ? first : 1) * NC * sizeof(double), &xa))) return rc;
+    if (n <= 0) { GCHK(hipMemsetAsync(S, 0, (size_t)g->C * NC * sizeof(double), c->stream)); return GMMIV_OK; }
+    for (int64_t b = 0; b < n; b += per) {
+        const int64_t m = n - b < per ? n - b : per;
+        c->t_begin("k_posteriors", b == 0);
+        GCHK(gmmk_posteriors(c->stream, dt == GMMIV_F64, x_at(xv, dt, t0 + b), (long)m, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc, lse + t0 + b,
+                             (double *)gam));
+        c->t_end();
+        GCHK(gmmk_build_xa(c->stream, dt == GMMIV_F64, x_at(xv, dt, t0 + b), xv.ldx, g->D, (long)m, sq ? 1 : 0, NC, (double *)xa));
+        GCHK(tvk_dgemm(c->stream, true, false, g->C, NC, (int)m, 1.0, (const double *)gam, g->C, 0, (const double *)xa, NC, 0, b == 0 ? 0.0 : 1.0, S, NC, 0, 1));
+    }
+    return GMMIV_OK;
+}
+
 // EM statistics of frames [0, T) into the partial blocks part[nseg] (summed by the caller)
 static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, int64_t T, int64_t Tc, double weight,
                       double *lse, int *nseg_out, void **part_out)
@@ -1230,6 +1298,14 @@ two_pass:
     // sum_t weight * log lk_t  and  sum_t weight
     GCHK(gmmk_llk_finalize(c->stream, lse, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
                            o.d + nacc - 2, weight, o.d + nacc - 1));
+    if (g->KS == GMMK_KS_GENERIC) { // no MFMA instantiation for this vectSize: gamma^T [x | 1 | x^2] on the fp64 GEMM
+        const int NC = 2 * g->D + 2;
+        void *S;
+        if ((rc = c->scratch(WS_PART, (size_t)g->C * NC * sizeof(double), &S))) return rc;
+        if ((rc = generic_gamma_gemm(c, g, xv, dt, 0, T, lse, true, NC, (double *)S))) return rc;
+        GCHK(gmmk_scatter_em(c->stream, g->C, g->D, NC, (const double *)S, weight, o.d));
+        return o.finish();
+    }
     // frame chunks: enough workgroups to fill the chip about twice, each >= 4096 frames
     const int nw = c->wg_waves == 8 ? 8 : 4;
     const int ngrp = (g->nct + nw - 1) / nw;
@@ -1470,6 +1546,17 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     }
     double *lse;
     if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
+    if (g->KS == GMMK_KS_GENERIC) { // utterance by utterance: S_u = gamma_u^T [x | 1], N row = its last column, F row = the rest
+        const int NC = g->D + 2 - (g->D & 1); // [x | 1] padded to an even width
+        void *S;
+        if ((rc = c->scratch(WS_PART, (size_t)g->C * NC * sizeof(double), &S))) return rc;
+        for (int64_t u = 0; u < U; ++u) {
+            if ((rc = generic_gamma_gemm(c, g, xv, dt, utt_begin[u], utt_begin[u + 1] - utt_begin[u], lse, false, NC, (double *)S))) return rc;
+            GCHK(gmmk_scatter_nf(c->stream, g->C, g->D, NC, (const double *)S, o_n.d + (size_t)u * g->C, o_f.d + (size_t)u * SV));
+        }
+        if ((rc = o_n.finish())) return rc;
+        return o_f.finish();
+    }
     // every (u, c < C) row is written by exactly one wave (zeros for an empty utterance)
     c->t_begin("k_stats_mfma");
     GCHK(gmmk_stats(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, lse, 0.0,

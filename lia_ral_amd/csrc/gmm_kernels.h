@@ -5,6 +5,8 @@
 
 #include "kopts.h"
 
+#define GMMK_KS_GENERIC 99 // "no MFMA instantiation for this vectSize": every KS > 15 / KS <= 15 test of the callers routes it to the fallback side
+#define GMMK_MAX_DIM 4096  // the generic kernels keep 4 frames x D doubles in LDS
 int gmmk_ks_for_dim(int D);   // k-steps (of 4 dims) of the compiled instantiation serving D, 0 = unsupported
 int gmmk_rl_for_ks(int KS);   // row length (doubles) of the LDS frame tile / half-width of an EM partial row
 int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, const double *w, const double *mean,
@@ -28,6 +30,18 @@ int gmmk_topc_determine(hipStream_t st, int x_f64, const void *x, long T, long l
                         const double *meanT, const double *ivT, const double *lwc, const double *w, int ctop,
                         int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
                         double *nw, double *llk);
+// generic statistics (capi_gmm.hip, models without an MFMA instantiation): Xa rows for the GEMM, scatter of S = gamma^T Xa
+int gmmk_build_xa(hipStream_t st, int x_f64, const void *x, long ldx, int D, long n, int sq, int NC, double *Xa);
+int gmmk_scatter_em(hipStream_t st, int C, int D, int NC, const double *S, double scale, double *acc);
+int gmmk_scatter_nf(hipStream_t st, int C, int D, int NC, const double *S, double *Nrow, double *Frow);
+size_t gmmk_topc_big_scratch_doubles(long T, int Cp);
+int gmmk_topc_determine_big(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp,
+                            const double *meanT, const double *ivT, const double *lwc, const double *w, int ctop,
+                            int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                            double *nw, double *llk, double *zs); // any C / D / ctop: logit rows in global scratch (gmmk_topc_big_scratch_doubles)
+int gmmk_topc_use_big(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
+                      const double *iv, const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete,
+                      double lo, double hi, double *llk); // ctop > 64
 int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
                   const double *iv, const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete,
                   double lo, double hi, double *llk);

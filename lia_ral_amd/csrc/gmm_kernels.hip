@@ -1006,6 +1006,141 @@ __global__ __launch_bounds__(256) void k_topc_determine(
     }
 }
 
+// The SAME selection for shapes the LDS kernel above does not serve -- any mixtureDistribCount, vectSize and topDistribsCount (all
+// free configuration keys of the reference: ComputeTest.cpp:129-215, TrainWorld.cfg): the logits of a frame live in a GLOBAL scratch
+// row (zs: 4 rows of Cp doubles per workgroup, L2-resident while the frame is worked on) instead of LDS, the selected Gaussians
+// are written as they are found (no per-lane result registers, so no bound of 64 on ctop; the row is never modified: round k takes
+// the first entry after the previous pick in the order (logit descending, index ascending)), sums relative to the largest logit M.
+// One wave per frame, four frames per workgroup.  Same rules as k_topc_determine: direct form, ties to the lowest index, a NaN
+// logit is likelihood 0, a zero-likelihood frame gets the lowest indices and lk 0.  A fallback (37 G pairs/s class), not a hot path.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_determine_big(
+    const void *__restrict__ x, long T, long ldx, int D, int C, int Cp, const double *__restrict__ meanT,
+    const double *__restrict__ ivT, const double *__restrict__ lwc, const double *__restrict__ w, int ctop,
+    int complete, double lo, double hi, int *__restrict__ idx_out, double *__restrict__ lk_out,
+    double *__restrict__ nontop_lk, double *__restrict__ nontop_llk, double *__restrict__ nontop_w,
+    double *__restrict__ llk_out, double *__restrict__ zs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem; // [4][D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tb = (long)blockIdx.x * 4;
+    double *zb = zs + (size_t)blockIdx.x * 4 * Cp;
+    for (int e = tid; e < 4 * D; e += 256) {
+        const int f = e / D, d = e - f * D;
+        xs[e] = (tb + f < T) ? feat_load<XT>::get(x, (tb + f) * ldx + d) : 0.0;
+    }
+    __syncthreads();
+    for (int c = tid; c < Cp; c += 256) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int d = 0; d < D; ++d) {
+            const double mu = meanT[(size_t)d * Cp + c], iv = ivT[(size_t)d * Cp + c];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const double dx = xs[f * D + d] - mu;
+                acc[f] = __builtin_fma(dx * dx, iv, acc[f]);
+            }
+        }
+        const double a = lwc[c];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const double z = __builtin_fma(-0.5, acc[f], a);
+            zb[(size_t)f * Cp + c] = z == z ? z : -__builtin_inf();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const long t = tb + wave;
+    if (t >= T) return;
+    const double *z = zb + (size_t)wave * Cp;
+    const double NINF = -__builtin_inf();
+    // The selection walks the total order (logit descending, index ascending): round k takes the first entry that comes AFTER the
+    // previous pick (pv, pc) -- nothing is marked in memory, the logit row is only ever read.
+    double M = 0.0, st = 0.0, snsw = 1.0, pv = __builtin_inf();
+    int pc = -1;
+    bool dead = false;
+    for (int k = 0; k < ctop; ++k) {
+        double bv = NINF;
+        int bc = 0x7fffffff;
+        if (!dead) {
+            for (int c = lane; c < C; c += 64) {
+                const double v = z[c];
+                const bool after = v < pv || (v == pv && c > pc);
+                if (after && (v > bv || (v == bv && c < bc))) { bv = v; bc = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = shfl_xor_f64(bv, o);
+                const int oc = __shfl_xor(bc, o, 64);
+                if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+            }
+        }
+        if (k == 0) { M = bv; dead = !(M > GMMIV_ZERO_LLK); }
+        if (dead) { bc = k; bv = NINF; } // zero-likelihood frame: the lowest indices, likelihoods 0
+        pv = bv; pc = bc;
+        st += dead ? 0.0 : gexp(bv - M);
+        snsw -= w[bc];
+        if (lane == 0) {
+            idx_out[t * ctop + k] = bc;
+            if (lk_out) lk_out[t * ctop + k] = dead ? 0.0 : exp(bv);
+        }
+    }
+    double sr = 0.0; // the remainder = every entry after the last pick
+    if (!dead)
+        for (int c = lane; c < C; c += 64) {
+            const double v = z[c];
+            sr += (v < pv || (v == pv && c > pc)) ? gexp(v - M) : 0.0;
+        }
+    sr = wave_sum_f64(sr);
+    if (lane == 0) {
+        const double rest_llk = (sr > 0.0 && !dead) ? M + log(sr) : NINF;
+        if (nontop_llk) nontop_llk[t] = rest_llk;
+        if (nontop_lk) nontop_lk[t] = (sr > 0.0 && !dead) ? exp(rest_llk) : 0.0;
+        if (llk_out) {
+            const double tot = complete ? st + sr : st;
+            llk_out[t] = dead ? lo : fmin(fmax(M + log(tot), lo), hi);
+        }
+        if (nontop_w) nontop_w[t] = snsw; // 1 - the selected weights, subtracted in selection order (TopGauss.cpp:183-186)
+    }
+}
+
+// USE_TOP_DISTRIBS with more than 64 selected Gaussians: one wave per frame, the candidates in rounds of 64 (two sweeps: the
+// largest logit, then the sum relative to it).  Indices outside the model are skipped, never dereferenced.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_topc_use_big(const void *__restrict__ x, long T, long ldx, int D,
+                                                      const double *__restrict__ mean, const double *__restrict__ iv,
+                                                      const double *__restrict__ lwc, int C, int ctop,
+                                                      const int *__restrict__ idx, const double *__restrict__ nontop_llk,
+                                                      int complete, double lo, double hi, double *__restrict__ llk_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long t = (long)blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    const double NINF = -__builtin_inf();
+    auto logit = [&](int k) {
+        const int c = k < ctop ? idx[t * ctop + k] : -1;
+        if ((unsigned)c >= (unsigned)C) return NINF;
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double dx = feat_load<XT>::get(x, t * ldx + d) - mean[(size_t)c * D + d];
+            acc = __builtin_fma(dx * dx, iv[(size_t)c * D + d], acc);
+        }
+        const double z = __builtin_fma(-0.5, acc, lwc[c]);
+        return z == z ? z : NINF;
+    };
+    const double r = (complete && nontop_llk) ? nontop_llk[t] : NINF;
+    double M = r;
+    for (int k0 = 0; k0 < ctop; k0 += 64) M = fmax(M, logit(k0 + lane));
+    M = wave_max_f64(M);
+    double s = 0.0;
+    for (int k0 = 0; k0 < ctop; k0 += 64) { const double z = logit(k0 + lane); s += z > NINF ? gexp(z - M) : 0.0; }
+    s = wave_sum_f64(s);
+    if (lane == 0) {
+        if (r > NINF) s += gexp(r - M);
+        llk_out[t] = fmin(fmax(M + log(s), lo), hi);
+    }
+}
+
 // K1u: USE_TOP_DISTRIBS for a client model; one wave per frame, lane j evaluates Gaussian idx[t][j].
 template <typename XT>
 __global__ __launch_bounds__(256) void k_topc_use(const void *__restrict__ x, long T, long ldx, int D,
@@ -1127,7 +1262,7 @@ int gmmk_ks_for_dim(int D)
     if (D <= 32) return 8;
     if (D <= 60) return 15;
     if (D <= 80) return 20;
-    return 0;
+    return D <= GMMK_MAX_DIM ? GMMK_KS_GENERIC : 0; // no MFMA instantiation: the generic (VALU logits + fp64 GEMM statistics) paths of capi_gmm.hip
 }
 int gmmk_rl_for_ks(int KS) { return ((4 * KS + 2 + 31) / 32) * 32; }
 
@@ -1137,7 +1272,7 @@ int gmmk_pack_model(hipStream_t st, int C, int D, int KS, int nct, int Cp64, con
     const int Cp = Cp64 > nct * 16 ? Cp64 : nct * 16;
     k_gmm_const<<<(Cp + 255) / 256, 256, 0, st>>>(C, Cp, D, w, mean, iv, a, lwc);
     long total = (long)nct * (2 * KS + 2) * 64;
-    k_gmm_pack<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(C, D, KS, nct, mean, iv, a, Pt);
+    if (KS != GMMK_KS_GENERIC) k_gmm_pack<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(C, D, KS, nct, mean, iv, a, Pt);
     long tt = (long)D * Cp64;
     k_gmm_transpose<<<(unsigned)((tt + 255) / 256), 256, 0, st>>>(C, Cp64, D, mean, iv, meanT, ivT);
     return (int)hipGetLastError();
@@ -1541,6 +1676,94 @@ int gmmk_topc_determine(hipStream_t st, int x_f64, const void *x, long T, long l
         return x_f64 ? launch_topc<4, double>(st, x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk)
                      : launch_topc<4, float>(st, x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk);
     return -1;
+}
+
+// ---- generic statistics (a vectSize without an MFMA instantiation): S = gamma^T [x | 1 | x^2] by the fp64 GEMM ----
+// Xa[t] = [x_t(D) | 1 | x_t^2(D) | 0] (sq, NC = 2 D + 2) or [x_t(D) | 1] padded to an even NC = D + 2 - (D & 1) ... the caller passes NC
+template <typename XT>
+__global__ void k_build_xa(const void *__restrict__ x, long ldx, int D, long n, int sq, int NC, double *__restrict__ Xa)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * NC) return;
+    const long t = e / NC;
+    const int j = (int)(e - t * NC);
+    double v = 0.0;
+    if (j < D) v = feat_load<XT>::get(x, t * ldx + j);
+    else if (j == D) v = 1.0;
+    else if (sq && j <= 2 * D) { const double xv = feat_load<XT>::get(x, t * ldx + (j - D - 1)); v = xv * xv; }
+    Xa[e] = v;
+}
+int gmmk_build_xa(hipStream_t st, int x_f64, const void *x, long ldx, int D, long n, int sq, int NC, double *Xa)
+{
+    if (n <= 0) return 0;
+    const long tot = n * NC;
+    if (x_f64) k_build_xa<double><<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(x, ldx, D, n, sq, NC, Xa);
+    else k_build_xa<float><<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(x, ldx, D, n, sq, NC, Xa);
+    return (int)hipGetLastError();
+}
+// acc (flat EM accumulator: occ | sum x | sum x^2 | ...) += scale * S, S [C x NC] = [sum g x | sum g | sum g x^2 | 0]
+__global__ void k_scatter_em(int C, int D, int NC, const double *__restrict__ S, double scale, double *__restrict__ acc)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * (2 * D + 1)) return;
+    const int c = (int)(e / (2 * D + 1)), j = (int)(e - (long)c * (2 * D + 1));
+    const double v = scale * S[(size_t)c * NC + j];
+    if (j < D) acc[(size_t)C + (size_t)c * D + j] += v;
+    else if (j == D) acc[c] += v;
+    else acc[(size_t)C + (size_t)C * D + (size_t)c * D + (j - D - 1)] += v;
+}
+int gmmk_scatter_em(hipStream_t st, int C, int D, int NC, const double *S, double scale, double *acc)
+{
+    const long tot = (long)C * (2 * D + 1);
+    k_scatter_em<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(C, D, NC, S, scale, acc);
+    return (int)hipGetLastError();
+}
+// Nrow[c] = S[c][D], Frow[c * D + d] = S[c][d]  (rows are overwritten, like the MFMA path)
+__global__ void k_scatter_nf(int C, int D, int NC, const double *__restrict__ S, double *__restrict__ Nrow, double *__restrict__ Frow)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)C * (D + 1)) return;
+    const int c = (int)(e / (D + 1)), j = (int)(e - (long)c * (D + 1));
+    const double v = S[(size_t)c * NC + j];
+    if (j < D) Frow[(size_t)c * D + j] = v;
+    else Nrow[c] = v;
+}
+int gmmk_scatter_nf(hipStream_t st, int C, int D, int NC, const double *S, double *Nrow, double *Frow)
+{
+    const long tot = (long)C * (D + 1);
+    k_scatter_nf<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(C, D, NC, S, Nrow, Frow);
+    return (int)hipGetLastError();
+}
+
+// zs: gmmk_topc_big_scratch_doubles(T, Cp) doubles of device scratch (the logit rows of the frames in flight)
+size_t gmmk_topc_big_scratch_doubles(long T, int Cp) { return (size_t)((T + 3) / 4) * 4 * (size_t)Cp; }
+int gmmk_topc_determine_big(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, int C, int Cp,
+                            const double *meanT, const double *ivT, const double *lwc, const double *w, int ctop,
+                            int complete, double lo, double hi, int *idx, double *lk, double *nlk, double *nllk,
+                            double *nw, double *llk, double *zs)
+{
+    if (T <= 0) return 0;
+    const size_t lds = (size_t)4 * D * sizeof(double);
+    if (lds > 150 * 1024) return -1;
+    const unsigned grid = (unsigned)((T + 3) / 4);
+    if (x_f64) {
+        HIPCHK((gmmiv_lds_attr<k_topc_determine_big<double>>(lds)));
+        k_topc_determine_big<double><<<grid, 256, lds, st>>>(x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk, zs);
+    } else {
+        HIPCHK((gmmiv_lds_attr<k_topc_determine_big<float>>(lds)));
+        k_topc_determine_big<float><<<grid, 256, lds, st>>>(x, T, ldx, D, C, Cp, meanT, ivT, lwc, w, ctop, complete, lo, hi, idx, lk, nlk, nllk, nw, llk, zs);
+    }
+    return (int)hipGetLastError();
+}
+int gmmk_topc_use_big(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
+                      const double *iv, const double *lwc, int C, int ctop, const int *idx, const double *nllk, int complete,
+                      double lo, double hi, double *llk)
+{
+    if (T <= 0) return 0;
+    const unsigned grid = (unsigned)((T + 3) / 4);
+    if (x_f64) k_topc_use_big<double><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
+    else k_topc_use_big<float><<<grid, 256, 0, st>>>(x, T, ldx, D, mean, iv, lwc, C, ctop, idx, nllk, complete, lo, hi, llk);
+    return (int)hipGetLastError();
 }
 
 int gmmk_topc_use(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, const double *mean,
