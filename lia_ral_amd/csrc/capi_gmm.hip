@@ -133,7 +133,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     if (!strcmp(key, "z_depth_em")) { const long prev = c->ko.z_depth_em; if (value == 2 || value == 4) c->ko.z_depth_em = (int)value; return prev; }
     if (!strcmp(key, "z_depth_tv")) { const long prev = c->ko.z_depth_tv; if (value == 2 || value == 4) c->ko.z_depth_tv = (int)value; return prev; }
     if (!strcmp(key, "z_tv4")) ks = &c->ko.z_tv4;                 // A/B knob: 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z
-    else if (!strcmp(key, "gemm_remap")) ks = &c->ko.gemm_remap;   // A/B knob: 0 = hardware tile order in k_dgemm
+    else if (!strcmp(key, "gemm_remap")) ks = &c->ko.gemm_remap;   // A/B knob: 2 = 8 x 8 tile blocks per XCD, 1 = M tiles fastest per XCD (rounds 2-4), 0 = hardware tile order in k_dgemm
     else if (!strcmp(key, "gemm_clamp")) ks = &c->ko.gemm_clamp;   // A/B knob: 0 = cut GEMM tiles on the per-element checked instantiation
     else if (!strcmp(key, "gemm_narrow")) ks = &c->ko.gemm_narrow; // A/B knob: 0 = 128 x 128 tiles on the strips cut by M / N too
     else if (!strcmp(key, "gemm_nt80")) ks = &c->ko.gemm_nt80;     // A/B knob: 0 = no 128 x 80 tiles for N = 5 x 80 (aux at rank 400)

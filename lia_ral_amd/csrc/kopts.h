@@ -9,7 +9,7 @@ struct gmmiv_kopts {
     int z_waves = 8;      // workgroup shape of k_stats_z: 8 (one workgroup per CU), 16, or 4 (two per CU)
     int z_tv4 = 1;        // 0 = two Gaussian tiles per wave in the N / F mode of k_stats_z too
     int z_depth_em = 2, z_depth_tv = 4; // stream register sets of k_stats_z per mode (measured: EM 30.5 ms (2) / 31.1 (4) per 4 M frames, N / F 14.2 (four tiles, 2) / 13.7 (two tiles, 4) per 3 M)
-    int gemm_remap = 1;   // XCD-aware tile order in k_dgemm
+    int gemm_remap = 1;   // XCD-aware tile order in k_dgemm: 1 = an XCD walks the M tiles of its N-tile columns fastest; 2 = in 8 x 8 tile blocks (A/B, round 5: same FETCH_SIZE, same time); 0 = hardware order
     int gemm_clamp = 1;   // 0 = cut tiles always on the per-element checked instantiation
     int gemm_narrow = 1;  // 0 = 128 x 128 tiles on the strips cut by M / N too
     int short_calls = 1;  // log-likelihood kernels: calls of at most 32768 frames on 4-wave workgroups (half the latency); 0 = the 8-wave shape of long calls

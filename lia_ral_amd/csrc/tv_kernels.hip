@@ -68,11 +68,27 @@ __global__ __launch_bounds__(256, (MODE == 1 ? 1 : 2)) void k_dgemm(int M, int N
     // of a wide GEMM then share one row panel of op(A) and stream 512 different column panels of op(B) -- every B panel comes
     // from HBM once per M tile row.  remap: XCD x takes the N tiles n = 8 g + x and walks the M tiles fastest, so a B panel is
     // fetched once (by one XCD's L2) and reused for the whole column of tiles; the A panels cycle through L2 / MALL.
+    // remap 2 (round 5, A/B knob): the same split of the N tiles over the XCDs, but an XCD walks its (M tile, own N tile) plane in
+    // BLOCKS of 8 x 8 tiles -- its ~64 resident workgroups then share 8 A panels and 8 B panels instead of 64 A panels and one B
+    // panel.  Tried because the 100 k x 100 k scoring GEMM (782 x 782 tiles of K = 400) fetches 127 M KB (FETCH_SIZE) per call against
+    // 0.64 GB of operands; measured: FETCH_SIZE 123.7 M KB against 124.8 M, 126.2 ms against 126.3 -- the L2 captures the same quarter
+    // of the 501 GB the tiles ask for in either order, and the kernel is not bound by it (0.79 of the MFMA peak, 2 TB/s of fetches +
+    // 0.63 TB/s of score writes).  Not the default.
     int bx = blockIdx.x, by = blockIdx.y;
     if (epi.remap) {
         const int Nt = gridDim.x, Mt = gridDim.y, G = Nt >> 3;
         const int id = by * Nt + bx;
-        if (id < G * 8 * Mt) {
+        if (id < G * 8 * Mt && epi.remap >= 2) {
+            const int xcd = id & 7, loc = id >> 3;   // loc: this XCD's own sequence over Mt x G tiles
+            const int bn = loc / (8 * Mt);           // block column (8 of the XCD's N tiles; the last one may be narrower)
+            const int w = G - 8 * bn < 8 ? G - 8 * bn : 8;
+            const int r = loc - bn * 8 * Mt;
+            const int bm = r / (8 * w);              // block row inside the column (the last one may be shorter)
+            const int h = Mt - 8 * bm < 8 ? Mt - 8 * bm : 8;
+            const int rr = r - bm * 8 * w;
+            by = 8 * bm + rr % h;
+            bx = (8 * bn + rr / h) * 8 + xcd;
+        } else if (id < G * 8 * Mt) {
             const int xcd = id & 7, loc = id >> 3;
             by = loc % Mt;
             bx = (loc / Mt) * 8 + xcd;
