@@ -342,18 +342,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     acc[0][h][r] = r0;
                     acc[1][h][r] = r1;
                     const int km = k0[r] > k1[r] ? k0[r] : k1[r];
-                    nm[r] = row_max_i32(km >> GEXP_TAB_BITS);
+                    nm[r] = km >> GEXP_TAB_BITS; // the row maximum only behind the branch (see the WZ epilogue below)
                     grow |= nm[r] - E[h][r] >= 64;
                 }
                 if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
+                        nm[r] = row_max_i32(nm[r]);
                         if (nm[r] - E[h][r] >= 64) {
                             int sh = E[h][r] - nm[r];
                             sh = sh < -2000 ? -2000 : sh;
                             sacc[h][r] = __builtin_ldexp(sacc[h][r], sh);
                             E[h][r] = nm[r];
                         }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -382,20 +384,26 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     acc[0][h][r] = r0;
                     acc[1][h][r] = r1;
                     const int km = k0[h][r] > k1[h][r] ? k0[h][r] : k1[h][r];
-                    nm[h][r] = (K1_ABL & 8) ? km >> GEXP_TAB_BITS : row_max_i32(km >> GEXP_TAB_BITS);
+                    // (round 5) the row maximum of the exponents is only needed when SOME lane's exponent has outgrown its row's E by 64:
+                    // "any row maximum - E >= 64" is "any lane's own exponent - E >= 64", so the eight DPP reductions (32 v_max_i32_dpp
+                    // per stage and wave -- MFMA time like every VALU instruction, section 3.2 of DESIGN.md) move behind the
+                    // wave-uniform branch that is taken in the first stages only.  Same E, same sums, bit for bit.
+                    nm[h][r] = km >> GEXP_TAB_BITS;
                     grow |= nm[h][r] - E[h][r] >= 64;
                 }
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
+                        if (!(K1_ABL & 8)) nm[h][r] = row_max_i32(nm[h][r]);
                         if (nm[h][r] - E[h][r] >= 64) {
                             int sh = E[h][r] - nm[h][r];
                             sh = sh < -2000 ? -2000 : sh;
                             sacc[h][r] = __builtin_ldexp(sacc[h][r], sh);
                             E[h][r] = nm[h][r];
                         }
+                    }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h)

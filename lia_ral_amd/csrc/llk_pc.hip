@@ -183,20 +183,22 @@ __global__ __launch_bounds__(512, 2) void k_llk_pc(const void *__restrict__ x, l
                 acc[0][h][r] = r0;
                 acc[1][h][r] = r1;
                 const int km = k0[h][r] > k1[h][r] ? k0[h][r] : k1[h][r];
-                nm[h][r] = row_max_i32(km >> GEXP_TAB_BITS);
+                nm[h][r] = km >> GEXP_TAB_BITS; // the row maximum only behind the branch, like k_llk_mfma
                 grow |= nm[h][r] - E[h][r] >= 64;
             }
         if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    nm[h][r] = row_max_i32(nm[h][r]);
                     if (nm[h][r] - E[h][r] >= 64) {
                         int sh = E[h][r] - nm[h][r];
                         sh = sh < -2000 ? -2000 : sh;
                         sacc[h][r] = __builtin_ldexp(sacc[h][r], sh);
                         E[h][r] = nm[h][r];
                     }
+                }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)

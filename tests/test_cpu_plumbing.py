@@ -414,3 +414,34 @@ def test_compute_map_methods_host_logic():
     w, m, c = h.compute_map("MAPOccDep", init, client, 100.0, reg=(10.0, 10.0, 10.0))
     a = client[0][3] * 100.0 / (client[0][3] * 100.0 + 10.0)
     assert np.allclose(m[3], (1 - a) * init[1][3] + a * client[1][3], rtol=1e-15) and np.array_equal(c, init[2]) and np.array_equal(w, init[0])
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_library_it_was_taken_on(tmp_path, monkeypatch):
+    """bench.load_traffic (round-4 verdict): profiles/traffic.json records the sha256 of the libgmmiv.so its PMC passes ran on; the
+    bench line quotes its figures only when the library that is loaded now has that sha256 -- another build gets `traffic: null` and
+    a note that names both builds."""
+    import hashlib
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    so = os.path.join(ROOT, "lia_ral_amd", "csrc", "libgmmiv.so")
+    sha = hashlib.sha256(open(so, "rb").read()).hexdigest()
+    assert bench.lib_identity()["libgmmiv_sha256"] == sha
+    real = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert len(real.get("libgmmiv_sha256", "")) == 64 and real["iv_extractor"]["hbm_bytes_per_utterance"] > 0 and real["tv_em"]["estep_hbm_bytes_per_utterance"] > 0
+    fake_root = tmp_path / "repo"
+    (fake_root / "profiles").mkdir(parents=True)
+    (fake_root / "lia_ral_amd" / "csrc").mkdir(parents=True)
+    os.symlink(so, fake_root / "lia_ral_amd" / "csrc" / "libgmmiv.so")
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    tj, note, me = bench.load_traffic()
+    assert tj is None and "not found" in note and me["libgmmiv_sha256"] == sha
+    json.dump(dict(real, libgmmiv_sha256="0" * 64), open(fake_root / "profiles" / "traffic.json", "w"))
+    tj, note, _ = bench.load_traffic()
+    assert tj is None and "PMC figures of another build are not quoted" in note and sha[:16] in note
+    json.dump(dict(real, libgmmiv_sha256=sha), open(fake_root / "profiles" / "traffic.json", "w"))
+    tj, note, _ = bench.load_traffic()
+    assert note is None and tj["k_llk_mfma_hbm_bytes_per_launch"] == real["k_llk_mfma_hbm_bytes_per_launch"]
+    d = {k: v for k, v in real.items() if k != "libgmmiv_sha256"}
+    json.dump(d, open(fake_root / "profiles" / "traffic.json", "w"))
+    assert bench.load_traffic()[0] is None
