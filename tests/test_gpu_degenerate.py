@@ -298,3 +298,56 @@ def test_screening_follows_the_buffer_that_is_read_not_the_accumulators_server()
     utt2 = np.searchsorted(ub, np.arange(1200), side="right") - 1
     No2, Fo2 = orc.tv_stats(orc.Gmm(w, mean, iv), x.astype(np.float64), utt2, 4)
     assert cnt2 == (0, 0) and af2 == 0 and rel(N2, No2) < 1e-9 and rel(F2, Fo2) < 1e-9
+
+
+def test_generic_paths_follow_the_same_rule():
+    """vectSize > 80 (no MFMA instantiation: VALU logits, statistics on the fp64 GEMM), topDistribsCount > 64 (the any-shape selection
+    kernel): the degenerate-input rule holds there too -- unusable frames are screened out, a far frame is a zero-likelihood frame
+    (counted), everything else equals the oracle."""
+    Cg, Dg, Tg = 96, 100, 310
+    w, mean, iv = make_gmm(Cg, Dg, seed=31, spread=0.5)
+    x = make_frames(w, mean, iv, Tg, seed=32)
+    bad = [4, 150, 309]
+    x[4, 3] = np.nan; x[150, 99] = np.inf; x[309, 50] = -1e25
+    x[77, :] = 2e17                                   # kind 2
+    zero = sorted(bad + [77])
+    good = np.setdiff1d(np.arange(Tg), zero)
+    ctx = _ctx({})
+    g = ctx.gmm(w, mean, iv)
+    og = orc.Gmm(w, mean, iv)
+    xg = x[good].astype(np.float64)
+    l = g.llk(x)
+    assert np.all(l[zero] == -200.0) and np.max(np.abs(l[good] - orc.llk(og, xg, -200.0, 200.0))) < 1e-9
+    for ctop in (7, 80):                               # 80 > 64: k_topc_determine_big for the 60-dim case below too
+        d = g.llk_determine_top(x, ctop)
+        do = orc.llk_determine_top(og, xg, ctop, True)
+        assert np.array_equal(d["idx"][good], do["idx"]) and np.max(np.abs(d["llk"][good] - do["llk"])) < 1e-9
+        for t in zero:
+            assert d["idx"][t].tolist() == list(range(ctop)) and np.all(d["lk"][t] == 0.0) and d["llk"][t] == -200.0
+        u = g.llk_use_top(x, d["idx"], d["nontop_llk"])
+        uo = orc.llk_use_top(og, xg, do["idx"], do["nontop_lk"], True)
+        assert np.all(u[zero] == -200.0) and np.max(np.abs(u[good] - uo)) < 1e-9
+    a = g.split_acc(g.em_accumulate(x))
+    ref = orc.em_accumulate(og, xg)
+    rel = lambda p, q: np.max(np.abs(p - q)) / np.max(np.abs(q))
+    assert a["count"] == len(good) and rel(a["occ"], ref["occ"]) < 1e-9 and rel(a["sx"], ref["sx"]) < 1e-9 and rel(a["sxx"], ref["sxx"]) < 1e-9
+    ub = np.array([0, 5, 5, 200, Tg])
+    N = np.zeros((4, Cg)); F = np.zeros((4, Cg * Dg))
+    g.tv_stats(x, ub, N, F)
+    utt = np.searchsorted(ub, good, side="right") - 1
+    No, Fo = orc.tv_stats(og, xg, utt, 4)
+    assert rel(N, No) < 1e-9 and rel(F, Fo) < 1e-9 and not N[1].any()
+    o = g.occ(x[:100])
+    assert np.all(o[4] == 0.0) and np.all(o[77] == 0.0) and abs(o[5].sum() - 1.0) < 1e-9
+    assert ctx.set_option("screened_frames", 0) >= len(bad) and ctx.set_option("zero_llk_frames", 0) >= 1
+    g.close()
+    # topDistribsCount > 64 on an MFMA-served model (60 dims): the selection falls through to the any-shape kernel
+    w6, m6, iv6 = make_gmm(200, 60, seed=33, spread=0.5)
+    x6 = make_frames(w6, m6, iv6, 90, seed=34)
+    x6[10, 0] = np.nan
+    g6 = ctx.gmm(w6, m6, iv6)
+    d = g6.llk_determine_top(x6, 70)
+    keep = np.setdiff1d(np.arange(90), [10])
+    do = orc.llk_determine_top(orc.Gmm(w6, m6, iv6), x6[keep].astype(np.float64), 70, True)
+    assert np.array_equal(d["idx"][keep], do["idx"]) and d["idx"][10].tolist() == list(range(70)) and d["llk"][10] == -200.0
+    g6.close(); ctx.close()
