@@ -387,7 +387,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_llk_mfma(const void *__restrict_
                     // (round 5) the row maximum of the exponents is only needed when SOME lane's exponent has outgrown its row's E by 64:
                     // "any row maximum - E >= 64" is "any lane's own exponent - E >= 64", so the eight DPP reductions (32 v_max_i32_dpp
                     // per stage and wave -- MFMA time like every VALU instruction, section 3.2 of DESIGN.md) move behind the
-                    // wave-uniform branch that is taken in the first stages only.  Same E, same sums, bit for bit.
+                    // wave-uniform branch that is taken in the first stages only.  Same E, same sums, bit for bit.  (ISA of the hot path per stage
+                    // and wave after this: 120 MFMAs, 293 VALU instructions -- 160 fp64, 133 integer / move -- against 357 before; measured
+                    // 26.03 -> 25.97 ms per 3.07 M frames: the reductions were not on the critical path of a 2-waves-per-SIMD kernel.)
                     nm[h][r] = km >> GEXP_TAB_BITS;
                     grow |= nm[h][r] - E[h][r] >= 64;
                 }
