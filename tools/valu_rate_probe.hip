@@ -23,6 +23,12 @@ template <int OP> __global__ __launch_bounds__(256) void k(double *out, double a
             if (OP == 9) asm volatile("v_ashrrev_i32 %0, 11, %0" : "+v"(iv[i]));
             if (OP == 10) asm volatile("v_max_i32 %0, %0, %1" : "+v"(iv[i]) : "v"(ia));
             if (OP == 11) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(iv[i]) : "v"(ia));
+            if (OP == 15) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(iv[i]) : "v"(ia) : "s20", "s21");
+            if (OP == 16) asm volatile("v_cmp_lt_i32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(iv[i]) : "v"(ia) : "vcc");
+            if (OP == 17) asm volatile("v_cmp_lt_i32_e64 s[20:21], %1, %0\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(iv[i]) : "v"(ia) : "s20", "s21");
+            if (OP == 18) asm volatile("v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(iv[i]));
+            if (OP == 19) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(iv[i]) : "v"(ia));
+            if (OP == 20) asm volatile("v_mov_b32 %0, %1" : "=v"(iv[i]) : "v"(ia));
             if (OP == 12) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(v[i]) : "v"(iv[i]));
             if (OP == 13) asm volatile("v_cmp_ge_f64 vcc, %0, %1" : : "v"(v[i]), "v"(b) : "vcc");
             if (OP == 14) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(iv[i]) : "v"(v[i]));
@@ -50,6 +56,8 @@ int main()
     double *d; hipMalloc(&d, 256 * 1024 * 8);
     run<0>("v_fma_f64", d); run<1>("v_mul_f64", d); run<2>("v_add_f64", d); run<3>("v_rndne_f64", d); run<4>("v_cvt_i32_f64", d);
     run<5>("v_ldexp_f64", d); run<6>("v_max_f64", d); run<12>("v_cvt_f64_i32", d); run<13>("v_cmp_ge_f64", d); run<14>("v_cvt_f32_f64", d);
-    run<7>("v_and_b32", d); run<8>("v_lshl_add_u32", d); run<9>("v_ashrrev_i32", d); run<10>("v_max_i32", d); run<11>("v_cndmask_b32", d);
+    run<7>("v_and_b32", d); run<8>("v_lshl_add_u32", d); run<9>("v_ashrrev_i32", d); run<10>("v_max_i32", d); run<11>("v_cndmask_b32 vcc", d);
+    run<15>("v_cndmask_e64 sgpr", d); run<16>("cmp+cndmask vcc (2)", d); run<17>("cmp+cndmask sgpr (2)", d); run<18>("v_max_i32_dpp", d);
+    run<19>("v_sub_u32", d); run<20>("v_mov_b32", d);
     return 0;
 }
