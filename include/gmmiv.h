@@ -95,6 +95,8 @@ const char *gmmiv_version(void);
  *                      results; MEASURED SLOWER (0.59 against 0.74 of the fp64 peak: on gfx950 an f64 MFMA occupies the vector ALUs, VALU
  *                      work of another wave does not overlap with a saturated matrix pipe -- profiles/r05/k1_pc_ablation.txt); kept as the
  *                      record of that experiment
+ *   "chol_uut64" 0     1: E = U U^T + w w^T of the T-matrix E-step with 64-column panels, the k range staged in two LDS halves (k_uut64);
+ *                      same results to 3e-15, measured slower (1.59 vs 1.09 ms per 1024 systems of order 400): an A/B record
  *   "chol_flow" 1      batched Cholesky k_chol_left2 (panel staged first, diagonal update from LDS on all waves); 0: round 2's k_chol_left
  *   "kopts_bound"      read-only: 1 when this context's kernel-launcher options are the set bound to the calling thread (they are
  *                      bound by each call of the context on entry)

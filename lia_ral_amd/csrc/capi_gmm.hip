@@ -142,6 +142,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "chol_waves")) ks = &c->ko.chol_waves;   // 16 = k_trinv_left / k_uut on 1024-thread workgroups
     else if (!strcmp(key, "short_calls")) ks = &c->ko.short_calls; // 0 = calls of at most 32768 frames on the kernel shapes of long calls
     else if (!strcmp(key, "k1_pc")) ks = &c->ko.k1_pc;             // 1 = k_llk_pc (producer / consumer waves) for the plain and stored-likelihood log-likelihood passes
+    else if (!strcmp(key, "chol_uut64")) ks = &c->ko.chol_uut64;   // 1 = k_uut64 for the packed E = U U^T + w w^T of the E-step
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
     if (!strcmp(key, "zero_llk_frames")) { // the device counter of kind-(2) frames: reading it waits for the stream (the counting itself never does)
