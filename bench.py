@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: one UBM EM pass (TrainWorld hot path) per step.
+"""bench.py -- ONE JSON line: the headline (a UBM EM pass, TrainWorld's hot path) and every other single-GPU BASELINE config at its stated size.
 
-Workload (BASELINE.json configs[1]): 2048-Gaussian diagonal UBM, 60-dim float32 frames,
-10 M synthetic frames resident in HBM per GPU.  One step = the E-step of one EM iteration:
-log-likelihood pass + full-posterior sufficient statistics over every frame (HIP, fp64 MFMA),
-the RCCL all-reduce of the 1.98 MB statistics when N > 1, the M-step and the model re-pack.
-Metric: Gframe-Gaussian evaluations/s, whole job (all ranks).  Scaling is weak (10 M frames/GPU).
+Headline (BASELINE.json configs[1]): 2048-Gaussian diagonal UBM, 60-dim float32 frames, 10 M synthetic frames resident in HBM per GPU.
+One step = one EM iteration: log-likelihood pass + full-posterior sufficient statistics over every frame (HIP, fp64 MFMA), the RCCL
+all-reduce of the 1.98 MB statistics when N > 1, the M-step, variance control and the model re-pack.  Metric: Gframe-Gaussian
+evaluations/s, whole job (all ranks).  Scaling is weak (10 M frames per GPU).
 
-`--workload tv` runs BASELINE.json configs[3] instead: one TotalVariability T-matrix EM iteration per step on
-utterance-sharded statistics (6250 utterances x 3000 frames per GPU = 50 k over 8 GPUs, 2048-g UBM, rank 400): estimateTETt,
-estimateAandC, reduce-scatter of A / Cmx by Gaussian blocks, sharded updateTestimate, all-gather of T, minDivergence.  With
-N > 1 the default (EM) run also reports that iteration as `tv_em`.  The collectives are the C ABI's own (gmmiv_comm_*: RCCL
-called by libgmmiv on the device buffers); torch.distributed only launches the ranks and carries the 128-byte RCCL id.
-
-Beside the headline the line carries (one GPU): `secondary` -- IvExtractor end to end on 512 utterances, i-vectors/s, with its own `roofline`
-(2.67 GFLOP per i-vector), `cpu_baseline` (oracle IvExtractor, thread sweep over utterance ranges), parity and the opt-in pruned rate;
-`computetest` -- ComputeTest's world / client passes; `host_layer` -- the same three workloads through the C++ host layer
-(libliatools_gpu.so: liagpu::trainModelStream at baggedFrameProbability 1.0 and 0.4, IvExtractor, computeTestLLR), each with its time, the ratio
-to the torch-driven number and parity against it; `dense_data`, `kernels`, `roofline`, `step_roofline`, `cpu_baseline`.
+Beside it, in the same line (DESIGN.md section 6 has the table):
+  `secondary`   configs[2] AT FULL SIZE: IvExtractor end to end on 10 000 utterances x 3000 frames per GPU -> i-vectors/s, with its own
+                `roofline` (2.67 GFLOP per i-vector), `cpu_baseline` (oracle IvExtractor, 1 and 32 threads), parity, and the opt-in paths
+                (pruned posteriors, single-pass statistics) as A/B legs on a 512-utterance slice (`slice_ab`);
+  `computetest` configs[0]'s path at scale: top-10 world pass on 10^6 frames + client pass for 4 client models;
+  `host_layer`  the same three workloads through the C++ host layer (libliatools_gpu.so: liagpu::trainModelStream at
+                baggedFrameProbability 1.0 and 0.4, IvExtractor, computeTestLLR), each with its time, the ratio to the torch-driven number
+                and parity against it (one rank only);
+  `tv_em`       configs[3]: one TotalVariability T-matrix EM iteration per step on utterance-sharded statistics, 6250 utterances x 3000
+                frames per GPU (= 50 k over 8 GPUs) -- at world 1 too; `--workload tv` runs this block alone;
+  `scoring`     configs[4] AT FULL SIZE: 100 k x 100 k trials of dimension 400, all four rules, 80 GB of scores resident (one rank only);
+  `dense_data`, `kernels`, `roofline`, `step_roofline`, `cpu_baseline`, `screening`, `library` (sha256 of the libgmmiv.so that ran:
+  `roofline.traffic` figures are quoted from profiles/traffic.json only when they were collected on that build).
+The collectives are the C ABI's own (gmmiv_comm_*: RCCL called by libgmmiv on the device buffers); torch.distributed only launches
+the ranks and carries the 128-byte RCCL id.
 
 Launch: python bench.py --gpus N (N > 1 without a launcher's WORLD_SIZE: bench.py starts its N ranks itself, like the reference
 tools start their own worker threads, AccumulateStat.cpp:234-299) | python -m torch.distributed.run --nproc-per-node N bench.py
