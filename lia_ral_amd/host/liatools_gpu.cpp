@@ -941,7 +941,6 @@ double TopGauss::get(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &se
     FiniteScope fin(srv, fs); // screening of THIS call follows THIS buffer
     unsigned long cap = 1;
     for (unsigned long t = 0; t < n; ++t) cap = std::max(cap, _nbg[t]);
-    if (cap > 64) throw Exception("TopGauss::get: more than 64 Gaussians stored for a frame");
     std::vector<int32_t> idx((size_t)n * cap, -1); // -1: no entry (never dereferenced by the USE kernel)
     std::vector<double> nllk(n), llk(n);
     unsigned long b = 0;

@@ -373,7 +373,7 @@ std::vector<double> computeTestLLR(FeatureBuffer &fs, const SegCluster &selected
 // The per-frame Gaussian selection the factor-analysis tools compute once per feature file and cache on disk.
 class TopGauss {
   public:
-    // compute (:136-198): DETERMINE_TOP_DISTRIBS on every selected frame with a list of topDistribsCount entries (<= 64), then
+    // compute (:136-198): DETERMINE_TOP_DISTRIBS on every selected frame with a list of topDistribsCount entries (any count up to the model's), then
     // topGauss >= 1: the (unsigned long)topGauss heaviest Gaussians of every frame; topGauss < 1: Gaussians until their cumulative
     // likelihood passes topGauss * exp(llk) -- a variable count per frame.  Returns getMeanLLK() of the DETERMINE pass.
     double compute(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &selectedSegments, double topGauss, int topDistribsCount,

@@ -896,8 +896,8 @@ def test_feature_selection_by_runs_matches_the_frame_list():
     ctx.close()
 
 
-@pytest.mark.parametrize("top_gauss", [0.9, 0.999, 5.0])
-def test_topgauss_mass_threshold_cache_file_and_get(top_gauss, tmp_path):
+@pytest.mark.parametrize("top_gauss,cap", [(0.9, 64), (0.999, 64), (5.0, 64), (0.99999999, 100), (90.0, 100)])   # lists longer than 64: the any-shape kernels (round 5)
+def test_topgauss_mass_threshold_cache_file_and_get(top_gauss, cap, tmp_path):
     """TopGauss (LIA_SpkTools/src/TopGauss.cpp): compute with topGauss < 1 -- Gaussians until the cumulative likelihood passes
     topGauss * exp(llk): a VARIABLE count per frame (:162-167) -- and with a fixed count (:170); sumNonSelectedWeights / LLK with
     the EPS_LK floor (:183-192); the nbGaussian cache file in the reference's binary layout (:200-224), read back (:76-98) and
@@ -912,7 +912,6 @@ def test_topgauss_mass_threshold_cache_file_and_get(top_gauss, tmp_path):
     rng = np.random.default_rng(3)
     mean2 = mean + rng.normal(0, 0.1, mean.shape)
     path = str(tmp_path / "utt.nbg")
-    cap = 64
     got = h.topgauss(x, seg_begin, seg_len, (w, mean, 1.0 / iv), top_gauss, path, top_distribs_count=cap, model2_mean=mean2)
     og = orc.Gmm(w, mean, iv)
     xs = x[sel].astype(np.float64)
@@ -944,7 +943,7 @@ def test_topgauss_mass_threshold_cache_file_and_get(top_gauss, tmp_path):
     assert np.array_equal(snsw_f, got["snsw"]) and np.array_equal(snsl_f, got["snsl"])
     # an unwritable path is reported like the reference does (TopGauss.cpp:204)
     with pytest.raises(h.HostError, match="Cannot find nbGaussian file"):
-        h.topgauss(x, seg_begin, seg_len, (w, mean, 1.0 / iv), top_gauss, str(tmp_path / "no" / "dir.nbg"))
+        h.topgauss(x, seg_begin, seg_len, (w, mean, 1.0 / iv), top_gauss, str(tmp_path / "no" / "dir.nbg"), top_distribs_count=cap)
 
 
 def test_segment_means_on_the_device():
