@@ -481,6 +481,7 @@ def scoring_cpu_baseline(R=400):
         sweep.append({"threads": th, "models": n, "segments": n, "seconds": dt, "trials_per_s": n * n / dt})
     n = 2000
     m = rng.normal(size=(R, n)); sg = rng.normal(size=(R, n))
+    _ = (Mah @ sg[:, :256]).sum()      # the host BLAS starts its thread pool on its first product: not part of the timed one
     t = time.time()
     QS = Mah @ sg
     gemm = m.T @ QS - 0.5 * np.einsum("km,km->m", m, Mah @ m)[:, None] - 0.5 * np.einsum("ks,ks->s", sg, QS)[None, :]
