@@ -95,6 +95,11 @@ const char *gmmiv_version(void);
  *                      results; MEASURED SLOWER (0.59 against 0.74 of the fp64 peak: on gfx950 an f64 MFMA occupies the vector ALUs, VALU
  *                      work of another wave does not overlap with a saturated matrix pipe -- profiles/r05/k1_pc_ablation.txt); kept as the
  *                      record of that experiment
+ *   "tv_overlap" 0     gmmiv_tv_stats over several chunks: 1 = the log-likelihood kernel of chunk k + 1 runs on the context's stream beside
+ *                      the N / F statistics kernel of chunk k on a side stream (two likelihood scratch sets); 2 = additionally the
+ *                      statistics kernel in its 4-wave / 51 KB shape, so that a CU holds a workgroup of each.  Bitwise the serial
+ *                      results; MEASURED SLOWER (104 -> 105 / 111 ms per 2560 utterances x 3000 frames, profiles/r05/tv_overlap_ab.txt):
+ *                      both kernels want the matrix pipe, interleaving them costs more than the stalls it fills.  An A/B record.
  *   "chol_uut64" 0     1: E = U U^T + w w^T of the T-matrix E-step with 64-column panels, the k range staged in two LDS halves (k_uut64);
  *                      same results to 3e-15, measured slower (1.59 vs 1.09 ms per 1024 systems of order 400): an A/B record
  *   "chol_flow" 1      batched Cholesky k_chol_left2 (panel staged first, diagonal update from LDS on all waves); 0: round 2's k_chol_left

@@ -84,6 +84,7 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
         for (hipEvent_t e : c->ev1[i]) (void)hipEventDestroy(e);
     }
     c->topc_pipe_free();
+    c->tv_pipe_free();
     if (c->d_zero_llk) (void)hipFree(c->d_zero_llk);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (g_kopts_src == &c->ko) gmmiv_kopts_bind(nullptr); // back to the defaults on this thread
@@ -115,6 +116,7 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
     else if (!strcmp(key, "tv_tett_direct")) slot = &c->tv_tett_direct;
     else if (!strcmp(key, "tv_stats_split")) slot = &c->tv_stats_split;
+    else if (!strcmp(key, "tv_overlap")) slot = &c->tv_overlap;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     else if (!strcmp(key, "tv_mstep_solve")) slot = &c->tv_mstep_solve;
     else if (!strcmp(key, "tv_md_device")) slot = &c->tv_md_device;
@@ -1527,6 +1529,46 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
                     if ((rc = o_n.finish())) return rc;
                     return o_f.finish();
                 }
+            }
+            if (c->tv_overlap && cu.size() > 2) {
+                // OPT-IN experiment: K1 of chunk k + 1 beside K3 of chunk k.  Two scratch sets; K1 and the counting kernel stay on the
+                // context's stream, K3 runs on the side stream behind its chunk's K1 (event), K1 of chunk k + 2 behind K3 of chunk k
+                // (its set is free again).  Same kernels on the same data in the same per-row order: results bitwise the serial form's.
+                void *zb2, *lsew2, *eit2, *inv2;
+                if ((rc = c->tv_pipe_init())) return rc;
+                if ((rc = c->scratch(WS_Z2, (size_t)g->nct * nfb * 2048, &zb2))) return rc;
+                if ((rc = c->scratch(WS_LSE2, (size_t)(maxn > 0 ? maxn : 1) * sizeof(double), &lsew2))) return rc;
+                if ((rc = c->scratch(WS_EIT2, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit2))) return rc;
+                if ((rc = c->scratch(WS_INV2, (size_t)(maxn > 0 ? maxn : 1) * (sizeof(double) + sizeof(int)), &inv2))) return rc;
+                void *zs[2] = {zb, zb2}, *ls[2] = {lsew, lsew2}, *es[2] = {eit, eit2}, *is[2] = {inv, inv2};
+                gmmiv_kopts ko3 = c->ko; // the statistics kernel's shape for this mode
+                if (c->tv_overlap == 2) ko3.z_waves = 4;
+                GCHK(hipEventRecord(c->tv_ev_k1[0], c->stream)); // everything enqueued so far (segment table, outputs) precedes the side stream's work
+                GCHK(hipStreamWaitEvent(c->tv_side, c->tv_ev_k1[0], 0));
+                for (size_t k = 0; k + 1 < cu.size(); ++k) {
+                    const int set = (int)(k & 1);
+                    const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;
+                    int *ef = (int *)((double *)is[set] + (maxn > 0 ? maxn : 1));
+                    if (k >= 2) GCHK(hipStreamWaitEvent(c->stream, c->tv_ev_k3[set], 0)); // the set's previous statistics pass has read it
+                    if (k == 0) c->t_begin("k_llk_mfma", true);
+                    GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)ls[set],
+                                    (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zs[set], nfb, (int *)es[set], (double *)is[set], ef));
+                    if (k == 0) c->t_end();
+                    GCHK(count_dead(c, (const double *)ls[set], n));
+                    GCHK(hipEventRecord(c->tv_ev_k1[set], c->stream));
+                    GCHK(hipStreamWaitEvent(c->tv_side, c->tv_ev_k1[set], 0));
+                    gmmiv_kopts_bind(&ko3);
+                    const int krc = gmmk_stats_z(c->tv_side, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zs[set],
+                                                 nfb, (const int *)es[set], (const double *)is[set], ef, 1.0, (const long *)seg + u0 + k, (int)(u1 - u0),
+                                                 o_n.d + (size_t)u0 * g->C, o_f.d + (size_t)u0 * SV, 1, 0, c->prune_thr());
+                    gmmiv_kopts_bind(&c->ko);
+                    GCHK(krc);
+                    GCHK(hipEventRecord(c->tv_ev_k3[set], c->tv_side));
+                }
+                GCHK(hipStreamWaitEvent(c->stream, c->tv_ev_k3[0], 0)); // the context's stream continues behind the last statistics passes
+                GCHK(hipStreamWaitEvent(c->stream, c->tv_ev_k3[1], 0));
+                if ((rc = o_n.finish())) return rc;
+                return o_f.finish();
             }
             for (size_t k = 0; k + 1 < cu.size(); ++k) {
                 const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;

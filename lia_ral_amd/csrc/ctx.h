@@ -34,7 +34,8 @@ void gmmiv_set_error(const char *fmt, ...);
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
        WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_EIT, WS_INV,
-       WS_XG, WS_GFLAG, WS_GMAP, WS_G0, WS_G1, WS_G2, WS_G3, WS_G4, WS_G5, WS_G6, WS_COUNT }; // WS_XG..: the screened (compacted) form of a call with unusable frames
+       WS_XG, WS_GFLAG, WS_GMAP, WS_G0, WS_G1, WS_G2, WS_G3, WS_G4, WS_G5, WS_G6,
+       WS_Z2, WS_LSE2, WS_EIT2, WS_INV2, WS_COUNT }; // WS_XG..: the screened (compacted) form of a call with unusable frames
 
 struct gmmiv_ctx {
     int device = 0;
@@ -111,6 +112,32 @@ struct gmmiv_ctx {
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)
     long tv_md_device = 1; // minDivergence: R normalised and factored on the device (one workgroup of k_chol_left); 0: on the host
     long tv_mstep_solve = 1; // updateTestimate by substitution through the Cholesky factor (k_chol_solve_multi); 0: explicit inverse + GEMM
+    // gmmiv_tv_stats over several chunks, OPT-IN experiment (round 5): 1 / 2 = the log-likelihood kernel of chunk k + 1 on the context's stream
+    // BESIDE the N / F statistics kernel of chunk k on a side stream (two likelihood scratch sets); 2 additionally runs the statistics kernel
+    // in its <4 waves, 2 tiles, 32-frame tiles> shape (51 KB of LDS) so that a CU can hold one workgroup of each kernel (80 + 51 KB)
+    long tv_overlap = 0;
+    hipStream_t tv_side = nullptr;
+    hipEvent_t tv_ev_k1[2] = {nullptr, nullptr}, tv_ev_k3[2] = {nullptr, nullptr};
+    int tv_pipe_init()
+    {
+        if (!tv_side) {
+            GCHK(hipStreamCreateWithFlags(&tv_side, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                GCHK(hipEventCreateWithFlags(&tv_ev_k1[i], hipEventDisableTiming));
+                GCHK(hipEventCreateWithFlags(&tv_ev_k3[i], hipEventDisableTiming));
+            }
+        }
+        return GMMIV_OK;
+    }
+    void tv_pipe_free()
+    {
+        if (tv_side) {
+            (void)hipStreamSynchronize(tv_side);
+            for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(tv_ev_k1[i]); (void)hipEventDestroy(tv_ev_k3[i]); }
+            (void)hipStreamDestroy(tv_side);
+            tv_side = nullptr;
+        }
+    }
     long tv_stats_split = 1; // gmmiv_tv_stats on at most 16 utterances: each utterance in pieces of whole tiles (more workgroups), summed back; 0 = one segment per utterance
     long tv_tett_direct = 1; // estimateTETt by k_tett_packed (lower triangle only, written packed); 0 = batched GEMM + pack
     long tv_batch = 1024; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)

@@ -440,7 +440,15 @@ def test_tv_stats_stored_logit_path_chunks_of_utterances(ctx, C, D, U, mb):
         N2, F2 = g.tv_stats(x, ub)
         nl = ctx.kernel_launches("k_stats_z")
         ctx.set_option("timing", 0)
+        # opt-in "tv_overlap" (round-5 experiment: the log-likelihood kernel of chunk k + 1 beside the statistics kernel of chunk k on
+        # a side stream, two scratch sets; 2 = the statistics kernel in its 4-wave shape): bitwise the serial chunks' rows
+        for mode in (1, 2):
+            ctx.set_option("tv_overlap", mode)
+            N3, F3 = g.tv_stats(x, ub)
+            ctx.set_option("tv_overlap", 0)
+            assert np.array_equal(N3, N2) and np.array_equal(F3, F2), mode
     finally:
+        ctx.set_option("tv_overlap", 0)
         ctx.set_option("z_scratch_mb", prev)
     assert nl >= 2, nl
     for N, F in ((N1, F1), (N2, F2)):
