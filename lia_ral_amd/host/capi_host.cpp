@@ -952,6 +952,70 @@ int liagpu_compute_test_files(int device, const char *world_path, int nClients, 
     })
 }
 
+// EnergyDetector on one energy column (EnergyDetector.cpp:190-285, thresholdMode meanStd): energy [T] float32 (featureServerMask picks
+// the column, vectSize 1), selected segments; out_begin / out_len [max_out] <- the output segments (frames of the SELECTION), model_out
+// [3 * C] <- weights | means | covariances, *threshold_out <- the threshold.
+int liagpu_energy_detector(int device, const float *energy, long T, const long *seg_begin, const long *seg_len, long nseg, int C, int nbTrainIt,
+                           double varianceFlooring, double varianceCeiling, double alpha, long *out_begin, long *out_len, long max_out,
+                           long *n_out, double *model_out, double *threshold_out)
+{
+    GUARD({
+        GpuServer srv(device);
+        FeatureBuffer fs(srv, energy, (unsigned long)T, 1);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg);
+        EnergyDetectorCfg cfg;
+        cfg.nbTrainIt = (unsigned long)nbTrainIt; cfg.mixtureDistribCount = (unsigned long)C;
+        cfg.varianceFlooring = varianceFlooring; cfg.varianceCeiling = varianceCeiling; cfg.alpha = alpha;
+        MixtureGD model(C, 1);
+        double th = 0.0;
+        SegCluster out = energyDetector(fs, segs, cfg, &model, &th);
+        if ((long)out.size() > max_out) throw Exception("out_begin too small");
+        for (size_t i = 0; i < out.size(); ++i) { out_begin[i] = (long)out[i].begin; out_len[i] = (long)out[i].length; }
+        *n_out = (long)out.size();
+        if (model_out)
+            for (int c = 0; c < C; ++c) { model_out[c] = model.weight(c); model_out[C + c] = model.getMean(c, 0); model_out[2 * C + c] = model.getCov(c, 0); }
+        if (threshold_out) *threshold_out = th;
+    })
+}
+
+// GmmTokenizer driven from its files (LIA_Utils/GmmTokenizer/src/GmmTokenizer.cpp:169-207 symbols, :120-164 confusion matrix): RAW world
+// model, .prm features (masked), .lbl segments with the selected label.  symbols_out [max_symbols] <- one best-Gaussian index per selected
+// frame (*n_symbols of them; skipped when symbols_out is NULL); confusion_out [C x C] (nullable, zeroed here) <- the nBest = topDistribsCount
+// confusion counts; matrix_path (nullable / "") <- the same matrix as a DT file, like mce_matrix.save (:160).
+int liagpu_gmm_tokenizer_files(int device, const char *world_path, const char *prm_path, const char *lbl_path, const char *mask,
+                               const char *label, double frameLength, int topDistribsCount, double minLLK, double maxLLK,
+                               long *symbols_out, long max_symbols, long *n_symbols, long *confusion_out, long *dims,
+                               const char *matrix_path)
+{
+    GUARD({
+        GpuServer srv(device);
+        MixtureGD world = readMixtureRAW(world_path);
+        FeatureFile ff = readFeatureFile(prm_path, mask ? mask : "");
+        if (ff.vectSize != world.getVectSize()) throw Exception("vectSize of features and world model differ");
+        FeatureBuffer fs(srv, ff.data.data(), ff.nFrames, ff.vectSize);
+        SegCluster segs = selectSegments(readLabelFile(lbl_path), label, frameLength);
+        DeviceMixture dworld(srv, world);
+        const unsigned long C = world.getDistribCount();
+        if (dims) { dims[0] = (long)C; dims[1] = (long)world.getVectSize(); dims[2] = (long)totalFrame(segs); }
+        if (symbols_out) {
+            std::vector<unsigned long> stream;
+            computeSymbols(segs, fs, dworld, stream, topDistribsCount, minLLK, maxLLK);
+            if ((long)stream.size() > max_symbols) throw Exception("symbols_out too small");
+            for (size_t i = 0; i < stream.size(); ++i) symbols_out[i] = (long)stream[i];
+            if (n_symbols) *n_symbols = (long)stream.size();
+        }
+        if (confusion_out || (matrix_path && *matrix_path)) {
+            std::vector<unsigned long> mce((size_t)C * C, 0);
+            computeConfusionMatrix(segs, fs, dworld, (unsigned long)topDistribsCount, mce, minLLK, maxLLK);
+            if (confusion_out) for (size_t i = 0; i < mce.size(); ++i) confusion_out[i] = (long)mce[i];
+            if (matrix_path && *matrix_path) {
+                MatrixD m; m.rows = C; m.cols = C; m.v.assign(mce.begin(), mce.end());
+                writeMatrixDT(matrix_path, m);
+            }
+        }
+    })
+}
+
 // XML mixture round trip + DB / DT matrices + per-id vector files (CPU tests; no GPU involved).
 // xml_in -> xml_out (re-written) and raw_out (the same model as a RAW file); dims = {C, D}; first = {weight 0, covInv(0,0), mean(0,0)}
 int liagpu_io_xml(const char *xml_in, const char *xml_out, const char *raw_out, long *dims, double *first)

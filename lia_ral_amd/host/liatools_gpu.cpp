@@ -932,6 +932,129 @@ double TopGauss::compute(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster
     return n ? s / (double)n : 0.0;
 }
 
+// ---- EnergyDetector ----------------------------------------------------------------------------------
+void energyMixtureInit(MixtureGD &world)
+{
+    const unsigned long vectSize = world.getVectSize(), distribCount = world.getDistribCount();
+    double mean = -2.0;
+    const double meanIncrement = distribCount > 1 ? 4.0 / (double)(distribCount - 1) : 1.0;
+    for (unsigned long indg = 0; indg < distribCount; ++indg)
+        for (unsigned long c = 0; c < vectSize; ++c, mean += meanIncrement) { // the increment sits in the coefficient loop (:175)
+            world.setCov(indg, 1.0, c);
+            world.setMean(indg, mean, c);
+        }
+    world.computeAll();
+    for (unsigned long indg = 0; indg < distribCount; ++indg) world.weight(indg) = 1.0 / (double)distribCount; // equalizeWeights
+}
+
+unsigned long findMaxEnergyDistrib(const MixtureGD &mixt)
+{
+    unsigned long cmpMax = 0;
+    for (unsigned long c = 1; c < mixt.getDistribCount(); ++c)
+        if (mixt.getMean(c, 0) > mixt.getMean(cmpMax, 0)) cmpMax = c;
+    return cmpMax;
+}
+
+unsigned long selectFrames(const std::vector<float> &energy, double threshold, const SegCluster &selectedSeg, SegCluster &outputSeg)
+{
+    unsigned long countFrames = 0, ind = 0, begin = 0;
+    bool in = false;
+    for (const Seg &seg : selectedSeg) {
+        for (unsigned long idx = seg.begin; idx < seg.begin + seg.length; ++idx) {
+            if (idx >= energy.size()) throw Exception("selectFrames: segment beyond the end of the feature file");
+            if ((double)energy[idx] > threshold) {
+                ++countFrames;
+                if (!in) { in = true; begin = ind; }
+            } else if (in) {
+                in = false;
+                Seg s; s.begin = begin; s.length = ind - begin; s.source = seg.source;           // :144 (ind = end + 1)
+                outputSeg.push_back(s);
+            }
+            ++ind;
+        }
+        if (in) {
+            in = false;
+            Seg s; s.begin = begin; s.length = ind - begin + 1; s.source = seg.source;           // :151, as written
+            outputSeg.push_back(s);
+        }
+    }
+    return countFrames;
+}
+
+SegCluster energyDetector(FeatureBuffer &fs, const SegCluster &selectedSegments, const EnergyDetectorCfg &cfg, MixtureGD *energyModelOut,
+                          double *thresholdOut)
+{
+    if (cfg.thresholdMode != "meanStd")
+        throw Exception("energyDetector: thresholdMode [" + cfg.thresholdMode + "] needs alize-core's Histo, only meanStd is available");
+    GpuServer &srv = fs.server();
+    std::vector<double> globalMean, globalCov;
+    computeMeanCov(fs, selectedSegments, globalMean, globalCov);                                  // globalMeanCov (:227-231)
+    MixtureGD energyModel(cfg.mixtureDistribCount, fs.getVectSize());
+    energyMixtureInit(energyModel);
+    DeviceMixture dm(srv, energyModel);
+    EMAcc emAcc(dm, energyModel);
+    for (unsigned long trainIt = 0; trainIt < cfg.nbTrainIt; ++trainIt) {                         // :241-250
+        emAcc.resetEM();
+        accumulateStatEM(fs, emAcc, selectedSegments);
+        energyModel = emAcc.getEM();
+        varianceControl(energyModel, cfg.varianceFlooring, cfg.varianceCeiling, globalCov);
+        dm.update(energyModel);
+        emAcc.setModel(energyModel);
+    }
+    const unsigned long higher = findMaxEnergyDistrib(energyModel);
+    const double threshold = energyModel.getMean(higher, 0) - cfg.alpha * sqrt(energyModel.getCov(higher, 0)); // :274
+    // coefficient 0 of every frame, back on the host for the run-length pass
+    std::vector<float> energy(fs.getFeatureCount());
+    if (!energy.empty()) {
+        hipcheck(hipMemcpy2DAsync(energy.data(), sizeof(float), fs.device(), fs.getVectSize() * sizeof(float), sizeof(float), energy.size(),
+                                  hipMemcpyDeviceToHost, (hipStream_t)srv.stream()), "energyDetector: download");
+        srv.sync();
+    }
+    SegCluster outputSeg;
+    selectFrames(energy, threshold, selectedSegments, outputSeg);
+    if (energyModelOut) *energyModelOut = energyModel;
+    if (thresholdOut) *thresholdOut = threshold;
+    return outputSeg;
+}
+
+// ---- GmmTokenizer -------------------------------------------------------------------------------------
+// the sorted top list of every selected frame, [n x ctop] (DETERMINE_TOP_DISTRIBS + getTopDistribIndexVector, GmmTokenizer.cpp:71-72, :100-101)
+static std::vector<int32_t> topListOfSelection(const SegCluster &selectedSegments, FeatureBuffer &fs, DeviceMixture &world, int ctop,
+                                               double minLLK, double maxLLK, unsigned long &n)
+{
+    if (ctop < 1 || (unsigned long)ctop > world.getDistribCount()) throw Exception("topDistribsCount must lie in 1 .. distribCount");
+    const float *x = fs.select(selectedSegments, n);
+    GpuServer &srv = fs.server();
+    FiniteScope fin(srv, fs);
+    std::vector<int32_t> idx((size_t)n * ctop);
+    if (n)
+        srv.check(gmmiv_llk_determine_top(srv.ctx(), world.handle(), x, GMMIV_F32, (int64_t)n, (int64_t)fs.getVectSize(), ctop, GMMIV_TOP_COMPLETE,
+                                          minLLK, maxLLK, idx.data(), nullptr, nullptr, nullptr, nullptr, nullptr));
+    return idx;
+}
+
+void computeSymbols(const SegCluster &selectedSegments, FeatureBuffer &fs, DeviceMixture &world, std::vector<unsigned long> &stream,
+                    int topDistribsCount, double minLLK, double maxLLK)
+{
+    unsigned long n = 0;
+    const std::vector<int32_t> idx = topListOfSelection(selectedSegments, fs, world, topDistribsCount, minLLK, maxLLK, n);
+    stream.reserve(stream.size() + n);
+    for (unsigned long t = 0; t < n; ++t) stream.push_back((unsigned long)idx[(size_t)t * topDistribsCount]); // v[0].idx (:102-103)
+}
+
+void computeConfusionMatrix(const SegCluster &selectedSegments, FeatureBuffer &fs, DeviceMixture &world, unsigned long nBest,
+                            std::vector<unsigned long> &mce_matrix, double minLLK, double maxLLK)
+{
+    const unsigned long C = world.getDistribCount();
+    if (mce_matrix.size() != (size_t)C * C) throw Exception("mce_matrix must be distribCount x distribCount");
+    unsigned long n = 0;
+    const std::vector<int32_t> idx = topListOfSelection(selectedSegments, fs, world, (int)nBest, minLLK, maxLLK, n);
+    for (unsigned long t = 0; t < n; ++t) {
+        const int32_t *v = &idx[(size_t)t * nBest];
+        for (unsigned long i = 0; i < nBest; ++i) mce_matrix[(size_t)v[0] * C + (size_t)v[i]]++; // :73-75
+    }
+}
+
 double TopGauss::get(DeviceMixture &ubm, FeatureBuffer &fs, const SegCluster &selectedSegments, bool complete, double minLLK, double maxLLK) const
 {
     unsigned long n = 0;

@@ -400,6 +400,38 @@ class TopGauss {
     std::vector<double> _snsw, _snsl;
 };
 
+// ---- GmmTokenizer (LIA_Utils/GmmTokenizer/src/GmmTokenizer.cpp): the two consumers of getTopDistribIndexVector() that ship golden
+// outputs (test/test1.sym.ref, test/mce_matrix.mat.ref -- KAT-5 of tests/golden) ------------------------------------------------
+// computeSymbols (:99-126): DETERMINE_TOP_DISTRIBS with a list of topDistribsCount entries on every selected frame, v[0].idx appended
+// to `stream` -- one symbol per frame, in cluster order.
+void computeSymbols(const SegCluster &selectedSegments, FeatureBuffer &fs, DeviceMixture &world, std::vector<unsigned long> &stream,
+                    int topDistribsCount = 1, double minLLK = -200.0, double maxLLK = 200.0);
+// computeConfusionMatrix (:69-97): mce_matrix(v[0].idx, v[i].idx)++ for i < nBest on every selected frame; mce_matrix is
+// [distribCount x distribCount], row-major, ACCUMULATED into (the caller sizes and zeroes it, like mce_matrix.setDimensions at :144).
+// nBest = topDistribsCount there (:132), so the list length and the loop bound are one number.
+void computeConfusionMatrix(const SegCluster &selectedSegments, FeatureBuffer &fs, DeviceMixture &world, unsigned long nBest,
+                            std::vector<unsigned long> &mce_matrix, double minLLK = -200.0, double maxLLK = 200.0);
+
+// ---- EnergyDetector (LIA_SpkDet/EnergyDetector/src/EnergyDetector.cpp): a two / three-Gaussian model of the energy coefficient trained
+// by FULL EM (weights, means AND variances) from a FIXED init -- no rand() -- then a threshold on that coefficient.  The one reference tool
+// whose output (test/test1.validate.enr.lbl, KAT-6 of tests/golden, "assumed") depends on the variance estimate of getEM.
+struct EnergyDetectorCfg {
+    unsigned long nbTrainIt = 10, mixtureDistribCount = 3;
+    double varianceFlooring = 0.5, varianceCeiling = 10.0, alpha = 0.0;
+    std::string thresholdMode = "meanStd"; // :199-203; "weight" needs alize-core's Histo (not in the LIA_RAL tree): Exception
+};
+void energyMixtureInit(MixtureGD &world);                    // :163-183: means from -2 in steps of 4 / (distribCount - 1), covariances 1, equal weights
+unsigned long findMaxEnergyDistrib(const MixtureGD &mixt);   // :83-93
+// selectFrames (:118-157): segments of consecutive frames of `selectedSeg` whose coefficient 0 exceeds the threshold; begin / length count
+// frames of the SELECTION (the reference's `ind`), and a run that reaches the end of an input segment is one frame longer than a run that
+// ends inside it (:144 vs :151 -- reproduced as written).  energy[t] = coefficient 0 of frame t of the file.  Returns the frames above.
+unsigned long selectFrames(const std::vector<float> &energy, double threshold, const SegCluster &selectedSeg, SegCluster &outputSeg);
+// energyDetector (:190-285): globalMeanCov -> energyMixtureInit -> nbTrainIt x (accumulateStatEM, getEM, varianceControl) -> threshold
+// = mean - alpha * sqrt(cov) of the highest-mean component -> selectFrames.  energyModel / threshold (optional) receive the trained model
+// and the threshold.
+SegCluster energyDetector(FeatureBuffer &fs, const SegCluster &selectedSegments, const EnergyDetectorCfg &cfg, MixtureGD *energyModel = nullptr,
+                          double *threshold = nullptr);
+
 // ---- AccumulateTVStat.h ----------------------------------------------------------------------------
 class TVAcc {
   public:

@@ -538,6 +538,34 @@ def compute_test_files(world_path, client_paths, client_names, prm_path, lbl_pat
     return llr[:len(lines)].reshape(-1, n), lines
 
 
+def energy_detector(energy, seg_begin, seg_len, C=2, nb_train_it=10, variance_flooring=0.5, variance_ceiling=10.0, alpha=0.25, device=0):
+    """EnergyDetector (meanStd mode) on one energy column -> dict(begin, length, w, mean, cov, threshold)."""
+    e = np.ascontiguousarray(energy, np.float32)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    ob = np.zeros(4096, np.int64); ol = np.zeros(4096, np.int64); n = ct.c_long(0)
+    model = np.zeros(3 * C); th = ct.c_double(0.0)
+    _chk(lib.liagpu_energy_detector(device, e.ctypes.data_as(_fp), ct.c_long(len(e)), bp, lp, ct.c_long(len(b)), int(C), int(nb_train_it),
+                                    ct.c_double(variance_flooring), ct.c_double(variance_ceiling), ct.c_double(alpha),
+                                    ob.ctypes.data_as(_lp), ol.ctypes.data_as(_lp), ct.c_long(len(ob)), ct.byref(n), _d(model), ct.byref(th)))
+    return dict(begin=ob[:n.value].copy(), length=ol[:n.value].copy(), w=model[:C].copy(), mean=model[C:2 * C].copy(), cov=model[2 * C:].copy(),
+                threshold=th.value)
+
+
+def gmm_tokenizer_files(world_path, prm_path, lbl_path, mask="", label="male", frame_length=0.01, top_c=1, min_llk=-200.0, max_llk=200.0,
+                        matrix_path="", device=0):
+    """GmmTokenizer from its files (GmmTokenizer.cpp:120-207): -> (symbols[n_selected], confusion[C, C]) with nBest = top_c."""
+    dims = np.zeros(3, np.int64)
+    sym = np.zeros(1 << 20, np.int64); n = ct.c_long(0)
+    _chk(lib.liagpu_gmm_tokenizer_files(device, world_path.encode(), prm_path.encode(), lbl_path.encode(), mask.encode(), label.encode(),
+                                        ct.c_double(frame_length), int(top_c), ct.c_double(min_llk), ct.c_double(max_llk),
+                                        sym.ctypes.data_as(_lp), ct.c_long(len(sym)), ct.byref(n), None, dims.ctypes.data_as(_lp), b""))
+    conf = np.zeros((int(dims[0]), int(dims[0])), np.int64)
+    _chk(lib.liagpu_gmm_tokenizer_files(device, world_path.encode(), prm_path.encode(), lbl_path.encode(), mask.encode(), label.encode(),
+                                        ct.c_double(frame_length), int(top_c), ct.c_double(min_llk), ct.c_double(max_llk),
+                                        None, ct.c_long(0), None, conf.ctypes.data_as(_lp), dims.ctypes.data_as(_lp), matrix_path.encode()))
+    return sym[:n.value].copy(), conf
+
+
 def io_roundtrip(raw_in, raw_out, prm_in, prm_out, mask):
     dims = np.zeros(4, np.int64); mean0 = np.zeros(512); frame0 = np.zeros(512, np.float32)
     _chk(lib.liagpu_io_roundtrip(raw_in.encode(), raw_out.encode(), prm_in.encode(), prm_out.encode(), mask.encode(),

@@ -6,6 +6,9 @@ What is extracted (data only -- model parameters, feature frames, expected numbe
   KAT-1  LIA_SpkDet/ComputeTest/test/{wld,test1,test1.prm,test1.lbl,test1.validate.res}
   KAT-2  LIA_SpkDet/TrainTarget/test/{wld,test1.prm,test1.lbl,test1.validate.gmm}
   KAT-4  LIA_SpkDet/NormFeat/test/{test1.prm,test1.validate.prm}
+  KAT-5  LIA_Utils/GmmTokenizer/test/{wld,test1.prm,test1.lbl,test1.sym.ref,mce_matrix.mat.ref}
+         (integers: the per-frame best Gaussian and the top-20 confusion counts of DETERMINE_TOP_DISTRIBS)
+  KAT-6  LIA_SpkDet/EnergyDetector/test/{test1.prm,test1.lbl,test1.validate.enr.lbl}   -- ASSUMED, not a pin (see the note it carries)
 
 The binary files in the reference checkout went through text-mode newline translation
 (every 0x0D 0x0A lost its 0x0D; lone 0x0D became 0x0A).  RAW GMM files are
@@ -182,6 +185,68 @@ def main():
         median_tol=np.array(1e-6), max_tol=np.array(0.05),
     )
     print("KAT-4 ok")
+    # ---- KAT-5: GmmTokenizer (LIA_Utils/GmmTokenizer/src/GmmTokenizer.cpp:69-76 confusion matrix, :99-104 symbols) ----
+    # wld is intact here (68 744 bytes = 8 + 8*128 + 128*(17 + 16*32): nothing dropped, repair inserts nothing); one record (81)
+    # fails the cst/det redundancy check -- a substituted low mantissa byte in cst/det, which are recomputed and never used.
+    d = "/root/reference/LIA_Utils/GmmTokenizer/test"
+    raw = open(d + "/wld", "rb").read()
+    fixed, n_ins, damaged = repair_raw_gmm(raw)
+    assert fixed == raw and n_ins == 0
+    tok = parse_raw_gmm(raw)
+    _, x5 = load_prm(d + "/test1.prm")
+    sym = np.array(open(d + "/test1.sym.ref").read().split(), dtype=np.int64)
+    lines = open(d + "/mce_matrix.mat.ref").read().split("\n")
+    assert lines[0].split() == ["128", "128"]                              # DT matrix: "rows cols" then one row per line
+    conf = np.array([[int(float(v)) for v in ln.split()] for ln in lines[1:129]], dtype=np.int64)
+    assert conf.shape == (128, 128)
+    np.savez_compressed(
+        OUT + "/kat5_gmmtokenizer.npz",
+        w=tok["w"], covinv=tok["covinv"], mean=tok["mean"],
+        x=mask_0_15_17_32(x5).astype(np.float32),
+        seg_begin=np.array([0, 30]), seg_len=np.array([26, 11]),           # test1.lbl "0 0.25 male" / "0.3 0.4 male", inclusive end
+        symbols=sym,                                                       # test1.sym.ref: 9 values for 37 selected frames
+        confusion=conf,                                                    # mce_matrix.mat.ref: sum 740 = 37 frames x 20
+        nbest=np.array(20),
+        note=np.array(
+            "nbest: GmmTokenizer.cfg says topDistribsCount 6, but the shipped matrix sums to 740 = 37 x 20 (6 would give 222): the "
+            "golden was produced with 20, the cfg is stale (like KAT-2's nbTrainIt).  symbols: computeSymbols (GmmTokenizer.cpp:99-104) "
+            "adds ONE value per selected frame (37); test1.sym.ref holds 9 -- it equals the per-frame best Gaussian with consecutive "
+            "repeats collapsed, exactly.  ULongVector::save is alize-core (not in the tree), so whether the collapse happened in save() "
+            "or in an older computeSymbols is not visible; the 9-integer match of the collapsed stream is the pin."),
+    )
+    import gzip, shutil
+    rf = OUT + "/ref_files"
+    shutil.copyfile(d + "/wld", rf + "/gmmtokenizer_wld.raw.gmm")          # reference test DATA (a model file), not source
+    shutil.copyfile(d + "/test1.sym.ref", rf + "/gmmtokenizer_test1.sym.ref")
+    with gzip.GzipFile(rf + "/gmmtokenizer_mce_matrix.mat.ref.gz", "wb", mtime=0) as g:
+        g.write(open(d + "/mce_matrix.mat.ref", "rb").read())
+    # ---- KAT-6 (assumed): EnergyDetector (LIA_SpkDet/EnergyDetector/src/EnergyDetector.cpp:163-183 fixed init, :227-263 training
+    # loop + meanStd threshold, :128-157 selectFrames) -- the one reference artefact that goes through the VARIANCE estimate of getEM
+    d = REF + "/EnergyDetector/test"
+    _, x6 = load_prm(d + "/test1.prm")
+    lab_in = open(d + "/test1.lbl").read().split()
+    lab_out = open(d + "/test1.validate.enr.lbl").read().split()
+    assert lab_in == ["0", "0.25", "male"] and lab_out == ["0.21", "0.26", "speech"]
+    np.savez_compressed(
+        OUT + "/kat6_energydetector_assumed.npz",
+        energy=x6[:, 16].astype(np.float32),                               # featureServerMask 16, vectSize 1
+        seg_begin=np.array([0]), seg_len=np.array([26]),                   # "0 0.25 male", inclusive end
+        nb_train_it=np.array(10), variance_flooring=np.array(0.5), variance_ceiling=np.array(10.0), alpha=np.array(0.25),
+        init_mean=np.array([-2.0, 2.0]), init_cov=np.array([1.0, 1.0]), init_w=np.array([0.5, 0.5]),   # energyMixtureInit, C = 2, D = 1
+        expected_frames=np.arange(21, 26),                                 # frames above the threshold
+        expected_seg=np.array([21, 6]),                                    # createSeg(begin, ind - begin + 1) with ind = 26 (:150-153)
+        expected_label=np.array("0.21 0.26 speech"),                       # begin * 0.01, (begin + length - 1) * 0.01
+        raw_frames=np.array([2, 17, 18, 19, 20, 21, 22, 23, 24, 25]),      # what the RAW energy column gives -- not the golden
+        note=np.array(
+            "ASSUMED, not pinned: the golden 0.21 0.26 comes out only when the energy column has mean 0 / variance 1 before the EM "
+            "(the fixed init puts the two Gaussians at -2 / +2 with variance 1, and EnergyDetector.cpp:204 says the input is an energy "
+            "parameter file -- in the LIA recipe NormFeat's energy normalisation runs first; the cfg does not state it and test1.prm is "
+            "the shared, un-normalised file).  Normalising on the 26 selected frames or on all 50 frames of the file gives the same "
+            "five frames; the raw column gives raw_frames.  The output is one coarse segment, so it constrains the variance path "
+            "(getEM variances, varianceControl with flooring 0.5 x globalCov hit from iteration 3 on) only loosely."),
+    )
+    print("KAT-6 (assumed) ok")
+    print("KAT-5: symbols", sym.tolist(), "confusion sum", int(conf.sum()), "damaged records", damaged)
 
 
 if __name__ == "__main__":
