@@ -737,9 +737,51 @@ def tv_parity_and_cpu_baseline(ops, R, U_chk=4, want_cpu=True):
     parity = {"max_rel_err": worst, "tolerance": 1e-9, "ok": bool(worst < 1e-9), "per_output": errs,
               "what": "estimateTETt + estimateAandC of %d utterances at C=%d, R=%d under the T of the last timed iteration: libgmmiv vs the "
                       "oracle's scalar loops (restatement, parity unpinned: no reference vector exists for this path)" % (U_chk, C, R)}
-    cpu = {"value": U_chk / dt, "unit": "utterances/s", "cores": 1, "kind": "port",
-           "sample": "estimateAandC on %d utterances at C=2048, R=%d, scalar fp64 oracle (-O2), %.1f s; TETt precomputed" % (U_chk, R, dt)}
+    cpu = {"value": U_chk / dt, "unit": "utterances/s (E-step only)", "cores": 1, "kind": "port",
+           "sample": "estimateAandC ALONE on %d utterances at C=2048, R=%d, the checker's strict scalar fp64 oracle (-O2), %.1f s; TETt precomputed; "
+                     "the whole-iteration threaded -O3 -ffast-math figure is cpu_baseline" % (U_chk, R, dt)}
     return parity, (cpu if want_cpu else None)
+
+
+def tv_iteration_cpu_baseline(ops, R, U_cpu=64, threads=32):
+    """ONE WHOLE T-matrix EM iteration (estimateTETt, estimateAandC, updateTestimate, minDivergence) of
+    the first U_cpu utterances of this rank, on the host cores with the reference's thread partition (oracle/oracle_mt.c
+    orc_tv_em_iteration_mt, gcc -O3 -ffast-math: AccumulateTVStat.cpp:826-950, :1831-2052 -- utterance ranges per thread, private
+    R / r / meanW, A and C shared under two mutexes), and the SAME iteration on the same utterances through libgmmiv; the relative
+    error of T and of the UBM means after it is the parity of the whole iteration.  Untimed for the GPU; the CPU time is the baseline."""
+    from lia_ral_amd import dist as gd
+    from oracle import oracle as orc
+    U_cpu = int(min(U_cpu, ops.N.shape[0]))
+    threads = int(max(1, min(threads, os.cpu_count() or 1, U_cpu)))
+    T0, m0 = ops.T.clone(), ops.means.clone()
+    sub = GpuTvOps(ops.ctx, ops.N[:U_cpu].contiguous(), torch.empty_like(ops.F_raw[:U_cpu]), T0.clone(), ops.invvar, m0.clone(), R,
+                   F_raw=ops.F_raw[:U_cpu].contiguous())
+    gd.tv_em_iteration(sub, U_cpu, C, D)                       # one rank, no exchange: recentre, tett, estep, update_t, min_divergence
+    torch.cuda.synchronize()
+    T_gpu, m_gpu = sub.T.cpu().numpy(), sub.means.cpu().numpy()
+    Nh = sub.N.cpu().numpy()
+    Fh = orc.tv_subtract_m(Nh, sub.F_raw.cpu().numpy(), m0.cpu().numpy())       # substractM under the means the iteration starts from
+    del sub
+    torch.cuda.empty_cache()
+    t = time.time()
+    ref = orc.tv_em_iteration_mt(Nh, Fh, T0.cpu().numpy(), ops.invvar.cpu().numpy(), m0.cpu().numpy(), threads=threads, upd_threads=threads)
+    dt = time.time() - t
+    relT = float(np.max(np.abs(T_gpu - ref["T"])) / np.max(np.abs(ref["T"])))
+    relm = float(np.max(np.abs(m_gpu - ref["means"])) / np.max(np.abs(ref["means"])))
+    ph = [float(v) for v in ref["phase_s"]]
+    cpu = {"value": U_cpu / dt, "unit": "utterances/s", "cores": threads, "kind": "port", "seconds": dt, "utterances": U_cpu,
+           "phases_s": {"estimateTETt": ph[0], "estimateAandC": ph[1], "updateTestimate": ph[2], "minDivergence": ph[3]},
+           "per_iteration_fixed_s": ph[0] + ph[2] + ph[3],
+           "sample": "ONE whole T-matrix EM iteration on %d utterances at C=%d, R=%d: estimateTETt + estimateAandC on %d threads with the "
+                     "reference's partition (utterance ranges, private R / r / meanW, A and C under two mutexes), then updateTestimate and "
+                     "minDivergence -- single-threaded in the reference, here ALSO on %d threads (Gaussian / column ranges: generous to the "
+                     "CPU); gcc -O3 -ffast-math; a restatement of the reference loops, not the original binary.  TETt, updateTestimate and "
+                     "minDivergence cost the same whatever the utterance count (per_iteration_fixed_s): utterances/s of this sample is NOT "
+                     "the rate of a 6250-utterance iteration" % (U_cpu, C, R, threads, threads)}
+    parity = {"max_rel_err_T": relT, "max_rel_err_means": relm, "tolerance": 1e-6, "ok": bool(relT < 1e-6 and relm < 1e-6),
+              "what": "T and the UBM means after ONE whole iteration on %d utterances from the T of the last timed step: libgmmiv vs the threaded "
+                      "-ffast-math oracle (restatement; parity unpinned -- no reference vector exists for this path)" % U_cpu}
+    return parity, cpu
 
 
 def em_parity(ctx, g, w, mean, iv, x, acc_last, frames_per_rank, world, nframes=2000):
@@ -781,7 +823,8 @@ def max_over_ranks(dt, world, dev):
     return float(tt.item())
 
 
-def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False, force=False, traffic=None):
+def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False, force=False, traffic=None,
+                cpu_utterances=64):
     """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
     then `steps` EM iterations timed, each the tool's full sequence: restore + substractM, estimateTETt, estimateAandC,
     updateTestimate (sharded), minDivergence.  Returns the JSON fields of the workload."""
@@ -853,7 +896,9 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
     if rank == 0 and check:
         res["parity"], cpub = tv_parity_and_cpu_baseline(ops, R, want_cpu=cpu)
         if cpub:
-            res["cpu_baseline"] = cpub
+            res["cpu_baseline_1thread_estep"] = cpub
+        if cpu:
+            res["parity"]["whole_iteration"], res["cpu_baseline"] = tv_iteration_cpu_baseline(ops, R, cpu_utterances, min(32, physical_cores()))
     return res
 
 
@@ -883,6 +928,7 @@ def main():
     ap.add_argument("--workload", choices=["em", "tv"], default="em", help="em: TrainWorld EM pass (headline); tv: TotalVariability T-matrix EM iteration (configs[3])")
     ap.add_argument("--tv-utterances", type=int, default=6250, help="utterances per GPU of the T-matrix EM workload")
     ap.add_argument("--tv-rank", type=int, default=400)
+    ap.add_argument("--tv-cpu-utterances", type=int, default=64, help="utterances of the whole-iteration CPU baseline of the T-matrix workload")
     ap.add_argument("--iv-utterances", type=int, default=10_000, help="utterances per GPU of the IvExtractor block (configs[2]: 10 000)")
     ap.add_argument("--score-vectors", type=int, default=100_000, help="enrolment = test i-vectors of the scoring block (configs[4]: 100 000)")
     ap.add_argument("--collectives", choices=["gmmiv", "torch"], default="gmmiv")
@@ -968,7 +1014,8 @@ def main():
     check = not args.no_cpu_baseline
     if args.workload == "tv":
         res = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, args.steps, args.warmup,
-                          check=check, cpu=(world == 1), overlap=bool(args.overlap), force=force, traffic=load_traffic())
+                          check=check, cpu=(world == 1), overlap=bool(args.overlap), force=force, traffic=load_traffic(),
+                          cpu_utterances=args.tv_cpu_utterances)
         if rank == 0:
             res["comm"] = comm_info
             if coll_note:
@@ -1107,7 +1154,7 @@ def main():
         del x_keep
         torch.cuda.empty_cache()
         tv_em = tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, args.tv_utterances, 3000, args.tv_rank, 3, 1, check=check, cpu=(world == 1),
-                            overlap=bool(args.overlap), traffic=traffic)
+                            overlap=bool(args.overlap), traffic=traffic, cpu_utterances=args.tv_cpu_utterances)
         torch.cuda.empty_cache()
         if world == 1:             # configs[4] is a single-GPU workload (model blocks shard without any exchange: lia_ral_amd.dist.score_model_block)
             scoring = scoring_block(ctx, dev, M=args.score_vectors, S=args.score_vectors, check=check, traffic=traffic)
@@ -1162,12 +1209,43 @@ def main():
                                 "frac": step_tf / (PEAK_F64_TFLOPS * world)}
         if world == 1 and check:
             out["cpu_baseline"] = cpu_baseline(w, mean, iv, seed=99)
+        out["summary"] = summarize(out)     # LAST key: the five BASELINE configs in a few hundred bytes (a truncated tail of the line still shows them)
         print(json.dumps(out), flush=True)
     g.close()
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def summarize(out):
+    """One compact entry per BASELINE.json config from the blocks of the line: value, unit, fraction of the fp64 peak, the CPU
+    baseline (value / threads) and the parity error of the block's checker leg."""
+    def cpu(b):
+        c = (b or {}).get("cpu_baseline")
+        return [c["value"], c["unit"], c["cores"]] if c else None
+
+    def entry(b, err_key, frac=None, cpu_of=None):
+        if not b:
+            return None
+        par = b.get("parity") or {}
+        e = par.get(err_key)
+        return {"value": b.get("value"), "unit": b.get("unit"), "frac": frac if frac is not None else (b.get("roofline") or {}).get("frac"),
+                "cpu": cpu(cpu_of or b), "parity_err": e, "ok": par.get("ok")}
+    ct = out.get("computetest")
+    s = {"configs[1] TrainWorld EM": entry(out, "max_rel_err", frac=(out.get("step_roofline") or {}).get("frac")),
+         "configs[2] IvExtractor": entry(out.get("secondary"), "max_rel_err_vs_oracle"),
+         "configs[3] TotalVariability": entry(out.get("tv_em"), "max_rel_err"),
+         "configs[4] IvTest scoring": entry(out.get("scoring"), "max_rel_err_vs_oracle"),
+         "configs[0] ComputeTest": None if not ct else {
+             "value": ct["world_pass_gpairs_per_s"], "unit": "Gframe-Gaussian/s (top-10 world pass)", "frac": None, "cpu": None,
+             "parity_err": (ct.get("parity") or {}).get("max_abs_err_llk"), "ok": (ct.get("parity") or {}).get("ok")}}
+    if s["configs[1] TrainWorld EM"] and out.get("roofline"):
+        s["configs[1] TrainWorld EM"]["k1_frac"] = out["roofline"]["frac"]
+    tv = out.get("tv_em") or {}
+    if s["configs[3] TotalVariability"] and (tv.get("parity") or {}).get("whole_iteration"):
+        s["configs[3] TotalVariability"]["parity_err_T_whole_iteration"] = tv["parity"]["whole_iteration"]["max_rel_err_T"]
+    return s
 
 
 if __name__ == "__main__":

@@ -373,6 +373,24 @@ def tv_min_divergence(Rm, r, meanW, means, Tm, n_sessions, C, D):
     return means, Tm
 
 
+def tv_em_iteration_mt(N, F, Tm, invvar, means, threads=1, upd_threads=1):
+    """One TotalVariability iteration (estimateTETt, estimateAandC, updateTestimate, minDivergence) on `threads` threads with the
+    reference's partition (oracle_mt.c, the -O3 -ffast-math build: bench.py's cpu_baseline of the T-matrix workload).  F centred.
+    -> dict(T, means, W, phase_s [TETt, estimateAandC, updateTestimate, minDivergence])."""
+    N, Np = _d(N); F, Fp = _d(F); iv, ivp = _d(invvar)
+    Tm = np.array(Tm, np.float64); means = np.array(means, np.float64).ravel()
+    U, C = N.shape
+    R = Tm.shape[0]
+    D = Tm.shape[1] // C
+    W = np.zeros((U, R)); ph = np.zeros(4)
+    f = _lib(True).orc_tv_em_iteration_mt
+    f.restype = ct.c_int
+    rc = f(ct.c_int(threads), ct.c_int(upd_threads), ct.c_long(U), ct.c_int(C), ct.c_int(D), ct.c_int(R), Np, Fp, Tm.ctypes.data_as(c_dp), ivp,
+           means.ctypes.data_as(c_dp), W.ctypes.data_as(c_dp), ph.ctypes.data_as(c_dp))
+    assert rc == 0, "orc_tv_em_iteration_mt rc %d" % rc
+    return dict(T=Tm, means=means, W=W, phase_s=ph)
+
+
 def tv_init_t(R, invvar, seed=1):
     iv, ivp = _d(invvar)
     Tm = np.empty((R, len(iv)))

@@ -307,3 +307,25 @@ def test_mixture_init_against_a_python_walk_with_glibc_rand():
         assert np.allclose(mean, s / n[:, None], rtol=1e-13, atol=1e-13)
     with pytest.raises(ValueError, match="does not terminate"):     # 1 < p < 4.9: the reference's fold loop never ends
         orc.mixture_init(5, rng.normal(size=(120, 3)), [5], [100], nb_frame_to_select=160.0)
+
+
+def test_threaded_tv_iteration_equals_the_unthreaded_steps():
+    """oracle_mt.c's T-matrix EM iteration (the reference's thread partition: AccumulateTVStat.cpp:826-950, :1831-2052; bench.py's
+    cpu_baseline of the T-matrix workload, -O3 -ffast-math) against the strict single-thread oracle steps on the same statistics."""
+    rng = np.random.default_rng(3)
+    U, C, D, R = 23, 6, 5, 7
+    N = rng.uniform(0.5, 40.0, (U, C))
+    means = rng.normal(size=C * D)
+    invvar = rng.uniform(0.5, 2.0, C * D)
+    F = rng.normal(size=(U, C * D)) * np.repeat(N, D, axis=1)
+    Tm = 0.1 * rng.normal(size=(R, C * D))
+    te = orc.tv_tett(Tm, invvar, C, D)
+    e = orc.tv_estimate_a_and_c(N, F, Tm, invvar, te)
+    Tn = orc.tv_update_t(e["A"], e["Cmx"], C, D)
+    m_ref, T_ref = orc.tv_min_divergence(e["Rm"], e["r"], e["meanW"], means, Tn, U, C, D)
+    for threads, upd in ((1, 1), (4, 1), (5, 3), (64, 8)):          # 64 > U: clamped to U like :1949
+        got = orc.tv_em_iteration_mt(N, F, Tm, invvar, means, threads=threads, upd_threads=upd)
+        assert np.max(np.abs(got["W"] - e["W"])) < 1e-10 * np.max(np.abs(e["W"]))
+        assert np.max(np.abs(got["T"] - T_ref)) < 1e-9 * np.max(np.abs(T_ref))
+        assert np.max(np.abs(got["means"] - m_ref)) < 1e-10 * np.max(np.abs(m_ref))
+        assert got["phase_s"].shape == (4,) and np.all(got["phase_s"] >= 0)
