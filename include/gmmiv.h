@@ -76,7 +76,7 @@ const char *gmmiv_version(void);
  *                      the same utterance extracted alone and inside a large batch gives N / F -- and i-vectors -- that agree to about
  *                      1e-13 relative, not bitwise (both within the 1e-9 of the parity tests); set the option to 0 when a row must not
  *                      depend on its neighbours
- *   "assume_finite" 0  1: skip the screening pass for unusable feature values ("DEGENERATE INPUTS" below)
+ *   "assume_finite" 0  1: skip the pass that COUNTS the frames with unusable feature values ("DEGENERATE INPUTS" below; results never depend on it)
  *   "screened_frames", "zero_llk_frames"   counters of the frames of kind (1) / kind (2) of "DEGENERATE INPUTS" (read: returns the
  *                      count so far and stores `value`)
  *   "tv_tett_direct" 1 estimateTETt as one kernel that computes the lower triangles only and writes them packed (D <= 64); 0 = batched
@@ -185,21 +185,26 @@ void gmmiv_gmm_destroy(gmmiv_gmm *g);
  *                                 log-likelihoods and nothing to the frame count (the M-step weights still sum to 1)
  *   gmmiv_tv_stats(_lines), gmmiv_jfa statistics    nothing added to N / F
  *   gmmiv_frame_moments           NOT screened: sums of the raw values, a NaN goes into the sums like in the reference
- * Frames of kind (1) are found by a screening pass over x at the start of every call (one read of x at HBM speed: 0.3 % of an EM
- * pass); a call that has any runs on the compacted usable frames and expands its per-frame outputs.  A caller whose features are
- * known to be clean sets the option "assume_finite" 1 and skips the pass (the C++ host layer checks a FeatureBuffer once, at
- * upload -- and decides per call, from the buffer the call reads).  The option "screened_frames" reads the number of frames of kind (1)
- * taken out so far.  Kind (2) is decided per frame where the log-likelihood kernel finishes a frame -- no per-element work in the hot
- * loops -- and COUNTED on the device by the entry points that drop such a frame from a sum: gmmiv_llk, gmmiv_em_accumulate,
- * gmmiv_tv_stats(_lines) (and the JFA statistics built on it), gmmiv_occ.  gmmiv_ctx_set_option(ctx, "zero_llk_frames", v) returns
- * the count so far and stores v (0 to reset); the read waits for the context's stream, the counting never does.  Not counted: the
- * top-C entry points (a zero-likelihood frame is visible there as llk = min_llk with lk = 0) and the opt-in "em_fused" form of
- * gmmiv_tv_stats.
+ * Frames of kind (1) are handled ON THE DEVICE, inside the kernels: every kernel that reads features reads an unusable value as 1e10
+ * (csrc/devutil.h, feat_sane: one compare + select where the value is loaded -- in the MFMA log-likelihood kernel once per frame and
+ * workgroup, outside its loop).  The value is finite, so no 0 x NaN reaches a statistic, and it puts every logit of the frame near
+ * -0.5e20 / variance: the frame then IS a frame of kind (2) for every kernel (holds for variances in 1e-17 .. 1e17) and follows the
+ * table above with no host decision -- no flags read back, no compaction, NO SYNCHRONISATION: a call whose arrays are all device
+ * pointers only enqueues on the context's stream (rounds 1-5 screened on the host and waited for the stream once per call).
+ * What remains of the screening is a COUNT: at the start of a frame-consuming call one pass over x (0.3 % of an EM pass) adds the number
+ * of kind-(1) frames to a device counter, option "screened_frames" (read / reset like "zero_llk_frames" below).  The option
+ * "assume_finite" 1 skips that pass; RESULTS do not depend on it (the C++ host layer checks a FeatureBuffer once, at upload, and
+ * sets it per call from the buffer the call reads).  Kind (2) is decided per frame where the log-likelihood kernel finishes a
+ * frame -- no per-element work in the hot loops -- and COUNTED on the device by the entry points that drop such a frame from a sum:
+ * gmmiv_llk, gmmiv_em_accumulate, gmmiv_tv_stats(_lines) (and the JFA statistics built on it), gmmiv_occ; a kind-(1) frame is
+ * evaluated as a kind-(2) frame and therefore counted here TOO.  gmmiv_ctx_set_option(ctx, "zero_llk_frames", v) returns the count so
+ * far and stores v (0 to reset); the read waits for the context's stream, the counting never does.  Not counted: the top-C entry
+ * points (a zero-likelihood frame is visible there as llk = min_llk with lk = 0) and the opt-in "em_fused" form of gmmiv_tv_stats.
  * Other edges: T = 0 is valid everywhere (outputs untouched, accumulators unchanged); a Gaussian of weight 0 has likelihood 0
  * (never selected before a Gaussian of positive likelihood, occupancy 0); gmmiv_em_get keeps the previous mean / covariance of a
  * Gaussian whose occupancy is 0 and gives it weight 0; identical Gaussians tie and the lower index wins.
  *
- * gmmiv_count_unusable_frames: the screening pass on its own -- *count = frames of kind (1). */
+ * gmmiv_count_unusable_frames: the counting pass on its own, read back -- *count = frames of kind (1) (this call waits for the stream). */
 int gmmiv_count_unusable_frames(gmmiv_ctx *ctx, const void *x, int x_dtype, int64_t T, int64_t ldx, int D,
                                 int64_t *count);
 

@@ -60,13 +60,14 @@ int gmmiv_ctx_create(int device, void *stream, gmmiv_ctx **out)
     else { GCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->n_cu = prop.multiProcessorCount; c->total_mem = prop.totalGlobalMem; }
-    if (hipMalloc((void **)&c->d_zero_llk, sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_zero_llk, 0, sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_zero_llk, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_zero_llk, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipGetLastError();
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
         gmmiv_set_error("ctx_create: hipMalloc of the context's device counters failed");
         return GMMIV_ERR_HIP;
     }
+    c->d_screened = c->d_zero_llk + 1;
     *out = c;
     return GMMIV_OK;
 }
@@ -128,7 +129,6 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "topc_rank2")) slot = &c->topc_rank2;
     else if (!strcmp(key, "topc_use_lanes")) slot = &c->topc_use_lanes;
     else if (!strcmp(key, "assume_finite")) slot = &c->assume_finite;
-    else if (!strcmp(key, "screened_frames")) slot = &c->screened_frames;
     // options read by the kernel launchers: kept in the context's gmmiv_kopts, bound to the calling thread by every call (GBIND)
     int *ks = nullptr;
     if (!strcmp(key, "z_waves")) { const long prev = c->ko.z_waves; c->ko.z_waves = (value == 4 || value == 16) ? (int)value : 8; return prev; }
@@ -147,11 +147,15 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "chol_uut64")) ks = &c->ko.chol_uut64;   // 1 = k_uut64 for the packed E = U U^T + w w^T of the E-step
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
-    if (!strcmp(key, "zero_llk_frames")) { // the device counter of kind-(2) frames: reading it waits for the stream (the counting itself never does)
+    // the device counters of kind-(2) frames (zero likelihood under the call's model -- this INCLUDES the kind-(1) frames, which every
+    // kernel evaluates as such) and of kind-(1) frames (unusable feature values, counted by the screening pass): reading one waits
+    // for the stream, the counting itself never does
+    if (!strcmp(key, "zero_llk_frames") || !strcmp(key, "screened_frames")) {
+        unsigned long long *ctr = key[0] == 'z' ? c->d_zero_llk : c->d_screened;
         unsigned long long prev = 0, nv = value > 0 ? (unsigned long long)value : 0;
         if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
-            hipMemcpy(&prev, c->d_zero_llk, sizeof prev, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(c->d_zero_llk, &nv, sizeof nv, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return -1; }
+            hipMemcpy(&prev, ctr, sizeof prev, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(ctr, &nv, sizeof nv, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return -1; }
         return (long)prev;
     }
     if (!strcmp(key, "kopts_bound")) return g_kopts_src == &c->ko ? 1 : 0; // read-only: is this context's set the one bound to the calling thread?
@@ -301,88 +305,23 @@ struct XView {
 // Screening = one HBM pass over x per call (skipped with the option "assume_finite"); in the -- rare -- call that has unusable
 // frames, the usable ones are compacted (k_gather_runs), the entry point runs on them and the per-frame outputs are expanded
 // back with the values the rule gives a zero-likelihood frame.  The hot kernels themselves carry no per-element checks.
-struct AssumeFinite {
-    gmmiv_ctx *c; long prev;
-    explicit AssumeFinite(gmmiv_ctx *c_) : c(c_), prev(c_->assume_finite) { c->assume_finite = 1; }
-    ~AssumeFinite() { c->assume_finite = prev; }
-};
-struct Screen {
-    int64_t T = 0, Tg = 0;      // frames of the call, usable frames
-    std::vector<long> map;      // host: compacted row of frame t, -1 = unusable (empty when every frame is usable)
-    const void *xg = nullptr;   // usable frames, compacted (device, ld = D)
-    long *dmap = nullptr;       // device copy of map
-    bool active() const { return !map.empty(); }
-    int init(gmmiv_ctx *c, const XView &xv, int dt, int64_t T_, int D)
-    {
-        T = Tg = T_;
-        if (c->assume_finite || T <= 0) return GMMIV_OK;
-        void *p;
-        int rc;
-        const size_t fbytes = ((size_t)T + 15) / 16 * 16;
-        if ((rc = c->scratch(WS_GFLAG, fbytes + 16, &p))) return rc;
-        unsigned char *flag = (unsigned char *)p;
-        int *any = (int *)(flag + fbytes);
-        GCHK(hipMemsetAsync(flag, 0, fbytes + 16, c->stream));
-        GCHK(gmmk_flag_frames(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, D, flag, any));
-        int h_any = 0;
-        GCHK(hipMemcpyAsync(&h_any, any, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        GCHK(hipStreamSynchronize(c->stream));
-        if (!h_any) return GMMIV_OK;
-        std::vector<unsigned char> hf((size_t)T);
-        GCHK(hipMemcpyAsync(hf.data(), flag, (size_t)T, hipMemcpyDeviceToHost, c->stream));
-        GCHK(hipStreamSynchronize(c->stream));
-        map.assign((size_t)T, -1);
-        std::vector<int64_t> runs; // (source frame, output row, length <= 64)
-        long g = 0;
-        for (int64_t t = 0; t < T;) {
-            if (hf[t]) { ++t; continue; }
-            int64_t e = t;
-            while (e < T && !hf[e] && e - t < 64) { map[e] = g + (e - t); ++e; }
-            runs.push_back(t); runs.push_back(g); runs.push_back(e - t);
-            g += (long)(e - t);
-            t = e;
-        }
-        Tg = g;
-        c->screened_frames += (long)(T - Tg);
-        if ((rc = c->scratch(WS_XG, (size_t)(Tg ? Tg : 1) * D * esize(dt), &p))) return rc;
-        xg = p;
-        if (Tg > 0) {
-            void *dr;
-            if ((rc = c->scratch(WS_G6, runs.size() * sizeof(int64_t), &dr))) return rc;
-            GCHK(hipMemcpyAsync(dr, runs.data(), runs.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-            GCHK(gmmk_gather_runs(c->stream, dt == GMMIV_F64, xv.d, xv.ldx, D, (const long *)dr, (long)(runs.size() / 3), p));
-        }
-        if ((rc = c->scratch(WS_GMAP, (size_t)T * sizeof(long), &p))) return rc;
-        dmap = (long *)p;
-        GCHK(hipMemcpyAsync(dmap, map.data(), (size_t)T * sizeof(long), hipMemcpyHostToDevice, c->stream));
-        GCHK(hipStreamSynchronize(c->stream)); // runs is a stack-lifetime vector
-        return GMMIV_OK;
-    }
-    // rows of a per-frame INPUT array (W elements of `bytes` bytes each) for the usable frames, compacted into scratch `slot`
-    int compact_rows(gmmiv_ctx *c, int slot, const void *src_dev, int W, int bytes, const void **out) const
-    {
-        void *p;
-        int rc = c->scratch(slot, (size_t)(Tg ? Tg : 1) * W * bytes, &p);
-        if (rc) return rc;
-        *out = p;
-        if (Tg == 0) return GMMIV_OK;
-        std::vector<int64_t> runs;
-        for (int64_t t = 0; t < T;) {
-            if (map[t] < 0) { ++t; continue; }
-            int64_t e = t;
-            while (e < T && map[e] >= 0 && e - t < 64) ++e;
-            runs.push_back(t); runs.push_back(map[t]); runs.push_back(e - t);
-            t = e;
-        }
-        void *dr;
-        if ((rc = c->scratch(WS_G6, runs.size() * sizeof(int64_t), &dr))) return rc;
-        GCHK(hipMemcpyAsync(dr, runs.data(), runs.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        // rows of W elements of 4 or 8 bytes move like feature rows of that type
-        GCHK(gmmk_gather_runs(c->stream, bytes == 8, src_dev, W, W, (const long *)dr, (long)(runs.size() / 3), p));
-        GCHK(hipStreamSynchronize(c->stream));
-        return GMMIV_OK;
-    }
-};
+// Kind (1) frames are not removed from a call: every kernel reads such a value as GMMIV_UNUSABLE_READ_AS (devutil.h, feat_sane), which makes the
+// frame a zero-likelihood frame on the device.  What is left for the host side is the COUNT ("screened_frames"): one pass over x that
+// flags the frames and adds their number to a device counter -- enqueued, never read back here (option "assume_finite" 1 skips it;
+// results do not depend on it).
+static int count_unusable(gmmiv_ctx *c, const XView &xv, int dt, int64_t T, int D)
+{
+    if (c->assume_finite || T <= 0) return GMMIV_OK;
+    void *p;
+    int rc;
+    const size_t fbytes = ((size_t)T + 15) / 16 * 16;
+    if ((rc = c->scratch(WS_GFLAG, fbytes + 16, &p))) return rc;
+    unsigned char *flag = (unsigned char *)p;
+    GCHK(hipMemsetAsync(flag, 0, fbytes + 16, c->stream));
+    GCHK(gmmk_flag_frames(c->stream, dt == GMMIV_F64, xv.d, T, xv.ldx, D, flag, (int *)(flag + fbytes)));
+    GCHK(gmmk_count_flags(c->stream, flag, (long)T, c->d_screened));
+    return GMMIV_OK;
+}
 
 static int check_model(gmmiv_ctx *c, const gmmiv_gmm *g)
 {
@@ -573,25 +512,7 @@ int gmmiv_llk(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
     if (T < 0) { gmmiv_set_error("llk: T < 0"); return GMMIV_ERR_ARG; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    Screen sc;
-    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
-    if (sc.active()) { // unusable frames: the call on the usable ones, llk = min_llk (the clamp of log 0) for the others
-        void *tmp, *full, *part;
-        if ((rc = c->scratch(WS_G0, (size_t)(sc.Tg ? sc.Tg : 1) * sizeof(double), &tmp))) return rc;
-        { AssumeFinite af(c); if ((rc = gmmiv_llk(c, g, sc.xg, dt, sc.Tg, g->D, min_llk, max_llk, (double *)tmp, nullptr))) return rc; }
-        DevOut<double> o_llk, o_sum;
-        if ((rc = c->scratch(WS_G1, (size_t)T * sizeof(double), &full))) return rc;
-        if ((rc = o_llk.init(c, WS_T0, llk_out ? llk_out : (double *)full, (size_t)T, false))) return rc;
-        if ((rc = o_sum.init(c, WS_T1, sums, 2, true))) return rc;
-        GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)tmp, o_llk.d, min_llk));
-        if (sums) {
-            if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &part))) return rc;
-            GCHK(gmmk_llk_finalize(c->stream, o_llk.d, T, min_llk, max_llk, nullptr, (double *)part, 1.0, 0.0, o_sum.d, nullptr));
-            GCHK(gmmk_add_scalar(c->stream, o_sum.d + 1, (double)T));
-        }
-        if (llk_out && (rc = o_llk.finish())) return rc;
-        return o_sum.finish();
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
     double *lse;
     if ((rc = run_lse(c, g, xv, dt, T, &lse))) return rc;
     DevOut<double> o_llk, o_sum;
@@ -625,52 +546,7 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
     //  the end of this function: mixtureDistribCount / vectSize / topDistribsCount are free keys of the reference, ComputeTest.cpp:129-215)
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    Screen sc;
-    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
-    if (sc.active()) {
-        // unusable frames are zero-likelihood frames: the lowest ctop indices (the tie rule on equal -- zero -- likelihoods), lk 0,
-        // remainder 0 / -inf, nontop_w = 1 - the weights of those indices, llk = min_llk; the usable frames as usual
-        const size_t n = (size_t)(sc.Tg ? sc.Tg : 1);
-        void *t_idx, *t_lk = nullptr, *t_nlk = nullptr, *t_nllk = nullptr, *t_nw = nullptr, *t_llk = nullptr;
-        if ((rc = c->scratch(WS_G0, n * ctop * sizeof(int32_t), &t_idx))) return rc;
-        if (lk && (rc = c->scratch(WS_G1, n * ctop * sizeof(double), &t_lk))) return rc;
-        if (nontop_lk && (rc = c->scratch(WS_G2, n * sizeof(double), &t_nlk))) return rc;
-        if (nontop_llk && (rc = c->scratch(WS_G3, n * sizeof(double), &t_nllk))) return rc;
-        if (nontop_w && (rc = c->scratch(WS_G4, n * sizeof(double), &t_nw))) return rc;
-        if (llk_out && (rc = c->scratch(WS_G5, n * sizeof(double), &t_llk))) return rc;
-        {
-            AssumeFinite af(c);
-            if ((rc = gmmiv_llk_determine_top(c, g, sc.xg, dt, sc.Tg, g->D, ctop, mode, min_llk, max_llk, (int32_t *)t_idx, (double *)t_lk,
-                                              (double *)t_nlk, (double *)t_nllk, (double *)t_nw, (double *)t_llk))) return rc;
-        }
-        double snsw = 1.0;
-        if (nontop_w) {
-            std::vector<double> hw((size_t)ctop);
-            GCHK(hipMemcpyAsync(hw.data(), g->w, (size_t)ctop * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            GCHK(hipStreamSynchronize(c->stream));
-            for (int k = 0; k < ctop; ++k) snsw -= hw[k];
-        }
-        DevOut<int32_t> o_idx;
-        DevOut<double> o_lk, o_nlk, o_nllk, o_nw, o_llk;
-        if ((rc = o_idx.init(c, WS_T0, idx, (size_t)T * ctop, false))) return rc;
-        if ((rc = o_lk.init(c, WS_T1, lk, (size_t)T * ctop, false))) return rc;
-        if ((rc = o_nlk.init(c, WS_T2, nontop_lk, (size_t)T, false))) return rc;
-        if ((rc = o_nllk.init(c, WS_T3, nontop_llk, (size_t)T, false))) return rc;
-        if ((rc = o_nw.init(c, WS_T4, nontop_w, (size_t)T, false))) return rc;
-        if ((rc = o_llk.init(c, WS_T5, llk_out, (size_t)T, false))) return rc;
-        GCHK(gmmk_expand_rows_i32(c->stream, T, ctop, sc.dmap, (const int *)t_idx, o_idx.d, 0, 1));
-        if (lk) GCHK(gmmk_expand_rows_f64(c->stream, T, ctop, sc.dmap, (const double *)t_lk, o_lk.d, 0.0));
-        if (nontop_lk) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_nlk, o_nlk.d, 0.0));
-        if (nontop_llk) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_nllk, o_nllk.d, -INFINITY));
-        if (nontop_w) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_nw, o_nw.d, snsw));
-        if (llk_out) GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)t_llk, o_llk.d, min_llk));
-        if ((rc = o_idx.finish())) return rc;
-        if ((rc = o_lk.finish())) return rc;
-        if ((rc = o_nlk.finish())) return rc;
-        if ((rc = o_nllk.finish())) return rc;
-        if ((rc = o_nw.finish())) return rc;
-        return o_llk.finish();
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
     DevOut<int32_t> o_idx;
     DevOut<double> o_lk, o_nlk, o_nllk, o_nw, o_llk;
     if ((rc = o_idx.init(c, WS_T0, idx, (size_t)T * ctop, false))) return rc;
@@ -935,18 +811,7 @@ int gmmiv_llk_use_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, i
     if ((rc = i_idx.init(c, WS_T0, idx, (size_t)T * ctop))) return rc;
     if ((rc = i_n.init(c, WS_T1, nontop_llk, (size_t)T))) return rc;
     if ((rc = o_llk.init(c, WS_T2, llk_out, (size_t)T, false))) return rc;
-    Screen sc;
-    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
-    if (sc.active()) { // unusable frames: llk = min_llk; the others on their own rows of idx / nontop_llk
-        const void *cidx, *cn = nullptr;
-        void *tmp;
-        if ((rc = sc.compact_rows(c, WS_G0, i_idx.d, ctop, 4, &cidx))) return rc;
-        if (i_n.d && (rc = sc.compact_rows(c, WS_G1, i_n.d, 1, 8, &cn))) return rc;
-        if ((rc = c->scratch(WS_G2, (size_t)(sc.Tg ? sc.Tg : 1) * sizeof(double), &tmp))) return rc;
-        { AssumeFinite af(c); if ((rc = gmmiv_llk_use_top(c, g, sc.xg, dt, sc.Tg, g->D, ctop, (const int32_t *)cidx, (const double *)cn, mode, min_llk, max_llk, (double *)tmp))) return rc; }
-        GCHK(gmmk_expand_rows_f64(c->stream, T, 1, sc.dmap, (const double *)tmp, o_llk.d, min_llk));
-        return o_llk.finish();
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
     c->t_begin("k_topc_use");
     // four lanes per candidate, one frame per wave ("topc_use_lanes" 1: one lane per candidate, four frames per wave) when the
     // selection has at most 16 entries (topc_z.hip); else one wave per frame
@@ -1002,15 +867,7 @@ int gmmiv_llk_use_top_multi(gmmiv_ctx *c, int n_clients, const gmmiv_gmm *const 
     GBIND(c);
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g0->D))) return rc;
-    {
-        Screen sc;
-        if ((rc = sc.init(c, xv, dt, T, g0->D))) return rc;
-        if (sc.active()) { // unusable frames present: client by client through gmmiv_llk_use_top (which applies the rule)
-            for (int i = 0; i < n_clients; ++i)
-                if ((rc = gmmiv_llk_use_top(c, clients[i], x, dt, T, ldx, ctop, idx, nontop_llk, mode, min_llk, max_llk, llk_out + (size_t)i * T))) return rc;
-            return GMMIV_OK;
-        }
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g0->D))) return rc;
     DevIn<int32_t> i_idx;
     DevIn<double> i_n;
     DevOut<double> o_llk;
@@ -1041,15 +898,7 @@ int gmmiv_occ(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int64_t T
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
     DevOut<double> o;
     if ((rc = o.init(c, WS_T0, gamma, (size_t)T * g->C, false))) return rc;
-    Screen sc;
-    if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
-    if (sc.active()) { // unusable frames: a row of zeros
-        void *tmp;
-        if ((rc = c->scratch(WS_G0, (size_t)(sc.Tg ? sc.Tg : 1) * g->C * sizeof(double), &tmp))) return rc;
-        { AssumeFinite af(c); if ((rc = gmmiv_occ(c, g, sc.xg, dt, sc.Tg, g->D, (double *)tmp))) return rc; }
-        GCHK(gmmk_expand_rows_f64(c->stream, T, g->C, sc.dmap, (const double *)tmp, o.d, 0.0));
-        return o.finish();
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
     // Fast path: logits on the matrix cores (k_llk_mfma<WZ>), posteriors = the stored scaled likelihoods rescaled and transposed
     const int64_t Tcz = c->topc_z ? z_chunk_frames(c, g) : 0;
     if (Tcz > 0 && T > 0) {
@@ -1089,14 +938,11 @@ size_t gmmiv_em_acc_len(int C, int D) { return (size_t)C * (1 + 2 * (size_t)D) +
 // frame segments [0,T) -> nseg pieces aligned to the 64-frame tile; device array in WS_SEG
 static int make_chunks(gmmiv_ctx *c, int64_t T, int nseg, long **dev)
 {
-    std::vector<long> h(nseg + 1);
     const int64_t per = ((T + nseg - 1) / nseg + 63) / 64 * 64;
-    for (int i = 0; i <= nseg; ++i) { int64_t b = (int64_t)i * per; h[i] = (long)(b < T ? b : T); }
     void *buf;
     int rc = c->scratch(WS_SEG, (nseg + 1) * sizeof(long), &buf);
     if (rc) return rc;
-    GCHK(hipMemcpyAsync(buf, h.data(), (nseg + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
-    GCHK(hipStreamSynchronize(c->stream)); // h is a stack-lifetime vector
+    GCHK(gmmk_fill_chunks(c->stream, (long *)buf, nseg, (long)per, (long)T)); // seg[i] = min(i per, T), on the device: nothing to wait for
     *dev = (long *)buf;
     return GMMIV_OK;
 }
@@ -1175,18 +1021,15 @@ static int em_stats_z(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt,
     if (nseg > cap) nseg = (int)((cap + 7) / 8 * 8);
     const int64_t nchunk = (T + Tc - 1) / Tc;
     // segment bounds relative to the chunk start: one table for full chunks, one for the last chunk
-    std::vector<long> h(2 * (nseg + 1));
-    auto fill = [&](long *dst, int64_t n) {
-        const int64_t per = ((n + nseg - 1) / nseg + 63) / 64 * 64;
-        for (int i = 0; i <= nseg; ++i) { int64_t b = (int64_t)i * per; dst[i] = (long)(b < n ? b : n); }
-    };
     const int64_t lastn = T - (nchunk - 1) * Tc;
-    fill(h.data(), first);
-    fill(h.data() + nseg + 1, lastn);
     void *seg, *zb, *part, *eit, *inv;
-    if ((rc = c->scratch(WS_SEG, h.size() * sizeof(long), &seg))) return rc;
-    GCHK(hipMemcpyAsync(seg, h.data(), h.size() * sizeof(long), hipMemcpyHostToDevice, c->stream));
-    GCHK(hipStreamSynchronize(c->stream));
+    if ((rc = c->scratch(WS_SEG, 2 * (size_t)(nseg + 1) * sizeof(long), &seg))) return rc;
+    auto fill = [&](long *dst, int64_t n) { // dst[i] = min(i per, n): written on the device, the call does not wait for the stream
+        const int64_t per = ((n + nseg - 1) / nseg + 63) / 64 * 64;
+        return gmmk_fill_chunks(c->stream, dst, nseg, (long)per, (long)n);
+    };
+    GCHK(fill((long *)seg, first));
+    GCHK(fill((long *)seg + nseg + 1, lastn));
     const long nfb = c->dbg & 64 ? 16 * ((first + 255) / 256) : z_tile_blocks(first);
     if ((rc = c->scratch(WS_Z, (size_t)g->nct * nfb * 2048, &zb))) return rc;
     if ((rc = c->scratch(WS_EIT, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit))) return rc;
@@ -1225,15 +1068,7 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     if (T == 0) return o.finish();
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    {
-        Screen sc;
-        if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
-        if (sc.active()) { // unusable frames add nothing, anywhere (no occupancy, no statistics, no log-likelihood, no frame count)
-            AssumeFinite af(c);
-            if ((rc = gmmiv_em_accumulate(c, g, sc.xg, dt, sc.Tg, g->D, weight, o.d))) return rc;
-            return o.finish();
-        }
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
     if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
         // single-pass path: teams of (nct/8) workgroups, one team per contiguous frame range
         const int ngrp = (g->nct + 7) / 8;
@@ -1396,18 +1231,7 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     if (U > 0x7fffffff / 64) { gmmiv_set_error("tv_stats: too many utterances in one call"); return GMMIV_ERR_UNSUPPORTED; }
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
-    {
-        Screen sc;
-        if ((rc = sc.init(c, xv, dt, T, g->D))) return rc;
-        if (sc.active()) { // unusable frames add nothing to N / F: the utterances keep their usable frames
-            std::vector<long> pre((size_t)T + 1, 0);
-            for (int64_t t = 0; t < T; ++t) pre[t + 1] = pre[t] + (sc.map[t] >= 0 ? 1 : 0);
-            std::vector<int64_t> ub((size_t)U + 1);
-            for (int64_t u = 0; u <= U; ++u) ub[u] = pre[utt_begin[u]];
-            AssumeFinite af(c);
-            return gmmiv_tv_stats(c, g, sc.xg, dt, sc.Tg, g->D, ub.data(), U, N, F);
-        }
-    }
+    if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
     std::vector<long> h(utt_begin, utt_begin + U + 1);
     void *seg;
     if ((rc = c->scratch(WS_SEG, (U + 1) * sizeof(long), &seg))) return rc;

@@ -34,8 +34,8 @@ void gmmiv_set_error(const char *fmt, ...);
 
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
        WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_EIT, WS_INV,
-       WS_XG, WS_GFLAG, WS_GMAP, WS_G0, WS_G1, WS_G2, WS_G3, WS_G4, WS_G5, WS_G6,
-       WS_Z2, WS_LSE2, WS_EIT2, WS_INV2, WS_COUNT }; // WS_XG..: the screened (compacted) form of a call with unusable frames
+       WS_GFLAG,
+       WS_Z2, WS_LSE2, WS_EIT2, WS_INV2, WS_COUNT }; // WS_GFLAG: the per-frame flags of the kind-(1) counting pass
 
 struct gmmiv_ctx {
     int device = 0;
@@ -100,13 +100,15 @@ struct gmmiv_ctx {
         }
         if (topc_hflags) { (void)hipHostFree(topc_hflags); topc_hflags = nullptr; topc_hflags_n = 0; }
     }
-    // 1: the caller vouches that every feature value is finite and |x| <= 1e18 -- the screening pass over the features (one read of
-    // x per call) is skipped.  The C++ host layer sets it around its calls once a FeatureBuffer has been checked at upload.
+    // 1: the caller vouches that every feature value is finite and |x| <= 1e18 -- the counting pass over the features (one read of x
+    // per call, enqueued: no synchronisation) is skipped.  RESULTS do not depend on it: every kernel reads an unusable value as
+    // GMMIV_UNUSABLE_READ_AS (devutil.h), which makes its frame a zero-likelihood frame on the device.
     long assume_finite = 0;
-    long screened_frames = 0; // unusable frames the screening has taken out of calls so far (read with set_option)
-    // kind (2) of the same rule: frames whose likelihood under the call's model is 0 in fp64, counted ON THE DEVICE (k_count_dead after the
-    // log-likelihood kernel of gmmiv_llk / _em_accumulate / _tv_stats(_lines) / _occ: no host synchronisation); option "zero_llk_frames" reads it
-    unsigned long long *d_zero_llk = nullptr;
+    // the rule's two counters live ON THE DEVICE (no host synchronisation when they are bumped; options "zero_llk_frames" /
+    // "screened_frames" read them): frames whose likelihood under the call's model is 0 in fp64 (k_count_dead after the log-likelihood
+    // kernel of gmmiv_llk / _em_accumulate / _tv_stats(_lines) / _occ; kind-(1) frames are among them) and frames with an unusable
+    // feature value (k_flag_frames + k_count_flags at the top of every frame-consuming call)
+    unsigned long long *d_zero_llk = nullptr, *d_screened = nullptr;
     long topc_fallbacks = 0; // calls the fused path handed to the slower paths (list overflow / margin check); read with set_option
     long topc_z = 1;     // DETERMINE_TOP_DISTRIBS from the stored MFMA likelihoods (topc_z.hip); 0: the direct-form VALU kernel
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)

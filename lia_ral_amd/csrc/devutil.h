@@ -305,10 +305,31 @@ __device__ __forceinline__ int xswz(int t) { return ((t << 1) ^ ((t & 1) << 4)) 
 // "lane base + compile-time immediate" and costs no VALU address arithmetic.
 __device__ __forceinline__ int xrot(int t) { return ((t & 1) << 4) + (((t >> 1) & 7) << 1); }
 
+// floor(e / D) for e < 2^16 by reciprocal multiplication: magic = 2^32 / D + 1 (host side: gmmiv_div_magic).  vectSize 1 has no
+// 32-bit magic (2^32 + 1 wraps to 1 and every quotient came out 0 -- the statistics of a ONE-dimensional model were garbage until
+// round 6; tests/golden's EnergyDetector case, C = 2, D = 1, found it): magic 0 stands for "divide by one".
+__device__ __forceinline__ int div_by_magic(unsigned e, unsigned magic) { return magic ? (int)__umulhi(e, magic) : (int)e; }
+static inline unsigned gmmiv_div_magic(int D) { return D == 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)D + 1); }
+
+// DEGENERATE INPUTS, kind (1) (include/gmmiv.h): a feature value that is NaN, infinite or beyond 1e18 in magnitude makes its frame a
+// zero-likelihood frame.  Every kernel that reads features reads them through feat_sane: such a value is READ AS 1e10 -- finite, so no
+// 0 x NaN can poison a statistic, and far enough from any mean that every logit of the frame lies near -0.5e20 / variance: the frame
+// then IS a zero-likelihood frame of kind (2) for every kernel, on the device, with no host decision (no flag read back, no
+// compaction, no synchronisation).  Holds for variances in (1e-17, 1e17); 1e10 is exact in float.  Usable values pass unchanged
+// (one compare + select per element loaded; in the MFMA log-likelihood kernel that is once per frame and workgroup, outside its loop).
+#define GMMIV_UNUSABLE_BOUND 1e18
+#define GMMIV_UNUSABLE_READ_AS 1e10
+#ifndef GMMIV_FEAT_SANE_OFF   // (tools/feat_sane_ab.sh builds a second library without the select to price it; never defined in the product build)
+__device__ __forceinline__ float feat_sane(float v) { return __builtin_fabsf(v) <= (float)GMMIV_UNUSABLE_BOUND ? v : (float)GMMIV_UNUSABLE_READ_AS; }
+__device__ __forceinline__ double feat_sane(double v) { return __builtin_fabs(v) <= GMMIV_UNUSABLE_BOUND ? v : GMMIV_UNUSABLE_READ_AS; }
+#else
+__device__ __forceinline__ float feat_sane(float v) { return v; }
+__device__ __forceinline__ double feat_sane(double v) { return v; }
+#endif
 template <typename T> struct feat_load;
 template <> struct feat_load<float> {
-    static __device__ __forceinline__ double get(const void *p, long i) { return (double)((const float *)p)[i]; }
+    static __device__ __forceinline__ double get(const void *p, long i) { return (double)feat_sane(((const float *)p)[i]); }
 };
 template <> struct feat_load<double> {
-    static __device__ __forceinline__ double get(const void *p, long i) { return ((const double *)p)[i]; }
+    static __device__ __forceinline__ double get(const void *p, long i) { return feat_sane(((const double *)p)[i]); }
 };

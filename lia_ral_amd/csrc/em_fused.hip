@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + NT * i;
-        const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
+        const int fr = div_by_magic((unsigned)e, magicD), d = e - fr * D;
         pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
     }
     auto load_tile = [&](int tl) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void k_em_fused(const void *__restrict__ x,
         const long rem = f1 - (f0 + (long)tl * FT);
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = (double)stg[i];
+            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = (double)feat_sane(stg[i]);
         for (int e = tid; e < npad; e += NT) { // pad columns: const 1 at Dp for existing rows, zeros elsewhere
             const int fr = e / (RL - D), d = D + (e - fr * (RL - D));
             dst[fr * RLp + xrot(fr) + d] = (d == Dp && fr < rem) ? 1.0 : 0.0;
@@ -370,7 +370,7 @@ static int launch_fused(hipStream_t st, const void *x, long ldx, int D, int C, c
     if (query_blocks) { *query_blocks = blocks_per_cu; return 0; }
     if (blocks_per_cu < 1 || nteams * ngrp > n_cu * blocks_per_cu) return (int)hipErrorCooperativeLaunchTooLarge;
     const unsigned grid = (unsigned)(8 * ngrp * ((nteams + 7) / 8));
-    const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);
+    const unsigned magicD = gmmiv_div_magic(D);
     k_em_fused<KS, XT, SQ><<<grid, 512, lds, st>>>(x, ldx, D, C, Pt, nct, lse_shift, seg_begin, nseg, nteams, ngrp, mode, out0, out1,
                                                     lse_out, (u64 *)slots,
                                                     (unsigned *)((u64 *)slots + gmmk_em_fused_slot_words(nteams, ngrp) - 2), magicD, dbg);

@@ -56,8 +56,8 @@ int gmmk_segment_means(hipStream_t st, const double *v, long ld, const long *ite
 int gmmk_topgauss_select(hipStream_t st, long T, int cap, double mass, int fixed_count, const double *w, int *idx, const double *lk,
                          const double *llk, int *count, double *snsw, double *snsl, unsigned long long *capped);
 int gmmk_flag_frames(hipStream_t st, int x_f64, const void *x, long T, long ldx, int D, unsigned char *flag, int *any);
-int gmmk_expand_rows_f64(hipStream_t st, long T, int W, const long *map, const double *src, double *dst, double fill);
-int gmmk_expand_rows_i32(hipStream_t st, long T, int W, const long *map, const int *src, int *dst, int fill, int fill_is_column);
+int gmmk_fill_chunks(hipStream_t st, long *dst, int nseg, long per, long n);
+int gmmk_count_flags(hipStream_t st, const unsigned char *flag, long T, unsigned long long *cnt);
 int gmmk_gather_runs(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *runs, long nrun, void *out);
 // em_fused.hip: single-pass EM statistics by teams of cooperating workgroups
 size_t gmmk_em_fused_slot_words(int nteams, int ngrp);

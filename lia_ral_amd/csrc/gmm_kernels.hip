@@ -702,7 +702,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_stats_mfma(const void *__restric
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + NT * i;
-        const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D; // e / D by reciprocal
+        const int fr = div_by_magic((unsigned)e, magicD), d = e - fr * D; // e / D by reciprocal
         pk[i] = fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
         goff[i] = (unsigned)(fr * (int)ldx + d);
     }
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_stats_mfma(const void *__restric
     auto write_tile = [&](double *dst) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = (double)stg[i];
+            if (pk[i] < ((unsigned)FT << 16)) *(double *)((char *)dst + (pk[i] & 0xffffu)) = (double)feat_sane(stg[i]);
         for (int e = tid; e < npad; e += NT) { // pad columns: 1.0 at Dp, zeros elsewhere
             const int fr = e / (RL - D), d = D + (e - fr * (RL - D));
             if (d != Dp + 1) dst[fr * RLp + xrot(fr) + d] = (d == Dp) ? 1.0 : 0.0;
@@ -1516,32 +1516,36 @@ int gmmk_flag_frames(hipStream_t st, int x_f64, const void *x, long T, long ldx,
     return (int)hipGetLastError();
 }
 
-// Results of a call on the usable frames only, back in the caller's frame order: dst[t][0..W) = src[map[t]][0..W) when map[t] >= 0,
-// else the value the rule gives a zero-likelihood frame: `fill`, or the column number (index lists: the lowest Gaussians).
-template <typename V>
-__global__ __launch_bounds__(256) void k_expand_rows(long T, int W, const long *__restrict__ map, const V *__restrict__ src, V *__restrict__ dst,
-                                                     V fill, int fill_is_column)
+// chunk table on the device: dst[i] = min(i * per, n), i = 0 .. nseg -- the frame ranges of the statistics kernels.  Written by a kernel so
+// that a frame-consuming call with device pointers ENQUEUES only (a host table would have to be copied from memory that outlives the call).
+__global__ void k_fill_chunks(long *__restrict__ dst, int nseg, long per, long n)
 {
-    const long n = T * W;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const long t = e / W;
-        const int j = (int)(e - t * W);
-        const long m = map[t];
-        dst[e] = m >= 0 ? src[m * W + j] : (fill_is_column ? (V)j : fill);
-    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nseg) { const long b = (long)i * per; dst[i] = b < n ? b : n; }
 }
-int gmmk_expand_rows_f64(hipStream_t st, long T, int W, const long *map, const double *src, double *dst, double fill)
+int gmmk_fill_chunks(hipStream_t st, long *dst, int nseg, long per, long n)
 {
-    if (T <= 0 || W <= 0) return 0;
-    const long n = T * W;
-    k_expand_rows<double><<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, st>>>(T, W, map, src, dst, fill, 0);
+    k_fill_chunks<<<(unsigned)(nseg + 1 + 255) / 256, 256, 0, st>>>(dst, nseg, per, n);
     return (int)hipGetLastError();
 }
-int gmmk_expand_rows_i32(hipStream_t st, long T, int W, const long *map, const int *src, int *dst, int fill, int fill_is_column)
+
+// number of flagged frames added to a device counter (the "screened_frames" option): one atomic per workgroup that saw one
+__global__ __launch_bounds__(256) void k_count_flags(const unsigned char *__restrict__ flag, long T, unsigned long long *__restrict__ cnt)
 {
-    if (T <= 0 || W <= 0) return 0;
-    const long n = T * W;
-    k_expand_rows<int><<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, st>>>(T, W, map, src, dst, fill, fill_is_column);
+    __shared__ unsigned int s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    unsigned int n = 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) n += flag[t] ? 1u : 0u;
+    if (n) atomicAdd(&s, n);
+    __syncthreads();
+    if (threadIdx.x == 0 && s) atomicAdd(cnt, (unsigned long long)s);
+}
+int gmmk_count_flags(hipStream_t st, const unsigned char *flag, long T, unsigned long long *cnt)
+{
+    if (T <= 0) return 0;
+    const unsigned blocks = (unsigned)((T + 255) / 256 > 1024 ? 1024 : (T + 255) / 256);
+    k_count_flags<<<blocks, 256, 0, st>>>(flag, T, cnt);
     return (int)hipGetLastError();
 }
 
@@ -1561,7 +1565,7 @@ static int launch_stats_p(hipStream_t st, const void *x, long ldx, int D, int C,
     HIPCHK((gmmiv_lds_attr<k_stats_mfma<KS, SQ, XT, NW, PRUNE>>(lds))); // per (device, kernel): lds_attr.h
     const int ngrp = (nct + NW - 1) / NW;
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
-    const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1); // floor(e/D) == umulhi(e, magicD) for e < 2^16
+    const unsigned magicD = gmmiv_div_magic(D); // floor(e/D) == umulhi(e, magicD) for e < 2^16
     k_stats_mfma<KS, SQ, XT, NW, PRUNE><<<grid, NW * 64, lds, st>>>(x, ldx, D, C, Pt, nct, lse, lse_shift, seg_begin, nseg, ngrp,
                                                      out0, out1, mode, magicD, prune_arg);
     return (int)hipGetLastError();

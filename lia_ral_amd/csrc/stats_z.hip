@@ -105,12 +105,12 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
     const bool contig = (ldx == D);
     auto plan_pk = [&](int i) -> unsigned {
         const int e = tid + NT * i;
-        const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
+        const int fr = div_by_magic((unsigned)e, magicD), d = e - fr * D;
         return fr < FT ? ((unsigned)fr << 16) | (unsigned)((fr * RLp + xrot(fr) + d) * 8) : 0xffff0000u;
     };
     auto plan_goff = [&](int i) -> unsigned {
         const int e = tid + NT * i;
-        const int fr = (int)__umulhi((unsigned)e, magicD), d = e - fr * D;
+        const int fr = div_by_magic((unsigned)e, magicD), d = e - fr * D;
         return fr < FT ? (contig ? (unsigned)e : (unsigned)(fr * (int)ldx + d)) : 0u;
     };
     unsigned pk_r[PLAN_IN_REGS ? NLD : 1], goff_r[PLAN_IN_REGS ? NLD : 1];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NW * 64, (TPW == 1 ? 4 : 2)) void k_stats_z(const v
         for (int i = 0; i < NLD; ++i)
         {
             const unsigned pki = PK(i);
-            if (pki < ((unsigned)FT << 16)) *(double *)((char *)dst + (pki & 0xffffu)) = pki < lim ? (double)stg[i] : 0.0;
+            if (pki < ((unsigned)FT << 16)) *(double *)((char *)dst + (pki & 0xffffu)) = pki < lim ? (double)feat_sane(stg[i]) : 0.0;
         }
         if (lane < FT) { // rows outside [f0, f1) get f = 0 -> posterior 0
             const long t = fb + lane;
@@ -331,7 +331,7 @@ static int launch_z(hipStream_t st, const void *x, long ldx, int D, int C, int n
     HIPCHK((gmmiv_lds_attr<k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT, ZD>>(lds))); // per (device, kernel): lds_attr.h
     const int ngrp = (nct + TPW * NW - 1) / (TPW * NW);
     const unsigned grid = (unsigned)(ngrp * 8 * ((nseg + 7) / 8));
-    const unsigned magicD = (unsigned)((1ULL << 32) / (unsigned)D + 1);
+    const unsigned magicD = gmmiv_div_magic(D);
     k_stats_z<KS, SQ, XT, PRUNE, NW, TPW, FT, ZD><<<grid, NW * 64, lds, st>>>(x, ldx, D, C, nct, zbuf, nfb, eit, inv, efin, scale, seg_begin, nseg, ngrp,
                                                               out0, out1, mode, accum, magicD, prune_thr);
     return (int)hipGetLastError();

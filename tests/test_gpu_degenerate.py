@@ -351,3 +351,49 @@ def test_generic_paths_follow_the_same_rule():
     do = orc.llk_determine_top(orc.Gmm(w6, m6, iv6), x6[keep].astype(np.float64), 70, True)
     assert np.array_equal(d["idx"][keep], do["idx"]) and d["idx"][10].tolist() == list(range(70)) and d["llk"][10] == -200.0
     g6.close(); ctx.close()
+
+
+def test_calls_on_device_pointers_only_enqueue_with_the_screening_on():
+    """include/gmmiv.h, DEGENERATE INPUTS: unusable frames are handled inside the kernels and only COUNTED by the screening pass, on the
+    device -- so a frame-consuming call whose arrays are all device pointers returns before the stream has drained, with `assume_finite`
+    at its default 0 and unusable frames in the call.  The stream is kept busy by a one-second spin kernel enqueued first: the calls
+    behind it must come back at once (they waited for the stream once per call in rounds 1-5), and their results -- read after the
+    synchronisation -- follow the rule."""
+    import ctypes as ct
+    import time
+    import torch
+    from lia_ral_amd import capi
+    w, mean, iv, x, zero, good = _case()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx = capi.Context(0, s.cuda_stream)
+        assert ctx.set_option("assume_finite", 0) == 0
+        g = ctx.gmm(w, mean, iv)
+        xd = torch.from_numpy(x).cuda()
+        acc = torch.zeros(g.em_acc_len(), dtype=torch.float64, device="cuda")
+        llk = torch.empty(T, dtype=torch.float64, device="cuda"); sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        gam = torch.empty((T, C), dtype=torch.float64, device="cuda")
+        g.em_accumulate(xd, acc=acc); g.llk(xd, out=llk, sums=sums); capi._chk(capi.lib.gmmiv_occ(ctx._h, g._h, capi._ptr(xd), capi.F32, ct.c_int64(T), ct.c_int64(D), capi._ptr(gam)))
+        torch.cuda.synchronize()                                  # warm-up: the workspaces exist now (hipMalloc synchronises)
+        acc.zero_(); sums.zero_()
+        ctx.set_option("screened_frames", 0); ctx.set_option("zero_llk_frames", 0)
+        torch.cuda._sleep(int(2.0e9))                             # ~1 s of spinning at ~2 GHz, on this stream
+        t0 = time.perf_counter()
+        g.em_accumulate(xd, acc=acc)
+        g.llk(xd, out=llk, sums=sums)
+        capi._chk(capi.lib.gmmiv_occ(ctx._h, g._h, capi._ptr(xd), capi.F32, ct.c_int64(T), ct.c_int64(D), capi._ptr(gam)))
+        dt = time.perf_counter() - t0
+        still_busy = not s.query()
+        torch.cuda.synchronize()
+        assert still_busy and dt < 0.25, (still_busy, dt)         # three calls enqueued while the spin kernel was still running
+        a = g.split_acc(acc.cpu().numpy())
+        ref = orc.em_accumulate(orc.Gmm(w, mean, iv), x[good].astype(np.float64))
+        rel = lambda p, q: np.max(np.abs(p - q)) / np.max(np.abs(q))
+        assert a["count"] == len(good) and rel(a["occ"], ref["occ"]) < 1e-9 and rel(a["sx"], ref["sx"]) < 1e-9 and rel(a["sxx"], ref["sxx"]) < 1e-9
+        l = llk.cpu().numpy()
+        assert np.all(l[zero] == -200.0) and sums.cpu().numpy()[1] == T
+        o = gam.cpu().numpy()
+        assert np.all(o[zero] == 0.0) and np.max(np.abs(o[good].sum(1) - 1.0)) < 1e-9
+        assert ctx.set_option("screened_frames", 0) == 3 * len(BAD)          # counted by each of the three calls, on the device
+        assert ctx.set_option("zero_llk_frames", 0) == 3 * len(zero)         # kind (1) frames are evaluated as kind (2) frames: counted here too
+        g.close(); ctx.close()

@@ -29,7 +29,10 @@ def relerr(a, b):
 
 
 CASES = [(8, 60, 1), (8, 60, 64), (128, 60, 1000), (2048, 60, 300), (37, 13, 257), (1024, 32, 50), (300, 75, 130),
-         (256, 128, 203), (40, 97, 66)]      # vectSize > 80: no MFMA instantiation, the generic paths (VALU logits, statistics on the fp64 GEMM)
+         (256, 128, 203), (40, 97, 66),      # vectSize > 80: no MFMA instantiation, the generic paths (VALU logits, statistics on the fp64 GEMM)
+         # the smallest shapes (round 6: EnergyDetector's model is 2 Gaussians x ONE dimension -- every statistic of a vectSize-1 model was
+         # garbage, the frame-staging plan divided by vectSize with a reciprocal that does not exist for 1): vectSize 1 / 2 / 3, 1 - 3 Gaussians
+         (2, 1, 26), (1, 1, 10), (3, 1, 50), (16, 1, 1000), (2, 2, 26), (1, 3, 10), (5, 2, 33), (2048, 1, 300)]
 
 
 @pytest.mark.parametrize("C,D,T", CASES)
@@ -85,6 +88,7 @@ def test_llk_clamp_and_device_pointers(ctx):
 
 
 @pytest.mark.parametrize("C,D,T,ctop", [(128, 60, 1000, 10), (2048, 60, 64, 10), (1024, 32, 50, 10), (8, 60, 33, 20), (300, 13, 100, 5),
+                                        (2, 1, 26, 2), (2, 1, 26, 1), (1, 1, 9, 1), (16, 1, 100, 5), (3, 2, 40, 3),
                                         # shapes the LDS / MFMA selection kernels do not serve (round-4 verdict: free keys of the reference):
                                         (256, 128, 70, 10), (8192, 60, 41, 10), (512, 60, 37, 100), (8192, 60, 13, 100), (200, 128, 21, 70)])
 @pytest.mark.parametrize("complete", [True, False])
@@ -326,7 +330,8 @@ def test_em_zero_frames_and_ragged_edges(ctx):
 
 
 @pytest.mark.parametrize("C,D", [(128, 60), (2048, 60), (37, 13), (32, 20), (96, 60),   # 8, 128, 4 (padded), 2 and 6 Gaussian tiles: both wave shapes
-                                 (96, 128), (33, 101)])                                    # vectSize > 80: the generic path (gamma^T [x | 1] per utterance)
+                                 (96, 128), (33, 101),                                     # vectSize > 80: the generic path (gamma^T [x | 1] per utterance)
+                                 (2, 1), (1, 1), (16, 1), (2, 2), (3, 3)])                 # the smallest models (vectSize 1: see CASES)
 def test_tv_stats_match_oracle(ctx, C, D):
     w, mean, iv = make_gmm(C, D, seed=C + 7)
     lens = [70, 0, 131, 64, 1]
