@@ -685,3 +685,19 @@ def test_fused_top_c_pipelined_sub_chunks_are_bitwise_the_serial_form(ctx):
     assert np.array_equal(out[1]["idx"][rows], do["idx"])
     assert np.max(np.abs(out[1]["llk"][rows] - do["llk"])) < 1e-9 and relerr(out[1]["lk"][rows], do["lk"]) < 1e-10
     g.close()
+
+
+def test_default_paths_are_bitwise_the_round_5_results(golden_dir):
+    """tests/golden/r05_bitwise.json holds SHA-256 digests of 83 result arrays (EM statistics, log-likelihoods, top-10 / top-20 lists,
+    posteriors, N / F, TETt, i-vectors, the T-matrix accumulators, updateTestimate, minDivergence, two scoring rules; three model shapes)
+    computed by the ROUND-5 library on an MI355X (tools/bitwise_fixture.py).  Round 6 took the measured-slower kernel variants out of
+    libgmmiv.so, moved the handling of unusable feature values into the kernels and the chunk tables onto the device: none of it may
+    move one bit of a default path on clean data."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bitwise_fixture as bf
+    ref = json.load(open(os.path.join(golden_dir, "r05_bitwise.json")))["arrays"]
+    got = bf.digests(bf.compute())
+    bad = [k for k in ref if got.get(k) != ref[k]]
+    assert len(ref) == 83 and not bad, bad
