@@ -46,7 +46,7 @@ FLOP_PER_PAIR_LLK = 240.0     # logit of one frame-Gaussian pair, 2
 FLOP_PER_PAIR_ACC = 242.0     # statistics of one pair: 2 flop x (1 + D + D)
 FLOP_PER_PAIR_STATS = 480.0   # the recomputing k_stats_mfma (stats_z = 0): logits again + statistics
 KERNEL_FLOP = {"k_llk_mfma": FLOP_PER_PAIR_LLK, "k_stats_z": FLOP_PER_PAIR_ACC, "k_stats_mfma": FLOP_PER_PAIR_STATS,
-               "k_em_fused": FLOP_PER_PAIR_LLK + FLOP_PER_PAIR_ACC}
+               }
 PEAK_F64_TFLOPS = 78.6        # MI355X fp64 matrix = vector peak (AMD datasheet; measured ceiling in DESIGN.md)
 
 
@@ -226,19 +226,6 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=10_000, frames=30
     sl = [run(S) for _ in range(NRUN)]
     slice_default = {"utterances": S, "ms": float(np.mean(sl)) * 1e3, "i-vectors/s": S / float(np.mean(sl)), "stats_ms": times["stats_ms"], "solve_ms": times["solve_ms"]}
     W_slice = W[:S].clone()
-    fused = {}
-    try:     # the same statistics through the single-pass cooperative kernel (opt-in, em_fused.hip)
-        ctx.set_option("em_fused", 1)
-        N2 = torch.empty((S, C), dtype=torch.float64, device=dev); F2 = torch.empty((S, C * D), dtype=torch.float64, device=dev)
-        g.tv_stats(x[:S * frames], ub[:S + 1], N2, F2); torch.cuda.synchronize()
-        t0 = time.perf_counter(); g.tv_stats(x[:S * frames], ub[:S + 1], N2, F2); torch.cuda.synchronize()
-        fused["stats_ms"] = (time.perf_counter() - t0) * 1e3
-        ctx.tv_subtract_m(N2, F2, means, C, D)
-        fused["max_rel_diff_F"] = float(((F2 - F[:S]).abs().max() / F[:S].abs().max()).item())
-        fused["i-vectors/s"] = S / (fused["stats_ms"] * 1e-3 + slice_default["solve_ms"] * 1e-3)
-        del N2, F2
-    finally:
-        ctx.set_option("em_fused", 0)
     # OPT-IN (not the default, not `value`): the N / F statistics with posteriors below 2^-100 skipped in groups (option "prune_log2":
     # at most 2^-100 of posterior mass per pair is dropped -- 1e-30 absolute on N / F, invisible in L, aux and the i-vector, but a
     # Gaussian whose whole occupancy is that small gets different statistics than the reference's sum of denormal-scale terms)
@@ -280,7 +267,7 @@ def ivector_secondary(ctx, g, w, mean, iv, dev, rank, world, U=10_000, frames=30
             "solve_ms": solve_ms, "timed_runs_ms": [r * 1e3 for r in runs], "timing": "mean of %d runs after two warm-ups" % NRUN,
             "hbm_resident_gb": {"features_f32": T * D * 4 / 1e9, "F": U * C * D * 8 / 1e9, "N": U * C * 8 / 1e9, "tett_packed": C * P * 8 / 1e9},
             "screening": screened, "finite": finite, "parity": parity, "roofline": roof,
-            "slice_ab": {"default": slice_default, "pruned_posteriors": pruned, "fused_stats": fused},
+            "slice_ab": {"default": slice_default, "pruned_posteriors": pruned},
             "_W": W[:S].clone(), "_Tm": Tm, "_x_slice": x[:S * frames].clone(), "_slice": S}
 
 
@@ -937,7 +924,6 @@ def main():
     ap.add_argument("--no-host-layer", action="store_true", help="skip the host_layer block (the C++ host layer timed on the same workloads)")
     ap.add_argument("--mean-spread", type=float, default=2.0,
                     help="std of the synthetic UBM means (SURVEY 8(d): 2.0; smaller = overlapping Gaussians)")
-    ap.add_argument("--em-fused", type=int, default=-1, help="A/B knob: 1 = single-pass cooperative EM kernel, 0 = two-kernel path")
     ap.add_argument("--wg-waves", type=int, default=0, help="A/B knob: waves per workgroup of the MFMA kernels (4 or 8)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="T-matrix EM: 1 = the reduce-scatter of A starts inside the E-step (under the Cmx GEMM), the all-gather of T is joined "
@@ -995,8 +981,6 @@ def main():
     ctx.set_option("timing", 1)
     if args.wg_waves:
         ctx.set_option("wg_waves", args.wg_waves)
-    if args.em_fused >= 0:
-        ctx.set_option("em_fused", args.em_fused)
     g = ctx.gmm(w, mean, iv)
     force = bool(args.force_collectives and world == 1)
     if force:

@@ -67,7 +67,6 @@ const char *gmmiv_version(void);
  *   "z_waves" 8        workgroup shape of k_stats_z (8, 16 or 4 waves)
  *   "z_depth_tv" 4     register sets of k_stats_z's likelihood stream (prefetch distance + 1; 2 or 4) in the N / F mode,
  *   "z_depth_em" 2     and in the EM mode; bit-identical results
- *   "em_fused" 0       1: single-pass cooperative kernel (em_fused.hip), falls back when the grid is not resident
  *   "prune_log2" 0     n > 0: skip groups of posteriors that are all below 2^-n (NOT the reference's arithmetic
  *                      for dead Gaussians; off by default)
  *   "tv_stats_split" 1 gmmiv_tv_stats on at most 16 utterances: every utterance in pieces of whole 64-frame tiles (more workgroups for the
@@ -90,18 +89,6 @@ const char *gmmiv_version(void);
  *   "gemm_nt80" 1      split-K NT products whose N is a multiple of 80 but not of 128 (aux = F (T Sigma^-1)^T at rank 400) on 128 x 80
  *                      tiles instead of 128 x 128 tiles + a 16-column strip; 0: the latter (A/B switch)
  *   "chol_lds" 1       chol_fused.hip stages the panel rows once per workgroup in LDS; 0: every wave fetches them itself (A/B switch)
- *   "k1_pc" 0          1: the log-likelihood pass as a producer / consumer pipeline (llk_pc.hip: four MFMA waves hand their logit tiles
- *                      through LDS to four exponential waves; D <= 60, calls of more than 32 768 frames).  Bitwise the default kernel's
- *                      results; MEASURED SLOWER (0.59 against 0.74 of the fp64 peak: on gfx950 an f64 MFMA occupies the vector ALUs, VALU
- *                      work of another wave does not overlap with a saturated matrix pipe -- profiles/r05/k1_pc_ablation.txt); kept as the
- *                      record of that experiment
- *   "tv_overlap" 0     gmmiv_tv_stats over several chunks: 1 = the log-likelihood kernel of chunk k + 1 runs on the context's stream beside
- *                      the N / F statistics kernel of chunk k on a side stream (two likelihood scratch sets); 2 = additionally the
- *                      statistics kernel in its 4-wave / 51 KB shape, so that a CU holds a workgroup of each.  Bitwise the serial
- *                      results; MEASURED SLOWER (104 -> 105 / 111 ms per 2560 utterances x 3000 frames, profiles/r05/tv_overlap_ab.txt):
- *                      both kernels want the matrix pipe, interleaving them costs more than the stalls it fills.  An A/B record.
- *   "chol_uut64" 0     1: E = U U^T + w w^T of the T-matrix E-step with 64-column panels, the k range staged in two LDS halves (k_uut64);
- *                      same results to 3e-15, measured slower (1.59 vs 1.09 ms per 1024 systems of order 400): an A/B record
  *   "chol_flow" 1      batched Cholesky k_chol_left2 (panel staged first, diagonal update from LDS on all waves); 0: round 2's k_chol_left
  *   "kopts_bound"      read-only: 1 when this context's kernel-launcher options are the set bound to the calling thread (they are
  *                      bound by each call of the context on entry)
@@ -111,8 +98,6 @@ const char *gmmiv_version(void);
  *   "topc_fused" 1     DETERMINE_TOP_DISTRIBS with the candidates collected in the epilogue of the MFMA log-likelihood kernel
  *                      (k_llk_mfma<TC> + k_topc_rank; C' <= 16, C <= 2048, D <= 64); 0 or not applicable: "topc_z".
  *                      "topc_fallbacks" counts the calls the fused path handed on (candidate list overflow / margin check)
- *   "topc_overlap" 0   fused path on more than 262 144 frames: 1 = the ranking of a sub-chunk runs on a side stream beside the
- *                      log-likelihood kernel of the next one (bitwise the same results; measured slower, hence off)
  *   "short_calls" 1    log-likelihood kernels: a call of at most 32 768 frames runs 4-wave workgroups (one round, one wave per SIMD: 0.3 ms
  *                      instead of 0.55 for the walk through a 2048-Gaussian model); 0 = the 8-wave workgroups of long calls.  Per-frame
  *                      results are the same either way.
@@ -199,7 +184,7 @@ void gmmiv_gmm_destroy(gmmiv_gmm *g);
  * gmmiv_llk, gmmiv_em_accumulate, gmmiv_tv_stats(_lines) (and the JFA statistics built on it), gmmiv_occ; a kind-(1) frame is
  * evaluated as a kind-(2) frame and therefore counted here TOO.  gmmiv_ctx_set_option(ctx, "zero_llk_frames", v) returns the count so
  * far and stores v (0 to reset); the read waits for the context's stream, the counting never does.  Not counted: the top-C entry
- * points (a zero-likelihood frame is visible there as llk = min_llk with lk = 0) and the opt-in "em_fused" form of gmmiv_tv_stats.
+ * points (a zero-likelihood frame is visible there as llk = min_llk with lk = 0).
  * Other edges: T = 0 is valid everywhere (outputs untouched, accumulators unchanged); a Gaussian of weight 0 has likelihood 0
  * (never selected before a Gaussian of positive likelihood, occupancy 0); gmmiv_em_get keeps the previous mean / covariance of a
  * Gaussian whose occupancy is 0 and gives it weight 0; identical Gaussians tie and the lower index wins.

@@ -84,8 +84,6 @@ void gmmiv_ctx_destroy(gmmiv_ctx *c)
         for (hipEvent_t e : c->ev0[i]) (void)hipEventDestroy(e);
         for (hipEvent_t e : c->ev1[i]) (void)hipEventDestroy(e);
     }
-    c->topc_pipe_free();
-    c->tv_pipe_free();
     if (c->d_zero_llk) (void)hipFree(c->d_zero_llk);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (g_kopts_src == &c->ko) gmmiv_kopts_bind(nullptr); // back to the defaults on this thread
@@ -110,20 +108,17 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "timing")) slot = &c->timing;
     else if (!strcmp(key, "wg_waves")) slot = &c->wg_waves;
     else if (!strcmp(key, "dbg")) slot = &c->dbg;
-    else if (!strcmp(key, "em_fused")) slot = &c->em_fused;
     else if (!strcmp(key, "prune_log2")) slot = &c->prune_log2;
     else if (!strcmp(key, "stats_z")) slot = &c->stats_z;
     else if (!strcmp(key, "z_scratch_mb")) slot = &c->z_scratch_mb;
     else if (!strcmp(key, "tv_batch")) slot = &c->tv_batch;
     else if (!strcmp(key, "tv_tett_direct")) slot = &c->tv_tett_direct;
     else if (!strcmp(key, "tv_stats_split")) slot = &c->tv_stats_split;
-    else if (!strcmp(key, "tv_overlap")) slot = &c->tv_overlap;
     else if (!strcmp(key, "topc_z")) slot = &c->topc_z;
     else if (!strcmp(key, "tv_mstep_solve")) slot = &c->tv_mstep_solve;
     else if (!strcmp(key, "tv_md_device")) slot = &c->tv_md_device;
     else if (!strcmp(key, "tv_acc_mb")) slot = &c->tv_acc_mb;
     else if (!strcmp(key, "topc_fused")) slot = &c->topc_fused;
-    else if (!strcmp(key, "topc_overlap")) slot = &c->topc_overlap;
     else if (!strcmp(key, "topc_fallbacks")) slot = &c->topc_fallbacks;
     else if (!strcmp(key, "topc_rank_direct")) slot = &c->topc_rank_direct;
     else if (!strcmp(key, "topc_rank2")) slot = &c->topc_rank2;
@@ -143,8 +138,6 @@ long gmmiv_ctx_set_option(gmmiv_ctx *c, const char *key, long value)
     else if (!strcmp(key, "chol_gemm")) ks = &c->ko.chol_gemm;     // the GEMM-built batched Cholesky instead of k_chol_left
     else if (!strcmp(key, "chol_waves")) ks = &c->ko.chol_waves;   // 16 = k_trinv_left / k_uut on 1024-thread workgroups
     else if (!strcmp(key, "short_calls")) ks = &c->ko.short_calls; // 0 = calls of at most 32768 frames on the kernel shapes of long calls
-    else if (!strcmp(key, "k1_pc")) ks = &c->ko.k1_pc;             // 1 = k_llk_pc (producer / consumer waves) for the plain and stored-likelihood log-likelihood passes
-    else if (!strcmp(key, "chol_uut64")) ks = &c->ko.chol_uut64;   // 1 = k_uut64 for the packed E = U U^T + w w^T of the E-step
     else if (!strcmp(key, "chol_flow")) ks = &c->ko.chol_flow;     // 0 = the round-2 k_chol_left (diagonal update from L2, eight partial blocks)
     if (ks) { const long prev = *ks; *ks = (int)value; return prev; }
     // the device counters of kind-(2) frames (zero likelihood under the call's model -- this INCLUDES the kind-(1) frames, which every
@@ -570,16 +563,13 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
         if (Tf >= 256) {
             const int64_t first = T < Tf ? (T + 255) / 256 * 256 : Tf;
             const int stats = getenv("GMMIV_TOPC_STATS") != nullptr;
-            const int64_t SUB = 262144; // frames per sub-chunk of the pipelined form below: 1024 workgroups of k_llk_mfma<TC>
-            const bool pipelined = c->topc_overlap && !stats && T > SUB && Tf >= 2 * SUB;
-            const int64_t nsub = pipelined ? (T + SUB - 1) / SUB : 1;
-            const int64_t nalloc = pipelined && first < 2 * SUB ? 2 * SUB : first; // two candidate sets of SUB frames fit
+            const int64_t nalloc = first;
             void *cand, *cnt, *th, *sl, *flg;
             if ((rc = c->scratch(WS_Z, (size_t)nalloc * per_frame, &cand))) return rc;
             if ((rc = c->scratch(WS_EIT, (size_t)nalloc * sizeof(int), &cnt))) return rc;
             if ((rc = c->scratch(WS_INV, (size_t)nalloc * (sizeof(double) + sizeof(int)), &sl))) return rc;
             if ((rc = c->scratch(WS_LSE, (size_t)nalloc * sizeof(double), &th))) return rc;
-            if ((rc = c->scratch(WS_FLAGS, (size_t)nsub * 64, &flg))) return rc;
+            if ((rc = c->scratch(WS_FLAGS, 64, &flg))) return rc;
             int *efin = (int *)((double *)sl + first);
             void *redo;
             if ((rc = c->scratch(WS_SEG, (size_t)nalloc * 2 * sizeof(long), &redo))) return rc; // second half: the frames k_topc_rank2 hands to k_topc_rank
@@ -631,69 +621,9 @@ int gmmiv_llk_determine_top(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int
                                        onllk, onw, ollk));
                 return GMMIV_OK;
             };
-            // Pipelined form (option "topc_overlap", OFF by default -- measured slower, see ctx.h; T > one sub-chunk): the ranking of sub-chunk i runs on a side stream
-            // BESIDE the log-likelihood kernel of sub-chunk i + 1 -- k_topc_rank is bound by L2 gathers and latency (2.25 ms per
-            // 10^6 frames), k_llk_mfma<TC> by the matrix cores (11.2 ms): two sets of candidate scratch, events between the streams,
-            // no host synchronisation inside the loop (the flag words of every sub-chunk land in pinned host memory and are looked at
-            // once, at the end; a sub-chunk with failed frames -- never observed on real data -- is simply run again through the serial
-            // form above).  Same kernels on the same frames: bitwise the results of the serial form.
-            if (pipelined) {
-                rc = c->topc_pipe_init((size_t)nsub);
-                if (rc) return rc;
-                void *cand2 = cand, *cnt2 = cnt, *th2 = th, *sl2 = sl, *redo2 = redo, *flg2 = flg; // the same scratch, cut in two sets
-                GCHK(hipMemsetAsync(flg2, 0, (size_t)nsub * 64, c->stream));
-                hipStream_t side = c->topc_side;
-                GCHK(hipEventRecord(c->topc_ev_k1[0], c->stream)); // everything enqueued so far (inputs, the memset) precedes the side stream's first kernel
-                GCHK(hipStreamWaitEvent(side, c->topc_ev_k1[0], 0));
-                for (int64_t i = 0; i < nsub && krc == 0; ++i) {
-                    const int set = (int)(i & 1);
-                    const int64_t c0 = i * SUB, n = (T - c0) < SUB ? (T - c0) : SUB;
-                    double *cand_s = (double *)cand2 + (size_t)set * SUB * (per_frame / 8);
-                    int *cnt_s = (int *)cnt2 + (size_t)set * SUB;
-                    double *th_s = (double *)th2 + (size_t)set * SUB;
-                    double *sl_s = (double *)sl2 + (size_t)set * SUB;                       // [2][SUB] doubles, then [2][SUB] ints
-                    int *ef_s = (int *)((double *)sl2 + 2 * SUB) + (size_t)set * SUB;
-                    long *redo_s = (long *)redo2 + (size_t)set * SUB;
-                    int *flg_s = (int *)flg2 + (size_t)i * 16;
-                    if (i >= 2) GCHK(hipStreamWaitEvent(c->stream, c->topc_ev_rank[set], 0)); // the set's previous ranking has read its candidates
-                    if (i == 0) c->t_begin("k_llk_mfma", true);
-                    krc = gmmk_llk_topc(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (int)c->use_glds,
-                                        ctop, cand_s, cnt_s, th_s, sl_s, ef_s);
-                    if (i == 0) c->t_end();
-                    if (krc) break;
-                    GCHK(hipEventRecord(c->topc_ev_k1[set], c->stream));
-                    GCHK(hipStreamWaitEvent(side, c->topc_ev_k1[set], 0));
-                    int *oi = o_idx.d + (size_t)c0 * ctop;
-                    double *olk = o_lk.d ? o_lk.d + (size_t)c0 * ctop : nullptr, *onlk = o_nlk.d ? o_nlk.d + c0 : nullptr;
-                    double *onllk = o_nllk.d ? o_nllk.d + c0 : nullptr, *onw = o_nw.d ? o_nw.d + c0 : nullptr, *ollk = o_llk.d ? o_llk.d + c0 : nullptr;
-                    krc = gmmk_topc_rank(side, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->C, cand_s, cnt_s, th_s, sl_s, ef_s, g->mean, g->iv,
-                                         g->lwc, g->w, ctop, mode == GMMIV_TOP_COMPLETE, min_llk, max_llk, oi, olk, onlk, onllk, onw, ollk, flg_s, redo_s,
-                                         (c->topc_rank_direct ? 2 : 0) | (c->topc_rank2 ? 0 : 4), (long *)redo2 + nalloc + (size_t)set * SUB);
-                    if (krc) break;
-                    GCHK(hipMemcpyAsync(c->topc_hflags + (size_t)i * 16, flg_s, 64, hipMemcpyDeviceToHost, side));
-                    GCHK(hipEventRecord(c->topc_ev_rank[set], side));
-                }
-                // join: the context's stream continues behind the last rankings; the host looks at the flags
-                GCHK(hipStreamWaitEvent(c->stream, c->topc_ev_rank[0], 0));
-                GCHK(hipStreamWaitEvent(c->stream, c->topc_ev_rank[1], 0));
-                GCHK(hipStreamSynchronize(side));
-                GCHK(hipStreamSynchronize(c->stream));
-                if (krc == 0) {
-                    int64_t failed = 0;
-                    for (int64_t i = 0; i < nsub; ++i) failed += c->topc_hflags[(size_t)i * 16];
-                    if (failed > T / 8 + 64) { whole = true; c->topc_fallbacks += failed; }
-                    else
-                        for (int64_t i = 0; i < nsub && krc == 0 && !whole; ++i)
-                            if (c->topc_hflags[(size_t)i * 16] > 0) { // rare: this sub-chunk again, serially, with the redo of its failed frames
-                                const int64_t c0 = i * SUB, n = (T - c0) < SUB ? (T - c0) : SUB;
-                                if ((rc = run_chunk(c0, n))) return rc;
-                            }
-                }
-            } else {
-                for (int64_t c0 = 0; c0 < T && krc == 0 && !whole; c0 += Tf) {
-                    const int64_t n = (T - c0) < Tf ? (T - c0) : Tf;
-                    if ((rc = run_chunk(c0, n))) return rc;
-                }
+            for (int64_t c0 = 0; c0 < T && krc == 0 && !whole; c0 += Tf) {
+                const int64_t n = (T - c0) < Tf ? (T - c0) : Tf;
+                if ((rc = run_chunk(c0, n))) return rc;
             }
             if (krc > 0) GCHK(krc);
             done = krc == 0 && !whole;
@@ -1069,54 +999,6 @@ int gmmiv_em_accumulate(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt,
     XView xv;
     if ((rc = xv.init(c, x, dt, T, ldx, g->D))) return rc;
     if ((rc = count_unusable(c, xv, dt, T, g->D))) return rc;
-    if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
-        // single-pass path: teams of (nct/8) workgroups, one team per contiguous frame range
-        const int ngrp = (g->nct + 7) / 8;
-        int wg_per_cu = 0;
-        GCHK(gmmk_em_fused(c->stream, g->KS, 1, dt == GMMIV_F64, nullptr, 0, g->D, g->C, nullptr, g->nct, 0.0, nullptr, 0, 0, ngrp, 0,
-                           nullptr, nullptr, nullptr, nullptr, c->n_cu, 0, &wg_per_cu));
-        int nteams = c->n_cu * wg_per_cu / ngrp;
-        const int64_t cap = (T + 2047) / 2048;
-        if (nteams > cap) nteams = (int)cap;
-        if (nteams >= 1) {
-            std::vector<long> h(nteams + 1);
-            const int64_t per = ((T + nteams - 1) / nteams + 31) / 32 * 32;
-            for (int i = 0; i <= nteams; ++i) { int64_t b = (int64_t)i * per; h[i] = (long)(b < T ? b : T); }
-            void *seg, *lsew, *part, *slots, *small;
-            if ((rc = c->scratch(WS_SEG, (nteams + 1) * sizeof(long), &seg))) return rc;
-            GCHK(hipMemcpyAsync(seg, h.data(), (nteams + 1) * sizeof(long), hipMemcpyHostToDevice, c->stream));
-            GCHK(hipStreamSynchronize(c->stream));
-            if ((rc = c->scratch(WS_LSE, (size_t)T * sizeof(double), &lsew))) return rc;
-            const int RL = gmmk_rl_for_ks(g->KS);
-            const size_t Cp = (size_t)g->nct * 16;
-            if ((rc = c->scratch(WS_PART, (size_t)nteams * Cp * 2 * RL * sizeof(double), &part))) return rc;
-            const size_t sw = gmmk_em_fused_slot_words(nteams, ngrp);
-            if ((rc = c->scratch(WS_SLOTS, sw * 8, &slots))) return rc;
-            if ((rc = c->scratch(WS_SMALL, 3 * 256 * sizeof(double), &small))) return rc;
-            GCHK(hipMemsetAsync(slots, 0, sw * 8, c->stream));
-            c->t_begin("k_em_fused");
-            int krc = gmmk_em_fused(c->stream, g->KS, 1, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, -log(weight),
-                                    (const long *)seg, nteams, nteams, ngrp, 0, (double *)part, nullptr, (double *)lsew,
-                                    (double *)slots, c->n_cu, (int)c->dbg, nullptr);
-            c->t_end();
-            if (krc == (int)hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); goto two_pass; }
-            GCHK(krc);
-            unsigned herr = 0;
-            GCHK(hipMemcpyAsync(&herr, (char *)slots + (sw - 2) * 8, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            GCHK(hipStreamSynchronize(c->stream));
-            if (herr) { // a peer never arrived (grid not fully resident): redo the block with the two-kernel path
-                gmmiv_set_error("em_accumulate(fused): hand-off timed out, fell back to the two-kernel path");
-                goto two_pass;
-            }
-            GCHK(count_dead(c, (const double *)lsew, T));
-            // sum_t weight log lk_t and sum_t weight over the frames that HAVE a likelihood (zero-likelihood frames add nothing anywhere)
-            GCHK(gmmk_llk_finalize(c->stream, (const double *)lsew, T, -INFINITY, INFINITY, nullptr, (double *)small, 0.0, weight, nullptr,
-                                   o.d + nacc - 2, weight, o.d + nacc - 1));
-            GCHK(gmmk_em_reduce(c->stream, (const double *)part, nteams, g->C, (int)Cp, g->D, g->KS, o.d));
-            return o.finish();
-        }
-    }
-two_pass:
     const int64_t Tc = z_chunk_frames(c, g);
     if (Tc > 0) { // logits written once, statistics from the stored logits
         void *lsew, *small, *part;
@@ -1241,37 +1123,6 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
     DevOut<double> o_n, o_f;
     if ((rc = o_n.init(c, WS_T0, N, (size_t)U * g->C, false))) return rc;
     if ((rc = o_f.init(c, WS_T1, F, (size_t)U * SV, false))) return rc;
-    if (c->em_fused && g->KS <= 15 && (g->nct + 7) / 8 <= 16 && xv.ldx == g->D) {
-        // single pass: each team of workgroups walks utterances team, team + nteams, ...
-        const int ngrp = (g->nct + 7) / 8;
-        int wg_per_cu = 0;
-        GCHK(gmmk_em_fused(c->stream, g->KS, 0, dt == GMMIV_F64, nullptr, 0, g->D, g->C, nullptr, g->nct, 0.0, nullptr, 0, 0, ngrp, 1,
-                           nullptr, nullptr, nullptr, nullptr, c->n_cu, 0, &wg_per_cu));
-        int nteams = c->n_cu * wg_per_cu / ngrp;
-        if (nteams > U) nteams = (int)U;
-        if (nteams >= 1) {
-            void *slots;
-            const size_t sw = gmmk_em_fused_slot_words(nteams, ngrp);
-            if ((rc = c->scratch(WS_SLOTS, sw * 8, &slots))) return rc;
-            GCHK(hipMemsetAsync(slots, 0, sw * 8, c->stream));
-            c->t_begin("k_em_fused");
-            int krc = gmmk_em_fused(c->stream, g->KS, 0, dt == GMMIV_F64, xv.d, xv.ldx, g->D, g->C, g->Pt, g->nct, 0.0, (const long *)seg,
-                                    (int)U, nteams, ngrp, 1, o_n.d, o_f.d, nullptr, (double *)slots, c->n_cu, (int)c->dbg, nullptr);
-            c->t_end();
-            if (krc == (int)hipErrorCooperativeLaunchTooLarge) (void)hipGetLastError();
-            else {
-                GCHK(krc);
-                unsigned herr = 0;
-                GCHK(hipMemcpyAsync(&herr, (char *)slots + (sw - 2) * 8, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-                GCHK(hipStreamSynchronize(c->stream));
-                if (!herr) {
-                    if ((rc = o_n.finish())) return rc;
-                    return o_f.finish();
-                }
-                gmmiv_set_error("tv_stats(fused): hand-off timed out, fell back to the two-kernel path");
-            }
-        }
-    }
     const int64_t Tcz = z_chunk_frames(c, g);
     if (Tcz > 0) {
         // chunks of whole utterances whose frames fit the logit scratch; an utterance longer than
@@ -1353,46 +1204,6 @@ int gmmiv_tv_stats(gmmiv_ctx *c, const gmmiv_gmm *g, const void *x, int dt, int6
                     if ((rc = o_n.finish())) return rc;
                     return o_f.finish();
                 }
-            }
-            if (c->tv_overlap && cu.size() > 2) {
-                // OPT-IN experiment: K1 of chunk k + 1 beside K3 of chunk k.  Two scratch sets; K1 and the counting kernel stay on the
-                // context's stream, K3 runs on the side stream behind its chunk's K1 (event), K1 of chunk k + 2 behind K3 of chunk k
-                // (its set is free again).  Same kernels on the same data in the same per-row order: results bitwise the serial form's.
-                void *zb2, *lsew2, *eit2, *inv2;
-                if ((rc = c->tv_pipe_init())) return rc;
-                if ((rc = c->scratch(WS_Z2, (size_t)g->nct * nfb * 2048, &zb2))) return rc;
-                if ((rc = c->scratch(WS_LSE2, (size_t)(maxn > 0 ? maxn : 1) * sizeof(double), &lsew2))) return rc;
-                if ((rc = c->scratch(WS_EIT2, (size_t)(g->nct / 2) * nfb * 16 * sizeof(int), &eit2))) return rc;
-                if ((rc = c->scratch(WS_INV2, (size_t)(maxn > 0 ? maxn : 1) * (sizeof(double) + sizeof(int)), &inv2))) return rc;
-                void *zs[2] = {zb, zb2}, *ls[2] = {lsew, lsew2}, *es[2] = {eit, eit2}, *is[2] = {inv, inv2};
-                gmmiv_kopts ko3 = c->ko; // the statistics kernel's shape for this mode
-                if (c->tv_overlap == 2) ko3.z_waves = 4;
-                GCHK(hipEventRecord(c->tv_ev_k1[0], c->stream)); // everything enqueued so far (segment table, outputs) precedes the side stream's work
-                GCHK(hipStreamWaitEvent(c->tv_side, c->tv_ev_k1[0], 0));
-                for (size_t k = 0; k + 1 < cu.size(); ++k) {
-                    const int set = (int)(k & 1);
-                    const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;
-                    int *ef = (int *)((double *)is[set] + (maxn > 0 ? maxn : 1));
-                    if (k >= 2) GCHK(hipStreamWaitEvent(c->stream, c->tv_ev_k3[set], 0)); // the set's previous statistics pass has read it
-                    if (k == 0) c->t_begin("k_llk_mfma", true);
-                    GCHK(gmmk_llk_z(c->stream, g->KS, dt == GMMIV_F64, x_at(xv, dt, c0), n, xv.ldx, g->D, g->Pt, g->nct, (double *)ls[set],
-                                    (int)(c->use_glds | ((c->dbg & 15) << 8)), (double *)zs[set], nfb, (int *)es[set], (double *)is[set], ef));
-                    if (k == 0) c->t_end();
-                    GCHK(count_dead(c, (const double *)ls[set], n));
-                    GCHK(hipEventRecord(c->tv_ev_k1[set], c->stream));
-                    GCHK(hipStreamWaitEvent(c->tv_side, c->tv_ev_k1[set], 0));
-                    gmmiv_kopts_bind(&ko3);
-                    const int krc = gmmk_stats_z(c->tv_side, g->KS, 0, dt == GMMIV_F64, x_at(xv, dt, c0), xv.ldx, g->D, g->C, g->nct, (const double *)zs[set],
-                                                 nfb, (const int *)es[set], (const double *)is[set], ef, 1.0, (const long *)seg + u0 + k, (int)(u1 - u0),
-                                                 o_n.d + (size_t)u0 * g->C, o_f.d + (size_t)u0 * SV, 1, 0, c->prune_thr());
-                    gmmiv_kopts_bind(&c->ko);
-                    GCHK(krc);
-                    GCHK(hipEventRecord(c->tv_ev_k3[set], c->tv_side));
-                }
-                GCHK(hipStreamWaitEvent(c->stream, c->tv_ev_k3[0], 0)); // the context's stream continues behind the last statistics passes
-                GCHK(hipStreamWaitEvent(c->stream, c->tv_ev_k3[1], 0));
-                if ((rc = o_n.finish())) return rc;
-                return o_f.finish();
             }
             for (size_t k = 0; k + 1 < cu.size(); ++k) {
                 const int64_t u0 = cu[k], u1 = cu[k + 1], c0 = utt_begin[u0], n = utt_begin[u1] - c0;

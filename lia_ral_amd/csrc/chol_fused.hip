@@ -1189,126 +1189,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
     }
 }
 
-// k_uut64 (round 5, option "chol_uut64"): the same product for the PACKED output of the T-matrix E-step with panels of 64 columns.
-// k_uut re-reads every row r of U once per 32-column panel j0 <= r (its own k range [r, n) each time): 3.6 GB of L2 misses per 1024
-// systems of order 400 against 1.3 GB of matrices, and the kernel runs at the speed of that stream.  With 64 panel rows as the A
-// operand a tile row is read half as often and feeds twice the MFMAs per load (32 per 32-wide chunk instead of 16).  64 rows x
-// (n - j0) columns do not fit LDS for the early panels -- exactly where the traffic is -- so the k range of a panel is cut in TWO
-// halves, each staged in turn (64 x <= 224 doubles = 116 KB); a tile's partial result of the first half is stored (+ w w^T), the
-// second half adds to it in place (same wave, same addresses; the barrier between the halves orders them).  One tile per wave and
-// pass, four accumulators (the four 16-column groups of the panel).  Rows of the panel's second half are not defined left of their
-// own 32-block (k_trinv_left writes the upper triangle and the diagonal blocks only): whatever the staging finds there multiplies
-// into entries ABOVE the diagonal, which are never stored.
-// MEASURED (tools/chol_probe.sh build -DCHOL_UUT64_FORCE=1, profiles/r05/chol_probe_uut64.txt), order 400: 0.315 ms against 0.227 ms for
-// 32 systems in flight (uncontended), 1.59 ms against 1.09 ms per 1024 systems; results equal to 3e-15.  Half the tile-row bytes did
-// not buy time: one tile per wave and pass with a store / add-in-place epilogue per half leaves a wave's k-loops too short (<= 6
-// chunks) to cover their own latency, and the uncontended case -- where no byte is contended -- is slower too.  The family is
-// bound by the latency of its short dependent loops first and by the panel re-reads second; OFF by default, kept as the record.
-__device__ __forceinline__ void uut64_dot(const double *la, int S2, int perm, int q, const double *(&pb)[1], int kb, int ke, int kbase,
-                                          d4 (&accA)[1][2], d4 (&accB)[1][2])
-{
-    if (ke - kb < 32) return;
-    const double *l0 = la + perm * S2 + LOFF_Q * q, *l1 = la + (16 + perm) * S2 + LOFF_Q * q;
-    const double *l2 = la + (32 + perm) * S2 + LOFF_Q * q, *l3 = la + (48 + perm) * S2 + LOFF_Q * q;
-    TileOps<1> A, B;
-    PanOps xa0, xa1, xb0, xb1;
-    const int last = ke - 32;
-    tiles_load<1>(A, pb, kb);
-    pan_load(xa0, l0, l1, kb - kbase);
-    pan_load(xa1, l2, l3, kb - kbase);
-    int k = kb;
-    for (; k + 64 <= ke; k += 64) {
-        tiles_load<1>(B, pb, k + 32);
-        pan_load(xb0, l0, l1, k + 32 - kbase);
-        pan_load(xb1, l2, l3, k + 32 - kbase);
-        ROWS_FENCE();
-        pan_mfma<1, false>(xa0, A, accA);
-        pan_mfma<1, false>(xa1, A, accB);
-        ROWS_FENCE();
-        const int kn = k + 64 < last ? k + 64 : last;
-        tiles_load<1>(A, pb, kn);
-        pan_load(xa0, l0, l1, kn - kbase);
-        pan_load(xa1, l2, l3, kn - kbase);
-        ROWS_FENCE();
-        pan_mfma<1, false>(xb0, B, accA);
-        pan_mfma<1, false>(xb1, B, accB);
-        ROWS_FENCE();
-    }
-    if (k < ke) {
-        pan_mfma<1, false>(xa0, A, accA);
-        pan_mfma<1, false>(xa1, A, accB);
-    }
-}
-__global__ __launch_bounds__(512, 1) void k_uut64(int n_, int S2, const double *__restrict__ Ufull, const double *__restrict__ wv,
-                                                  double *__restrict__ packed, long sp)
-{
-    extern __shared__ __attribute__((aligned(16))) double dyn_lds[]; // 64 panel rows x one half of their k range
-    double *pan = dyn_lds;
-    const long n = n_;
-    const double *Um = Ufull + (size_t)blockIdx.x * n * n;
-    double *Pk = packed + (size_t)blockIdx.x * sp;
-    const double *wm = wv ? wv + (size_t)blockIdx.x * n : nullptr;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
-    const int perm = 4 * (i16 & 3) + (i16 >> 2);
-    const int nfl = n_ & ~31;
-    for (int j0 = 0; j0 < n_; j0 += 64) {
-        const int nblk = nfl > j0 ? (nfl - j0) >> 5 : 0;
-        const int kmid = j0 + 32 * ((nblk + 1) >> 1);
-        const int nt = (n_ - j0 + 15) >> 4; // row tiles from the panel's first diagonal block down
-        // the lane's four panel rows in memory (for the masked tail k >= nfl)
-        const double *pg[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            long ra = j0 + 16 * g + perm;
-            ra = ra < n ? ra : n - 1;
-            pg[g] = Um + ra * n + KOFF_Q * q;
-        }
-        for (int h = 0; h < 2; ++h) {
-            const int kh0 = h ? kmid : j0, kh1 = h ? (nfl > kmid ? nfl : kmid) : kmid;
-            if (h == 0 && kh1 <= kh0) continue; // (nothing left of the tail: the second pass does it all)
-            __syncthreads(); // every wave is done with the previous staging; the first half's stores are complete (vmcnt(0) inside)
-            if (kh1 > kh0) {
-                stage_panel<16>(pan, S2, Um, n, j0, kh0, kh1 - kh0, tid);
-                stage_panel<16>(pan + 32 * S2, S2, Um, n, j0 + 32, kh0, kh1 - kh0, tid);
-            }
-            __syncthreads();
-            for (int t = wave; t < nt; t += 8) {
-                const long r0 = j0 + 16L * t;
-                const int ks = (int)(r0 >> 5) << 5; // the tile's rows are zero left of their own 32-block
-                const bool both = ks < kmid;        // the tile has a part in each half: h = 0 stores, h = 1 adds
-                if (h == 0 && !both) continue;
-                const long row = r0 + i16;
-                const long rc = row < n ? row : n - 1;
-                const double *pb[1] = {Um + rc * n + KOFF_Q * q};
-                d4 accA[1][2], accB[1][2];
-                accA[0][0] = accA[0][1] = accB[0][0] = accB[0][1] = d4{0.0, 0.0, 0.0, 0.0};
-                const int kb = ks > kh0 ? ks : kh0;
-                if (kb < kh1) uut64_dot(pan, S2, perm, q, pb, kb, kh1, kh0, accA, accB);
-                if (h == 1 && nfl < n_) {
-                    rowdot_tail<1>(pg[0], pg[1], pb, nfl, n_, q, accA);
-                    rowdot_tail<1>(pg[2], pg[3], pb, nfl, n_, q, accB);
-                }
-                if (row < n) {
-                    const bool add = h == 1 && both;
-                    const double wr = (wm && !add) ? wm[row] : 0.0;
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        const long c0 = j0 + 16 * ct + 4 * q;
-                        const d4 &a = ct < 2 ? accA[0][ct] : accB[0][ct - 2];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (c0 + r <= row) {
-                                double *pp = Pk + row * (row + 1) / 2 + c0 + r;
-                                const double v = a[r] + ((wm && !add) ? wr * wm[c0 + r] : 0.0);
-                                *pp = add ? *pp + v : v;
-                            }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // X = A^-1 B for NR <= 64 right-hand sides per system through the Cholesky factor (k_chol_left) and the inverses of its 32 x 32
 // diagonal blocks: blocked forward (L Y = B) and backward (L^T X = Y) substitution on the matrix cores, one workgroup per system.
 // TVAcc::updateTestimate (AccumulateTVStat.cpp:981-1000) is T_c = A_c^-1 Cmx_c with 60 columns: the reference inverts A_c
@@ -1480,20 +1360,6 @@ int launch_uut(hipStream_t st, int n, int nb, const double *U, double *inv, cons
         if (rc16) return rc16;
         k_uut<true, 1, 16><<<nb, 1024, l.uut, st>>>(n, U, inv, w, packed, sp);
         return (int)hipGetLastError();
-    }
-#ifndef CHOL_UUT64_FORCE
-#define CHOL_UUT64_FORCE 0 // tools/chol_probe.sh build -DCHOL_UUT64_FORCE=1: the probe binary has no context to set the option on
-#endif
-    if (l.use && packed && !inv && (gmmiv_kopts_cur().chol_uut64 || CHOL_UUT64_FORCE)) { // 64-column panels, k range in two LDS halves
-        const int nfl = n & ~31, hmax = 32 * (((nfl >> 5) + 1) >> 1);
-        const int S2 = (hmax & 2) ? hmax : hmax + 2;
-        const size_t lds64 = (size_t)64 * S2 * sizeof(double);
-        if (hmax >= 32 && lds64 <= 156 * 1024) {
-            int rc64 = (int)gmmiv_lds_attr<k_uut64>(lds64);
-            if (rc64) return rc64;
-            k_uut64<<<nb, 512, lds64, st>>>(n, S2, U, w, packed, sp);
-            return (int)hipGetLastError();
-        }
     }
     int rc = l.use ? (int)gmmiv_lds_attr<k_uut<true, 2>>(l.uut) : (int)gmmiv_lds_attr<k_uut<false, CHOL_TW_NOLDS>>(l.uut);
     if (rc) return rc;

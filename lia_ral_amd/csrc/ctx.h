@@ -35,7 +35,7 @@ void gmmiv_set_error(const char *fmt, ...);
 enum { WS_X = 0, WS_LSE, WS_PART, WS_SEG, WS_SMALL, WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8,
        WS_T9, WS_TIV, WS_LP, WS_AUX, WS_SLAB, WS_SLOTS, WS_FLAGS, WS_Z, WS_EIT, WS_INV,
        WS_GFLAG,
-       WS_Z2, WS_LSE2, WS_EIT2, WS_INV2, WS_COUNT }; // WS_GFLAG: the per-frame flags of the kind-(1) counting pass
+       WS_COUNT }; // WS_GFLAG: the per-frame flags of the kind-(1) counting pass
 
 struct gmmiv_ctx {
     int device = 0;
@@ -48,7 +48,6 @@ struct gmmiv_ctx {
     long em_chunks = 0; // 0 = auto
     long timing = 0;
     long dbg = 0; // timing experiments (wrong results when != 0)
-    long em_fused = 0; // 1: single-pass cooperative EM kernel (em_fused.hip) instead of k_llk + k_stats
     // statistics kernels, OPT-IN: groups of 4 frames x 16 Gaussians whose posteriors are ALL below
     // 2^-prune_log2 are skipped (exp + MFMAs).  0 (default) = never skip: every pair is accumulated
     // like the reference does.  With 100, at most 2e10 pairs x 2^-100 = 1.6e-20 of posterior mass is
@@ -65,41 +64,6 @@ struct gmmiv_ctx {
     long topc_rank2 = 1;       // k_topc_rank2 (two frames per wave) + k_topc_rank on the frames it passes on; 0 = k_topc_rank for every frame
     long topc_rank_direct = 0; // k_topc_rank: 1 = every frame's survivors re-evaluated in the direct form (round 2); 0 = only near-ties
     long topc_fused = 1; // DETERMINE_TOP_DISTRIBS with the candidates collected inside k_llk_mfma<TC> (no likelihood round trip); 0: topc_z
-    // fused top-C, OPT-IN: rank sub-chunk i on a side stream beside the log-likelihood kernel of sub-chunk i + 1.  Measured SLOWER
-    // (10^6 frames: 13.48 -> 14.16 ms, 4 x 10^6: 52.3 -> 59.7): k_topc_rank's workgroups take LDS and wave slots from k_llk_mfma<TC>,
-    // which loses more than the 2.25 ms the ranking would have cost behind it.  Bitwise the serial results (tested); off.
-    long topc_overlap = 0;
-    hipStream_t topc_side = nullptr;
-    hipEvent_t topc_ev_k1[2] = {nullptr, nullptr}, topc_ev_rank[2] = {nullptr, nullptr};
-    int *topc_hflags = nullptr; // pinned: 16 flag words per sub-chunk
-    size_t topc_hflags_n = 0;
-    int topc_pipe_init(size_t nsub)
-    {
-        if (!topc_side) {
-            GCHK(hipStreamCreateWithFlags(&topc_side, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) {
-                GCHK(hipEventCreateWithFlags(&topc_ev_k1[i], hipEventDisableTiming));
-                GCHK(hipEventCreateWithFlags(&topc_ev_rank[i], hipEventDisableTiming));
-            }
-        }
-        if (topc_hflags_n < nsub) {
-            if (topc_hflags) { (void)hipHostFree(topc_hflags); topc_hflags = nullptr; topc_hflags_n = 0; }
-            GCHK(hipHostMalloc((void **)&topc_hflags, nsub * 64, hipHostMallocDefault));
-            topc_hflags_n = nsub;
-        }
-        memset(topc_hflags, 0, nsub * 64);
-        return GMMIV_OK;
-    }
-    void topc_pipe_free()
-    {
-        if (topc_side) {
-            (void)hipStreamSynchronize(topc_side);
-            for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(topc_ev_k1[i]); (void)hipEventDestroy(topc_ev_rank[i]); }
-            (void)hipStreamDestroy(topc_side);
-            topc_side = nullptr;
-        }
-        if (topc_hflags) { (void)hipHostFree(topc_hflags); topc_hflags = nullptr; topc_hflags_n = 0; }
-    }
     // 1: the caller vouches that every feature value is finite and |x| <= 1e18 -- the counting pass over the features (one read of x
     // per call, enqueued: no synchronisation) is skipped.  RESULTS do not depend on it: every kernel reads an unusable value as
     // GMMIV_UNUSABLE_READ_AS (devutil.h), which makes its frame a zero-likelihood frame on the device.
@@ -114,32 +78,6 @@ struct gmmiv_ctx {
     long tv_acc_mb = 8192; // T-matrix E-step: MiB of packed E_u kept per super-batch before A / Cmx are updated (one GEMM with K = its utterances)
     long tv_md_device = 1; // minDivergence: R normalised and factored on the device (one workgroup of k_chol_left); 0: on the host
     long tv_mstep_solve = 1; // updateTestimate by substitution through the Cholesky factor (k_chol_solve_multi); 0: explicit inverse + GEMM
-    // gmmiv_tv_stats over several chunks, OPT-IN experiment (round 5): 1 / 2 = the log-likelihood kernel of chunk k + 1 on the context's stream
-    // BESIDE the N / F statistics kernel of chunk k on a side stream (two likelihood scratch sets); 2 additionally runs the statistics kernel
-    // in its <4 waves, 2 tiles, 32-frame tiles> shape (51 KB of LDS) so that a CU can hold one workgroup of each kernel (80 + 51 KB)
-    long tv_overlap = 0;
-    hipStream_t tv_side = nullptr;
-    hipEvent_t tv_ev_k1[2] = {nullptr, nullptr}, tv_ev_k3[2] = {nullptr, nullptr};
-    int tv_pipe_init()
-    {
-        if (!tv_side) {
-            GCHK(hipStreamCreateWithFlags(&tv_side, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) {
-                GCHK(hipEventCreateWithFlags(&tv_ev_k1[i], hipEventDisableTiming));
-                GCHK(hipEventCreateWithFlags(&tv_ev_k3[i], hipEventDisableTiming));
-            }
-        }
-        return GMMIV_OK;
-    }
-    void tv_pipe_free()
-    {
-        if (tv_side) {
-            (void)hipStreamSynchronize(tv_side);
-            for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(tv_ev_k1[i]); (void)hipEventDestroy(tv_ev_k3[i]); }
-            (void)hipStreamDestroy(tv_side);
-            tv_side = nullptr;
-        }
-    }
     long tv_stats_split = 1; // gmmiv_tv_stats on at most 16 utterances: each utterance in pieces of whole tiles (more workgroups), summed back; 0 = one segment per utterance
     long tv_tett_direct = 1; // estimateTETt by k_tett_packed (lower triangle only, written packed); 0 = batched GEMM + pack
     long tv_batch = 1024; // utterances per batch of the i-vector solve / T-matrix E-step (one workgroup per system)

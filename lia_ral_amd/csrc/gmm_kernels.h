@@ -59,20 +59,12 @@ int gmmk_flag_frames(hipStream_t st, int x_f64, const void *x, long T, long ldx,
 int gmmk_fill_chunks(hipStream_t st, long *dst, int nseg, long per, long n);
 int gmmk_count_flags(hipStream_t st, const unsigned char *flag, long T, unsigned long long *cnt);
 int gmmk_gather_runs(hipStream_t st, int x_f64, const void *x, long ldx, int D, const long *runs, long nrun, void *out);
-// em_fused.hip: single-pass EM statistics by teams of cooperating workgroups
-size_t gmmk_em_fused_slot_words(int nteams, int ngrp);
-int gmmk_em_fused(hipStream_t st, int KS, int sq, int x_f64, const void *x, long ldx, int D, int C, const double *Pt, int nct,
-                  double lse_shift, const long *seg_begin, int nseg, int nteams, int ngrp, int mode, double *out0, double *out1,
-                  double *lse_out, double *slots, int n_cu, int dbg, int *query_blocks);
 
 // stats_z.hip / k_llk_mfma<WZ>: scaled likelihoods written once by the log-likelihood kernel, statistics from them
 int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct,
                double *lse, int use_glds, double *zbuf, long nfb, int *eit, double *inv, int *efin);
 // k_llk_mfma<TC>: candidates of the top-C' selection collected in the log-likelihood kernel (see gmm_kernels.hip), ranked by
 // gmmk_topc_rank (topc_z.hip)
-// llk_pc.hip: the same pass with role-split waves (option "k1_pc"); zbuf == NULL: plain log-likelihood
-int gmmk_llk_pc(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct, double *lse,
-                double *zbuf, long nfb, int *eit, double *inv, int *efin);
 int gmmk_topc_cap(void);
 int gmmk_llk_topc(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx, int D, const double *Pt, int nct, int use_glds,
                   int ctop, double *cand, int *cnt, double *theta, double *slow, int *efin);

@@ -1308,8 +1308,6 @@ int gmmk_llk(hipStream_t st, int KS, int x_f64, const void *x, long T, long ldx,
 {
     if (T <= 0) return 0;
     if (T <= 32768 && gmmiv_kopts_cur().short_calls) wg_waves = 4; // short calls: one round of 4-wave workgroups, half the time per stage (see gmmk_llk_topc)
-    else if (KS == 15 && wg_waves == 8 && gmmiv_kopts_cur().k1_pc && (use_glds & 1) && (use_glds >> 8) == 0)
-        return gmmk_llk_pc(st, KS, x_f64, x, T, ldx, D, Pt, nct, lse, nullptr, 0, nullptr, nullptr, nullptr);
 #define CASE(K)                                                                                      \
     case K:                                                                                          \
         if (wg_waves == 8)                                                                           \
@@ -1332,8 +1330,6 @@ int gmmk_llk_z(hipStream_t st, int KS, int x_f64, const void *x, long T, long ld
 {
     if (T <= 0) return 0;
     const bool small = T <= 32768 && gmmiv_kopts_cur().short_calls; // one round of 4-wave workgroups: half the time per stage (see gmmk_llk_topc); same blocks, same values
-    if (!small && KS == 15 && gmmiv_kopts_cur().k1_pc && (use_glds & 1) && (use_glds >> 8) == 0)
-        return gmmk_llk_pc(st, KS, x_f64, x, T, ldx, D, Pt, nct, lse, zbuf, nfb, eit, inv, efin);
 #define CASE(K)                                                                                                              \
     case K:                                                                                                                  \
         if (small)                                                                                                           \

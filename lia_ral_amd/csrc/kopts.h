@@ -19,8 +19,6 @@ struct gmmiv_kopts {
     // k_trinv_left / k_uut: 8 waves of 256 VGPRs, or (A/B) 16 waves of 128, one row tile per wave and pass -- twice the waves per SIMD
     // to cover a stalled one, but 30 / 66 spilled VGPRs and twice the LDS operand reads: 0.80 -> 0.96 and 1.13 -> 1.67 ms per 1024 systems
     int chol_waves = 8;
-    int k1_pc = 0;        // log-likelihood kernel as a producer / consumer pipeline (llk_pc.hip: 4 MFMA waves + 4 exp waves per workgroup); D <= 60 shapes (KS = 15), long calls
-    int chol_uut64 = 0;   // U U^T of the T-matrix E-step with 64-column panels, the k range staged in two LDS halves (k_uut64); 0: k_uut (32-column panels)
     int chol_flow = 1;    // 1: k_chol_left2 (panel staged first, diagonal update from LDS, wave 0 last in line for tiles); 0: k_chol_left (round 2)
 };
 const gmmiv_kopts &gmmiv_kopts_cur();          // the set bound to this thread (the defaults before any call)

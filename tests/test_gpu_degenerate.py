@@ -20,7 +20,6 @@ PATHS = [
     {"topc_fused": 0, "topc_z": 0},                # direct-form top-C kernel
     {"stats_z": 0},                                # recomputing statistics kernel
     {"wg_waves": 4},                               # 4-wave shapes of the two MFMA kernels
-    {"em_fused": 1},                               # single-pass cooperative EM kernel
     {"short_calls": 0},
 ]
 
@@ -166,8 +165,7 @@ def test_kind_2_threshold_is_log_2_pow_minus_1075_on_every_path(opts):
     No = np.stack([gam[:100].sum(0), gam[live][live >= 100].sum(0)])
     Fo = np.stack([(gam[:100].T @ x[:100].astype(np.float64)).ravel(), (gam[live][live >= 100].T @ x[live][live >= 100].astype(np.float64)).ravel()])
     assert rel(N, No) < 1e-9 and rel(F, Fo) < 1e-9 and abs(N[0].sum() - 100) < 1e-6 and abs(N[1].sum() - 99) < 1e-6
-    if not opts.get("em_fused"):                     # the opt-in single-pass N / F kernel keeps no per-frame log-sum to count from (gmmiv.h)
-        assert ctx.set_option("zero_llk_frames", 0) == 1
+    assert ctx.set_option("zero_llk_frames", 0) == 1
     # top-C: B gets the lowest indices and min_llk, A its true selection
     d = g.llk_determine_top(x, 5, min_llk=-1e4, max_llk=1e4)
     assert d["idx"][B].tolist() == [0, 1, 2, 3, 4] and d["llk"][B] == -1e4 and np.all(d["lk"][B] == 0.0)

@@ -244,30 +244,6 @@ def test_em_accumulates_weights_and_chunks(ctx):
     assert relerr(wn, wo) < 1e-9 and relerr(mn, mo) < 1e-9 and relerr(cn, co) < 1e-8
 
 
-def test_k1_producer_consumer_is_bitwise_the_alternating_kernel(ctx):
-    """llk_pc.hip (option "k1_pc", round-5 experiment, off by default): four MFMA waves hand their logit tiles through LDS to four
-    exponential waves.  Same arithmetic on the same values in the same order per frame row as k_llk_mfma: the EM accumulator, the
-    Baum-Welch N / F rows, the posterior matrix and the plain per-frame log-likelihoods are BITWISE those of the default kernel (a
-    call of more than 32 768 frames -- shorter ones keep the 4-wave kernel -- with a ragged last workgroup), and the oracle's."""
-    w, mean, iv = make_gmm(512, 60, seed=21)
-    T = 40_000 + 77
-    x = make_frames(w, mean, iv, T, seed=22)
-    g = ctx.gmm(w, mean, iv)
-    ub = np.array([0, 10_000, 10_000, 33_333, T])
-    out = {}
-    for pc in (0, 1):
-        ctx.set_option("k1_pc", pc)
-        N = np.zeros((4, 512)); F = np.zeros((4, 512 * 60))
-        g.tv_stats(x, ub, N, F)
-        out[pc] = (g.em_accumulate(x), g.llk(x), N, F, g.occ(x[:33_000]))
-    ctx.set_option("k1_pc", 0)
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a, b)
-    ref = orc.em_accumulate(orc.Gmm(w, mean, iv), x.astype(np.float64))
-    a = g.split_acc(out[1][0])
-    assert a["count"] == T and relerr(a["occ"], ref["occ"]) < 1e-9 and relerr(a["sx"], ref["sx"]) < 1e-9 and relerr(a["sxx"], ref["sxx"]) < 1e-9
-
-
 def test_workgroup_shapes_agree(ctx):
     """4-wave and 8-wave workgroup variants of the two MFMA kernels compute the same sums."""
     w, mean, iv = make_gmm(2048, 60, seed=21)
@@ -297,24 +273,6 @@ def test_posterior_pruning_is_invisible(ctx, spread):
     n_on, f_on = g.tv_stats(x, ub)
     ctx.set_option("prune_log2", 0)
     assert relerr(a_on, a_off) < 1e-14 and relerr(n_on, n_off) < 1e-14 and relerr(f_on, f_off) < 1e-14
-
-
-@pytest.mark.parametrize("C,D,T", [(2048, 60, 70000), (128, 60, 5000), (300, 32, 4097), (2048, 60, 31), (37, 13, 257)])
-def test_fused_single_pass_em_matches_two_pass(ctx, C, D, T):
-    """em_fused: teams of cooperating workgroups compute every logit once (em_fused.hip)."""
-    w, mean, iv = make_gmm(C, D, seed=C + 3)
-    x = make_frames(w, mean, iv, T, seed=T + 5)
-    g = ctx.gmm(w, mean, iv)
-    ref = g.em_accumulate(x, weight=0.75)
-    ctx.set_option("em_fused", 1)
-    try:
-        got = g.em_accumulate(x, weight=0.75)
-        got2 = g.em_accumulate(x, weight=0.75)
-    finally:
-        ctx.set_option("em_fused", 0)
-    assert relerr(got, ref) < 1e-12
-    assert np.array_equal(got, got2)          # deterministic: no atomics in the data path
-    assert abs(got[-2] - ref[-2]) < 1e-9 * max(1, T) and got[-1] == ref[-1]
 
 
 def test_em_zero_frames_and_ragged_edges(ctx):
@@ -370,31 +328,6 @@ def test_tv_stats_of_a_few_utterances_in_pieces_match_one_segment_per_utterance(
             assert not out[1][0][u].any() and not out[1][1][u].any()
 
 
-@pytest.mark.parametrize("C,D,U", [(128, 60, 7), (2048, 60, 40), (37, 13, 5), (512, 24, 70)])
-def test_tv_stats_fused_single_pass_matches_two_pass(ctx, C, D, U):
-    """tv_stats through em_fused.hip: a team of workgroups walks several utterances (ragged, some
-    empty, more utterances than teams); same N and F as the two-kernel path."""
-    rng = np.random.default_rng(U)
-    lens = rng.integers(0, 400, U)
-    lens[1] = 0
-    lens[-1] = 1
-    ub = np.concatenate([[0], np.cumsum(lens)])
-    w, mean, iv = make_gmm(C, D, seed=C + 9)
-    x = make_frames(w, mean, iv, int(ub[-1]), seed=13)
-    g = ctx.gmm(w, mean, iv)
-    N0, F0 = g.tv_stats(x, ub)
-    ctx.set_option("em_fused", 1)
-    try:
-        N1, F1 = g.tv_stats(x, ub)
-        N2, F2 = g.tv_stats(x, ub)
-    finally:
-        ctx.set_option("em_fused", 0)
-    assert relerr(N1, N0) < 1e-12 and relerr(F1, F0) < 1e-12
-    assert np.array_equal(N1, N2) and np.array_equal(F1, F2)
-    assert not N1[1].any() and not F1[1].any()
-    assert np.allclose(N1.sum(1), lens, rtol=1e-10, atol=1e-10)
-
-
 @pytest.mark.parametrize("C,D,T,mb", [(128, 60, 20000, 8), (2048, 60, 9000, 100), (37, 13, 7001, 4), (300, 24, 15000, 16)])
 def test_stored_logit_path_chunked_matches_recompute(ctx, C, D, T, mb):
     """Default EM path (k_llk_mfma<WZ> + k_stats_z, frames in chunks that fit the logit scratch) against
@@ -445,15 +378,7 @@ def test_tv_stats_stored_logit_path_chunks_of_utterances(ctx, C, D, U, mb):
         N2, F2 = g.tv_stats(x, ub)
         nl = ctx.kernel_launches("k_stats_z")
         ctx.set_option("timing", 0)
-        # opt-in "tv_overlap" (round-5 experiment: the log-likelihood kernel of chunk k + 1 beside the statistics kernel of chunk k on
-        # a side stream, two scratch sets; 2 = the statistics kernel in its 4-wave shape): bitwise the serial chunks' rows
-        for mode in (1, 2):
-            ctx.set_option("tv_overlap", mode)
-            N3, F3 = g.tv_stats(x, ub)
-            ctx.set_option("tv_overlap", 0)
-            assert np.array_equal(N3, N2) and np.array_equal(F3, F2), mode
     finally:
-        ctx.set_option("tv_overlap", 0)
         ctx.set_option("z_scratch_mb", prev)
     assert nl >= 2, nl
     for N, F in ((N1, F1), (N2, F2)):
@@ -657,34 +582,6 @@ def test_fused_top_c_two_frames_per_wave_matches_one_frame_per_wave(ctx, spread,
     do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x[:600].astype(np.float64), ctop, True)
     assert np.array_equal(res[1]["idx"][:600], do["idx"])
     assert np.max(np.abs(res[1]["llk"][:600] - do["llk"])) < 1e-9
-
-
-def test_fused_top_c_pipelined_sub_chunks_are_bitwise_the_serial_form(ctx):
-    """gmmiv_llk_determine_top on more than one sub-chunk of 262 144 frames (option "topc_overlap"; off by default, it measured slower): the ranking of
-    sub-chunk i runs on a side stream beside the log-likelihood kernel of sub-chunk i + 1, two sets of candidate scratch, flags read once at
-    the end, sub-chunks with failed frames run again serially.  Same kernels on the same frames: every output is BITWISE the serial
-    form's, failed frames included (a few frames drawn from 100 identical low-weight Gaussians pile up more than 64 survivors), and the
-    frames around the sub-chunk boundaries agree with the oracle."""
-    C, D, T, ctop = 256, 60, 600_000, 10
-    w, mean, iv = make_gmm(C, D, seed=31)
-    mean[100:200] = mean[100]; iv[100:200] = iv[100]; w[100:200] = 5e-5; w /= w.sum()     # ~0.5 % of the frames come from the pile
-    x = make_frames(w, mean, iv, T, seed=32)
-    g = ctx.gmm(w, mean, iv)
-    out = {}
-    for ov in (0, 1):
-        ctx.set_option("topc_overlap", ov)
-        ctx.set_option("topc_fallbacks", 0)
-        out[ov] = g.llk_determine_top(x, ctop, True)
-        out[ov]["redone"] = ctx.set_option("topc_fallbacks", 0)
-    ctx.set_option("topc_overlap", 0)
-    for k in ("idx", "lk", "nontop_lk", "nontop_llk", "nontop_w", "llk"):
-        assert np.array_equal(out[0][k], out[1][k]), k
-    assert 0 < out[0]["redone"] == out[1]["redone"] < T // 8
-    rows = np.concatenate([np.arange(0, 1500), np.arange(262144 - 700, 262144 + 700), np.arange(524288 - 700, 524288 + 700), np.arange(T - 1500, T)])
-    do = orc.llk_determine_top(orc.Gmm(w, mean, iv), x[rows].astype(np.float64), ctop, True)
-    assert np.array_equal(out[1]["idx"][rows], do["idx"])
-    assert np.max(np.abs(out[1]["llk"][rows] - do["llk"])) < 1e-9 and relerr(out[1]["lk"][rows], do["lk"]) < 1e-10
-    g.close()
 
 
 def test_default_paths_are_bitwise_the_round_5_results(golden_dir):

@@ -457,28 +457,6 @@ def test_tv_estep_batching_does_not_change_the_statistics(ctx):
     assert relerr(outs[0]["A"], outs[1]["A"]) < 1e-12 and np.array_equal(outs[0]["W"], outs[1]["W"])
 
 
-@pytest.mark.parametrize("R", [400, 96, 200, 130])
-def test_uut_with_64_column_panels_matches_the_default_kernel_and_the_oracle(ctx, R):
-    """k_uut64 (option "chol_uut64", round-5 experiment, off by default: measured slower): E = U U^T + w w^T with 64-column panels
-    and the k range staged in two LDS halves (first half stored, second half added in place).  The E-step accumulators with it
-    equal those of k_uut to 1e-12 and the oracle's to 1e-9 -- orders with a partial last 32-block (R = 400, 200, 130) and without."""
-    C, D, U = 8, 12, 7
-    p = tv_problem(C, D, R, U, seed=33, frames=90)
-    invvar = p["iv"].ravel()
-    F0 = orc.tv_subtract_m(p["N"], p["F"], p["mean"].ravel())
-    o = orc.tv_estimate_a_and_c(p["N"], F0, p["Tm"], invvar, orc.tv_tett(p["Tm"], invvar, C, D))
-    te = ctx.tv_tett(p["Tm"], invvar, C, D)
-    il = np.tril_indices(R)
-    A_o = o["A"].reshape(C, R, R)[:, il[0], il[1]]
-    outs = []
-    for on in (0, 1):
-        prev = ctx.set_option("chol_uut64", on)
-        outs.append(ctx.tv_estimate_a_and_c(p["N"], F0, p["Tm"], invvar, te, C, D))
-        ctx.set_option("chol_uut64", prev)
-    assert relerr(outs[1]["A"], A_o) < 1e-9 and relerr(outs[1]["W"], o["W"]) < 1e-9 and relerr(outs[1]["Rm"], o["Rm"]) < 1e-9
-    assert relerr(outs[1]["A"], outs[0]["A"]) < 1e-12 and np.array_equal(outs[1]["W"], outs[0]["W"])
-
-
 def test_options_are_state_of_the_context_not_of_the_thread():
     """gmmiv_ctx_set_option: the kernel-launcher options ("z_waves", "z_depth_*", "z_tv4", "chol_lds", "chol_gemm", "gemm_*")
     live in the context.  Two contexts on ONE thread keep different settings and each call runs with its own context's set; one

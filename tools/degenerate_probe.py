@@ -19,7 +19,7 @@ for t, v in bad.items():
     x[t, 7] = v
 x[17, :] = 3e38            # finite float32, the distance overflows fp64? no: 9e76 * iv fits; stays finite
 for waves in (8, 4):
-    for opts in ({}, {"stats_z": 0}, {"topc_fused": 0}, {"topc_fused": 0, "topc_z": 0}, {"em_fused": 1}):
+    for opts in ({}, {"stats_z": 0}, {"topc_fused": 0}, {"topc_fused": 0, "topc_z": 0}):
         ctx = capi.Context(0)
         ctx.set_option("wg_waves", waves)
         for k, v in opts.items():

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   mkdir -p tools/bin/nosane
-  for f in capi_gmm gmm_kernels llk_pc stats_z em_fused capi_tv tv_kernels chol_fused topc_z capi_comm; do
+  for f in capi_gmm gmm_kernels stats_z capi_tv tv_kernels chol_fused topc_z capi_comm; do
     [ -f lia_ral_amd/csrc/$f.hip ] || continue
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DGMMIV_FEAT_SANE_OFF -c lia_ral_amd/csrc/$f.hip -o tools/bin/nosane/$f.o &
   done

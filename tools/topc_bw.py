@@ -16,7 +16,6 @@ ctx.set_option("topc_fused", int(os.environ.get("TOPC_FUSED", "1")))
 ctx.set_option("topc_rank_direct", int(os.environ.get("TOPC_RANK_DIRECT", "0")))   # 1 = survivors of every frame re-evaluated in the direct form (round 2)
 ctx.set_option("topc_use_lanes", int(os.environ.get("TOPC_USE_LANES", "4")))   # lanes per candidate in the client pass: 4 (default) or 1
 ctx.set_option("topc_rank2", int(os.environ.get("TOPC_RANK2", "1")))   # 0 = one frame per wave for every frame
-ctx.set_option("topc_overlap", int(os.environ.get("TOPC_OVERLAP", "0")))   # ranking of sub-chunk i beside the log-likelihood kernel of sub-chunk i + 1
 C, D, T, ctop = 2048, 60, int(os.environ.get("T", "1000000")), 10
 w, mean, iv = make_gmm(C, D, seed=0, spread=float(os.environ.get("SPREAD", "2.0")))
 x = synth_frames(w, mean, iv, T, dev, seed=5)
