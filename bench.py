@@ -810,6 +810,40 @@ def max_over_ranks(dt, world, dev):
     return float(tt.item())
 
 
+def gather_over_ranks(obj, world):
+    """every rank's value, in rank order (the launcher's process group carries it as a Python object)"""
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def tensor_digest(t):
+    """SHA-256 of a device tensor's bytes: replicated results must be the SAME BITS on every rank after a collective"""
+    import hashlib
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def multi_rank_report(world, rank, dt_rank, steps, digests, event_ms=None):
+    """What the first run on real multi-GPU hardware should show beside the headline: every rank's own
+    ms_per_step (the line's ms_per_step is their MAX), the collectives' times from HIP events on the stream they are enqueued on, and
+    whether the replicated results behind a collective are bitwise equal on all ranks (digests: name -> sha256 on this rank)."""
+    per_rank = gather_over_ranks(dt_rank / max(steps, 1) * 1e3, world)
+    all_dig = gather_over_ranks(digests, world)
+    rep = {"ms_per_step_per_rank": per_rank,
+           "bitwise_equal_across_ranks": {k: all(d.get(k) == all_dig[0].get(k) for d in all_dig) for k in all_dig[0]}}
+    if event_ms is not None:
+        ev = gather_over_ranks(event_ms, world)
+        rep["collective_ms_per_step_per_rank"] = ev
+    bad = [k for k, v in rep["bitwise_equal_across_ranks"].items() if not v]
+    if bad:
+        print("bench.py: rank %d: replicated results differ between ranks after the collective: %s" % (rank, bad), file=sys.stderr, flush=True)
+        sys.exit(4)
+    return rep
+
+
 def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps, warmup, check=True, cpu=True, overlap=False, force=False, traffic=None,
                 cpu_utterances=64):
     """BASELINE.json configs[3]: N / F of this rank's U utterances computed once (untimed, like TotalVariability loads them),
@@ -850,9 +884,14 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
     for _ in range(steps):
         gd.tv_em_iteration(ops, n_total, C, D, rank, world, coll, phases, overlap=overlap, force_collectives=force)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    dt_rank = time.perf_counter() - t0
+    dt = max_over_ranks(dt_rank, world, dev)
     nbytes = coll.take_bytes() / max(steps, 1)
     ph = {k: v / steps * 1e3 for k, v in phases.items() if k != "sync"}
+    multi = None
+    if world > 1:      # T and the UBM means are replicated: the all-gather of T and the all-reduce of R / r / meanW must leave the same bits everywhere
+        multi = multi_rank_report(world, rank, dt_rank, steps, {"T_after_iteration": tensor_digest(ops.T), "ubm_means_after_min_divergence": tensor_digest(ops.means)},
+                                  {k: ph.get(k) for k in ("reduce_scatter", "allgather", "min_divergence", "estep")})
     estep_tf = TV_FLOP_PER_UTT * U / (ph["estep"] * 1e-3) / 1e12
     finite = bool(torch.isfinite(ops.T).all().item())
     tr = tr_note = None
@@ -880,6 +919,8 @@ def tv_workload(ctx, g, coll, w, mean, iv, dev, rank, world, U, frames, R, steps
                      "algorithmic_flop_per_utterance": TV_FLOP_PER_UTT, "kernel_ms": ph["estep"],
                      "algorithmic_bytes": float(U) * (C * D + C) * 8.0},      # the N / F rows read once
     }
+    if multi:
+        res["multi_rank"] = multi
     if rank == 0 and check:
         res["parity"], cpub = tv_parity_and_cpu_baseline(ops, R, want_cpu=cpu)
         if cpub:
@@ -1025,6 +1066,7 @@ def main():
     cov_signal = cov_d.mean(0).contiguous()       # stands in for the global covariance of computeMeanCov
 
     kern_ms = {}
+    ar_events = []
 
     def step(record=False):
         nonlocal mean_d, cov_d, nm_d, nc_d
@@ -1035,7 +1077,12 @@ def main():
                 if ctx.kernel_launches(name) > 0:
                     kern_ms.setdefault(name, []).append((ctx.kernel_ms(name), ctx.kernel_launches(name)))
         if world > 1:
-            coll.allreduce(acc)                             # EM sufficient statistics, 1.98 MB fp64 (gmmiv_allreduce_f64)
+            if record:                                      # HIP events on the stream the collective is enqueued on (the context's = torch's current)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); coll.allreduce(acc); e1.record()
+                ar_events.append((e0, e1))
+            else:
+                coll.allreduce(acc)                         # EM sufficient statistics, 1.98 MB fp64 (gmmiv_allreduce_f64)
         # M-step (MixtureStat::getEM) + variance flooring + re-pack of the device model
         capi._chk(capi.lib.gmmiv_em_get(ctx._h, C, D, capi._ptr(acc), capi._ptr(mean_d), capi._ptr(cov_d),
                                         capi._ptr(w_d), capi._ptr(nm_d), capi._ptr(nc_d)))
@@ -1056,7 +1103,13 @@ def main():
     for _ in range(args.steps):
         step(record=True)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    dt_rank = time.perf_counter() - t0
+    dt = max_over_ranks(dt_rank, world, dev)
+    multi = None
+    if world > 1:      # acc still holds the LAST step's all-reduced accumulator; the M-step outputs are replicated too
+        ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events])) if ar_events else None
+        multi = multi_rank_report(world, rank, dt_rank, args.steps, {"em_accumulator_after_allreduce": tensor_digest(acc), "weights_after_m_step": tensor_digest(w_d),
+                                                                     "means_after_m_step": tensor_digest(mean_d)}, {"allreduce": ar_ms})
     parity = em_parity(ctx, g, w, mean, iv, x, acc, T, world) if rank == 0 and check else None   # untimed checker leg
 
     pairs_per_step = float(T) * C * world
@@ -1074,6 +1127,8 @@ def main():
     }
     if parity:
         out["parity"] = parity
+    if multi:
+        out["multi_rank"] = multi
     if coll_note:
         out["collectives_note"] = coll_note
     # the same E-step on a heavily overlapping mixture (means ~ N(0, 0.3^2)): hundreds of Gaussians carry

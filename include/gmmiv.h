@@ -140,7 +140,9 @@ long gmmiv_ctx_kernel_launches(gmmiv_ctx *ctx, const char *kernel_name);
  * (LIA_SpkDet/TrainWorld/cfg/TrainWorld.cfg, ComputeTest.cpp:129-215) and none of them is refused here: vectSize <= 80 runs the fp64
  * MFMA kernels (compiled for D <= 16 / 32 / 60 / 80; the stored-likelihood statistics path for D <= 60); a larger vectSize (<= 4096)
  * runs generic paths with the same results -- logits in the reference's direct form on the vector ALUs, statistics as
- * gamma^T [x | 1 | x^2] on the fp64 GEMM -- at about a tenth of the rate.  The fused / stored-likelihood top-C selection serves
+ * gamma^T [x | 1 | x^2] on the fp64 GEMM -- at about a tenth of the rate; gmmiv_tv_stats walks the UTTERANCES one by one there (per
+ * utterance: posteriors, one C x (vectSize + 2) x length GEMM, a scatter -- five launches), so a call of many short utterances is
+ * launch-bound on that path, not merely slower (vectSize 1 .. 80 never takes it).  The fused / stored-likelihood top-C selection serves
  * topDistribsCount <= 16 / <= 60, the LDS selection kernel <= 64 with up to ~4 700 Gaussians; anything beyond (8192 Gaussians,
  * topDistribsCount 100, ...) goes through an any-shape selection kernel whose logit rows live in device scratch. */
 int gmmiv_gmm_create(gmmiv_ctx *ctx, int C, int D, const double *w, const double *mean,

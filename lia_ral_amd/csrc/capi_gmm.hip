@@ -462,17 +462,18 @@ static int topc_big(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, i
     void *zs;
     int rc = c->scratch(WS_Z, gmmk_topc_big_scratch_doubles((long)per, g->Cp64) * sizeof(double), &zs);
     if (rc) return rc;
-    c->t_begin("k_topc_determine");
-    for (int64_t c0 = 0; c0 < T; c0 += per) {
+    for (int64_t c0 = 0; c0 < T; c0 += per) { // one timed launch per chunk, like the other chunked paths (kernel_launches counts them)
         const int64_t n = T - c0 < per ? T - c0 : per;
+        c->t_begin("k_topc_determine", c0 == 0);
         int krc = gmmk_topc_determine_big(c->stream, dt == GMMIV_F64, x_at(xv, dt, c0), (long)n, xv.ldx, g->D, g->C, g->Cp64, g->meanT, g->ivT, g->lwc,
-                                          g->w, ctop, complete, lo, hi, idx + (size_t)c0 * ctop, lk ? lk + (size_t)c0 * ctop : nullptr,
+                                          g->w, ctop, complete, lo, hi, idx ? idx + (size_t)c0 * ctop : nullptr, lk ? lk + (size_t)c0 * ctop : nullptr,
                                           nlk ? nlk + c0 : nullptr, nllk ? nllk + c0 : nullptr, nw ? nw + c0 : nullptr, llk ? llk + c0 : nullptr,
                                           (double *)zs);
+        c->t_end();
         if (krc == -1) { gmmiv_set_error("vectSize %d exceeds the generic kernels' bound", g->D); return GMMIV_ERR_UNSUPPORTED; }
+        if (krc == -2) { gmmiv_set_error("topDistribsCount %d outside 1 .. mixtureDistribCount %d", ctop, g->C); return GMMIV_ERR_ARG; }
         GCHK(krc);
     }
-    c->t_end();
     return GMMIV_OK;
 }
 
@@ -482,9 +483,7 @@ static int run_lse(gmmiv_ctx *c, const gmmiv_gmm *g, const XView &xv, int dt, in
     int rc = c->scratch(WS_LSE, (size_t)(T > 0 ? T : 1) * sizeof(double), &lse);
     if (rc) return rc;
     if (g->KS == GMMK_KS_GENERIC) { // no MFMA instantiation: log sum_c w_c lk_c in the direct form (the top-1 pass of the any-shape kernel, COMPLETE)
-        void *ix;
-        if ((rc = c->scratch(WS_EIT, (size_t)(T > 0 ? T : 1) * sizeof(int), &ix))) return rc;
-        if ((rc = topc_big(c, g, xv, dt, T, 1, 1, -INFINITY, INFINITY, (int *)ix, nullptr, nullptr, nullptr, nullptr, (double *)lse))) return rc;
+        if ((rc = topc_big(c, g, xv, dt, T, 1, 1, -INFINITY, INFINITY, nullptr, nullptr, nullptr, nullptr, nullptr, (double *)lse))) return rc;
         GCHK(count_dead(c, (const double *)lse, T));
         *lse_out = (double *)lse;
         return GMMIV_OK;

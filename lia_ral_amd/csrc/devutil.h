@@ -329,7 +329,9 @@ __device__ __forceinline__ double feat_sane(double v) { return v; }
 template <typename T> struct feat_load;
 template <> struct feat_load<float> {
     static __device__ __forceinline__ double get(const void *p, long i) { return (double)feat_sane(((const float *)p)[i]); }
+    static __device__ __forceinline__ double raw(const void *p, long i) { return (double)((const float *)p)[i]; } // FrameAccGD: not screened (gmmiv.h)
 };
 template <> struct feat_load<double> {
     static __device__ __forceinline__ double get(const void *p, long i) { return feat_sane(((const double *)p)[i]); }
+    static __device__ __forceinline__ double raw(const void *p, long i) { return ((const double *)p)[i]; }
 };

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_topc_determine_big(
         st += dead ? 0.0 : gexp(bv - M);
         snsw -= w[bc];
         if (lane == 0) {
-            idx_out[t * ctop + k] = bc;
+            if (idx_out) idx_out[t * ctop + k] = bc;
             if (lk_out) lk_out[t * ctop + k] = dead ? 0.0 : exp(bv);
         }
     }
@@ -1204,7 +1204,8 @@ __global__ __launch_bounds__(256) void k_posteriors(const void *__restrict__ x, 
             const double dx = xs[d] - meanT[(size_t)d * Cp + c];
             acc = __builtin_fma(dx * dx, ivT[(size_t)d * Cp + c], acc);
         }
-        gamma[t * C + c] = exp(__builtin_fma(-0.5, acc, lwc[c]) - l);
+        const double z = __builtin_fma(-0.5, acc, lwc[c]);
+        gamma[t * C + c] = z == z ? exp(z - l) : 0.0; // a NaN logit (weight 0: lwc = log 0 + ... may be NaN) is a term of likelihood 0, as in k_topc_determine_big
     }
 }
 
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_frame_moments(const void *__restrict__ 
         const int dd = d0 + d;
         if (dd < D)
             for (long t = (long)blockIdx.x * 4 + rs; t < T; t += (long)gridDim.x * 4) {
-                const double v = feat_load<XT>::get(x, t * ldx + dd);
+                const double v = feat_load<XT>::raw(x, t * ldx + dd); // the raw value: a NaN goes into the sums like in the reference
                 s += v;
                 ss = __builtin_fma(v, v, ss);
             }
@@ -1753,6 +1754,7 @@ int gmmk_topc_determine_big(hipStream_t st, int x_f64, const void *x, long T, lo
                             double *nw, double *llk, double *zs)
 {
     if (T <= 0) return 0;
+    if (ctop < 1 || ctop > C) return -2; // the selection loop indexes w[] with every pick: it must find ctop entries (not left to the callers)
     const size_t lds = (size_t)4 * D * sizeof(double);
     if (lds > 150 * 1024) return -1;
     const unsigned grid = (unsigned)((T + 3) / 4);

@@ -298,6 +298,16 @@ def test_screening_follows_the_buffer_that_is_read_not_the_accumulators_server()
     assert cnt2 == (0, 0) and af2 == 0 and rel(N2, No2) < 1e-9 and rel(F2, Fo2) < 1e-9
 
 
+def capi_determine_too_many(g, x):
+    """gmmiv_llk_determine_top with topDistribsCount > mixtureDistribCount through the raw ABI (the Python wrapper clamps): ERR_ARG"""
+    import ctypes as ct
+    from lia_ral_amd import capi
+    ctop = g.C + 1
+    idx = np.empty((len(x), ctop), np.int32)
+    capi._chk(capi.lib.gmmiv_llk_determine_top(g.ctx._h, g._h, capi._ptr(x), capi.F32, ct.c_int64(len(x)), ct.c_int64(x.shape[1]), ctop, 1,
+                                               ct.c_double(-200.0), ct.c_double(200.0), capi._ptr(idx), None, None, None, None, None))
+
+
 def test_generic_paths_follow_the_same_rule():
     """vectSize > 80 (no MFMA instantiation: VALU logits, statistics on the fp64 GEMM), topDistribsCount > 64 (the any-shape selection
     kernel): the degenerate-input rule holds there too -- unusable frames are screened out, a far frame is a zero-likelihood frame
@@ -339,6 +349,22 @@ def test_generic_paths_follow_the_same_rule():
     assert np.all(o[4] == 0.0) and np.all(o[77] == 0.0) and abs(o[5].sum() - 1.0) < 1e-9
     assert ctx.set_option("screened_frames", 0) >= len(bad) and ctx.set_option("zero_llk_frames", 0) >= 1
     g.close()
+    # a Gaussian of weight 0 on the generic paths (a logit that is -inf or NaN is a term of likelihood 0 for the selection
+    # kernel AND for the posteriors that feed the statistics GEMM -- nothing of it may reach S): occupancy 0, finite everywhere
+    w0 = w.copy(); w0[3] = 0.0; w0 /= w0.sum()
+    g0 = ctx.gmm(w0, mean, iv)
+    a0 = g0.split_acc(g0.em_accumulate(x))
+    ref0 = orc.em_accumulate(orc.Gmm(w0, mean, iv), xg)
+    assert a0["occ"][3] == 0.0 and not a0["sx"][3].any() and not a0["sxx"][3].any()
+    assert np.isfinite(a0["occ"]).all() and np.isfinite(a0["sx"]).all() and np.isfinite(a0["sxx"]).all()
+    assert rel(a0["occ"], ref0["occ"]) < 1e-9 and rel(a0["sx"], ref0["sx"]) < 1e-9 and rel(a0["sxx"], ref0["sxx"]) < 1e-9
+    o0 = g0.occ(x[:20])
+    assert np.all(o0[:, 3] == 0.0) and np.isfinite(o0).all()
+    d0 = g0.llk_determine_top(x, 80)
+    assert np.array_equal(d0["idx"][good], orc.llk_determine_top(orc.Gmm(w0, mean, iv), xg, 80, True)["idx"])
+    with pytest.raises(Exception, match="topDistribsCount|exceeds"):
+        capi_determine_too_many(g0, x)
+    g0.close()
     # topDistribsCount > 64 on an MFMA-served model (60 dims): the selection falls through to the any-shape kernel
     w6, m6, iv6 = make_gmm(200, 60, seed=33, spread=0.5)
     x6 = make_frames(w6, m6, iv6, 90, seed=34)

@@ -391,3 +391,34 @@ def test_bench_self_launches_its_ranks(extra):
     if "tv" in extra:
         assert d["finite"] and set(d["phases_ms"]) >= {"recentre", "tett", "estep", "reduce_scatter", "update_t", "allgather", "min_divergence"}
         assert d["collective_bytes_per_step_per_rank"] > 0
+    _check_multi_rank_block(d, 2)
+
+
+def _check_multi_rank_block(d, world):
+    """the fields the first run on real multi-GPU hardware is read by (bench.py multi_rank_report): every rank's own ms_per_step (the
+    line's is their MAX), the collectives' times per rank, and the replicated results behind each collective bitwise equal on all ranks"""
+    m = d["multi_rank"]
+    assert len(m["ms_per_step_per_rank"]) == world and abs(max(m["ms_per_step_per_rank"]) - d["ms_per_step"]) < 1e-6 * d["ms_per_step"] + 1e-9
+    assert m["bitwise_equal_across_ranks"] and all(m["bitwise_equal_across_ranks"].values())
+    assert len(m["collective_ms_per_step_per_rank"]) == world and all(v is not None for e in m["collective_ms_per_step_per_rank"] for v in e.values())
+    assert "rccl_comm_count" in d["comm"] and d["comm"]["world"] == world
+
+
+@pytest.mark.parametrize("extra", [["--frames", "200000", "--steps", "2", "--warmup", "1", "--no-secondary"],
+                                   ["--workload", "tv", "--tv-utterances", "40", "--steps", "1", "--warmup", "1"]])
+def test_bench_eight_ranks_on_one_gpu_carry_the_multi_rank_report(extra):
+    """`python bench.py --gpus 8 --share-gpu`: exactly the code path the driver's 8-GPU run takes (same launcher, same sharding, same
+    collective calls -- over the shm transport, since RCCL refuses two ranks on one device), so that the first run on an 8-GPU node is
+    informative from its first line: per-rank step times, per-rank collective times, rccl_comm_count, bitwise-equal replicated results."""
+    import json
+    out = _run_bench(["--gpus", "8", "--share-gpu"] + extra, timeout=1800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["comm"]["gpu_sharing"] is True and d["parity"]["ok"] is True
+    _check_multi_rank_block(d, 8)
+    if "tv" in extra:
+        assert set(d["multi_rank"]["bitwise_equal_across_ranks"]) == {"T_after_iteration", "ubm_means_after_min_divergence"}
+    else:
+        assert "em_accumulator_after_allreduce" in d["multi_rank"]["bitwise_equal_across_ranks"]
