@@ -1002,6 +1002,25 @@ __global__ __launch_bounds__(512, 1) void k_chol_left2(int n_, double *Afull, do
 // for the row tiles c < i0.  U[c][k] = 0 for k < c: a tile's k range starts at its own 32-block (whose diagonal
 // block is stored with its zeros), and tiles of one wave (128 rows apart) join the k loop one after the other.
 // Only the upper triangle (plus the diagonal blocks) of U is written; nothing else of U is ever read.
+// Row tiles of a panel are dealt to the waves in SNAKE order: round j hands tile NWV j + slot to the wave with slot = wave (j even) or
+// NWV - 1 - wave (j odd).  The k range of a tile shrinks with its row index (k_trinv_left: [tile's block, i0); k_uut: [tile's block, n)), so
+// with the plain deal wave 0 always held the longest tile of every round -- 832 against a mean of 674 chunk-columns on the first panel of
+// k_uut at order 400 -- and everybody waited for it at the panel's barrier; the snake brings that to 720.  Which wave computes a tile
+// does not change its value.  Round j is valid for a prefix of j (tile index grows with j), as the pass structure assumes.
+// MEASURED (round 6, profiles/r06/chol_experiments.txt, 1024 systems of order 400): k_trinv_left 0.772 -> 0.751 ms, k_uut 1.048 -> 1.024 ms.
+// The other round-6 experiment -- TWO independent 4-wave workgroups per CU, each on its own system, so that the hardware interleaves the
+// phases of two systems (panel rows per wave from L2: two 100 KB panels do not fit LDS) -- lost: 1.035 / 1.431 ms; the LDS copy of the
+// panel rows is worth more than the interleaving (the 8-wave kernels WITHOUT it: 1.122 / 1.395).  Not kept in the product.
+#ifndef CHOL_SNAKE
+#define CHOL_SNAKE 1
+#endif
+template <int NWV> __device__ __forceinline__ int snake_slot(int wave, int j) { return (CHOL_SNAKE && (j & 1)) ? NWV - 1 - wave : wave; }
+template <int NWV> __device__ __forceinline__ int snake_count(int wave, int nt)
+{
+    const int full = nt / NWV; // rounds in which every wave has a tile
+    return full + (snake_slot<NWV>(wave, full) < nt - NWV * full ? 1 : 0);
+}
+
 template <bool use_lds, int TW, int NWV = 8>
 __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double *__restrict__ Lfull, const double *__restrict__ invd,
                                                        long sinv, double *Ufull)
@@ -1028,7 +1047,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double
         if (use_lds && i0 > 0) stage_panel<2 * NWV>(pan, S, Lm, n, i0, 0, i0, tid);
         __syncthreads();
         const int nt = i0 >> 4; // full row tiles above the diagonal block
-        const int mine = nt > wave ? (nt - wave + NWV - 1) / NWV : 0;
+        const int mine = snake_count<NWV>(wave, nt);
         long ra0 = i0 + perm, ra1 = i0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
@@ -1041,7 +1060,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_trinv_left(int n_, const double
             int ks[TW + 1];
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                long r0 = 16L * (wave + NWV * (TW * g + u));
+                long r0 = 16L * (snake_slot<NWV>(wave, TW * g + u) + NWV * (TW * g + u));
                 r0 = u < cnt ? r0 : 16L * wave; // unused slots alias a valid tile
                 rows[u] = r0 + i16;
                 pb[u] = Um + rows[u] * n + KOFF_Q * q;
@@ -1116,7 +1135,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
         PROF_PANEL(j0 >> 5);
         STAMP(); // 0
         const int nt = (n_ - j0 + 15) >> 4; // row tiles from the diagonal block down
-        const int mine = nt > wave ? (nt - wave + NWV - 1) / NWV : 0;
+        const int mine = snake_count<NWV>(wave, nt);
         long ra0 = j0 + perm, ra1 = j0 + 16 + perm;
         ra0 = ra0 < n ? ra0 : n - 1;
         ra1 = ra1 < n ? ra1 : n - 1;
@@ -1135,7 +1154,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_uut(int n_, const double *__res
             int ks[TW + 1];
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                long r0 = j0 + 16L * (wave + NWV * (TW * g + u));
+                long r0 = j0 + 16L * (snake_slot<NWV>(wave, TW * g + u) + NWV * (TW * g + u));
                 r0 = u < cnt ? r0 : j0 + 16L * wave;
                 rows[u] = r0 + i16;
                 const long rc = rows[u] < n ? rows[u] : n - 1;
