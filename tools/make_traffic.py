@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the rocprofv3 PMC summaries of tools/profile_r05.sh (gpurun_out/prof_r05/*pmc*.txt, written by
+"""profiles/traffic.json from the rocprofv3 PMC summaries of tools/profile_r06.sh (gpurun_out/prof_r06/*pmc*.txt, written by
 tools/rocpd_summary.py --pmc: one row per kernel and counter with CALLS and the AVERAGE counter value per launch).
 HBM bytes = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (both counters count KB; FETCH_SIZE x 2 is the gfx950 correction of
 MI355X_MICROARCH.md's HBM section, calibrated with tools/calib_fetch.py in round 1).  The file records the sha256 of the libgmmiv.so
 the passes ran on (written on the GPU box) and the git revision of the tree that was sent: bench.py quotes these figures only when
-the library it loads has the same sha256.   usage: python tools/make_traffic.py [gpurun_out/prof_r05] [profiles/r05]"""
+the library it loads has the same sha256.   usage: python tools/make_traffic.py [gpurun_out/prof_r06] [profiles/r06]"""
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r05")
-ref = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r06")
+ref = sys.argv[2] if len(sys.argv) > 2 else "profiles/r06"
 
 
 def rows(name):
@@ -34,11 +34,11 @@ def one(tab, prefix):
 sha = open(os.path.join(src, "libgmmiv_sha256.txt")).read().strip()
 rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "lia_ral_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
-T = {"_comment": "HBM bytes from the rocprofv3 PMC passes of round 5 (tools/profile_r05.sh -> %s/*pmc*.txt -> tools/make_traffic.py). FETCH_SIZE and "
+T = {"_comment": "HBM bytes from the rocprofv3 PMC passes of round 6 (tools/profile_r06.sh -> %s/*pmc*.txt -> tools/make_traffic.py). FETCH_SIZE and "
                  "WRITE_SIZE count KB; FETCH_SIZE x 2 is the gfx950 correction.  bench.py quotes a figure only when the libgmmiv.so it loads has the "
                  "sha256 recorded here." % ref,
      "libgmmiv_sha256": sha, "git_rev": rev + ("+uncommitted kernel changes" if dirty else ""),
-     "source": "%s/bench_em_pmc_fetch_size.txt, %s/bench_em_pmc_write_size.txt (tools/profile_r05.sh)" % (ref, ref)}
+     "source": "%s/bench_em_pmc_fetch_size.txt, %s/bench_em_pmc_write_size.txt (tools/profile_r06.sh)" % (ref, ref)}
 
 # ---- EM headline: 10 M frames, (warm-up + steps) iterations of the same launches --------------------------------------------
 f, w = rows("bench_em_pmc_fetch_size.txt"), rows("bench_em_pmc_write_size.txt")
