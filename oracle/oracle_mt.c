@@ -1,10 +1,13 @@
 /*
- * oracle_mt.c -- pthread driver around the oracle's EM / TV-stat loops, used ONLY by bench.py's
- * cpu_baseline leg (TEST INFRASTRUCTURE).  It reproduces the reference's CPU partitioning:
+ * oracle_mt.c -- pthread drivers around the oracle's EM / TV loops: TEST INFRASTRUCTURE, used only by bench.py's
+ * cpu_baseline legs and by tests/test_oracle_selfcheck.py (which holds them to the single-thread oracle); never linked into,
+ * loaded by or called from the product.  They reproduce the reference's CPU partitioning:
  *   - EM: workers take frame ranges and own a private accumulator, merged at the end
  *     (LIA_SpkTools/src/AccumulateStat.cpp:170-212 EMthread, :286-292 addAccEM merge);
  *   - TV stats / i-vectors: contiguous utterance ranges per thread, disjoint output rows
- *     (LIA_SpkTools/src/AccumulateTVStat.cpp:498-507, :2282-2300).
+ *     (LIA_SpkTools/src/AccumulateTVStat.cpp:498-507, :2282-2300);
+ *   - one whole TotalVariability iteration: estimateTETtThreaded (:826-950), estimateAandCThreaded (:1831-2052: utterance ranges,
+ *     private R / r / meanW, A and C shared under two mutexes), updateTestimate (:974-1005), minDivergence (:2056-2099).
  */
 #include <pthread.h>
 #include <stdlib.h>
