@@ -11,7 +11,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("which,at_least", [("gmm", 1500), ("tv", 1500), ("score", 500), ("backend", 100)])
+@pytest.mark.parametrize("which,at_least", [("gmm", 1500), ("gmm_paths", 1400), ("tv", 1500), ("score", 500), ("backend", 100)])
 def test_boundary_shapes_match_the_oracle(which, at_least):
     import shape_sweep
     n, failed = shape_sweep.run([which])

@@ -22,7 +22,7 @@ def run(which):
     del bad[:]; nchk[0] = 0
     try:
         for name in which:
-            {"gmm": gmm_sweep, "tv": tv_sweep, "score": score_sweep, "backend": backend_sweep}[name]()
+            {"gmm": gmm_sweep, "gmm_paths": gmm_paths_sweep, "tv": tv_sweep, "score": score_sweep, "backend": backend_sweep}[name]()
     finally:
         ctx.close(); ctx = None
     return nchk[0], list(bad)
@@ -47,6 +47,52 @@ def chk(name, shape, fn, tol=1e-9):
             bad.append((name, shape, e)); print("FAIL %-28s %-28s err %.3g" % (name, shape, e), flush=True)
     except Exception as ex:     # noqa: BLE001
         bad.append((name, shape, repr(ex)[:120])); print("EXC  %-28s %-28s %s" % (name, shape, repr(ex)[:160]), flush=True)
+
+
+GMM_PATHS = [{"stats_z": 0}, {"wg_waves": 4}, {"short_calls": 0}, {"topc_fused": 0}, {"topc_fused": 0, "topc_z": 0}, {"glds": 0}, {"topc_rank2": 0},
+             {"z_waves": 4}, {"z_waves": 16}, {"tv_stats_split": 0}]
+
+
+def gmm_paths_sweep():
+    """the non-default kernel paths of the GMM side (options of the context) on a shorter list of boundary shapes"""
+    shapes = [(1, 1, 1), (2, 1, 26), (3, 2, 17), (16, 3, 64), (17, 4, 65), (33, 5, 129), (2, 15, 33), (5, 16, 257), (64, 17, 31), (65, 31, 16), (15, 32, 15),
+              (31, 33, 63), (7, 59, 2), (128, 60, 300), (3, 61, 127), (16, 63, 255), (32, 64, 64), (9, 65, 65), (2, 79, 17), (40, 80, 40), (2048, 1, 50), (2048, 60, 70)]
+    defaults = {}
+    for opts in GMM_PATHS:
+        for k, v in opts.items():
+            defaults[k] = ctx.set_option(k, v)
+        tag = ",".join("%s=%s" % kv for kv in opts.items())
+        try:
+            for C, D, T in shapes:
+                w, mean, iv = make_gmm(C, D, seed=C * 7 + D, spread=0.5 if D > 60 else 2.0)
+                x = make_frames(w, mean, iv, T, seed=T * 3 + D)
+                xo = x.astype(np.float64)
+                g = ctx.gmm(w, mean, iv); og = orc.Gmm(w, mean, iv)
+                sh = "C%d D%d T%d [%s]" % (C, D, T, tag)
+                chk("llk", sh, lambda: float(np.max(np.abs(g.llk(x, -1e9, 1e9) - orc.llk(og, xo, -1e9, 1e9)))), 1e-9)
+                ref = orc.em_accumulate(og, xo)
+                def em():
+                    a = g.split_acc(g.em_accumulate(x))
+                    return max(rel(a["occ"], ref["occ"]), rel(a["sx"], ref["sx"]), rel(a["sxx"], ref["sxx"]), abs(a["count"] - T))
+                chk("em_accumulate", sh, em)
+                chk("occ", sh, lambda: rel(g.occ(x), orc.occ(og, xo)))
+                for ctop in sorted({1, min(C, 3), min(C, 16), min(C, 20)}):
+                    do = orc.llk_determine_top(og, xo, ctop, True)
+                    def top():
+                        d = g.llk_determine_top(x, ctop, True)
+                        return max(0.0 if np.array_equal(d["idx"], do["idx"]) else np.inf, float(np.max(np.abs(d["llk"] - do["llk"]))), rel(d["lk"], do["lk"]))
+                    chk("determine_top c%d" % ctop, sh, top)
+                ub = np.array([0, T // 3, T // 3, T])
+                utt = np.minimum(np.searchsorted(ub, np.arange(T), side="right") - 1, 2)
+                def tvs():
+                    N, F = g.tv_stats(x, ub)
+                    No, Fo = orc.tv_stats(og, xo, utt, 3)
+                    return max(rel(N, No), rel(F, Fo))
+                chk("tv_stats", sh, tvs)
+                g.close()
+        finally:
+            for k in opts:
+                ctx.set_option(k, defaults[k])
 
 
 def gmm_sweep():
@@ -186,6 +232,6 @@ def backend_sweep():
 
 
 if __name__ == "__main__":
-    n, failed = run(sys.argv[1:] or ["gmm", "tv", "score", "backend"])
+    n, failed = run(sys.argv[1:] or ["gmm", "gmm_paths", "tv", "score", "backend"])
     print("%d checks, %d failed" % (n, len(failed)))
     sys.exit(1 if failed else 0)
