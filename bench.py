@@ -358,11 +358,63 @@ def computetest_secondary(ctx, g, w, mean, iv, dev, rank, world, T=1_000_000, ct
         parity = {"frames_checked": n, "indices_identical": same_idx, "max_abs_err_llk": err, "tolerance": 1e-9, "ok": same_idx and err < 1e-9,
                   "what": "top-%d indices of the world pass (exact) and per-frame log-likelihoods of world and %d client models vs the CPU oracle" % (ctop, n_clients)}
     llr = (llkc.mean(1) - llkw.mean()).cpu().numpy()       # ComputeTest's file-mode score per client (mean llk_client - mean llk_world)
-    return {"metric": "ComputeTest: top-%d world pass, frame-Gaussian pairs/s; client pass, frames/s per client model" % ctop,
+    world_tf = FLOP_PER_PAIR_LLK * T * C / tw / 1e12
+    extra = {"roofline": {"bound": "mfma", "kernel": "k_llk_mfma<TC> + k_topc_rank2 (world pass)", "achieved": world_tf, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                          "frac": world_tf / PEAK_F64_TFLOPS, "traffic": None, "algorithmic_flop_per_pair": FLOP_PER_PAIR_LLK, "kernel_ms": tw * 1e3,
+                          "algorithmic_bytes": float(T) * (D * 4 + ctop * 4 + 16)}}
+    if rank == 0 and check and world == 1:
+        extra["cpu_baseline"], extra["config0"] = computetest_cpu_and_config0(ctx, w, mean, iv, cm[0], ctop)
+    return {"metric": "ComputeTest: top-%d world pass, frame-Gaussian pairs/s; client pass, frames/s per client model" % ctop, **extra,
+            "value": T * C * world / tw / 1e9, "unit": "Gframe-Gaussian/s (top-%d world pass)" % ctop,
             "_llr": llr, "_client_means": cm, "_seed": 991 + rank,
             "world_pass_gpairs_per_s": T * C * world / tw / 1e9, "world_pass_ms": tw * 1e3,
             "client_pass_mframes_per_s_per_client": T * n_clients * world / tc / 1e6, "client_pass_ms": tc * 1e3,
             "frames_per_gpu": T, "clients": n_clients, "parity": parity}
+
+
+def computetest_cpu_and_config0(ctx, w, mean, iv, client_mean, ctop):
+    """(1) cpu_baseline of the ComputeTest block: the oracle's DETERMINE_TOP_DISTRIBS + USE_TOP_DISTRIBS loop (ComputeTest.cpp:154-207 restated,
+    the checker's strict -O2 build, ONE thread like the reference tool) on a bounded sample of the same 2048-Gaussian workload.
+    (2) BASELINE.json configs[0] LITERALLY: 128-Gaussian UBM, 60 dims, 1000 frames, top-10 COMPLETE, one client -- the LLR through libgmmiv
+    and through the oracle (value parity, microseconds per frame on one CPU thread; no throughput claim)."""
+    from conftest import make_frames, make_gmm
+    from oracle import oracle as orc
+    n = 50_000                                                              # ~10 s of one CPU thread
+    xs = make_frames(w, mean, iv, n, seed=4242).astype(np.float64)
+    og, oc = orc.Gmm(w, mean, iv), orc.Gmm(w, client_mean, iv)
+    t0 = time.time()
+    do = orc.llk_determine_top(og, xs, ctop, True)
+    t1 = time.time()
+    orc.llk_use_top(oc, xs, do["idx"], do["nontop_lk"], True)
+    t2 = time.time()
+    cpu = {"value": n * C / (t1 - t0) / 1e9, "unit": "Gframe-Gaussian/s (top-%d world pass)" % ctop, "cores": 1, "kind": "port",
+           "client_pass_mframes_per_s_per_client": n / (t2 - t1) / 1e6,
+           "sample": "oracle DETERMINE_TOP_DISTRIBS on %d frames x %d Gaussians (%.1f s) + USE_TOP_DISTRIBS of one client (%.3f s), one thread, gcc -O2 "
+                     "(the checker's build; a restatement of the reference loops, not the original binary)" % (n, C, t1 - t0, t2 - t1)}
+    w0, m0, iv0 = make_gmm(128, 60, seed=0)
+    x0 = make_frames(w0, m0, iv0, 1000, seed=1)
+    rng = np.random.default_rng(5)
+    mc = m0 + rng.normal(0, 0.1, m0.shape)
+    gw, gc = ctx.gmm(w0, m0, iv0), ctx.gmm(w0, mc, iv0)
+    gw.llk_determine_top(x0, 10, True)                                       # warm-up
+    t0 = time.perf_counter()
+    d = gw.llk_determine_top(x0, 10, True)
+    lc = gc.llk_use_top(x0, d["idx"], d["nontop_llk"], True)
+    dt_gpu = time.perf_counter() - t0
+    llr = float(lc.mean() - d["llk"].mean())
+    xo = x0.astype(np.float64)
+    t0 = time.time()
+    do0 = orc.llk_determine_top(orc.Gmm(w0, m0, iv0), xo, 10, True)
+    lco = orc.llk_use_top(orc.Gmm(w0, mc, iv0), xo, do0["idx"], do0["nontop_lk"], True)
+    dt_cpu = time.time() - t0
+    llr_o = float(lco.mean() - do0["llk"].mean())
+    gw.close(); gc.close()
+    cfg0 = {"workload": "BASELINE.json configs[0]: ComputeTest LLR, 128-Gaussian diag UBM, 60-dim, 1000 synthetic frames, top-10 COMPLETE, one client",
+            "llr": llr, "llr_oracle": llr_o, "abs_err": abs(llr - llr_o), "indices_identical": bool(np.array_equal(d["idx"], do0["idx"])),
+            "ok": bool(abs(llr - llr_o) < 1e-9 and np.array_equal(d["idx"], do0["idx"])),
+            "cpu_us_per_frame_1thread": dt_cpu / 1000 * 1e6, "gpu_call_ms_host_arrays": dt_gpu * 1e3,
+            "note": "plumbing + parity configuration (host arrays in and out: the GPU figure is a call latency, not a rate)"}
+    return cpu, cfg0
 
 
 SCORE_FLOP = 800.0          # SURVEY 8(d) / BASELINE.md: one score of dim 400 as a GEMM element: 2 x 400 flop, 8 B written
@@ -1276,9 +1328,9 @@ def summarize(out):
          "configs[2] IvExtractor": entry(out.get("secondary"), "max_rel_err_vs_oracle"),
          "configs[3] TotalVariability": entry(out.get("tv_em"), "max_rel_err"),
          "configs[4] IvTest scoring": entry(out.get("scoring"), "max_rel_err_vs_oracle"),
-         "configs[0] ComputeTest": None if not ct else {
-             "value": ct["world_pass_gpairs_per_s"], "unit": "Gframe-Gaussian/s (top-10 world pass)", "frac": None, "cpu": None,
-             "parity_err": (ct.get("parity") or {}).get("max_abs_err_llk"), "ok": (ct.get("parity") or {}).get("ok")}}
+         "configs[0] ComputeTest": entry(ct, "max_abs_err_llk")}
+    if s["configs[0] ComputeTest"] and (ct or {}).get("config0"):
+        s["configs[0] ComputeTest"]["literal_config_llr_abs_err"] = ct["config0"]["abs_err"]
     if s["configs[1] TrainWorld EM"] and out.get("roofline"):
         s["configs[1] TrainWorld EM"]["k1_frac"] = out["roofline"]["frac"]
     tv = out.get("tv_em") or {}
