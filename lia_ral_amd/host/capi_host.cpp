@@ -978,6 +978,21 @@ int liagpu_energy_detector(int device, const float *energy, long T, const long *
     })
 }
 
+// selectFrames alone (EnergyDetector.cpp:118-157; host only, no GPU): energy [T], threshold, selected segments -> output segments
+int liagpu_select_frames(const float *energy, long T, double threshold, const long *seg_begin, const long *seg_len, long nseg, long *out_begin,
+                         long *out_len, long max_out, long *n_out, long *count_out)
+{
+    GUARD({
+        std::vector<float> e(energy, energy + T);
+        SegCluster segs = make_cluster(seg_begin, seg_len, nseg), out;
+        const unsigned long cnt = selectFrames(e, threshold, segs, out);
+        if ((long)out.size() > max_out) throw Exception("out_begin too small");
+        for (size_t i = 0; i < out.size(); ++i) { out_begin[i] = (long)out[i].begin; out_len[i] = (long)out[i].length; }
+        *n_out = (long)out.size();
+        if (count_out) *count_out = (long)cnt;
+    })
+}
+
 // GmmTokenizer driven from its files (LIA_Utils/GmmTokenizer/src/GmmTokenizer.cpp:169-207 symbols, :120-164 confusion matrix): RAW world
 // model, .prm features (masked), .lbl segments with the selected label.  symbols_out [max_symbols] <- one best-Gaussian index per selected
 // frame (*n_symbols of them; skipped when symbols_out is NULL); confusion_out [C x C] (nullable, zeroed here) <- the nBest = topDistribsCount

@@ -551,6 +551,16 @@ def energy_detector(energy, seg_begin, seg_len, C=2, nb_train_it=10, variance_fl
                 threshold=th.value)
 
 
+def select_frames(energy, threshold, seg_begin, seg_len):
+    """selectFrames (EnergyDetector.cpp:118-157) on the host: -> (begin[], length[], frames above the threshold)."""
+    e = np.ascontiguousarray(energy, np.float32)
+    b, l, bp, lp = _segs(seg_begin, seg_len)
+    ob = np.zeros(max(16, len(e) + 1), np.int64); ol = np.zeros_like(ob); n = ct.c_long(0); cnt = ct.c_long(0)
+    _chk(lib.liagpu_select_frames(e.ctypes.data_as(_fp), ct.c_long(len(e)), ct.c_double(threshold), bp, lp, ct.c_long(len(b)),
+                                  ob.ctypes.data_as(_lp), ol.ctypes.data_as(_lp), ct.c_long(len(ob)), ct.byref(n), ct.byref(cnt)))
+    return ob[:n.value].copy(), ol[:n.value].copy(), cnt.value
+
+
 def gmm_tokenizer_files(world_path, prm_path, lbl_path, mask="", label="male", frame_length=0.01, top_c=1, min_llk=-200.0, max_llk=200.0,
                         matrix_path="", device=0):
     """GmmTokenizer from its files (GmmTokenizer.cpp:120-207): -> (symbols[n_selected], confusion[C, C]) with nBest = top_c."""

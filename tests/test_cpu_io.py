@@ -127,3 +127,30 @@ def test_dt_db_matrices_and_vector_files(tmp_path):
     with pytest.raises(h.HostError, match="fit neither"):
         (tmp_path / "bad.db").write_bytes(b"\x02\x00\x00\x00\x03\x00\x00\x00" + b"\x00" * 40)
         h.io_matrix_convert(str(tmp_path / "bad.db"), "DB", str(tmp_path / "o"), "DT")
+
+
+def test_select_frames_of_the_energy_detector_as_written():
+    """liagpu::selectFrames (EnergyDetector.cpp:118-157) against the Python restatement the KAT-6 test uses: a run that reaches the end of
+    an input segment is one frame LONGER than a run that ends inside it (:144 `ind - begin` with ind = end + 1, :151 `ind - begin + 1` with
+    ind already past the end) -- reproduced as written; begin counts frames of the SELECTION, not of the file."""
+    from lia_ral_amd import host_capi as h
+    from test_oracle_kat import energy_select_frames
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        T = int(rng.integers(1, 60))
+        e = rng.normal(size=T).astype(np.float32)
+        nseg = int(rng.integers(0, 4))
+        cuts = np.sort(rng.integers(0, T + 1, 2 * nseg))
+        sb, sl = cuts[0::2], cuts[1::2] - cuts[0::2]
+        th = float(rng.normal(0, 0.7))
+        b, l, cnt = h.select_frames(e, th, sb, sl)
+        ref = energy_select_frames(e, th, sb, sl)
+        assert list(zip(b.tolist(), l.tolist())) == ref, (trial, e, th, sb, sl)
+        assert cnt == sum(int((e[s:s + n] > th).sum()) for s, n in zip(sb, sl))
+    # the asymmetry itself: one selected segment of 10 frames, the last 3 above the threshold -> length 4; an inner run of 3 -> length 3
+    e = np.array([0, 0, 0, 0, 0, 0, 0, 1, 1, 1], np.float32)
+    assert [x.tolist() for x in h.select_frames(e, 0.5, [0], [10])[:2]] == [[7], [4]]
+    e = np.array([0, 0, 1, 1, 1, 0, 0, 0, 0, 0], np.float32)
+    assert [x.tolist() for x in h.select_frames(e, 0.5, [0], [10])[:2]] == [[2], [3]]
+    with pytest.raises(h.HostError, match="beyond the end"):
+        h.select_frames(e, 0.5, [5], [10])
