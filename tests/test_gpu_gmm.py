@@ -585,8 +585,8 @@ def test_fused_top_c_two_frames_per_wave_matches_one_frame_per_wave(ctx, spread,
 
 
 def test_default_paths_are_bitwise_the_round_5_results(golden_dir):
-    """tests/golden/r05_bitwise.json holds SHA-256 digests of 83 result arrays (EM statistics, log-likelihoods, top-10 / top-20 lists,
-    posteriors, N / F, TETt, i-vectors, the T-matrix accumulators, updateTestimate, minDivergence, two scoring rules; three model shapes)
+    """tests/golden/r05_bitwise.json holds SHA-256 digests of 107 result arrays (EM statistics, log-likelihoods, top-10 / top-20 lists,
+    posteriors, N / F, TETt, i-vectors, the T-matrix accumulators, updateTestimate, minDivergence, two scoring rules; three model shapes; the Cholesky family at orders 400 / 200 / 130)
     computed by the ROUND-5 library on an MI355X (tools/bitwise_fixture.py).  Round 6 took the measured-slower kernel variants out of
     libgmmiv.so, moved the handling of unusable feature values into the kernels and the chunk tables onto the device: none of it may
     move one bit of a default path on clean data."""
@@ -597,4 +597,4 @@ def test_default_paths_are_bitwise_the_round_5_results(golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "r05_bitwise.json")))["arrays"]
     got = bf.digests(bf.compute())
     bad = [k for k in ref if got.get(k) != ref[k]]
-    assert len(ref) == 83 and not bad, bad
+    assert len(ref) == 107 and not bad, bad

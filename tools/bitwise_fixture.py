@@ -54,6 +54,20 @@ def compute():
         ctx.tv_min_divergence(acc["Rm"].copy(), acc["r"].copy(), acc["meanW"] / len(lens), m2, Tn, len(lens), C, D)
         out["Tmd_" + k] = np.asarray(Tn); out["means_md_" + k] = m2
         g.close()
+    # the Cholesky family at the order of the BASELINE configs (rank 400: 13 panels per system, several row-tile rounds per wave) and at
+    # orders with a partial last block -- the i-vector solve and the E-step accumulators of a few utterances
+    for R, C, D, U in ((400, 8, 12, 7), (200, 4, 12, 5), (130, 3, 5, 4)):
+        rng = np.random.default_rng(R)
+        N = rng.uniform(0.5, 40.0, (U, C)); invvar = rng.uniform(0.5, 2.0, C * D)
+        F = rng.normal(size=(U, C * D)) * np.repeat(N, D, axis=1)
+        Tm = 0.05 * rng.normal(size=(R, C * D))
+        te = ctx.tv_tett(Tm, invvar, C, D)
+        k = "R%d" % R
+        out["W_" + k] = ctx.tv_estimate_w(N, F, Tm, invvar, te, C, D)
+        acc = ctx.tv_estimate_a_and_c(N, F, Tm, invvar, te, C, D)
+        for f in ("A", "Cmx", "Rm", "r", "meanW", "W"):
+            out["estep_%s_%s" % (f, k)] = np.asarray(acc[f])
+        out["Tnew_" + k] = np.asarray(ctx.tv_update_t(acc["A"], acc["Cmx"], C, D)).copy()
     # scoring
     rng = np.random.default_rng(3)
     M, S, dim = 70, 130, 40
