@@ -54,3 +54,15 @@ def test_gmmiv_h_is_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(f)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_c99_example_compiles_and_links_against_the_abi_alone(tmp_path):
+    """examples/computetest_llr.c: a plain C99 caller (no HIP headers, no C++) builds with -pedantic -Werror and links against libgmmiv.so
+    only -- the boundary is plain pointers and sizes (it is RUN, on the ComputeTest golden, by tests/test_gpu_kat5.py)."""
+    exe = tmp_path / "computetest_llr"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "computetest_llr.c"),
+                        "-L", os.path.join(ROOT, "lia_ral_amd", "csrc"), "-lgmmiv", "-Wl,-rpath," + os.path.join(ROOT, "lia_ral_amd", "csrc"),
+                        "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
+    assert "libgmmiv.so" in out and "libtorch" not in out and "python" not in out

@@ -178,3 +178,31 @@ def test_kat6_energydetector_through_the_host_layer(golden_dir):
     assert not (list(raw["begin"]) == [21] and list(raw["length"]) == [6])
     r3 = h.energy_detector(e, k["seg_begin"], k["seg_len"], C=3, alpha=float(k["alpha"]))
     assert abs(r3["w"].sum() - 1.0) < 1e-12 and np.all(r3["cov"] > 0)
+
+
+def test_c99_example_reproduces_the_reference_llr(tmp_path, golden_dir):
+    """examples/computetest_llr.c -- a C99 program that sees nothing but include/gmmiv.h and libgmmiv.so -- on the ComputeTest golden (KAT-1:
+    world `wld`, client `test1`, frames 0..25 of test1.prm): prints the reference's 5.06601 (fixture tolerance 5e-5)."""
+    import re
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "computetest_llr")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "computetest_llr.c"), "-L",
+                    os.path.join(root, "lia_ral_amd", "csrc"), "-lgmmiv", "-Wl,-rpath," + os.path.join(root, "lia_ral_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib",
+                    "-lm", "-o", exe], check=True)
+    k = np.load(os.path.join(golden_dir, "kat1_computetest.npz"))
+    for seg, want in zip(range(2), k["expected_llr"]):
+        b, n = int(k["seg_begin"][seg]), int(k["seg_len"][seg])
+        x = np.ascontiguousarray(k["x"][b:b + n], np.float32)
+        C, D = k["mean_world"].shape
+        path = str(tmp_path / ("model%d.bin" % seg))
+        with open(path, "wb") as f:
+            f.write(struct.pack("<4i", C, D, n, int(k["top_c"])))
+            for a in (k["w"], k["mean_world"], k["covinv"], k["mean_client"]):
+                f.write(np.ascontiguousarray(a, "<f8").tobytes())
+            f.write(x.tobytes())
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        llr = float(re.search(r"LLR (-?[0-9.]+)", out.stdout).group(1))
+        assert abs(llr - float(want)) < float(k["abs_tol"]) + 1e-6, (out.stdout, want)
