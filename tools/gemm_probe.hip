@@ -2,7 +2,16 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip lia_ral_amd/csrc/chol_fused.hip -o tools/bin/gemm_probe
 #include "../lia_ral_amd/csrc/tv_kernels.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
+
+__global__ void k_fill_hash(double *p, size_t n, unsigned seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((double)h / 4294967296.0 - 0.5) * 2.0;      // uniform in (-1, 1): every mantissa bit toggles
+    }
+}
 
 struct Shape { const char *name; bool ta, tb; int M, N, K; double beta = 0.0; };
 
@@ -39,7 +48,9 @@ int main()
         const size_t na = (size_t)s.M * s.K, nb = (size_t)s.K * s.N, nc = (size_t)s.M * s.N;
         double *A, *B, *C;
         hipMalloc(&A, na * 8); hipMalloc(&B, nb * 8); hipMalloc(&C, nc * 8);
-        hipMemset(A, 0, na * 8); hipMemset(B, 0, nb * 8); hipMemset(C, 0, nc * 8);
+        const int fill = getenv("GEMM_FILL") ? atoi(getenv("GEMM_FILL")) : 0;   // byte pattern of the operands: 0 = zeros; 63 (0x3f) = 4.8e-4 in every element
+        hipMemset(A, fill, na * 8); hipMemset(B, fill, nb * 8); hipMemset(C, 0, nc * 8);
+        if (fill < 0) { k_fill_hash<<<4096, 256, 0, st>>>(A, na, 1u); k_fill_hash<<<4096, 256, 0, st>>>(B, nb, 2u); }   // GEMM_FILL=-1: pseudo-random operands
         const long lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
