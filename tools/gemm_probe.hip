@@ -3,6 +3,7 @@
 #include "../lia_ral_amd/csrc/tv_kernels.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 __global__ void k_fill_hash(double *p, size_t n, unsigned seed)
@@ -44,7 +45,9 @@ int main()
     };
     hipStream_t st;
     hipStreamCreate(&st);
+    const char *only = getenv("GEMM_ONLY");   // substring of the shape names to run (PMC passes want one kernel shape per run)
     for (const Shape &s : shapes) {
+        if (only && !strstr(s.name, only)) continue;
         const size_t na = (size_t)s.M * s.K, nb = (size_t)s.K * s.N, nc = (size_t)s.M * s.N;
         double *A, *B, *C;
         hipMalloc(&A, na * 8); hipMalloc(&B, nb * 8); hipMalloc(&C, nc * 8);
@@ -67,7 +70,7 @@ int main()
         printf("%-75s %8.3f ms  %6.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
         hipFree(A); hipFree(B); hipFree(C);
     }
-    { // split-K of aux = F Tiv^T (1024 x 400 x 122880 NT): which layer count fills 2 x 256 workgroup slots best?
+    if (!only) { // split-K of aux = F Tiv^T (1024 x 400 x 122880 NT): which layer count fills 2 x 256 workgroup slots best?
         const int M = 1024, N = 400, K = 122880;
         double *A, *B, *C, *slabs;
         hipMalloc(&A, (size_t)M * K * 8); hipMalloc(&B, (size_t)N * K * 8); hipMalloc(&C, (size_t)M * N * 8); hipMalloc(&slabs, (size_t)128 * M * N * 8);
