@@ -445,3 +445,69 @@ def test_bench_quotes_pmc_traffic_only_for_the_library_it_was_taken_on(tmp_path,
     d = {k: v for k, v in real.items() if k != "libgmmiv_sha256"}
     json.dump(d, open(fake_root / "profiles" / "traffic.json", "w"))
     assert bench.load_traffic()[0] is None
+
+
+def _multi_rank_worker(rank, world, port, q, disagree):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    acc = torch.arange(10, dtype=torch.float64) * (1.0 + (1e-16 if False else 0.0))
+    if disagree and rank == 1:
+        acc = acc.clone(); acc[3] = np.nextafter(3.0, 4.0)        # ONE bit off on one rank
+    code = 0
+    try:
+        rep = bench.multi_rank_report(world, rank, 0.5 + 0.1 * rank, 5, {"acc": bench.tensor_digest(acc)}, {"allreduce": 0.25 * (rank + 1)})
+        q.put((rank, rep))
+    except SystemExit as e:                                         # ranks whose replicated results differ end the run with status 4
+        code = e.code
+        q.put((rank, {"exit": code}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("disagree", [False, True])
+def test_bench_multi_rank_report_two_ranks_gloo(disagree):
+    """bench.py's report for world > 1 (what the first run on multi-GPU hardware is read by): every rank's own ms_per_step and collective
+    times in rank order, and the replicated results behind a collective compared BIT FOR BIT over the launcher's group -- one differing bit
+    on one rank ends every rank with status 4 instead of a number."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_multi_rank_worker, args=(r, 2, port, q, disagree)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if disagree:
+        assert res[0] == {"exit": 4} and res[1] == {"exit": 4}
+        return
+    for r in (0, 1):
+        m = res[r]
+        assert m["ms_per_step_per_rank"] == pytest.approx([100.0, 120.0]) and m["bitwise_equal_across_ranks"] == {"acc": True}
+        assert m["collective_ms_per_step_per_rank"] == [{"allreduce": 0.25}, {"allreduce": 0.5}]
+
+
+def test_bench_summary_has_the_five_configs():
+    """the LAST key of the bench line: one compact entry per BASELINE config, built from the blocks (a truncated tail of the stored record
+    still shows i-vectors/s)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    blk = lambda v, u, key, err: {"value": v, "unit": u, "roofline": {"frac": 0.7}, "cpu_baseline": {"value": 1.0, "unit": u, "cores": 32},
+                                  "parity": {key: err, "ok": True}}
+    out = dict(blk(126.0, "Gframe-Gaussian/s", "max_rel_err", 5e-16), step_roofline={"frac": 0.78}, roofline={"frac": 0.74},
+               secondary=blk(20500.0, "i-vectors/s", "max_rel_err_vs_oracle", 1.6e-14),
+               tv_em=dict(blk(55000.0, "utterances/s", "max_rel_err", 1.8e-14)),
+               scoring=blk(7.7e10, "trials/s", "max_rel_err_vs_oracle", 6e-15),
+               computetest=dict(blk(177.0, "Gframe-Gaussian/s (top-10 world pass)", "max_abs_err_llk", 2e-13), config0={"abs_err": 1e-14}))
+    out["tv_em"]["parity"]["whole_iteration"] = {"max_rel_err_T": 2e-12}
+    s = bench.summarize(out)
+    assert list(s) == ["configs[1] TrainWorld EM", "configs[2] IvExtractor", "configs[3] TotalVariability", "configs[4] IvTest scoring", "configs[0] ComputeTest"]
+    assert s["configs[2] IvExtractor"]["value"] == 20500.0 and s["configs[2] IvExtractor"]["cpu"] == [1.0, "i-vectors/s", 32]
+    assert s["configs[1] TrainWorld EM"]["frac"] == 0.78 and s["configs[1] TrainWorld EM"]["k1_frac"] == 0.74
+    assert s["configs[3] TotalVariability"]["parity_err_T_whole_iteration"] == 2e-12 and s["configs[0] ComputeTest"]["literal_config_llr_abs_err"] == 1e-14
+    assert all(e["ok"] for e in s.values()) and len(__import__("json").dumps(s)) < 2500
